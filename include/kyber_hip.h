@@ -1,0 +1,90 @@
+/*
+ * kyber_hip.h -- C ABI of libkyberhip.so, the MI355X (gfx950) batched
+ * group-arithmetic engine that sits behind dedis/kyber's kyber.Point.Mul /
+ * pairing.Suite hot path.
+ *
+ * This is what a cgo binding in the reference would import (see INTEGRATION.md
+ * for the Go stub).  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - every entry point returns 0 on success, <0 on a call-level error
+ *     (KYB_E_*); kyb_last_error() gives a message for the calling thread.
+ *   - wire formats are exactly the reference's MarshalBinary encodings;
+ *     element-major, densely packed.
+ *   - where decoding an input can fail (UnmarshalBinary returning an error in
+ *     the reference) the call takes `status[n]`: 0 = ok, KYB_ST_* otherwise,
+ *     and the corresponding output element is all-zero bytes.
+ *   - "*_dev" variants take DEVICE pointers (already resident in HBM) and a
+ *     hipStream_t passed as void* (NULL = default stream); they only enqueue
+ *     work and never synchronise.  The host variants copy in, run, copy out
+ *     and synchronise.
+ *   - all entry points are thread-safe; state is a per-device context that is
+ *     created on first use on the calling thread's current HIP device.
+ */
+#ifndef KYBER_HIP_H
+#define KYBER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KYB_OK 0
+#define KYB_E_ARG (-1)    /* bad argument (NULL pointer, bad flags) */
+#define KYB_E_HIP (-2)    /* a HIP runtime call failed */
+#define KYB_E_NODEV (-3)  /* no usable gfx950 device */
+#define KYB_E_ALLOC (-4)  /* workspace allocation failed */
+
+#define KYB_ST_OK 0
+#define KYB_ST_BAD_POINT 1 /* encoding is not a curve point (reference: UnmarshalBinary error) */
+#define KYB_ST_NOT_IN_SUBGROUP 2
+
+/* flags */
+#define KYB_F_VARTIME 1u /* Ed25519: geScalarMultVartime semantics (all 256 scalar bits honoured,
+                            group/edwards25519/ge_mult_vartime.go:11). Default = constant-time
+                            path semantics of ge.go:443 incl. its >= 2^255 behaviour. */
+
+int kyb_version(void);
+const char *kyb_last_error(void);
+
+/* Number of visible devices; creates nothing. */
+int kyb_device_count(void);
+/* Eagerly create the context (tables, workspace) for the current HIP device. */
+int kyb_init(void);
+/* Release every per-device context. */
+int kyb_shutdown(void);
+
+/* ------------------------------------------------------------------ Ed25519
+ * scalars: 32-byte little-endian, taken as plain 256-bit integers (never
+ * reduced mod l: group/edwards25519/scalar.go:226-233).
+ * points : 32-byte compressed (group/edwards25519/ge.go:99-150).           */
+
+/* out[i] = scalars[i] * B.   Replaces (*point).Mul(s, nil) ->
+ * geScalarMultBase (group/edwards25519/point.go:243, ge.go:373) + MarshalBinary. */
+int kyb_ed25519_mul_base(size_t n, const uint8_t *scalars, uint8_t *out, uint32_t flags);
+int kyb_ed25519_mul_base_dev(size_t n, const void *d_scalars, void *d_out, uint32_t flags, void *stream);
+
+/* out[i] = scalars[i] * points[i].   Replaces UnmarshalBinary + (*point).Mul(s, A)
+ * -> geScalarMult / geScalarMultVartime (point.go:235-258, ge.go:443,
+ * ge_mult_vartime.go:11) + MarshalBinary. */
+int kyb_ed25519_mul(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t *out,
+                    uint8_t *status, uint32_t flags);
+int kyb_ed25519_mul_dev(size_t n, const void *d_scalars, const void *d_points, void *d_out,
+                        void *d_status, uint32_t flags, void *stream);
+
+/* out[i] = scalars[i] * point  (one shared base).  Replaces the loop of
+ * share.PriPoly.Commit (share/poly.go:143-149).  If the point does not decode
+ * every status[i] is KYB_ST_BAD_POINT and every output is zero. */
+int kyb_ed25519_mul_same_base(size_t n, const uint8_t *scalars, const uint8_t point[32],
+                              uint8_t *out, uint8_t *status, uint32_t flags);
+
+/* Introspection used by the tests: copy the device-built fixed-base table
+ * (33 x 8 entries of (y+x, y-x, 2dxy), 10 int32 limbs each) to the host. */
+int kyb_ed25519_debug_base_table(int32_t *out /* 33*8*30 */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,67 @@
+"""ctypes binding of libkyberhip.so (the C ABI in include/kyber_hip.h).
+
+Fails loudly when the library is absent or a symbol is missing: there is no
+CPU fallback in the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libkyberhip.so")
+
+KYB_F_VARTIME = 1
+ST_OK, ST_BAD_POINT, ST_NOT_IN_SUBGROUP = 0, 1, 2
+
+
+class KyberHipError(RuntimeError):
+    pass
+
+
+_vp, _sz, _u32, _int = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int
+
+# name -> argtypes; restype is int unless listed in _RESTYPES
+SIGNATURES = {
+    "kyb_version": [],
+    "kyb_last_error": [],
+    "kyb_device_count": [],
+    "kyb_init": [],
+    "kyb_shutdown": [],
+    "kyb_ed25519_mul_base": [_sz, _vp, _vp, _u32],
+    "kyb_ed25519_mul_base_dev": [_sz, _vp, _vp, _u32, _vp],
+    "kyb_ed25519_mul": [_sz, _vp, _vp, _vp, _vp, _u32],
+    "kyb_ed25519_mul_dev": [_sz, _vp, _vp, _vp, _vp, _u32, _vp],
+    "kyb_ed25519_mul_same_base": [_sz, _vp, _vp, _vp, _vp, _u32],
+    "kyb_ed25519_debug_base_table": [_vp],
+}
+_RESTYPES = {"kyb_last_error": C.c_char_p}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load (once) and return the library; raise if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KyberHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise KyberHipError(f"libkyberhip.so lacks symbol {name}") from e
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().kyb_last_error()
+        raise KyberHipError(f"{what} failed rc={rc}: {msg.decode() if msg else ''}")

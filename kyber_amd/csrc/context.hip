@@ -1,0 +1,91 @@
+#include "context.h"
+
+#include <map>
+
+namespace kyb {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+static std::mutex g_mu;
+static std::map<int, DeviceCtx*> g_ctx;
+
+int get_ctx(DeviceCtx** out) {
+    int dev = 0;
+    KYB_HIP_CHECK(hipGetDevice(&dev));
+    DeviceCtx* ctx = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_ctx.find(dev);
+        if (it == g_ctx.end()) {
+            ctx = new DeviceCtx();
+            ctx->device = dev;
+            g_ctx[dev] = ctx;
+        } else {
+            ctx = it->second;
+        }
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!ctx->ready) {
+        hipDeviceProp_t prop;
+        KYB_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        ctx->num_cu = prop.multiProcessorCount;
+        int rc = ed25519_build_tables(ctx);
+        if (rc) return rc;
+        ctx->ready = true;
+    }
+    *out = ctx;
+    return KYB_OK;
+}
+
+int ctx_workspace(DeviceCtx* ctx, size_t bytes, void** out) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (bytes > ctx->ws_bytes) {
+        if (ctx->ws) {
+            KYB_HIP_CHECK(hipDeviceSynchronize());
+            KYB_HIP_CHECK(hipFree(ctx->ws));
+            ctx->ws = nullptr;
+            ctx->ws_bytes = 0;
+        }
+        size_t want = bytes + bytes / 4;
+        if (hipMalloc(&ctx->ws, want) != hipSuccess) {
+            set_error("workspace hipMalloc failed");
+            return KYB_E_ALLOC;
+        }
+        ctx->ws_bytes = want;
+    }
+    *out = ctx->ws;
+    return KYB_OK;
+}
+
+}  // namespace kyb
+
+extern "C" {
+
+int kyb_version(void) { return 1; }
+const char* kyb_last_error(void) { return kyb::g_err.c_str(); }
+
+int kyb_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int kyb_init(void) {
+    kyb::DeviceCtx* ctx;
+    return kyb::get_ctx(&ctx);
+}
+
+int kyb_shutdown(void) {
+    std::lock_guard<std::mutex> lk(kyb::g_mu);
+    for (auto& kv : kyb::g_ctx) {
+        kyb::DeviceCtx* c = kv.second;
+        hipSetDevice(c->device);
+        kyb::ed25519_free_tables(c);
+        if (c->ws) hipFree(c->ws);
+        delete c;
+    }
+    kyb::g_ctx.clear();
+    return KYB_OK;
+}
+}

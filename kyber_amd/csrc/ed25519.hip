@@ -1,0 +1,369 @@
+// Ed25519 batched scalar multiplication kernels for gfx950 + their C-ABI entry
+// points.  One scalar multiplication per lane, uniform control flow across the
+// wave (signed radix-16 fixed windows), integer VALU only.
+//
+// Replaces, in the reference (group/edwards25519):
+//   geScalarMultBase  ge.go:373-417      -> ed25519_mul_base_kernel
+//   geScalarMult      ge.go:443-502      -> ed25519_mul_kernel
+//   geScalarMultVartime ge_mult_vartime.go:11 (semantics via KYB_F_VARTIME)
+//   FromBytes/ToBytes ge.go:99-150       -> fused into the kernels
+#include "context.h"
+#include "ge25519.cuh"
+
+namespace kyb {
+
+constexpr int ED_TAB_POS = 33;  // 32 byte positions + 2^256*B for the 65th digit
+constexpr int ED_TAB_WORDS = ED_TAB_POS * 8 * 30;
+
+KYB_DEV void load_words8(uint32_t w[8], const uint32_t* __restrict__ p) {
+    const uint4 a = reinterpret_cast<const uint4*>(p)[0];
+    const uint4 b = reinterpret_cast<const uint4*>(p)[1];
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+    w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+KYB_DEV void store_words8(uint32_t* __restrict__ p, const uint32_t w[8]) {
+    reinterpret_cast<uint4*>(p)[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    reinterpret_cast<uint4*>(p)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+// ---------------------------------------------------------------- table build
+// Thread (i, j) computes (j+1) * 256^i * B by MSB-first double-and-add and
+// stores its affine (y+x, y-x, 2dxy).  Runs once per device.
+__global__ void ed25519_build_base_table_kernel(int32_t* __restrict__ tab) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ED_TAB_POS * 8) return;
+    const int pos = t >> 3, j = t & 7;
+    ge_p3 B;
+    B.X = fe_bx(); B.Y = fe_by(); fe_1(B.Z); B.T = fe_bt();
+    ge_cached cB;
+    ge_p3_to_cached(cB, B);
+    ge_p3 acc;
+    ge_p3_0(acc);
+    ge_p1p1 r;
+    // multiplier = (j+1) << (8*pos): 4 significant bits then 8*pos doublings
+#pragma unroll 1
+    for (int bit = 3; bit >= 0; bit--) {
+        ge_dbl(r, acc.X, acc.Y, acc.Z);
+        ge_p1p1_to_p3(acc, r);
+        if (((j + 1) >> bit) & 1) {
+            ge_add(r, acc, cB);
+            ge_p1p1_to_p3(acc, r);
+        }
+    }
+#pragma unroll 1
+    for (int k = 0; k < 8 * pos; k++) {
+        ge_dbl(r, acc.X, acc.Y, acc.Z);
+        ge_p1p1_to_p3(acc, r);
+    }
+    fe zi, x, y, ypx, ymx, xy2d, z;
+    fe_invert(zi, acc.Z);
+    fe_mul(x, acc.X, zi);
+    fe_mul(y, acc.Y, zi);
+    fe_add(ypx, y, x);
+    fe_sub(ymx, y, x);
+    fe_mul(xy2d, x, y);
+    fe_mul(xy2d, xy2d, fe_d2());
+    // one pass through mul-by-one normalises y+x / y-x to reduced limbs
+    fe_1(z);
+    fe_mul(ypx, ypx, z);
+    fe_mul(ymx, ymx, z);
+    int32_t* o = tab + (size_t)t * 30;
+#pragma unroll
+    for (int l = 0; l < 10; l++) {
+        o[l] = ypx.v[l];
+        o[10 + l] = ymx.v[l];
+        o[20 + l] = xy2d.v[l];
+    }
+}
+
+// ------------------------------------------------------------ fixed-base mul
+// LDS holds the whole 33x8 table (31,680 B); every lane gathers its own entry.
+// Entry stride is 30 dwords, so the 8 possible |digit| values of one position
+// land on 8 different banks and equal digits broadcast.
+KYB_DEV void select_precomp_lds(ge_precomp& t, const int32_t* s_tab, int pos, int b) {
+    const bool neg = b < 0;
+    const int babs = neg ? -b : b;
+    const int32_t* e = s_tab + (pos * 8 + (babs ? babs - 1 : 0)) * 30;
+#pragma unroll
+    for (int l = 0; l < 10; l++) {
+        t.ypx.v[l] = e[l];
+        t.ymx.v[l] = e[10 + l];
+        t.xy2d.v[l] = e[20 + l];
+    }
+    if (babs == 0) {  // identity: (1, 1, 0)
+        fe_1(t.ypx);
+        fe_1(t.ymx);
+        fe_0(t.xy2d);
+    }
+    ge_precomp_cneg(t, neg);
+}
+
+__global__ __launch_bounds__(256) void ed25519_mul_base_kernel(
+    size_t n, const uint32_t* __restrict__ scalars, uint32_t* __restrict__ out,
+    const int32_t* __restrict__ tab, uint32_t flags) {
+    __shared__ int32_t s_tab[ED_TAB_WORDS];
+    for (int i = threadIdx.x; i < ED_TAB_WORDS; i += blockDim.x) s_tab[i] = tab[i];
+    __syncthreads();
+    const bool full = (flags & KYB_F_VARTIME) != 0;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        uint32_t a[8];
+        load_words8(a, scalars + idx * 8);
+        int8_t e[65];
+        recode16(e, a, full);
+        ge_p3 h;
+        ge_p3_0(h);
+        ge_precomp t;
+        ge_p1p1 r;
+#pragma unroll 1
+        for (int i = 1; i < 64; i += 2) {
+            select_precomp_lds(t, s_tab, i >> 1, e[i]);
+            ge_madd(r, h, t);
+            ge_p1p1_to_p3(h, r);
+        }
+        ge_p2 s;
+        ge_dbl(r, h.X, h.Y, h.Z);
+        ge_p1p1_to_p2(s, r);
+        ge_dbl(r, s.X, s.Y, s.Z);
+        ge_p1p1_to_p2(s, r);
+        ge_dbl(r, s.X, s.Y, s.Z);
+        ge_p1p1_to_p2(s, r);
+        ge_dbl(r, s.X, s.Y, s.Z);
+        ge_p1p1_to_p3(h, r);
+        const int last = full ? 64 : 62;
+#pragma unroll 1
+        for (int i = 0; i <= last; i += 2) {
+            select_precomp_lds(t, s_tab, i >> 1, e[i]);
+            ge_madd(r, h, t);
+            ge_p1p1_to_p3(h, r);
+        }
+        uint32_t w[8];
+        ge_p3_towords(w, h);
+        store_words8(out + idx * 8, w);
+    }
+}
+
+// --------------------------------------------------------- variable-base mul
+// Shared ladder: h = sum_i e[i] 16^i * A using an 8-entry cached table held in
+// the lane's private (scratch) memory.
+KYB_DEV void select_cached(ge_cached& c, const ge_cached tab[8], int b) {
+    const bool neg = b < 0;
+    const int babs = neg ? -b : b;
+    c = tab[babs ? babs - 1 : 0];
+    if (babs == 0) ge_cached_0(c);
+    ge_cached_cneg(c, neg);
+}
+
+KYB_DEV void ge_scalarmult_w4(ge_p3& h, const int8_t e[65], const ge_p3& A, bool full) {
+    ge_cached tab[8];
+    ge_p1p1 t;
+    ge_p3 u;
+    ge_p2 r;
+    ge_cached c;
+    ge_p3_to_cached(tab[0], A);
+#pragma unroll 1
+    for (int i = 0; i < 7; i++) {
+        ge_add(t, A, tab[i]);
+        ge_p1p1_to_p3(u, t);
+        ge_p3_to_cached(tab[i + 1], u);
+    }
+    ge_p3_0(u);
+    int top = 63;
+    if (full) top = 64;  // uniform across the grid
+    select_cached(c, tab, e[top]);
+    ge_add(t, u, c);
+#pragma unroll 1
+    for (int i = top - 1; i >= 0; i--) {
+        ge_p1p1_to_p2(r, t);
+        ge_dbl(t, r.X, r.Y, r.Z);
+        ge_p1p1_to_p2(r, t);
+        ge_dbl(t, r.X, r.Y, r.Z);
+        ge_p1p1_to_p2(r, t);
+        ge_dbl(t, r.X, r.Y, r.Z);
+        ge_p1p1_to_p2(r, t);
+        ge_dbl(t, r.X, r.Y, r.Z);
+        ge_p1p1_to_p3(u, t);
+        select_cached(c, tab, e[i]);
+        ge_add(t, u, c);
+    }
+    ge_p1p1_to_p3(h, t);
+}
+
+// points_stride = 8 words for per-element points, 0 for one shared base
+__global__ __launch_bounds__(128) void ed25519_mul_kernel(
+    size_t n, const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ points,
+    size_t points_stride, uint32_t* __restrict__ out, uint8_t* __restrict__ status,
+    uint32_t flags) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const bool full = (flags & KYB_F_VARTIME) != 0;
+    uint32_t pw[8], a[8];
+    load_words8(pw, points + idx * points_stride);
+    load_words8(a, scalars + idx * 8);
+    ge_p3 A;
+    const bool ok = ge_p3_fromwords(A, pw);
+    int8_t e[65];
+    recode16(e, a, full);
+    ge_p3 h;
+    ge_scalarmult_w4(h, e, A, full);
+    uint32_t w[8];
+    ge_p3_towords(w, h);
+    if (!ok) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = 0;
+    }
+    store_words8(out + idx * 8, w);
+    if (status) status[idx] = ok ? KYB_ST_OK : KYB_ST_BAD_POINT;
+}
+
+// ---------------------------------------------------------------- host side
+int ed25519_build_tables(DeviceCtx* ctx) {
+    KYB_HIP_CHECK(hipMalloc(&ctx->ed_base_tab, ED_TAB_WORDS * sizeof(int32_t)));
+    hipLaunchKernelGGL(ed25519_build_base_table_kernel, dim3((ED_TAB_POS * 8 + 63) / 64), dim3(64), 0,
+                       nullptr, ctx->ed_base_tab);
+    KYB_HIP_CHECK(hipGetLastError());
+    KYB_HIP_CHECK(hipStreamSynchronize(nullptr));
+    return KYB_OK;
+}
+void ed25519_free_tables(DeviceCtx* ctx) {
+    if (ctx->ed_base_tab) hipFree(ctx->ed_base_tab);
+    ctx->ed_base_tab = nullptr;
+}
+
+static int launch_mul_base(DeviceCtx* ctx, size_t n, const void* d_scalars, void* d_out, uint32_t flags,
+                           hipStream_t st) {
+    if (n == 0) return KYB_OK;
+    const int block = 256;
+    size_t want = (n + block - 1) / block;
+    size_t cap = (size_t)ctx->num_cu * 4;  // table staging is per block: keep blocks long-lived
+    int grid = (int)(want < cap ? want : cap);
+    hipLaunchKernelGGL(ed25519_mul_base_kernel, dim3(grid), dim3(block), 0, st, n,
+                       (const uint32_t*)d_scalars, (uint32_t*)d_out, ctx->ed_base_tab, flags);
+    KYB_HIP_CHECK(hipGetLastError());
+    return KYB_OK;
+}
+static int launch_mul(size_t n, const void* d_scalars, const void* d_points, size_t stride, void* d_out,
+                      void* d_status, uint32_t flags, hipStream_t st) {
+    if (n == 0) return KYB_OK;
+    const int block = 128;
+    size_t grid = (n + block - 1) / block;
+    hipLaunchKernelGGL(ed25519_mul_kernel, dim3((unsigned)grid), dim3(block), 0, st, n,
+                       (const uint32_t*)d_scalars, (const uint32_t*)d_points, stride, (uint32_t*)d_out,
+                       (uint8_t*)d_status, flags);
+    KYB_HIP_CHECK(hipGetLastError());
+    return KYB_OK;
+}
+
+}  // namespace kyb
+
+using namespace kyb;
+
+extern "C" {
+
+int kyb_ed25519_mul_base_dev(size_t n, const void* d_scalars, void* d_out, uint32_t flags, void* stream) {
+    if ((n && (!d_scalars || !d_out)) || (flags & ~KYB_F_VARTIME)) {
+        set_error("kyb_ed25519_mul_base_dev: bad argument");
+        return KYB_E_ARG;
+    }
+    DeviceCtx* ctx;
+    int rc = get_ctx(&ctx);
+    if (rc) return rc;
+    return launch_mul_base(ctx, n, d_scalars, d_out, flags, (hipStream_t)stream);
+}
+
+int kyb_ed25519_mul_dev(size_t n, const void* d_scalars, const void* d_points, void* d_out, void* d_status,
+                        uint32_t flags, void* stream) {
+    if ((n && (!d_scalars || !d_points || !d_out)) || (flags & ~KYB_F_VARTIME)) {
+        set_error("kyb_ed25519_mul_dev: bad argument");
+        return KYB_E_ARG;
+    }
+    DeviceCtx* ctx;
+    int rc = get_ctx(&ctx);
+    if (rc) return rc;
+    return launch_mul(n, d_scalars, d_points, 8, d_out, d_status, flags, (hipStream_t)stream);
+}
+
+int kyb_ed25519_mul_base(size_t n, const uint8_t* scalars, uint8_t* out, uint32_t flags) {
+    if ((n && (!scalars || !out)) || (flags & ~KYB_F_VARTIME)) {
+        set_error("kyb_ed25519_mul_base: bad argument");
+        return KYB_E_ARG;
+    }
+    if (n == 0) return KYB_OK;
+    DeviceCtx* ctx;
+    int rc = get_ctx(&ctx);
+    if (rc) return rc;
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    KYB_HIP_CHECK(hipMalloc(&d_in, n * 32));
+    KYB_HIP_CHECK(hipMalloc(&d_out, n * 32));
+    KYB_HIP_CHECK(hipMemcpy(d_in, scalars, n * 32, hipMemcpyHostToDevice));
+    rc = launch_mul_base(ctx, n, d_in, d_out, flags, nullptr);
+    if (rc == KYB_OK) {
+        hipError_t e = hipMemcpy(out, d_out, n * 32, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            set_error(std::string("D2H: ") + hipGetErrorString(e));
+            rc = KYB_E_HIP;
+        }
+    }
+    hipFree(d_in);
+    hipFree(d_out);
+    return rc;
+}
+
+static int mul_host(size_t n, const uint8_t* scalars, const uint8_t* points, size_t stride, uint8_t* out,
+                    uint8_t* status, uint32_t flags) {
+    DeviceCtx* ctx;
+    int rc = get_ctx(&ctx);
+    if (rc) return rc;
+    const size_t npts = stride ? n : 1;
+    uint8_t *d_s = nullptr, *d_p = nullptr, *d_o = nullptr, *d_st = nullptr;
+    KYB_HIP_CHECK(hipMalloc(&d_s, n * 32));
+    KYB_HIP_CHECK(hipMalloc(&d_p, npts * 32));
+    KYB_HIP_CHECK(hipMalloc(&d_o, n * 32));
+    KYB_HIP_CHECK(hipMalloc(&d_st, n));
+    KYB_HIP_CHECK(hipMemcpy(d_s, scalars, n * 32, hipMemcpyHostToDevice));
+    KYB_HIP_CHECK(hipMemcpy(d_p, points, npts * 32, hipMemcpyHostToDevice));
+    rc = launch_mul(n, d_s, d_p, stride, d_o, d_st, flags, nullptr);
+    if (rc == KYB_OK) {
+        hipError_t e = hipMemcpy(out, d_o, n * 32, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && status) e = hipMemcpy(status, d_st, n, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            set_error(std::string("D2H: ") + hipGetErrorString(e));
+            rc = KYB_E_HIP;
+        }
+    }
+    hipFree(d_s);
+    hipFree(d_p);
+    hipFree(d_o);
+    hipFree(d_st);
+    return rc;
+}
+
+int kyb_ed25519_mul(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* out, uint8_t* status,
+                    uint32_t flags) {
+    if ((n && (!scalars || !points || !out)) || (flags & ~KYB_F_VARTIME)) {
+        set_error("kyb_ed25519_mul: bad argument");
+        return KYB_E_ARG;
+    }
+    if (n == 0) return KYB_OK;
+    return mul_host(n, scalars, points, 8, out, status, flags);
+}
+
+int kyb_ed25519_mul_same_base(size_t n, const uint8_t* scalars, const uint8_t point[32], uint8_t* out,
+                              uint8_t* status, uint32_t flags) {
+    if ((n && (!scalars || !out)) || !point || (flags & ~KYB_F_VARTIME)) {
+        set_error("kyb_ed25519_mul_same_base: bad argument");
+        return KYB_E_ARG;
+    }
+    if (n == 0) return KYB_OK;
+    return mul_host(n, scalars, point, 0, out, status, flags);
+}
+
+int kyb_ed25519_debug_base_table(int32_t* out) {
+    if (!out) return KYB_E_ARG;
+    DeviceCtx* ctx;
+    int rc = get_ctx(&ctx);
+    if (rc) return rc;
+    KYB_HIP_CHECK(hipMemcpy(out, ctx->ed_base_tab, ED_TAB_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return KYB_OK;
+}
+}

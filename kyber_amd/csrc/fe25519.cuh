@@ -1,0 +1,260 @@
+// GF(2^255-19) device arithmetic for gfx950 (one field element per lane).
+//
+// Replaces the reference's group/edwards25519/fe.go (feMul fe.go:348, feSquare
+// fe.go:590, feSquare2 fe.go:749, feInvert fe.go:906, fePow22523 fe.go:961,
+// feToBytes fe.go:163, feFromBytes fe.go:81).  Representation: ten signed
+// limbs in radix 2^25.5 (26,25,26,25,... bits) held in VGPRs; every product is
+// one v_mad_i64_i32 into a 64-bit column accumulator, so a multiplication is
+// 100 integer MADs + 9 small multiplies + one carry sweep and needs no carry
+// handling inside the product loop.  Bounds follow the classic analysis for
+// this radix: mul/sq accept |limb| <= 1.65*2^26 (even) / 1.65*2^25 (odd) and
+// return |limb| <= 1.01*2^25 / 1.01*2^24, so one add/sub of two products may
+// feed the next product without a carry.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kyb {
+
+struct fe {
+    int32_t v[10];
+};
+
+#define KYB_DEV __device__ __forceinline__
+
+KYB_DEV void fe_0(fe& h) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) h.v[i] = 0;
+}
+KYB_DEV void fe_1(fe& h) {
+    fe_0(h);
+    h.v[0] = 1;
+}
+KYB_DEV void fe_add(fe& h, const fe& f, const fe& g) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) h.v[i] = f.v[i] + g.v[i];
+}
+KYB_DEV void fe_sub(fe& h, const fe& f, const fe& g) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) h.v[i] = f.v[i] - g.v[i];
+}
+KYB_DEV void fe_neg(fe& h, const fe& f) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) h.v[i] = -f.v[i];
+}
+// f = b ? g : f
+KYB_DEV void fe_cmov(fe& f, const fe& g, bool b) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) f.v[i] = b ? g.v[i] : f.v[i];
+}
+KYB_DEV void fe_cswap(fe& f, fe& g, bool b) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        int32_t x = f.v[i], y = g.v[i];
+        f.v[i] = b ? y : x;
+        g.v[i] = b ? x : y;
+    }
+}
+
+// One carry step: move the rounded high part of t[i] (limb width w) into t[i+1].
+#define KYB_CARRY(t, i, w)                                                  \
+    {                                                                       \
+        int64_t c_ = ((t)[i] + ((int64_t)1 << ((w) - 1))) >> (w);          \
+        (t)[(i) + 1] += c_;                                                 \
+        (t)[i] -= c_ << (w);                                                \
+    }
+
+// Reduce ten 64-bit columns to limbs; two interleaved chains (0..4 / 4..9) keep
+// the dependent-shift chain short.
+KYB_DEV void fe_carry_store(fe& h, int64_t t[10]) {
+    KYB_CARRY(t, 0, 26);
+    KYB_CARRY(t, 4, 26);
+    KYB_CARRY(t, 1, 25);
+    KYB_CARRY(t, 5, 25);
+    KYB_CARRY(t, 2, 26);
+    KYB_CARRY(t, 6, 26);
+    KYB_CARRY(t, 3, 25);
+    KYB_CARRY(t, 7, 25);
+    KYB_CARRY(t, 4, 26);
+    KYB_CARRY(t, 8, 26);
+    {
+        int64_t c = (t[9] + ((int64_t)1 << 24)) >> 25;
+        t[0] += c * 19;
+        t[9] -= c << 25;
+    }
+    KYB_CARRY(t, 0, 26);
+#pragma unroll
+    for (int i = 0; i < 10; i++) h.v[i] = (int32_t)t[i];
+}
+
+// h = f * g
+KYB_DEV void fe_mul(fe& h, const fe& f, const fe& g) {
+    int32_t g19[10], f2[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        g19[i] = 19 * g.v[i];
+        f2[i] = 2 * f.v[i];
+    }
+    int64_t t[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        int64_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            const int j = (k - i + 10) % 10;
+            const bool wrap = i > k;                    // i + j == k + 10
+            const bool both_odd = (i & 1) && (j & 1);   // 2^25.5 radix: odd*odd carries a factor 2
+            const int32_t a = both_odd ? f2[i] : f.v[i];
+            const int32_t b = wrap ? g19[j] : g.v[j];
+            acc += (int64_t)a * (int64_t)b;
+        }
+        t[k] = acc;
+    }
+    fe_carry_store(h, t);
+}
+
+// h = (DBL ? 2 : 1) * f^2   (55 products)
+template <bool DBL>
+KYB_DEV void fe_sq_t(fe& h, const fe& f) {
+    int32_t f2[10], f19[10], f38[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        f2[i] = 2 * f.v[i];
+        f19[i] = 19 * f.v[i];
+        f38[i] = 38 * f.v[i];
+    }
+    int64_t t[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        int64_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            const int j = (k - i + 10) % 10;
+            if (i > j) continue;
+            const bool wrap = (i + j) >= 10;
+            const bool both_odd = (i & 1) && (j & 1);
+            // total coefficient = (i==j ? 1 : 2) * (both_odd ? 2 : 1) * (wrap ? 19 : 1)
+            // split as  a-side in {1,2}  x  b-side in {1,2,19,38}
+            int32_t a, b;
+            if (i == j) {
+                a = f.v[i];
+                b = wrap ? (both_odd ? f38[j] : f19[j]) : (both_odd ? f2[j] : f.v[j]);
+            } else {
+                a = f2[i];
+                b = wrap ? (both_odd ? f38[j] : f19[j]) : (both_odd ? f2[j] : f.v[j]);
+            }
+            acc += (int64_t)a * (int64_t)b;
+        }
+        t[k] = DBL ? (acc + acc) : acc;
+    }
+    fe_carry_store(h, t);
+}
+KYB_DEV void fe_sq(fe& h, const fe& f) { fe_sq_t<false>(h, f); }
+KYB_DEV void fe_sq2(fe& h, const fe& f) { fe_sq_t<true>(h, f); }
+
+// n >= 1 squarings; a real loop (not unrolled) keeps code size down in the
+// 250-squaring exponentiation chains.
+KYB_DEV void fe_sqn(fe& h, const fe& f, int n) {
+    fe_sq(h, f);
+#pragma unroll 1
+    for (int i = 1; i < n; i++) fe_sq(h, h);
+}
+
+// t = z^(2^250-1), z11 = z^11
+KYB_DEV void fe_pow_2_250_1(fe& out, fe& z11, const fe& z) {
+    fe z2, z9, t, a5, a10, a20, a50, a100;
+    fe_sq(z2, z);
+    fe_sqn(t, z2, 2);
+    fe_mul(z9, t, z);
+    fe_mul(z11, z9, z2);
+    fe_sq(t, z11);
+    fe_mul(a5, t, z9);  // 2^5 - 1
+    fe_sqn(t, a5, 5);
+    fe_mul(a10, t, a5);
+    fe_sqn(t, a10, 10);
+    fe_mul(a20, t, a10);
+    fe_sqn(t, a20, 20);
+    fe_mul(t, t, a20);  // 2^40 - 1
+    fe_sqn(t, t, 10);
+    fe_mul(a50, t, a10);
+    fe_sqn(t, a50, 50);
+    fe_mul(a100, t, a50);
+    fe_sqn(t, a100, 100);
+    fe_mul(t, t, a100);  // 2^200 - 1
+    fe_sqn(t, t, 50);
+    fe_mul(out, t, a50);  // 2^250 - 1
+}
+// out = z^(p-2)
+KYB_DEV void fe_invert(fe& out, const fe& z) {
+    fe t, z11;
+    fe_pow_2_250_1(t, z11, z);
+    fe_sqn(t, t, 5);
+    fe_mul(out, t, z11);
+}
+// out = z^((p-5)/8) = z^(2^252-3)
+KYB_DEV void fe_pow22523(fe& out, const fe& z) {
+    fe t, z11;
+    fe_pow_2_250_1(t, z11, z);
+    fe_sqn(t, t, 2);
+    fe_mul(out, t, z);
+}
+
+// Canonical little-endian bytes as eight 32-bit words.
+KYB_DEV void fe_towords(uint32_t w[8], const fe& f) {
+    int32_t h[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) h[i] = f.v[i];
+    // q = floor((h + 19) / 2^255) computed limb by limb: 0 or 1 for |h| < 2^255ish
+    int32_t q = (19 * h[9] + (1 << 24)) >> 25;
+#pragma unroll
+    for (int i = 0; i < 10; i++) q = (h[i] + q) >> ((i & 1) ? 25 : 26);
+    h[0] += 19 * q;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int w_ = (i & 1) ? 25 : 26;
+        int32_t c = h[i] >> w_;
+        h[i + 1] += c;
+        h[i] -= c << w_;
+    }
+    h[9] &= (1 << 25) - 1;  // drop 2^255 * q
+    // pack: limb offsets 0,26,51,77,102,128,153,179,204,230
+    uint32_t u[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) u[i] = (uint32_t)h[i];
+    w[0] = u[0] | (u[1] << 26);
+    w[1] = (u[1] >> 6) | (u[2] << 19);
+    w[2] = (u[2] >> 13) | (u[3] << 13);
+    w[3] = (u[3] >> 19) | (u[4] << 6);
+    w[4] = u[5] | (u[6] << 25);
+    w[5] = (u[6] >> 7) | (u[7] << 19);
+    w[6] = (u[7] >> 13) | (u[8] << 12);
+    w[7] = (u[8] >> 20) | (u[9] << 6);
+}
+// Limbs from eight little-endian words; bit 255 is ignored (fe.go:91).
+KYB_DEV void fe_fromwords(fe& h, const uint32_t w[8]) {
+    h.v[0] = (int32_t)(w[0] & 0x3ffffff);
+    h.v[1] = (int32_t)(((w[0] >> 26) | (w[1] << 6)) & 0x1ffffff);
+    h.v[2] = (int32_t)(((w[1] >> 19) | (w[2] << 13)) & 0x3ffffff);
+    h.v[3] = (int32_t)(((w[2] >> 13) | (w[3] << 19)) & 0x1ffffff);
+    h.v[4] = (int32_t)((w[3] >> 6) & 0x3ffffff);
+    h.v[5] = (int32_t)(w[4] & 0x1ffffff);
+    h.v[6] = (int32_t)(((w[4] >> 25) | (w[5] << 7)) & 0x3ffffff);
+    h.v[7] = (int32_t)(((w[5] >> 19) | (w[6] << 13)) & 0x1ffffff);
+    h.v[8] = (int32_t)(((w[6] >> 12) | (w[7] << 20)) & 0x3ffffff);
+    h.v[9] = (int32_t)((w[7] >> 6) & 0x1ffffff);
+}
+KYB_DEV bool fe_isnegative(const fe& f) {
+    uint32_t w[8];
+    fe_towords(w, f);
+    return w[0] & 1;
+}
+KYB_DEV bool fe_isnonzero(const fe& f) {
+    uint32_t w[8];
+    fe_towords(w, f);
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r |= w[i];
+    return r != 0;
+}
+
+}  // namespace kyb
