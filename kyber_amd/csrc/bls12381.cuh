@@ -1,0 +1,448 @@
+// BLS12-381 G1 / G2 / GT device library: ZCash (de)serialisation with the reference's acceptance
+// rules, subgroup checks, scalar multiplication, optimal ate pairing.
+//
+// Replaces the external arithmetic behind pairing/bls12381/kilic (adapter call sites:
+// kilic/g1.go:110-131 Mul / MarshalBinary / UnmarshalBinary, kilic/g2.go, kilic/gt.go:85-117,
+// kilic/suite.go:57-75 ValidatePairing / Pair) -- the arithmetic itself is
+// github.com/kilic/bls12-381 v0.1.0 (go.mod:8), not in the reference tree; what is implemented
+// here is the published curve / encoding / pairing definition, validated
+// against oracle/bls12381.py.
+#pragma once
+#include "bls12381_params.h"
+#include "curve.cuh"
+
+namespace kyb {
+namespace bls {
+
+using FC = Bls12381Fp;
+using TC = Bls12381Tower;
+using CC = Bls12381Curve;
+using fp = Fp<FC>;
+using fp2 = Fp2<TC>;
+using fp6 = Fp6<TC>;
+using fp12 = Fp12<TC>;
+using g1_aff = Aff<fp>;
+using g2_aff = Aff<fp2>;
+using g1_jac = Jac<fp>;
+using g2_jac = Jac<fp2>;
+
+constexpr int ST_OK = 0, ST_BAD_POINT = 1, ST_NOT_IN_SUBGROUP = 2;
+
+KYB_HD void fp_const(fp& r, const uint32_t (&c)[FC::N]) {
+#pragma unroll
+    for (int l = 0; l < FC::N; l++) r.v[l] = c[l];
+}
+
+// y > (p - 1) / 2 on the canonical value
+KYB_HD bool fp_is_larger(const fp& y) {
+    uint32_t w[FC::NWORDS];
+    fp_to_words<FC>(w, y);
+    return words_gt<FC::NWORDS>(w, FC::HALF);
+}
+KYB_HD bool fp2_is_larger(const fp2& y) {
+    const bool c1z = fp_is_zero(y.c1);
+    return c1z ? fp_is_larger(y.c0) : fp_is_larger(y.c1);
+}
+
+// ------------------------------------------------------------- subgroup checks
+// G1: P has order r  <=>  phi(P) = [-x^2] P, phi(x, y) = (beta x, y)   (Scott, eprint 2021/1130)
+KYB_HD bool g1_in_subgroup(const g1_aff& a) {
+    g1_jac p, q;
+    jac_from_aff(p, a);
+    jac_mul_u64(q, p, CC::X_ABS);
+    jac_mul_u64(q, q, CC::X_ABS);  // x^2 P
+    fp beta, bx, ny, z2, z3, l, r;
+    fp_const(beta, CC::BETA);
+    fp_mul(bx, a.x, beta);
+    fp_neg(ny, a.y);
+    // -q == (beta x, y)  <=>  q.X = bx Z^2, q.Y = -y Z^3, Z != 0
+    fp_sqr(z2, q.Z);
+    fp_mul(z3, z2, q.Z);
+    fp_mul(l, bx, z2);
+    fp_mul(r, ny, z3);
+    const bool ok = fp_eq(l, q.X) & fp_eq(r, q.Y) & !fp_is_zero(q.Z);
+    return a.inf | ok;
+}
+// G2: psi(Q) = [x] Q, psi = twist o Frobenius o untwist
+KYB_HD bool g2_in_subgroup(const g2_aff& a) {
+    g2_jac p, q;
+    jac_from_aff(p, a);
+    jac_mul_u64(q, p, CC::X_ABS);  // |x| Q ; need psi(Q) = -q
+    fp2 cx, cy, px, py, z2, z3, l, r;
+    fp2_load_const<TC>(cx, CC::PSI_CX);
+    fp2_load_const<TC>(cy, CC::PSI_CY);
+    fp2_conj(px, a.x);
+    fp2_mul(px, px, cx);
+    fp2_conj(py, a.y);
+    fp2_mul(py, py, cy);
+    fp2_neg(py, py);
+    fp2_sqr(z2, q.Z);
+    fp2_mul(z3, z2, q.Z);
+    fp2_mul(l, px, z2);
+    fp2_mul(r, py, z3);
+    const bool ok = fp2_eq(l, q.X) & fp2_eq(r, q.Y) & !fp2_is_zero(q.Z);
+    return a.inf | ok;
+}
+
+// ------------------------------------------------------------------ decoding
+// 48-byte ZCash compressed G1 (kilic/g1.go:127-131 FromCompressed + subgroup check).
+KYB_HD int g1_decode(g1_aff& a, const uint8_t* in, bool check_subgroup) {
+    uint32_t w[12];
+    words_from_be<12>(w, in);
+    const uint32_t top = w[11] >> 29;
+    const bool c = top & 4, inf = top & 2, s = top & 1;
+    w[11] &= 0x1fffffffu;
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) any |= w[k];
+    fp_zero(a.x);
+    fp_zero(a.y);
+    a.inf = true;
+    if (!c) return ST_BAD_POINT;
+    if (inf) return (s || any) ? ST_BAD_POINT : ST_OK;
+    if (!fp_words_lt_p<FC>(w)) return ST_BAD_POINT;
+    fp x, y, rhs, b, t;
+    fp_from_words<FC>(x, w);
+    fp_const(b, CC::B1);
+    fp_sqr(rhs, x);
+    fp_mul(rhs, rhs, x);
+    fp_add(rhs, rhs, b);
+    fp_pow_words<FC>(y, rhs, FC::SQRT_EXP, FC::SQRT_BITS);
+    fp_sqr(t, y);
+    if (!fp_eq(t, rhs)) return ST_BAD_POINT;
+    fp_neg(t, y);
+    fp_cmov(y, t, fp_is_larger(y) != s);
+    a.x = x;
+    a.y = y;
+    a.inf = false;
+    if (check_subgroup && !g1_in_subgroup(a)) return ST_NOT_IN_SUBGROUP;
+    return ST_OK;
+}
+
+// Square root in Fp2 (p = 3 mod 4) with two base-field exponentiations; false if none exists.
+KYB_HD bool fp2_sqrt(fp2& r, const fp2& a) {
+    fp n, s, t, u, c, c2, h, inv2;
+    fp_const(inv2, FC::INV2);
+    fp_sqr(n, a.c0);
+    fp_sqr(t, a.c1);
+    fp_add(n, n, t);
+    fp_pow_words<FC>(s, n, FC::SQRT_EXP, FC::SQRT_BITS);  // sqrt of the norm (if it is a square)
+    fp_add(t, a.c0, s);
+    fp_mul(t, t, inv2);
+    fp_cmov(t, a.c0, fp_is_zero(a.c1));
+    fp_pow_words<FC>(u, t, FC::PM3D4, FC::SQRT_BITS);  // t^((p-3)/4)
+    fp_mul(c, u, t);                                   // t^((p+1)/4)
+    fp_sqr(c2, c);
+    const bool qr = fp_eq(c2, t);  // chi(t) = +1 ; otherwise c^2 = -t and 1/c = -u
+    fp_mul(h, a.c1, inv2);
+    fp_mul(h, h, u);  // a1 / (2c) up to the sign chi
+    fp2 x;
+    if (qr) {
+        x.c0 = c;
+        x.c1 = h;
+    } else {
+        fp_neg(x.c0, h);
+        x.c1 = c;
+    }
+    fp2 chk;
+    fp2_sqr(chk, x);
+    r = x;
+    return fp2_eq(chk, a);
+}
+
+// 96-byte ZCash compressed G2: x.c1 || x.c0 big-endian, flags in the first byte.
+KYB_HD int g2_decode(g2_aff& a, const uint8_t* in, bool check_subgroup) {
+    uint32_t w1[12], w0[12];
+    words_from_be<12>(w1, in);
+    words_from_be<12>(w0, in + 48);
+    const uint32_t top = w1[11] >> 29;
+    const bool c = top & 4, inf = top & 2, s = top & 1;
+    w1[11] &= 0x1fffffffu;
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) any |= w1[k] | w0[k];
+    fp2_zero(a.x);
+    fp2_zero(a.y);
+    a.inf = true;
+    if (!c) return ST_BAD_POINT;
+    if (inf) return (s || any) ? ST_BAD_POINT : ST_OK;
+    if (!fp_words_lt_p<FC>(w1) || !fp_words_lt_p<FC>(w0)) return ST_BAD_POINT;
+    fp2 x, y, rhs, b, t;
+    fp_from_words<FC>(x.c0, w0);
+    fp_from_words<FC>(x.c1, w1);
+    fp2_load_const<TC>(b, CC::B2);
+    fp2_sqr(rhs, x);
+    fp2_mul(rhs, rhs, x);
+    fp2_add(rhs, rhs, b);
+    if (!fp2_sqrt(y, rhs)) return ST_BAD_POINT;
+    fp2_neg(t, y);
+    fp2_cmov(y, t, fp2_is_larger(y) != s);
+    a.x = x;
+    a.y = y;
+    a.inf = false;
+    if (check_subgroup && !g2_in_subgroup(a)) return ST_NOT_IN_SUBGROUP;
+    return ST_OK;
+}
+
+// ------------------------------------------------------------------ encoding
+KYB_HD void g1_encode(uint8_t* out, const g1_aff& a) {
+    uint32_t w[12];
+    fp_to_words<FC>(w, a.x);
+    uint32_t flags = 0x80000000u | (fp_is_larger(a.y) ? 0x20000000u : 0u);
+    if (a.inf) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) w[k] = 0;
+        flags = 0xC0000000u;
+    }
+    w[11] |= flags;
+    words_to_be<12>(out, w);
+}
+KYB_HD void g2_encode(uint8_t* out, const g2_aff& a) {
+    uint32_t w1[12], w0[12];
+    fp_to_words<FC>(w1, a.x.c1);
+    fp_to_words<FC>(w0, a.x.c0);
+    uint32_t flags = 0x80000000u | (fp2_is_larger(a.y) ? 0x20000000u : 0u);
+    if (a.inf) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) w1[k] = w0[k] = 0;
+        flags = 0xC0000000u;
+    }
+    w1[11] |= flags;
+    words_to_be<12>(out, w1);
+    words_to_be<12>(out + 48, w0);
+}
+// 576 bytes: Fp12.c1 then c0; within Fp6 c2, c1, c0; within Fp2 c1, c0; big-endian (oracle gt_to_bytes)
+KYB_HD void gt_encode(uint8_t* out, const fp12& f) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const fp6& s = h == 0 ? f.c1 : f.c0;
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            const fp2& c = m == 0 ? s.c2 : (m == 1 ? s.c1 : s.c0);
+            uint32_t w[12];
+            fp_to_words<FC>(w, c.c1);
+            words_to_be<12>(out + (h * 3 + m) * 96, w);
+            fp_to_words<FC>(w, c.c0);
+            words_to_be<12>(out + (h * 3 + m) * 96 + 48, w);
+        }
+    }
+}
+// 32-byte big-endian scalar (mod.Int wire format, group/mod/int.go:334-350) -> little-endian words
+KYB_HD void scalar_from_be(uint32_t (&k)[8], const uint8_t* in) { words_from_be<8>(k, in); }
+
+// ------------------------------------------------------------------- pairing
+// One step of the Miller loop works on T in Jacobian coordinates on the twist and returns the
+// line through T (tangent, or chord to Q) evaluated at P as the sparse element
+//   o0 + (o1 xP) v + (o4 yP) v w       (w-basis positions 0, 2, 3), scaled by a factor in Fp2.
+KYB_HD void miller_dbl_step(fp12& f, g2_jac& t, const fp& xp, const fp& yp) {
+    fp2 A, B, C, D, E, G, Z2, o0, o1, o4, u;
+    fp2_sqr(A, t.X);
+    fp2_sqr(B, t.Y);
+    fp2_sqr(C, B);
+    fp2_add(u, t.X, B);
+    fp2_sqr(u, u);
+    fp2_sub(u, u, A);
+    fp2_sub(u, u, C);
+    fp2_dbl(D, u);
+    fp2_dbl(E, A);
+    fp2_add(E, E, A);
+    fp2_sqr(G, E);
+    fp2_sqr(Z2, t.Z);
+    // line: (3X^3 - 2Y^2) , -(3X^2 Z^2) xP , (Z3 Z^2) yP
+    fp2_mul(o0, E, t.X);
+    fp2_dbl(u, B);
+    fp2_sub(o0, o0, u);
+    fp2_mul(o1, E, Z2);
+    fp2_neg(o1, o1);
+    fp2_mul_fp(o1, o1, xp);
+    // T = 2T
+    fp2_add(u, t.Y, t.Z);
+    fp2_sqr(u, u);
+    fp2_sub(u, u, B);
+    fp2_sub(t.Z, u, Z2);  // 2 Y Z
+    fp2_dbl(u, D);
+    fp2_sub(t.X, G, u);
+    fp2_sub(u, D, t.X);
+    fp2_mul(u, E, u);
+    fp2_dbl(C, C);
+    fp2_dbl(C, C);
+    fp2_dbl(C, C);
+    fp2_sub(t.Y, u, C);
+    fp2_mul(o4, t.Z, Z2);
+    fp2_mul_fp(o4, o4, yp);
+    fp12_sqr(f, f);
+    fp12_mul_by_014(f, o0, o1, o4);
+}
+KYB_HD void miller_add_step(fp12& f, g2_jac& t, const g2_aff& q, const fp& xp, const fp& yp) {
+    fp2 Z2, U2, S2, H, rr, Z3, o0, o1, o4, HH, HHH, V, u;
+    fp2_sqr(Z2, t.Z);
+    fp2_mul(U2, q.x, Z2);
+    fp2_mul(S2, Z2, t.Z);
+    fp2_mul(S2, q.y, S2);
+    fp2_sub(H, U2, t.X);
+    fp2_sub(rr, S2, t.Y);
+    fp2_mul(Z3, t.Z, H);
+    // line: rr x2 - y2 Z3 , -rr xP , Z3 yP
+    fp2_mul(o0, rr, q.x);
+    fp2_mul(u, q.y, Z3);
+    fp2_sub(o0, o0, u);
+    fp2_neg(o1, rr);
+    fp2_mul_fp(o1, o1, xp);
+    fp2_mul_fp(o4, Z3, yp);
+    fp12_mul_by_014(f, o0, o1, o4);
+    // T = T + Q
+    fp2_sqr(HH, H);
+    fp2_mul(HHH, H, HH);
+    fp2_mul(V, t.X, HH);
+    fp2_sqr(u, rr);
+    fp2_sub(u, u, HHH);
+    fp2_sub(u, u, V);
+    fp2_sub(u, u, V);
+    fp2 y3;
+    fp2_sub(y3, V, u);
+    fp2_mul(y3, rr, y3);
+    fp2_mul(HHH, t.Y, HHH);
+    fp2_sub(t.Y, y3, HHH);
+    t.X = u;
+    t.Z = Z3;
+}
+// f_{|x|,Q}(P), conjugated because x < 0.  P or Q at infinity gives one.
+KYB_HD void miller_loop(fp12& f, const g1_aff& p, const g2_aff& q) {
+    fp12_one(f);
+    g2_jac t;
+    jac_from_aff(t, q);
+#pragma unroll 1
+    for (int i = 62; i >= 0; i--) {
+        miller_dbl_step(f, t, p.x, p.y);
+        if ((CC::X_ABS >> i) & 1) miller_add_step(f, t, q, p.x, p.y);
+    }
+    fp12_conj(f, f);
+    if (p.inf | q.inf) fp12_one(f);
+}
+// a^|x| then conjugate (x < 0); a in the cyclotomic subgroup
+KYB_HD void cyclo_pow_x(fp12& r, const fp12& a) {
+    fp12 acc = a;
+#pragma unroll 1
+    for (int i = 62; i >= 0; i--) {
+        fp12_cyclo_sqr(acc, acc);
+        if ((CC::X_ABS >> i) & 1) fp12_mul(acc, acc, a);
+    }
+    fp12_conj(r, acc);
+}
+KYB_HD void cyclo_pow_words(fp12& r, const fp12& a, const uint32_t* e, int nbits) {
+    fp12 acc = a;
+#pragma unroll 1
+    for (int i = nbits - 2; i >= 0; i--) {
+        fp12_cyclo_sqr(acc, acc);
+        if ((e[i >> 5] >> (i & 31)) & 1) fp12_mul(acc, acc, a);
+    }
+    r = acc;
+}
+// f^((p^12 - 1) / r), the canonical reduced pairing exponent.
+// Hard part: (p^4 - p^2 + 1)/r = l0 + l1 p + l2 p^2 + l3 p^3 with l3 = (x-1)^2/3, l2 = x l3,
+// l1 = x l2 - l3, l0 = x l1 + 1 (checked in gen_consts.py).
+KYB_HD void final_exp(fp12& r, const fp12& f) {
+    fp12 g, t, t3, t2, t1, t0;
+    fp12_conj(g, f);
+    fp12_inv(t, f);
+    fp12_mul(g, g, t);  // f^(p^6 - 1)
+    fp12_frob<TC, 2>(t, g);
+    fp12_mul(g, t, g);  // ^(p^2 + 1): now in the cyclotomic subgroup
+    cyclo_pow_words(t3, g, CC::LAMBDA3, CC::LAMBDA3_BITS);
+    cyclo_pow_x(t2, t3);
+    cyclo_pow_x(t1, t2);
+    fp12_conj(t, t3);
+    fp12_mul(t1, t1, t);
+    cyclo_pow_x(t0, t1);
+    fp12_mul(t0, t0, g);
+    fp12_frob<TC, 1>(t, t1);
+    fp12_mul(t0, t0, t);
+    fp12_frob<TC, 2>(t, t2);
+    fp12_mul(t0, t0, t);
+    fp12_frob<TC, 3>(t, t3);
+    fp12_mul(r, t0, t);
+}
+
+// ------------------------------------------------- per-element wire-level operations
+// (what one lane of a batch kernel does; tests/host_harness.cpp runs the same functions on the CPU)
+KYB_HD void zero_bytes(uint8_t* out, int n) {
+    uint32_t* q = reinterpret_cast<uint32_t*>(out);
+    for (int k = 0; k < n / 4; k++) q[k] = 0;
+}
+// out = k * P   (G1Elt.UnmarshalBinary + Mul + MarshalBinary, kilic/g1.go:110-131)
+KYB_HD int g1_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt) {
+    g1_aff a;
+    const int st = g1_decode(a, pt, true);
+    if (st != ST_OK) {
+        zero_bytes(out, 48);
+        return st;
+    }
+    uint32_t k[8];
+    scalar_from_be(k, scalar_be);
+    g1_jac p, r;
+    jac_from_aff(p, a);
+    jac_mul_u256(r, p, k);
+    jac_to_aff(a, r);
+    g1_encode(out, a);
+    return ST_OK;
+}
+KYB_HD int g2_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt) {
+    g2_aff a;
+    const int st = g2_decode(a, pt, true);
+    if (st != ST_OK) {
+        zero_bytes(out, 96);
+        return st;
+    }
+    uint32_t k[8];
+    scalar_from_be(k, scalar_be);
+    g2_jac p, r;
+    jac_from_aff(p, a);
+    jac_mul_u256(r, p, k);
+    jac_to_aff(a, r);
+    g2_encode(out, a);
+    return ST_OK;
+}
+// gt = e(P, Q)   (Suite.Pair, kilic/suite.go:70-75)
+KYB_HD int pair_wire(uint8_t* gt, const uint8_t* g1, const uint8_t* g2) {
+    g1_aff p;
+    g2_aff q;
+    int st = g1_decode(p, g1, true);
+    const int st2 = g2_decode(q, g2, true);
+    if (st == ST_OK) st = st2;
+    if (st != ST_OK) {
+        zero_bytes(gt, 576);
+        return st;
+    }
+    fp12 f;
+    miller_loop(f, p, q);
+    final_exp(f, f);
+    gt_encode(gt, f);
+    return ST_OK;
+}
+// ok = (e(p1, p2) == e(inv1, inv2))   (Suite.ValidatePairing, pairing/pairing.go:13-15,
+// kilic/suite.go:57-68: AddPair(p1, p2); AddPairInv(inv1, inv2); Check())
+KYB_HD int pair_check_wire(uint8_t* ok, const uint8_t* p1, const uint8_t* p2, const uint8_t* inv1,
+                           const uint8_t* inv2) {
+    g1_aff a, c;
+    g2_aff b, d;
+    int st = g1_decode(a, p1, true);
+    int s2 = g2_decode(b, p2, true);
+    if (st == ST_OK) st = s2;
+    s2 = g1_decode(c, inv1, true);
+    if (st == ST_OK) st = s2;
+    s2 = g2_decode(d, inv2, true);
+    if (st == ST_OK) st = s2;
+    *ok = 0;
+    if (st != ST_OK) return st;
+    fp_neg(c.y, c.y);
+    fp12 f, g;
+    miller_loop(f, a, b);
+    miller_loop(g, c, d);
+    fp12_mul(f, f, g);
+    final_exp(f, f);
+    *ok = fp12_is_one(f) ? 1 : 0;
+    return ST_OK;
+}
+
+}  // namespace bls
+}  // namespace kyb

@@ -1,0 +1,228 @@
+// Short-Weierstrass (a = 0) group arithmetic in Jacobian coordinates over any field of the tower
+// (F = Fp<C> for G1, Fp2<T> for G2), one point per lane.
+//
+// Replaces: pairing/bn256 curvePoint/twistPoint Add/Double/Mul/MakeAffine (curve.go:69,156,189,205;
+// twist.go:162) and the g1/g2 layers of the external BLS12-381 backends (kilic/g1.go:110-116 ->
+// MulScalarBig).  Only canonical affine encodings are observable, so the scalar multiplication is
+// free to use a signed radix-16 window instead of the reference's bit-serial double-and-add.
+#pragma once
+#include "tower.cuh"
+
+namespace kyb {
+
+// ---- uniform names over Fp / Fp2 so the point formulas are written once
+template <class C> KYB_HD void f_add(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) { fp_add(r, a, b); }
+template <class C> KYB_HD void f_sub(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) { fp_sub(r, a, b); }
+template <class C> KYB_HD void f_mul(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) { fp_mul(r, a, b); }
+template <class C> KYB_HD void f_sqr(Fp<C>& r, const Fp<C>& a) { fp_sqr(r, a); }
+template <class C> KYB_HD void f_dbl(Fp<C>& r, const Fp<C>& a) { fp_dbl(r, a); }
+template <class C> KYB_HD void f_neg(Fp<C>& r, const Fp<C>& a) { fp_neg(r, a); }
+template <class C> KYB_HD void f_inv(Fp<C>& r, const Fp<C>& a) { fp_inv(r, a); }
+template <class C> KYB_HD void f_zero(Fp<C>& r) { fp_zero(r); }
+template <class C> KYB_HD void f_one(Fp<C>& r) { fp_one(r); }
+template <class C> KYB_HD bool f_is_zero(const Fp<C>& a) { return fp_is_zero(a); }
+template <class C> KYB_HD bool f_eq(const Fp<C>& a, const Fp<C>& b) { return fp_eq(a, b); }
+template <class C> KYB_HD void f_cmov(Fp<C>& r, const Fp<C>& a, bool c) { fp_cmov(r, a, c); }
+template <class T> KYB_HD void f_add(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) { fp2_add(r, a, b); }
+template <class T> KYB_HD void f_sub(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) { fp2_sub(r, a, b); }
+template <class T> KYB_HD void f_mul(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) { fp2_mul(r, a, b); }
+template <class T> KYB_HD void f_sqr(Fp2<T>& r, const Fp2<T>& a) { fp2_sqr(r, a); }
+template <class T> KYB_HD void f_dbl(Fp2<T>& r, const Fp2<T>& a) { fp2_dbl(r, a); }
+template <class T> KYB_HD void f_neg(Fp2<T>& r, const Fp2<T>& a) { fp2_neg(r, a); }
+template <class T> KYB_HD void f_inv(Fp2<T>& r, const Fp2<T>& a) { fp2_inv(r, a); }
+template <class T> KYB_HD void f_zero(Fp2<T>& r) { fp2_zero(r); }
+template <class T> KYB_HD void f_one(Fp2<T>& r) { fp2_one(r); }
+template <class T> KYB_HD bool f_is_zero(const Fp2<T>& a) { return fp2_is_zero(a); }
+template <class T> KYB_HD bool f_eq(const Fp2<T>& a, const Fp2<T>& b) { return fp2_eq(a, b); }
+template <class T> KYB_HD void f_cmov(Fp2<T>& r, const Fp2<T>& a, bool c) { fp2_cmov(r, a, c); }
+
+template <class F>
+struct Jac {  // (X : Y : Z), x = X/Z^2, y = Y/Z^3, infinity <=> Z = 0
+    F X, Y, Z;
+};
+template <class F>
+struct Aff {
+    F x, y;
+    bool inf;
+};
+
+template <class F> KYB_HD void jac_set_inf(Jac<F>& r) { f_one(r.X); f_one(r.Y); f_zero(r.Z); }
+template <class F> KYB_HD bool jac_is_inf(const Jac<F>& p) { return f_is_zero(p.Z); }
+template <class F>
+KYB_HD void jac_from_aff(Jac<F>& r, const Aff<F>& a) {
+    r.X = a.x;
+    r.Y = a.y;
+    f_one(r.Z);
+    if (a.inf) jac_set_inf(r);
+}
+template <class F>
+KYB_HD void jac_cmov(Jac<F>& r, const Jac<F>& a, bool c) {
+    f_cmov(r.X, a.X, c);
+    f_cmov(r.Y, a.Y, c);
+    f_cmov(r.Z, a.Z, c);
+}
+template <class F> KYB_HD void jac_neg(Jac<F>& r, const Jac<F>& p) { r.X = p.X; f_neg(r.Y, p.Y); r.Z = p.Z; }
+
+// dbl-2009-l (a = 0): 2M + 5S.  Maps infinity to infinity and 2-torsion points (Y = 0) to infinity.
+template <class F>
+KYB_HD void jac_dbl(Jac<F>& r, const Jac<F>& p) {
+    F A, B, C, D, E, G, t;
+    f_sqr(A, p.X);
+    f_sqr(B, p.Y);
+    f_sqr(C, B);
+    f_add(t, p.X, B);
+    f_sqr(t, t);
+    f_sub(t, t, A);
+    f_sub(t, t, C);
+    f_dbl(D, t);  // 4 X Y^2
+    f_dbl(E, A);
+    f_add(E, E, A);  // 3 X^2
+    f_sqr(G, E);
+    f_mul(t, p.Y, p.Z);
+    f_dbl(r.Z, t);  // uses p.Y, p.Z before they are overwritten (r may alias p)
+    f_dbl(t, D);
+    f_sub(r.X, G, t);
+    f_sub(t, D, r.X);
+    f_mul(t, E, t);
+    f_dbl(C, C);
+    f_dbl(C, C);
+    f_dbl(C, C);
+    f_sub(r.Y, t, C);
+}
+
+// add-2007-bl with the exceptional cases handled (either operand infinity, P = Q, P = -Q).
+template <class F>
+KYB_HD void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
+    const bool pinf = jac_is_inf(p), qinf = jac_is_inf(q);
+    F Z1Z1, Z2Z2, U1, U2, S1, S2, H, I, J, rr, V, t;
+    f_sqr(Z1Z1, p.Z);
+    f_sqr(Z2Z2, q.Z);
+    f_mul(U1, p.X, Z2Z2);
+    f_mul(U2, q.X, Z1Z1);
+    f_mul(t, q.Z, Z2Z2);
+    f_mul(S1, p.Y, t);
+    f_mul(t, p.Z, Z1Z1);
+    f_mul(S2, q.Y, t);
+    f_sub(H, U2, U1);
+    f_sub(rr, S2, S1);
+    if (!pinf && !qinf && f_is_zero(H)) {  // same x: doubling or cancellation (rare; divergence is fine)
+        if (f_is_zero(rr)) {
+            jac_dbl(r, p);
+        } else {
+            jac_set_inf(r);
+        }
+        return;
+    }
+    Jac<F> o;
+    f_dbl(rr, rr);
+    f_dbl(I, H);
+    f_sqr(I, I);
+    f_mul(J, H, I);
+    f_mul(V, U1, I);
+    f_sqr(o.X, rr);
+    f_sub(o.X, o.X, J);
+    f_sub(o.X, o.X, V);
+    f_sub(o.X, o.X, V);
+    f_sub(t, V, o.X);
+    f_mul(t, rr, t);
+    f_mul(S1, S1, J);
+    f_dbl(S1, S1);
+    f_sub(o.Y, t, S1);
+    f_add(t, p.Z, q.Z);
+    f_sqr(t, t);
+    f_sub(t, t, Z1Z1);
+    f_sub(t, t, Z2Z2);
+    f_mul(o.Z, t, H);
+    jac_cmov(o, q, pinf);
+    jac_cmov(o, p, qinf);
+    r = o;
+}
+
+// Signed radix-16 digits of a 256-bit scalar given as eight little-endian words:
+// e[0..63] in [-8, 8), e[64] in {0, 1}.
+KYB_HD void recode16_u256(int8_t (&e)[65], const uint32_t (&k)[8]) {
+    int carry = 0;
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        int d = (int)((k[i >> 3] >> ((i & 7) * 4)) & 15) + carry;
+        carry = (d + 8) >> 4;
+        d -= carry << 4;
+        e[i] = (int8_t)d;
+    }
+    e[64] = (int8_t)carry;
+}
+
+// r = k * p, k a plain 256-bit integer (eight little-endian words).  Uniform control flow: every
+// window does 4 doublings and one addition whose result is kept only when the digit is non-zero.
+template <class F>
+KYB_HD void jac_mul_u256(Jac<F>& r, const Jac<F>& p, const uint32_t (&k)[8]) {
+    Jac<F> tab[8];  // (j + 1) * p
+    tab[0] = p;
+    jac_dbl(tab[1], p);
+#pragma unroll 1
+    for (int j = 2; j < 8; j++) jac_add(tab[j], tab[j - 1], p);
+    int8_t e[65];
+    recode16_u256(e, k);
+    Jac<F> acc, t, s;
+    jac_set_inf(acc);
+#pragma unroll 1
+    for (int i = 64; i >= 0; i--) {
+        if (i != 64) {
+            jac_dbl(acc, acc);
+            jac_dbl(acc, acc);
+            jac_dbl(acc, acc);
+            jac_dbl(acc, acc);
+        }
+        const int d = e[i];
+        const int ad = d < 0 ? -d : d;
+        t = tab[ad ? ad - 1 : 0];
+        F ny;
+        f_neg(ny, t.Y);
+        f_cmov(t.Y, ny, d < 0);
+        jac_add(s, acc, t);
+        jac_cmov(acc, s, d != 0);
+    }
+    r = acc;
+}
+// Short public multiplier (e.g. the curve parameter |x|), MSB-first double-and-add; uniform.
+template <class F>
+KYB_HD void jac_mul_u64(Jac<F>& r, const Jac<F>& p, uint64_t k) {
+    Jac<F> acc;
+    jac_set_inf(acc);
+#pragma unroll 1
+    for (int i = 63; i >= 0; i--) {
+        jac_dbl(acc, acc);
+        if ((k >> i) & 1) jac_add(acc, acc, p);
+    }
+    r = acc;
+}
+
+template <class F>
+KYB_HD void jac_to_aff(Aff<F>& a, const Jac<F>& p) {
+    a.inf = jac_is_inf(p);
+    F zi, zi2;
+    f_inv(zi, p.Z);
+    f_sqr(zi2, zi);
+    f_mul(a.x, p.X, zi2);
+    f_mul(zi2, zi2, zi);
+    f_mul(a.y, p.Y, zi2);
+}
+// Equality of the points represented (both finite or both infinite).
+template <class F>
+KYB_HD bool jac_eq(const Jac<F>& p, const Jac<F>& q) {
+    const bool pinf = jac_is_inf(p), qinf = jac_is_inf(q);
+    F z1, z2, a, b;
+    f_sqr(z1, p.Z);
+    f_sqr(z2, q.Z);
+    f_mul(a, p.X, z2);
+    f_mul(b, q.X, z1);
+    bool ok = f_eq(a, b);
+    f_mul(z1, z1, p.Z);
+    f_mul(z2, z2, q.Z);
+    f_mul(a, p.Y, z2);
+    f_mul(b, q.Y, z1);
+    ok = ok & f_eq(a, b);
+    return (pinf || qinf) ? (pinf && qinf) : ok;
+}
+
+}  // namespace kyb

@@ -1,0 +1,293 @@
+// Prime-field arithmetic in Montgomery form for the pairing curves (BLS12-381 Fp, bn256 Fp),
+// one field element per lane, integer VALU only.
+//
+// Replaces: pairing/bn256 gfP + gfpMul (gfp.go:15, gfp_generic.go:158, gfp_amd64.s) and the Fp
+// layer of the external BLS12-381 backends (kilic/bls12-381 fp.go etc., go.mod:6-8).
+//
+// Representation: N unsaturated limbs of W bits (BLS12-381: 13 x 30, bn256: 9 x 29) held in
+// VGPRs, value always fully reduced to [0, p) and every limb < 2^W, Montgomery radix
+// R = 2^(N*W).  Unsaturated limbs are what makes v_mad_u64_u32 the whole inner loop: a
+// product of two limbs is < 2^(2W) <= 2^60, so a 64-bit column accumulator absorbs up to
+// MAXP products with no carry instructions between them (32-bit saturated limbs would need a
+// v_add_co/v_addc pair per product, +50% VALU issue).  Multiplication is the interleaved
+// (CIOS-order) product/reduction over a sliding window of N column accumulators; when 2N
+// products per column would overflow 64 bits (BLS12-381: 26 x 2^60) one mid-way carry sweep
+// renormalises the window.
+#pragma once
+#include "hd.h"
+
+namespace kyb {
+
+// A field configuration C provides:
+//   N, W                       limb count / limb width
+//   P[N]                       modulus limbs
+//   NINV                       -p^-1 mod 2^W
+//   ONE[N], R2[N]              R mod p, R^2 mod p
+//   NWORDS                     32-bit words of the wire encoding (12 for 48 bytes, 8 for 32 bytes)
+template <class C>
+struct Fp {
+    uint32_t v[C::N];
+};
+
+template <class C>
+KYB_HD void fp_zero(Fp<C>& r) {
+#pragma unroll
+    for (int j = 0; j < C::N; j++) r.v[j] = 0;
+}
+template <class C>
+KYB_HD void fp_one(Fp<C>& r) {
+#pragma unroll
+    for (int j = 0; j < C::N; j++) r.v[j] = C::ONE[j];
+}
+template <class C>
+KYB_HD bool fp_is_zero(const Fp<C>& a) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int j = 0; j < C::N; j++) o |= a.v[j];
+    return o == 0;
+}
+template <class C>
+KYB_HD bool fp_eq(const Fp<C>& a, const Fp<C>& b) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int j = 0; j < C::N; j++) o |= a.v[j] ^ b.v[j];
+    return o == 0;
+}
+// r = c ? a : r
+template <class C>
+KYB_HD void fp_cmov(Fp<C>& r, const Fp<C>& a, bool c) {
+#pragma unroll
+    for (int j = 0; j < C::N; j++) r.v[j] = c ? a.v[j] : r.v[j];
+}
+
+// s (normalised limbs, value < 2p) -> s mod p
+template <class C>
+KYB_HD void fp_reduce_once(uint32_t (&s)[C::N]) {
+    constexpr uint32_t MASK = (1u << C::W) - 1;
+    uint32_t d[C::N];
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int j = 0; j < C::N; j++) {
+        const uint32_t x = s[j] - C::P[j] - borrow;
+        borrow = x >> 31;
+        d[j] = x & MASK;
+    }
+#pragma unroll
+    for (int j = 0; j < C::N; j++) s[j] = borrow ? s[j] : d[j];
+}
+
+template <class C>
+KYB_HD void fp_add(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
+    constexpr uint32_t MASK = (1u << C::W) - 1;
+    uint32_t s[C::N];
+    uint32_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < C::N; j++) {
+        const uint32_t u = a.v[j] + b.v[j] + carry;
+        s[j] = u & MASK;
+        carry = u >> C::W;
+    }
+    fp_reduce_once<C>(s);
+#pragma unroll
+    for (int j = 0; j < C::N; j++) r.v[j] = s[j];
+}
+template <class C>
+KYB_HD void fp_dbl(Fp<C>& r, const Fp<C>& a) {
+    fp_add(r, a, a);
+}
+template <class C>
+KYB_HD void fp_sub(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
+    constexpr uint32_t MASK = (1u << C::W) - 1;
+    uint32_t d[C::N];
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int j = 0; j < C::N; j++) {
+        const uint32_t x = a.v[j] - b.v[j] - borrow;
+        borrow = x >> 31;
+        d[j] = x & MASK;
+    }
+    const uint32_t m = 0u - borrow;  // all ones when a < b: add p back
+    uint32_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < C::N; j++) {
+        const uint32_t u = d[j] + (C::P[j] & m) + carry;
+        r.v[j] = u & MASK;
+        carry = u >> C::W;
+    }
+}
+template <class C>
+KYB_HD void fp_neg(Fp<C>& r, const Fp<C>& a) {
+    Fp<C> z;
+    fp_zero(z);
+    fp_sub(r, z, a);
+}
+
+// r = a * b * R^-1 mod p
+template <class C>
+KYB_HD void fp_mul(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
+    constexpr int N = C::N, W = C::W;
+    constexpr uint32_t MASK = (1u << W) - 1;
+    // products of two W-bit limbs that fit a 64-bit column together with a carry-in
+    constexpr int MAXP = (W >= 32) ? 0 : (int)((~0ull) / ((uint64_t)MASK * MASK)) - 1;
+    static_assert(MAXP >= 4, "limb width too large for lazy column accumulation");
+    uint64_t t[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) t[j] = 0;
+    int pending = 0;  // products accumulated in the fullest column since the last sweep
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        if (pending + 2 > MAXP) {
+#pragma unroll
+            for (int j = 0; j < N - 1; j++) {
+                t[j + 1] += t[j] >> W;
+                t[j] &= MASK;
+            }
+            pending = 0;
+        }
+        pending += 2;
+        const uint32_t ai = a.v[i];
+#pragma unroll
+        for (int j = 0; j < N; j++) t[j] += (uint64_t)ai * b.v[j];
+        const uint32_t m = ((uint32_t)t[0] * C::NINV) & MASK;
+#pragma unroll
+        for (int j = 0; j < N; j++) t[j] += (uint64_t)m * C::P[j];
+        const uint64_t carry = t[0] >> W;  // low W bits are zero by construction
+#pragma unroll
+        for (int j = 0; j < N - 1; j++) t[j] = t[j + 1];
+        t[N - 1] = 0;
+        t[0] += carry;
+    }
+    uint32_t s[N];
+#pragma unroll
+    for (int j = 0; j < N - 1; j++) {
+        t[j + 1] += t[j] >> W;
+        s[j] = (uint32_t)t[j] & MASK;
+    }
+    s[N - 1] = (uint32_t)t[N - 1];
+    fp_reduce_once<C>(s);
+#pragma unroll
+    for (int j = 0; j < N; j++) r.v[j] = s[j];
+}
+template <class C>
+KYB_HD void fp_sqr(Fp<C>& r, const Fp<C>& a) {
+    fp_mul(r, a, a);
+}
+
+// Small-constant multiples
+template <class C>
+KYB_HD void fp_mul3(Fp<C>& r, const Fp<C>& a) {
+    Fp<C> t;
+    fp_add(t, a, a);
+    fp_add(r, t, a);
+}
+
+// r = a^e for a public exponent held as NW little-endian 32-bit words (uniform control flow).
+template <class C>
+KYB_HD void fp_pow_words(Fp<C>& r, const Fp<C>& a, const uint32_t* e, int nbits) {
+    Fp<C> acc;
+    fp_one(acc);
+#pragma unroll 1
+    for (int i = nbits - 1; i >= 0; i--) {
+        fp_sqr(acc, acc);
+        if ((e[i >> 5] >> (i & 31)) & 1) fp_mul(acc, acc, a);
+    }
+    r = acc;
+}
+template <class C>
+KYB_HD void fp_inv(Fp<C>& r, const Fp<C>& a) {  // a^(p-2); inv(0) = 0
+    fp_pow_words<C>(r, a, C::PM2, C::PBITS);
+}
+
+// ------------------------------------------------------------ wire <-> limbs
+// w: NWORDS little-endian 32-bit words of a plain integer
+template <class C>
+KYB_HD void fp_limbs_from_words(uint32_t (&v)[C::N], const uint32_t (&w)[C::NWORDS]) {
+    constexpr uint32_t MASK = (1u << C::W) - 1;
+#pragma unroll
+    for (int j = 0; j < C::N; j++) {
+        const int off = j * C::W, idx = off >> 5, sh = off & 31;
+        uint32_t x = 0;
+        if (idx < C::NWORDS) x = w[idx] >> sh;
+        if (sh + C::W > 32 && idx + 1 < C::NWORDS) x |= w[idx + 1] << (32 - sh);
+        v[j] = x & MASK;
+    }
+}
+template <class C>
+KYB_HD void fp_words_from_limbs(uint32_t (&w)[C::NWORDS], const uint32_t (&v)[C::N]) {
+#pragma unroll
+    for (int k = 0; k < C::NWORDS; k++) w[k] = 0;
+#pragma unroll
+    for (int j = 0; j < C::N; j++) {
+        const int off = j * C::W, idx = off >> 5, sh = off & 31;
+        if (idx < C::NWORDS) w[idx] |= v[j] << sh;
+        if (sh + C::W > 32 && idx + 1 < C::NWORDS) w[idx + 1] |= v[j] >> (32 - sh);
+    }
+}
+// true when the plain integer in w is < p
+template <class C>
+KYB_HD bool fp_words_lt_p(const uint32_t (&w)[C::NWORDS]) {
+    uint32_t v[C::N];
+    fp_limbs_from_words<C>(v, w);
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int j = 0; j < C::N; j++) borrow = (v[j] - C::P[j] - borrow) >> 31;
+    // bits of w above N*W cannot be set when NWORDS*32 <= N*W, which holds for both curves
+    return borrow != 0;
+}
+// plain integer words (must be < p) -> Montgomery element
+template <class C>
+KYB_HD void fp_from_words(Fp<C>& r, const uint32_t (&w)[C::NWORDS]) {
+    Fp<C> raw, r2;
+    fp_limbs_from_words<C>(raw.v, w);
+#pragma unroll
+    for (int j = 0; j < C::N; j++) r2.v[j] = C::R2[j];
+    fp_mul(r, raw, r2);
+}
+// Montgomery element -> canonical plain integer words
+template <class C>
+KYB_HD void fp_to_words(uint32_t (&w)[C::NWORDS], const Fp<C>& a) {
+    Fp<C> one_raw, c;
+    fp_zero(one_raw);
+    one_raw.v[0] = 1;
+    fp_mul(c, a, one_raw);
+    fp_words_from_limbs<C>(w, c.v);
+}
+// Montgomery element from a small unsigned constant
+template <class C>
+KYB_HD void fp_from_u32(Fp<C>& r, uint32_t x) {
+    uint32_t w[C::NWORDS];
+#pragma unroll
+    for (int k = 0; k < C::NWORDS; k++) w[k] = 0;
+    w[0] = x;
+    fp_from_words<C>(r, w);
+}
+
+// Big-endian byte strings <-> words.  Buffers are 4-byte aligned (element sizes are multiples of 16).
+KYB_HD uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
+template <int NW>
+KYB_HD void words_from_be(uint32_t (&w)[NW], const uint8_t* p) {
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+#pragma unroll
+    for (int k = 0; k < NW; k++) w[k] = bswap32(q[NW - 1 - k]);
+}
+template <int NW>
+KYB_HD void words_to_be(uint8_t* p, const uint32_t (&w)[NW]) {
+    uint32_t* q = reinterpret_cast<uint32_t*>(p);
+#pragma unroll
+    for (int k = 0; k < NW; k++) q[NW - 1 - k] = bswap32(w[k]);
+}
+// a > b on plain little-endian word arrays
+template <int NW>
+KYB_HD bool words_gt(const uint32_t (&a)[NW], const uint32_t (&b)[NW]) {
+    bool gt = false, decided = false;
+#pragma unroll
+    for (int k = NW - 1; k >= 0; k--) {
+        if (!decided && a[k] != b[k]) {
+            gt = a[k] > b[k];
+            decided = true;
+        }
+    }
+    return gt;
+}
+
+}  // namespace kyb

@@ -1,0 +1,332 @@
+// Extension-field tower Fp2 / Fp6 / Fp12 over a Montgomery base field (mont.cuh), shared by the
+// BLS12-381 and bn256 pairings:
+//   Fp2  = Fp[i]/(i^2 + 1)            elements c0 + c1 i
+//   Fp6  = Fp2[v]/(v^3 - xi)          xi = XI0 + i   (BLS12-381: 1 + i, bn256: 3 + i)
+//   Fp12 = Fp6[w]/(w^2 - v)
+//
+// Replaces: pairing/bn256 gfP2/gfP6/gfP12 (gfp2.go:11, gfp6.go:11, gfp12.go:15 -- same tower,
+// different variable names: gfP2{x,y} = x i + y, gfP6{x,y,z} = x v^2 + y v + z, gfP12{x,y} = x w + y)
+// and the fp2/fp6/fp12 layers of the external BLS12-381 backends (go.mod:6-8).
+//
+// A tower configuration T provides: typedef F (field config for mont.cuh), XI0, and the
+// Frobenius constants FROB[3][6][2][N] = xi^(j (p^k - 1)/6), k = 1..3, j = 0..5, as Fp2
+// Montgomery limbs.
+#pragma once
+#include "mont.cuh"
+
+namespace kyb {
+
+template <class T>
+struct Fp2 {
+    Fp<typename T::F> c0, c1;
+};
+template <class T>
+struct Fp6 {
+    Fp2<T> c0, c1, c2;
+};
+template <class T>
+struct Fp12 {
+    Fp6<T> c0, c1;
+};
+
+// ----------------------------------------------------------------------- Fp2
+template <class T> KYB_HD void fp2_zero(Fp2<T>& r) { fp_zero(r.c0); fp_zero(r.c1); }
+template <class T> KYB_HD void fp2_one(Fp2<T>& r) { fp_one(r.c0); fp_zero(r.c1); }
+template <class T> KYB_HD bool fp2_is_zero(const Fp2<T>& a) { return fp_is_zero(a.c0) & fp_is_zero(a.c1); }
+template <class T> KYB_HD bool fp2_eq(const Fp2<T>& a, const Fp2<T>& b) { return fp_eq(a.c0, b.c0) & fp_eq(a.c1, b.c1); }
+template <class T> KYB_HD void fp2_cmov(Fp2<T>& r, const Fp2<T>& a, bool c) { fp_cmov(r.c0, a.c0, c); fp_cmov(r.c1, a.c1, c); }
+template <class T> KYB_HD void fp2_add(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) { fp_add(r.c0, a.c0, b.c0); fp_add(r.c1, a.c1, b.c1); }
+template <class T> KYB_HD void fp2_sub(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) { fp_sub(r.c0, a.c0, b.c0); fp_sub(r.c1, a.c1, b.c1); }
+template <class T> KYB_HD void fp2_dbl(Fp2<T>& r, const Fp2<T>& a) { fp_dbl(r.c0, a.c0); fp_dbl(r.c1, a.c1); }
+template <class T> KYB_HD void fp2_neg(Fp2<T>& r, const Fp2<T>& a) { fp_neg(r.c0, a.c0); fp_neg(r.c1, a.c1); }
+template <class T> KYB_HD void fp2_conj(Fp2<T>& r, const Fp2<T>& a) { r.c0 = a.c0; fp_neg(r.c1, a.c1); }
+
+// Karatsuba: 3 base-field multiplications
+template <class T>
+KYB_HD void fp2_mul(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) {
+    Fp<typename T::F> t0, t1, t2, s0, s1;
+    fp_mul(t0, a.c0, b.c0);
+    fp_mul(t1, a.c1, b.c1);
+    fp_add(s0, a.c0, a.c1);
+    fp_add(s1, b.c0, b.c1);
+    fp_mul(t2, s0, s1);
+    fp_sub(t2, t2, t0);
+    fp_sub(r.c1, t2, t1);
+    fp_sub(r.c0, t0, t1);
+}
+// (c0 + c1)(c0 - c1), 2 c0 c1: 2 base-field multiplications
+template <class T>
+KYB_HD void fp2_sqr(Fp2<T>& r, const Fp2<T>& a) {
+    Fp<typename T::F> s, d, m;
+    fp_add(s, a.c0, a.c1);
+    fp_sub(d, a.c0, a.c1);
+    fp_mul(m, a.c0, a.c1);
+    fp_mul(r.c0, s, d);
+    fp_dbl(r.c1, m);
+}
+// by an element of the base field
+template <class T>
+KYB_HD void fp2_mul_fp(Fp2<T>& r, const Fp2<T>& a, const Fp<typename T::F>& b) {
+    fp_mul(r.c0, a.c0, b);
+    fp_mul(r.c1, a.c1, b);
+}
+// r = a * xi, xi = XI0 + i:  (XI0 a0 - a1) + (a0 + XI0 a1) i
+template <class T>
+KYB_HD void fp2_mul_xi(Fp2<T>& r, const Fp2<T>& a) {
+    Fp<typename T::F> x0 = a.c0, x1 = a.c1, t0 = a.c0, t1 = a.c1;
+#pragma unroll
+    for (int k = 1; k < T::XI0; k++) {
+        fp_add(t0, t0, x0);
+        fp_add(t1, t1, x1);
+    }
+    fp_sub(r.c0, t0, x1);
+    fp_add(r.c1, t1, x0);
+}
+template <class T>
+KYB_HD void fp2_inv(Fp2<T>& r, const Fp2<T>& a) {
+    Fp<typename T::F> n, t;
+    fp_sqr(n, a.c0);
+    fp_sqr(t, a.c1);
+    fp_add(n, n, t);
+    fp_inv(n, n);
+    fp_mul(r.c0, a.c0, n);
+    fp_mul(t, a.c1, n);
+    fp_neg(r.c1, t);
+}
+
+// ----------------------------------------------------------------------- Fp6
+template <class T> KYB_HD void fp6_zero(Fp6<T>& r) { fp2_zero(r.c0); fp2_zero(r.c1); fp2_zero(r.c2); }
+template <class T> KYB_HD void fp6_one(Fp6<T>& r) { fp2_one(r.c0); fp2_zero(r.c1); fp2_zero(r.c2); }
+template <class T> KYB_HD void fp6_add(Fp6<T>& r, const Fp6<T>& a, const Fp6<T>& b) { fp2_add(r.c0, a.c0, b.c0); fp2_add(r.c1, a.c1, b.c1); fp2_add(r.c2, a.c2, b.c2); }
+template <class T> KYB_HD void fp6_sub(Fp6<T>& r, const Fp6<T>& a, const Fp6<T>& b) { fp2_sub(r.c0, a.c0, b.c0); fp2_sub(r.c1, a.c1, b.c1); fp2_sub(r.c2, a.c2, b.c2); }
+template <class T> KYB_HD void fp6_neg(Fp6<T>& r, const Fp6<T>& a) { fp2_neg(r.c0, a.c0); fp2_neg(r.c1, a.c1); fp2_neg(r.c2, a.c2); }
+template <class T> KYB_HD bool fp6_eq(const Fp6<T>& a, const Fp6<T>& b) { return fp2_eq(a.c0, b.c0) & fp2_eq(a.c1, b.c1) & fp2_eq(a.c2, b.c2); }
+// r = a * v
+template <class T>
+KYB_HD void fp6_mul_v(Fp6<T>& r, const Fp6<T>& a) {
+    Fp2<T> t;
+    fp2_mul_xi(t, a.c2);
+    r.c2 = a.c1;
+    r.c1 = a.c0;
+    r.c0 = t;
+}
+// Karatsuba, 6 Fp2 multiplications
+template <class T>
+KYB_HD void fp6_mul(Fp6<T>& r, const Fp6<T>& a, const Fp6<T>& b) {
+    Fp2<T> v0, v1, v2, s, u, t0, t1, t2;
+    fp2_mul(v0, a.c0, b.c0);
+    fp2_mul(v1, a.c1, b.c1);
+    fp2_mul(v2, a.c2, b.c2);
+    fp2_add(s, a.c1, a.c2);
+    fp2_add(u, b.c1, b.c2);
+    fp2_mul(t0, s, u);
+    fp2_sub(t0, t0, v1);
+    fp2_sub(t0, t0, v2);
+    fp2_mul_xi(t0, t0);
+    fp2_add(t0, t0, v0);  // c0
+    fp2_add(s, a.c0, a.c1);
+    fp2_add(u, b.c0, b.c1);
+    fp2_mul(t1, s, u);
+    fp2_sub(t1, t1, v0);
+    fp2_sub(t1, t1, v1);
+    fp2_mul_xi(s, v2);
+    fp2_add(t1, t1, s);  // c1
+    fp2_add(s, a.c0, a.c2);
+    fp2_add(u, b.c0, b.c2);
+    fp2_mul(t2, s, u);
+    fp2_sub(t2, t2, v0);
+    fp2_sub(t2, t2, v2);
+    fp2_add(t2, t2, v1);  // c2
+    r.c0 = t0;
+    r.c1 = t1;
+    r.c2 = t2;
+}
+template <class T>
+KYB_HD void fp6_sqr(Fp6<T>& r, const Fp6<T>& a) {
+    // Chung-Hasan SQR2: 2 multiplications + 3 squarings in Fp2
+    Fp2<T> s0, s1, s2, s3, s4, t;
+    fp2_sqr(s0, a.c0);
+    fp2_mul(t, a.c0, a.c1);
+    fp2_dbl(s1, t);
+    fp2_sub(t, a.c0, a.c1);
+    fp2_add(t, t, a.c2);
+    fp2_sqr(s2, t);
+    fp2_mul(t, a.c1, a.c2);
+    fp2_dbl(s3, t);
+    fp2_sqr(s4, a.c2);
+    // c0 = s0 + xi s3 ; c1 = s1 + xi s4 ; c2 = s1 + s2 + s3 - s0 - s4
+    fp2_mul_xi(t, s3);
+    fp2_add(r.c0, s0, t);
+    fp2_mul_xi(t, s4);
+    fp2_add(r.c1, s1, t);
+    fp2_add(t, s1, s2);
+    fp2_add(t, t, s3);
+    fp2_sub(t, t, s0);
+    fp2_sub(r.c2, t, s4);
+}
+// a * (b0 + b1 v)   -- 5 Fp2 multiplications
+template <class T>
+KYB_HD void fp6_mul_by_01(Fp6<T>& r, const Fp6<T>& a, const Fp2<T>& b0, const Fp2<T>& b1) {
+    Fp2<T> v0, v1, t0, t1, t2, s, u;
+    fp2_mul(v0, a.c0, b0);
+    fp2_mul(v1, a.c1, b1);
+    fp2_mul(t0, a.c2, b1);
+    fp2_mul_xi(t0, t0);
+    fp2_add(t0, t0, v0);  // c0 = xi a2 b1 + a0 b0
+    fp2_add(s, a.c0, a.c1);
+    fp2_add(u, b0, b1);
+    fp2_mul(t1, s, u);
+    fp2_sub(t1, t1, v0);
+    fp2_sub(t1, t1, v1);  // c1 = a0 b1 + a1 b0
+    fp2_mul(t2, a.c2, b0);
+    fp2_add(t2, t2, v1);  // c2 = a2 b0 + a1 b1
+    r.c0 = t0;
+    r.c1 = t1;
+    r.c2 = t2;
+}
+// a * (b1 v)   -- 3 Fp2 multiplications
+template <class T>
+KYB_HD void fp6_mul_by_1(Fp6<T>& r, const Fp6<T>& a, const Fp2<T>& b1) {
+    Fp2<T> t0, t1, t2;
+    fp2_mul(t0, a.c2, b1);
+    fp2_mul_xi(t0, t0);
+    fp2_mul(t1, a.c0, b1);
+    fp2_mul(t2, a.c1, b1);
+    r.c0 = t0;
+    r.c1 = t1;
+    r.c2 = t2;
+}
+template <class T>
+KYB_HD void fp6_mul_fp2(Fp6<T>& r, const Fp6<T>& a, const Fp2<T>& b) {
+    fp2_mul(r.c0, a.c0, b);
+    fp2_mul(r.c1, a.c1, b);
+    fp2_mul(r.c2, a.c2, b);
+}
+template <class T>
+KYB_HD void fp6_inv(Fp6<T>& r, const Fp6<T>& a) {
+    Fp2<T> t0, t1, t2, d, s;
+    fp2_sqr(t0, a.c0);
+    fp2_mul(s, a.c1, a.c2);
+    fp2_mul_xi(s, s);
+    fp2_sub(t0, t0, s);  // a0^2 - xi a1 a2
+    fp2_sqr(t1, a.c2);
+    fp2_mul_xi(t1, t1);
+    fp2_mul(s, a.c0, a.c1);
+    fp2_sub(t1, t1, s);  // xi a2^2 - a0 a1
+    fp2_sqr(t2, a.c1);
+    fp2_mul(s, a.c0, a.c2);
+    fp2_sub(t2, t2, s);  // a1^2 - a0 a2
+    fp2_mul(d, a.c2, t1);
+    fp2_mul(s, a.c1, t2);
+    fp2_add(d, d, s);
+    fp2_mul_xi(d, d);
+    fp2_mul(s, a.c0, t0);
+    fp2_add(d, d, s);
+    fp2_inv(d, d);
+    fp2_mul(r.c0, t0, d);
+    fp2_mul(r.c1, t1, d);
+    fp2_mul(r.c2, t2, d);
+}
+
+// ---------------------------------------------------------------------- Fp12
+template <class T> KYB_HD void fp12_one(Fp12<T>& r) { fp6_one(r.c0); fp6_zero(r.c1); }
+template <class T> KYB_HD bool fp12_eq(const Fp12<T>& a, const Fp12<T>& b) { return fp6_eq(a.c0, b.c0) & fp6_eq(a.c1, b.c1); }
+template <class T> KYB_HD void fp12_conj(Fp12<T>& r, const Fp12<T>& a) { r.c0 = a.c0; fp6_neg(r.c1, a.c1); }
+template <class T>
+KYB_HD bool fp12_is_one(const Fp12<T>& a) {
+    Fp12<T> o;
+    fp12_one(o);
+    return fp12_eq(a, o);
+}
+template <class T>
+KYB_HD void fp12_mul(Fp12<T>& r, const Fp12<T>& a, const Fp12<T>& b) {
+    Fp6<T> v0, v1, s, u, t;
+    fp6_mul(v0, a.c0, b.c0);
+    fp6_mul(v1, a.c1, b.c1);
+    fp6_add(s, a.c0, a.c1);
+    fp6_add(u, b.c0, b.c1);
+    fp6_mul(t, s, u);
+    fp6_sub(t, t, v0);
+    fp6_sub(r.c1, t, v1);
+    fp6_mul_v(t, v1);
+    fp6_add(r.c0, v0, t);
+}
+template <class T>
+KYB_HD void fp12_sqr(Fp12<T>& r, const Fp12<T>& a) {
+    // complex squaring: 2 Fp6 multiplications
+    Fp6<T> ab, s, u, t;
+    fp6_mul(ab, a.c0, a.c1);
+    fp6_add(s, a.c0, a.c1);
+    fp6_mul_v(t, a.c1);
+    fp6_add(u, a.c0, t);
+    fp6_mul(s, s, u);  // (a0 + a1)(a0 + v a1) = a0^2 + v a1^2 + (1 + v) a0 a1
+    fp6_sub(s, s, ab);
+    fp6_mul_v(t, ab);
+    fp6_sub(r.c0, s, t);
+    fp6_add(r.c1, ab, ab);
+}
+template <class T>
+KYB_HD void fp12_inv(Fp12<T>& r, const Fp12<T>& a) {
+    Fp6<T> t0, t1;
+    fp6_sqr(t0, a.c0);
+    fp6_sqr(t1, a.c1);
+    fp6_mul_v(t1, t1);
+    fp6_sub(t0, t0, t1);
+    fp6_inv(t0, t0);
+    fp6_mul(r.c0, a.c0, t0);
+    fp6_mul(t1, a.c1, t0);
+    fp6_neg(r.c1, t1);
+}
+// f * (o0 + o1 v + o4 v w): the sparse line value of an M-type twist (BLS12-381); 13 Fp2 mults
+template <class T>
+KYB_HD void fp12_mul_by_014(Fp12<T>& f, const Fp2<T>& o0, const Fp2<T>& o1, const Fp2<T>& o4) {
+    Fp6<T> aa, bb, s, t;
+    Fp2<T> o;
+    fp6_mul_by_01(aa, f.c0, o0, o1);
+    fp6_mul_by_1(bb, f.c1, o4);
+    fp2_add(o, o1, o4);
+    fp6_add(s, f.c1, f.c0);
+    fp6_mul_by_01(t, s, o0, o);
+    fp6_sub(t, t, aa);
+    fp6_sub(f.c1, t, bb);
+    fp6_mul_v(t, bb);
+    fp6_add(f.c0, t, aa);
+}
+
+// w-basis coefficient j of an Fp12 element: a = sum_j coeff_j w^j
+template <class T>
+KYB_HD Fp2<T>& fp12_coeff(Fp12<T>& a, int j) {
+    Fp6<T>& h = (j & 1) ? a.c1 : a.c0;
+    return (j >> 1) == 0 ? h.c0 : ((j >> 1) == 1 ? h.c1 : h.c2);
+}
+template <class T>
+KYB_HD void fp2_load_const(Fp2<T>& r, const uint32_t (&c)[2][T::F::N]) {
+#pragma unroll
+    for (int l = 0; l < T::F::N; l++) {
+        r.c0.v[l] = c[0][l];
+        r.c1.v[l] = c[1][l];
+    }
+}
+// r = a^(p^K), K = 1, 2, 3
+template <class T, int K>
+KYB_HD void fp12_frob(Fp12<T>& r, const Fp12<T>& a) {
+    Fp12<T> x = a;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        Fp2<T>& c = fp12_coeff(x, j);
+        if (K & 1) fp2_conj(c, c);
+        if (j > 0) {
+            Fp2<T> g;
+            fp2_load_const<T>(g, T::FROB[K - 1][j]);
+            fp2_mul(c, c, g);
+        }
+    }
+    r = x;
+}
+// Squaring in the cyclotomic subgroup (after the easy part of the final exponentiation).
+template <class T>
+KYB_HD void fp12_cyclo_sqr(Fp12<T>& r, const Fp12<T>& a) {
+    fp12_sqr(r, a);
+}
+
+}  // namespace kyb

@@ -1,0 +1,53 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into libkyberhip.so.
+// Compiles the device arithmetic headers (kyber_amd/csrc/*.cuh) for the host CPU with g++, so the
+// exact field / tower / curve / pairing code the HIP kernels run per lane can be diffed against
+// the big-integer oracle in this GPU-less container (tests/test_host_harness.py).
+#include <stdint.h>
+#include <string.h>
+
+#include "../kyber_amd/csrc/bls12381.cuh"
+
+using namespace kyb;
+
+extern "C" {
+
+// canonical big-endian in/out through the Montgomery domain
+void hh_bls_fp_op(int op, const uint8_t* a48, const uint8_t* b48, uint8_t* out48) {
+    uint32_t wa[12], wb[12], wo[12];
+    words_from_be<12>(wa, a48);
+    words_from_be<12>(wb, b48);
+    bls::fp a, b, r;
+    fp_from_words<bls::FC>(a, wa);
+    fp_from_words<bls::FC>(b, wb);
+    switch (op) {
+        case 0: fp_mul(r, a, b); break;
+        case 1: fp_add(r, a, b); break;
+        case 2: fp_sub(r, a, b); break;
+        case 3: fp_neg(r, a); break;
+        case 4: fp_inv(r, a); break;
+        default: fp_sqr(r, a); break;
+    }
+    fp_to_words<bls::FC>(wo, r);
+    words_to_be<12>(out48, wo);
+}
+int hh_bls_g1_decode(const uint8_t* in, int check) { bls::g1_aff a; return bls::g1_decode(a, in, check != 0); }
+int hh_bls_g2_decode(const uint8_t* in, int check) { bls::g2_aff a; return bls::g2_decode(a, in, check != 0); }
+int hh_bls_g1_recode(const uint8_t* in, uint8_t* out) {
+    bls::g1_aff a;
+    int st = bls::g1_decode(a, in, false);
+    bls::g1_encode(out, a);
+    return st;
+}
+int hh_bls_g2_recode(const uint8_t* in, uint8_t* out) {
+    bls::g2_aff a;
+    int st = bls::g2_decode(a, in, false);
+    bls::g2_encode(out, a);
+    return st;
+}
+int hh_bls_g1_mul(const uint8_t* k, const uint8_t* pt, uint8_t* out) { return bls::g1_mul_wire(out, k, pt); }
+int hh_bls_g2_mul(const uint8_t* k, const uint8_t* pt, uint8_t* out) { return bls::g2_mul_wire(out, k, pt); }
+int hh_bls_pair(const uint8_t* g1, const uint8_t* g2, uint8_t* gt) { return bls::pair_wire(gt, g1, g2); }
+int hh_bls_pair_check(const uint8_t* p1, const uint8_t* p2, const uint8_t* i1, const uint8_t* i2, uint8_t* ok) {
+    return bls::pair_check_wire(ok, p1, p2, i1, i2);
+}
+}

@@ -1,0 +1,90 @@
+"""Pin the BLS12-381 oracle (oracle/bls12381.py) against what the reference's own tests hold for this
+path: the ZCash deserialisation fixtures (bls12381_test.go:74-186) and the algebraic identities of
+bls12381_test.go:424-474,580-630."""
+import json
+import os
+import random
+
+import pytest
+
+from oracle import bls12381 as O
+
+
+def _fixtures(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "bls12381_zcash.json")))
+
+
+def test_generators_and_orders():
+    assert O.g1_on_curve(O.G1_GEN) and O.g2_on_curve(O.G2_GEN)
+    assert O.g1_in_subgroup(O.G1_GEN) and O.g2_in_subgroup(O.G2_GEN)
+    assert O.g1_mul(O.R - 1, O.G1_GEN) == O.g1_neg(O.G1_GEN)
+
+
+def test_zcash_g1(golden_dir):
+    for e in _fixtures(golden_dir)["G1"]:
+        buf = bytes.fromhex(e["hex"])
+        try:
+            p = O.g1_decompress(buf)
+            ok = True
+        except O.DecodeError:
+            ok = False
+        assert ok == e["valid"], e["name"]
+        if ok:
+            assert O.g1_compress(p) == buf, e["name"]
+
+
+def test_zcash_g2(golden_dir):
+    for e in _fixtures(golden_dir)["G2"]:
+        buf = bytes.fromhex(e["hex"])
+        try:
+            p = O.g2_decompress(buf)
+            ok = True
+        except O.DecodeError:
+            ok = False
+        assert ok == e["valid"], e["name"]
+        if ok:
+            assert O.g2_compress(p) == buf, e["name"]
+
+
+def test_compress_roundtrip_and_homomorphism():
+    rng = random.Random(7)
+    for _ in range(4):
+        a, b = rng.randrange(O.R), rng.randrange(O.R)
+        A, B = O.g1_mul(a, O.G1_GEN), O.g1_mul(b, O.G1_GEN)
+        assert O.g1_decompress(O.g1_compress(A)) == A
+        assert O.g1_add(A, B) == O.g1_mul((a + b) % O.R, O.G1_GEN)
+        A2, B2 = O.g2_mul(a, O.G2_GEN), O.g2_mul(b, O.G2_GEN)
+        assert O.g2_decompress(O.g2_compress(A2)) == A2
+        assert O.g2_add(A2, B2) == O.g2_mul((a + b) % O.R, O.G2_GEN)
+
+
+def test_frobenius_constants():
+    # f12_frob must equal the generic p-th power
+    rng = random.Random(3)
+    a = [(rng.randrange(O.P), rng.randrange(O.P)) for _ in range(6)]
+    assert O.f12_frob(a) == O.f12_pow(a, O.P)
+    assert O.f12_mul(a, O.f12_inv(a)) == O.F12_ONE
+
+
+def test_pairing_bilinear_and_order():
+    rng = random.Random(11)
+    a, b = rng.randrange(1, O.R), rng.randrange(1, O.R)
+    e = O.pair(O.G1_GEN, O.G2_GEN)
+    assert e != O.F12_ONE
+    assert O.f12_pow(e, O.R) == O.F12_ONE
+    lhs = O.pair(O.g1_mul(a, O.G1_GEN), O.g2_mul(b, O.G2_GEN))
+    assert lhs == O.f12_pow(e, a * b % O.R)
+    assert lhs == O.pair(O.g1_mul(a * b % O.R, O.G1_GEN), O.G2_GEN)
+
+
+def test_pair_check_truth_table():
+    rng = random.Random(5)
+    x, h = rng.randrange(1, O.R), rng.randrange(1, O.R)
+    H = O.g1_mul(h, O.G1_GEN)  # "hashed message"
+    X = O.g2_mul(x, O.G2_GEN)  # public key
+    sig = O.g1_mul(x, H)
+    # bls.Verify: e(H, X) == e(sig, G2)   (sign/bls/bls.go:36-38)
+    assert O.pair_check(H, X, sig, O.G2_GEN)
+    assert not O.pair_check(H, X, O.g1_add(sig, O.G1_GEN), O.G2_GEN)
+    assert O.pair_check(None, X, None, O.G2_GEN)
+    assert len(O.gt_to_bytes(O.pair(H, X))) == 576
