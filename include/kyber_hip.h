@@ -84,6 +84,45 @@ int kyb_ed25519_mul_same_base(size_t n, const uint8_t *scalars, const uint8_t po
  * (33 x 8 entries of (y+x, y-x, 2dxy), 10 int32 limbs each) to the host. */
 int kyb_ed25519_debug_base_table(int32_t *out /* 33*8*30 */);
 
+/* --------------------------------------------------------------- BLS12-381
+ * The three reference suites pairing/bls12381/{kilic,circl,gnark} are adapters over external
+ * modules (go.mod:6-8); their MarshalBinary wire formats are identical and are what crosses
+ * this boundary:
+ *   scalars : 32-byte big-endian (mod.Int, group/mod/int.go:334-350; kilic/scalar.go), taken as
+ *             plain 256-bit integers
+ *   G1      : 48-byte ZCash compressed (kilic/g1.go:119-131)      G2 : 96-byte (kilic/g2.go)
+ *   GT      : 576 bytes (kilic/gt.go:115-117); layout documented in DESIGN.md (parity unpinned
+ *             by the reference)
+ * UnmarshalBinary semantics: flag rules + on-curve + subgroup membership, exactly the cases of
+ * pairing/bls12381/deserialization_tests (bls12381_test.go:74-186).  A rejected input gives
+ * status KYB_ST_BAD_POINT / KYB_ST_NOT_IN_SUBGROUP and an all-zero output element.          */
+
+/* out[i] = scalars[i] * points[i].  Replaces G1Elt.UnmarshalBinary + Mul + MarshalBinary
+ * (pairing/bls12381/kilic/g1.go:110-131; circl/g1.go:89-96; gnark/g1.go:118-127). */
+int kyb_bls12381_g1_mul(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status);
+/* same on G2 (kilic/g2.go; this is what suite.Point().Mul is for the *.adapter suites) */
+int kyb_bls12381_g2_mul(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status);
+/* out[i] = scalars[i] * point: the loop of share.PriPoly.Commit (share/poly.go:143-149). */
+int kyb_bls12381_g1_mul_same_base(size_t n, const uint8_t *scalars, const uint8_t point[48], uint8_t *out,
+                                  uint8_t *status);
+int kyb_bls12381_g2_mul_same_base(size_t n, const uint8_t *scalars, const uint8_t point[96], uint8_t *out,
+                                  uint8_t *status);
+/* point_stride: 48 / 96 for per-element points, 0 for one shared base point */
+int kyb_bls12381_g1_mul_dev(size_t n, const void *d_scalars, const void *d_points, size_t point_stride, void *d_out,
+                            void *d_status, void *stream);
+int kyb_bls12381_g2_mul_dev(size_t n, const void *d_scalars, const void *d_points, size_t point_stride, void *d_out,
+                            void *d_status, void *stream);
+
+/* gt[i] = e(g1[i], g2[i]).  Replaces Suite.Pair (pairing/pairing.go:12; kilic/suite.go:70-75). */
+int kyb_bls12381_pair(size_t n, const uint8_t *g1, const uint8_t *g2, uint8_t *gt, uint8_t *status);
+int kyb_bls12381_pair_dev(size_t n, const void *d_g1, const void *d_g2, void *d_gt, void *d_status, void *stream);
+/* ok[i] = (e(p1[i], p2[i]) == e(inv1[i], inv2[i])).  Replaces Suite.ValidatePairing
+ * (pairing/pairing.go:13-15; kilic/suite.go:57-68), the core of sign/bls Verify (bls.go:82-96). */
+int kyb_bls12381_pair_check(size_t n, const uint8_t *p1, const uint8_t *p2, const uint8_t *inv1, const uint8_t *inv2,
+                            uint8_t *ok, uint8_t *status);
+int kyb_bls12381_pair_check_dev(size_t n, const void *d_p1, const void *d_p2, const void *d_inv1, const void *d_inv2,
+                                void *d_ok, void *d_status, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

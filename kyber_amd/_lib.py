@@ -34,6 +34,16 @@ SIGNATURES = {
     "kyb_ed25519_mul_dev": [_sz, _vp, _vp, _vp, _vp, _u32, _vp],
     "kyb_ed25519_mul_same_base": [_sz, _vp, _vp, _vp, _vp, _u32],
     "kyb_ed25519_debug_base_table": [_vp],
+    "kyb_bls12381_g1_mul": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_bls12381_g2_mul": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_bls12381_g1_mul_same_base": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_bls12381_g2_mul_same_base": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_bls12381_g1_mul_dev": [_sz, _vp, _vp, _sz, _vp, _vp, _vp],
+    "kyb_bls12381_g2_mul_dev": [_sz, _vp, _vp, _sz, _vp, _vp, _vp],
+    "kyb_bls12381_pair": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_bls12381_pair_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
+    "kyb_bls12381_pair_check": [_sz, _vp, _vp, _vp, _vp, _vp, _vp],
+    "kyb_bls12381_pair_check_dev": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 _RESTYPES = {"kyb_last_error": C.c_char_p}
 

@@ -46,7 +46,7 @@ KYB_HD bool fp2_is_larger(const fp2& y) {
 
 // ------------------------------------------------------------- subgroup checks
 // G1: P has order r  <=>  phi(P) = [-x^2] P, phi(x, y) = (beta x, y)   (Scott, eprint 2021/1130)
-KYB_HD bool g1_in_subgroup(const g1_aff& a) {
+KYB_HD_NOINLINE bool g1_in_subgroup(const g1_aff& a) {
     g1_jac p, q;
     jac_from_aff(p, a);
     jac_mul_u64(q, p, CC::X_ABS);
@@ -64,7 +64,7 @@ KYB_HD bool g1_in_subgroup(const g1_aff& a) {
     return a.inf | ok;
 }
 // G2: psi(Q) = [x] Q, psi = twist o Frobenius o untwist
-KYB_HD bool g2_in_subgroup(const g2_aff& a) {
+KYB_HD_NOINLINE bool g2_in_subgroup(const g2_aff& a) {
     g2_jac p, q;
     jac_from_aff(p, a);
     jac_mul_u64(q, p, CC::X_ABS);  // |x| Q ; need psi(Q) = -q
@@ -86,7 +86,7 @@ KYB_HD bool g2_in_subgroup(const g2_aff& a) {
 
 // ------------------------------------------------------------------ decoding
 // 48-byte ZCash compressed G1 (kilic/g1.go:127-131 FromCompressed + subgroup check).
-KYB_HD int g1_decode(g1_aff& a, const uint8_t* in, bool check_subgroup) {
+KYB_HD_NOINLINE int g1_decode(g1_aff& a, const uint8_t* in, bool check_subgroup) {
     uint32_t w[12];
     words_from_be<12>(w, in);
     const uint32_t top = w[11] >> 29;
@@ -120,7 +120,7 @@ KYB_HD int g1_decode(g1_aff& a, const uint8_t* in, bool check_subgroup) {
 }
 
 // Square root in Fp2 (p = 3 mod 4) with two base-field exponentiations; false if none exists.
-KYB_HD bool fp2_sqrt(fp2& r, const fp2& a) {
+KYB_HD_NOINLINE bool fp2_sqrt(fp2& r, const fp2& a) {
     fp n, s, t, u, c, c2, h, inv2;
     fp_const(inv2, FC::INV2);
     fp_sqr(n, a.c0);
@@ -151,7 +151,7 @@ KYB_HD bool fp2_sqrt(fp2& r, const fp2& a) {
 }
 
 // 96-byte ZCash compressed G2: x.c1 || x.c0 big-endian, flags in the first byte.
-KYB_HD int g2_decode(g2_aff& a, const uint8_t* in, bool check_subgroup) {
+KYB_HD_NOINLINE int g2_decode(g2_aff& a, const uint8_t* in, bool check_subgroup) {
     uint32_t w1[12], w0[12];
     words_from_be<12>(w1, in);
     words_from_be<12>(w0, in + 48);
@@ -185,7 +185,7 @@ KYB_HD int g2_decode(g2_aff& a, const uint8_t* in, bool check_subgroup) {
 }
 
 // ------------------------------------------------------------------ encoding
-KYB_HD void g1_encode(uint8_t* out, const g1_aff& a) {
+KYB_HD_NOINLINE void g1_encode(uint8_t* out, const g1_aff& a) {
     uint32_t w[12];
     fp_to_words<FC>(w, a.x);
     uint32_t flags = 0x80000000u | (fp_is_larger(a.y) ? 0x20000000u : 0u);
@@ -197,7 +197,7 @@ KYB_HD void g1_encode(uint8_t* out, const g1_aff& a) {
     w[11] |= flags;
     words_to_be<12>(out, w);
 }
-KYB_HD void g2_encode(uint8_t* out, const g2_aff& a) {
+KYB_HD_NOINLINE void g2_encode(uint8_t* out, const g2_aff& a) {
     uint32_t w1[12], w0[12];
     fp_to_words<FC>(w1, a.x.c1);
     fp_to_words<FC>(w0, a.x.c0);
@@ -212,7 +212,7 @@ KYB_HD void g2_encode(uint8_t* out, const g2_aff& a) {
     words_to_be<12>(out + 48, w0);
 }
 // 576 bytes: Fp12.c1 then c0; within Fp6 c2, c1, c0; within Fp2 c1, c0; big-endian (oracle gt_to_bytes)
-KYB_HD void gt_encode(uint8_t* out, const fp12& f) {
+KYB_HD_NOINLINE void gt_encode(uint8_t* out, const fp12& f) {
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const fp6& s = h == 0 ? f.c1 : f.c0;
@@ -234,7 +234,7 @@ KYB_HD void scalar_from_be(uint32_t (&k)[8], const uint8_t* in) { words_from_be<
 // One step of the Miller loop works on T in Jacobian coordinates on the twist and returns the
 // line through T (tangent, or chord to Q) evaluated at P as the sparse element
 //   o0 + (o1 xP) v + (o4 yP) v w       (w-basis positions 0, 2, 3), scaled by a factor in Fp2.
-KYB_HD void miller_dbl_step(fp12& f, g2_jac& t, const fp& xp, const fp& yp) {
+KYB_HD_NOINLINE void miller_dbl_step(fp12& f, g2_jac& t, const fp& xp, const fp& yp) {
     fp2 A, B, C, D, E, G, Z2, o0, o1, o4, u;
     fp2_sqr(A, t.X);
     fp2_sqr(B, t.Y);
@@ -273,7 +273,7 @@ KYB_HD void miller_dbl_step(fp12& f, g2_jac& t, const fp& xp, const fp& yp) {
     fp12_sqr(f, f);
     fp12_mul_by_014(f, o0, o1, o4);
 }
-KYB_HD void miller_add_step(fp12& f, g2_jac& t, const g2_aff& q, const fp& xp, const fp& yp) {
+KYB_HD_NOINLINE void miller_add_step(fp12& f, g2_jac& t, const g2_aff& q, const fp& xp, const fp& yp) {
     fp2 Z2, U2, S2, H, rr, Z3, o0, o1, o4, HH, HHH, V, u;
     fp2_sqr(Z2, t.Z);
     fp2_mul(U2, q.x, Z2);
@@ -307,7 +307,7 @@ KYB_HD void miller_add_step(fp12& f, g2_jac& t, const g2_aff& q, const fp& xp, c
     t.Z = Z3;
 }
 // f_{|x|,Q}(P), conjugated because x < 0.  P or Q at infinity gives one.
-KYB_HD void miller_loop(fp12& f, const g1_aff& p, const g2_aff& q) {
+KYB_HD_NOINLINE void miller_loop(fp12& f, const g1_aff& p, const g2_aff& q) {
     fp12_one(f);
     g2_jac t;
     jac_from_aff(t, q);
@@ -320,7 +320,7 @@ KYB_HD void miller_loop(fp12& f, const g1_aff& p, const g2_aff& q) {
     if (p.inf | q.inf) fp12_one(f);
 }
 // a^|x| then conjugate (x < 0); a in the cyclotomic subgroup
-KYB_HD void cyclo_pow_x(fp12& r, const fp12& a) {
+KYB_HD_NOINLINE void cyclo_pow_x(fp12& r, const fp12& a) {
     fp12 acc = a;
 #pragma unroll 1
     for (int i = 62; i >= 0; i--) {
@@ -329,7 +329,7 @@ KYB_HD void cyclo_pow_x(fp12& r, const fp12& a) {
     }
     fp12_conj(r, acc);
 }
-KYB_HD void cyclo_pow_words(fp12& r, const fp12& a, const uint32_t* e, int nbits) {
+KYB_HD_NOINLINE void cyclo_pow_words(fp12& r, const fp12& a, const uint32_t* e, int nbits) {
     fp12 acc = a;
 #pragma unroll 1
     for (int i = nbits - 2; i >= 0; i--) {
@@ -341,7 +341,7 @@ KYB_HD void cyclo_pow_words(fp12& r, const fp12& a, const uint32_t* e, int nbits
 // f^((p^12 - 1) / r), the canonical reduced pairing exponent.
 // Hard part: (p^4 - p^2 + 1)/r = l0 + l1 p + l2 p^2 + l3 p^3 with l3 = (x-1)^2/3, l2 = x l3,
 // l1 = x l2 - l3, l0 = x l1 + 1 (checked in gen_consts.py).
-KYB_HD void final_exp(fp12& r, const fp12& f) {
+KYB_HD_NOINLINE void final_exp(fp12& r, const fp12& f) {
     fp12 g, t, t3, t2, t1, t0;
     fp12_conj(g, f);
     fp12_inv(t, f);

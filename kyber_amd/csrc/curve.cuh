@@ -65,7 +65,7 @@ template <class F> KYB_HD void jac_neg(Jac<F>& r, const Jac<F>& p) { r.X = p.X; 
 
 // dbl-2009-l (a = 0): 2M + 5S.  Maps infinity to infinity and 2-torsion points (Y = 0) to infinity.
 template <class F>
-KYB_HD void jac_dbl(Jac<F>& r, const Jac<F>& p) {
+KYB_HD_NOINLINE void jac_dbl(Jac<F>& r, const Jac<F>& p) {
     F A, B, C, D, E, G, t;
     f_sqr(A, p.X);
     f_sqr(B, p.Y);
@@ -92,7 +92,7 @@ KYB_HD void jac_dbl(Jac<F>& r, const Jac<F>& p) {
 
 // add-2007-bl with the exceptional cases handled (either operand infinity, P = Q, P = -Q).
 template <class F>
-KYB_HD void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
+KYB_HD_NOINLINE void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
     const bool pinf = jac_is_inf(p), qinf = jac_is_inf(q);
     F Z1Z1, Z2Z2, U1, U2, S1, S2, H, I, J, rr, V, t;
     f_sqr(Z1Z1, p.Z);
@@ -155,7 +155,7 @@ KYB_HD void recode16_u256(int8_t (&e)[65], const uint32_t (&k)[8]) {
 // r = k * p, k a plain 256-bit integer (eight little-endian words).  Uniform control flow: every
 // window does 4 doublings and one addition whose result is kept only when the digit is non-zero.
 template <class F>
-KYB_HD void jac_mul_u256(Jac<F>& r, const Jac<F>& p, const uint32_t (&k)[8]) {
+KYB_HD_NOINLINE void jac_mul_u256(Jac<F>& r, const Jac<F>& p, const uint32_t (&k)[8]) {
     Jac<F> tab[8];  // (j + 1) * p
     tab[0] = p;
     jac_dbl(tab[1], p);
@@ -186,7 +186,7 @@ KYB_HD void jac_mul_u256(Jac<F>& r, const Jac<F>& p, const uint32_t (&k)[8]) {
 }
 // Short public multiplier (e.g. the curve parameter |x|), MSB-first double-and-add; uniform.
 template <class F>
-KYB_HD void jac_mul_u64(Jac<F>& r, const Jac<F>& p, uint64_t k) {
+KYB_HD_NOINLINE void jac_mul_u64(Jac<F>& r, const Jac<F>& p, uint64_t k) {
     Jac<F> acc;
     jac_set_inf(acc);
 #pragma unroll 1
@@ -198,7 +198,7 @@ KYB_HD void jac_mul_u64(Jac<F>& r, const Jac<F>& p, uint64_t k) {
 }
 
 template <class F>
-KYB_HD void jac_to_aff(Aff<F>& a, const Jac<F>& p) {
+KYB_HD_NOINLINE void jac_to_aff(Aff<F>& a, const Jac<F>& p) {
     a.inf = jac_is_inf(p);
     F zi, zi2;
     f_inv(zi, p.Z);

@@ -183,7 +183,7 @@ KYB_HD void fp_mul3(Fp<C>& r, const Fp<C>& a) {
 
 // r = a^e for a public exponent held as NW little-endian 32-bit words (uniform control flow).
 template <class C>
-KYB_HD void fp_pow_words(Fp<C>& r, const Fp<C>& a, const uint32_t* e, int nbits) {
+KYB_HD_NOINLINE void fp_pow_words(Fp<C>& r, const Fp<C>& a, const uint32_t* e, int nbits) {
     Fp<C> acc;
     fp_one(acc);
 #pragma unroll 1
@@ -236,7 +236,7 @@ KYB_HD bool fp_words_lt_p(const uint32_t (&w)[C::NWORDS]) {
 }
 // plain integer words (must be < p) -> Montgomery element
 template <class C>
-KYB_HD void fp_from_words(Fp<C>& r, const uint32_t (&w)[C::NWORDS]) {
+KYB_HD_NOINLINE void fp_from_words(Fp<C>& r, const uint32_t (&w)[C::NWORDS]) {
     Fp<C> raw, r2;
     fp_limbs_from_words<C>(raw.v, w);
 #pragma unroll
@@ -245,7 +245,7 @@ KYB_HD void fp_from_words(Fp<C>& r, const uint32_t (&w)[C::NWORDS]) {
 }
 // Montgomery element -> canonical plain integer words
 template <class C>
-KYB_HD void fp_to_words(uint32_t (&w)[C::NWORDS], const Fp<C>& a) {
+KYB_HD_NOINLINE void fp_to_words(uint32_t (&w)[C::NWORDS], const Fp<C>& a) {
     Fp<C> one_raw, c;
     fp_zero(one_raw);
     one_raw.v[0] = 1;

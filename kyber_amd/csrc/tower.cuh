@@ -35,15 +35,15 @@ template <class T> KYB_HD void fp2_one(Fp2<T>& r) { fp_one(r.c0); fp_zero(r.c1);
 template <class T> KYB_HD bool fp2_is_zero(const Fp2<T>& a) { return fp_is_zero(a.c0) & fp_is_zero(a.c1); }
 template <class T> KYB_HD bool fp2_eq(const Fp2<T>& a, const Fp2<T>& b) { return fp_eq(a.c0, b.c0) & fp_eq(a.c1, b.c1); }
 template <class T> KYB_HD void fp2_cmov(Fp2<T>& r, const Fp2<T>& a, bool c) { fp_cmov(r.c0, a.c0, c); fp_cmov(r.c1, a.c1, c); }
-template <class T> KYB_HD void fp2_add(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) { fp_add(r.c0, a.c0, b.c0); fp_add(r.c1, a.c1, b.c1); }
-template <class T> KYB_HD void fp2_sub(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) { fp_sub(r.c0, a.c0, b.c0); fp_sub(r.c1, a.c1, b.c1); }
-template <class T> KYB_HD void fp2_dbl(Fp2<T>& r, const Fp2<T>& a) { fp_dbl(r.c0, a.c0); fp_dbl(r.c1, a.c1); }
-template <class T> KYB_HD void fp2_neg(Fp2<T>& r, const Fp2<T>& a) { fp_neg(r.c0, a.c0); fp_neg(r.c1, a.c1); }
+template <class T> KYB_HD_NOINLINE void fp2_add(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) { fp_add(r.c0, a.c0, b.c0); fp_add(r.c1, a.c1, b.c1); }
+template <class T> KYB_HD_NOINLINE void fp2_sub(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) { fp_sub(r.c0, a.c0, b.c0); fp_sub(r.c1, a.c1, b.c1); }
+template <class T> KYB_HD_NOINLINE void fp2_dbl(Fp2<T>& r, const Fp2<T>& a) { fp_dbl(r.c0, a.c0); fp_dbl(r.c1, a.c1); }
+template <class T> KYB_HD_NOINLINE void fp2_neg(Fp2<T>& r, const Fp2<T>& a) { fp_neg(r.c0, a.c0); fp_neg(r.c1, a.c1); }
 template <class T> KYB_HD void fp2_conj(Fp2<T>& r, const Fp2<T>& a) { r.c0 = a.c0; fp_neg(r.c1, a.c1); }
 
 // Karatsuba: 3 base-field multiplications
 template <class T>
-KYB_HD void fp2_mul(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) {
+KYB_HD_NOINLINE void fp2_mul(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) {
     Fp<typename T::F> t0, t1, t2, s0, s1;
     fp_mul(t0, a.c0, b.c0);
     fp_mul(t1, a.c1, b.c1);
@@ -56,7 +56,7 @@ KYB_HD void fp2_mul(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) {
 }
 // (c0 + c1)(c0 - c1), 2 c0 c1: 2 base-field multiplications
 template <class T>
-KYB_HD void fp2_sqr(Fp2<T>& r, const Fp2<T>& a) {
+KYB_HD_NOINLINE void fp2_sqr(Fp2<T>& r, const Fp2<T>& a) {
     Fp<typename T::F> s, d, m;
     fp_add(s, a.c0, a.c1);
     fp_sub(d, a.c0, a.c1);
@@ -66,13 +66,13 @@ KYB_HD void fp2_sqr(Fp2<T>& r, const Fp2<T>& a) {
 }
 // by an element of the base field
 template <class T>
-KYB_HD void fp2_mul_fp(Fp2<T>& r, const Fp2<T>& a, const Fp<typename T::F>& b) {
+KYB_HD_NOINLINE void fp2_mul_fp(Fp2<T>& r, const Fp2<T>& a, const Fp<typename T::F>& b) {
     fp_mul(r.c0, a.c0, b);
     fp_mul(r.c1, a.c1, b);
 }
 // r = a * xi, xi = XI0 + i:  (XI0 a0 - a1) + (a0 + XI0 a1) i
 template <class T>
-KYB_HD void fp2_mul_xi(Fp2<T>& r, const Fp2<T>& a) {
+KYB_HD_NOINLINE void fp2_mul_xi(Fp2<T>& r, const Fp2<T>& a) {
     Fp<typename T::F> x0 = a.c0, x1 = a.c1, t0 = a.c0, t1 = a.c1;
 #pragma unroll
     for (int k = 1; k < T::XI0; k++) {
@@ -83,7 +83,7 @@ KYB_HD void fp2_mul_xi(Fp2<T>& r, const Fp2<T>& a) {
     fp_add(r.c1, t1, x0);
 }
 template <class T>
-KYB_HD void fp2_inv(Fp2<T>& r, const Fp2<T>& a) {
+KYB_HD_NOINLINE void fp2_inv(Fp2<T>& r, const Fp2<T>& a) {
     Fp<typename T::F> n, t;
     fp_sqr(n, a.c0);
     fp_sqr(t, a.c1);
@@ -112,7 +112,7 @@ KYB_HD void fp6_mul_v(Fp6<T>& r, const Fp6<T>& a) {
 }
 // Karatsuba, 6 Fp2 multiplications
 template <class T>
-KYB_HD void fp6_mul(Fp6<T>& r, const Fp6<T>& a, const Fp6<T>& b) {
+KYB_HD_NOINLINE void fp6_mul(Fp6<T>& r, const Fp6<T>& a, const Fp6<T>& b) {
     Fp2<T> v0, v1, v2, s, u, t0, t1, t2;
     fp2_mul(v0, a.c0, b.c0);
     fp2_mul(v1, a.c1, b.c1);
@@ -142,7 +142,7 @@ KYB_HD void fp6_mul(Fp6<T>& r, const Fp6<T>& a, const Fp6<T>& b) {
     r.c2 = t2;
 }
 template <class T>
-KYB_HD void fp6_sqr(Fp6<T>& r, const Fp6<T>& a) {
+KYB_HD_NOINLINE void fp6_sqr(Fp6<T>& r, const Fp6<T>& a) {
     // Chung-Hasan SQR2: 2 multiplications + 3 squarings in Fp2
     Fp2<T> s0, s1, s2, s3, s4, t;
     fp2_sqr(s0, a.c0);
@@ -166,7 +166,7 @@ KYB_HD void fp6_sqr(Fp6<T>& r, const Fp6<T>& a) {
 }
 // a * (b0 + b1 v)   -- 5 Fp2 multiplications
 template <class T>
-KYB_HD void fp6_mul_by_01(Fp6<T>& r, const Fp6<T>& a, const Fp2<T>& b0, const Fp2<T>& b1) {
+KYB_HD_NOINLINE void fp6_mul_by_01(Fp6<T>& r, const Fp6<T>& a, const Fp2<T>& b0, const Fp2<T>& b1) {
     Fp2<T> v0, v1, t0, t1, t2, s, u;
     fp2_mul(v0, a.c0, b0);
     fp2_mul(v1, a.c1, b1);
@@ -186,7 +186,7 @@ KYB_HD void fp6_mul_by_01(Fp6<T>& r, const Fp6<T>& a, const Fp2<T>& b0, const Fp
 }
 // a * (b1 v)   -- 3 Fp2 multiplications
 template <class T>
-KYB_HD void fp6_mul_by_1(Fp6<T>& r, const Fp6<T>& a, const Fp2<T>& b1) {
+KYB_HD_NOINLINE void fp6_mul_by_1(Fp6<T>& r, const Fp6<T>& a, const Fp2<T>& b1) {
     Fp2<T> t0, t1, t2;
     fp2_mul(t0, a.c2, b1);
     fp2_mul_xi(t0, t0);
@@ -203,7 +203,7 @@ KYB_HD void fp6_mul_fp2(Fp6<T>& r, const Fp6<T>& a, const Fp2<T>& b) {
     fp2_mul(r.c2, a.c2, b);
 }
 template <class T>
-KYB_HD void fp6_inv(Fp6<T>& r, const Fp6<T>& a) {
+KYB_HD_NOINLINE void fp6_inv(Fp6<T>& r, const Fp6<T>& a) {
     Fp2<T> t0, t1, t2, d, s;
     fp2_sqr(t0, a.c0);
     fp2_mul(s, a.c1, a.c2);
@@ -239,7 +239,7 @@ KYB_HD bool fp12_is_one(const Fp12<T>& a) {
     return fp12_eq(a, o);
 }
 template <class T>
-KYB_HD void fp12_mul(Fp12<T>& r, const Fp12<T>& a, const Fp12<T>& b) {
+KYB_HD_NOINLINE void fp12_mul(Fp12<T>& r, const Fp12<T>& a, const Fp12<T>& b) {
     Fp6<T> v0, v1, s, u, t;
     fp6_mul(v0, a.c0, b.c0);
     fp6_mul(v1, a.c1, b.c1);
@@ -252,7 +252,7 @@ KYB_HD void fp12_mul(Fp12<T>& r, const Fp12<T>& a, const Fp12<T>& b) {
     fp6_add(r.c0, v0, t);
 }
 template <class T>
-KYB_HD void fp12_sqr(Fp12<T>& r, const Fp12<T>& a) {
+KYB_HD_NOINLINE void fp12_sqr(Fp12<T>& r, const Fp12<T>& a) {
     // complex squaring: 2 Fp6 multiplications
     Fp6<T> ab, s, u, t;
     fp6_mul(ab, a.c0, a.c1);
@@ -266,7 +266,7 @@ KYB_HD void fp12_sqr(Fp12<T>& r, const Fp12<T>& a) {
     fp6_add(r.c1, ab, ab);
 }
 template <class T>
-KYB_HD void fp12_inv(Fp12<T>& r, const Fp12<T>& a) {
+KYB_HD_NOINLINE void fp12_inv(Fp12<T>& r, const Fp12<T>& a) {
     Fp6<T> t0, t1;
     fp6_sqr(t0, a.c0);
     fp6_sqr(t1, a.c1);
@@ -279,7 +279,7 @@ KYB_HD void fp12_inv(Fp12<T>& r, const Fp12<T>& a) {
 }
 // f * (o0 + o1 v + o4 v w): the sparse line value of an M-type twist (BLS12-381); 13 Fp2 mults
 template <class T>
-KYB_HD void fp12_mul_by_014(Fp12<T>& f, const Fp2<T>& o0, const Fp2<T>& o1, const Fp2<T>& o4) {
+KYB_HD_NOINLINE void fp12_mul_by_014(Fp12<T>& f, const Fp2<T>& o0, const Fp2<T>& o1, const Fp2<T>& o4) {
     Fp6<T> aa, bb, s, t;
     Fp2<T> o;
     fp6_mul_by_01(aa, f.c0, o0, o1);
@@ -309,7 +309,7 @@ KYB_HD void fp2_load_const(Fp2<T>& r, const uint32_t (&c)[2][T::F::N]) {
 }
 // r = a^(p^K), K = 1, 2, 3
 template <class T, int K>
-KYB_HD void fp12_frob(Fp12<T>& r, const Fp12<T>& a) {
+KYB_HD_NOINLINE void fp12_frob(Fp12<T>& r, const Fp12<T>& a) {
     Fp12<T> x = a;
 #pragma unroll
     for (int j = 0; j < 6; j++) {

@@ -1,0 +1,160 @@
+"""GPU parity tests for the BLS12-381 hot path, through the C ABI, bit-exact against the oracle and
+the reference's ZCash fixtures; size-independent properties at larger batch sizes."""
+import hashlib
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import bls12381 as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bls():
+    import torch
+
+    assert torch.cuda.is_available()
+    from kyber_amd.pairing import bls12381 as bls
+
+    return bls
+
+
+def _scalars(label: bytes, n: int) -> np.ndarray:
+    raw = hashlib.shake_256(label).digest(n * 64)
+    out = np.empty((n, 32), dtype=np.uint8)
+    for i in range(n):
+        out[i] = np.frombuffer((int.from_bytes(raw[64 * i:64 * i + 64], "big") % O.R).to_bytes(32, "big"), dtype=np.uint8)
+    return out
+
+
+def test_zcash_fixtures_through_the_engine(bls, golden_dir):
+    d = json.load(open(os.path.join(golden_dir, "bls12381_zcash.json")))
+    one = (1).to_bytes(32, "big")
+    for grp, fn, size in (("G1", bls.g1_batch_mul, 48), ("G2", bls.g2_batch_mul, 96)):
+        for e in d[grp]:
+            buf = bytes.fromhex(e["hex"])
+            if len(buf) != size:
+                with pytest.raises(ValueError):
+                    (bls.G1Elt() if grp == "G1" else bls.G2Elt()).UnmarshalBinary(buf)
+                continue
+            out, st = fn(one, buf)
+            assert (st[0] == 0) == e["valid"], (grp, e["name"], st[0])
+            if e["valid"]:
+                assert bytes(out[0]) == buf
+            else:
+                assert not out.any()
+
+
+def test_g1_g2_mul_vs_oracle(bls):
+    rng = random.Random(4)
+    edge = [0, 1, 2, 15, 16, 17, O.R - 1, O.R, O.R + 5, (1 << 256) - 1, 8 << 252]
+    ks = edge + [rng.randrange(O.R) for _ in range(21)]
+    hs = [rng.randrange(1, O.R) for _ in ks]
+    p1 = [O.g1_compress(O.g1_mul(h, O.G1_GEN)) for h in hs]
+    p2 = [O.g2_compress(O.g2_mul(h, O.G2_GEN)) for h in hs]
+    p1[3], p2[3] = O.g1_compress(None), O.g2_compress(None)
+    kb = [k.to_bytes(32, "big") for k in ks]
+    out, st = bls.g1_batch_mul(b"".join(kb), b"".join(p1))
+    assert not st.any()
+    for i in range(len(ks)):
+        assert bytes(out[i]) == O.g1_mul_bytes(kb[i], p1[i]), i
+    out, st = bls.g2_batch_mul(b"".join(kb), b"".join(p2))
+    assert not st.any()
+    for i in range(len(ks)):
+        assert bytes(out[i]) == O.g2_mul_bytes(kb[i], p2[i]), i
+    # Commit (same base) == per-element mul
+    out2, st2 = bls.g1_commit(b"".join(kb), p1[0])
+    for i in range(0, len(ks), 5):
+        assert bytes(out2[i]) == O.g1_mul_bytes(kb[i], p1[0])
+
+
+def test_bad_inputs_status_and_zero_output(bls):
+    k = (7).to_bytes(32, "big")
+    good = O.g1_compress(O.G1_GEN)
+    pts = good + bytes(48) + good
+    out, st = bls.g1_batch_mul(k * 3, pts)
+    assert list(st) == [0, 1, 0] and not out[1].any() and bytes(out[0]) == bytes(out[2])
+
+
+def test_pairing_vs_oracle(bls):
+    rng = random.Random(5)
+    n = 6
+    g1 = [O.g1_compress(O.g1_mul(rng.randrange(1, O.R), O.G1_GEN)) for _ in range(n)]
+    g2 = [O.g2_compress(O.g2_mul(rng.randrange(1, O.R), O.G2_GEN)) for _ in range(n)]
+    g1[4] = O.g1_compress(None)
+    gt, st = bls.batch_pair(b"".join(g1), b"".join(g2))
+    assert not st.any()
+    for i in range(n):
+        assert bytes(gt[i]) == O.pair_bytes(g1[i], g2[i]), i
+
+
+def test_pairing_bilinear_at_scale(bls):
+    """e(a P, b Q) == e(ab P, Q) == e(P, ab Q) for 2048 independent (a, b): bls12381_test.go:448-474."""
+    n = 2048
+    a, b = _scalars(b"t/a", n), _scalars(b"t/b", n)
+    ab = np.empty_like(a)
+    for i in range(n):
+        x = int.from_bytes(bytes(a[i]), "big") * int.from_bytes(bytes(b[i]), "big") % O.R
+        ab[i] = np.frombuffer(x.to_bytes(32, "big"), dtype=np.uint8)
+    aP, st = bls.g1_commit(a)
+    abP, _ = bls.g1_commit(ab)
+    bQ, _ = bls.g2_commit(b)
+    abQ, _ = bls.g2_commit(ab)
+    assert not st.any()
+    G2 = np.tile(np.frombuffer(bls.G2_BASE, dtype=np.uint8), (n, 1))
+    G1 = np.tile(np.frombuffer(bls.G1_BASE, dtype=np.uint8), (n, 1))
+    e1, s1 = bls.batch_pair(aP, bQ)
+    e2, s2 = bls.batch_pair(abP, G2)
+    e3, s3 = bls.batch_pair(G1, abQ)
+    assert not (s1.any() or s2.any() or s3.any())
+    assert (e1 == e2).all() and (e1 == e3).all()
+    assert len({bytes(r) for r in e1[:64]}) == 64  # and they are not all the same value
+
+
+def test_validate_pairing_truth_table_at_scale(bls):
+    """bls.Verify shape (sign/bls/bls.go:36-38): e(H, X) == e(sig, G2), with a sprinkle of forgeries."""
+    n = 1024
+    x, h = _scalars(b"t/x", n), _scalars(b"t/h", n)
+    xh = np.empty_like(x)
+    for i in range(n):
+        v = int.from_bytes(bytes(x[i]), "big") * int.from_bytes(bytes(h[i]), "big") % O.R
+        xh[i] = np.frombuffer(v.to_bytes(32, "big"), dtype=np.uint8)
+    Hm, _ = bls.g1_commit(h)
+    X, _ = bls.g2_commit(x)
+    sig, _ = bls.g1_commit(xh)
+    G2 = np.tile(np.frombuffer(bls.G2_BASE, dtype=np.uint8), (n, 1))
+    bad = np.zeros(n, dtype=bool)
+    bad[::7] = True
+    sig = sig.copy()
+    sig[bad] = Hm[bad]  # wrong signature (valid point, wrong value)
+    ok, st = bls.batch_validate_pairing(Hm, X, sig, G2)
+    assert not st.any()
+    assert (ok.astype(bool) == ~bad).all()
+
+
+def test_device_resident_path_matches_host_path(bls):
+    import torch
+
+    n = 256
+    k = _scalars(b"t/k", n)
+    P, _ = bls.g1_commit(_scalars(b"t/p", n))
+    out_h, st_h = bls.g1_batch_mul(k, P)
+    out_d, st_d = bls.g1_batch_mul(torch.from_numpy(k).cuda(), torch.from_numpy(P).cuda())
+    torch.cuda.synchronize()
+    assert (out_d.cpu().numpy() == out_h).all() and not st_d.any().item()
+
+
+def test_suite_mirror(bls):
+    s = bls.NewSuite()
+    a, b = s.G1().Scalar().SetInt64(5), s.G1().Scalar().SetInt64(7)
+    P = s.G1().Point().Mul(a, None)
+    Q = s.G2().Point().Mul(b, None)
+    ab = s.G1().Scalar().Mul(a, b)
+    assert s.Pair(P, Q).Equal(s.Pair(s.G1().Point().Mul(ab, None), s.G2().Point().Base()))
+    assert s.ValidatePairing(P, Q, s.G1().Point().Mul(ab, None), s.G2().Point().Base())
+    with pytest.raises(TypeError):
+        P.Equal(Q)
