@@ -123,6 +123,34 @@ int kyb_bls12381_pair_check(size_t n, const uint8_t *p1, const uint8_t *p2, cons
 int kyb_bls12381_pair_check_dev(size_t n, const void *d_p1, const void *d_p2, const void *d_inv1, const void *d_inv2,
                                 void *d_ok, void *d_status, void *stream);
 
+/* ------------------------------------------------------------------ bn256
+ * pairing/bn256 (dclxvi parameters; arithmetic in-tree).  Wire formats (point.go):
+ *   scalars : 32-byte big-endian (mod.Int), taken as plain 256-bit integers (curve.go:189-203)
+ *   G1      : 64 bytes x || y, big-endian, infinity = 64 zero bytes (point.go:170-238)
+ *   G2      : 128 bytes x.x || x.y || y.x || y.y with gfP2{x, y} = x i + y (point.go:423-499)
+ *   GT      : 384 bytes, 12 x 32, order x.x.x ... y.z.y (point.go:630-662)
+ * UnmarshalBinary semantics kept: coordinates are reduced mod p (not rejected), (0,0) is
+ * infinity, on-curve check only -- G2 inputs outside the order-n subgroup are accepted and
+ * processed like the reference does.  status: KYB_ST_BAD_POINT, output zeroed. */
+int kyb_bn256_g1_mul(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status);
+int kyb_bn256_g2_mul(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status);
+int kyb_bn256_g1_mul_same_base(size_t n, const uint8_t *scalars, const uint8_t point[64], uint8_t *out,
+                               uint8_t *status);
+int kyb_bn256_g2_mul_same_base(size_t n, const uint8_t *scalars, const uint8_t point[128], uint8_t *out,
+                               uint8_t *status);
+int kyb_bn256_g1_mul_dev(size_t n, const void *d_scalars, const void *d_points, size_t point_stride, void *d_out,
+                         void *d_status, void *stream);
+int kyb_bn256_g2_mul_dev(size_t n, const void *d_scalars, const void *d_points, size_t point_stride, void *d_out,
+                         void *d_status, void *stream);
+/* gt[i] = e(g1[i], g2[i]): Suite.Pair (pairing/bn256/suite.go:97-103 -> optate.go:266-274). */
+int kyb_bn256_pair(size_t n, const uint8_t *g1, const uint8_t *g2, uint8_t *gt, uint8_t *status);
+int kyb_bn256_pair_dev(size_t n, const void *d_g1, const void *d_g2, void *d_gt, void *d_status, void *stream);
+/* ok[i] = Pair(p1, p2).Equal(Pair(inv1, inv2)): Suite.ValidatePairing (suite.go:105-107). */
+int kyb_bn256_pair_check(size_t n, const uint8_t *p1, const uint8_t *p2, const uint8_t *inv1, const uint8_t *inv2,
+                         uint8_t *ok, uint8_t *status);
+int kyb_bn256_pair_check_dev(size_t n, const void *d_p1, const void *d_p2, const void *d_inv1, const void *d_inv2,
+                             void *d_ok, void *d_status, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,16 @@ SIGNATURES = {
     "kyb_bls12381_pair_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
     "kyb_bls12381_pair_check": [_sz, _vp, _vp, _vp, _vp, _vp, _vp],
     "kyb_bls12381_pair_check_dev": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "kyb_bn256_g1_mul": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_bn256_g2_mul": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_bn256_g1_mul_same_base": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_bn256_g2_mul_same_base": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_bn256_g1_mul_dev": [_sz, _vp, _vp, _sz, _vp, _vp, _vp],
+    "kyb_bn256_g2_mul_dev": [_sz, _vp, _vp, _sz, _vp, _vp, _vp],
+    "kyb_bn256_pair": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_bn256_pair_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
+    "kyb_bn256_pair_check": [_sz, _vp, _vp, _vp, _vp, _vp, _vp],
+    "kyb_bn256_pair_check_dev": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 _RESTYPES = {"kyb_last_error": C.c_char_p}
 

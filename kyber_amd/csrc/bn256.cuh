@@ -1,0 +1,403 @@
+// bn256 (dclxvi parameters) G1 / G2 / GT device library: the reference's wire formats and
+// acceptance rules, scalar multiplication, optimal ate pairing.
+//
+// Replaces pairing/bn256 (all in-tree): pointG1/G2.Mul + (Un)MarshalBinary (point.go:154-238,
+// 405-499), curvePoint/twistPoint.Mul (curve.go:189, twist.go:162), miller / lineFunctionAdd /
+// lineFunctionDouble / mulLine / finalExponentiation / optimalAte (optate.go), pointGT.MarshalBinary
+// (point.go:630-662), Suite.Pair / ValidatePairing (suite.go:97-107).
+// The Miller loop and the final exponentiation follow optate.go's formulas and addition chain so
+// that GT bytes are those of the reference (oracle/bn256.py restates the same code).
+#pragma once
+#include "bn256_params.h"
+#include "curve.cuh"
+
+namespace kyb {
+namespace bn {
+
+using FC = Bn256Fp;
+using TC = Bn256Tower;
+using CC = Bn256Curve;
+using fp = Fp<FC>;
+using fp2 = Fp2<TC>;
+using fp6 = Fp6<TC>;
+using fp12 = Fp12<TC>;
+using g1_aff = Aff<fp>;
+using g2_aff = Aff<fp2>;
+using g1_jac = Jac<fp>;
+using g2_jac = Jac<fp2>;
+
+constexpr int ST_OK = 0, ST_BAD_POINT = 1;
+
+KYB_HD void fp_const(fp& r, const uint32_t (&c)[FC::N]) {
+#pragma unroll
+    for (int l = 0; l < FC::N; l++) r.v[l] = c[l];
+}
+
+// ------------------------------------------------------------------ decoding
+// 32-byte big-endian coordinate, reduced mod p like montEncode does (point.go:218-221): values
+// >= p are accepted.
+KYB_HD void fp_decode(fp& r, const uint8_t* in) {
+    uint32_t w[8];
+    words_from_be<8>(w, in);
+    fp_from_words<FC>(r, w);
+}
+KYB_HD void fp_encode(uint8_t* out, const fp& a) {
+    uint32_t w[8];
+    fp_to_words<FC>(w, a);
+    words_to_be<8>(out, w);
+}
+// pointG1.UnmarshalBinary (point.go:206-238): (0, 0) is infinity; otherwise y^2 = x^3 + 3.
+KYB_HD_NOINLINE int g1_decode(g1_aff& a, const uint8_t* in) {
+    fp_decode(a.x, in);
+    fp_decode(a.y, in + 32);
+    a.inf = fp_is_zero(a.x) & fp_is_zero(a.y);
+    fp y2, x3, b;
+    fp_const(b, CC::B1);
+    fp_sqr(y2, a.y);
+    fp_sqr(x3, a.x);
+    fp_mul(x3, x3, a.x);
+    fp_add(x3, x3, b);
+    return (a.inf || fp_eq(y2, x3)) ? ST_OK : ST_BAD_POINT;
+}
+// pointG2.UnmarshalBinary (point.go:466-499): x.x, x.y, y.x, y.y with gfP2{x, y} = x i + y;
+// on-curve check only, never a subgroup check.
+KYB_HD_NOINLINE int g2_decode(g2_aff& a, const uint8_t* in) {
+    fp_decode(a.x.c1, in);
+    fp_decode(a.x.c0, in + 32);
+    fp_decode(a.y.c1, in + 64);
+    fp_decode(a.y.c0, in + 96);
+    a.inf = fp2_is_zero(a.x) & fp2_is_zero(a.y);
+    fp2 y2, x3, b;
+    fp2_load_const<TC>(b, CC::B2);
+    fp2_sqr(y2, a.y);
+    fp2_sqr(x3, a.x);
+    fp2_mul(x3, x3, a.x);
+    fp2_add(x3, x3, b);
+    return (a.inf || fp2_eq(y2, x3)) ? ST_OK : ST_BAD_POINT;
+}
+// MarshalBinary: infinity is all zero bytes (point.go:170-192, 423-452)
+KYB_HD_NOINLINE void g1_encode(uint8_t* out, const g1_aff& a) {
+    fp x = a.x, y = a.y;
+    if (a.inf) {
+        fp_zero(x);
+        fp_zero(y);
+    }
+    fp_encode(out, x);
+    fp_encode(out + 32, y);
+}
+KYB_HD_NOINLINE void g2_encode(uint8_t* out, const g2_aff& a) {
+    fp2 x = a.x, y = a.y;
+    if (a.inf) {
+        fp2_zero(x);
+        fp2_zero(y);
+    }
+    fp_encode(out, x.c1);
+    fp_encode(out + 32, x.c0);
+    fp_encode(out + 64, y.c1);
+    fp_encode(out + 96, y.c0);
+}
+// pointGT.MarshalBinary (point.go:630-662): x.x.x, x.x.y, ..., y.z.y  ==  omega-coefficient
+// first, tau^2 / tau / 1 order inside, imaginary part before real part.
+KYB_HD_NOINLINE void gt_encode(uint8_t* out, const fp12& f) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const fp6& s = h == 0 ? f.c1 : f.c0;
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            const fp2& c = m == 0 ? s.c2 : (m == 1 ? s.c1 : s.c0);
+            fp_encode(out + (h * 3 + m) * 64, c.c1);
+            fp_encode(out + (h * 3 + m) * 64 + 32, c.c0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------- pairing
+struct twist_pt {  // Jacobian with t = z^2 cached, as twistPoint (twist.go:12-14)
+    fp2 x, y, z, t;
+};
+
+// ret *= (a tau + b) omega + c        (mulLine, optate.go:96-115; 13 Fp2 multiplications)
+KYB_HD_NOINLINE void mul_line(fp12& ret, const fp2& a, const fp2& b, const fp2& c) {
+    fp6 a2, t3, t2, s;
+    fp2 t;
+    fp6_mul_by_01(a2, ret.c1, b, a);
+    fp6_mul_fp2(t3, ret.c0, c);
+    fp2_add(t, b, c);
+    fp6_add(s, ret.c1, ret.c0);
+    fp6_mul_by_01(t2, s, t, a);
+    fp6_sub(t2, t2, a2);
+    fp6_sub(ret.c1, t2, t3);
+    fp6_mul_v(a2, a2);
+    fp6_add(ret.c0, t3, a2);
+}
+// lineFunctionDouble (optate.go:54-94): r <- 2r, line coefficients (a, b, c)
+KYB_HD_NOINLINE void line_double(fp2& a, fp2& b, fp2& c, twist_pt& r, const fp& qx, const fp& qy) {
+    fp2 A, B, C, D, E, G, t;
+    twist_pt o;
+    fp2_sqr(A, r.x);
+    fp2_sqr(B, r.y);
+    fp2_sqr(C, B);
+    fp2_add(D, r.x, B);
+    fp2_sqr(D, D);
+    fp2_sub(D, D, A);
+    fp2_sub(D, D, C);
+    fp2_dbl(D, D);
+    fp2_dbl(E, A);
+    fp2_add(E, E, A);
+    fp2_sqr(G, E);
+    fp2_sub(o.x, G, D);
+    fp2_sub(o.x, o.x, D);
+    fp2_add(o.z, r.y, r.z);
+    fp2_sqr(o.z, o.z);
+    fp2_sub(o.z, o.z, B);
+    fp2_sub(o.z, o.z, r.t);
+    fp2_sub(o.y, D, o.x);
+    fp2_mul(o.y, o.y, E);
+    fp2_dbl(t, C);
+    fp2_dbl(t, t);
+    fp2_dbl(t, t);
+    fp2_sub(o.y, o.y, t);
+    fp2_sqr(o.t, o.z);
+    fp2_mul(t, E, r.t);
+    fp2_dbl(t, t);
+    fp2_neg(b, t);
+    fp2_mul_fp(b, b, qx);
+    fp2_add(a, r.x, E);
+    fp2_sqr(a, a);
+    fp2_sub(a, a, A);
+    fp2_sub(a, a, G);
+    fp2_dbl(t, B);
+    fp2_dbl(t, t);
+    fp2_sub(a, a, t);
+    fp2_mul(c, o.z, r.t);
+    fp2_dbl(c, c);
+    fp2_mul_fp(c, c, qy);
+    r = o;
+}
+// lineFunctionAdd (optate.go:5-52): r <- r + p (p affine on the twist, r2 = p.y^2)
+KYB_HD_NOINLINE void line_add(fp2& a, fp2& b, fp2& c, twist_pt& r, const fp2& px, const fp2& py, const fp2& r2,
+                              const fp& qx, const fp& qy) {
+    fp2 B, D, H, I, E, J, L1, V, t, t2;
+    twist_pt o;
+    fp2_mul(B, px, r.t);
+    fp2_add(D, py, r.z);
+    fp2_sqr(D, D);
+    fp2_sub(D, D, r2);
+    fp2_sub(D, D, r.t);
+    fp2_mul(D, D, r.t);
+    fp2_sub(H, B, r.x);
+    fp2_sqr(I, H);
+    fp2_dbl(E, I);
+    fp2_dbl(E, E);
+    fp2_mul(J, H, E);
+    fp2_sub(L1, D, r.y);
+    fp2_sub(L1, L1, r.y);
+    fp2_mul(V, r.x, E);
+    fp2_sqr(o.x, L1);
+    fp2_sub(o.x, o.x, J);
+    fp2_sub(o.x, o.x, V);
+    fp2_sub(o.x, o.x, V);
+    fp2_add(o.z, r.z, H);
+    fp2_sqr(o.z, o.z);
+    fp2_sub(o.z, o.z, r.t);
+    fp2_sub(o.z, o.z, I);
+    fp2_sub(t, V, o.x);
+    fp2_mul(t, t, L1);
+    fp2_mul(t2, r.y, J);
+    fp2_dbl(t2, t2);
+    fp2_sub(o.y, t, t2);
+    fp2_sqr(o.t, o.z);
+    fp2_add(t, py, o.z);
+    fp2_sqr(t, t);
+    fp2_sub(t, t, r2);
+    fp2_sub(t, t, o.t);
+    fp2_mul(t2, L1, px);
+    fp2_dbl(t2, t2);
+    fp2_sub(a, t2, t);
+    fp2_mul_fp(c, o.z, qy);
+    fp2_dbl(c, c);
+    fp2_neg(b, L1);
+    fp2_mul_fp(b, b, qx);
+    fp2_dbl(b, b);
+    r = o;
+}
+// miller (optate.go:126-213); q, p affine and finite
+KYB_HD_NOINLINE void miller(fp12& ret, const g2_aff& q, const g1_aff& p) {
+    fp12_one(ret);
+    twist_pt r;
+    r.x = q.x;
+    r.y = q.y;
+    fp2_one(r.z);
+    fp2_one(r.t);
+    fp2 r2, a, b, c, my;
+    fp2_sqr(r2, q.y);
+    fp2_neg(my, q.y);
+#pragma unroll 1
+    for (int i = CC::NAF_LEN - 1; i > 0; i--) {
+        line_double(a, b, c, r, p.x, p.y);
+        if (i != CC::NAF_LEN - 1) fp12_sqr(ret, ret);
+        mul_line(ret, a, b, c);
+        const int k = i - 1;
+        const bool plus = k < 64 ? ((CC::NAF_PLUS_LO >> k) & 1) : ((CC::NAF_PLUS_HI >> (k - 64)) & 1);
+        const bool minus = k < 64 ? ((CC::NAF_MINUS_LO >> k) & 1) : ((CC::NAF_MINUS_HI >> (k - 64)) & 1);
+        if (plus) {
+            line_add(a, b, c, r, q.x, q.y, r2, p.x, p.y);
+            mul_line(ret, a, b, c);
+        } else if (minus) {
+            line_add(a, b, c, r, q.x, my, r2, p.x, p.y);
+            mul_line(ret, a, b, c);
+        }
+    }
+    // Q1 = Frobenius(Q), -Q2 = -Frobenius^2(Q) on the twist (optate.go:182-207)
+    fp2 q1x, q1y, k;
+    fp2_conj(q1x, q.x);
+    fp2_load_const<TC>(k, CC::Q1X);
+    fp2_mul(q1x, q1x, k);
+    fp2_conj(q1y, q.y);
+    fp2_load_const<TC>(k, CC::Q1Y);
+    fp2_mul(q1y, q1y, k);
+    fp2_sqr(r2, q1y);
+    line_add(a, b, c, r, q1x, q1y, r2, p.x, p.y);
+    mul_line(ret, a, b, c);
+    fp q2k;
+    fp_const(q2k, CC::Q2X);
+    fp2 q2x;
+    fp2_mul_fp(q2x, q.x, q2k);
+    fp2_sqr(r2, q.y);
+    line_add(a, b, c, r, q2x, q.y, r2, p.x, p.y);
+    mul_line(ret, a, b, c);
+}
+// gfP12.Exp(a, u) (gfp12.go:177-192), u = 6518589491078791937 (63 bits)
+KYB_HD_NOINLINE void pow_u(fp12& r, const fp12& a) {
+    fp12 acc = a;
+#pragma unroll 1
+    for (int i = 61; i >= 0; i--) {
+        fp12_sqr(acc, acc);
+        if ((CC::U >> i) & 1) fp12_mul(acc, acc, a);
+    }
+    r = acc;
+}
+// finalExponentiation (optate.go:215-264), same addition chain
+KYB_HD_NOINLINE void final_exp(fp12& out, const fp12& in) {
+    fp12 t1, t2, inv, fp_, fp2_, fp3_, fu, fu2, fu3, y0, y1, y2, y3, y4, y5, y6, fu2p, fu3p, t0;
+    fp12_conj(t1, in);
+    fp12_inv(inv, in);
+    fp12_mul(t1, t1, inv);
+    fp12_frob<TC, 2>(t2, t1);
+    fp12_mul(t1, t1, t2);
+    fp12_frob<TC, 1>(fp_, t1);
+    fp12_frob<TC, 2>(fp2_, t1);
+    fp12_frob<TC, 1>(fp3_, fp2_);
+    pow_u(fu, t1);
+    pow_u(fu2, fu);
+    pow_u(fu3, fu2);
+    fp12_frob<TC, 1>(y3, fu);
+    fp12_frob<TC, 1>(fu2p, fu2);
+    fp12_frob<TC, 1>(fu3p, fu3);
+    fp12_frob<TC, 2>(y2, fu2);
+    fp12_mul(y0, fp_, fp2_);
+    fp12_mul(y0, y0, fp3_);
+    fp12_conj(y1, t1);
+    fp12_conj(y5, fu2);
+    fp12_conj(y3, y3);
+    fp12_mul(y4, fu, fu2p);
+    fp12_conj(y4, y4);
+    fp12_mul(y6, fu3, fu3p);
+    fp12_conj(y6, y6);
+    fp12_sqr(t0, y6);
+    fp12_mul(t0, t0, y4);
+    fp12_mul(t0, t0, y5);
+    fp12_mul(t1, y3, y5);
+    fp12_mul(t1, t1, t0);
+    fp12_mul(t0, t0, y2);
+    fp12_sqr(t1, t1);
+    fp12_mul(t1, t1, t0);
+    fp12_sqr(t1, t1);
+    fp12_mul(t0, t1, y1);
+    fp12_mul(t1, t1, y0);
+    fp12_sqr(t0, t0);
+    fp12_mul(out, t0, t1);
+}
+// optimalAte (optate.go:266-274)
+KYB_HD void optimal_ate(fp12& f, const g2_aff& q, const g1_aff& p) {
+    miller(f, q, p);
+    final_exp(f, f);
+    if (q.inf | p.inf) fp12_one(f);
+}
+
+// ------------------------------------------------- per-element wire-level operations
+KYB_HD void zero_bytes(uint8_t* out, int n) {
+    uint32_t* q = reinterpret_cast<uint32_t*>(out);
+    for (int k = 0; k < n / 4; k++) q[k] = 0;
+}
+KYB_HD int g1_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt) {
+    g1_aff a;
+    const int st = g1_decode(a, pt);
+    if (st != ST_OK) {
+        zero_bytes(out, 64);
+        return st;
+    }
+    uint32_t k[8];
+    words_from_be<8>(k, scalar_be);
+    g1_jac p, r;
+    jac_from_aff(p, a);
+    jac_mul_u256(r, p, k);
+    jac_to_aff(a, r);
+    g1_encode(out, a);
+    return ST_OK;
+}
+KYB_HD int g2_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt) {
+    g2_aff a;
+    const int st = g2_decode(a, pt);
+    if (st != ST_OK) {
+        zero_bytes(out, 128);
+        return st;
+    }
+    uint32_t k[8];
+    words_from_be<8>(k, scalar_be);
+    g2_jac p, r;
+    jac_from_aff(p, a);
+    jac_mul_u256(r, p, k);
+    jac_to_aff(a, r);
+    g2_encode(out, a);
+    return ST_OK;
+}
+// gt = e(g1, g2)   (Suite.Pair, suite.go:97-103)
+KYB_HD int pair_wire(uint8_t* gt, const uint8_t* g1, const uint8_t* g2) {
+    g1_aff p;
+    g2_aff q;
+    int st = g1_decode(p, g1);
+    const int st2 = g2_decode(q, g2);
+    if (st == ST_OK) st = st2;
+    if (st != ST_OK) {
+        zero_bytes(gt, 384);
+        return st;
+    }
+    fp12 f;
+    optimal_ate(f, q, p);
+    gt_encode(gt, f);
+    return ST_OK;
+}
+// ok = Pair(p1, p2).Equal(Pair(inv1, inv2))   (Suite.ValidatePairing, suite.go:105-107)
+KYB_HD int pair_check_wire(uint8_t* ok, const uint8_t* p1, const uint8_t* p2, const uint8_t* inv1,
+                           const uint8_t* inv2) {
+    g1_aff a, c;
+    g2_aff b, d;
+    int st = g1_decode(a, p1);
+    int s2 = g2_decode(b, p2);
+    if (st == ST_OK) st = s2;
+    s2 = g1_decode(c, inv1);
+    if (st == ST_OK) st = s2;
+    s2 = g2_decode(d, inv2);
+    if (st == ST_OK) st = s2;
+    *ok = 0;
+    if (st != ST_OK) return st;
+    fp12 f, g;
+    optimal_ate(f, b, a);
+    optimal_ate(g, d, c);
+    *ok = fp12_eq(f, g) ? 1 : 0;
+    return ST_OK;
+}
+
+}  // namespace bn
+}  // namespace kyb

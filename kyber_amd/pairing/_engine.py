@@ -1,0 +1,284 @@
+"""Shared host-side plumbing for the pairing suites (BLS12-381, bn256): batch entry points over the
+C ABI and kyber.Scalar / kyber.Point / pairing.Suite mirrors holding canonical wire encodings.
+No curve or field arithmetic happens in Python (scalars mod the group order are host plumbing,
+like the reference's group/mod.Int)."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from .._lib import check, load
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _host(buf, width: int) -> np.ndarray:
+    a = np.frombuffer(buf, dtype=np.uint8) if isinstance(buf, (bytes, bytearray, memoryview)) else np.asarray(buf, dtype=np.uint8)
+    return np.ascontiguousarray(a).reshape(-1, width)
+
+
+def _stream():
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Engine:
+    """Batch API of one pairing suite; `prefix` selects the kyb_<prefix>_* entry points."""
+
+    def __init__(self, prefix, name, order, g1_len, g2_len, gt_len, g1_base, g2_base, g1_null, g2_null):
+        self.prefix, self.name, self.ORDER = prefix, name, order
+        self.G1_LEN, self.G2_LEN, self.GT_LEN, self.SCALAR_LEN = g1_len, g2_len, gt_len, 32
+        self.G1_BASE, self.G2_BASE, self.G1_NULL, self.G2_NULL = g1_base, g2_base, g1_null, g2_null
+
+    def _fn(self, suffix):
+        return getattr(load(), f"kyb_{self.prefix}_{suffix}"), f"kyb_{self.prefix}_{suffix}"
+
+    def mul(self, group: int, scalars, points, same_base: bool):
+        w = self.G1_LEN if group == 1 else self.G2_LEN
+        if _is_torch(scalars):
+            import torch
+
+            s = scalars.contiguous().view(-1, 32)
+            p = points.contiguous().view(-1, w)
+            n = s.shape[0]
+            if not same_base and p.shape[0] != n:
+                raise ValueError("scalars/points length mismatch")
+            out = torch.empty((n, w), dtype=torch.uint8, device=s.device)
+            st = torch.empty(n, dtype=torch.uint8, device=s.device)
+            fn, nm = self._fn(f"g{group}_mul_dev")
+            check(fn(n, s.data_ptr(), p.data_ptr(), 0 if same_base else w, out.data_ptr(), st.data_ptr(), _stream()), nm)
+            return out, st
+        s = _host(scalars, 32)
+        p = _host(points, w)
+        n = s.shape[0]
+        out = np.empty((n, w), dtype=np.uint8)
+        st = np.empty(n, dtype=np.uint8)
+        if same_base:
+            fn, nm = self._fn(f"g{group}_mul_same_base")
+        else:
+            if p.shape[0] != n:
+                raise ValueError("scalars/points length mismatch")
+            fn, nm = self._fn(f"g{group}_mul")
+        check(fn(n, s.ctypes.data, p.ctypes.data, out.ctypes.data, st.ctypes.data), nm)
+        return out, st
+
+    def g1_batch_mul(self, scalars, points):
+        """(out, status): out[i] = scalars[i] * points[i] on G1."""
+        return self.mul(1, scalars, points, False)
+
+    def g2_batch_mul(self, scalars, points):
+        return self.mul(2, scalars, points, False)
+
+    def g1_commit(self, scalars, base=None):
+        """share.PriPoly.Commit (share/poly.go:143-149): commits[i] = coeffs[i] * base."""
+        return self.mul(1, scalars, self.G1_BASE if base is None else base, True)
+
+    def g2_commit(self, scalars, base=None):
+        return self.mul(2, scalars, self.G2_BASE if base is None else base, True)
+
+    def batch_pair(self, g1, g2):
+        """(gt, status): gt[i] = e(g1[i], g2[i])  (N x Suite.Pair)."""
+        if _is_torch(g1):
+            import torch
+
+            a = g1.contiguous().view(-1, self.G1_LEN)
+            b = g2.contiguous().view(-1, self.G2_LEN)
+            n = a.shape[0]
+            if b.shape[0] != n:
+                raise ValueError("g1/g2 length mismatch")
+            gt = torch.empty((n, self.GT_LEN), dtype=torch.uint8, device=a.device)
+            st = torch.empty(n, dtype=torch.uint8, device=a.device)
+            fn, nm = self._fn("pair_dev")
+            check(fn(n, a.data_ptr(), b.data_ptr(), gt.data_ptr(), st.data_ptr(), _stream()), nm)
+            return gt, st
+        a, b = _host(g1, self.G1_LEN), _host(g2, self.G2_LEN)
+        n = a.shape[0]
+        if b.shape[0] != n:
+            raise ValueError("g1/g2 length mismatch")
+        gt = np.empty((n, self.GT_LEN), dtype=np.uint8)
+        st = np.empty(n, dtype=np.uint8)
+        fn, nm = self._fn("pair")
+        check(fn(n, a.ctypes.data, b.ctypes.data, gt.ctypes.data, st.ctypes.data), nm)
+        return gt, st
+
+    def batch_validate_pairing(self, p1, p2, inv1, inv2):
+        """(ok, status): ok[i] = e(p1[i], p2[i]) == e(inv1[i], inv2[i])  (N x Suite.ValidatePairing,
+        pairing/pairing.go:13-15).  p1/inv1 are G1, p2/inv2 are G2."""
+        if _is_torch(p1):
+            import torch
+
+            a, c = p1.contiguous().view(-1, self.G1_LEN), inv1.contiguous().view(-1, self.G1_LEN)
+            b, d = p2.contiguous().view(-1, self.G2_LEN), inv2.contiguous().view(-1, self.G2_LEN)
+            n = a.shape[0]
+            if not (b.shape[0] == c.shape[0] == d.shape[0] == n):
+                raise ValueError("length mismatch")
+            ok = torch.empty(n, dtype=torch.uint8, device=a.device)
+            st = torch.empty(n, dtype=torch.uint8, device=a.device)
+            fn, nm = self._fn("pair_check_dev")
+            check(fn(n, a.data_ptr(), b.data_ptr(), c.data_ptr(), d.data_ptr(), ok.data_ptr(), st.data_ptr(), _stream()), nm)
+            return ok, st
+        a, c = _host(p1, self.G1_LEN), _host(inv1, self.G1_LEN)
+        b, d = _host(p2, self.G2_LEN), _host(inv2, self.G2_LEN)
+        n = a.shape[0]
+        if not (b.shape[0] == c.shape[0] == d.shape[0] == n):
+            raise ValueError("length mismatch")
+        ok = np.empty(n, dtype=np.uint8)
+        st = np.empty(n, dtype=np.uint8)
+        fn, nm = self._fn("pair_check")
+        check(fn(n, a.ctypes.data, b.ctypes.data, c.ctypes.data, d.ctypes.data, ok.ctypes.data, st.ctypes.data), nm)
+        return ok, st
+
+    # ------------------------------------------------------------ kyber interface mirrors
+    def make_types(self):
+        eng = self
+        ORDER = self.ORDER
+
+        class Scalar:
+            """mod.Int modulo the group order, 32-byte big-endian wire format (group/mod/int.go:334-350)."""
+
+            __slots__ = ("v",)
+
+            def __init__(self, v: int = 0):
+                self.v = v % ORDER
+
+            def MarshalBinary(self) -> bytes:
+                return self.v.to_bytes(32, "big")
+
+            def UnmarshalBinary(self, buf: bytes):
+                if len(buf) != 32:
+                    raise ValueError("UnmarshalBinary: wrong size buffer")
+                x = int.from_bytes(buf, "big")
+                if x >= ORDER:  # group/mod/int.go:362-364
+                    raise ValueError("UnmarshalBinary: value out of range")
+                self.v = x
+                return self
+
+            def MarshalSize(self) -> int: return 32
+            def SetInt64(self, x: int): self.v = x % ORDER; return self
+            def SetBytes(self, b: bytes): self.v = int.from_bytes(b, "big") % ORDER; return self
+            def Zero(self): return self.SetInt64(0)
+            def One(self): return self.SetInt64(1)
+            def Set(self, a): self.v = _sc(a).v; return self
+            def Clone(self): return Scalar(self.v)
+            def Equal(self, a) -> bool: return self.v == _sc(a).v
+            def Add(self, a, b): self.v = (_sc(a).v + _sc(b).v) % ORDER; return self
+            def Sub(self, a, b): self.v = (_sc(a).v - _sc(b).v) % ORDER; return self
+            def Neg(self, a): self.v = -_sc(a).v % ORDER; return self
+            def Mul(self, a, b): self.v = _sc(a).v * _sc(b).v % ORDER; return self
+            def Inv(self, a): self.v = pow(_sc(a).v, ORDER - 2, ORDER); return self
+            def Div(self, a, b): self.v = _sc(a).v * pow(_sc(b).v, ORDER - 2, ORDER) % ORDER; return self
+
+            def Pick(self, rand=None):
+                raw = rand(64) if rand is not None else os.urandom(64)
+                self.v = int.from_bytes(raw, "big") % ORDER
+                return self
+
+            def String(self) -> str: return self.MarshalBinary().hex()
+            __repr__ = String
+
+        def _sc(s) -> Scalar:
+            if not isinstance(s, Scalar):
+                raise TypeError(f"ErrTypeCast: not a {eng.name} scalar")
+            return s
+
+        class _Elt:
+            """G1/G2 element held as its canonical wire encoding; arithmetic = engine calls."""
+
+            __slots__ = ("enc",)
+            GROUP, LEN, BASE, NULL = 0, 0, b"", b""
+
+            def __init__(self, enc=None):
+                self.enc = self.NULL if enc is None else bytes(enc)
+
+            def MarshalBinary(self) -> bytes: return self.enc
+            def MarshalSize(self) -> int: return self.LEN
+
+            def UnmarshalBinary(self, buf: bytes):
+                if len(buf) != self.LEN:
+                    raise ValueError(f"{eng.name}: wrong size buffer")
+                out, st = eng.mul(self.GROUP, (1).to_bytes(32, "big"), buf, False)
+                if st[0]:
+                    raise ValueError(f"{eng.name}: malformed point" if st[0] == 1 else f"{eng.name}: point not in subgroup")
+                self.enc = bytes(out[0])
+                return self
+
+            def Null(self): self.enc = self.NULL; return self
+            def Base(self): self.enc = self.BASE; return self
+            def Set(self, p): self.enc = self._cast(p).enc; return self
+            def Clone(self): return type(self)(self.enc)
+            def Equal(self, p) -> bool: return self.enc == self._cast(p).enc
+
+            def Mul(self, s, A=None):
+                base = self.BASE if A is None else self._cast(A).enc
+                out, st = eng.mul(self.GROUP, _sc(s).MarshalBinary(), base, False)
+                if st[0]:
+                    raise ValueError(f"{eng.name}: invalid point")
+                self.enc = bytes(out[0])
+                return self
+
+            def _cast(self, p):
+                if type(p) is not type(self):
+                    raise TypeError(f"ErrTypeCast: wrong {eng.name} group element")
+                return p
+
+            def String(self) -> str: return self.enc.hex()
+            __repr__ = String
+
+        class G1Elt(_Elt):
+            __slots__ = ()
+            GROUP, LEN, BASE, NULL = 1, eng.G1_LEN, eng.G1_BASE, eng.G1_NULL
+
+        class G2Elt(_Elt):
+            __slots__ = ()
+            GROUP, LEN, BASE, NULL = 2, eng.G2_LEN, eng.G2_BASE, eng.G2_NULL
+
+        class GTElt:
+            __slots__ = ("enc",)
+
+            def __init__(self, enc: bytes = b""):
+                self.enc = bytes(enc)
+
+            def MarshalBinary(self) -> bytes: return self.enc
+            def MarshalSize(self) -> int: return eng.GT_LEN
+            def Equal(self, o) -> bool: return self.enc == o.enc
+
+            def Pair(self, p1, p2):
+                gt, st = eng.batch_pair(p1.enc, p2.enc)
+                if st[0]:
+                    raise ValueError(f"{eng.name}: invalid pairing input")
+                self.enc = bytes(gt[0])
+                return self
+
+        class _Group:
+            def __init__(self, elt, gname):
+                self._elt, self._name = elt, gname
+
+            def String(self): return self._name
+            def ScalarLen(self): return 32
+            def Scalar(self): return Scalar()
+            def PointLen(self): return self._elt.LEN
+            def Point(self): return self._elt()
+
+        class Suite:
+            """pairing.Suite (pairing/pairing.go:8-20): G1(), G2(), GT(), Pair, ValidatePairing."""
+
+            def G1(self): return _Group(G1Elt, eng.name + ".G1")
+            def G2(self): return _Group(G2Elt, eng.name + ".G2")
+            def GT(self): return GTElt
+
+            def Pair(self, p1, p2):
+                if not isinstance(p1, G1Elt) or not isinstance(p2, G2Elt):
+                    raise TypeError("ErrTypeCast")
+                return GTElt().Pair(p1, p2)
+
+            def ValidatePairing(self, p1, p2, inv1, inv2) -> bool:
+                ok, st = eng.batch_validate_pairing(p1.enc, p2.enc, inv1.enc, inv2.enc)
+                if st[0]:
+                    raise ValueError(f"{eng.name}: invalid pairing input")
+                return bool(ok[0])
+
+        return Scalar, G1Elt, G2Elt, GTElt, Suite

@@ -1,0 +1,30 @@
+"""Host-side mirror of the reference's ``pairing/bn256`` suite for the hot path (pairing.Suite,
+pairing/bn256/suite.go:22-107; point.go), backed by the HIP engine through the C ABI.
+
+Wire formats (pairing/bn256/point.go): scalars 32-byte big-endian (mod.Int), G1 64 bytes x || y,
+G2 128 bytes x.x || x.y || y.x || y.y, GT 384 bytes; infinity is all-zero bytes.
+"""
+from ._engine import Engine
+
+# constants.go:25
+ORDER = 65000549695646603732796438742359905742570406053903786389881062969044166799969
+_P = 65000549695646603732796438742359905742825358107623003571877145026864184071783
+G1_LEN, G2_LEN, GT_LEN, SCALAR_LEN = 64, 128, 384, 32
+G1_BASE = (1).to_bytes(32, "big") + (_P - 2).to_bytes(32, "big")  # curve.go:19-24
+G2_BASE = bytes.fromhex(  # twist.go:21-33 in wire order x.x x.y y.x y.y
+    "2ecca446ff6f3d4d03c76e9b5c752f28bc37b364cb05ac4a37eb32e1c3245970"
+    "8f25386f72c9462b81597d65ae2092c4b97792155dcdaad32b8a6dd41792534c"
+    "2db10ef5233b0fe3962b9ee6a4bbc2b5bde01a54f3513d42df972e128f31bf12"
+    "274e5747e8cafacc3716cc8699db79b22f0e4ff3c23e898f694420a3be3087a5")
+G1_NULL, G2_NULL = bytes(64), bytes(128)
+
+ENGINE = Engine("bn256", "bn256", ORDER, G1_LEN, G2_LEN, GT_LEN, G1_BASE, G2_BASE, G1_NULL, G2_NULL)
+g1_batch_mul, g2_batch_mul = ENGINE.g1_batch_mul, ENGINE.g2_batch_mul
+g1_commit, g2_commit = ENGINE.g1_commit, ENGINE.g2_commit
+batch_pair, batch_validate_pairing = ENGINE.batch_pair, ENGINE.batch_validate_pairing
+_mul = ENGINE.mul
+Scalar, G1Elt, G2Elt, GTElt, Suite = ENGINE.make_types()
+
+
+def NewSuite() -> Suite:
+    return Suite()

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "../kyber_amd/csrc/bls12381.cuh"
+#include "../kyber_amd/csrc/bn256.cuh"
 
 using namespace kyb;
 
@@ -49,5 +50,29 @@ int hh_bls_g2_mul(const uint8_t* k, const uint8_t* pt, uint8_t* out) { return bl
 int hh_bls_pair(const uint8_t* g1, const uint8_t* g2, uint8_t* gt) { return bls::pair_wire(gt, g1, g2); }
 int hh_bls_pair_check(const uint8_t* p1, const uint8_t* p2, const uint8_t* i1, const uint8_t* i2, uint8_t* ok) {
     return bls::pair_check_wire(ok, p1, p2, i1, i2);
+}
+
+// ---- bn256
+void hh_bn_fp_op(int op, const uint8_t* a32, const uint8_t* b32, uint8_t* out32) {
+    bn::fp a, b, r;
+    bn::fp_decode(a, a32);
+    bn::fp_decode(b, b32);
+    switch (op) {
+        case 0: fp_mul(r, a, b); break;
+        case 1: fp_add(r, a, b); break;
+        case 2: fp_sub(r, a, b); break;
+        case 3: fp_neg(r, a); break;
+        case 4: fp_inv(r, a); break;
+        default: fp_sqr(r, a); break;
+    }
+    bn::fp_encode(out32, r);
+}
+int hh_bn_g1_decode(const uint8_t* in) { bn::g1_aff a; return bn::g1_decode(a, in); }
+int hh_bn_g2_decode(const uint8_t* in) { bn::g2_aff a; return bn::g2_decode(a, in); }
+int hh_bn_g1_mul(const uint8_t* k, const uint8_t* pt, uint8_t* out) { return bn::g1_mul_wire(out, k, pt); }
+int hh_bn_g2_mul(const uint8_t* k, const uint8_t* pt, uint8_t* out) { return bn::g2_mul_wire(out, k, pt); }
+int hh_bn_pair(const uint8_t* g1, const uint8_t* g2, uint8_t* gt) { return bn::pair_wire(gt, g1, g2); }
+int hh_bn_pair_check(const uint8_t* p1, const uint8_t* p2, const uint8_t* i1, const uint8_t* i2, uint8_t* ok) {
+    return bn::pair_check_wire(ok, p1, p2, i1, i2);
 }
 }

@@ -1,0 +1,142 @@
+"""GPU parity tests for the bn256 hot path (config 5), through the C ABI: the reference's golden
+vectors (BDN fixtures, Hash outputs feed the signatures), bit-exact vs the oracle restatement of
+pairing/bn256, and size-independent properties at batch scale."""
+import hashlib
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle import bn256 as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bn():
+    import torch
+
+    assert torch.cuda.is_available()
+    from kyber_amd.pairing import bn256 as bn
+
+    return bn
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "bn256.json")))
+
+
+def _scalars(label: bytes, n: int) -> np.ndarray:
+    raw = hashlib.shake_256(label).digest(n * 64)
+    out = np.empty((n, 32), dtype=np.uint8)
+    for i in range(n):
+        out[i] = np.frombuffer((int.from_bytes(raw[64 * i:64 * i + 64], "big") % O.ORDER).to_bytes(32, "big"), dtype=np.uint8)
+    return out
+
+
+def _fp(x):
+    return x.to_bytes(32, "big")
+
+
+def test_bdn_golden_fixtures(bn, G):
+    Hm = O.g1_marshal(O.hash_to_g1(G["bdn_msg"].encode()))
+    privs = b"".join(bytes.fromhex(p) for p in G["bdn_privs"])
+    pubs, st = bn.g2_commit(privs)  # public keys = x * G2 base
+    assert not st.any()
+    sigs, st = bn.g1_commit(privs, Hm)  # signatures = x * Hash(msg)
+    assert not st.any()
+    for i in range(3):
+        assert bytes(pubs[i]).hex() == G["bdn_pubs"][i]
+        assert bytes(sigs[i]).hex() == G["bdn_sigs"][i]
+    ok, st = bn.batch_validate_pairing(Hm * 3, pubs, sigs, bn.G2_BASE * 3)
+    assert not st.any() and ok.all()
+    ok, st = bn.batch_validate_pairing(Hm * 3, pubs, np.roll(sigs, 1, axis=0), bn.G2_BASE * 3)
+    assert not ok.any()
+
+
+def test_bdn_aggregated_key_terms(bn, G):
+    # publicTerms[i] = c_i * P_i + P_i with P_i = (i+1) G2 (mask.go:57-61); their sum is the fixture
+    ks = b"".join(_fp(i + 1) for i in range(3))
+    P, _ = bn.g2_commit(ks)
+    cp1 = b"".join(_fp(int(c, 16) + 1) for c in G["bdn_coefs"])
+    terms, st = bn.g2_batch_mul(cp1, P)
+    assert not st.any()
+    acc = None
+    for t in terms:
+        acc = O.g2_add(acc, O.g2_unmarshal(bytes(t)))
+    assert O.g2_marshal(acc).hex() == G["bdn_agg_key"]
+
+
+def test_mul_vs_oracle_and_edges(bn):
+    rng = random.Random(4)
+    ks = [0, 1, 2, 16, 17, O.ORDER - 1, O.ORDER, O.ORDER + 3, (1 << 256) - 1] + [rng.randrange(O.ORDER) for _ in range(15)]
+    hs = [rng.randrange(1, O.ORDER) for _ in ks]
+    p1 = [O.g1_marshal(O.g1_mul(h, O.G1_GEN)) for h in hs]
+    p2 = [O.g2_marshal(O.g2_mul(h, O.G2_GEN)) for h in hs]
+    p1[2], p2[2] = bytes(64), bytes(128)
+    x, y = O.G1_GEN
+    p1[3] = _fp(x + O.P) + _fp(y)  # non-canonical coordinate accepted (point.go:218-221)
+    kb = [_fp(k) for k in ks]
+    out, st = bn.g1_batch_mul(b"".join(kb), b"".join(p1))
+    assert not st.any()
+    for i in range(len(ks)):
+        assert bytes(out[i]) == O.g1_mul_bytes(kb[i], p1[i]), i
+    out, st = bn.g2_batch_mul(b"".join(kb), b"".join(p2))
+    assert not st.any()
+    for i in range(len(ks)):
+        assert bytes(out[i]) == O.g2_mul_bytes(kb[i], p2[i]), i
+    out, st = bn.g1_batch_mul(kb[0] * 2, _fp(5) * 2 + p1[0])
+    assert list(st) == [1, 0] and not out[0].any()
+
+
+def test_pairing_bytes_vs_oracle(bn):
+    rng = random.Random(5)
+    n = 5
+    g1 = [O.g1_marshal(O.g1_mul(rng.randrange(1, O.ORDER), O.G1_GEN)) for _ in range(n)]
+    g2 = [O.g2_marshal(O.g2_mul(rng.randrange(1, O.ORDER), O.G2_GEN)) for _ in range(n)]
+    g1[3] = bytes(64)
+    # an on-curve G2 point outside the order-n subgroup (accepted by the reference, point.go:466-499)
+    while True:
+        x = (rng.randrange(O.P), rng.randrange(O.P))
+        y = O.f2_sqrt(O.f2_add(O.f2_mul(O.f2_sqr(x), x), O.TWIST_B))
+        if y is not None:
+            g2[4] = O.g2_marshal((x, y))
+            break
+    gt, st = bn.batch_pair(b"".join(g1), b"".join(g2))
+    assert not st.any()
+    for i in range(n):
+        assert bytes(gt[i]) == O.pair_bytes(g1[i], g2[i]), i
+
+
+def test_bilinearity_at_scale(bn):
+    """e(aP, bQ) == e(abP, Q) == e(P, abQ) (suite_test.go:231-259) for 2048 independent pairs."""
+    n = 2048
+    a, b = _scalars(b"bn/a", n), _scalars(b"bn/b", n)
+    ab = np.empty_like(a)
+    for i in range(n):
+        v = int.from_bytes(bytes(a[i]), "big") * int.from_bytes(bytes(b[i]), "big") % O.ORDER
+        ab[i] = np.frombuffer(_fp(v), dtype=np.uint8)
+    aP, _ = bn.g1_commit(a)
+    abP, _ = bn.g1_commit(ab)
+    bQ, _ = bn.g2_commit(b)
+    abQ, _ = bn.g2_commit(ab)
+    G1 = np.tile(np.frombuffer(bn.G1_BASE, dtype=np.uint8), (n, 1))
+    G2 = np.tile(np.frombuffer(bn.G2_BASE, dtype=np.uint8), (n, 1))
+    e1, s1 = bn.batch_pair(aP, bQ)
+    e2, s2 = bn.batch_pair(abP, G2)
+    e3, s3 = bn.batch_pair(G1, abQ)
+    assert not (s1.any() or s2.any() or s3.any())
+    assert (e1 == e2).all() and (e1 == e3).all()
+    assert len({bytes(r) for r in e1[:64]}) == 64
+
+
+def test_suite_mirror(bn):
+    s = bn.NewSuite()
+    a, b = s.G1().Scalar().SetInt64(5), s.G1().Scalar().SetInt64(7)
+    P, Q = s.G1().Point().Mul(a, None), s.G2().Point().Mul(b, None)
+    ab = s.G1().Scalar().Mul(a, b)
+    assert s.Pair(P, Q).Equal(s.Pair(s.G1().Point().Mul(ab, None), s.G2().Point().Base()))
+    assert s.ValidatePairing(P, Q, s.G1().Point().Mul(ab, None), s.G2().Point().Base())

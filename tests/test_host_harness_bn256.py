@@ -1,0 +1,95 @@
+"""The bn256 device code (bn256.cuh over mont.cuh / tower.cuh / curve.cuh), compiled for the host,
+against the oracle restatement of pairing/bn256 and the reference's golden vectors."""
+import json
+import os
+import random
+
+import pytest
+
+from oracle import bn256 as O
+from tests import _host_harness as H
+
+
+def _fp(x):
+    return x.to_bytes(32, "big")
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "bn256.json")))
+
+
+def test_fp_ops():
+    rng = random.Random(1)
+    vals = [0, 1, 2, O.P - 1, O.P - 2, O.P, O.P + 1, (1 << 256) - 1] + [rng.randrange(O.P) for _ in range(100)]
+    for i in range(len(vals)):
+        a, b = vals[i], vals[(i * 7 + 3) % len(vals)]
+        assert H.call("hh_bn_fp_op", 0, _fp(a), _fp(b), out_sizes=(32,))[1] == _fp(a * b % O.P)
+        assert H.call("hh_bn_fp_op", 1, _fp(a), _fp(b), out_sizes=(32,))[1] == _fp((a + b) % O.P)
+        assert H.call("hh_bn_fp_op", 2, _fp(a), _fp(b), out_sizes=(32,))[1] == _fp((a - b) % O.P)
+    for a in vals[:10]:
+        exp = pow(a, -1, O.P) if a % O.P else 0
+        assert H.call("hh_bn_fp_op", 4, _fp(a), _fp(0), out_sizes=(32,))[1] == _fp(exp)
+
+
+def test_golden_bdn_fixtures(G):
+    Hm = O.g1_marshal(O.hash_to_g1(G["bdn_msg"].encode()))
+    base2 = O.g2_marshal(O.G2_GEN)
+    for priv, pub, sig in zip(G["bdn_privs"], G["bdn_pubs"], G["bdn_sigs"]):
+        k = bytes.fromhex(priv)
+        assert H.call("hh_bn_g2_mul", k, base2, out_sizes=(128,)) == (0, bytes.fromhex(pub))
+        assert H.call("hh_bn_g1_mul", k, Hm, out_sizes=(64,)) == (0, bytes.fromhex(sig))
+        # the fixture signature verifies: e(H, X) == e(sig, G2)
+        assert H.call("hh_bn_pair_check", Hm, bytes.fromhex(pub), bytes.fromhex(sig), base2, out_sizes=(1,)) == (0, b"\x01")
+    assert H.call("hh_bn_pair_check", Hm, bytes.fromhex(G["bdn_pubs"][0]), bytes.fromhex(G["bdn_sigs"][1]), base2,
+                  out_sizes=(1,)) == (0, b"\x00")
+
+
+def test_wire_edge_cases():
+    x, y = O.G1_GEN
+    assert H.call("hh_bn_g1_decode", bytes(64))[0] == 0
+    assert H.call("hh_bn_g1_decode", _fp(5) + _fp(5))[0] == 1
+    one = _fp(1)
+    # non-canonical coordinate (x + p) is accepted and reduced
+    assert H.call("hh_bn_g1_mul", one, _fp(x + O.P) + _fp(y), out_sizes=(64,)) == (0, O.g1_marshal(O.G1_GEN))
+    # infinity in -> 64 zero bytes out; (p, p) is infinity too
+    assert H.call("hh_bn_g1_mul", _fp(7), bytes(64), out_sizes=(64,)) == (0, bytes(64))
+    assert H.call("hh_bn_g1_mul", _fp(7), _fp(O.P) * 2, out_sizes=(64,)) == (0, bytes(64))
+    assert H.call("hh_bn_g2_mul", _fp(7), bytes(128), out_sizes=(128,)) == (0, bytes(128))
+    assert H.call("hh_bn_g2_decode", _fp(1) * 4)[0] == 1
+
+
+def test_scalar_mul_vs_oracle():
+    rng = random.Random(4)
+    ks = [0, 1, 2, 16, 17, O.ORDER - 1, O.ORDER, O.ORDER + 3, (1 << 256) - 1] + [rng.randrange(O.ORDER) for _ in range(5)]
+    h = rng.randrange(1, O.ORDER)
+    p1 = O.g1_marshal(O.g1_mul(h, O.G1_GEN))
+    p2 = O.g2_marshal(O.g2_mul(h, O.G2_GEN))
+    for k in ks:
+        assert H.call("hh_bn_g1_mul", _fp(k), p1, out_sizes=(64,)) == (0, O.g1_mul_bytes(_fp(k), p1)), hex(k)
+        assert H.call("hh_bn_g2_mul", _fp(k), p2, out_sizes=(128,)) == (0, O.g2_mul_bytes(_fp(k), p2)), hex(k)
+
+
+def test_pairing_bytes_vs_oracle():
+    rng = random.Random(5)
+    for _ in range(2):
+        g1 = O.g1_marshal(O.g1_mul(rng.randrange(1, O.ORDER), O.G1_GEN))
+        g2 = O.g2_marshal(O.g2_mul(rng.randrange(1, O.ORDER), O.G2_GEN))
+        assert H.call("hh_bn_pair", g1, g2, out_sizes=(384,)) == (0, O.pair_bytes(g1, g2))
+    one = O.gt_marshal(O.F12_ONE)
+    assert H.call("hh_bn_pair", bytes(64), g2, out_sizes=(384,)) == (0, one)
+    assert H.call("hh_bn_pair", g1, bytes(128), out_sizes=(384,)) == (0, one)
+
+
+def test_pairing_off_subgroup_g2_vs_oracle():
+    rng = random.Random(10)
+    for _ in range(64):
+        x = (rng.randrange(O.P), rng.randrange(O.P))
+        y = O.f2_sqrt(O.f2_add(O.f2_mul(O.f2_sqr(x), x), O.TWIST_B))
+        if y is None:
+            continue
+        q = O.g2_marshal((x, y))
+        g1 = O.g1_marshal(O.g1_mul(12345, O.G1_GEN))
+        assert H.call("hh_bn_pair", g1, q, out_sizes=(384,)) == (0, O.pair_bytes(g1, q))
+        return
+    raise AssertionError
