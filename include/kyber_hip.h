@@ -151,6 +151,30 @@ int kyb_bn256_pair_check(size_t n, const uint8_t *p1, const uint8_t *p2, const u
 int kyb_bn256_pair_check_dev(size_t n, const void *d_p1, const void *d_p2, const void *d_inv1, const void *d_inv2,
                              void *d_ok, void *d_status, void *stream);
 
+/* ------------------------------------------------------- multi-scalar multiplication
+ * out = sum_i scalars[i] * points[i]  (one point).  The reference has no MSM function: its
+ * MSM-shaped call sites do N x (Mul + Add) sequentially -- share.PubPoly.Eval (share/poly.go:340-348),
+ * share.RecoverCommit (share/poly.go:449-476), bdn.AggregateSignatures / AggregatePublicKeys
+ * (sign/bdn/bdn.go:126-181, mask.go:57-61).  Encodings are canonical, so the Pippenger result is
+ * byte-identical to that sequential sum.  status[i] reports undecodable inputs; if any input is
+ * rejected the output is all-zero bytes.  n == 0 yields the encoding of the identity.
+ * The _dev variants use the per-device workspace: one MSM in flight per device at a time.        */
+int kyb_ed25519_msm(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t out[32], uint8_t *status);
+int kyb_ed25519_msm_dev(size_t n, const void *d_scalars, const void *d_points, void *d_out, void *d_status,
+                        void *stream);
+int kyb_bls12381_g1_msm(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t out[48], uint8_t *status);
+int kyb_bls12381_g2_msm(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t out[96], uint8_t *status);
+int kyb_bls12381_g1_msm_dev(size_t n, const void *d_scalars, const void *d_points, void *d_out, void *d_status,
+                            void *stream);
+int kyb_bls12381_g2_msm_dev(size_t n, const void *d_scalars, const void *d_points, void *d_out, void *d_status,
+                            void *stream);
+int kyb_bn256_g1_msm(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t out[64], uint8_t *status);
+int kyb_bn256_g2_msm(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t out[128], uint8_t *status);
+int kyb_bn256_g1_msm_dev(size_t n, const void *d_scalars, const void *d_points, void *d_out, void *d_status,
+                         void *stream);
+int kyb_bn256_g2_msm_dev(size_t n, const void *d_scalars, const void *d_points, void *d_out, void *d_status,
+                         void *stream);
+
 #ifdef __cplusplus
 }
 #endif

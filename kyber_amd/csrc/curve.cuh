@@ -138,6 +138,55 @@ KYB_HD_NOINLINE void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
     r = o;
 }
 
+// Mixed addition r = p + (x2, y2) with the second operand affine (madd-2007-bl, 7M + 4S), exceptional
+// cases handled: p at infinity, q at infinity (q_inf), p = q (doubling), p = -q (infinity).
+template <class F>
+KYB_HD_NOINLINE void jac_madd(Jac<F>& r, const Jac<F>& p, const F& x2, const F& y2, bool q_inf) {
+    const bool pinf = jac_is_inf(p);
+    F Z1Z1, U2, S2, H, HH, I, J, rr, V, t;
+    f_sqr(Z1Z1, p.Z);
+    f_mul(U2, x2, Z1Z1);
+    f_mul(t, p.Z, Z1Z1);
+    f_mul(S2, y2, t);
+    f_sub(H, U2, p.X);
+    f_sub(rr, S2, p.Y);
+    if (!pinf && !q_inf && f_is_zero(H)) {
+        if (f_is_zero(rr)) {
+            jac_dbl(r, p);
+        } else {
+            jac_set_inf(r);
+        }
+        return;
+    }
+    Jac<F> o;
+    f_sqr(HH, H);
+    f_dbl(I, HH);
+    f_dbl(I, I);
+    f_mul(J, H, I);
+    f_dbl(rr, rr);
+    f_mul(V, p.X, I);
+    f_sqr(o.X, rr);
+    f_sub(o.X, o.X, J);
+    f_sub(o.X, o.X, V);
+    f_sub(o.X, o.X, V);
+    f_sub(t, V, o.X);
+    f_mul(t, rr, t);
+    f_mul(J, p.Y, J);
+    f_dbl(J, J);
+    f_sub(o.Y, t, J);
+    f_add(t, p.Z, H);
+    f_sqr(t, t);
+    f_sub(t, t, Z1Z1);
+    f_sub(o.Z, t, HH);
+    Jac<F> q;
+    q.X = x2;
+    q.Y = y2;
+    f_one(q.Z);
+    jac_cmov(o, q, pinf);
+    jac_cmov(o, p, q_inf);
+    r = o;
+}
+
 // Signed radix-16 digits of a 256-bit scalar given as eight little-endian words:
 // e[0..63] in [-8, 8), e[64] in {0, 1}.
 KYB_HD void recode16_u256(int8_t (&e)[65], const uint32_t (&k)[8]) {

@@ -9,6 +9,7 @@
 //   FromBytes/ToBytes ge.go:99-150       -> fused into the kernels
 #include "context.h"
 #include "ge25519.cuh"
+#include "msm.cuh"
 
 namespace kyb {
 
@@ -365,5 +366,71 @@ int kyb_ed25519_debug_base_table(int32_t* out) {
     if (rc) return rc;
     KYB_HIP_CHECK(hipMemcpy(out, ctx->ed_base_tab, ED_TAB_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost));
     return KYB_OK;
+}
+}
+
+// ---------------------------------------------------------------- MSM (msm.cuh pipeline)
+// sum_i a_i * A_i with a_i plain 256-bit integers: what PubPoly.Eval / RecoverCommit
+// (share/poly.go:340-348, 449-476) compute with N x (Mul + Add).
+namespace kyb {
+struct EdMsm {
+    using Aff = ge_precomp;  // (y + x, y - x, 2dxy): one unified mixed addition = 7M
+    using Acc = ge_p3;
+    static constexpr int WIRE = 32, OUT = 32;
+    __device__ static int decode(Aff& a, const uint8_t* wire) {
+        uint32_t w[8];
+        load_words8(w, reinterpret_cast<const uint32_t*>(wire));
+        ge_p3 p;
+        const bool ok = ge_p3_fromwords(p, w);
+        fe one;
+        fe_1(one);
+        fe_add(a.ypx, p.Y, p.X);
+        fe_sub(a.ymx, p.Y, p.X);
+        fe_mul(a.ypx, a.ypx, one);  // reduce the sums so table entries stay in the multiplier's input range
+        fe_mul(a.ymx, a.ymx, one);
+        fe_mul(a.xy2d, p.T, fe_d2());
+        return ok ? KYB_ST_OK : KYB_ST_BAD_POINT;
+    }
+    __device__ static void scalar_words(uint32_t (&k)[8], const uint8_t* wire) {
+        load_words8(k, reinterpret_cast<const uint32_t*>(wire));
+    }
+    __device__ static void identity(Acc& a) { ge_p3_0(a); }
+    __device__ static void madd(Acc& acc, const Aff& p, bool neg) {
+        ge_precomp t = p;
+        ge_precomp_cneg(t, neg);
+        ge_p1p1 r;
+        ge_madd(r, acc, t);
+        ge_p1p1_to_p3(acc, r);
+    }
+    __device__ static void add(Acc& r, const Acc& a, const Acc& b) {
+        ge_cached c;
+        ge_p3_to_cached(c, b);
+        ge_p1p1 t;
+        ge_add(t, a, c);
+        ge_p1p1_to_p3(r, t);
+    }
+    __device__ static void dbl(Acc& r, const Acc& a) {
+        ge_p1p1 t;
+        ge_dbl(t, a.X, a.Y, a.Z);
+        ge_p1p1_to_p3(r, t);
+    }
+    __device__ static void encode(uint8_t* out, const Acc& a) {
+        uint32_t w[8];
+        ge_p3_towords(w, a);
+        store_words8(reinterpret_cast<uint32_t*>(out), w);
+    }
+};
+}  // namespace kyb
+
+extern "C" {
+int kyb_ed25519_msm(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t out[32], uint8_t* status) {
+    return kyb::msm::run_host<kyb::EdMsm>(n, scalars, points, out, status);
+}
+int kyb_ed25519_msm_dev(size_t n, const void* d_scalars, const void* d_points, void* d_out, void* d_status,
+                        void* stream) {
+    kyb::DeviceCtx* ctx;
+    int rc = kyb::get_ctx(&ctx);
+    if (rc) return rc;
+    return kyb::msm::run<kyb::EdMsm>(ctx, n, d_scalars, d_points, d_out, d_status, (hipStream_t)stream);
 }
 }

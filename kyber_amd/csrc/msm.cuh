@@ -1,0 +1,326 @@
+// Multi-scalar multiplication  sum_i k_i * P_i -> one point  (Pippenger bucket method) for any of
+// the engine's groups, written once over a small curve adapter.
+//
+// Replaces the reference's sequential N x (Mul + Add) at its MSM-shaped call sites
+// (share/poly.go:340-348 PubPoly.Eval, :449-476 RecoverCommit, sign/bdn/bdn.go:126-161
+// AggregateSignatures, sign/bdn/mask.go:57-61); the reference has no MSM function, and because
+// encodings are canonical any correct summation order gives the same bytes.
+//
+// Pipeline (all on one stream, no host synchronisation):
+//   1 decode    : lane i decodes point i to affine form in HBM (AoS, one gather unit per point),
+//                 recodes scalar i into signed c-bit digits and histograms them per (window, |digit|)
+//   2 scan      : exclusive prefix sum of the histogram -> start offset of every bucket
+//   3 scatter   : counting sort of point indices (sign in bit 31) by (window, bucket)
+//   4 accumulate: one lane per bucket adds its points (mixed additions, ~n / 2^(c-1) each)
+//   5 reduce    : per window, chunks of buckets -> sum_b b * B_b by running sums, one lane per chunk
+//   6 final     : one lane per window sums its chunks and shifts by 2^(c w); lane 0 adds the windows
+//                 and encodes.  If any input failed to decode the output is all-zero bytes.
+// Sorting instead of atomics on ~150-byte points: the only atomics are 32-bit counters.
+//
+// Adapter A: typename Aff (decoded input), Acc (accumulator); WIRE (input bytes), OUT (output bytes);
+//   decode(Aff&, const uint8_t*) -> status, scalar_words(uint32_t(&)[8], const uint8_t*),
+//   identity(Acc&), madd(Acc&, const Aff&, bool neg), add(Acc&, const Acc&, const Acc&),
+//   dbl(Acc&, const Acc&), encode(uint8_t*, const Acc&).
+#pragma once
+#include "context.h"
+
+namespace kyb {
+namespace msm {
+
+struct Plan {
+    size_t n;
+    int c;        // window bits
+    int nwin;     // number of windows (incl. the carry window)
+    int nb;       // buckets per window = 2^(c-1)
+    int chunk;    // buckets per reduce lane
+    int nchunks;  // chunks per window
+};
+
+inline Plan make_plan(size_t n) {
+    Plan p;
+    p.n = n;
+    int lg = 0;
+    while ((size_t(1) << (lg + 1)) <= n) lg++;
+    int c = lg - 3;
+    if (c < 2) c = 2;
+    if (c > 16) c = 16;
+    p.c = c;
+    p.nwin = (256 + c) / c;  // ceil(257 / c): 256 scalar bits + the recoding carry
+    p.nb = 1 << (c - 1);
+    p.chunk = p.nb < 64 ? p.nb : 64;
+    p.nchunks = p.nb / p.chunk;
+    return p;
+}
+
+// signed digit w of k (c-bit windows, digits in [-2^(c-1), 2^(c-1)]), computed independently per window:
+// digit = raw_w + carry_in(w) - (carry_out << c), carry_in(w) = 1 iff the lower part, recoded, overflowed.
+// Sequential recoding is cheap (<= 129 steps), so each lane recodes its whole scalar once.
+template <int MAXWIN>
+__device__ __forceinline__ void recode(int32_t (&dig)[MAXWIN], const uint32_t (&k)[8], int c, int nwin) {
+    int carry = 0;
+    const int half = 1 << (c - 1);
+    for (int w = 0; w < nwin; w++) {
+        const int bit = w * c;
+        uint32_t raw = 0;
+        if (bit < 256) {
+            const int idx = bit >> 5, sh = bit & 31;
+            raw = k[idx] >> sh;
+            if (sh + c > 32 && idx + 1 < 8) raw |= k[idx + 1] << (32 - sh);
+            raw &= (1u << c) - 1;
+        }
+        int d = (int)raw + carry;
+        carry = d > half ? 1 : 0;
+        d -= carry << c;
+        dig[w] = d;
+    }
+}
+
+template <class A>
+__global__ __launch_bounds__(64) void decode_kernel(Plan p, const uint8_t* __restrict__ scalars,
+                                                    const uint8_t* __restrict__ points,
+                                                    typename A::Aff* __restrict__ aff, int32_t* __restrict__ digits,
+                                                    uint32_t* __restrict__ hist, uint8_t* __restrict__ status,
+                                                    uint32_t* __restrict__ bad) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    typename A::Aff a;
+    const int st = A::decode(a, points + (size_t)A::WIRE * i);
+    aff[i] = a;
+    if (status) status[i] = (uint8_t)st;
+    if (st) atomicAdd(bad, 1u);
+    uint32_t k[8];
+    A::scalar_words(k, scalars + 32 * i);
+    int32_t dig[129];
+    recode<129>(dig, k, p.c, p.nwin);
+    for (int w = 0; w < p.nwin; w++) {
+        const int d = st ? 0 : dig[w];
+        digits[(size_t)w * p.n + i] = d;
+        if (d) atomicAdd(&hist[(size_t)w * p.nb + (d < 0 ? -d : d) - 1], 1u);
+    }
+}
+
+// exclusive scan of hist[0..m) into offs[0..m], single workgroup
+static __global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* __restrict__ hist, uint32_t* __restrict__ offs,
+                                                    size_t m) {
+    __shared__ uint32_t part[1024];
+    const size_t per = (m + 1023) / 1024;
+    const size_t lo = threadIdx.x * per, hi = lo + per < m ? lo + per : m;
+    uint32_t s = 0;
+    for (size_t j = lo; j < hi; j++) s += hist[j];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int t = 0; t < 1024; t++) {
+            const uint32_t v = part[t];
+            part[t] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (size_t j = lo; j < hi; j++) {
+        offs[j] = run;
+        run += hist[j];
+    }
+    if (threadIdx.x == 1023) offs[m] = run;
+}
+
+static __global__ __launch_bounds__(256) void scatter_kernel(Plan p, const int32_t* __restrict__ digits,
+                                                      const uint32_t* __restrict__ offs,
+                                                      uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= p.n * (size_t)p.nwin) return;
+    const size_t w = t / p.n, i = t - w * p.n;
+    const int d = digits[t];
+    if (!d) return;
+    const size_t b = w * p.nb + (d < 0 ? -d : d) - 1;
+    const uint32_t pos = atomicAdd(&cursor[b], 1u);
+    sorted[offs[b] + pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+}
+
+template <class A>
+__global__ __launch_bounds__(64) void accumulate_kernel(Plan p, const typename A::Aff* __restrict__ aff,
+                                                        const uint32_t* __restrict__ offs,
+                                                        const uint32_t* __restrict__ sorted,
+                                                        typename A::Acc* __restrict__ buckets) {
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= (size_t)p.nwin * p.nb) return;
+    typename A::Acc acc;
+    A::identity(acc);
+    const uint32_t lo = offs[b], hi = offs[b + 1];
+#pragma unroll 1
+    for (uint32_t j = lo; j < hi; j++) {
+        const uint32_t e = sorted[j];
+        const typename A::Aff pt = aff[e & 0x7fffffffu];
+        A::madd(acc, pt, (e >> 31) != 0);
+    }
+    buckets[b] = acc;
+}
+
+// partial[w][ch] = sum_{b in chunk} (b + 1) * B_b   (b = bucket index from 0, digit value b + 1)
+template <class A>
+__global__ __launch_bounds__(64) void reduce_kernel(Plan p, const typename A::Acc* __restrict__ buckets,
+                                                    typename A::Acc* __restrict__ partial) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)p.nwin * p.nchunks) return;
+    const size_t w = t / p.nchunks, ch = t - w * p.nchunks;
+    const int lo = (int)ch * p.chunk;
+    typename A::Acc run, tot;
+    A::identity(run);
+    A::identity(tot);
+#pragma unroll 1
+    for (int b = lo + p.chunk - 1; b >= lo; b--) {
+        const typename A::Acc bk = buckets[w * p.nb + b];
+        A::add(run, run, bk);
+        A::add(tot, tot, run);
+    }
+    // tot = sum (b - lo + 1) B_b ; add lo * run   (lo < 2^15)
+    typename A::Acc m;
+    A::identity(m);
+#pragma unroll 1
+    for (int bit = 14; bit >= 0; bit--) {
+        A::dbl(m, m);
+        if ((lo >> bit) & 1) A::add(m, m, run);
+    }
+    A::add(tot, tot, m);
+    partial[t] = tot;
+}
+
+template <class A>
+__global__ __launch_bounds__(256) void final_kernel(Plan p, const typename A::Acc* __restrict__ partial,
+                                                    typename A::Acc* __restrict__ winsum, const uint32_t* __restrict__ bad,
+                                                    uint8_t* __restrict__ out) {
+    const int w = threadIdx.x;
+    if (w < p.nwin) {
+        typename A::Acc s;
+        A::identity(s);
+#pragma unroll 1
+        for (int ch = 0; ch < p.nchunks; ch++) {
+            const typename A::Acc v = partial[(size_t)w * p.nchunks + ch];
+            A::add(s, s, v);
+        }
+#pragma unroll 1
+        for (int k = 0; k < w * p.c; k++) A::dbl(s, s);
+        winsum[w] = s;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        typename A::Acc s;
+        A::identity(s);
+#pragma unroll 1
+        for (int k = 0; k < p.nwin; k++) {
+            const typename A::Acc v = winsum[k];
+            A::add(s, s, v);
+        }
+        if (*bad) {
+            for (int k = 0; k < A::OUT; k++) out[k] = 0;
+        } else {
+            A::encode(out, s);
+        }
+    }
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+// Enqueue the whole MSM on `st`.  d_status may be null.  n == 0 writes the identity encoding.
+template <class A>
+int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, void* d_out, void* d_status,
+        hipStream_t st) {
+    if (n >= (size_t(1) << 31)) {
+        set_error("msm: n too large");
+        return KYB_E_ARG;
+    }
+    const Plan p = make_plan(n ? n : 1);
+    Plan pr = p;
+    pr.n = n;
+    const size_t nbk = (size_t)p.nwin * p.nb;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += align256(bytes);
+        return o;
+    };
+    const size_t o_aff = take(sizeof(typename A::Aff) * (n ? n : 1));
+    const size_t o_dig = take(sizeof(int32_t) * (n ? n : 1) * p.nwin);
+    const size_t o_sorted = take(sizeof(uint32_t) * (n ? n : 1) * p.nwin);
+    const size_t o_hist = take(sizeof(uint32_t) * nbk);
+    const size_t o_cursor = take(sizeof(uint32_t) * nbk);
+    const size_t o_bad = take(256);
+    const size_t zero_end = off;  // hist, cursor, bad are zeroed together
+    const size_t o_offs = take(sizeof(uint32_t) * (nbk + 1));
+    const size_t o_buckets = take(sizeof(typename A::Acc) * nbk);
+    const size_t o_partial = take(sizeof(typename A::Acc) * (size_t)p.nwin * p.nchunks);
+    const size_t o_winsum = take(sizeof(typename A::Acc) * p.nwin);
+    void* ws;
+    int rc = ctx_workspace(ctx, off, &ws);
+    if (rc) return rc;
+    uint8_t* base = (uint8_t*)ws;
+    auto* aff = (typename A::Aff*)(base + o_aff);
+    auto* digits = (int32_t*)(base + o_dig);
+    auto* sorted = (uint32_t*)(base + o_sorted);
+    auto* hist = (uint32_t*)(base + o_hist);
+    auto* cursor = (uint32_t*)(base + o_cursor);
+    auto* bad = (uint32_t*)(base + o_bad);
+    auto* offs = (uint32_t*)(base + o_offs);
+    auto* buckets = (typename A::Acc*)(base + o_buckets);
+    auto* partial = (typename A::Acc*)(base + o_partial);
+    auto* winsum = (typename A::Acc*)(base + o_winsum);
+    KYB_HIP_CHECK(hipMemsetAsync(hist, 0, zero_end - o_hist, st));
+    if (n) {
+        hipLaunchKernelGGL(decode_kernel<A>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, pr, (const uint8_t*)d_scalars,
+                           (const uint8_t*)d_points, aff, digits, hist, (uint8_t*)d_status, bad);
+    }
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, hist, offs, nbk);
+    if (n) {
+        const size_t tot = n * (size_t)p.nwin;
+        hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, pr, digits, offs, cursor,
+                           sorted);
+    }
+    hipLaunchKernelGGL(accumulate_kernel<A>, dim3((unsigned)((nbk + 63) / 64)), dim3(64), 0, st, pr, aff, offs, sorted,
+                       buckets);
+    const size_t nred = (size_t)p.nwin * p.nchunks;
+    hipLaunchKernelGGL(reduce_kernel<A>, dim3((unsigned)((nred + 63) / 64)), dim3(64), 0, st, pr, buckets, partial);
+    hipLaunchKernelGGL(final_kernel<A>, dim3(1), dim3(256), 0, st, pr, partial, winsum, bad, (uint8_t*)d_out);
+    KYB_HIP_CHECK(hipGetLastError());
+    return KYB_OK;
+}
+
+// Host-buffer wrapper: copy in, run, copy out, synchronise.
+template <class A>
+int run_host(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* out, uint8_t* status) {
+    if ((n && (!scalars || !points)) || !out) {
+        set_error("msm: bad argument");
+        return KYB_E_ARG;
+    }
+    DeviceCtx* ctx;
+    int rc = get_ctx(&ctx);
+    if (rc) return rc;
+    uint8_t *d_s = nullptr, *d_p = nullptr, *d_o = nullptr, *d_st = nullptr;
+    KYB_HIP_CHECK(hipMalloc(&d_s, n * 32 + 1));
+    KYB_HIP_CHECK(hipMalloc(&d_p, n * A::WIRE + 1));
+    KYB_HIP_CHECK(hipMalloc(&d_o, A::OUT));
+    KYB_HIP_CHECK(hipMalloc(&d_st, n + 1));
+    if (n) {
+        KYB_HIP_CHECK(hipMemcpy(d_s, scalars, n * 32, hipMemcpyHostToDevice));
+        KYB_HIP_CHECK(hipMemcpy(d_p, points, n * A::WIRE, hipMemcpyHostToDevice));
+    }
+    rc = run<A>(ctx, n, d_s, d_p, d_o, d_st, nullptr);
+    if (rc == KYB_OK) {
+        hipError_t e = hipMemcpy(out, d_o, A::OUT, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && status && n) e = hipMemcpy(status, d_st, n, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            set_error(std::string("msm D2H: ") + hipGetErrorString(e));
+            rc = KYB_E_HIP;
+        }
+    }
+    hipFree(d_s);
+    hipFree(d_p);
+    hipFree(d_o);
+    hipFree(d_st);
+    return rc;
+}
+
+}  // namespace msm
+}  // namespace kyb

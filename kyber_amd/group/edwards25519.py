@@ -118,6 +118,36 @@ def commit(scalars, base=None, vartime: bool = False):
     return out
 
 
+def msm(scalars, points):
+    """(out, status): out = sum_i scalars[i] * points[i] as one 32-byte point -- what PubPoly.Eval /
+    RecoverCommit (share/poly.go:340-348, 449-476) compute with N x (Mul + Add).  Scalars are plain
+    256-bit little-endian integers (never reduced mod l).  If any status is non-zero the output is
+    all-zero bytes."""
+    lib = load()
+    if _is_torch(scalars):
+        import torch
+
+        s = scalars.contiguous().view(-1, 32)
+        p = points.contiguous().view(-1, 32)
+        if s.shape != p.shape:
+            raise ValueError("scalars/points length mismatch")
+        n = s.shape[0]
+        out = torch.empty(32, dtype=torch.uint8, device=s.device)
+        st = torch.empty(max(n, 1), dtype=torch.uint8, device=s.device)
+        check(lib.kyb_ed25519_msm_dev(n, s.data_ptr(), p.data_ptr(), out.data_ptr(), st.data_ptr(), _stream_ptr()),
+              "kyb_ed25519_msm_dev")
+        return out, st[:n]
+    s = _as_host(scalars, 32)
+    p = _as_host(points, 32)
+    if s.shape != p.shape:
+        raise ValueError("scalars/points length mismatch")
+    n = s.shape[0]
+    out = np.empty(32, dtype=np.uint8)
+    st = np.zeros(max(n, 1), dtype=np.uint8)
+    check(lib.kyb_ed25519_msm(n, s.ctypes.data, p.ctypes.data, out.ctypes.data, st.ctypes.data), "kyb_ed25519_msm")
+    return out, st[:n]
+
+
 # ------------------------------------------------------- kyber.Scalar mirror
 class Scalar:
     """kyber.Scalar for Ed25519 (group/edwards25519/scalar.go:32-34): 32 bytes LE."""

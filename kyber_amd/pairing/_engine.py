@@ -80,6 +80,41 @@ class Engine:
     def g2_commit(self, scalars, base=None):
         return self.mul(2, scalars, self.G2_BASE if base is None else base, True)
 
+    def msm(self, group: int, scalars, points):
+        """(out, status): out = sum_i scalars[i] * points[i] as ONE encoded point -- the MSM-shaped call
+        sites of the reference (share/poly.go:340-348, 449-476; sign/bdn/bdn.go:126-181).  If any
+        status is non-zero the output is all-zero bytes."""
+        w = self.G1_LEN if group == 1 else self.G2_LEN
+        if _is_torch(scalars):
+            import torch
+
+            s = scalars.contiguous().view(-1, 32)
+            p = points.contiguous().view(-1, w)
+            n = s.shape[0]
+            if p.shape[0] != n:
+                raise ValueError("scalars/points length mismatch")
+            out = torch.empty(w, dtype=torch.uint8, device=s.device)
+            st = torch.empty(max(n, 1), dtype=torch.uint8, device=s.device)
+            fn, nm = self._fn(f"g{group}_msm_dev")
+            check(fn(n, s.data_ptr(), p.data_ptr(), out.data_ptr(), st.data_ptr(), _stream()), nm)
+            return out, st[:n]
+        s = _host(scalars, 32)
+        p = _host(points, w)
+        n = s.shape[0]
+        if p.shape[0] != n:
+            raise ValueError("scalars/points length mismatch")
+        out = np.empty(w, dtype=np.uint8)
+        st = np.zeros(max(n, 1), dtype=np.uint8)
+        fn, nm = self._fn(f"g{group}_msm")
+        check(fn(n, s.ctypes.data, p.ctypes.data, out.ctypes.data, st.ctypes.data), nm)
+        return out, st[:n]
+
+    def g1_msm(self, scalars, points):
+        return self.msm(1, scalars, points)
+
+    def g2_msm(self, scalars, points):
+        return self.msm(2, scalars, points)
+
     def batch_pair(self, g1, g2):
         """(gt, status): gt[i] = e(g1[i], g2[i])  (N x Suite.Pair)."""
         if _is_torch(g1):
