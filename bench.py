@@ -1,21 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): Ed25519 batched fixed-base + variable-base
-scalar multiplication, 2^20 scalars per GPU.  One "step" = one pass of the hot
-path over one batch: 2^20 x Point.Mul(s, nil) (fixed-base) followed by
-2^20 x Point.Mul(s, P) (variable-base, compressed points in, compressed out),
-inputs already resident in HBM.  value = scalar-muls/s over the whole job.
+Headline workload (BASELINE.json configs[1]): Ed25519 batched fixed-base + variable-base scalar
+multiplication, 2^20 scalars per GPU.  One "step" = one pass of the hot path over one batch:
+2^20 x Point.Mul(s, nil) (fixed-base) followed by 2^20 x Point.Mul(s, P) (variable-base; compressed
+points in, compressed points out), inputs already resident in HBM.  value = scalar-muls/s over the
+whole job.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the batch shards
-trivially -- every rank owns its own 2^20-element batch (weak scaling); there
-is no data-path collective for independent scalar multiplications, only the
-timing barrier and a MAX all-reduce of the elapsed time.
+N > 1 (launched by torch.distributed.run, one rank per GPU): the batch shards trivially -- every
+rank owns its own 2^20-element batch (weak scaling); independent scalar multiplications have no
+data-path collective, only the timing barrier and a MAX all-reduce of the elapsed time.
+
+BASELINE.json's metric is composite ("scalar-muls/s + pairings/s per node; MSM sec at 2^20"), so the
+same JSON line also carries, under "other_workloads", the BLS12-381 pairing rates at 2^16 pairs per
+GPU (configs[3]), the node-wide BLS12-381 G1 MSM time at 2^20 points sharded over the ranks with
+the RCCL all-gather of partial points (configs[2]) and the bn256 pairing rate (configs[4]); they
+are measured outside the headline's timed region.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
-import ctypes
 import hashlib
 import json
 import os
@@ -32,10 +36,10 @@ N_PER_GPU = 1 << 20
 # algorithmic bytes per unit: var-base 32+32 in, 32 out; fixed-base 32 in, 32 out
 BYTES_VAR, BYTES_FIX = 96, 64
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# field multiplications (M) / squarings (S) per variable-base op as built:
-#   decode 14M+255S... counted exactly in DESIGN.md; products per M = 100, per S = 55 (v_mad_i64_i32)
-IMADS_VAR = None  # filled from DESIGN.md numbers below
-IMAD_PEAK = None  # lane-MADs/s measured by tools/valu_peak (profiles/valu_peak_r01.json)
+# 64-bit integer multiply-adds (v_mad_i64_i32) per scalar multiplication as built:
+# a field multiplication is 100 MADs, a squaring 55; variable-base = 1366 M + 1517 S, fixed-base = 475 M + 270 S
+IMADS_VAR = 1366 * 100 + 1517 * 55
+IMADS_FIX = 475 * 100 + 270 * 55
 
 
 def shake(label: bytes, nbytes: int) -> np.ndarray:
@@ -43,9 +47,9 @@ def shake(label: bytes, nbytes: int) -> np.ndarray:
 
 
 def make_inputs(n: int, rank: int):
-    """Deterministic synthetic inputs: canonical scalars (< 2^252 <= l) from
-    labelled SHAKE-256 streams; points P_i = h_i * B produced by the verified
-    fixed-base path (prime-order subgroup, like util/key/key.go:41-49)."""
+    """Deterministic synthetic inputs: canonical scalars (< 2^252 <= l) from labelled SHAKE-256 streams;
+    points P_i = h_i * B produced by the verified fixed-base path (prime-order subgroup, like
+    util/key/key.go:41-49)."""
     s = shake(b"kyberhip/v1/ed25519/scalars/%d" % rank, n * 32).reshape(n, 32).copy()
     h = shake(b"kyberhip/v1/ed25519/point-seeds/%d" % rank, n * 32).reshape(n, 32).copy()
     s[:, 31] &= 0x0F
@@ -53,25 +57,108 @@ def make_inputs(n: int, rank: int):
     return s, h
 
 
+def be_scalars(label: bytes, n: int) -> np.ndarray:
+    """n big-endian 32-byte scalars < 2^254 (valid for both pairing curves' plain-integer semantics)."""
+    a = shake(label, n * 32).reshape(n, 32).copy()
+    a[:, 0] &= 0x3F
+    return a
+
+
 def cpu_baseline(scalars: np.ndarray, points: np.ndarray):
-    """The oracle's C restatement (kind "port") on all host cores, bounded sample."""
+    """The oracle's C restatement (kind "port") on the host cores, bounded sample (~10-20 s)."""
     from tests import _oracle_c as OC
 
     cores = os.cpu_count() or 1
-    probe = 512
+
+    def rate(n, threads):
+        t0 = time.perf_counter()
+        OC.ed_mul(scalars[:n], points[:n], threads=threads)
+        OC.ed_mul_base(scalars[:n], threads=threads)
+        return 2 * n / (time.perf_counter() - t0)
+
+    r1 = rate(2048, 1)
+    rall = rate(min(len(scalars), 2048 * min(cores, 64)), cores)
+    threads = cores if rall > r1 else 1
+    per_s = max(r1, rall)
+    n = int(min(len(scalars), max(4096, per_s * 5.0)))  # ~10 s of CPU work (two kernels x 5 s)
     t0 = time.perf_counter()
-    OC.ed_mul(scalars[:probe], points[:probe], threads=cores)
-    OC.ed_mul_base(scalars[:probe], threads=cores)
+    OC.ed_mul(scalars[:n], points[:n], threads=threads)
+    OC.ed_mul_base(scalars[:n], threads=threads)
     dt = time.perf_counter() - t0
-    target_s = 6.0
-    n = int(min(len(scalars), max(probe, probe * target_s / max(dt, 1e-6))))
-    t0 = time.perf_counter()
-    OC.ed_mul(scalars[:n], points[:n], threads=cores)
-    OC.ed_mul_base(scalars[:n], threads=cores)
-    dt = time.perf_counter() - t0
-    return {"value": 2 * n / dt, "unit": "scalar-muls/s", "cores": cores, "kind": "port",
+    return {"value": 2 * n / dt, "unit": "scalar-muls/s", "cores": threads, "kind": "port",
+            "single_thread_value": r1,
             "sample": f"{n} fixed-base + {n} variable-base Ed25519 scalar-muls of the same batch, "
-                      f"oracle/ed25519_ref.c (radix-2^51 C restatement of ge.go:373/443), {cores} threads"}
+                      f"oracle/ed25519_ref.c (radix-2^51 C restatement of ge.go:373/443, gcc -O3), "
+                      f"{threads} thread(s) of {cores} logical cores; the Go reference itself cannot run "
+                      f"here (no Go toolchain)"}
+
+
+def timed(fn, reps):
+    import torch
+
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def other_workloads(rank, world, dist):
+    """BLS12-381 / bn256 pairing rates and the node-wide G1 MSM (outside the headline timing)."""
+    import torch
+
+    from kyber_amd import dist as kd
+    from kyber_amd.pairing import bls12381 as bls, bn256 as bn
+
+    out = {}
+    npair = 1 << 16
+    for name, m in (("bls12381", bls), ("bn256", bn)):
+        k = torch.from_numpy(be_scalars(b"kyberhip/v1/%s/k/%d" % (name.encode(), rank), npair)).cuda()
+        h = torch.from_numpy(be_scalars(b"kyberhip/v1/%s/h/%d" % (name.encode(), rank), npair)).cuda()
+        g1b = torch.from_numpy(np.frombuffer(m.G1_BASE, dtype=np.uint8).copy()).cuda()
+        g2b = torch.from_numpy(np.frombuffer(m.G2_BASE, dtype=np.uint8).copy()).cuda()
+        P, st1 = m._mul(1, h, g1b, True)
+        Q, st2 = m._mul(2, k, g2b, True)
+        ms_pair = timed(lambda: m.batch_pair(P, Q), 2)
+        # valid BLS-verify shaped quadruples: e(H, X) == e(sig, G2) with sig = x H  (sign/bls/bls.go:36-38)
+        sig, _ = m.g1_batch_mul(k, P)
+        G2 = g2b.repeat(npair, 1)
+        ok, st3 = m.batch_validate_pairing(P, Q, sig, G2)
+        ms_chk = timed(lambda: m.batch_validate_pairing(P, Q, sig, G2), 2)
+        ms_g1 = timed(lambda: m.g1_batch_mul(k, P), 2)
+        ms_g2 = timed(lambda: m.g2_batch_mul(k, Q), 2)
+        t = torch.tensor([ms_pair, ms_chk, ms_g1, ms_g2], dtype=torch.float64, device="cuda")
+        if dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms_pair, ms_chk, ms_g1, ms_g2 = [float(x) for x in t]
+        good = bool(ok.all().item()) and not (st1.any().item() or st2.any().item() or st3.any().item())
+        out[name] = {"pairs_per_gpu": npair, "pairings_per_s": world * npair / ms_pair * 1e3,
+                     "pairing_checks_per_s": world * npair / ms_chk * 1e3,
+                     "g1_muls_per_s": world * npair / ms_g1 * 1e3, "g2_muls_per_s": world * npair / ms_g2 * 1e3,
+                     "all_checks_true": good}
+        if name == "bls12381":
+            # node-wide MSM at 2^20 points: points sharded over the ranks, all-gather of the partial points
+            n = 1 << 20
+            lo, hi = kd.shard_range(n, rank, world)
+            ks = torch.from_numpy(be_scalars(b"kyberhip/v1/msm/k", n)[lo:hi].copy()).cuda()
+            hs = torch.from_numpy(be_scalars(b"kyberhip/v1/msm/h", n)[lo:hi].copy()).cuda()
+            pts, _ = m._mul(1, hs, g1b, True)
+            if dist:
+                fn = lambda: kd.bls12381_g1_msm(ks, pts)
+            else:
+                fn = lambda: m.g1_msm(ks, pts)
+            ms = timed(fn, 2)
+            t = torch.tensor([ms], dtype=torch.float64, device="cuda")
+            if dist:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            out["bls12381_g1_msm_2p20"] = {"points": n, "seconds": float(t.item()) * 1e-3, "scaling": "strong",
+                                           "exchange": "all-gather of %d encoded partial points" % world if dist else "none"}
+            del ks, hs, pts
+    return out
 
 
 def main():
@@ -81,6 +168,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=N_PER_GPU, help="elements per GPU (default 2^20)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other", action="store_true", help="skip the pairing / MSM side measurements")
     args = ap.parse_args()
 
     import torch
@@ -120,6 +208,7 @@ def main():
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
+    # HIP events on the launch stream (torch's current stream is the one the C ABI is handed)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     ev0 = torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
@@ -136,7 +225,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-kernel durations from HIP events on the launch stream
     var_ms = [a.elapsed_time(b) for a, b in evs]
     fix_ms = []
     prev = ev0
@@ -145,10 +233,21 @@ def main():
         prev = b
     var_ms_avg = sum(var_ms) / len(var_ms)
     fix_ms_avg = sum(fix_ms) / len(fix_ms)
-
     ok = int(outs[2].sum().item()) == 0
+
+    other = None
+    if not args.no_other:
+        other = other_workloads(rank, world, dist)
+
     if rank == 0:
         total_ops = 2 * n * args.steps * world
+        var_s = var_ms_avg * 1e-3
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "roofline_inputs.json")))
+        except Exception:
+            prof = {}
+        imad_peak = prof.get("imad_peak_lane_ops_per_s")
+        traffic = prof.get("ed25519_mul_kernel_hbm_bytes_per_launch")
         res = {
             "metric": "scalar-muls/s + pairings/s per node; MSM sec at 2^20 points",
             "value": total_ops / elapsed,
@@ -160,26 +259,23 @@ def main():
             "config": {"workload": "Ed25519 batched fixed-base + var-base scalar-mul, 2^20 scalars per GPU "
                                    "(BASELINE.json configs[1])",
                        "elements_per_gpu": n, "sharding": f"independent batches x{world}, no collective"},
-            "detail": {"var_base_per_s_per_gpu": n / (var_ms_avg * 1e-3),
+            "detail": {"var_base_per_s_per_gpu": n / var_s,
                        "fixed_base_per_s_per_gpu": n / (fix_ms_avg * 1e-3),
                        "var_base_kernel_ms": var_ms_avg, "fixed_base_kernel_ms": fix_ms_avg,
                        "all_status_ok": ok},
-            "roofline": {"bound": "hbm", "kernel": "ed25519_mul_kernel (variable-base)",
-                         "achieved": BYTES_VAR * n / (var_ms_avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": BYTES_VAR * n / (var_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "traffic": None,
-                         "note": "integer-VALU bound, not HBM bound: see valu sub-object and DESIGN.md"},
+            "roofline": {"bound": "hbm", "kernel": "ed25519_mul_kernel (variable-base, dominant: ~80% of a step)",
+                         "achieved": BYTES_VAR * n / var_s / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": BYTES_VAR * n / var_s / 1e9 / HBM_PEAK_GBS,
+                         "traffic": traffic,
+                         "binding_resource": "integer VALU issue (v_mad_i64_i32), not HBM and not MFMA: "
+                                             "96 algorithmic bytes per 2.2e5 integer MADs -- see 'valu'",
+                         "valu": {"imads_per_op": IMADS_VAR, "achieved": IMADS_VAR * n / var_s,
+                                  "peak": imad_peak, "unit": "v_mad_i64_i32 lane-ops/s",
+                                  "frac": (IMADS_VAR * n / var_s / imad_peak) if imad_peak else None,
+                                  "peak_source": "tools/valu_peak.hip measured on MI355X (profiles/r01_valu_peak.json)"}},
         }
-        try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "valu_model.json")))
-            imads = prof["imads_per_var_base_op"]
-            peak = prof["imad_peak_lane_ops_per_s"]
-            ach = imads * n / (var_ms_avg * 1e-3)
-            res["roofline"]["valu"] = {"achieved": ach, "peak": peak, "unit": "v_mad_i64_i32 lane-ops/s",
-                                       "frac": ach / peak, "traffic_bytes_per_launch": prof.get("hbm_bytes_per_launch")}
-            res["roofline"]["traffic"] = prof.get("hbm_bytes_per_launch")
-        except Exception:
-            pass
+        if other is not None:
+            res["other_workloads"] = other
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(s_h, d_pts.cpu().numpy())
         print(json.dumps(res))
