@@ -272,7 +272,7 @@ KYB_HD_NOINLINE void pow_u(fp12& r, const fp12& a) {
     fp12 acc = a;
 #pragma unroll 1
     for (int i = 61; i >= 0; i--) {
-        fp12_sqr(acc, acc);
+        fp12_cyclo_sqr(acc, acc);  // inputs are in the cyclotomic subgroup: equals gfP12.Square there
         if ((CC::U >> i) & 1) fp12_mul(acc, acc, a);
     }
     r = acc;
