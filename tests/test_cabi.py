@@ -37,7 +37,8 @@ def test_version_and_error_string_without_gpu():
 
 def test_headers_cite_reference_lines():
     src = open(os.path.join(ROOT, "include", "kyber_hip.h")).read()
-    for cite in ("ge.go:373", "ge.go:443", "share/poly.go:143"):
+    for cite in ("ge.go:373", "ge.go:443", "share/poly.go:143", "kilic/suite.go:57-68", "optate.go:266",
+                 "share/poly.go:340-348", "point.go:630-662"):
         assert cite in src
 
 
