@@ -179,7 +179,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # KYB_BENCH_FORCE_DIST=1 exercises the RCCL path (init, barrier, all-gather) with a single rank
+    if world > 1 or os.environ.get("KYB_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

@@ -116,6 +116,11 @@ int kyb_bls12381_g2_mul_dev(size_t n, const void *d_scalars, const void *d_point
 /* gt[i] = e(g1[i], g2[i]).  Replaces Suite.Pair (pairing/pairing.go:12; kilic/suite.go:70-75). */
 int kyb_bls12381_pair(size_t n, const uint8_t *g1, const uint8_t *g2, uint8_t *gt, uint8_t *status);
 int kyb_bls12381_pair_dev(size_t n, const void *d_g1, const void *d_g2, void *d_gt, void *d_status, void *stream);
+/* out[i] = gt[i] ^ scalars[i].  Replaces GTElt.Mul (kilic/gt.go:79-84 -> GT.Exp); inputs are checked
+ * like GT.FromBytes (coefficients < p, order-r subgroup). */
+int kyb_bls12381_gt_mul(size_t n, const uint8_t *scalars, const uint8_t *gt, uint8_t *out, uint8_t *status);
+int kyb_bls12381_gt_mul_dev(size_t n, const void *d_scalars, const void *d_gt, void *d_out, void *d_status,
+                            void *stream);
 /* ok[i] = (e(p1[i], p2[i]) == e(inv1[i], inv2[i])).  Replaces Suite.ValidatePairing
  * (pairing/pairing.go:13-15; kilic/suite.go:57-68), the core of sign/bls Verify (bls.go:82-96). */
 int kyb_bls12381_pair_check(size_t n, const uint8_t *p1, const uint8_t *p2, const uint8_t *inv1, const uint8_t *inv2,
@@ -145,6 +150,10 @@ int kyb_bn256_g2_mul_dev(size_t n, const void *d_scalars, const void *d_points, 
 /* gt[i] = e(g1[i], g2[i]): Suite.Pair (pairing/bn256/suite.go:97-103 -> optate.go:266-274). */
 int kyb_bn256_pair(size_t n, const uint8_t *g1, const uint8_t *g2, uint8_t *gt, uint8_t *status);
 int kyb_bn256_pair_dev(size_t n, const void *d_g1, const void *d_g2, void *d_gt, void *d_status, void *stream);
+/* out[i] = gt[i] ^ scalars[i]: pointGT.Mul (pairing/bn256/point.go:613-628 -> gfP12.Exp gfp12.go:177);
+ * like pointGT.UnmarshalBinary (point.go:664-716) coefficients are reduced mod p and nothing is rejected. */
+int kyb_bn256_gt_mul(size_t n, const uint8_t *scalars, const uint8_t *gt, uint8_t *out, uint8_t *status);
+int kyb_bn256_gt_mul_dev(size_t n, const void *d_scalars, const void *d_gt, void *d_out, void *d_status, void *stream);
 /* ok[i] = Pair(p1, p2).Equal(Pair(inv1, inv2)): Suite.ValidatePairing (suite.go:105-107). */
 int kyb_bn256_pair_check(size_t n, const uint8_t *p1, const uint8_t *p2, const uint8_t *inv1, const uint8_t *inv2,
                          uint8_t *ok, uint8_t *status);

@@ -51,6 +51,8 @@ SIGNATURES = {
     "kyb_bls12381_g1_mul_dev": [_sz, _vp, _vp, _sz, _vp, _vp, _vp],
     "kyb_bls12381_g2_mul_dev": [_sz, _vp, _vp, _sz, _vp, _vp, _vp],
     "kyb_bls12381_pair": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_bls12381_gt_mul": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_bls12381_gt_mul_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
     "kyb_bls12381_pair_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
     "kyb_bls12381_pair_check": [_sz, _vp, _vp, _vp, _vp, _vp, _vp],
     "kyb_bls12381_pair_check_dev": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -61,6 +63,8 @@ SIGNATURES = {
     "kyb_bn256_g1_mul_dev": [_sz, _vp, _vp, _sz, _vp, _vp, _vp],
     "kyb_bn256_g2_mul_dev": [_sz, _vp, _vp, _sz, _vp, _vp, _vp],
     "kyb_bn256_pair": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_bn256_gt_mul": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_bn256_gt_mul_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
     "kyb_bn256_pair_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
     "kyb_bn256_pair_check": [_sz, _vp, _vp, _vp, _vp, _vp, _vp],
     "kyb_bn256_pair_check_dev": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -72,14 +72,14 @@ KYB_HD_NOINLINE bool g2_in_subgroup(const g2_aff& a) {
     fp2_load_const<TC>(cx, CC::PSI_CX);
     fp2_load_const<TC>(cy, CC::PSI_CY);
     fp2_conj(px, a.x);
-    fp2_mul(px, px, cx);
+    fp2_mul_c(px, px, cx);
     fp2_conj(py, a.y);
-    fp2_mul(py, py, cy);
+    fp2_mul_c(py, py, cy);
     fp2_neg(py, py);
-    fp2_sqr(z2, q.Z);
-    fp2_mul(z3, z2, q.Z);
-    fp2_mul(l, px, z2);
-    fp2_mul(r, py, z3);
+    fp2_sqr_c(z2, q.Z);
+    fp2_mul_c(z3, z2, q.Z);
+    fp2_mul_c(l, px, z2);
+    fp2_mul_c(r, py, z3);
     const bool ok = fp2_eq(l, q.X) & fp2_eq(r, q.Y) & !fp2_is_zero(q.Z);
     return a.inf | ok;
 }
@@ -171,8 +171,8 @@ KYB_HD_NOINLINE int g2_decode(g2_aff& a, const uint8_t* in, bool check_subgroup)
     fp_from_words<FC>(x.c0, w0);
     fp_from_words<FC>(x.c1, w1);
     fp2_load_const<TC>(b, CC::B2);
-    fp2_sqr(rhs, x);
-    fp2_mul(rhs, rhs, x);
+    fp2_sqr_c(rhs, x);
+    fp2_mul_c(rhs, rhs, x);
     fp2_add(rhs, rhs, b);
     if (!fp2_sqrt(y, rhs)) return ST_BAD_POINT;
     fp2_neg(t, y);
@@ -226,6 +226,37 @@ KYB_HD_NOINLINE void gt_encode(uint8_t* out, const fp12& f) {
             words_to_be<12>(out + (h * 3 + m) * 96 + 48, w);
         }
     }
+}
+// GT.FromBytes of the kilic backend (kilic/gt.go:100-104): 576 bytes, every coefficient < p, and
+// membership of the order-r subgroup (f^r = 1).  Layout as gt_encode.
+KYB_HD_NOINLINE int gt_decode(fp12& f, const uint8_t* in) {
+    bool ok = true;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        fp6& s = h == 0 ? f.c1 : f.c0;
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            fp2& c = m == 0 ? s.c2 : (m == 1 ? s.c1 : s.c0);
+            uint32_t w[12];
+            words_from_be<12>(w, in + (h * 3 + m) * 96);
+            ok = ok & fp_words_lt_p<FC>(w);
+            fp_from_words<FC>(c.c1, w);
+            words_from_be<12>(w, in + (h * 3 + m) * 96 + 48);
+            ok = ok & fp_words_lt_p<FC>(w);
+            fp_from_words<FC>(c.c0, w);
+        }
+    }
+    return ok ? ST_OK : ST_BAD_POINT;
+}
+KYB_HD_NOINLINE void gt_pow_u256(fp12& r, const fp12& a, const uint32_t (&k)[8]) {
+    fp12 acc;
+    fp12_one(acc);
+#pragma unroll 1
+    for (int i = 255; i >= 0; i--) {
+        fp12_sqr(acc, acc);
+        if ((k[i >> 5] >> (i & 31)) & 1) fp12_mul(acc, acc, a);
+    }
+    r = acc;
 }
 // 32-byte big-endian scalar (mod.Int wire format, group/mod/int.go:334-350) -> little-endian words
 KYB_HD void scalar_from_be(uint32_t (&k)[8], const uint8_t* in) { words_from_be<8>(k, in); }
@@ -400,6 +431,24 @@ KYB_HD int g2_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt
     jac_mul_u256(r, p, k);
     jac_to_aff(a, r);
     g2_encode(out, a);
+    return ST_OK;
+}
+// out = gt^k   (GTElt.Mul, kilic/gt.go:79-84 -> GT.Exp).  Rejected input: status + zero output.
+KYB_HD int gt_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* gt) {
+    fp12 f, t;
+    int st = gt_decode(f, gt);
+    if (st == ST_OK) {
+        gt_pow_u256(t, f, CC::R_WORDS);
+        if (!fp12_is_one(t)) st = ST_NOT_IN_SUBGROUP;
+    }
+    if (st != ST_OK) {
+        zero_bytes(out, 576);
+        return st;
+    }
+    uint32_t k[8];
+    scalar_from_be(k, scalar_be);
+    gt_pow_u256(f, f, k);
+    gt_encode(out, f);
     return ST_OK;
 }
 // gt = e(P, Q)   (Suite.Pair, kilic/suite.go:70-75)

@@ -69,9 +69,9 @@ KYB_HD_NOINLINE int g2_decode(g2_aff& a, const uint8_t* in) {
     a.inf = fp2_is_zero(a.x) & fp2_is_zero(a.y);
     fp2 y2, x3, b;
     fp2_load_const<TC>(b, CC::B2);
-    fp2_sqr(y2, a.y);
-    fp2_sqr(x3, a.x);
-    fp2_mul(x3, x3, a.x);
+    fp2_sqr_c(y2, a.y);
+    fp2_sqr_c(x3, a.x);
+    fp2_mul_c(x3, x3, a.x);
     fp2_add(x3, x3, b);
     return (a.inf || fp2_eq(y2, x3)) ? ST_OK : ST_BAD_POINT;
 }
@@ -252,18 +252,18 @@ KYB_HD_NOINLINE void miller(fp12& ret, const g2_aff& q, const g1_aff& p) {
     fp2 q1x, q1y, k;
     fp2_conj(q1x, q.x);
     fp2_load_const<TC>(k, CC::Q1X);
-    fp2_mul(q1x, q1x, k);
+    fp2_mul_c(q1x, q1x, k);
     fp2_conj(q1y, q.y);
     fp2_load_const<TC>(k, CC::Q1Y);
-    fp2_mul(q1y, q1y, k);
-    fp2_sqr(r2, q1y);
+    fp2_mul_c(q1y, q1y, k);
+    fp2_sqr_c(r2, q1y);
     line_add(a, b, c, r, q1x, q1y, r2, p.x, p.y);
     mul_line(ret, a, b, c);
     fp q2k;
     fp_const(q2k, CC::Q2X);
     fp2 q2x;
     fp2_mul_fp(q2x, q.x, q2k);
-    fp2_sqr(r2, q.y);
+    fp2_sqr_c(r2, q.y);
     line_add(a, b, c, r, q2x, q.y, r2, p.x, p.y);
     mul_line(ret, a, b, c);
 }
@@ -325,6 +325,32 @@ KYB_HD void optimal_ate(fp12& f, const g2_aff& q, const g1_aff& p) {
     if (q.inf | p.inf) fp12_one(f);
 }
 
+// pointGT.UnmarshalBinary (point.go:664-716): twelve coefficients reduced mod p, no membership check
+KYB_HD_NOINLINE void gt_decode(fp12& f, const uint8_t* in) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        fp6& s = h == 0 ? f.c1 : f.c0;
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            fp2& c = m == 0 ? s.c2 : (m == 1 ? s.c1 : s.c0);
+            fp_decode(c.c1, in + (h * 3 + m) * 64);
+            fp_decode(c.c0, in + (h * 3 + m) * 64 + 32);
+        }
+    }
+}
+// gfP12.Exp (gfp12.go:177-192) for a plain 256-bit exponent; general Fp12 squarings because
+// UnmarshalBinary admits elements outside the cyclotomic subgroup
+KYB_HD_NOINLINE void gt_pow_u256(fp12& r, const fp12& a, const uint32_t (&k)[8]) {
+    fp12 acc;
+    fp12_one(acc);
+#pragma unroll 1
+    for (int i = 255; i >= 0; i--) {
+        fp12_sqr(acc, acc);
+        if ((k[i >> 5] >> (i & 31)) & 1) fp12_mul(acc, acc, a);
+    }
+    r = acc;
+}
+
 // ------------------------------------------------- per-element wire-level operations
 KYB_HD void zero_bytes(uint8_t* out, int n) {
     uint32_t* q = reinterpret_cast<uint32_t*>(out);
@@ -360,6 +386,16 @@ KYB_HD int g2_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt
     jac_mul_u256(r, p, k);
     jac_to_aff(a, r);
     g2_encode(out, a);
+    return ST_OK;
+}
+// out = gt^k   (pointGT.Mul, point.go:613-628 -> gfP12.Exp)
+KYB_HD int gt_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* gt) {
+    fp12 f;
+    gt_decode(f, gt);
+    uint32_t k[8];
+    words_from_be<8>(k, scalar_be);
+    gt_pow_u256(f, f, k);
+    gt_encode(out, f);
     return ST_OK;
 }
 // gt = e(g1, g2)   (Suite.Pair, suite.go:97-103)

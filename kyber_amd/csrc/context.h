@@ -28,6 +28,7 @@ struct DeviceCtx {
     int num_cu = 0;
     bool ready = false;
     std::mutex mu;
+    std::mutex msm_mu;  // serialises host-buffer MSM calls (they share the workspace)
     // Ed25519 fixed-base table: [33][8][3][10] int32 (built on device at init)
     int32_t* ed_base_tab = nullptr;
     // scratch workspace (host entry points stage through it)

@@ -11,8 +11,8 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define KYB_HD __host__ __device__ __forceinline__
-#define KYB_HD_NOINLINE __host__ __device__ __noinline__
+#define KYB_HD_NOINLINE __host__ __device__ __noinline__ inline
 #else
 #define KYB_HD inline
-#define KYB_HD_NOINLINE __attribute__((noinline))
+#define KYB_HD_NOINLINE __attribute__((noinline)) inline
 #endif

@@ -168,9 +168,69 @@ KYB_HD void fp_mul(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
 #pragma unroll
     for (int j = 0; j < N; j++) r.v[j] = s[j];
 }
+// r = a^2 * R^-1 mod p.  Same interleaved product/reduction walk as fp_mul, but row i only adds
+// a_i^2 and the doubled cross products 2 a_i a_j (j > i): N(N+1)/2 + N^2 MADs instead of 2 N^2
+// (BLS12-381: 260 vs 338).  `cnt` tracks, per window slot, how many 2^(2W)-sized products the
+// column may hold (a doubled product counts twice); all of it folds at compile time after unrolling.
 template <class C>
 KYB_HD void fp_sqr(Fp<C>& r, const Fp<C>& a) {
-    fp_mul(r, a, a);
+    constexpr int N = C::N, W = C::W;
+    constexpr uint32_t MASK = (1u << W) - 1;
+    constexpr int MAXP = (W >= 32) ? 0 : (int)((~0ull) / ((uint64_t)MASK * MASK)) - 1;
+    static_assert(MAXP >= 6, "limb width too large for lazy column accumulation");
+    uint64_t t[N];
+    int cnt[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        t[j] = 0;
+        cnt[j] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        bool need = false;
+#pragma unroll
+        for (int j = 0; j < N; j++) need |= cnt[j] + (j == i ? 2 : (j > i ? 3 : 1)) > MAXP;
+        if (need) {
+#pragma unroll
+            for (int j = 0; j < N - 1; j++) {
+                t[j + 1] += t[j] >> W;
+                t[j] &= MASK;
+            }
+#pragma unroll
+            for (int j = 0; j < N; j++) cnt[j] = 1;
+        }
+        const uint32_t ai = a.v[i], ai2 = ai << 1;
+        t[i] += (uint64_t)ai * ai;
+#pragma unroll
+        for (int j = i + 1; j < N; j++) t[j] += (uint64_t)ai2 * a.v[j];
+        const uint32_t m = ((uint32_t)t[0] * C::NINV) & MASK;
+#pragma unroll
+        for (int j = 0; j < N; j++) t[j] += (uint64_t)m * C::P[j];
+#pragma unroll
+        for (int j = 0; j < N; j++) cnt[j] += (j == i ? 2 : (j > i ? 3 : 1));
+        const uint64_t carry = t[0] >> W;
+        // slide the window one column up; slot indices of the not-yet-added rows shift with it, so the
+        // products of row i' > i still land on slot (column - base): re-index by rotating t
+#pragma unroll
+        for (int j = 0; j < N - 1; j++) {
+            t[j] = t[j + 1];
+            cnt[j] = cnt[j + 1];
+        }
+        t[N - 1] = 0;
+        cnt[N - 1] = 0;
+        t[0] += carry;
+        cnt[0] += 1;
+    }
+    uint32_t s[N];
+#pragma unroll
+    for (int j = 0; j < N - 1; j++) {
+        t[j + 1] += t[j] >> W;
+        s[j] = (uint32_t)t[j] & MASK;
+    }
+    s[N - 1] = (uint32_t)t[N - 1];
+    fp_reduce_once<C>(s);
+#pragma unroll
+    for (int j = 0; j < N; j++) r.v[j] = s[j];
 }
 
 // Small-constant multiples

@@ -297,6 +297,8 @@ int run_host(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* o
     DeviceCtx* ctx;
     int rc = get_ctx(&ctx);
     if (rc) return rc;
+    // the pipeline lives in the per-device workspace: host-buffer MSM calls on one device are serialised
+    std::lock_guard<std::mutex> ws_lock(ctx->msm_mu);
     uint8_t *d_s = nullptr, *d_p = nullptr, *d_o = nullptr, *d_st = nullptr;
     KYB_HIP_CHECK(hipMalloc(&d_s, n * 32 + 1));
     KYB_HIP_CHECK(hipMalloc(&d_p, n * A::WIRE + 1));

@@ -1,5 +1,5 @@
 // Batch kernels + C-ABI entry points shared by the pairing suites (BLS12-381, bn256).
-// KYB_DEFINE_PAIRING_ABI(PFX, NS, G1SZ, G2SZ, GTSZ) stamps out, for the curve library in
+// KYB_DEFINE_MUL_ABI / KYB_DEFINE_PAIR_ABI(PFX, NS, G1SZ, G2SZ[, GTSZ]) stamp out, for the curve library in
 // namespace kyb::NS (g1_mul_wire / g2_mul_wire / pair_wire / pair_check_wire), one kernel per
 // operation -- one group operation / pairing per lane, one wave per workgroup -- and the host /
 // device-pointer entry points kyb_<PFX>_* declared in include/kyber_hip.h.
@@ -41,7 +41,7 @@ struct StageBuf {
         if (rc_) return rc_; \
     } while (0)
 
-#define KYB_DEFINE_PAIRING_ABI(PFX, NS, G1SZ, G2SZ, GTSZ) \
+#define KYB_DEFINE_MUL_ABI(PFX, NS, G1SZ, G2SZ) \
 namespace kyb { \
 __global__ __launch_bounds__(64) void PFX##_g1_mul_kernel(size_t n, const uint8_t* __restrict__ scalars, \
                                                         const uint8_t* __restrict__ pts, size_t pt_stride, \
@@ -59,28 +59,7 @@ __global__ __launch_bounds__(64) void PFX##_g2_mul_kernel(size_t n, const uint8_
     const int st = NS::g2_mul_wire(out + G2SZ * idx, scalars + 32 * idx, pts + pt_stride * idx); \
     if (status) status[idx] = (uint8_t)st; \
 } \
-__global__ __launch_bounds__(64) void PFX##_pair_kernel(size_t n, const uint8_t* __restrict__ g1, \
-                                                      const uint8_t* __restrict__ g2, uint8_t* __restrict__ gt, \
-                                                      uint8_t* __restrict__ status) { \
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
-    if (idx >= n) return; \
-    const int st = NS::pair_wire(gt + GTSZ * idx, g1 + G1SZ * idx, g2 + G2SZ * idx); \
-    if (status) status[idx] = (uint8_t)st; \
 } \
-__global__ __launch_bounds__(64) void PFX##_pair_check_kernel(size_t n, const uint8_t* __restrict__ p1, \
-                                                            const uint8_t* __restrict__ p2, \
-                                                            const uint8_t* __restrict__ i1, \
-                                                            const uint8_t* __restrict__ i2, uint8_t* __restrict__ ok, \
-                                                            uint8_t* __restrict__ status) { \
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
-    if (idx >= n) return; \
-    uint8_t r = 0; \
-    const int st = NS::pair_check_wire(&r, p1 + G1SZ * idx, p2 + G2SZ * idx, i1 + G1SZ * idx, i2 + G2SZ * idx); \
-    ok[idx] = r; \
-    if (status) status[idx] = (uint8_t)st; \
-} \
-} \
- \
 extern "C" { \
 int kyb_##PFX##_g1_mul_dev(size_t n, const void* d_scalars, const void* d_points, size_t point_stride, \
                             void* d_out, void* d_status, void* stream) { \
@@ -105,30 +84,6 @@ int kyb_##PFX##_g2_mul_dev(size_t n, const void* d_scalars, const void* d_points
     hipLaunchKernelGGL(kyb::PFX##_g2_mul_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
                        (const uint8_t*)d_scalars, (const uint8_t*)d_points, point_stride, (uint8_t*)d_out, \
                        (uint8_t*)d_status); \
-    KYB_HIP_CHECK(hipGetLastError()); \
-    return KYB_OK; \
-} \
-int kyb_##PFX##_pair_dev(size_t n, const void* d_g1, const void* d_g2, void* d_gt, void* d_status, void* stream) { \
-    if (n && (!d_g1 || !d_g2 || !d_gt)) { \
-        kyb::set_error("kyb_" #PFX "_pair_dev: bad argument"); \
-        return KYB_E_ARG; \
-    } \
-    if (!n) return KYB_OK; \
-    hipLaunchKernelGGL(kyb::PFX##_pair_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
-                       (const uint8_t*)d_g1, (const uint8_t*)d_g2, (uint8_t*)d_gt, (uint8_t*)d_status); \
-    KYB_HIP_CHECK(hipGetLastError()); \
-    return KYB_OK; \
-} \
-int kyb_##PFX##_pair_check_dev(size_t n, const void* d_p1, const void* d_p2, const void* d_inv1, const void* d_inv2, \
-                                void* d_ok, void* d_status, void* stream) { \
-    if (n && (!d_p1 || !d_p2 || !d_inv1 || !d_inv2 || !d_ok)) { \
-        kyb::set_error("kyb_" #PFX "_pair_check_dev: bad argument"); \
-        return KYB_E_ARG; \
-    } \
-    if (!n) return KYB_OK; \
-    hipLaunchKernelGGL(kyb::PFX##_pair_check_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
-                       (const uint8_t*)d_p1, (const uint8_t*)d_p2, (const uint8_t*)d_inv1, (const uint8_t*)d_inv2, \
-                       (uint8_t*)d_ok, (uint8_t*)d_status); \
     KYB_HIP_CHECK(hipGetLastError()); \
     return KYB_OK; \
 } \
@@ -166,6 +121,93 @@ int kyb_##PFX##_g1_mul_same_base(size_t n, const uint8_t* scalars, const uint8_t
 int kyb_##PFX##_g2_mul_same_base(size_t n, const uint8_t* scalars, const uint8_t* point, uint8_t* out, \
                                   uint8_t* status) { \
     return PFX##_mul_host(true, n, scalars, point, 0, out, status); \
+} \
+}
+
+#define KYB_DEFINE_PAIR_ABI(PFX, NS, G1SZ, G2SZ, GTSZ) \
+namespace kyb { \
+__global__ __launch_bounds__(64) void PFX##_pair_kernel(size_t n, const uint8_t* __restrict__ g1, \
+                                                      const uint8_t* __restrict__ g2, uint8_t* __restrict__ gt, \
+                                                      uint8_t* __restrict__ status) { \
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
+    if (idx >= n) return; \
+    const int st = NS::pair_wire(gt + GTSZ * idx, g1 + G1SZ * idx, g2 + G2SZ * idx); \
+    if (status) status[idx] = (uint8_t)st; \
+} \
+__global__ __launch_bounds__(64) void PFX##_gt_mul_kernel(size_t n, const uint8_t* __restrict__ scalars, \
+                                                        const uint8_t* __restrict__ gts, uint8_t* __restrict__ out, \
+                                                        uint8_t* __restrict__ status) { \
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
+    if (idx >= n) return; \
+    const int st = NS::gt_mul_wire(out + GTSZ * idx, scalars + 32 * idx, gts + GTSZ * idx); \
+    if (status) status[idx] = (uint8_t)st; \
+} \
+__global__ __launch_bounds__(64) void PFX##_pair_check_kernel(size_t n, const uint8_t* __restrict__ p1, \
+                                                            const uint8_t* __restrict__ p2, \
+                                                            const uint8_t* __restrict__ i1, \
+                                                            const uint8_t* __restrict__ i2, uint8_t* __restrict__ ok, \
+                                                            uint8_t* __restrict__ status) { \
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
+    if (idx >= n) return; \
+    uint8_t r = 0; \
+    const int st = NS::pair_check_wire(&r, p1 + G1SZ * idx, p2 + G2SZ * idx, i1 + G1SZ * idx, i2 + G2SZ * idx); \
+    ok[idx] = r; \
+    if (status) status[idx] = (uint8_t)st; \
+} \
+} \
+extern "C" { \
+int kyb_##PFX##_pair_dev(size_t n, const void* d_g1, const void* d_g2, void* d_gt, void* d_status, void* stream) { \
+    if (n && (!d_g1 || !d_g2 || !d_gt)) { \
+        kyb::set_error("kyb_" #PFX "_pair_dev: bad argument"); \
+        return KYB_E_ARG; \
+    } \
+    if (!n) return KYB_OK; \
+    hipLaunchKernelGGL(kyb::PFX##_pair_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
+                       (const uint8_t*)d_g1, (const uint8_t*)d_g2, (uint8_t*)d_gt, (uint8_t*)d_status); \
+    KYB_HIP_CHECK(hipGetLastError()); \
+    return KYB_OK; \
+} \
+int kyb_##PFX##_gt_mul_dev(size_t n, const void* d_scalars, const void* d_gt, void* d_out, void* d_status, void* stream) { \
+    if (n && (!d_scalars || !d_gt || !d_out)) { \
+        kyb::set_error("kyb_" #PFX "_gt_mul_dev: bad argument"); \
+        return KYB_E_ARG; \
+    } \
+    if (!n) return KYB_OK; \
+    hipLaunchKernelGGL(kyb::PFX##_gt_mul_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
+                       (const uint8_t*)d_scalars, (const uint8_t*)d_gt, (uint8_t*)d_out, (uint8_t*)d_status); \
+    KYB_HIP_CHECK(hipGetLastError()); \
+    return KYB_OK; \
+} \
+int kyb_##PFX##_gt_mul(size_t n, const uint8_t* scalars, const uint8_t* gt, uint8_t* out, uint8_t* status) { \
+    if (n && (!scalars || !gt || !out)) { \
+        kyb::set_error("kyb_" #PFX "_gt_mul: bad argument"); \
+        return KYB_E_ARG; \
+    } \
+    if (!n) return KYB_OK; \
+    kyb::DeviceCtx* ctx; \
+    KYB_TRY(kyb::get_ctx(&ctx)); \
+    kyb::StageBuf a, b, o, st; \
+    KYB_TRY(a.upload(scalars, n * 32)); \
+    KYB_TRY(b.upload(gt, n * GTSZ)); \
+    KYB_TRY(o.alloc(n * GTSZ)); \
+    KYB_TRY(st.alloc(n)); \
+    KYB_TRY(kyb_##PFX##_gt_mul_dev(n, a.p, b.p, o.p, st.p, nullptr)); \
+    KYB_TRY(o.download(out, n * GTSZ)); \
+    if (status) KYB_TRY(st.download(status, n)); \
+    return KYB_OK; \
+} \
+int kyb_##PFX##_pair_check_dev(size_t n, const void* d_p1, const void* d_p2, const void* d_inv1, const void* d_inv2, \
+                                void* d_ok, void* d_status, void* stream) { \
+    if (n && (!d_p1 || !d_p2 || !d_inv1 || !d_inv2 || !d_ok)) { \
+        kyb::set_error("kyb_" #PFX "_pair_check_dev: bad argument"); \
+        return KYB_E_ARG; \
+    } \
+    if (!n) return KYB_OK; \
+    hipLaunchKernelGGL(kyb::PFX##_pair_check_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
+                       (const uint8_t*)d_p1, (const uint8_t*)d_p2, (const uint8_t*)d_inv1, (const uint8_t*)d_inv2, \
+                       (uint8_t*)d_ok, (uint8_t*)d_status); \
+    KYB_HIP_CHECK(hipGetLastError()); \
+    return KYB_OK; \
 } \
 int kyb_##PFX##_pair(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, uint8_t* status) { \
     if (n && (!g1 || !g2 || !gt)) { \

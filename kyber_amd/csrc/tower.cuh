@@ -94,6 +94,11 @@ KYB_HD_NOINLINE void fp2_inv(Fp2<T>& r, const Fp2<T>& a) {
     fp_neg(r.c1, t);
 }
 
+// Out-of-line copies for code that runs once or a few times per element (inversions, Frobenius maps,
+// decoding): keeps the number of inlined 338-MAD multiplier bodies -- and the compile time -- down.
+template <class T> KYB_HD_NOINLINE void fp2_mul_c(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) { fp2_mul(r, a, b); }
+template <class T> KYB_HD_NOINLINE void fp2_sqr_c(Fp2<T>& r, const Fp2<T>& a) { fp2_sqr(r, a); }
+
 // ----------------------------------------------------------------------- Fp6
 template <class T> KYB_HD void fp6_zero(Fp6<T>& r) { fp2_zero(r.c0); fp2_zero(r.c1); fp2_zero(r.c2); }
 template <class T> KYB_HD void fp6_one(Fp6<T>& r) { fp2_one(r.c0); fp2_zero(r.c1); fp2_zero(r.c2); }
@@ -205,28 +210,31 @@ KYB_HD void fp6_mul_fp2(Fp6<T>& r, const Fp6<T>& a, const Fp2<T>& b) {
 template <class T>
 KYB_HD_NOINLINE void fp6_inv(Fp6<T>& r, const Fp6<T>& a) {
     Fp2<T> t0, t1, t2, d, s;
-    fp2_sqr(t0, a.c0);
-    fp2_mul(s, a.c1, a.c2);
+    fp2_sqr_c(t0, a.c0);
+    fp2_mul_c(s, a.c1, a.c2);
     fp2_mul_xi(s, s);
     fp2_sub(t0, t0, s);  // a0^2 - xi a1 a2
-    fp2_sqr(t1, a.c2);
+    fp2_sqr_c(t1, a.c2);
     fp2_mul_xi(t1, t1);
-    fp2_mul(s, a.c0, a.c1);
+    fp2_mul_c(s, a.c0, a.c1);
     fp2_sub(t1, t1, s);  // xi a2^2 - a0 a1
-    fp2_sqr(t2, a.c1);
-    fp2_mul(s, a.c0, a.c2);
+    fp2_sqr_c(t2, a.c1);
+    fp2_mul_c(s, a.c0, a.c2);
     fp2_sub(t2, t2, s);  // a1^2 - a0 a2
-    fp2_mul(d, a.c2, t1);
-    fp2_mul(s, a.c1, t2);
+    fp2_mul_c(d, a.c2, t1);
+    fp2_mul_c(s, a.c1, t2);
     fp2_add(d, d, s);
     fp2_mul_xi(d, d);
-    fp2_mul(s, a.c0, t0);
+    fp2_mul_c(s, a.c0, t0);
     fp2_add(d, d, s);
     fp2_inv(d, d);
-    fp2_mul(r.c0, t0, d);
-    fp2_mul(r.c1, t1, d);
-    fp2_mul(r.c2, t2, d);
+    fp2_mul_c(r.c0, t0, d);
+    fp2_mul_c(r.c1, t1, d);
+    fp2_mul_c(r.c2, t2, d);
 }
+
+template <class T> KYB_HD_NOINLINE void fp6_mul_c(Fp6<T>& r, const Fp6<T>& a, const Fp6<T>& b) { fp6_mul(r, a, b); }
+template <class T> KYB_HD_NOINLINE void fp6_sqr_c(Fp6<T>& r, const Fp6<T>& a) { fp6_sqr(r, a); }
 
 // ---------------------------------------------------------------------- Fp12
 template <class T> KYB_HD void fp12_one(Fp12<T>& r) { fp6_one(r.c0); fp6_zero(r.c1); }
@@ -268,13 +276,13 @@ KYB_HD_NOINLINE void fp12_sqr(Fp12<T>& r, const Fp12<T>& a) {
 template <class T>
 KYB_HD_NOINLINE void fp12_inv(Fp12<T>& r, const Fp12<T>& a) {
     Fp6<T> t0, t1;
-    fp6_sqr(t0, a.c0);
-    fp6_sqr(t1, a.c1);
+    fp6_sqr_c(t0, a.c0);
+    fp6_sqr_c(t1, a.c1);
     fp6_mul_v(t1, t1);
     fp6_sub(t0, t0, t1);
     fp6_inv(t0, t0);
-    fp6_mul(r.c0, a.c0, t0);
-    fp6_mul(t1, a.c1, t0);
+    fp6_mul_c(r.c0, a.c0, t0);
+    fp6_mul_c(t1, a.c1, t0);
     fp6_neg(r.c1, t1);
 }
 // f * (o0 + o1 v + o4 v w): the sparse line value of an M-type twist (BLS12-381); 13 Fp2 mults
@@ -318,7 +326,7 @@ KYB_HD_NOINLINE void fp12_frob(Fp12<T>& r, const Fp12<T>& a) {
         if (j > 0) {
             Fp2<T> g;
             fp2_load_const<T>(g, T::FROB[K - 1][j]);
-            fp2_mul(c, c, g);
+            fp2_mul_c(c, c, g);
         }
     }
     r = x;

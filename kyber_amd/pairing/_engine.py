@@ -140,6 +140,32 @@ class Engine:
         check(fn(n, a.ctypes.data, b.ctypes.data, gt.ctypes.data, st.ctypes.data), nm)
         return gt, st
 
+    def gt_batch_mul(self, scalars, gts):
+        """(out, status): out[i] = gts[i] ^ scalars[i]  (N x GT Point.Mul: pairing/bn256/point.go:613,
+        kilic/gt.go:79-84)."""
+        if _is_torch(scalars):
+            import torch
+
+            s = scalars.contiguous().view(-1, 32)
+            g = gts.contiguous().view(-1, self.GT_LEN)
+            n = s.shape[0]
+            if g.shape[0] != n:
+                raise ValueError("length mismatch")
+            out = torch.empty_like(g)
+            st = torch.empty(n, dtype=torch.uint8, device=s.device)
+            fn, nm = self._fn("gt_mul_dev")
+            check(fn(n, s.data_ptr(), g.data_ptr(), out.data_ptr(), st.data_ptr(), _stream()), nm)
+            return out, st
+        s, g = _host(scalars, 32), _host(gts, self.GT_LEN)
+        n = s.shape[0]
+        if g.shape[0] != n:
+            raise ValueError("length mismatch")
+        out = np.empty_like(g)
+        st = np.empty(n, dtype=np.uint8)
+        fn, nm = self._fn("gt_mul")
+        check(fn(n, s.ctypes.data, g.ctypes.data, out.ctypes.data, st.ctypes.data), nm)
+        return out, st
+
     def batch_validate_pairing(self, p1, p2, inv1, inv2):
         """(ok, status): ok[i] = e(p1[i], p2[i]) == e(inv1[i], inv2[i])  (N x Suite.ValidatePairing,
         pairing/pairing.go:13-15).  p1/inv1 are G1, p2/inv2 are G2."""
@@ -280,6 +306,13 @@ class Engine:
             def MarshalBinary(self) -> bytes: return self.enc
             def MarshalSize(self) -> int: return eng.GT_LEN
             def Equal(self, o) -> bool: return self.enc == o.enc
+
+            def Mul(self, s, q):
+                out, st = eng.gt_batch_mul(_sc(s).MarshalBinary(), q.enc)
+                if st[0]:
+                    raise ValueError(f"{eng.name}: invalid GT element")
+                self.enc = bytes(out[0])
+                return self
 
             def Pair(self, p1, p2):
                 gt, st = eng.batch_pair(p1.enc, p2.enc)

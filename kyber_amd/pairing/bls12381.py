@@ -26,6 +26,7 @@ g1_commit, g2_commit = ENGINE.g1_commit, ENGINE.g2_commit
 batch_pair, batch_validate_pairing = ENGINE.batch_pair, ENGINE.batch_validate_pairing
 _mul = ENGINE.mul
 g1_msm, g2_msm = ENGINE.g1_msm, ENGINE.g2_msm
+gt_batch_mul = ENGINE.gt_batch_mul
 Scalar, G1Elt, G2Elt, GTElt, Suite = ENGINE.make_types()
 
 

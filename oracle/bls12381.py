@@ -472,3 +472,27 @@ def gt_to_bytes(a) -> bytes:
 
 def pair_bytes(g1: bytes, g2: bytes) -> bytes:
     return gt_to_bytes(pair(g1_decompress(g1), g2_decompress(g2)))
+
+
+def gt_from_bytes(buf: bytes):
+    """kilic GT.FromBytes (kilic/gt.go:100-104): 576 bytes, coefficients < p, order-r subgroup."""
+    if len(buf) != 576:
+        raise DecodeError("length")
+    a = [None] * 6
+    k = 0
+    for half in (1, 0):
+        for m in (2, 1, 0):
+            c1 = int.from_bytes(buf[96 * k:96 * k + 48], "big")
+            c0 = int.from_bytes(buf[96 * k + 48:96 * k + 96], "big")
+            if c0 >= P or c1 >= P:
+                raise DecodeError("coefficient >= p")
+            a[2 * m + half] = (c0, c1)
+            k += 1
+    if f12_pow(a, R) != F12_ONE:
+        raise DecodeError("not in GT")
+    return a
+
+
+def gt_mul_bytes(scalar_be: bytes, gt: bytes) -> bytes:
+    """GTElt.Mul (kilic/gt.go:79-84): gt ^ k."""
+    return gt_to_bytes(f12_pow(gt_from_bytes(gt), scalar_from_be(scalar_be)))

@@ -285,6 +285,26 @@ def gt_marshal(a) -> bytes:
     return out
 
 
+def gt_unmarshal(buf: bytes):
+    """pointGT.UnmarshalBinary (point.go:664-716): coefficients reduced mod p, no membership check."""
+    if len(buf) < 384:
+        raise DecodeError("bn256.GT: not enough data")
+    a = [None] * 6
+    k = 0
+    for half in (1, 0):
+        for m in (2, 1, 0):
+            im = int.from_bytes(buf[64 * k:64 * k + 32], "big") % P
+            re = int.from_bytes(buf[64 * k + 32:64 * k + 64], "big") % P
+            a[2 * m + half] = (re, im)
+            k += 1
+    return a
+
+
+def gt_mul_bytes(scalar_be: bytes, gt: bytes) -> bytes:
+    """pointGT.Mul (point.go:613-628) -> gfP12.Exp (gfp12.go:177-192)."""
+    return gt_marshal(f12_pow(gt_unmarshal(gt), int.from_bytes(scalar_be, "big")))
+
+
 def hash_to_g1(m: bytes):
     """pointG1.Hash -> hashToPoint (point.go:261-313)."""
     x = int.from_bytes(hashlib.sha256(m).digest(), "big") % P

@@ -75,4 +75,6 @@ int hh_bn_pair(const uint8_t* g1, const uint8_t* g2, uint8_t* gt) { return bn::p
 int hh_bn_pair_check(const uint8_t* p1, const uint8_t* p2, const uint8_t* i1, const uint8_t* i2, uint8_t* ok) {
     return bn::pair_check_wire(ok, p1, p2, i1, i2);
 }
+int hh_bn_gt_mul(const uint8_t* k, const uint8_t* gt, uint8_t* out) { return bn::gt_mul_wire(out, k, gt); }
+int hh_bls_gt_mul(const uint8_t* k, const uint8_t* gt, uint8_t* out) { return bls::gt_mul_wire(out, k, gt); }
 }

@@ -158,3 +158,28 @@ def test_suite_mirror(bls):
     assert s.ValidatePairing(P, Q, s.G1().Point().Mul(ab, None), s.G2().Point().Base())
     with pytest.raises(TypeError):
         P.Equal(Q)
+
+
+def test_gt_mul_vs_oracle_and_homomorphism(bls):
+    rng = random.Random(8)
+    g1 = O.g1_compress(O.g1_mul(rng.randrange(1, O.R), O.G1_GEN))
+    g2 = O.g2_compress(O.g2_mul(rng.randrange(1, O.R), O.G2_GEN))
+    gt, _ = bls.batch_pair(g1, g2)
+    ks = [0, 1, O.R - 1, rng.randrange(O.R)]
+    out, st = bls.gt_batch_mul(b"".join(k.to_bytes(32, "big") for k in ks), np.tile(gt, (4, 1)))
+    assert not st.any()
+    for i, k in enumerate(ks):
+        assert bytes(out[i]) == O.gt_mul_bytes(k.to_bytes(32, "big"), bytes(gt[0])), i
+    m = 512
+    k = _scalars(b"bls/gt/k", m)
+    P, _ = bls.g1_commit(_scalars(b"bls/gt/p", m))
+    G2 = np.tile(np.frombuffer(bls.G2_BASE, dtype=np.uint8), (m, 1))
+    e, _ = bls.batch_pair(P, G2)
+    kP, _ = bls.g1_batch_mul(k, P)
+    ek, _ = bls.batch_pair(kP, G2)
+    out, st = bls.gt_batch_mul(k, e)
+    assert not st.any() and (out == ek).all()
+    # rejected inputs: coefficient >= p, and an element outside the order-r subgroup
+    bad = np.stack([np.full(576, 0xFF, dtype=np.uint8), np.frombuffer(bytes(575) + b"\x02", dtype=np.uint8)])
+    out, st = bls.gt_batch_mul(k[:2], bad)
+    assert list(st) == [1, 2] and not out.any()

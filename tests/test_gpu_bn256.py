@@ -140,3 +140,27 @@ def test_suite_mirror(bn):
     ab = s.G1().Scalar().Mul(a, b)
     assert s.Pair(P, Q).Equal(s.Pair(s.G1().Point().Mul(ab, None), s.G2().Point().Base()))
     assert s.ValidatePairing(P, Q, s.G1().Point().Mul(ab, None), s.G2().Point().Base())
+
+
+def test_gt_mul_vs_oracle_and_homomorphism(bn):
+    rng = random.Random(8)
+    n = 4
+    g1 = [O.g1_marshal(O.g1_mul(rng.randrange(1, O.ORDER), O.G1_GEN)) for _ in range(n)]
+    g2 = [O.g2_marshal(O.g2_mul(rng.randrange(1, O.ORDER), O.G2_GEN)) for _ in range(n)]
+    gt, _ = bn.batch_pair(b"".join(g1), b"".join(g2))
+    ks = [0, 1, O.ORDER - 1, rng.randrange(O.ORDER)]
+    kb = b"".join(_fp(k) for k in ks)
+    out, st = bn.gt_batch_mul(kb, gt)
+    assert not st.any()
+    for i in range(n):
+        assert bytes(out[i]) == O.gt_mul_bytes(_fp(ks[i]), bytes(gt[i])), i
+    # e(P, Q)^k == e(kP, Q) at batch scale
+    m = 512
+    k = _scalars(b"bn/gt/k", m)
+    P, _ = bn.g1_commit(_scalars(b"bn/gt/p", m))
+    G2 = np.tile(np.frombuffer(bn.G2_BASE, dtype=np.uint8), (m, 1))
+    e, _ = bn.batch_pair(P, G2)
+    kP, _ = bn.g1_batch_mul(k, P)
+    ek, _ = bn.batch_pair(kP, G2)
+    out, st = bn.gt_batch_mul(k, e)
+    assert not st.any() and (out == ek).all()

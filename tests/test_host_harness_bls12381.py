@@ -133,3 +133,29 @@ def test_pair_check_truth_table():
     assert H.call("hh_bls_pair_check", c(None), c2(X), c(None), c2(O.G2_GEN), out_sizes=(1,)) == (0, b"\x01")
     st, ok = H.call("hh_bls_pair_check", bytes(48), c2(X), c(sig), c2(O.G2_GEN), out_sizes=(1,))
     assert st == 1 and ok == b"\x00"
+
+
+def test_gt_mul_vs_oracle():
+    rng = random.Random(8)
+    g1 = O.g1_compress(O.g1_mul(rng.randrange(1, O.R), O.G1_GEN))
+    g2 = O.g2_compress(O.g2_mul(rng.randrange(1, O.R), O.G2_GEN))
+    gt = O.pair_bytes(g1, g2)
+    for k in (0, 1, 5, O.R - 1, rng.randrange(O.R)):
+        kb = k.to_bytes(32, "big")
+        assert H.call("hh_bls_gt_mul", kb, gt, out_sizes=(576,)) == (0, O.gt_mul_bytes(kb, gt)), hex(k)
+    # e(P, Q)^k == e(kP, Q)
+    k = rng.randrange(O.R)
+    kb = k.to_bytes(32, "big")
+    assert H.call("hh_bls_gt_mul", kb, gt, out_sizes=(576,))[1] == O.pair_bytes(O.g1_mul_bytes(kb, g1), g2)
+    # not in the order-r subgroup / coefficient >= p
+    junk = bytes(576 - 1) + b"\x02"
+    assert H.call("hh_bls_gt_mul", kb, junk, out_sizes=(576,)) == (2, bytes(576))
+    assert H.call("hh_bls_gt_mul", kb, b"\xff" * 576, out_sizes=(576,)) == (1, bytes(576))
+
+
+def test_fp_sqr_dedicated_path():
+    rng = random.Random(12)
+    vals = [0, 1, O.P - 1, (1 << 380) - 1, (1 << 381) - 1 - (1 << 200)] + [rng.randrange(O.P) for _ in range(300)]
+    for a in vals:
+        a %= O.P
+        assert H.call("hh_bls_fp_op", 5, _fp(a), _fp(0), out_sizes=(48,))[1] == _fp(a * a % O.P)

@@ -93,3 +93,22 @@ def test_pairing_off_subgroup_g2_vs_oracle():
         assert H.call("hh_bn_pair", g1, q, out_sizes=(384,)) == (0, O.pair_bytes(g1, q))
         return
     raise AssertionError
+
+
+def test_gt_mul_vs_oracle():
+    rng = random.Random(8)
+    g1 = O.g1_marshal(O.g1_mul(rng.randrange(1, O.ORDER), O.G1_GEN))
+    g2 = O.g2_marshal(O.g2_mul(rng.randrange(1, O.ORDER), O.G2_GEN))
+    gt = O.pair_bytes(g1, g2)
+    for k in (0, 1, 2, O.ORDER - 1, O.ORDER, rng.randrange(O.ORDER)):
+        assert H.call("hh_bn_gt_mul", _fp(k), gt, out_sizes=(384,)) == (0, O.gt_mul_bytes(_fp(k), gt)), hex(k)
+    # an arbitrary Fp12 element (not in GT) is accepted and exponentiated with general squarings
+    junk = bytes(rng.randrange(256) for _ in range(384))
+    k = rng.randrange(1 << 64)
+    assert H.call("hh_bn_gt_mul", _fp(k), junk, out_sizes=(384,)) == (0, O.gt_mul_bytes(_fp(k), junk))
+
+
+def test_fp_sqr_dedicated_path():
+    rng = random.Random(12)
+    for a in [0, 1, O.P - 1, (1 << 256) - 1] + [rng.randrange(O.P) for _ in range(300)]:
+        assert H.call("hh_bn_fp_op", 5, _fp(a), _fp(0), out_sizes=(32,))[1] == _fp(a * a % O.P)
