@@ -11,9 +11,11 @@
 //                 recodes scalar i into signed c-bit digits and histograms them per (window, |digit|)
 //   2 scan      : exclusive prefix sum of the histogram -> start offset of every bucket
 //   3 scatter   : counting sort of point indices (sign in bit 31) by (window, bucket)
-//   4 accumulate: one lane per bucket adds its points (mixed additions, ~n / 2^(c-1) each)
+//   4 accumulate: one lane per bucket piece (<= 64 points; long buckets from skewed digits are split)
+//                 adds its points with mixed additions, then one lane per bucket joins the pieces
 //   5 reduce    : per window, chunks of buckets -> sum_b b * B_b by running sums, one lane per chunk
-//   6 final     : one lane per window sums its chunks and shifts by 2^(c w); lane 0 adds the windows
+//   6 fold+final: chunk partials are folded 32 at a time, then one lane per window sums what is left and
+//                 shifts by 2^(c w); lane 0 adds the windows
 //                 and encodes.  If any input failed to decode the output is all-zero bytes.
 // Sorting instead of atomics on ~150-byte points: the only atomics are 32-bit counters.
 //
@@ -47,7 +49,10 @@ inline Plan make_plan(size_t n) {
     p.c = c;
     p.nwin = (256 + c) / c;  // ceil(257 / c): 256 scalar bits + the recoding carry
     p.nb = 1 << (c - 1);
-    p.chunk = p.nb < 64 ? p.nb : 64;
+    // buckets per reduce lane: enough lanes (>= ~16k) to fill the chip, between 8 and 64 buckets each
+    int chunk = 64;
+    while (chunk > 8 && (size_t)p.nwin * (p.nb / chunk) < 16384) chunk >>= 1;
+    p.chunk = p.nb < chunk ? p.nb : chunk;
     p.nchunks = p.nb / p.chunk;
     return p;
 }
@@ -139,21 +144,63 @@ static __global__ __launch_bounds__(256) void scatter_kernel(Plan p, const int32
     sorted[offs[b] + pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
 }
 
-template <class A>
-__global__ __launch_bounds__(64) void accumulate_kernel(Plan p, const typename A::Aff* __restrict__ aff,
-                                                        const uint32_t* __restrict__ offs,
-                                                        const uint32_t* __restrict__ sorted,
-                                                        typename A::Acc* __restrict__ buckets) {
+constexpr int SUB = 64;  // points per accumulate lane: a bucket longer than this is split (skewed digits)
+
+// nsub[b] = number of SUB-sized pieces of bucket b
+static __global__ __launch_bounds__(256) void subcount_kernel(size_t nbk, const uint32_t* __restrict__ offs,
+                                                              uint32_t* __restrict__ nsub) {
     const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= (size_t)p.nwin * p.nb) return;
+    if (b >= nbk) return;
+    nsub[b] = (offs[b + 1] - offs[b] + SUB - 1) / SUB;
+}
+
+// One lane per bucket piece: sums up to SUB points (mixed additions).  The piece -> bucket map is a
+// binary search in the scanned piece counts.
+template <class A>
+__global__ __launch_bounds__(64) void accumulate_kernel(size_t nbk, size_t max_pieces,
+                                                        const typename A::Aff* __restrict__ aff,
+                                                        const uint32_t* __restrict__ offs,
+                                                        const uint32_t* __restrict__ suboffs,
+                                                        const uint32_t* __restrict__ sorted,
+                                                        typename A::Acc* __restrict__ pieces) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= max_pieces || t >= suboffs[nbk]) return;
+    size_t lo_b = 0, hi_b = nbk;  // largest b with suboffs[b] <= t
+    while (hi_b - lo_b > 1) {
+        const size_t mid = (lo_b + hi_b) >> 1;
+        if (suboffs[mid] <= t) lo_b = mid; else hi_b = mid;
+    }
+    const size_t b = lo_b;
+    const uint32_t j = (uint32_t)(t - suboffs[b]);
+    const uint32_t lo = offs[b] + j * SUB;
+    const uint32_t end = offs[b + 1];
+    const uint32_t hi = lo + SUB < end ? lo + SUB : end;
     typename A::Acc acc;
     A::identity(acc);
-    const uint32_t lo = offs[b], hi = offs[b + 1];
 #pragma unroll 1
-    for (uint32_t j = lo; j < hi; j++) {
-        const uint32_t e = sorted[j];
+    for (uint32_t q = lo; q < hi; q++) {
+        const uint32_t e = sorted[q];
         const typename A::Aff pt = aff[e & 0x7fffffffu];
         A::madd(acc, pt, (e >> 31) != 0);
+    }
+    pieces[t] = acc;
+}
+
+// bucket b = sum of its pieces (one piece for all but skewed buckets)
+template <class A>
+__global__ __launch_bounds__(64) void bucket_kernel(size_t nbk, const uint32_t* __restrict__ suboffs,
+                                                    const typename A::Acc* __restrict__ pieces,
+                                                    typename A::Acc* __restrict__ buckets) {
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbk) return;
+    const uint32_t lo = suboffs[b], hi = suboffs[b + 1];
+    typename A::Acc acc;
+    A::identity(acc);
+    if (hi > lo) acc = pieces[lo];
+#pragma unroll 1
+    for (uint32_t q = lo + 1; q < hi; q++) {
+        const typename A::Acc v = pieces[q];
+        A::add(acc, acc, v);
     }
     buckets[b] = acc;
 }
@@ -187,8 +234,28 @@ __global__ __launch_bounds__(64) void reduce_kernel(Plan p, const typename A::Ac
     partial[t] = tot;
 }
 
+// out[w][g] = sum of in[w][g * G .. g * G + G): folds the per-window chunk partials G at a time so the
+// single-workgroup final step only has a handful of additions per window left
 template <class A>
-__global__ __launch_bounds__(256) void final_kernel(Plan p, const typename A::Acc* __restrict__ partial,
+__global__ __launch_bounds__(64) void fold_kernel(int nwin, int nin, int G, const typename A::Acc* __restrict__ in,
+                                                  typename A::Acc* __restrict__ out) {
+    const int nout = (nin + G - 1) / G;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)nwin * nout) return;
+    const size_t w = t / nout, g = t - w * nout;
+    typename A::Acc s;
+    A::identity(s);
+    const int hi = (int)(g * G + G) < nin ? (int)(g * G + G) : nin;
+#pragma unroll 1
+    for (int k = (int)g * G; k < hi; k++) {
+        const typename A::Acc v = in[w * nin + k];
+        A::add(s, s, v);
+    }
+    out[t] = s;
+}
+
+template <class A>
+__global__ __launch_bounds__(256) void final_kernel(Plan p, int nparts, const typename A::Acc* __restrict__ partial,
                                                     typename A::Acc* __restrict__ winsum, const uint32_t* __restrict__ bad,
                                                     uint8_t* __restrict__ out) {
     const int w = threadIdx.x;
@@ -196,8 +263,8 @@ __global__ __launch_bounds__(256) void final_kernel(Plan p, const typename A::Ac
         typename A::Acc s;
         A::identity(s);
 #pragma unroll 1
-        for (int ch = 0; ch < p.nchunks; ch++) {
-            const typename A::Acc v = partial[(size_t)w * p.nchunks + ch];
+        for (int ch = 0; ch < nparts; ch++) {
+            const typename A::Acc v = partial[(size_t)w * nparts + ch];
             A::add(s, s, v);
         }
 #pragma unroll 1
@@ -250,8 +317,15 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     const size_t o_bad = take(256);
     const size_t zero_end = off;  // hist, cursor, bad are zeroed together
     const size_t o_offs = take(sizeof(uint32_t) * (nbk + 1));
+    const size_t o_nsub = take(sizeof(uint32_t) * nbk);
+    const size_t o_suboffs = take(sizeof(uint32_t) * (nbk + 1));
+    const size_t max_pieces = nbk + ((n ? n : 1) * (size_t)p.nwin + SUB - 1) / SUB;
+    const size_t o_pieces = take(sizeof(typename A::Acc) * max_pieces);
     const size_t o_buckets = take(sizeof(typename A::Acc) * nbk);
     const size_t o_partial = take(sizeof(typename A::Acc) * (size_t)p.nwin * p.nchunks);
+    const int fold_g = 32;
+    const int nfold = (p.nchunks + fold_g - 1) / fold_g;
+    const size_t o_fold = take(sizeof(typename A::Acc) * (size_t)p.nwin * nfold);
     const size_t o_winsum = take(sizeof(typename A::Acc) * p.nwin);
     void* ws;
     int rc = ctx_workspace(ctx, off, &ws);
@@ -264,9 +338,13 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     auto* cursor = (uint32_t*)(base + o_cursor);
     auto* bad = (uint32_t*)(base + o_bad);
     auto* offs = (uint32_t*)(base + o_offs);
+    auto* nsub = (uint32_t*)(base + o_nsub);
+    auto* suboffs = (uint32_t*)(base + o_suboffs);
+    auto* pieces = (typename A::Acc*)(base + o_pieces);
     auto* buckets = (typename A::Acc*)(base + o_buckets);
     auto* partial = (typename A::Acc*)(base + o_partial);
     auto* winsum = (typename A::Acc*)(base + o_winsum);
+    auto* folded = (typename A::Acc*)(base + o_fold);
     KYB_HIP_CHECK(hipMemsetAsync(hist, 0, zero_end - o_hist, st));
     if (n) {
         hipLaunchKernelGGL(decode_kernel<A>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, pr, (const uint8_t*)d_scalars,
@@ -278,11 +356,22 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
         hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, pr, digits, offs, cursor,
                            sorted);
     }
-    hipLaunchKernelGGL(accumulate_kernel<A>, dim3((unsigned)((nbk + 63) / 64)), dim3(64), 0, st, pr, aff, offs, sorted,
-                       buckets);
+    hipLaunchKernelGGL(subcount_kernel, dim3((unsigned)((nbk + 255) / 256)), dim3(256), 0, st, nbk, offs, nsub);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, nsub, suboffs, nbk);
+    hipLaunchKernelGGL(accumulate_kernel<A>, dim3((unsigned)((max_pieces + 63) / 64)), dim3(64), 0, st, nbk, max_pieces, aff,
+                       offs, suboffs, sorted, pieces);
+    hipLaunchKernelGGL(bucket_kernel<A>, dim3((unsigned)((nbk + 63) / 64)), dim3(64), 0, st, nbk, suboffs, pieces, buckets);
     const size_t nred = (size_t)p.nwin * p.nchunks;
     hipLaunchKernelGGL(reduce_kernel<A>, dim3((unsigned)((nred + 63) / 64)), dim3(64), 0, st, pr, buckets, partial);
-    hipLaunchKernelGGL(final_kernel<A>, dim3(1), dim3(256), 0, st, pr, partial, winsum, bad, (uint8_t*)d_out);
+    if (p.nchunks > 16) {
+        const size_t nf = (size_t)p.nwin * nfold;
+        hipLaunchKernelGGL(fold_kernel<A>, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, st, p.nwin, p.nchunks, fold_g,
+                           partial, folded);
+        hipLaunchKernelGGL(final_kernel<A>, dim3(1), dim3(256), 0, st, pr, nfold, folded, winsum, bad, (uint8_t*)d_out);
+    } else {
+        hipLaunchKernelGGL(final_kernel<A>, dim3(1), dim3(256), 0, st, pr, p.nchunks, partial, winsum, bad,
+                           (uint8_t*)d_out);
+    }
     KYB_HIP_CHECK(hipGetLastError());
     return KYB_OK;
 }

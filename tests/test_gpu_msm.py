@@ -168,3 +168,20 @@ def test_bdn_aggregate_key_fixture_via_msm(golden_dir):
     cp1 = b"".join((int(c, 16) + 1).to_bytes(32, "big") for c in G["bdn_coefs"])
     out, st = m.g2_msm(cp1, P)
     assert not st.any() and bytes(out).hex() == G["bdn_agg_key"]
+
+
+def test_ed25519_msm_all_equal_scalars_skew(ed):
+    """Every scalar equal: all points fall into ONE bucket per window (the piece-splitting path)."""
+    from oracle import ed25519 as O
+
+    n = 5000
+    s, P = _ed_inputs(ed, n, b"skew")
+    s[:] = s[0]
+    out, st = ed.msm(s, P)
+    assert not st.any()
+    # sum_i k P_i = k * sum_i P_i ; sum of points via an MSM with unit scalars, then one var-base mul
+    ones = np.zeros((n, 32), dtype=np.uint8)
+    ones[:, 0] = 1
+    tot, _ = ed.msm(ones, P)
+    exp, st2 = ed.batch_mul(s[0], tot)
+    assert bytes(out) == bytes(exp[0])
