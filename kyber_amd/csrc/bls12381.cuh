@@ -265,8 +265,8 @@ KYB_HD void scalar_from_be(uint32_t (&k)[8], const uint8_t* in) { words_from_be<
 // One step of the Miller loop works on T in Jacobian coordinates on the twist and returns the
 // line through T (tangent, or chord to Q) evaluated at P as the sparse element
 //   o0 + (o1 xP) v + (o4 yP) v w       (w-basis positions 0, 2, 3), scaled by a factor in Fp2.
-KYB_HD_NOINLINE void miller_dbl_step(fp12& f, g2_jac& t, const fp& xp, const fp& yp) {
-    fp2 A, B, C, D, E, G, Z2, o0, o1, o4, u;
+KYB_HD_NOINLINE void miller_dbl_line(fp2& o0, fp2& o1, fp2& o4, g2_jac& t, const fp& xp, const fp& yp) {
+    fp2 A, B, C, D, E, G, Z2, u;
     fp2_sqr(A, t.X);
     fp2_sqr(B, t.Y);
     fp2_sqr(C, B);
@@ -301,11 +301,10 @@ KYB_HD_NOINLINE void miller_dbl_step(fp12& f, g2_jac& t, const fp& xp, const fp&
     fp2_sub(t.Y, u, C);
     fp2_mul(o4, t.Z, Z2);
     fp2_mul_fp(o4, o4, yp);
-    fp12_sqr(f, f);
-    fp12_mul_by_014(f, o0, o1, o4);
 }
-KYB_HD_NOINLINE void miller_add_step(fp12& f, g2_jac& t, const g2_aff& q, const fp& xp, const fp& yp) {
-    fp2 Z2, U2, S2, H, rr, Z3, o0, o1, o4, HH, HHH, V, u;
+KYB_HD_NOINLINE void miller_add_line(fp2& o0, fp2& o1, fp2& o4, g2_jac& t, const g2_aff& q, const fp& xp,
+                                     const fp& yp) {
+    fp2 Z2, U2, S2, H, rr, Z3, HH, HHH, V, u;
     fp2_sqr(Z2, t.Z);
     fp2_mul(U2, q.x, Z2);
     fp2_mul(S2, Z2, t.Z);
@@ -320,7 +319,6 @@ KYB_HD_NOINLINE void miller_add_step(fp12& f, g2_jac& t, const g2_aff& q, const 
     fp2_neg(o1, rr);
     fp2_mul_fp(o1, o1, xp);
     fp2_mul_fp(o4, Z3, yp);
-    fp12_mul_by_014(f, o0, o1, o4);
     // T = T + Q
     fp2_sqr(HH, H);
     fp2_mul(HHH, H, HH);
@@ -342,13 +340,44 @@ KYB_HD_NOINLINE void miller_loop(fp12& f, const g1_aff& p, const g2_aff& q) {
     fp12_one(f);
     g2_jac t;
     jac_from_aff(t, q);
+    fp2 o0, o1, o4;
 #pragma unroll 1
     for (int i = 62; i >= 0; i--) {
-        miller_dbl_step(f, t, p.x, p.y);
-        if ((CC::X_ABS >> i) & 1) miller_add_step(f, t, q, p.x, p.y);
+        miller_dbl_line(o0, o1, o4, t, p.x, p.y);
+        if (i != 62) fp12_sqr(f, f);  // f = 1 before the first step
+        fp12_mul_by_014(f, o0, o1, o4);
+        if ((CC::X_ABS >> i) & 1) {
+            miller_add_line(o0, o1, o4, t, q, p.x, p.y);
+            fp12_mul_by_014(f, o0, o1, o4);
+        }
     }
     fp12_conj(f, f);
     if (p.inf | q.inf) fp12_one(f);
+}
+// f_{|x|,Q1}(P1) * f_{|x|,Q2}(P2) with the squarings shared (one Fp12 squaring per bit for both
+// pairs), conjugated.  A pair with an operand at infinity contributes one.
+KYB_HD_NOINLINE void miller_loop2(fp12& f, const g1_aff& p1, const g2_aff& q1, const g1_aff& p2, const g2_aff& q2) {
+    fp12_one(f);
+    g2_jac t1, t2;
+    jac_from_aff(t1, q1);
+    jac_from_aff(t2, q2);
+    const bool live1 = !(p1.inf | q1.inf), live2 = !(p2.inf | q2.inf);
+    fp2 o0, o1, o4;
+#pragma unroll 1
+    for (int i = 62; i >= 0; i--) {
+        if (i != 62) fp12_sqr(f, f);
+        miller_dbl_line(o0, o1, o4, t1, p1.x, p1.y);
+        if (live1) fp12_mul_by_014(f, o0, o1, o4);
+        miller_dbl_line(o0, o1, o4, t2, p2.x, p2.y);
+        if (live2) fp12_mul_by_014(f, o0, o1, o4);
+        if ((CC::X_ABS >> i) & 1) {
+            miller_add_line(o0, o1, o4, t1, q1, p1.x, p1.y);
+            if (live1) fp12_mul_by_014(f, o0, o1, o4);
+            miller_add_line(o0, o1, o4, t2, q2, p2.x, p2.y);
+            if (live2) fp12_mul_by_014(f, o0, o1, o4);
+        }
+    }
+    fp12_conj(f, f);
 }
 // a^|x| then conjugate (x < 0); a in the cyclotomic subgroup
 KYB_HD_NOINLINE void cyclo_pow_x(fp12& r, const fp12& a) {
@@ -484,10 +513,8 @@ KYB_HD int pair_check_wire(uint8_t* ok, const uint8_t* p1, const uint8_t* p2, co
     *ok = 0;
     if (st != ST_OK) return st;
     fp_neg(c.y, c.y);
-    fp12 f, g;
-    miller_loop(f, a, b);
-    miller_loop(g, c, d);
-    fp12_mul(f, f, g);
+    fp12 f;
+    miller_loop2(f, a, b, c, d);
     final_exp(f, f);
     *ok = fp12_is_one(f) ? 1 : 0;
     return ST_OK;

@@ -30,6 +30,7 @@ from .._lib import KYB_F_VARTIME, check, load
 
 # group/edwards25519/const.go:15
 ORDER = 2**252 + 27742317777372353535851937790883648493
+_P = 2**255 - 19
 POINT_LEN = 32
 SCALAR_LEN = 32
 _BASE_ENC = bytes([0x58]) + bytes([0x66]) * 31
@@ -285,6 +286,30 @@ class Point:
 
     def Equal(self, p: "Point") -> bool:
         return self.enc == _pt(p).enc
+
+    def Add(self, a: "Point", b: "Point") -> "Point":
+        """a + b as a two-term MSM with unit scalars (the engine's complete unified addition, ge.go:183)."""
+        one = (1).to_bytes(32, "little")
+        out, st = msm(one + one, _pt(a).enc + _pt(b).enc)
+        if st.any():
+            raise ValueError("invalid Ed25519 curve point")
+        self.enc = bytes(out)
+        return self
+
+    def Neg(self, a: "Point") -> "Point":
+        """-(x, y) = (-x, y): flip the sign bit of the encoding unless x = 0 (ge.go Neg: X and T negated)."""
+        e = _pt(a).enc
+        y = int.from_bytes(e, "little") & ((1 << 255) - 1)
+        self.enc = e if y in (1, _P - 1) else e[:31] + bytes([e[31] ^ 0x80])
+        return self
+
+    def Sub(self, a: "Point", b: "Point") -> "Point":
+        return self.Add(a, Point().Neg(b))
+
+    def Pick(self, rand=None) -> "Point":
+        """A random element of the prime-order subgroup, k * B.  (The reference's Pick embeds random
+        data, point.go:177-233; its outputs are random too and only reproducible with Go's XOF stream.)"""
+        return self.Mul(Scalar().Pick(rand), None)
 
     def Mul(self, s: Scalar, A: "Point | None") -> "Point":
         a = _sc(s).v

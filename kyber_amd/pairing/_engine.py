@@ -29,8 +29,9 @@ def _stream():
 class Engine:
     """Batch API of one pairing suite; `prefix` selects the kyb_<prefix>_* entry points."""
 
-    def __init__(self, prefix, name, order, g1_len, g2_len, gt_len, g1_base, g2_base, g1_null, g2_null):
+    def __init__(self, prefix, name, order, g1_len, g2_len, gt_len, g1_base, g2_base, g1_null, g2_null, neg):
         self.prefix, self.name, self.ORDER = prefix, name, order
+        self.neg = neg  # neg(group, encoding) -> encoding of the inverse point (wire-level, no curve arithmetic)
         self.G1_LEN, self.G2_LEN, self.GT_LEN, self.SCALAR_LEN = g1_len, g2_len, gt_len, 32
         self.G1_BASE, self.G2_BASE, self.G1_NULL, self.G2_NULL = g1_base, g2_base, g1_null, g2_null
 
@@ -272,6 +273,27 @@ class Engine:
             def Set(self, p): self.enc = self._cast(p).enc; return self
             def Clone(self): return type(self)(self.enc)
             def Equal(self, p) -> bool: return self.enc == self._cast(p).enc
+
+            def Add(self, a, b):
+                """a + b as a two-term MSM with unit scalars (the engine's complete addition)."""
+                one = (1).to_bytes(32, "big")
+                out, st = eng.msm(self.GROUP, one + one, self._cast(a).enc + self._cast(b).enc)
+                if st.any():
+                    raise ValueError(f"{eng.name}: invalid point")
+                self.enc = bytes(out)
+                return self
+
+            def Neg(self, a):
+                self.enc = eng.neg(self.GROUP, self._cast(a).enc)
+                return self
+
+            def Sub(self, a, b):
+                nb = type(self)().Neg(b)
+                return self.Add(a, nb)
+
+            def Pick(self, rand=None):
+                """A uniformly random group element as k * Base (what pairing/bn256/point.go:48-57 does)."""
+                return self.Mul(Scalar().Pick(rand), None)
 
             def Mul(self, s, A=None):
                 base = self.BASE if A is None else self._cast(A).enc

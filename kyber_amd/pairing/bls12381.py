@@ -20,7 +20,16 @@ G2_BASE = bytes.fromhex(
 G1_NULL = bytes([0xC0]) + bytes(47)
 G2_NULL = bytes([0xC0]) + bytes(95)
 
-ENGINE = Engine("bls12381", "bls12-381", ORDER, G1_LEN, G2_LEN, GT_LEN, G1_BASE, G2_BASE, G1_NULL, G2_NULL)
+
+
+def _neg(group: int, enc: bytes) -> bytes:
+    """-P on the ZCash compressed encoding: flip the y-sign flag (no point of the r-torsion has y = 0)."""
+    if enc[0] & 0x40:  # infinity
+        return enc
+    return bytes([enc[0] ^ 0x20]) + enc[1:]
+
+
+ENGINE = Engine("bls12381", "bls12-381", ORDER, G1_LEN, G2_LEN, GT_LEN, G1_BASE, G2_BASE, G1_NULL, G2_NULL, _neg)
 g1_batch_mul, g2_batch_mul = ENGINE.g1_batch_mul, ENGINE.g2_batch_mul
 g1_commit, g2_commit = ENGINE.g1_commit, ENGINE.g2_commit
 batch_pair, batch_validate_pairing = ENGINE.batch_pair, ENGINE.batch_validate_pairing

@@ -18,7 +18,19 @@ G2_BASE = bytes.fromhex(  # twist.go:21-33 in wire order x.x x.y y.x y.y
     "274e5747e8cafacc3716cc8699db79b22f0e4ff3c23e898f694420a3be3087a5")
 G1_NULL, G2_NULL = bytes(64), bytes(128)
 
-ENGINE = Engine("bn256", "bn256", ORDER, G1_LEN, G2_LEN, GT_LEN, G1_BASE, G2_BASE, G1_NULL, G2_NULL)
+
+
+def _neg(group: int, enc: bytes) -> bytes:
+    """-P on the wire format: y -> p - y per coordinate (curvePoint.Neg / twistPoint.Neg act on y only)."""
+    half = len(enc) // 2
+    out = bytearray(enc[:half])
+    for i in range(half, len(enc), 32):
+        y = int.from_bytes(enc[i:i + 32], "big") % _P
+        out += ((_P - y) % _P).to_bytes(32, "big")
+    return bytes(out)
+
+
+ENGINE = Engine("bn256", "bn256", ORDER, G1_LEN, G2_LEN, GT_LEN, G1_BASE, G2_BASE, G1_NULL, G2_NULL, _neg)
 g1_batch_mul, g2_batch_mul = ENGINE.g1_batch_mul, ENGINE.g2_batch_mul
 g1_commit, g2_commit = ENGINE.g1_commit, ENGINE.g2_commit
 batch_pair, batch_validate_pairing = ENGINE.batch_pair, ENGINE.batch_validate_pairing
