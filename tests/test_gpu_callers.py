@@ -1,0 +1,95 @@
+"""The reference's hot-path CALLERS replayed over the engine:
+sign/bls Sign / Verify, sign/bdn aggregation against TestBDNFixtures, share/poly Commit / Eval / Check /
+RecoverCommit against the sequential Mul + Add the reference performs."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "bn256.json")))
+
+
+def test_bls_sign_and_batch_verify_bn256_fixtures(G):
+    from kyber_amd.sign import bls
+
+    sch = bls.NewSchemeOnG1_bn256()
+    msg = G["bdn_msg"].encode()
+    sigs = [sch.sign(bytes.fromhex(p), msg) for p in G["bdn_privs"]]
+    assert [s.hex() for s in sigs] == G["bdn_sigs"]  # TestBDNFixtures sig1..3 (bdn_vartime_test.go:104-118)
+    pubs = [bytes.fromhex(p) for p in G["bdn_pubs"]]
+    ok = sch.batch_verify(pubs, [msg] * 3, sigs)
+    assert ok.all()
+    ok = sch.batch_verify(pubs, [msg, b"other message", msg], [sigs[0], sigs[1], sigs[0]])
+    assert list(ok) == [True, False, False]
+    ok = sch.batch_verify(pubs[:1], [msg], [bytes(63) + b"\x05"])  # undecodable signature
+    assert not ok[0]
+
+
+def test_bdn_aggregation_fixtures(G):
+    from kyber_amd.pairing import bn256
+    from kyber_amd.sign import bdn, bls
+
+    sch = bdn.Scheme(bn256)
+    pubs = [bytes.fromhex(p) for p in G["bdn_pubs"]]
+    sigs = [bytes.fromhex(s) for s in G["bdn_sigs"]]
+    mask = [True, False, True]  # bdn_vartime_test.go:120-123
+    agg_sig = sch.aggregate_signatures([sigs[0], sigs[2]], pubs, mask)
+    agg_key = sch.aggregate_public_keys(pubs, mask)
+    assert agg_sig.hex() == G["bdn_fixture_agg_sig_mask101"]
+    assert agg_key.hex() == G["bdn_fixture_agg_key_mask101"]
+    # and the aggregate verifies as a plain BLS signature under the aggregate key (bdn.go:107-124)
+    assert bls.NewSchemeOnG1_bn256().verify(agg_key, G["bdn_msg"].encode(), agg_sig)
+    # TestBDN_HashPointToR_BN256: P, 2P, 3P with all bits set
+    P, _ = bn256.g2_commit(b"".join((i + 1).to_bytes(32, "big") for i in range(3)))
+    assert sch.aggregate_public_keys([bytes(p) for p in P], [True] * 3).hex() == G["bdn_agg_key"]
+
+
+def _groups():
+    from kyber_amd.group import edwards25519 as ed
+    from kyber_amd.pairing import bls12381 as bls, bn256 as bn
+
+    return {"Ed25519": ed.NewSuite(), "bls12381.G1": bls.NewSuite().G1(), "bn256.G2": bn.NewSuite().G2()}
+
+
+@pytest.mark.parametrize("name", ["Ed25519", "bls12381.G1", "bn256.G2"])
+def test_share_poly_commit_eval_recover(name):
+    """poly_test.go style: commitments of a degree t-1 polynomial; public shares evaluate consistently with
+    private shares; any t public shares recover the secret commitment."""
+    from kyber_amd.share import poly
+
+    g = _groups()[name]
+    rng = random.Random(7)
+    rand = lambda n: bytes(rng.randrange(256) for _ in range(n))
+    t, n = 5, 9
+    pri = poly.PriPoly.new(g, t, rand=rand)
+    pub = pri.Commit(None)
+    assert pub.Threshold() == t
+    # commitments are coeffs[i] * B (poly.go:146), one by one through Point.Mul
+    for c, A in zip(pri.coeffs, pub.commits):
+        assert g.Point().Mul(c, None).Equal(A)
+    # sequential Horner of the reference (poly.go:340-348) == the MSM result
+    for i in (0, 3, n - 1):
+        x = g.Scalar().SetInt64(1 + i)
+        v = g.Point().Null()
+        for A in reversed(pub.commits):
+            v = g.Point().Add(g.Point().Mul(x, v), A)
+        assert pub.Eval(i).V.Equal(v)
+        assert pub.Check(pri.Eval(i))
+    shares = [pub.Eval(i) for i in range(n)]
+    shares[1] = None
+    rng.shuffle(shares)
+    assert poly.recover_commit(g, shares, t, n).Equal(pub.Commit())
+    with pytest.raises(ValueError):
+        poly.recover_commit(g, shares[:2], t, n)
+    # a custom base point
+    b = g.Point().Pick(rand)
+    pub_b = pri.Commit(b)
+    assert pub_b.commits[2].Equal(g.Point().Mul(pri.coeffs[2], b))
+    assert pub_b.Check(pri.Eval(4))
