@@ -140,6 +140,20 @@ def other_workloads(rank, world, dist):
                      "pairing_checks_per_s": world * npair / ms_chk * 1e3,
                      "g1_muls_per_s": world * npair / ms_g1 * 1e3, "g2_muls_per_s": world * npair / ms_g2 * 1e3,
                      "all_checks_true": good}
+        if name == "bn256":
+            # the whole sign/bls Verify pipeline on the device: Hash(msg) (SHA-256 + try-and-increment) then the
+            # pairing check (sign/bls/bls.go:82-96), 32-byte messages
+            msgs = torch.from_numpy(shake(b"kyberhip/v1/bn256/msgs/%d" % rank, npair * 32).reshape(npair, 32).copy()).cuda()
+
+            def verify():
+                Hm, _ = m.batch_hash_g1(msgs)
+                return m.batch_validate_pairing(Hm, Q, sig, G2)
+
+            ms_v = timed(verify, 2)
+            tv = torch.tensor([ms_v], dtype=torch.float64, device="cuda")
+            if dist:
+                dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+            out[name]["bls_verify_pipeline_per_s"] = world * npair / float(tv.item()) * 1e3
         if name == "bls12381":
             # node-wide MSM at 2^20 points: points sharded over the ranks, all-gather of the partial points
             n = 1 << 20
@@ -158,6 +172,20 @@ def other_workloads(rank, world, dist):
             out["bls12381_g1_msm_2p20"] = {"points": n, "seconds": float(t.item()) * 1e-3, "scaling": "strong",
                                            "exchange": "all-gather of %d encoded partial points" % world if dist else "none"}
             del ks, hs, pts
+    # Ed25519 MSM at 2^20 points (PubPoly.Eval / RecoverCommit shape), sharded like the BLS one
+    from kyber_amd.group import edwards25519 as ed
+
+    n = 1 << 20
+    lo, hi = kd.shard_range(n, rank, world)
+    s_all, h_all = make_inputs(n, 1000)
+    ks = torch.from_numpy(s_all[lo:hi].copy()).cuda()
+    pts = ed.batch_mul_base(torch.from_numpy(h_all[lo:hi].copy()).cuda())
+    fn = (lambda: kd.ed25519_msm(ks, pts)) if dist else (lambda: ed.msm(ks, pts))
+    ms = timed(fn, 2)
+    t = torch.tensor([ms], dtype=torch.float64, device="cuda")
+    if dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    out["ed25519_msm_2p20"] = {"points": n, "seconds": float(t.item()) * 1e-3, "scaling": "strong"}
     return out
 
 

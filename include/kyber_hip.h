@@ -150,6 +150,11 @@ int kyb_bn256_g2_mul_dev(size_t n, const void *d_scalars, const void *d_points, 
 /* gt[i] = e(g1[i], g2[i]): Suite.Pair (pairing/bn256/suite.go:97-103 -> optate.go:266-274). */
 int kyb_bn256_pair(size_t n, const uint8_t *g1, const uint8_t *g2, uint8_t *gt, uint8_t *status);
 int kyb_bn256_pair_dev(size_t n, const void *d_g1, const void *d_g2, void *d_gt, void *d_status, void *stream);
+/* out[i] = Hash(msgs[i]) on G1: pointG1.Hash -> hashToPoint (pairing/bn256/point.go:261-313), SHA-256 then
+ * try-and-increment; the step before the pairing check in sign/bls Verify (bls.go:87-88).  All n messages
+ * have the same length msg_len and are packed back to back (hash variable-length inputs down first). */
+int kyb_bn256_hash_g1(size_t n, const uint8_t *msgs, size_t msg_len, uint8_t *out, uint8_t *status);
+int kyb_bn256_hash_g1_dev(size_t n, const void *d_msgs, size_t msg_len, void *d_out, void *d_status, void *stream);
 /* out[i] = gt[i] ^ scalars[i]: pointGT.Mul (pairing/bn256/point.go:613-628 -> gfP12.Exp gfp12.go:177);
  * like pointGT.UnmarshalBinary (point.go:664-716) coefficients are reduced mod p and nothing is rejected. */
 int kyb_bn256_gt_mul(size_t n, const uint8_t *scalars, const uint8_t *gt, uint8_t *out, uint8_t *status);

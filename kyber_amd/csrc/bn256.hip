@@ -11,3 +11,44 @@
 #include "pairing_abi.cuh"
 
 KYB_DEFINE_MUL_ABI(bn256, bn, 64, 128)
+
+// ---- pointG1.Hash (pairing/bn256/point.go:261-313): the step before the pairing check in sign/bls Verify
+namespace kyb {
+__global__ __launch_bounds__(64) void bn256_hash_g1_kernel(size_t n, const uint8_t* __restrict__ msgs, size_t msg_len,
+                                                           uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int st = bn::hash_g1_wire(out + 64 * idx, msgs + msg_len * idx, msg_len);
+    if (status) status[idx] = (uint8_t)st;
+}
+}  // namespace kyb
+extern "C" {
+int kyb_bn256_hash_g1_dev(size_t n, const void* d_msgs, size_t msg_len, void* d_out, void* d_status, void* stream) {
+    if (n && ((!d_msgs && msg_len) || !d_out)) {
+        kyb::set_error("kyb_bn256_hash_g1_dev: bad argument");
+        return KYB_E_ARG;
+    }
+    if (!n) return KYB_OK;
+    hipLaunchKernelGGL(kyb::bn256_hash_g1_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n,
+                       (const uint8_t*)d_msgs, msg_len, (uint8_t*)d_out, (uint8_t*)d_status);
+    KYB_HIP_CHECK(hipGetLastError());
+    return KYB_OK;
+}
+int kyb_bn256_hash_g1(size_t n, const uint8_t* msgs, size_t msg_len, uint8_t* out, uint8_t* status) {
+    if (n && ((!msgs && msg_len) || !out)) {
+        kyb::set_error("kyb_bn256_hash_g1: bad argument");
+        return KYB_E_ARG;
+    }
+    if (!n) return KYB_OK;
+    kyb::DeviceCtx* ctx;
+    KYB_TRY(kyb::get_ctx(&ctx));
+    kyb::StageBuf m, o, st;
+    KYB_TRY(m.upload(msgs, n * msg_len));
+    KYB_TRY(o.alloc(n * 64));
+    KYB_TRY(st.alloc(n));
+    KYB_TRY(kyb_bn256_hash_g1_dev(n, m.p, msg_len, o.p, st.p, nullptr));
+    KYB_TRY(o.download(out, n * 64));
+    if (status) KYB_TRY(st.download(status, n));
+    return KYB_OK;
+}
+}

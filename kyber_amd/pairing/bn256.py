@@ -42,3 +42,39 @@ Scalar, G1Elt, G2Elt, GTElt, Suite = ENGINE.make_types()
 
 def NewSuite() -> Suite:
     return Suite()
+
+
+def batch_hash_g1(msgs, msg_len: int | None = None):
+    """(out, status): out[i] = pointG1.Hash(msgs[i]) (pairing/bn256/point.go:261-313) for n equal-length
+    messages.  `msgs` is a list of equal-length bytes objects, or a packed (n, msg_len) uint8 array /
+    CUDA tensor."""
+    import numpy as np
+
+    from .._lib import check, load
+    from ._engine import _is_torch, _stream
+
+    lib = load()
+    if _is_torch(msgs):
+        import torch
+
+        m = msgs.contiguous()
+        n, ln = m.shape[0], (m.shape[1] if m.dim() > 1 else msg_len)
+        out = torch.empty((n, 64), dtype=torch.uint8, device=m.device)
+        st = torch.empty(n, dtype=torch.uint8, device=m.device)
+        check(lib.kyb_bn256_hash_g1_dev(n, m.data_ptr(), ln, out.data_ptr(), st.data_ptr(), _stream()), "kyb_bn256_hash_g1_dev")
+        return out, st
+    if isinstance(msgs, (list, tuple)):
+        ln = len(msgs[0]) if msgs else 0
+        if any(len(x) != ln for x in msgs):
+            raise ValueError("batch_hash_g1: messages must have equal length")
+        n = len(msgs)
+        buf = np.frombuffer(b"".join(msgs), dtype=np.uint8)
+    else:
+        a = np.ascontiguousarray(msgs, dtype=np.uint8)
+        n, ln = a.shape[0], a.shape[1]
+        buf = a.reshape(-1)
+    buf = np.ascontiguousarray(buf) if buf.size else np.zeros(1, dtype=np.uint8)
+    out = np.empty((n, 64), dtype=np.uint8)
+    st = np.empty(n, dtype=np.uint8)
+    check(lib.kyb_bn256_hash_g1(n, buf.ctypes.data, ln, out.ctypes.data, st.ctypes.data), "kyb_bn256_hash_g1")
+    return out, st

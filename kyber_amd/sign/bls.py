@@ -1,38 +1,41 @@
 """Host-side mirror of ``sign/bls`` (bls.go:22-96) over the batch engine, signatures on G1 / keys on G2
 (NewSchemeOnG1, bls.go:30-43): Sign = x * H(m), Verify = ValidatePairing(H(m), X, sig, G2.Base()).
 
-``hash_to_g1`` is the suite's HashablePoint.Hash.  For bn256 it is the reference's try-and-increment
-over SHA-256 (pairing/bn256/point.go:261-313), which the reference itself computes with host big
-integers, not with its field code; it stays host plumbing here too.  BLS12-381 hash-to-curve (RFC 9380
-SSWU) is not built (isogeny constants unavailable offline).
+``batch_hash`` is the suite's HashablePoint.Hash over a list of messages.  For bn256 it is the reference's
+try-and-increment over SHA-256 (pairing/bn256/point.go:261-313), run on the device (kyb_bn256_hash_g1).
+BLS12-381 hash-to-curve (RFC 9380 SSWU) is not built (isogeny constants unavailable offline, SURVEY.md
+Appendix A).
 """
 from __future__ import annotations
-
-import hashlib
 
 import numpy as np
 
 
-def bn256_hash_to_g1(msg: bytes) -> bytes:
-    """pointG1.Hash -> hashToPoint (pairing/bn256/point.go:261-313): 64-byte G1 encoding."""
-    from ..pairing.bn256 import _P as P
+def bn256_batch_hash_g1(msgs) -> np.ndarray:
+    """HashablePoint.Hash for a list of messages through the engine (kyb_bn256_hash_g1: SHA-256 +
+    try-and-increment on the device, pairing/bn256/point.go:261-313).  Messages are grouped by length,
+    one launch per distinct length."""
+    from ..pairing import bn256
 
-    x = int.from_bytes(hashlib.sha256(msg).digest(), "big") % P
-    while True:
-        t = (x * x * x + 3) % P
-        y = pow(t, (P + 1) // 4, P)  # big.Int.ModSqrt for p = 3 mod 4
-        if y * y % P == t:
-            return x.to_bytes(32, "big") + y.to_bytes(32, "big")
-        x = (x + 1) % P
+    out = np.empty((len(msgs), 64), dtype=np.uint8)
+    by_len = {}
+    for i, m in enumerate(msgs):
+        by_len.setdefault(len(m), []).append(i)
+    for ln, idx in by_len.items():
+        h, st = bn256.batch_hash_g1([bytes(msgs[i]) for i in idx])
+        if st.any():
+            raise ValueError("bn256: hash-to-point did not terminate")
+        out[idx] = h
+    return out
 
 
 class SchemeOnG1:
-    def __init__(self, suite_module, hash_to_g1):
-        self.m, self.hash = suite_module, hash_to_g1
+    def __init__(self, suite_module, batch_hash):
+        self.m, self.batch_hash = suite_module, batch_hash
 
     def sign(self, private_be: bytes, msg: bytes) -> bytes:
         """bls.go:67-80: sig = x * H(msg)."""
-        out, st = self.m.g1_batch_mul(private_be, self.hash(msg))
+        out, st = self.m.g1_batch_mul(private_be, self.batch_hash([msg]))
         if st.any():
             raise ValueError("bls: hash-to-point produced an invalid point")
         return bytes(out[0])
@@ -41,7 +44,7 @@ class SchemeOnG1:
         """N x Verify (bls.go:82-96) as ONE pairing-check launch: ok[i] = e(H(m_i), X_i) == e(sig_i, B2).
         Returns a bool array; an undecodable key / signature verifies false (the reference returns an error)."""
         n = len(msgs)
-        H = b"".join(self.hash(m) for m in msgs)
+        H = self.batch_hash(msgs)
         X = b"".join(publics)
         S = b"".join(sigs)
         ok, st = self.m.batch_validate_pairing(H, X, S, self.m.G2_BASE * n)
@@ -54,4 +57,4 @@ class SchemeOnG1:
 def NewSchemeOnG1_bn256() -> SchemeOnG1:
     from ..pairing import bn256
 
-    return SchemeOnG1(bn256, bn256_hash_to_g1)
+    return SchemeOnG1(bn256, bn256_batch_hash_g1)

@@ -77,4 +77,5 @@ int hh_bn_pair_check(const uint8_t* p1, const uint8_t* p2, const uint8_t* i1, co
 }
 int hh_bn_gt_mul(const uint8_t* k, const uint8_t* gt, uint8_t* out) { return bn::gt_mul_wire(out, k, gt); }
 int hh_bls_gt_mul(const uint8_t* k, const uint8_t* gt, uint8_t* out) { return bls::gt_mul_wire(out, k, gt); }
+int hh_bn_hash_g1(const uint8_t* msg, int len, uint8_t* out) { return bn::hash_g1_wire(out, msg, (size_t)len); }
 }

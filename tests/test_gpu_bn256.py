@@ -164,3 +164,18 @@ def test_gt_mul_vs_oracle_and_homomorphism(bn):
     ek, _ = bn.batch_pair(kP, G2)
     out, st = bn.gt_batch_mul(k, e)
     assert not st.any() and (out == ek).all()
+
+
+def test_hash_g1_fixtures_and_batch(bn, G):
+    for h in G["hash_g1"]:
+        out, st = bn.batch_hash_g1([bytes.fromhex(h["msg_hex"])])
+        assert st[0] == 0 and bytes(out[0]).hex() == h["point"]  # point_test.go:13-45
+    msgs = [hashlib.sha256(b"m%d" % i).digest() for i in range(500)]
+    out, st = bn.batch_hash_g1(msgs)
+    assert not st.any()
+    for i in range(0, 500, 37):
+        assert bytes(out[i]) == O.g1_marshal(O.hash_to_g1(msgs[i]))
+    for ln in (0, 1, 55, 56, 64, 65, 119, 120):
+        m = bytes((3 * i + ln) & 0xFF for i in range(ln))
+        out, st = bn.batch_hash_g1([m, m])
+        assert bytes(out[1]) == O.g1_marshal(O.hash_to_g1(m)), ln

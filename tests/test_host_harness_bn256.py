@@ -112,3 +112,17 @@ def test_fp_sqr_dedicated_path():
     rng = random.Random(12)
     for a in [0, 1, O.P - 1, (1 << 256) - 1] + [rng.randrange(O.P) for _ in range(300)]:
         assert H.call("hh_bn_fp_op", 5, _fp(a), _fp(0), out_sizes=(32,))[1] == _fp(a * a % O.P)
+
+
+def test_hash_g1_reference_fixtures_and_lengths(G):
+    import hashlib
+
+    for h in G["hash_g1"]:
+        msg = bytes.fromhex(h["msg_hex"])
+        assert H.call("hh_bn_hash_g1", msg, len(msg), out_sizes=(64,)) == (0, bytes.fromhex(h["point"]))
+    msg = G["bdn_msg"].encode()
+    assert H.call("hh_bn_hash_g1", msg, len(msg), out_sizes=(64,))[1] == O.g1_marshal(O.hash_to_g1(msg))
+    # SHA-256 padding boundaries: lengths around 55 / 56 / 64 / 119 / 120 bytes, and the empty message
+    for ln in (0, 1, 54, 55, 56, 57, 63, 64, 65, 119, 120, 121, 200):
+        msg = bytes((7 * i + ln) & 0xFF for i in range(ln))
+        assert H.call("hh_bn_hash_g1", msg or b"\\x00", ln, out_sizes=(64,))[1] == O.g1_marshal(O.hash_to_g1(msg)), ln
