@@ -93,3 +93,29 @@ def test_share_poly_commit_eval_recover(name):
     pub_b = pri.Commit(b)
     assert pub_b.commits[2].Equal(g.Point().Mul(pri.coeffs[2], b))
     assert pub_b.Check(pri.Eval(4))
+
+
+def test_tbls_sign_recover_verify_bn256():
+    """internal/test/threshold.go shape: t-of-n shares sign, any t partials recover the signature the
+    secret itself would produce, a corrupted partial is skipped."""
+    from kyber_amd.pairing import bn256
+    from kyber_amd.share import poly
+    from kyber_amd.sign import bls, tbls
+
+    rng = random.Random(11)
+    rand = lambda n: bytes(rng.randrange(256) for _ in range(n))
+    suite = bn256.NewSuite()
+    t, n = 3, 5
+    pri = poly.PriPoly.new(suite.G2(), t, rand=rand)
+    pub = pri.Commit(None)  # public sharing polynomial on the key group G2
+    sch = tbls.NewThresholdSchemeOnG1_bn256()
+    msg = b"Hello threshold Boneh-Lynn-Shacham"
+    partials = [sch.sign(pri.Eval(i), msg) for i in range(n)]
+    assert all(sch.verify_partial(pub, msg, s) for s in partials)
+    partials[1] = partials[1][:10] + bytes([partials[1][10] ^ 1]) + partials[1][11:]  # corrupt one
+    sig = sch.recover(pub, msg, partials, t, n)
+    plain = bls.NewSchemeOnG1_bn256()
+    assert sig == plain.sign(pri.coeffs[0].MarshalBinary(), msg)
+    assert plain.verify(pub.Commit().MarshalBinary(), msg, sig)
+    with pytest.raises(ValueError):
+        sch.recover(pub, msg, partials[:2], t, n)
