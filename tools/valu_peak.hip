@@ -29,6 +29,10 @@ __global__ __launch_bounds__(256) void k(uint64_t* out, uint32_t seed) {
             if (KIND == 6) facc[c] = fma(facc[c], fa, fb);                                      // v_fma_f64
             if (KIND == 7) acc[c] = acc[c] + (((uint64_t)b << 32) | a);                         // 64-bit add (2 instr)
             if (KIND == 8) acc[c] = (uint64_t)((int64_t)acc[c] >> 26) + b;                      // 64-bit ashr + add
+            if (KIND == 9) acc[c] = (uint64_t)acc[c] * 3 + ((uint64_t)a * b);                   // pure mad chain (mul by small const + mad)
+            if (KIND == 10) acc[c] = (acc[c] << 3) + (((uint64_t)b << 32) | a);                  // v_lshl_add_u64
+            if (KIND == 11) acc[c] = (uint64_t)(__builtin_amdgcn_alignbit((uint32_t)(acc[c] >> 32), (uint32_t)acc[c], 26) + a) | ((uint64_t)b << 32);  // alignbit + add
+            if (KIND == 12) { uint32_t lo = (uint32_t)acc[c], hi = (uint32_t)(acc[c] >> 32); acc[c] = (uint64_t)lo * hi + acc[c]; }  // v_mad_u64_u32 fully dependent
         }
     }
     uint64_t r = 0;
@@ -69,5 +73,8 @@ int main() {
     run<6>("fma_f64", d);
     run<7>("add_u64", d);
     run<8>("ashr_i64+add", d);
+    run<10>("lshl_add_u64", d);
+    run<11>("alignbit+add(+or)", d);
+    run<12>("mad_u64_u32 dependent operands", d);
     return 0;
 }
