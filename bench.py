@@ -264,6 +264,14 @@ def main():
     fix_ms_avg = sum(fix_ms) / len(fix_ms)
     ok = int(outs[2].sum().item()) == 0
 
+    # PCIe-inclusive rate of the host-buffer entry points (allocate, H2D, kernels, D2H, free): reported, never `value`
+    host_rate = None
+    if rank == 0:
+        t0 = time.perf_counter()
+        o1 = ed.batch_mul_base(s_h)
+        o2, st_h = ed.batch_mul(s_h, o1)
+        host_rate = 2 * n / (time.perf_counter() - t0)
+
     other = None
     if not args.no_other:
         other = other_workloads(rank, world, dist)
@@ -291,7 +299,8 @@ def main():
             "detail": {"var_base_per_s_per_gpu": n / var_s,
                        "fixed_base_per_s_per_gpu": n / (fix_ms_avg * 1e-3),
                        "var_base_kernel_ms": var_ms_avg, "fixed_base_kernel_ms": fix_ms_avg,
-                       "all_status_ok": ok},
+                       "all_status_ok": ok,
+                       "host_buffer_path_scalar_muls_per_s": host_rate},
             "roofline": {"bound": "hbm", "kernel": "ed25519_mul_kernel (variable-base, dominant: ~80% of a step)",
                          "achieved": BYTES_VAR * n / var_s / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": BYTES_VAR * n / var_s / 1e9 / HBM_PEAK_GBS,

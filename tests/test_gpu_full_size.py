@@ -1,0 +1,90 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties (the oracle cannot finish
+2^20 units in seconds): checksum-of-checksums by MSM, linearity in the scalar, bilinearity, plus a sampled
+element-wise comparison against the oracle."""
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _shake(label, n):
+    return np.frombuffer(hashlib.shake_256(label).digest(n), dtype=np.uint8)
+
+
+def test_ed25519_config2_2p20_fixed_and_var_base():
+    """configs[1]: 2^20 fixed-base + 2^20 variable-base scalar-muls."""
+    import torch
+
+    from kyber_amd.group import edwards25519 as ed
+    from oracle import ed25519 as O
+    from tests import _oracle_c as OC
+
+    n = 1 << 20
+    s = _shake(b"full/ed/s", n * 32).reshape(n, 32).copy()
+    h = _shake(b"full/ed/h", n * 32).reshape(n, 32).copy()
+    s[:, 31] &= 0x0F
+    h[:, 31] &= 0x0F
+    d_s, d_h = torch.from_numpy(s).cuda(), torch.from_numpy(h).cuda()
+    P = ed.batch_mul_base(d_h)  # fixed-base: P_i = h_i B
+    A, st = ed.batch_mul(d_s, P)  # variable-base: A_i = s_i P_i
+    assert not st.any().item()
+    ones = torch.zeros((n, 32), dtype=torch.uint8, device="cuda")
+    ones[:, 0] = 1
+    # checksum of the 2^20 fixed-base outputs: sum_i P_i == (sum_i h_i mod l) B
+    sumP, _ = ed.msm(ones, P)
+    hs = [int.from_bytes(bytes(x), "little") for x in h]
+    tot_h = sum(hs) % O.L
+    assert bytes(sumP.cpu().numpy()) == bytes(ed.batch_mul_base(tot_h.to_bytes(32, "little"))[0])
+    # checksum of the 2^20 variable-base outputs: sum_i A_i == (sum_i s_i h_i mod l) B, and == MSM(s, P)
+    sumA, _ = ed.msm(ones, A)
+    tot = sum(int.from_bytes(bytes(x), "little") * y for x, y in zip(s, hs)) % O.L
+    exp = bytes(ed.batch_mul_base(tot.to_bytes(32, "little"))[0])
+    assert bytes(sumA.cpu().numpy()) == exp
+    msm, _ = ed.msm(d_s, P)
+    assert bytes(msm.cpu().numpy()) == exp
+    # sampled element-wise comparison against the C oracle
+    idx = np.arange(0, n, 4099)
+    Pc, Ac = P.cpu().numpy(), A.cpu().numpy()
+    assert (OC.ed_mul_base(h[idx], threads=1) == Pc[idx]).all()
+    out, st2 = OC.ed_mul(s[idx], Pc[idx], threads=1)
+    assert not st2.any() and (out == Ac[idx]).all()
+
+
+@pytest.mark.parametrize("name,n", [("bls12381", 1 << 16), ("bn256", 1 << 18)])
+def test_pairing_suites_at_config_sizes(name, n):
+    """configs[3] (BLS12-381, 2^16 pairs) and configs[4] (bn256, 2^18): G1 mul checksum by MSM, bilinearity
+    e(kP, Q) == e(P, kQ) over the whole batch, ValidatePairing truth table with forged entries."""
+    import importlib
+
+    import torch
+
+    m = importlib.import_module("kyber_amd.pairing." + name)
+    raw = _shake(b"full/" + name.encode(), 3 * n * 32).reshape(3, n, 32).copy()
+    raw[:, :, 0] &= 0x3F
+    k, a, b = (torch.from_numpy(x).cuda() for x in raw)
+    g1b = torch.from_numpy(np.frombuffer(m.G1_BASE, dtype=np.uint8).copy()).cuda()
+    g2b = torch.from_numpy(np.frombuffer(m.G2_BASE, dtype=np.uint8).copy()).cuda()
+    P, st = m._mul(1, a, g1b, True)
+    Q, st2 = m._mul(2, b, g2b, True)
+    assert not st.any().item() and not st2.any().item()
+    kP, _ = m.g1_batch_mul(k, P)
+    kQ, _ = m.g2_batch_mul(k, Q)
+    # checksum: sum_i k_i P_i via the MSM == sum of the batch outputs (MSM with unit scalars)
+    ones = torch.zeros((n, 32), dtype=torch.uint8, device="cuda")
+    ones[:, 31] = 1
+    lhs, _ = m.g1_msm(k, P)
+    rhs, _ = m.g1_msm(ones, kP)
+    assert bytes(lhs.cpu().numpy()) == bytes(rhs.cpu().numpy())
+    e1, s1 = m.batch_pair(kP, Q)
+    e2, s2 = m.batch_pair(P, kQ)
+    assert not s1.any().item() and not s2.any().item()
+    assert torch.equal(e1, e2)
+    # ValidatePairing(kP, Q, P, kQ) holds; forge every 97th entry
+    forged = kP.clone()
+    forged[::97] = P[::97]
+    ok, st3 = m.batch_validate_pairing(forged, Q, P, kQ)
+    exp = torch.ones(n, dtype=torch.bool, device="cuda")
+    exp[::97] = False
+    assert not st3.any().item() and torch.equal(ok.bool(), exp)
