@@ -496,3 +496,91 @@ def gt_from_bytes(buf: bytes):
 def gt_mul_bytes(scalar_be: bytes, gt: bytes) -> bytes:
     """GTElt.Mul (kilic/gt.go:79-84): gt ^ k."""
     return gt_to_bytes(f12_pow(gt_from_bytes(gt), scalar_from_be(scalar_be)))
+
+
+# ------------------------------------------------------- hash to curve (RFC 9380 section 8.8)
+# kilic/g1.go:161-170 (G1Elt.Hash -> HashToCurve with the suite DST) and g2.go likewise.  The isogeny
+# constants are derived by tools/derive_bls12381_isogenies.py (the backends are not vendored); the choice among
+# the automorphisms of the j = 0 curve is pinned by the drand fixtures (tests/test_oracle_bls12381_h2c.py).
+def expand_message_xmd(msg: bytes, dst: bytes, n: int) -> bytes:
+    import hashlib
+    import struct
+
+    ell = (n + 31) // 32
+    if ell > 255 or len(dst) > 255:
+        raise ValueError("expand_message_xmd: bad lengths")
+    dst_prime = dst + bytes([len(dst)])
+    b0 = hashlib.sha256(bytes(64) + msg + struct.pack(">H", n) + b"\x00" + dst_prime).digest()
+    b = [hashlib.sha256(b0 + b"\x01" + dst_prime).digest()]
+    for i in range(2, ell + 1):
+        b.append(hashlib.sha256(bytes(x ^ y for x, y in zip(b0, b[-1])) + bytes([i]) + dst_prime).digest())
+    return b"".join(b)[:n]
+
+
+def _poly(c, x, F):
+    acc = F.zero
+    for a in reversed(c):
+        acc = F.add(F.mul(acc, x), a)
+    return acc
+
+
+def _sgn0_fp(x):
+    return x & 1
+
+
+def _sgn0_fp2(x):
+    return (x[0] & 1) | ((x[0] == 0) & (x[1] & 1))
+
+
+def _sswu(F, A, B, Z, u, sqrt, sgn0):
+    """map_to_curve_simple_swu (RFC 9380 section 6.6.2) on y^2 = x^3 + A x + B."""
+    u2 = F.mul(u, u)
+    tv1 = F.add(F.mul(F.mul(Z, Z), F.mul(u2, u2)), F.mul(Z, u2))
+    if tv1 == F.zero:
+        x1 = F.mul(B, F.inv(F.mul(Z, A)))
+    else:
+        x1 = F.mul(F.mul(F.neg(B), F.inv(A)), F.add(F.one, F.inv(tv1)))
+    g = lambda x: F.add(F.add(F.mul(F.mul(x, x), x), F.mul(A, x)), B)
+    y = sqrt(g(x1))
+    if y is None:
+        x1 = F.mul(F.mul(Z, u2), x1)
+        y = sqrt(g(x1))
+    if sgn0(u) != sgn0(y):
+        y = F.neg(y)
+    return (x1, y)
+
+
+def _iso(F, consts, pt):
+    xn, xd, yn, yd = consts
+    x, y = pt
+    return (F.mul(_poly(xn, x, F), F.inv(_poly(xd, x, F))), F.mul(y, F.mul(_poly(yn, x, F), F.inv(_poly(yd, x, F)))))
+
+
+H_EFF_G1 = 0xD201000000010001  # 1 - x
+_XX = -X_ABS
+H2 = (_XX**8 - 4 * _XX**7 + 5 * _XX**6 - 4 * _XX**4 + 6 * _XX**3 - 4 * _XX**2 - 4 * _XX + 13) // 9
+H_EFF_G2 = H2 * (3 * _XX * _XX - 3)
+
+
+def hash_to_g1(msg: bytes, dst: bytes):
+    from . import bls12381_h2c_consts as K
+
+    ub = expand_message_xmd(msg, dst, 128)
+    pts = []
+    for k in range(2):
+        u = int.from_bytes(ub[64 * k:64 * k + 64], "big") % P
+        q = _sswu(_Fp, K.G1_A, K.G1_B, K.G1_Z, u, fp_sqrt, _sgn0_fp)
+        pts.append(_iso(_Fp, (K.G1_XNUM, K.G1_XDEN, K.G1_YNUM, K.G1_YDEN), q))
+    return g1_mul(H_EFF_G1, g1_add(pts[0], pts[1]))
+
+
+def hash_to_g2(msg: bytes, dst: bytes):
+    from . import bls12381_h2c_consts as K
+
+    ub = expand_message_xmd(msg, dst, 256)
+    e = [int.from_bytes(ub[64 * k:64 * k + 64], "big") % P for k in range(4)]
+    pts = []
+    for u in ((e[0], e[1]), (e[2], e[3])):
+        q = _sswu(_Fp2, K.G2_A, K.G2_B, K.G2_Z, u, f2_sqrt, _sgn0_fp2)
+        pts.append(_iso(_Fp2, (K.G2_XNUM, K.G2_XDEN, K.G2_YNUM, K.G2_YDEN), q))
+    return g2_mul(H_EFF_G2, g2_add(pts[0], pts[1]))
