@@ -140,10 +140,10 @@ def other_workloads(rank, world, dist):
                      "pairing_checks_per_s": world * npair / ms_chk * 1e3,
                      "g1_muls_per_s": world * npair / ms_g1 * 1e3, "g2_muls_per_s": world * npair / ms_g2 * 1e3,
                      "all_checks_true": good}
-        if name == "bn256":
-            # the whole sign/bls Verify pipeline on the device: Hash(msg) (SHA-256 + try-and-increment) then the
-            # pairing check (sign/bls/bls.go:82-96), 32-byte messages
-            msgs = torch.from_numpy(shake(b"kyberhip/v1/bn256/msgs/%d" % rank, npair * 32).reshape(npair, 32).copy()).cuda()
+        if True:
+            # the whole sign/bls Verify pipeline on the device: Hash(msg) (bn256: SHA-256 + try-and-increment;
+            # BLS12-381: RFC 9380 hash_to_curve) then the pairing check (sign/bls/bls.go:82-96), 32-byte messages
+            msgs = torch.from_numpy(shake(b"kyberhip/v1/%s/msgs/%d" % (name.encode(), rank), npair * 32).reshape(npair, 32).copy()).cuda()
 
             def verify():
                 Hm, _ = m.batch_hash_g1(msgs)

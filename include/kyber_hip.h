@@ -116,6 +116,18 @@ int kyb_bls12381_g2_mul_dev(size_t n, const void *d_scalars, const void *d_point
 /* gt[i] = e(g1[i], g2[i]).  Replaces Suite.Pair (pairing/pairing.go:12; kilic/suite.go:70-75). */
 int kyb_bls12381_pair(size_t n, const uint8_t *g1, const uint8_t *g2, uint8_t *gt, uint8_t *status);
 int kyb_bls12381_pair_dev(size_t n, const void *d_g1, const void *d_g2, void *d_gt, void *d_status, void *stream);
+/* out[i] = hash_to_curve(msgs[i], dst) on G1 / G2 (RFC 9380 BLS12381G1/G2_XMD:SHA-256_SSWU_RO_).  Replaces
+ * G1Elt.Hash / G2Elt.Hash (pairing/bls12381/kilic/g1.go:161-170, g2.go; default DSTs kilic/g1.go:17, g2.go:18), the
+ * step before the pairing check in sign/bls Verify (bls.go:87-88).  The n messages have the same length msg_len
+ * and are packed back to back; dst is a HOST pointer (at most 255 bytes) in every variant. */
+int kyb_bls12381_hash_g1(size_t n, const uint8_t *msgs, size_t msg_len, const uint8_t *dst, size_t dst_len,
+                         uint8_t *out, uint8_t *status);
+int kyb_bls12381_hash_g2(size_t n, const uint8_t *msgs, size_t msg_len, const uint8_t *dst, size_t dst_len,
+                         uint8_t *out, uint8_t *status);
+int kyb_bls12381_hash_g1_dev(size_t n, const void *d_msgs, size_t msg_len, const uint8_t *dst, size_t dst_len,
+                             void *d_out, void *d_status, void *stream);
+int kyb_bls12381_hash_g2_dev(size_t n, const void *d_msgs, size_t msg_len, const uint8_t *dst, size_t dst_len,
+                             void *d_out, void *d_status, void *stream);
 /* out[i] = gt[i] ^ scalars[i].  Replaces GTElt.Mul (kilic/gt.go:79-84 -> GT.Exp); inputs are checked
  * like GT.FromBytes (coefficients < p, order-r subgroup). */
 int kyb_bls12381_gt_mul(size_t n, const uint8_t *scalars, const uint8_t *gt, uint8_t *out, uint8_t *status);

@@ -1,0 +1,98 @@
+// BLS12-381 hash-to-curve kernels + C-ABI entry points (bls12381_h2c.cuh): one message per lane.
+// Replaces G1Elt.Hash / G2Elt.Hash (pairing/bls12381/kilic/g1.go:161-170, g2.go) -- HashablePoint.Hash, the step
+// before the pairing check in sign/bls Verify (sign/bls/bls.go:87-88).
+#include "bls12381_h2c.cuh"
+#include "pairing_abi.cuh"
+
+#include <string.h>
+
+namespace kyb {
+__global__ __launch_bounds__(64) void bls12381_hash_g1_kernel(size_t n, const uint8_t* __restrict__ msgs, size_t msg_len,
+                                                              bls::DstArg dst, uint8_t* __restrict__ out,
+                                                              uint8_t* __restrict__ status) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int st = bls::hash_g1_wire(out + 48 * idx, msgs + msg_len * idx, msg_len, dst);
+    if (status) status[idx] = (uint8_t)st;
+}
+__global__ __launch_bounds__(64) void bls12381_hash_g2_kernel(size_t n, const uint8_t* __restrict__ msgs, size_t msg_len,
+                                                              bls::DstArg dst, uint8_t* __restrict__ out,
+                                                              uint8_t* __restrict__ status) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int st = bls::hash_g2_wire(out + 96 * idx, msgs + msg_len * idx, msg_len, dst);
+    if (status) status[idx] = (uint8_t)st;
+}
+}  // namespace kyb
+
+using namespace kyb;
+
+static int make_dst(bls::DstArg& d, const uint8_t* dst, size_t dst_len) {
+    if (dst_len > 255 || (dst_len && !dst)) {
+        set_error("hash-to-curve: the domain separation tag must be at most 255 bytes");
+        return KYB_E_ARG;
+    }
+    memset(&d, 0, sizeof d);
+    if (dst_len) memcpy(d.b, dst, dst_len);
+    d.len = (uint32_t)dst_len;
+    return KYB_OK;
+}
+
+extern "C" {
+int kyb_bls12381_hash_g1_dev(size_t n, const void* d_msgs, size_t msg_len, const uint8_t* dst, size_t dst_len, void* d_out,
+                             void* d_status, void* stream) {
+    if (n && ((!d_msgs && msg_len) || !d_out)) {
+        set_error("kyb_bls12381_hash_g1_dev: bad argument");
+        return KYB_E_ARG;
+    }
+    bls::DstArg d;
+    KYB_TRY(make_dst(d, dst, dst_len));
+    if (!n) return KYB_OK;
+    hipLaunchKernelGGL(bls12381_hash_g1_kernel, dim3(grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n,
+                       (const uint8_t*)d_msgs, msg_len, d, (uint8_t*)d_out, (uint8_t*)d_status);
+    KYB_HIP_CHECK(hipGetLastError());
+    return KYB_OK;
+}
+int kyb_bls12381_hash_g2_dev(size_t n, const void* d_msgs, size_t msg_len, const uint8_t* dst, size_t dst_len, void* d_out,
+                             void* d_status, void* stream) {
+    if (n && ((!d_msgs && msg_len) || !d_out)) {
+        set_error("kyb_bls12381_hash_g2_dev: bad argument");
+        return KYB_E_ARG;
+    }
+    bls::DstArg d;
+    KYB_TRY(make_dst(d, dst, dst_len));
+    if (!n) return KYB_OK;
+    hipLaunchKernelGGL(bls12381_hash_g2_kernel, dim3(grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n,
+                       (const uint8_t*)d_msgs, msg_len, d, (uint8_t*)d_out, (uint8_t*)d_status);
+    KYB_HIP_CHECK(hipGetLastError());
+    return KYB_OK;
+}
+static int hash_host(bool g2, size_t n, const uint8_t* msgs, size_t msg_len, const uint8_t* dst, size_t dst_len,
+                     uint8_t* out, uint8_t* status) {
+    if (n && ((!msgs && msg_len) || !out)) {
+        set_error("kyb_bls12381_hash_g*: bad argument");
+        return KYB_E_ARG;
+    }
+    if (!n) return KYB_OK;
+    DeviceCtx* ctx;
+    KYB_TRY(get_ctx(&ctx));
+    const size_t osz = g2 ? 96 : 48;
+    StageBuf m, o, st;
+    KYB_TRY(m.upload(msgs, n * msg_len));
+    KYB_TRY(o.alloc(n * osz));
+    KYB_TRY(st.alloc(n));
+    KYB_TRY(g2 ? kyb_bls12381_hash_g2_dev(n, m.p, msg_len, dst, dst_len, o.p, st.p, nullptr)
+               : kyb_bls12381_hash_g1_dev(n, m.p, msg_len, dst, dst_len, o.p, st.p, nullptr));
+    KYB_TRY(o.download(out, n * osz));
+    if (status) KYB_TRY(st.download(status, n));
+    return KYB_OK;
+}
+int kyb_bls12381_hash_g1(size_t n, const uint8_t* msgs, size_t msg_len, const uint8_t* dst, size_t dst_len, uint8_t* out,
+                         uint8_t* status) {
+    return hash_host(false, n, msgs, msg_len, dst, dst_len, out, status);
+}
+int kyb_bls12381_hash_g2(size_t n, const uint8_t* msgs, size_t msg_len, const uint8_t* dst, size_t dst_len, uint8_t* out,
+                         uint8_t* status) {
+    return hash_host(true, n, msgs, msg_len, dst, dst_len, out, status);
+}
+}

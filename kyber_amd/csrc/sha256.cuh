@@ -1,6 +1,7 @@
-// SHA-256 of one message per lane (FIPS 180-4), used by the bn256 hash-to-point kernel
-// (pairing/bn256/point.go:286-288: h := sha256.Sum256(m)).  All lanes of a launch hash messages of
-// the same length, so control flow is uniform.
+// SHA-256 (FIPS 180-4), one message per lane: one-shot digest for the bn256 hash-to-point kernel
+// (pairing/bn256/point.go:286-288) and an incremental context for expand_message_xmd (RFC 9380 section 5.3.1,
+// used by the BLS12-381 hash-to-curve kernels).  All lanes of a launch hash inputs of the same length, so
+// control flow is uniform.
 #pragma once
 #include "hd.h"
 
@@ -8,7 +9,7 @@ namespace kyb {
 
 KYB_HD uint32_t sha_rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
 
-KYB_HD void sha256_block(uint32_t (&h)[8], const uint32_t (&blk)[16]) {
+KYB_HD_NOINLINE void sha256_block(uint32_t (&h)[8], const uint32_t (&blk)[16]) {
     constexpr uint32_t K[64] = {
         0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
         0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
@@ -40,33 +41,52 @@ KYB_HD void sha256_block(uint32_t (&h)[8], const uint32_t (&blk)[16]) {
     h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
 }
 
-// digest (eight big-endian words, h[0] first) of msg[0..len)
-KYB_HD_NOINLINE void sha256(uint32_t (&h)[8], const uint8_t* msg, size_t len) {
-    h[0] = 0x6a09e667; h[1] = 0xbb67ae85; h[2] = 0x3c6ef372; h[3] = 0xa54ff53a;
-    h[4] = 0x510e527f; h[5] = 0x9b05688c; h[6] = 0x1f83d9ab; h[7] = 0x5be0cd19;
-    const size_t total_blocks = (len + 9 + 63) / 64;
-#pragma unroll 1
-    for (size_t blk = 0; blk < total_blocks; blk++) {
-        uint32_t w[16];
-#pragma unroll 1
-        for (int i = 0; i < 16; i++) {
-            uint32_t x = 0;
-            for (int k = 0; k < 4; k++) {
-                const size_t pos = blk * 64 + (size_t)i * 4 + k;
-                uint32_t byte = 0;
-                if (pos < len) byte = msg[pos];
-                else if (pos == len) byte = 0x80;
-                x = (x << 8) | byte;
-            }
-            w[i] = x;
+// Incremental context: absorb bytes, then finish() leaves the digest in h (eight big-endian words, h[0] first).
+struct Sha256 {
+    uint32_t h[8];
+    uint32_t w[16];   // current block, big-endian words being filled
+    uint64_t len;     // bytes absorbed
+    KYB_HD void init() {
+        h[0] = 0x6a09e667; h[1] = 0xbb67ae85; h[2] = 0x3c6ef372; h[3] = 0xa54ff53a;
+        h[4] = 0x510e527f; h[5] = 0x9b05688c; h[6] = 0x1f83d9ab; h[7] = 0x5be0cd19;
+        len = 0;
+        for (int i = 0; i < 16; i++) w[i] = 0;
+    }
+    KYB_HD void put(uint8_t byte) {
+        const int pos = (int)(len & 63);
+        const int wi = pos >> 2, sh = 24 - 8 * (pos & 3);
+        w[wi] |= (uint32_t)byte << sh;
+        len++;
+        if ((len & 63) == 0) {
+            sha256_block(h, w);
+            for (int i = 0; i < 16; i++) w[i] = 0;
         }
-        if (blk == total_blocks - 1) {
-            const uint64_t bits = (uint64_t)len * 8;
-            w[14] = (uint32_t)(bits >> 32);
-            w[15] = (uint32_t)bits;
-        }
+    }
+    KYB_HD void update(const uint8_t* p, size_t n) {
+        for (size_t i = 0; i < n; i++) put(p[i]);
+    }
+    KYB_HD void update_words_be(const uint32_t* d, int nwords) {  // nwords big-endian 32-bit words
+        for (int i = 0; i < nwords; i++)
+            for (int k = 0; k < 4; k++) put((uint8_t)(d[i] >> (24 - 8 * k)));
+    }
+    KYB_HD void finish() {
+        const uint64_t bits = len * 8;
+        put(0x80);
+        while ((len & 63) != 56) put(0);
+        w[14] = (uint32_t)(bits >> 32);
+        w[15] = (uint32_t)bits;
         sha256_block(h, w);
     }
+};
+
+// digest (eight big-endian words, h[0] first) of msg[0..len)
+KYB_HD_NOINLINE void sha256(uint32_t (&h)[8], const uint8_t* msg, size_t len) {
+    Sha256 c;
+    c.init();
+    c.update(msg, len);
+    c.finish();
+#pragma unroll
+    for (int i = 0; i < 8; i++) h[i] = c.h[i];
 }
 
 }  // namespace kyb

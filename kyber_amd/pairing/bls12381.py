@@ -41,3 +41,55 @@ Scalar, G1Elt, G2Elt, GTElt, Suite = ENGINE.make_types()
 
 def NewSuite() -> Suite:
     return Suite()
+
+DOMAIN_G1 = b"BLS_SIG_BLS12381G1_XMD:SHA-256_SSWU_RO_NUL_"  # kilic/g1.go:17
+DOMAIN_G2 = b"BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_"  # kilic/g2.go:18
+
+
+def _batch_hash(group: int, msgs, dst: bytes):
+    import ctypes
+
+    import numpy as np
+
+    from .._lib import check, load
+    from ._engine import _is_torch, _stream
+
+    lib = load()
+    w = G1_LEN if group == 1 else G2_LEN
+    dbuf = ctypes.create_string_buffer(bytes(dst), len(dst)) if dst else None
+    dptr = ctypes.cast(dbuf, ctypes.c_void_p) if dst else None
+    if _is_torch(msgs):
+        import torch
+
+        m = msgs.contiguous()
+        n, ln = m.shape[0], m.shape[1]
+        out = torch.empty((n, w), dtype=torch.uint8, device=m.device)
+        st = torch.empty(n, dtype=torch.uint8, device=m.device)
+        fn = getattr(lib, f"kyb_bls12381_hash_g{group}_dev")
+        check(fn(n, m.data_ptr(), ln, dptr, len(dst), out.data_ptr(), st.data_ptr(), _stream()), "hash_dev")
+        return out, st
+    if isinstance(msgs, (list, tuple)):
+        ln = len(msgs[0]) if msgs else 0
+        if any(len(x) != ln for x in msgs):
+            raise ValueError("batch hash: messages must have equal length")
+        n = len(msgs)
+        buf = np.frombuffer(b"".join(msgs), dtype=np.uint8)
+    else:
+        a = np.ascontiguousarray(msgs, dtype=np.uint8)
+        n, ln = a.shape[0], a.shape[1]
+        buf = a.reshape(-1)
+    buf = np.ascontiguousarray(buf) if buf.size else np.zeros(1, dtype=np.uint8)
+    out = np.empty((n, w), dtype=np.uint8)
+    st = np.empty(n, dtype=np.uint8)
+    fn = getattr(lib, f"kyb_bls12381_hash_g{group}")
+    check(fn(n, buf.ctypes.data, ln, dptr, len(dst), out.ctypes.data, st.ctypes.data), "hash")
+    return out, st
+
+
+def batch_hash_g1(msgs, dst: bytes = DOMAIN_G1):
+    """(out, status): G1Elt.Hash for n equal-length messages (kilic/g1.go:161-170, RFC 9380 hash_to_curve)."""
+    return _batch_hash(1, msgs, dst)
+
+
+def batch_hash_g2(msgs, dst: bytes = DOMAIN_G2):
+    return _batch_hash(2, msgs, dst)

@@ -54,6 +54,61 @@ class SchemeOnG1:
         return bool(self.batch_verify([public], [msg], [sig])[0])
 
 
+def _grouped(hash_fn, width):
+    def batch_hash(msgs):
+        out = np.empty((len(msgs), width), dtype=np.uint8)
+        by_len = {}
+        for i, m in enumerate(msgs):
+            by_len.setdefault(len(m), []).append(i)
+        for _, idx in by_len.items():
+            h, st = hash_fn([bytes(msgs[i]) for i in idx])
+            if np.asarray(st).any():
+                raise ValueError("hash-to-curve failed")
+            out[idx] = h
+        return out
+
+    return batch_hash
+
+
+def NewSchemeOnG1_bls12381(dst: bytes | None = None) -> SchemeOnG1:
+    """sign/bls NewSchemeOnG1 over the BLS12-381 suite: signatures on G1 (hash_to_curve with the G1 DST of
+    kilic/g1.go:17 unless `dst` is given, as NewBLS12381SuiteWithDST allows), keys on G2."""
+    from ..pairing import bls12381
+
+    d = bls12381.DOMAIN_G1 if dst is None else dst
+    return SchemeOnG1(bls12381, _grouped(lambda m: bls12381.batch_hash_g1(m, d), 48))
+
+
+class SchemeOnG2:
+    """sign/bls NewSchemeOnG2 (bls.go:45-58): signatures on G2, keys on G1; Verify =
+    ValidatePairing(G1.Base(), sig, X, H(m)) (the argument order of bls.go:51-53)."""
+
+    def __init__(self, suite_module, batch_hash):
+        self.m, self.batch_hash = suite_module, batch_hash
+
+    def sign(self, private_be: bytes, msg: bytes) -> bytes:
+        out, st = self.m.g2_batch_mul(private_be, self.batch_hash([msg]))
+        if st.any():
+            raise ValueError("bls: hash-to-point produced an invalid point")
+        return bytes(out[0])
+
+    def batch_verify(self, publics, msgs, sigs):
+        n = len(msgs)
+        H = self.batch_hash(msgs)
+        ok, st = self.m.batch_validate_pairing(self.m.G1_BASE * n, b"".join(sigs), b"".join(publics), H)
+        return (np.asarray(ok) == 1) & (np.asarray(st) == 0)
+
+    def verify(self, public: bytes, msg: bytes, sig: bytes) -> bool:
+        return bool(self.batch_verify([public], [msg], [sig])[0])
+
+
+def NewSchemeOnG2_bls12381(dst: bytes | None = None) -> SchemeOnG2:
+    from ..pairing import bls12381
+
+    d = bls12381.DOMAIN_G2 if dst is None else dst
+    return SchemeOnG2(bls12381, _grouped(lambda m: bls12381.batch_hash_g2(m, d), 96))
+
+
 def NewSchemeOnG1_bn256() -> SchemeOnG1:
     from ..pairing import bn256
 

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "../kyber_amd/csrc/bls12381.cuh"
+#include "../kyber_amd/csrc/bls12381_h2c.cuh"
 #include "../kyber_amd/csrc/bn256.cuh"
 
 using namespace kyb;
@@ -78,4 +79,17 @@ int hh_bn_pair_check(const uint8_t* p1, const uint8_t* p2, const uint8_t* i1, co
 int hh_bn_gt_mul(const uint8_t* k, const uint8_t* gt, uint8_t* out) { return bn::gt_mul_wire(out, k, gt); }
 int hh_bls_gt_mul(const uint8_t* k, const uint8_t* gt, uint8_t* out) { return bls::gt_mul_wire(out, k, gt); }
 int hh_bn_hash_g1(const uint8_t* msg, int len, uint8_t* out) { return bn::hash_g1_wire(out, msg, (size_t)len); }
+static bls::DstArg mk_dst(const uint8_t* dst, int len) {
+    bls::DstArg d;
+    memset(&d, 0, sizeof d);
+    memcpy(d.b, dst, (size_t)len);
+    d.len = (uint32_t)len;
+    return d;
+}
+int hh_bls_hash_g1(const uint8_t* msg, int len, const uint8_t* dst, int dlen, uint8_t* out) {
+    return bls::hash_g1_wire(out, msg, (size_t)len, mk_dst(dst, dlen));
+}
+int hh_bls_hash_g2(const uint8_t* msg, int len, const uint8_t* dst, int dlen, uint8_t* out) {
+    return bls::hash_g2_wire(out, msg, (size_t)len, mk_dst(dst, dlen));
+}
 }

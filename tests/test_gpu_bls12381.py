@@ -183,3 +183,48 @@ def test_gt_mul_vs_oracle_and_homomorphism(bls):
     bad = np.stack([np.full(576, 0xFF, dtype=np.uint8), np.frombuffer(bytes(575) + b"\x02", dtype=np.uint8)])
     out, st = bls.gt_batch_mul(k[:2], bad)
     assert list(st) == [1, 2] and not out.any()
+
+
+def test_drand_fixtures_through_the_engine(bls, golden_dir):
+    """The reference's BLS12-381 signature fixtures replayed on the GPU: hash-to-curve + decompression + pairing
+    check (kilic/suite_test.go:17-72,84-106; gnark/suite_test.go:16-40; bls12381_test.go:877-904)."""
+    import struct
+
+    from kyber_amd.sign import bls as sbls
+
+    D = json.load(open(os.path.join(golden_dir, "bls12381_drand.json")))
+    f = D["sig_on_g1"]
+    msg = hashlib.sha256(struct.pack(">Q", f["round"])).digest()
+    pk, sig = bytes.fromhex(f["pk_g2"]), bytes.fromhex(f["sig_g1"])
+    assert not sbls.NewSchemeOnG1_bls12381().verify(pk, msg, sig)  # default G1 domain: must fail
+    assert sbls.NewSchemeOnG1_bls12381(D["dst_g2"].encode()).verify(pk, msg, sig)  # G2 domain on G1: passes
+    f = D["sig_on_g2"]
+    msg = hashlib.sha256(bytes.fromhex(f["prev_sig"]) + struct.pack(">Q", f["round"])).digest()
+    assert sbls.NewSchemeOnG2_bls12381().verify(bytes.fromhex(f["pk_g1"]), msg, bytes.fromhex(f["sig_g2"]))
+    f = D["edge_case"]
+    assert sbls.NewSchemeOnG1_bls12381().verify(bytes.fromhex(f["pk_g2"]), bytes.fromhex(f["msg"]), bytes.fromhex(f["sig_g1"]))
+
+
+def test_hash_to_curve_vs_oracle_and_sign_verify(bls):
+    from kyber_amd.sign import bls as sbls
+
+    msgs = [hashlib.sha256(b"m%d" % i).digest() for i in range(64)]
+    h1, st = bls.batch_hash_g1(msgs)
+    assert not st.any()
+    for i in range(0, 64, 9):
+        assert bytes(h1[i]) == O.g1_compress(O.hash_to_g1(msgs[i], bls.DOMAIN_G1))
+    h2, st = bls.batch_hash_g2(msgs[:8])
+    assert not st.any()
+    for i in (0, 7):
+        assert bytes(h2[i]) == O.g2_compress(O.hash_to_g2(msgs[i], bls.DOMAIN_G2))
+    for ln in (0, 1, 55, 56, 64, 100):
+        m = bytes((5 * i + ln) & 0xFF for i in range(ln))
+        out, st = bls.batch_hash_g1([m], b"QUUX-V01-CS02-with-BLS12381G1_XMD:SHA-256_SSWU_RO_")
+        assert bytes(out[0]) == O.g1_compress(O.hash_to_g1(m, b"QUUX-V01-CS02-with-BLS12381G1_XMD:SHA-256_SSWU_RO_")), ln
+    # sign / verify round trip on both schemes (internal/test/scheme.go shape)
+    x = (0x1234567890ABCDEF << 64 | 0xFEDCBA) % bls.ORDER
+    xb = x.to_bytes(32, "big")
+    for sch, pub in ((sbls.NewSchemeOnG1_bls12381(), bls.g2_commit(xb)[0][0]), (sbls.NewSchemeOnG2_bls12381(), bls.g1_commit(xb)[0][0])):
+        sig = sch.sign(xb, b"Hello Boneh-Lynn-Shacham")
+        assert sch.verify(bytes(pub), b"Hello Boneh-Lynn-Shacham", sig)
+        assert not sch.verify(bytes(pub), b"another message", sig)

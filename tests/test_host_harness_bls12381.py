@@ -159,3 +159,15 @@ def test_fp_sqr_dedicated_path():
     for a in vals:
         a %= O.P
         assert H.call("hh_bls_fp_op", 5, _fp(a), _fp(0), out_sizes=(48,))[1] == _fp(a * a % O.P)
+
+
+def test_hash_to_curve_vs_oracle():
+    dst1 = b"BLS_SIG_BLS12381G1_XMD:SHA-256_SSWU_RO_NUL_"
+    dst2 = b"BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_"
+    for msg in (b"", b"abc", bytes(range(32)), b"x" * 55, b"y" * 64, b"z" * 200):
+        for dst in (dst1, dst2, b"QUUX-V01-CS02-with-BLS12381G1_XMD:SHA-256_SSWU_RO_"):
+            exp = O.g1_compress(O.hash_to_g1(msg, dst))
+            assert H.call("hh_bls_hash_g1", msg or b"\\x00", len(msg), dst, len(dst), out_sizes=(48,)) == (0, exp), (msg, dst)
+    for msg in (b"", b"abc", bytes(range(32)), b"w" * 100):
+        exp = O.g2_compress(O.hash_to_g2(msg, dst2))
+        assert H.call("hh_bls_hash_g2", msg or b"\\x00", len(msg), dst2, len(dst2), out_sizes=(96,)) == (0, exp), msg

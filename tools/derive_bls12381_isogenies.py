@@ -228,7 +228,8 @@ def main():
          "namespace kyb {", "struct Bls12381H2c {"]
     neg_b_over_a = (-g1["B"] * pow(g1["A"], -1, p)) % p
     b_over_za = g1["B"] * pow(g1["Z"] * g1["A"], -1, p) % p
-    H += [f"    static constexpr uint32_t G1_A[13] = {m1(g1['A'])};",
+    H += [f"    static constexpr uint32_t TWO384[13] = {m1(pow(2, 384, p))};  // 2^384 mod p (hash_to_field: 512-bit -> Fp)",
+          f"    static constexpr uint32_t G1_A[13] = {m1(g1['A'])};",
           f"    static constexpr uint32_t G1_B[13] = {m1(g1['B'])};",
           f"    static constexpr uint32_t G1_Z[13] = {m1(g1['Z'])};",
           f"    static constexpr uint32_t G1_NEG_B_OVER_A[13] = {m1(neg_b_over_a)};",
