@@ -128,6 +128,16 @@ int kyb_bls12381_hash_g1_dev(size_t n, const void *d_msgs, size_t msg_len, const
                              void *d_out, void *d_status, void *stream);
 int kyb_bls12381_hash_g2_dev(size_t n, const void *d_msgs, size_t msg_len, const uint8_t *dst, size_t dst_len,
                              void *d_out, void *d_status, void *stream);
+/* ok[i] = bls.Verify(pubkeys[i], msgs[i], sigs[i]) for the scheme with signatures on G1 and keys on G2
+ * (sign/bls/bls.go:82-96 with the pairing closure of bls.go:36-38): e(H(msg), X) == e(sig, G2.Base()), hashing,
+ * both UnmarshalBinary checks, two Miller loops and one final exponentiation fused per lane (the hashed point is
+ * never encoded / re-decoded).  Equal-length messages packed back to back; dst is a HOST pointer.  status[i] != 0
+ * (and ok[i] = 0) where the key or the signature does not unmarshal -- the reference returns an error there. */
+int kyb_bls12381_verify_g1(size_t n, const uint8_t *pubkeys, const uint8_t *msgs, size_t msg_len, const uint8_t *dst,
+                           size_t dst_len, const uint8_t *sigs, uint8_t *ok, uint8_t *status);
+int kyb_bls12381_verify_g1_dev(size_t n, const void *d_pubkeys, const void *d_msgs, size_t msg_len,
+                               const uint8_t *dst, size_t dst_len, const void *d_sigs, void *d_ok, void *d_status,
+                               void *stream);
 /* out[i] = gt[i] ^ scalars[i].  Replaces GTElt.Mul (kilic/gt.go:79-84 -> GT.Exp); inputs are checked
  * like GT.FromBytes (coefficients < p, order-r subgroup). */
 int kyb_bls12381_gt_mul(size_t n, const uint8_t *scalars, const uint8_t *gt, uint8_t *out, uint8_t *status);

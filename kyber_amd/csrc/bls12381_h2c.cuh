@@ -153,10 +153,21 @@ KYB_HD_NOINLINE void g1_iso_map(g1_jac& q, const fp& x, const fp& y) {
     fp_mul(q.Y, t, y);
 }
 // G1Elt.Hash: out = hash_to_curve(msg, dst) as a 48-byte compressed point
+KYB_HD_NOINLINE void hash_g1_point(g1_jac& r, const uint8_t* msg, size_t msg_len, const DstArg& dst);
 KYB_HD int hash_g1_wire(uint8_t* out, const uint8_t* msg, size_t msg_len, const DstArg& dst) {
+    g1_jac r;
+    hash_g1_point(r, msg, msg_len, dst);
+    g1_aff a;
+    jac_to_aff(a, r);
+    g1_encode(out, a);
+    return ST_OK;
+}
+
+// hash_to_curve(msg, dst) as a Jacobian point (no encoding): shared by hash_g1_wire and verify_g1_wire
+KYB_HD_NOINLINE void hash_g1_point(g1_jac& r, const uint8_t* msg, size_t msg_len, const DstArg& dst) {
     uint32_t ub[32];
     expand_message_xmd<4>(ub, msg, msg_len, dst);
-    g1_jac q0, q1, r;
+    g1_jac q0, q1;
     fp u, x, y;
     fp_from_be512(u, ub);
     g1_sswu(x, y, u);
@@ -165,10 +176,32 @@ KYB_HD int hash_g1_wire(uint8_t* out, const uint8_t* msg, size_t msg_len, const 
     g1_sswu(x, y, u);
     g1_iso_map(q1, x, y);
     jac_add(r, q0, q1);
-    jac_mul_u64(r, r, 0xd201000000010001ull);  // h_eff = 1 - x
-    g1_aff a;
-    jac_to_aff(a, r);
-    g1_encode(out, a);
+    jac_mul_u64(r, r, 0xd201000000010001ull);
+}
+// One whole sign/bls Verify (scheme with signatures on G1, keys on G2; sign/bls/bls.go:82-96 with the pairing
+// closure of bls.go:36-38): ok = e(H(msg), X) == e(sig, G2.Base()), where X and sig are unmarshalled with the
+// adapter's checks and H(msg) never leaves the lane -- no encode / re-decode / re-check of the hashed point, and
+// the G2 generator is a constant instead of a decoded operand.
+KYB_HD int verify_g1_wire(uint8_t* ok, const uint8_t* pk96, const uint8_t* msg, size_t msg_len, const DstArg& dst,
+                          const uint8_t* sig48) {
+    g1_aff s, h;
+    g2_aff x, g;
+    *ok = 0;
+    int st = g2_decode(x, pk96, true);
+    const int st2 = g1_decode(s, sig48, true);
+    if (st == ST_OK) st = st2;
+    if (st != ST_OK) return st;
+    g1_jac hj;
+    hash_g1_point(hj, msg, msg_len, dst);
+    jac_to_aff(h, hj);
+    fp2_load_const<TC>(g.x, CC::G2X);
+    fp2_load_const<TC>(g.y, CC::G2Y);
+    g.inf = false;
+    fp_neg(s.y, s.y);
+    fp12 f;
+    miller_loop2(f, h, x, s, g);
+    final_exp(f, f);
+    *ok = fp12_is_one(f) ? 1 : 0;
     return ST_OK;
 }
 

@@ -93,3 +93,47 @@ def batch_hash_g1(msgs, dst: bytes = DOMAIN_G1):
 
 def batch_hash_g2(msgs, dst: bytes = DOMAIN_G2):
     return _batch_hash(2, msgs, dst)
+
+
+def batch_verify_g1(pubkeys, msgs, sigs, dst: bytes = DOMAIN_G1):
+    """(ok, status): N x bls.Verify (sign/bls/bls.go:82-96; signatures on G1, keys on G2) fused in ONE kernel:
+    hash_to_curve, both unmarshal checks, two Miller loops sharing their squarings and one final exponentiation
+    per lane.  msgs: (n, msg_len) uint8 array / CUDA tensor or list of equal-length bytes."""
+    import ctypes
+
+    import numpy as np
+
+    from .._lib import check, load
+    from ._engine import _host, _is_torch, _stream
+
+    lib = load()
+    dbuf = ctypes.create_string_buffer(bytes(dst), len(dst)) if dst else None
+    dptr = ctypes.cast(dbuf, ctypes.c_void_p) if dst else None
+    if _is_torch(msgs):
+        import torch
+
+        m, p, s = msgs.contiguous(), pubkeys.contiguous().view(-1, 96), sigs.contiguous().view(-1, 48)
+        n, ln = m.shape[0], m.shape[1]
+        ok = torch.empty(n, dtype=torch.uint8, device=m.device)
+        st = torch.empty(n, dtype=torch.uint8, device=m.device)
+        check(lib.kyb_bls12381_verify_g1_dev(n, p.data_ptr(), m.data_ptr(), ln, dptr, len(dst), s.data_ptr(), ok.data_ptr(),
+                                             st.data_ptr(), _stream()), "kyb_bls12381_verify_g1_dev")
+        return ok, st
+    if isinstance(msgs, (list, tuple)):
+        ln = len(msgs[0]) if msgs else 0
+        if any(len(x) != ln for x in msgs):
+            raise ValueError("batch_verify_g1: messages must have equal length")
+        mb = np.frombuffer(b"".join(msgs), dtype=np.uint8)
+        n = len(msgs)
+    else:
+        a = np.ascontiguousarray(msgs, dtype=np.uint8)
+        n, ln = a.shape[0], a.shape[1]
+        mb = a.reshape(-1)
+    mb = np.ascontiguousarray(mb) if mb.size else np.zeros(1, dtype=np.uint8)
+    p = _host(pubkeys if not isinstance(pubkeys, (list, tuple)) else b"".join(pubkeys), 96)
+    s = _host(sigs if not isinstance(sigs, (list, tuple)) else b"".join(sigs), 48)
+    ok = np.empty(n, dtype=np.uint8)
+    st = np.empty(n, dtype=np.uint8)
+    check(lib.kyb_bls12381_verify_g1(n, p.ctypes.data, mb.ctypes.data, ln, dptr, len(dst), s.ctypes.data, ok.ctypes.data,
+                                     st.ctypes.data), "kyb_bls12381_verify_g1")
+    return ok, st

@@ -70,13 +70,33 @@ def _grouped(hash_fn, width):
     return batch_hash
 
 
+class _Bls12381SchemeOnG1(SchemeOnG1):
+    """Same interface, but batch_verify is the fused kernel (kyb_bls12381_verify_g1): hash, unmarshal checks,
+    two Miller loops and one final exponentiation per lane in one launch per distinct message length."""
+
+    def __init__(self, suite_module, batch_hash, dst):
+        super().__init__(suite_module, batch_hash)
+        self.dst = dst
+
+    def batch_verify(self, publics, msgs, sigs):
+        out = np.zeros(len(msgs), dtype=bool)
+        by_len = {}
+        for i, m in enumerate(msgs):
+            by_len.setdefault(len(m), []).append(i)
+        for _, idx in by_len.items():
+            ok, st = self.m.batch_verify_g1([publics[i] for i in idx], [bytes(msgs[i]) for i in idx],
+                                            [sigs[i] for i in idx], self.dst)
+            out[idx] = (np.asarray(ok) == 1) & (np.asarray(st) == 0)
+        return out
+
+
 def NewSchemeOnG1_bls12381(dst: bytes | None = None) -> SchemeOnG1:
     """sign/bls NewSchemeOnG1 over the BLS12-381 suite: signatures on G1 (hash_to_curve with the G1 DST of
     kilic/g1.go:17 unless `dst` is given, as NewBLS12381SuiteWithDST allows), keys on G2."""
     from ..pairing import bls12381
 
     d = bls12381.DOMAIN_G1 if dst is None else dst
-    return SchemeOnG1(bls12381, _grouped(lambda m: bls12381.batch_hash_g1(m, d), 48))
+    return _Bls12381SchemeOnG1(bls12381, _grouped(lambda m: bls12381.batch_hash_g1(m, d), 48), d)
 
 
 class SchemeOnG2:

@@ -228,3 +228,29 @@ def test_hash_to_curve_vs_oracle_and_sign_verify(bls):
         sig = sch.sign(xb, b"Hello Boneh-Lynn-Shacham")
         assert sch.verify(bytes(pub), b"Hello Boneh-Lynn-Shacham", sig)
         assert not sch.verify(bytes(pub), b"another message", sig)
+
+
+def test_fused_verify_matches_hash_plus_pairing_check(bls):
+    """kyb_bls12381_verify_g1 == batch_hash_g1 + batch_validate_pairing on 1024 (key, msg, sig) triples with
+    forged entries and undecodable inputs sprinkled in."""
+    n = 1024
+    x = _scalars(b"fv/x", n)
+    msgs = np.frombuffer(hashlib.shake_256(b"fv/m").digest(n * 32), dtype=np.uint8).reshape(n, 32).copy()
+    X, _ = bls.g2_commit(x)
+    Hm, st = bls.batch_hash_g1(msgs)
+    assert not st.any()
+    sig, _ = bls.g1_batch_mul(x, Hm)
+    sig = sig.copy()
+    sig[::5] = Hm[::5]  # forged: valid point, wrong value
+    sig[7] = 0  # does not unmarshal (compression flag missing)
+    X = X.copy()
+    X[11] = 0xFF
+    ok_f, st_f = bls.batch_verify_g1(X, msgs, sig)
+    G2 = np.tile(np.frombuffer(bls.G2_BASE, dtype=np.uint8), (n, 1))
+    ok_r, st_r = bls.batch_validate_pairing(Hm, X, sig, G2)
+    assert ((st_f != 0) == (st_r != 0)).all() and st_f[7] != 0 and st_f[11] != 0
+    assert (ok_f == ok_r).all()
+    exp = np.ones(n, dtype=bool)
+    exp[::5] = False
+    exp[[7, 11]] = False
+    assert (ok_f.astype(bool) == exp).all()

@@ -171,3 +171,21 @@ def test_hash_to_curve_vs_oracle():
     for msg in (b"", b"abc", bytes(range(32)), b"w" * 100):
         exp = O.g2_compress(O.hash_to_g2(msg, dst2))
         assert H.call("hh_bls_hash_g2", msg or b"\\x00", len(msg), dst2, len(dst2), out_sizes=(96,)) == (0, exp), msg
+
+
+def test_fused_verify_replays_drand_fixtures(golden_dir):
+    import hashlib
+    import struct
+
+    D = json.load(open(os.path.join(golden_dir, "bls12381_drand.json")))
+    f = D["sig_on_g1"]
+    msg = hashlib.sha256(struct.pack(">Q", f["round"])).digest()
+    pk, sig = bytes.fromhex(f["pk_g2"]), bytes.fromhex(f["sig_g1"])
+    d1, d2 = D["dst_g1"].encode(), D["dst_g2"].encode()
+    assert H.call("hh_bls_verify_g1", pk, msg, 32, d1, len(d1), sig, out_sizes=(1,)) == (0, bytes([0]))
+    assert H.call("hh_bls_verify_g1", pk, msg, 32, d2, len(d2), sig, out_sizes=(1,)) == (0, bytes([1]))
+    f = D["edge_case"]
+    assert H.call("hh_bls_verify_g1", bytes.fromhex(f["pk_g2"]), bytes.fromhex(f["msg"]), 32, d1, len(d1),
+                  bytes.fromhex(f["sig_g1"]), out_sizes=(1,)) == (0, bytes([1]))
+    st, ok = H.call("hh_bls_verify_g1", bytes(96), msg, 32, d1, len(d1), sig, out_sizes=(1,))
+    assert st == 1 and ok == bytes([0])
