@@ -80,6 +80,13 @@ int kyb_ed25519_mul_dev(size_t n, const void *d_scalars, const void *d_points, v
 int kyb_ed25519_mul_same_base(size_t n, const uint8_t *scalars, const uint8_t point[32],
                               uint8_t *out, uint8_t *status, uint32_t flags);
 
+/* out[i] = Hash(msgs[i], dst): (*point).Hash (group/edwards25519/point.go:325-334), RFC 9380 suite
+ * edwards25519_XMD:SHA-512_ELL2_RO_ (hashToField :336-360, expandMessageXMD :362-430, Elligator 2, cofactor 8).
+ * Equal-length messages packed back to back; dst is a HOST pointer of 1..255 bytes. */
+int kyb_ed25519_hash(size_t n, const uint8_t *msgs, size_t msg_len, const uint8_t *dst, size_t dst_len, uint8_t *out);
+int kyb_ed25519_hash_dev(size_t n, const void *d_msgs, size_t msg_len, const uint8_t *dst, size_t dst_len,
+                         void *d_out, void *stream);
+
 /* Introspection used by the tests: copy the device-built fixed-base table
  * (33 x 8 entries of (y+x, y-x, 2dxy), 10 int32 limbs each) to the host. */
 int kyb_ed25519_debug_base_table(int32_t *out /* 33*8*30 */);

@@ -34,6 +34,8 @@ SIGNATURES = {
     "kyb_ed25519_mul_dev": [_sz, _vp, _vp, _vp, _vp, _u32, _vp],
     "kyb_ed25519_mul_same_base": [_sz, _vp, _vp, _vp, _vp, _u32],
     "kyb_ed25519_debug_base_table": [_vp],
+    "kyb_ed25519_hash": [_sz, _vp, _sz, _vp, _sz, _vp],
+    "kyb_ed25519_hash_dev": [_sz, _vp, _sz, _vp, _sz, _vp, _vp],
     "kyb_ed25519_msm": [_sz, _vp, _vp, _vp, _vp],
     "kyb_ed25519_msm_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
     "kyb_bls12381_g1_msm": [_sz, _vp, _vp, _vp, _vp],

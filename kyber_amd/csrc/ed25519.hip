@@ -10,6 +10,8 @@
 #include "context.h"
 #include "ge25519.cuh"
 #include "msm.cuh"
+#include "ed25519_h2c.cuh"
+#include <string.h>
 
 namespace kyb {
 
@@ -432,5 +434,56 @@ int kyb_ed25519_msm_dev(size_t n, const void* d_scalars, const void* d_points, v
     int rc = kyb::get_ctx(&ctx);
     if (rc) return rc;
     return kyb::msm::run<kyb::EdMsm>(ctx, n, d_scalars, d_points, d_out, d_status, (hipStream_t)stream);
+}
+}
+
+// ---------------------------------------------------------------- (*point).Hash (point.go:325-334)
+namespace kyb {
+__global__ __launch_bounds__(64) void ed25519_hash_kernel(size_t n, const uint8_t* __restrict__ msgs, size_t msg_len,
+                                                          EdDstArg dst, uint8_t* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    ed_hash_wire(out + 32 * idx, msgs + msg_len * idx, msg_len, dst);
+}
+}  // namespace kyb
+
+extern "C" {
+int kyb_ed25519_hash_dev(size_t n, const void* d_msgs, size_t msg_len, const uint8_t* dst, size_t dst_len, void* d_out,
+                         void* stream) {
+    if ((n && ((!d_msgs && msg_len) || !d_out)) || !dst || dst_len == 0 || dst_len > 255) {
+        kyb::set_error("kyb_ed25519_hash_dev: bad argument (the domain separation tag must be 1..255 bytes)");
+        return KYB_E_ARG;
+    }
+    if (!n) return KYB_OK;
+    kyb::EdDstArg d;
+    memset(&d, 0, sizeof d);
+    memcpy(d.b, dst, dst_len);
+    d.len = (uint32_t)dst_len;
+    hipLaunchKernelGGL(kyb::ed25519_hash_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, n,
+                       (const uint8_t*)d_msgs, msg_len, d, (uint8_t*)d_out);
+    KYB_HIP_CHECK(hipGetLastError());
+    return KYB_OK;
+}
+int kyb_ed25519_hash(size_t n, const uint8_t* msgs, size_t msg_len, const uint8_t* dst, size_t dst_len, uint8_t* out) {
+    if (n && ((!msgs && msg_len) || !out)) {
+        kyb::set_error("kyb_ed25519_hash: bad argument");
+        return KYB_E_ARG;
+    }
+    if (!n) return KYB_OK;
+    kyb::DeviceCtx* ctx;
+    int rc = kyb::get_ctx(&ctx);
+    if (rc) return rc;
+    uint8_t *d_m = nullptr, *d_o = nullptr;
+    KYB_HIP_CHECK(hipMalloc(&d_m, n * msg_len + 1));
+    KYB_HIP_CHECK(hipMalloc(&d_o, n * 32));
+    if (msg_len) KYB_HIP_CHECK(hipMemcpy(d_m, msgs, n * msg_len, hipMemcpyHostToDevice));
+    rc = kyb_ed25519_hash_dev(n, d_m, msg_len, dst, dst_len, d_o, nullptr);
+    if (rc == KYB_OK && hipMemcpy(out, d_o, n * 32, hipMemcpyDeviceToHost) != hipSuccess) {
+        kyb::set_error("kyb_ed25519_hash: D2H failed");
+        rc = KYB_E_HIP;
+    }
+    hipFree(d_m);
+    hipFree(d_o);
+    return rc;
 }
 }

@@ -11,8 +11,7 @@
 // return |limb| <= 1.01*2^25 / 1.01*2^24, so one add/sub of two products may
 // feed the next product without a carry.
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "hd.h"
 
 namespace kyb {
 
@@ -20,7 +19,11 @@ struct fe {
     int32_t v[10];
 };
 
+#if defined(__HIPCC__)
 #define KYB_DEV __device__ __forceinline__
+#else
+#define KYB_DEV inline  // host build: tests/host_harness.cpp only
+#endif
 
 KYB_DEV void fe_0(fe& h) {
 #pragma unroll

@@ -149,6 +149,39 @@ def msm(scalars, points):
     return out, st[:n]
 
 
+def batch_hash(msgs, dst: bytes):
+    """out[i] = Hash(msgs[i], dst): (*point).Hash (point.go:325-334, RFC 9380 edwards25519_XMD:SHA-512_ELL2_RO_)
+    for n equal-length messages (list of bytes, (n, len) uint8 array or CUDA tensor)."""
+    import ctypes
+
+    lib = load()
+    dbuf = ctypes.create_string_buffer(bytes(dst), len(dst))
+    dptr = ctypes.cast(dbuf, ctypes.c_void_p)
+    if _is_torch(msgs):
+        import torch
+
+        m = msgs.contiguous()
+        n, ln = m.shape[0], m.shape[1]
+        out = torch.empty((n, 32), dtype=torch.uint8, device=m.device)
+        check(lib.kyb_ed25519_hash_dev(n, m.data_ptr(), ln, dptr, len(dst), out.data_ptr(), _stream_ptr()),
+              "kyb_ed25519_hash_dev")
+        return out
+    if isinstance(msgs, (list, tuple)):
+        ln = len(msgs[0]) if msgs else 0
+        if any(len(x) != ln for x in msgs):
+            raise ValueError("batch_hash: messages must have equal length")
+        n = len(msgs)
+        buf = np.frombuffer(b"".join(msgs), dtype=np.uint8)
+    else:
+        a = np.ascontiguousarray(msgs, dtype=np.uint8)
+        n, ln = a.shape[0], a.shape[1]
+        buf = a.reshape(-1)
+    buf = np.ascontiguousarray(buf) if buf.size else np.zeros(1, dtype=np.uint8)
+    out = np.empty((n, 32), dtype=np.uint8)
+    check(lib.kyb_ed25519_hash(n, buf.ctypes.data, ln, dptr, len(dst), out.ctypes.data), "kyb_ed25519_hash")
+    return out
+
+
 # ------------------------------------------------------- kyber.Scalar mirror
 class Scalar:
     """kyber.Scalar for Ed25519 (group/edwards25519/scalar.go:32-34): 32 bytes LE."""
@@ -310,6 +343,12 @@ class Point:
         """A random element of the prime-order subgroup, k * B.  (The reference's Pick embeds random
         data, point.go:177-233; its outputs are random too and only reproducible with Go's XOF stream.)"""
         return self.Mul(Scalar().Pick(rand), None)
+
+    def Hash(self, m: bytes, dst: str | bytes) -> "Point":
+        """kyber.HashablePoint (hash.go:13; point.go:325-334)."""
+        d = dst.encode() if isinstance(dst, str) else bytes(dst)
+        self.enc = bytes(batch_hash([bytes(m)], d)[0])
+        return self
 
     def Mul(self, s: Scalar, A: "Point | None") -> "Point":
         a = _sc(s).v

@@ -274,3 +274,30 @@ def hash_to_curve_from_u(u0: int, u1: int):
     """point.go:325-334 Hash after hashToField: Q0 + Q1, times cofactor 8."""
     q = add(map_to_curve_elligator2(u0), map_to_curve_elligator2(u1))
     return mul_int(8, q)
+
+
+def expand_message_xmd_sha512(msg: bytes, dst: bytes, n: int) -> bytes:
+    """point.go:362-430 expandMessageXMD with SHA-512 (RFC 9380 section 5.3.1; b_in_bytes 64, s_in_bytes 128)."""
+    import struct
+
+    ell = (n + 63) // 64
+    if ell > 255 or n > 65535 or not dst or len(dst) > 255:
+        raise ValueError("invalid parameters")
+    dst_prime = dst + bytes([len(dst)])
+    b0 = hashlib.sha512(bytes(128) + msg + struct.pack(">H", n) + b"\x00" + dst_prime).digest()
+    b = [hashlib.sha512(b0 + b"\x01" + dst_prime).digest()]
+    for i in range(2, ell + 1):
+        b.append(hashlib.sha512(bytes(x ^ y for x, y in zip(b0, b[-1])) + bytes([i]) + dst_prime).digest())
+    return b"".join(b)[:n]
+
+
+def hash_to_field(msg: bytes, dst: bytes):
+    """point.go:336-360 hashToField(m, dst, 2): two 48-byte big-endian integers mod p."""
+    ub = expand_message_xmd_sha512(msg, dst, 96)
+    return int.from_bytes(ub[:48], "big") % P, int.from_bytes(ub[48:], "big") % P
+
+
+def hash_to_curve(msg: bytes, dst: bytes) -> bytes:
+    """(*point).Hash (point.go:325-334): 32-byte encoding of clear_cofactor(map(u0) + map(u1))."""
+    u0, u1 = hash_to_field(msg, dst)
+    return encode(hash_to_curve_from_u(u0, u1))

@@ -74,7 +74,15 @@ def main():
     us = re.findall(r'"([0-9a-f]{40,64})"', f1)
     ps = re.findall(r'"([0-9a-f]{40,64})"', f2)[:10]
     assert len(us) == 10 and len(ps) == 10
-    misc["rfc9380"] = [dict(u0=us[2 * i], u1=us[2 * i + 1], x=ps[2 * i], y=ps[2 * i + 1])
+    # the five RFC 9380 input messages (point_test.go:21-38) and the suite DST (point_test.go:370)
+    blk = src[src.index("inputsTestVectRFC9380 = []string{"):]
+    blk = blk[:blk.index("\n\t}")]
+    msgs = ["".join(re.findall(r'"([^"]*)"', part)) for part in re.split(r",\n\t\t(?=\")", blk[blk.index("{") + 1:])]
+    msgs = [m for m in msgs][:5]
+    assert [len(m) for m in msgs] == [0, 3, 16, 133, 517], [len(m) for m in msgs]
+    dst = re.search(r'func TestHashToPoint.*?dst := "([^"]+)"', src, re.S).group(1)
+    misc["rfc9380_dst"] = dst
+    misc["rfc9380"] = [dict(msg=msgs[i], u0=us[2 * i], u1=us[2 * i + 1], x=ps[2 * i], y=ps[2 * i + 1])
                        for i in range(5)]
 
     src = open(f"{REF}/group/edwards25519/const.go").read()

@@ -8,6 +8,7 @@
 #include "../kyber_amd/csrc/bls12381.cuh"
 #include "../kyber_amd/csrc/bls12381_h2c.cuh"
 #include "../kyber_amd/csrc/bn256.cuh"
+#include "../kyber_amd/csrc/ed25519_h2c.cuh"
 
 using namespace kyb;
 
@@ -95,5 +96,12 @@ int hh_bls_hash_g2(const uint8_t* msg, int len, const uint8_t* dst, int dlen, ui
 int hh_bls_verify_g1(const uint8_t* pk, const uint8_t* msg, int len, const uint8_t* dst, int dlen, const uint8_t* sig,
                      uint8_t* ok) {
     return bls::verify_g1_wire(ok, pk, msg, (size_t)len, mk_dst(dst, dlen), sig);
+}
+void hh_ed_hash(const uint8_t* msg, int len, const uint8_t* dst, int dlen, uint8_t* out) {
+    EdDstArg d;
+    memset(&d, 0, sizeof d);
+    memcpy(d.b, dst, (size_t)dlen);
+    d.len = (uint32_t)dlen;
+    ed_hash_wire(out, msg, (size_t)len, d);
 }
 }

@@ -193,3 +193,20 @@ def test_point_scalar_mirror_api(ed):
     for v in misc["rfc8032"]:
         sec, _, _ = suite.NewKeyAndSeedWithInput(bytes.fromhex(v["seed"]))
         assert suite.Point().Mul(sec, None).MarshalBinary().hex() == v["pub"]
+
+
+def test_hash_to_curve_rfc9380_vectors(ed):
+    """point_test.go:405-445 TestHashToPoint through the engine, plus batch vs oracle."""
+    import json
+
+    M = json.load(open(os.path.join(G, "ed25519_misc.json")))
+    dst = M["rfc9380_dst"]
+    for v in M["rfc9380"]:
+        P = ed.Point().Hash(v["msg"].encode(), dst)
+        assert O.decode(P.MarshalBinary()) == (int(v["x"], 16), int(v["y"], 16))
+    msgs = [hashlib.sha256(b"h%d" % i).digest() for i in range(300)]
+    out = ed.batch_hash(msgs, b"kyber-test-DST")
+    for i in range(0, 300, 23):
+        assert bytes(out[i]) == O.hash_to_curve(msgs[i], b"kyber-test-DST")
+    with pytest.raises(Exception):
+        ed.batch_hash(msgs[:1], b"")  # the reference rejects an empty domain separator (point.go:365)

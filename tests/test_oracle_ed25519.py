@@ -123,3 +123,13 @@ def test_consttime_high_bit_quirk():
 def test_decode_rejects_nonsquare():
     # y = 2 has no x on the curve
     assert O.decode((2).to_bytes(32, "little")) is None
+
+
+def test_rfc9380_full_pipeline_hash_to_field_and_point():
+    """point_test.go:369-445 TestHashToField / TestHashToPoint from the messages themselves."""
+    dst = MISC["rfc9380_dst"].encode()
+    for v in MISC["rfc9380"]:
+        u0, u1 = O.hash_to_field(v["msg"].encode(), dst)
+        assert (u0, u1) == (int(v["u0"], 16), int(v["u1"], 16))
+        x, y = O.decode(O.hash_to_curve(v["msg"].encode(), dst))
+        assert (x, y) == (int(v["x"], 16), int(v["y"], 16))
