@@ -80,6 +80,11 @@ int kyb_ed25519_mul_dev(size_t n, const void *d_scalars, const void *d_points, v
 int kyb_ed25519_mul_same_base(size_t n, const uint8_t *scalars, const uint8_t point[32],
                               uint8_t *out, uint8_t *status, uint32_t flags);
 
+/* out[i] = a[i] + b[i]: (*point).Add (group/edwards25519/point.go:216-223 -> ge.go:183), both operands
+ * unmarshalled with the reference's rules. */
+int kyb_ed25519_add(size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out, uint8_t *status);
+int kyb_ed25519_add_dev(size_t n, const void *d_a, const void *d_b, void *d_out, void *d_status, void *stream);
+
 /* out[i] = Hash(msgs[i], dst): (*point).Hash (group/edwards25519/point.go:325-334), RFC 9380 suite
  * edwards25519_XMD:SHA-512_ELL2_RO_ (hashToField :336-360, expandMessageXMD :362-430, Elligator 2, cofactor 8).
  * Equal-length messages packed back to back; dst is a HOST pointer of 1..255 bytes. */
@@ -119,6 +124,10 @@ int kyb_bls12381_g1_mul_dev(size_t n, const void *d_scalars, const void *d_point
                             void *d_status, void *stream);
 int kyb_bls12381_g2_mul_dev(size_t n, const void *d_scalars, const void *d_points, size_t point_stride, void *d_out,
                             void *d_status, void *stream);
+
+/* out[i] = a[i] + b[i]: G1Elt.Add / G2Elt.Add (kilic/g1.go:90-96, g2.go). */
+int kyb_bls12381_g1_add(size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out, uint8_t *status);
+int kyb_bls12381_g2_add(size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out, uint8_t *status);
 
 /* gt[i] = e(g1[i], g2[i]).  Replaces Suite.Pair (pairing/pairing.go:12; kilic/suite.go:70-75). */
 int kyb_bls12381_pair(size_t n, const uint8_t *g1, const uint8_t *g2, uint8_t *gt, uint8_t *status);
@@ -176,6 +185,9 @@ int kyb_bn256_g1_mul_dev(size_t n, const void *d_scalars, const void *d_points, 
                          void *d_status, void *stream);
 int kyb_bn256_g2_mul_dev(size_t n, const void *d_scalars, const void *d_points, size_t point_stride, void *d_out,
                          void *d_status, void *stream);
+/* out[i] = a[i] + b[i]: pointG1.Add / pointG2.Add (pairing/bn256/point.go:130-140, 381-391 -> curve.go:69). */
+int kyb_bn256_g1_add(size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out, uint8_t *status);
+int kyb_bn256_g2_add(size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out, uint8_t *status);
 /* gt[i] = e(g1[i], g2[i]): Suite.Pair (pairing/bn256/suite.go:97-103 -> optate.go:266-274). */
 int kyb_bn256_pair(size_t n, const uint8_t *g1, const uint8_t *g2, uint8_t *gt, uint8_t *status);
 int kyb_bn256_pair_dev(size_t n, const void *d_g1, const void *d_g2, void *d_gt, void *d_status, void *stream);

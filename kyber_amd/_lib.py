@@ -34,6 +34,8 @@ SIGNATURES = {
     "kyb_ed25519_mul_dev": [_sz, _vp, _vp, _vp, _vp, _u32, _vp],
     "kyb_ed25519_mul_same_base": [_sz, _vp, _vp, _vp, _vp, _u32],
     "kyb_ed25519_debug_base_table": [_vp],
+    "kyb_ed25519_add": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_ed25519_add_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
     "kyb_ed25519_hash": [_sz, _vp, _sz, _vp, _sz, _vp],
     "kyb_ed25519_hash_dev": [_sz, _vp, _sz, _vp, _sz, _vp, _vp],
     "kyb_ed25519_msm": [_sz, _vp, _vp, _vp, _vp],
@@ -52,6 +54,8 @@ SIGNATURES = {
     "kyb_bls12381_g2_mul_same_base": [_sz, _vp, _vp, _vp, _vp],
     "kyb_bls12381_g1_mul_dev": [_sz, _vp, _vp, _sz, _vp, _vp, _vp],
     "kyb_bls12381_g2_mul_dev": [_sz, _vp, _vp, _sz, _vp, _vp, _vp],
+    "kyb_bls12381_g1_add": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_bls12381_g2_add": [_sz, _vp, _vp, _vp, _vp],
     "kyb_bls12381_pair": [_sz, _vp, _vp, _vp, _vp],
     "kyb_bls12381_hash_g1": [_sz, _vp, _sz, _vp, _sz, _vp, _vp],
     "kyb_bls12381_hash_g2": [_sz, _vp, _sz, _vp, _sz, _vp, _vp],
@@ -70,6 +74,8 @@ SIGNATURES = {
     "kyb_bn256_g2_mul_same_base": [_sz, _vp, _vp, _vp, _vp],
     "kyb_bn256_g1_mul_dev": [_sz, _vp, _vp, _sz, _vp, _vp, _vp],
     "kyb_bn256_g2_mul_dev": [_sz, _vp, _vp, _sz, _vp, _vp, _vp],
+    "kyb_bn256_g1_add": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_bn256_g2_add": [_sz, _vp, _vp, _vp, _vp],
     "kyb_bn256_pair": [_sz, _vp, _vp, _vp, _vp],
     "kyb_bn256_hash_g1": [_sz, _vp, _sz, _vp, _vp],
     "kyb_bn256_hash_g1_dev": [_sz, _vp, _sz, _vp, _vp, _vp],

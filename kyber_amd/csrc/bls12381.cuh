@@ -462,6 +462,41 @@ KYB_HD int g2_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt
     g2_encode(out, a);
     return ST_OK;
 }
+// out = a + b   (Point.Add: kilic/g1.go:90-96, pairing/bn256/point.go:130-140 -> curve.go:69)
+KYB_HD int g1_add_wire(uint8_t* out, const uint8_t* pa, const uint8_t* pb) {
+    g1_aff a, b;
+    int st = g1_decode(a, pa, true);
+    const int st2 = g1_decode(b, pb, true);
+    if (st == ST_OK) st = st2;
+    if (st != ST_OK) {
+        zero_bytes(out, 48);
+        return st;
+    }
+    g1_jac p, q, r;
+    jac_from_aff(p, a);
+    jac_from_aff(q, b);
+    jac_add(r, p, q);
+    jac_to_aff(a, r);
+    g1_encode(out, a);
+    return ST_OK;
+}
+KYB_HD int g2_add_wire(uint8_t* out, const uint8_t* pa, const uint8_t* pb) {
+    g2_aff a, b;
+    int st = g2_decode(a, pa, true);
+    const int st2 = g2_decode(b, pb, true);
+    if (st == ST_OK) st = st2;
+    if (st != ST_OK) {
+        zero_bytes(out, 96);
+        return st;
+    }
+    g2_jac p, q, r;
+    jac_from_aff(p, a);
+    jac_from_aff(q, b);
+    jac_add(r, p, q);
+    jac_to_aff(a, r);
+    g2_encode(out, a);
+    return ST_OK;
+}
 // out = gt^k   (GTElt.Mul, kilic/gt.go:79-84 -> GT.Exp).  Rejected input: status + zero output.
 KYB_HD int gt_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* gt) {
     fp12 f, t;

@@ -389,6 +389,41 @@ KYB_HD int g2_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt
     g2_encode(out, a);
     return ST_OK;
 }
+// out = a + b   (Point.Add: kilic/g1.go:90-96, pairing/bn256/point.go:130-140 -> curve.go:69)
+KYB_HD int g1_add_wire(uint8_t* out, const uint8_t* pa, const uint8_t* pb) {
+    g1_aff a, b;
+    int st = g1_decode(a, pa);
+    const int st2 = g1_decode(b, pb);
+    if (st == ST_OK) st = st2;
+    if (st != ST_OK) {
+        zero_bytes(out, 64);
+        return st;
+    }
+    g1_jac p, q, r;
+    jac_from_aff(p, a);
+    jac_from_aff(q, b);
+    jac_add(r, p, q);
+    jac_to_aff(a, r);
+    g1_encode(out, a);
+    return ST_OK;
+}
+KYB_HD int g2_add_wire(uint8_t* out, const uint8_t* pa, const uint8_t* pb) {
+    g2_aff a, b;
+    int st = g2_decode(a, pa);
+    const int st2 = g2_decode(b, pb);
+    if (st == ST_OK) st = st2;
+    if (st != ST_OK) {
+        zero_bytes(out, 128);
+        return st;
+    }
+    g2_jac p, q, r;
+    jac_from_aff(p, a);
+    jac_from_aff(q, b);
+    jac_add(r, p, q);
+    jac_to_aff(a, r);
+    g2_encode(out, a);
+    return ST_OK;
+}
 // pointG1.Hash -> hashToPoint (point.go:261-313): x = SHA-256(m) mod p; while x^3 + 3 has no square root
 // x += 1; y = (x^3 + 3)^((p+1)/4) (big.Int.ModSqrt for p = 3 mod 4).  Output: 64-byte G1 encoding.
 KYB_HD int hash_g1_wire(uint8_t* out, const uint8_t* msg, size_t len) {

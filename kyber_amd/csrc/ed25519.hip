@@ -487,3 +487,74 @@ int kyb_ed25519_hash(size_t n, const uint8_t* msgs, size_t msg_len, const uint8_
     return rc;
 }
 }
+
+// ---------------------------------------------------------------- batch Point.Add (point.go:216-223 -> ge.go:183)
+namespace kyb {
+__global__ __launch_bounds__(128) void ed25519_add_kernel(size_t n, const uint32_t* __restrict__ a,
+                                                          const uint32_t* __restrict__ b, uint32_t* __restrict__ out,
+                                                          uint8_t* __restrict__ status) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    uint32_t wa[8], wb[8], w[8];
+    load_words8(wa, a + idx * 8);
+    load_words8(wb, b + idx * 8);
+    ge_p3 A, B, R;
+    const bool ok = ge_p3_fromwords(A, wa) & ge_p3_fromwords(B, wb);
+    ge_cached c;
+    ge_p3_to_cached(c, B);
+    ge_p1p1 t;
+    ge_add(t, A, c);
+    ge_p1p1_to_p3(R, t);
+    ge_p3_towords(w, R);
+    if (!ok) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = 0;
+    }
+    store_words8(out + idx * 8, w);
+    if (status) status[idx] = ok ? KYB_ST_OK : KYB_ST_BAD_POINT;
+}
+}  // namespace kyb
+extern "C" {
+int kyb_ed25519_add_dev(size_t n, const void* d_a, const void* d_b, void* d_out, void* d_status, void* stream) {
+    if (n && (!d_a || !d_b || !d_out)) {
+        kyb::set_error("kyb_ed25519_add_dev: bad argument");
+        return KYB_E_ARG;
+    }
+    if (!n) return KYB_OK;
+    hipLaunchKernelGGL(kyb::ed25519_add_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (hipStream_t)stream, n,
+                       (const uint32_t*)d_a, (const uint32_t*)d_b, (uint32_t*)d_out, (uint8_t*)d_status);
+    KYB_HIP_CHECK(hipGetLastError());
+    return KYB_OK;
+}
+int kyb_ed25519_add(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, uint8_t* status) {
+    if (n && (!a || !b || !out)) {
+        kyb::set_error("kyb_ed25519_add: bad argument");
+        return KYB_E_ARG;
+    }
+    if (!n) return KYB_OK;
+    kyb::DeviceCtx* ctx;
+    int rc = kyb::get_ctx(&ctx);
+    if (rc) return rc;
+    uint8_t *d_a = nullptr, *d_b = nullptr, *d_o = nullptr, *d_st = nullptr;
+    KYB_HIP_CHECK(hipMalloc(&d_a, n * 32));
+    KYB_HIP_CHECK(hipMalloc(&d_b, n * 32));
+    KYB_HIP_CHECK(hipMalloc(&d_o, n * 32));
+    KYB_HIP_CHECK(hipMalloc(&d_st, n));
+    KYB_HIP_CHECK(hipMemcpy(d_a, a, n * 32, hipMemcpyHostToDevice));
+    KYB_HIP_CHECK(hipMemcpy(d_b, b, n * 32, hipMemcpyHostToDevice));
+    rc = kyb_ed25519_add_dev(n, d_a, d_b, d_o, d_st, nullptr);
+    if (rc == KYB_OK) {
+        hipError_t e = hipMemcpy(out, d_o, n * 32, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && status) e = hipMemcpy(status, d_st, n, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            kyb::set_error("kyb_ed25519_add: D2H failed");
+            rc = KYB_E_HIP;
+        }
+    }
+    hipFree(d_a);
+    hipFree(d_b);
+    hipFree(d_o);
+    hipFree(d_st);
+    return rc;
+}
+}

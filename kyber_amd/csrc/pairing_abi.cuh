@@ -59,6 +59,22 @@ __global__ __launch_bounds__(64) void PFX##_g2_mul_kernel(size_t n, const uint8_
     const int st = NS::g2_mul_wire(out + G2SZ * idx, scalars + 32 * idx, pts + pt_stride * idx); \
     if (status) status[idx] = (uint8_t)st; \
 } \
+__global__ __launch_bounds__(64) void PFX##_g1_add_kernel(size_t n, const uint8_t* __restrict__ a, \
+                                                        const uint8_t* __restrict__ b, uint8_t* __restrict__ out, \
+                                                        uint8_t* __restrict__ status) { \
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
+    if (idx >= n) return; \
+    const int st = NS::g1_add_wire(out + G1SZ * idx, a + G1SZ * idx, b + G1SZ * idx); \
+    if (status) status[idx] = (uint8_t)st; \
+} \
+__global__ __launch_bounds__(64) void PFX##_g2_add_kernel(size_t n, const uint8_t* __restrict__ a, \
+                                                        const uint8_t* __restrict__ b, uint8_t* __restrict__ out, \
+                                                        uint8_t* __restrict__ status) { \
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
+    if (idx >= n) return; \
+    const int st = NS::g2_add_wire(out + G2SZ * idx, a + G2SZ * idx, b + G2SZ * idx); \
+    if (status) status[idx] = (uint8_t)st; \
+} \
 } \
 extern "C" { \
 int kyb_##PFX##_g1_mul_dev(size_t n, const void* d_scalars, const void* d_points, size_t point_stride, \
@@ -121,6 +137,37 @@ int kyb_##PFX##_g1_mul_same_base(size_t n, const uint8_t* scalars, const uint8_t
 int kyb_##PFX##_g2_mul_same_base(size_t n, const uint8_t* scalars, const uint8_t* point, uint8_t* out, \
                                   uint8_t* status) { \
     return PFX##_mul_host(true, n, scalars, point, 0, out, status); \
+} \
+static int PFX##_add_host(bool g2, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, uint8_t* status) { \
+    const size_t psz = g2 ? G2SZ : G1SZ; \
+    if (n && (!a || !b || !out)) { \
+        kyb::set_error("kyb_" #PFX "_g*_add: bad argument"); \
+        return KYB_E_ARG; \
+    } \
+    if (!n) return KYB_OK; \
+    kyb::DeviceCtx* ctx; \
+    KYB_TRY(kyb::get_ctx(&ctx)); \
+    kyb::StageBuf x, y, o, st; \
+    KYB_TRY(x.upload(a, n * psz)); \
+    KYB_TRY(y.upload(b, n * psz)); \
+    KYB_TRY(o.alloc(n * psz)); \
+    KYB_TRY(st.alloc(n)); \
+    if (g2) \
+        hipLaunchKernelGGL(kyb::PFX##_g2_add_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, nullptr, n, (const uint8_t*)x.p, \
+                           (const uint8_t*)y.p, (uint8_t*)o.p, (uint8_t*)st.p); \
+    else \
+        hipLaunchKernelGGL(kyb::PFX##_g1_add_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, nullptr, n, (const uint8_t*)x.p, \
+                           (const uint8_t*)y.p, (uint8_t*)o.p, (uint8_t*)st.p); \
+    KYB_HIP_CHECK(hipGetLastError()); \
+    KYB_TRY(o.download(out, n * psz)); \
+    if (status) KYB_TRY(st.download(status, n)); \
+    return KYB_OK; \
+} \
+int kyb_##PFX##_g1_add(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, uint8_t* status) { \
+    return PFX##_add_host(false, n, a, b, out, status); \
+} \
+int kyb_##PFX##_g2_add(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, uint8_t* status) { \
+    return PFX##_add_host(true, n, a, b, out, status); \
 } \
 }
 

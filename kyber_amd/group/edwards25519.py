@@ -149,6 +149,29 @@ def msm(scalars, points):
     return out, st[:n]
 
 
+def batch_add(a, b):
+    """(out, status): out[i] = a[i] + b[i]  (N x Point.Add, point.go:216-223)."""
+    lib = load()
+    if _is_torch(a):
+        import torch
+
+        x, y = a.contiguous().view(-1, 32), b.contiguous().view(-1, 32)
+        if x.shape != y.shape:
+            raise ValueError("length mismatch")
+        out = torch.empty_like(x)
+        st = torch.empty(x.shape[0], dtype=torch.uint8, device=x.device)
+        check(lib.kyb_ed25519_add_dev(x.shape[0], x.data_ptr(), y.data_ptr(), out.data_ptr(), st.data_ptr(), _stream_ptr()),
+              "kyb_ed25519_add_dev")
+        return out, st
+    x, y = _as_host(a, 32), _as_host(b, 32)
+    if x.shape != y.shape:
+        raise ValueError("length mismatch")
+    out = np.empty_like(x)
+    st = np.empty(x.shape[0], dtype=np.uint8)
+    check(lib.kyb_ed25519_add(x.shape[0], x.ctypes.data, y.ctypes.data, out.ctypes.data, st.ctypes.data), "kyb_ed25519_add")
+    return out, st
+
+
 def batch_hash(msgs, dst: bytes):
     """out[i] = Hash(msgs[i], dst): (*point).Hash (point.go:325-334, RFC 9380 edwards25519_XMD:SHA-512_ELL2_RO_)
     for n equal-length messages (list of bytes, (n, len) uint8 array or CUDA tensor)."""
@@ -321,12 +344,11 @@ class Point:
         return self.enc == _pt(p).enc
 
     def Add(self, a: "Point", b: "Point") -> "Point":
-        """a + b as a two-term MSM with unit scalars (the engine's complete unified addition, ge.go:183)."""
-        one = (1).to_bytes(32, "little")
-        out, st = msm(one + one, _pt(a).enc + _pt(b).enc)
+        """a + b through the engine's batch addition (the complete unified addition, ge.go:183)."""
+        out, st = batch_add(_pt(a).enc, _pt(b).enc)
         if st.any():
             raise ValueError("invalid Ed25519 curve point")
-        self.enc = bytes(out)
+        self.enc = bytes(out[0])
         return self
 
     def Neg(self, a: "Point") -> "Point":

@@ -81,6 +81,19 @@ class Engine:
     def g2_commit(self, scalars, base=None):
         return self.mul(2, scalars, self.G2_BASE if base is None else base, True)
 
+    def add(self, group: int, a, b):
+        """(out, status): out[i] = a[i] + b[i]  (N x Point.Add)."""
+        w = self.G1_LEN if group == 1 else self.G2_LEN
+        x, y = _host(a, w), _host(b, w)
+        if x.shape != y.shape:
+            raise ValueError("length mismatch")
+        n = x.shape[0]
+        out = np.empty((n, w), dtype=np.uint8)
+        st = np.empty(n, dtype=np.uint8)
+        fn, nm = self._fn(f"g{group}_add")
+        check(fn(n, x.ctypes.data, y.ctypes.data, out.ctypes.data, st.ctypes.data), nm)
+        return out, st
+
     def msm(self, group: int, scalars, points):
         """(out, status): out = sum_i scalars[i] * points[i] as ONE encoded point -- the MSM-shaped call
         sites of the reference (share/poly.go:340-348, 449-476; sign/bdn/bdn.go:126-181).  If any
@@ -275,12 +288,10 @@ class Engine:
             def Equal(self, p) -> bool: return self.enc == self._cast(p).enc
 
             def Add(self, a, b):
-                """a + b as a two-term MSM with unit scalars (the engine's complete addition)."""
-                one = (1).to_bytes(32, "big")
-                out, st = eng.msm(self.GROUP, one + one, self._cast(a).enc + self._cast(b).enc)
+                out, st = eng.add(self.GROUP, self._cast(a).enc, self._cast(b).enc)
                 if st.any():
                     raise ValueError(f"{eng.name}: invalid point")
-                self.enc = bytes(out)
+                self.enc = bytes(out[0])
                 return self
 
             def Neg(self, a):

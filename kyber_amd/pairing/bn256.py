@@ -37,6 +37,8 @@ batch_pair, batch_validate_pairing = ENGINE.batch_pair, ENGINE.batch_validate_pa
 _mul = ENGINE.mul
 g1_msm, g2_msm = ENGINE.g1_msm, ENGINE.g2_msm
 gt_batch_mul = ENGINE.gt_batch_mul
+g1_batch_add = lambda a, b: ENGINE.add(1, a, b)
+g2_batch_add = lambda a, b: ENGINE.add(2, a, b)
 Scalar, G1Elt, G2Elt, GTElt, Suite = ENGINE.make_types()
 
 

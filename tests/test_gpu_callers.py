@@ -119,3 +119,53 @@ def test_tbls_sign_recover_verify_bn256():
     assert plain.verify(pub.Commit().MarshalBinary(), msg, sig)
     with pytest.raises(ValueError):
         sch.recover(pub, msg, partials[:2], t, n)
+
+
+def test_eddsa_wycheproof_vectors_through_the_engine(golden_dir):
+    """sign/eddsa/eddsa_test.go:355 TestWycheProof: all 150 cases, result must equal the vector's verdict."""
+    from kyber_amd.sign import eddsa
+
+    M = json.load(open(os.path.join(golden_dir, "ed25519_misc.json")))
+    W = M["wycheproof"]
+    ok = eddsa.batch_verify_with_checks([bytes.fromhex(c["pk"]) for c in W], [bytes.fromhex(c["msg"]) for c in W],
+                                        [bytes.fromhex(c["sig"]) for c in W])
+    bad = [c["id"] for c, o in zip(W, ok) if bool(o) != c["valid"]]
+    assert not bad, bad
+    # RFC 8032 vectors (eddsa_test.go:24-52) verify too
+    R8 = M["rfc8032"]
+    ok = eddsa.batch_verify_with_checks([bytes.fromhex(c["pub"]) for c in R8], [bytes.fromhex(c["msg"]) for c in R8],
+                                        [bytes.fromhex(c["sig"]) for c in R8])
+    assert ok.all()
+
+
+def test_batch_add_all_groups():
+    from kyber_amd.group import edwards25519 as ed
+    from kyber_amd.pairing import bls12381 as bls, bn256 as bn
+    from oracle import bls12381 as OB, bn256 as ON, ed25519 as O
+
+    rng = random.Random(21)
+    # Ed25519: incl. identity, doubling (a == b) and inverse (a + (-a))
+    ks = [rng.randrange(1, O.L) for _ in range(6)]
+    pts = [O.mul_int(k, O.B) for k in ks]
+    a = [pts[0], pts[1], pts[2], pts[3], O.IDENTITY, pts[4]]
+    b = [pts[1], pts[1], O.neg(pts[2]), O.IDENTITY, pts[5], pts[5]]
+    out, st = ed.batch_add(b"".join(O.encode(p) for p in a), b"".join(O.encode(p) for p in b))
+    assert not st.any()
+    for i in range(6):
+        assert bytes(out[i]) == O.encode(O.add(a[i], b[i])), i
+    out, st = ed.batch_add(O.encode(pts[0]), bytes([2]) + bytes(31))
+    assert st[0] == 1 and not out.any()
+    for m, OR, e1, e2, order in ((bls, OB, OB.g1_compress, OB.g2_compress, OB.R), (bn, ON, ON.g1_marshal, ON.g2_marshal, ON.ORDER)):
+        ks = [rng.randrange(1, order) for _ in range(4)]
+        p1 = [OR.g1_mul(k, OR.G1_GEN) for k in ks]
+        p2 = [OR.g2_mul(k, OR.G2_GEN) for k in ks]
+        a1, b1 = [p1[0], p1[1], p1[2], None], [p1[1], p1[1], OR.g1_neg(p1[2]), p1[3]]
+        a2, b2 = [p2[0], p2[1], p2[2], None], [p2[1], p2[1], OR.g2_neg(p2[2]), p2[3]]
+        out, st = m.g1_batch_add(b"".join(e1(p) for p in a1), b"".join(e1(p) for p in b1))
+        assert not st.any()
+        for i in range(4):
+            assert bytes(out[i]) == e1(OR.g1_add(a1[i], b1[i])), (m.__name__, i)
+        out, st = m.g2_batch_add(b"".join(e2(p) for p in a2), b"".join(e2(p) for p in b2))
+        assert not st.any()
+        for i in range(4):
+            assert bytes(out[i]) == e2(OR.g2_add(a2[i], b2[i])), (m.__name__, i)
