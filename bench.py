@@ -37,9 +37,12 @@ N_PER_GPU = 1 << 20
 BYTES_VAR, BYTES_FIX = 96, 64
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # 64-bit integer multiply-adds (v_mad_i64_i32) per scalar multiplication as built:
-# a field multiplication is 100 MADs, a squaring 55; variable-base = 1366 M + 1517 S, fixed-base = 475 M + 270 S
-IMADS_VAR = 1366 * 100 + 1517 * 55
-IMADS_FIX = 475 * 100 + 270 * 55
+# a field multiplication is 100 MADs, a squaring 55.  With an in-kernel ToBytes, variable-base = 1366 M + 1517 S
+# and fixed-base = 475 M + 270 S; batches >= 4096 defer the encoding to ed25519_encode_kernel, which replaces the
+# per-element inversion (254 S + 11 M) by 3 M + 1/16 of an inversion (Montgomery's trick over 16 elements).
+_INV_SAVED = (254 * 55 + 11 * 100) - (3 * 100 + (254 * 55 + 11 * 100) / 16)
+IMADS_VAR = int(1366 * 100 + 1517 * 55 - _INV_SAVED)
+IMADS_FIX = int(475 * 100 + 270 * 55 - _INV_SAVED)
 
 
 def shake(label: bytes, nbytes: int) -> np.ndarray:
@@ -345,7 +348,7 @@ def main():
                          "unit": "GB/s", "frac": BYTES_VAR * n / var_s / 1e9 / HBM_PEAK_GBS,
                          "traffic": traffic,
                          "binding_resource": "integer VALU issue (v_mad_i64_i32), not HBM and not MFMA: "
-                                             "96 algorithmic bytes per 2.2e5 integer MADs -- see 'valu'",
+                                             "96 algorithmic bytes per 2.06e5 integer MADs -- see 'valu'",
                          "valu": {"imads_per_op": IMADS_VAR, "achieved": IMADS_VAR * n / var_s,
                                   "peak": imad_peak, "unit": "v_mad_i64_i32 lane-ops/s",
                                   "frac": (IMADS_VAR * n / var_s / imad_peak) if imad_peak else None,

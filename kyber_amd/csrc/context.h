@@ -31,6 +31,9 @@ struct DeviceCtx {
     std::mutex msm_mu;  // serialises host-buffer MSM calls (they share the workspace)
     // Ed25519 fixed-base table: [33][8][3][10] int32 (built on device at init)
     int32_t* ed_base_tab = nullptr;
+    // Ed25519 deferred-encoding workspace: parked (X, Y, Z) triples of the last large batch
+    void* ed_proj = nullptr;
+    size_t ed_proj_bytes = 0;
     // scratch workspace (host entry points stage through it)
     void* ws = nullptr;
     size_t ws_bytes = 0;

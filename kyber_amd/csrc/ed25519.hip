@@ -79,6 +79,67 @@ __global__ void ed25519_build_base_table_kernel(int32_t* __restrict__ tab) {
     }
 }
 
+// ------------------------------------------------------ deferred encoding (batched inversion)
+// The field inversion of ToBytes (254 squarings, 22 % of a fixed-base and 6 % of a variable-base
+// multiplication) is amortised: the multiplication kernels park (X, Y, Z) in HBM (30 limbs, 120 B per
+// element) and a second kernel inverts ENC_CHUNK Z's per lane with Montgomery's trick -- 3 multiplications
+// per element plus 1/ENC_CHUNK of an inversion -- before encoding.
+constexpr int ENC_CHUNK = 16;
+
+KYB_DEV void store_proj(int32_t* __restrict__ proj, size_t idx, const ge_p3& h) {
+    int32_t* o = proj + idx * 30;
+#pragma unroll
+    for (int l = 0; l < 10; l++) {
+        o[l] = h.X.v[l];
+        o[10 + l] = h.Y.v[l];
+        o[20 + l] = h.Z.v[l];
+    }
+}
+KYB_DEV void load_fe(fe& f, const int32_t* __restrict__ p) {
+#pragma unroll
+    for (int l = 0; l < 10; l++) f.v[l] = p[l];
+}
+__global__ __launch_bounds__(64) void ed25519_encode_kernel(size_t n, const int32_t* __restrict__ proj,
+                                                            const uint8_t* __restrict__ status,
+                                                            uint32_t* __restrict__ out) {
+    const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t lo = lane * ENC_CHUNK;
+    if (lo >= n) return;
+    const int cnt = (int)((n - lo) < (size_t)ENC_CHUNK ? (n - lo) : (size_t)ENC_CHUNK);
+    fe pre[ENC_CHUNK];  // pre[j] = Z_0 ... Z_j
+    fe z, acc;
+    load_fe(acc, proj + lo * 30 + 20);
+    pre[0] = acc;
+#pragma unroll 1
+    for (int j = 1; j < cnt; j++) {
+        load_fe(z, proj + (lo + j) * 30 + 20);
+        fe_mul(acc, acc, z);
+        pre[j] = acc;
+    }
+    fe inv;
+    fe_invert(inv, acc);  // 1 / (Z_0 ... Z_{cnt-1})
+#pragma unroll 1
+    for (int j = cnt - 1; j >= 0; j--) {
+        fe zi, X, Y;
+        load_fe(z, proj + (lo + j) * 30 + 20);
+        if (j > 0) {
+            fe_mul(zi, inv, pre[j - 1]);  // 1 / Z_j
+            fe_mul(inv, inv, z);
+        } else {
+            zi = inv;
+        }
+        load_fe(X, proj + (lo + j) * 30);
+        load_fe(Y, proj + (lo + j) * 30 + 10);
+        uint32_t w[8];
+        ge_encode_with_zinv(w, X, Y, zi);
+        if (status && status[lo + j]) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) w[i] = 0;
+        }
+        store_words8(out + (lo + j) * 8, w);
+    }
+}
+
 // ------------------------------------------------------------ fixed-base mul
 // LDS holds the whole 33x8 table (31,680 B); every lane gathers its own entry.
 // Entry stride is 30 dwords, so the 8 possible |digit| values of one position
@@ -103,7 +164,7 @@ KYB_DEV void select_precomp_lds(ge_precomp& t, const int32_t* s_tab, int pos, in
 
 __global__ __launch_bounds__(256) void ed25519_mul_base_kernel(
     size_t n, const uint32_t* __restrict__ scalars, uint32_t* __restrict__ out,
-    const int32_t* __restrict__ tab, uint32_t flags) {
+    const int32_t* __restrict__ tab, uint32_t flags, int32_t* __restrict__ proj) {
     __shared__ int32_t s_tab[ED_TAB_WORDS];
     for (int i = threadIdx.x; i < ED_TAB_WORDS; i += blockDim.x) s_tab[i] = tab[i];
     __syncthreads();
@@ -139,6 +200,10 @@ __global__ __launch_bounds__(256) void ed25519_mul_base_kernel(
             select_precomp_lds(t, s_tab, i >> 1, e[i]);
             ge_madd(r, h, t);
             ge_p1p1_to_p3(h, r);
+        }
+        if (proj) {  // encoding deferred to ed25519_encode_kernel
+            store_proj(proj, idx, h);
+            continue;
         }
         uint32_t w[8];
         ge_p3_towords(w, h);
@@ -196,7 +261,7 @@ KYB_DEV void ge_scalarmult_w4(ge_p3& h, const int8_t e[65], const ge_p3& A, bool
 __global__ __launch_bounds__(128) void ed25519_mul_kernel(
     size_t n, const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ points,
     size_t points_stride, uint32_t* __restrict__ out, uint8_t* __restrict__ status,
-    uint32_t flags) {
+    uint32_t flags, int32_t* __restrict__ proj) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     const bool full = (flags & KYB_F_VARTIME) != 0;
@@ -209,6 +274,11 @@ __global__ __launch_bounds__(128) void ed25519_mul_kernel(
     recode16(e, a, full);
     ge_p3 h;
     ge_scalarmult_w4(h, e, A, full);
+    if (proj) {  // encoding deferred to ed25519_encode_kernel (status carries the decode verdict)
+        store_proj(proj, idx, h);
+        if (status) status[idx] = ok ? KYB_ST_OK : KYB_ST_BAD_POINT;
+        return;
+    }
     uint32_t w[8];
     ge_p3_towords(w, h);
     if (!ok) {
@@ -231,6 +301,38 @@ int ed25519_build_tables(DeviceCtx* ctx) {
 void ed25519_free_tables(DeviceCtx* ctx) {
     if (ctx->ed_base_tab) hipFree(ctx->ed_base_tab);
     ctx->ed_base_tab = nullptr;
+    if (ctx->ed_proj) hipFree(ctx->ed_proj);
+    ctx->ed_proj = nullptr;
+    ctx->ed_proj_bytes = 0;
+}
+
+// Batches of at least this many elements take the deferred-encoding path (below it the extra launch costs
+// more than the inversions it saves).
+constexpr size_t ENC_DEFER_MIN = 4096;
+
+// Grow-only per-device buffer for the parked (X, Y, Z) triples (+ a status array when the caller passes none).
+// Like the MSM workspace it is shared by all Ed25519 calls on the device: calls on one stream are ordered, and
+// concurrent streams on the same device must not interleave Ed25519 batches larger than ENC_DEFER_MIN.
+static int ed_proj_workspace(DeviceCtx* ctx, size_t n, bool need_status, int32_t** proj, uint8_t** status) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const size_t want = n * 30 * sizeof(int32_t) + (need_status ? n : 0) + 256;
+    if (want > ctx->ed_proj_bytes) {
+        if (ctx->ed_proj) {
+            KYB_HIP_CHECK(hipDeviceSynchronize());
+            KYB_HIP_CHECK(hipFree(ctx->ed_proj));
+            ctx->ed_proj = nullptr;
+            ctx->ed_proj_bytes = 0;
+        }
+        const size_t cap = want + want / 4;
+        if (hipMalloc(&ctx->ed_proj, cap) != hipSuccess) {
+            set_error("ed25519: projective workspace allocation failed");
+            return KYB_E_ALLOC;
+        }
+        ctx->ed_proj_bytes = cap;
+    }
+    *proj = (int32_t*)ctx->ed_proj;
+    if (status) *status = (uint8_t*)ctx->ed_proj + n * 30 * sizeof(int32_t);
+    return KYB_OK;
 }
 
 static int launch_mul_base(DeviceCtx* ctx, size_t n, const void* d_scalars, void* d_out, uint32_t flags,
@@ -240,8 +342,18 @@ static int launch_mul_base(DeviceCtx* ctx, size_t n, const void* d_scalars, void
     size_t want = (n + block - 1) / block;
     size_t cap = (size_t)ctx->num_cu * 4;  // table staging is per block: keep blocks long-lived
     int grid = (int)(want < cap ? want : cap);
+    int32_t* proj = nullptr;
+    if (n >= ENC_DEFER_MIN) {
+        int rc = ed_proj_workspace(ctx, n, false, &proj, nullptr);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(ed25519_mul_base_kernel, dim3(grid), dim3(block), 0, st, n,
-                       (const uint32_t*)d_scalars, (uint32_t*)d_out, ctx->ed_base_tab, flags);
+                       (const uint32_t*)d_scalars, (uint32_t*)d_out, ctx->ed_base_tab, flags, proj);
+    if (proj) {
+        const size_t lanes = (n + ENC_CHUNK - 1) / ENC_CHUNK;
+        hipLaunchKernelGGL(ed25519_encode_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, n, proj,
+                           (const uint8_t*)nullptr, (uint32_t*)d_out);
+    }
     KYB_HIP_CHECK(hipGetLastError());
     return KYB_OK;
 }
@@ -250,9 +362,23 @@ static int launch_mul(size_t n, const void* d_scalars, const void* d_points, siz
     if (n == 0) return KYB_OK;
     const int block = 128;
     size_t grid = (n + block - 1) / block;
+    int32_t* proj = nullptr;
+    uint8_t* stat = (uint8_t*)d_status;
+    if (n >= ENC_DEFER_MIN) {
+        DeviceCtx* ctx;
+        int rc = get_ctx(&ctx);
+        if (rc) return rc;
+        rc = ed_proj_workspace(ctx, n, stat == nullptr, &proj, stat ? nullptr : &stat);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(ed25519_mul_kernel, dim3((unsigned)grid), dim3(block), 0, st, n,
-                       (const uint32_t*)d_scalars, (const uint32_t*)d_points, stride, (uint32_t*)d_out,
-                       (uint8_t*)d_status, flags);
+                       (const uint32_t*)d_scalars, (const uint32_t*)d_points, stride, (uint32_t*)d_out, stat, flags,
+                       proj);
+    if (proj) {
+        const size_t lanes = (n + ENC_CHUNK - 1) / ENC_CHUNK;
+        hipLaunchKernelGGL(ed25519_encode_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, n, proj,
+                           (const uint8_t*)stat, (uint32_t*)d_out);
+    }
     KYB_HIP_CHECK(hipGetLastError());
     return KYB_OK;
 }
