@@ -46,6 +46,22 @@ extern "C" {
                             group/edwards25519/ge_mult_vartime.go:11). Default = constant-time
                             path semantics of ge.go:443 incl. its >= 2^255 behaviour. */
 
+/* Pairing-suite calls (trailing `flags` argument of mul / msm / pair / pair_check / verify):
+ *  KYB_F_UNCOMPRESSED  BLS12-381 point INPUTS are ZCash uncompressed affine (G1 96 B x||y, G2 192 B
+ *                      x.c1||x.c0||y.c1||y.c0): no square root (the `_aff` form of SURVEY.md 8b).  Outputs stay
+ *                      compressed.  bn256's wire format is already uncompressed: the flag changes nothing there.
+ *  KYB_F_TRUSTED(i)    point argument i (0-based, in declaration order) holds points that were validated before --
+ *                      outputs of this library or of an earlier UnmarshalBinary, as every kyber.Point handed to
+ *                      Mul / Pair already is in the reference (validation happens once, in UnmarshalBinary,
+ *                      kilic/g1.go:127-131) -- so the subgroup check (and, for uncompressed input, the curve-equation
+ *                      check) is skipped.  Precondition, not a check: a point outside the subgroup then gives a
+ *                      result the reference could never produce.  bn256 has no subgroup check to skip. */
+#define KYB_F_UNCOMPRESSED 2u
+#define KYB_F_UNCOMPRESSED_OUT 4u /* g1/g2 mul and mul_same_base: write uncompressed outputs (96 / 192 B) as well, so a
+                                     pipeline can keep points in the form that needs no square root; bn256: no-op */
+#define KYB_F_TRUSTED(i) (0x100u << (i))
+#define KYB_F_TRUSTED_ALL 0xF00u
+
 int kyb_version(void);
 const char *kyb_last_error(void);
 
@@ -111,27 +127,28 @@ int kyb_ed25519_debug_base_table(int32_t *out /* 33*8*30 */);
 
 /* out[i] = scalars[i] * points[i].  Replaces G1Elt.UnmarshalBinary + Mul + MarshalBinary
  * (pairing/bls12381/kilic/g1.go:110-131; circl/g1.go:89-96; gnark/g1.go:118-127). */
-int kyb_bls12381_g1_mul(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status);
+int kyb_bls12381_g1_mul(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status, uint32_t flags);
 /* same on G2 (kilic/g2.go; this is what suite.Point().Mul is for the *.adapter suites) */
-int kyb_bls12381_g2_mul(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status);
+int kyb_bls12381_g2_mul(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status, uint32_t flags);
 /* out[i] = scalars[i] * point: the loop of share.PriPoly.Commit (share/poly.go:143-149). */
 int kyb_bls12381_g1_mul_same_base(size_t n, const uint8_t *scalars, const uint8_t point[48], uint8_t *out,
-                                  uint8_t *status);
+                                  uint8_t *status, uint32_t flags);
 int kyb_bls12381_g2_mul_same_base(size_t n, const uint8_t *scalars, const uint8_t point[96], uint8_t *out,
-                                  uint8_t *status);
-/* point_stride: 48 / 96 for per-element points, 0 for one shared base point */
+                                  uint8_t *status, uint32_t flags);
+/* point_stride: the input element size (48 / 96, or 96 / 192 with KYB_F_UNCOMPRESSED) for per-element points,
+ * 0 for one shared base point */
 int kyb_bls12381_g1_mul_dev(size_t n, const void *d_scalars, const void *d_points, size_t point_stride, void *d_out,
-                            void *d_status, void *stream);
+                            void *d_status, uint32_t flags, void *stream);
 int kyb_bls12381_g2_mul_dev(size_t n, const void *d_scalars, const void *d_points, size_t point_stride, void *d_out,
-                            void *d_status, void *stream);
+                            void *d_status, uint32_t flags, void *stream);
 
 /* out[i] = a[i] + b[i]: G1Elt.Add / G2Elt.Add (kilic/g1.go:90-96, g2.go). */
 int kyb_bls12381_g1_add(size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out, uint8_t *status);
 int kyb_bls12381_g2_add(size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out, uint8_t *status);
 
 /* gt[i] = e(g1[i], g2[i]).  Replaces Suite.Pair (pairing/pairing.go:12; kilic/suite.go:70-75). */
-int kyb_bls12381_pair(size_t n, const uint8_t *g1, const uint8_t *g2, uint8_t *gt, uint8_t *status);
-int kyb_bls12381_pair_dev(size_t n, const void *d_g1, const void *d_g2, void *d_gt, void *d_status, void *stream);
+int kyb_bls12381_pair(size_t n, const uint8_t *g1, const uint8_t *g2, uint8_t *gt, uint8_t *status, uint32_t flags);
+int kyb_bls12381_pair_dev(size_t n, const void *d_g1, const void *d_g2, void *d_gt, void *d_status, uint32_t flags, void *stream);
 /* out[i] = hash_to_curve(msgs[i], dst) on G1 / G2 (RFC 9380 BLS12381G1/G2_XMD:SHA-256_SSWU_RO_).  Replaces
  * G1Elt.Hash / G2Elt.Hash (pairing/bls12381/kilic/g1.go:161-170, g2.go; default DSTs kilic/g1.go:17, g2.go:18), the
  * step before the pairing check in sign/bls Verify (bls.go:87-88).  The n messages have the same length msg_len
@@ -150,10 +167,10 @@ int kyb_bls12381_hash_g2_dev(size_t n, const void *d_msgs, size_t msg_len, const
  * never encoded / re-decoded).  Equal-length messages packed back to back; dst is a HOST pointer.  status[i] != 0
  * (and ok[i] = 0) where the key or the signature does not unmarshal -- the reference returns an error there. */
 int kyb_bls12381_verify_g1(size_t n, const uint8_t *pubkeys, const uint8_t *msgs, size_t msg_len, const uint8_t *dst,
-                           size_t dst_len, const uint8_t *sigs, uint8_t *ok, uint8_t *status);
+                           size_t dst_len, const uint8_t *sigs, uint8_t *ok, uint8_t *status, uint32_t flags);
 int kyb_bls12381_verify_g1_dev(size_t n, const void *d_pubkeys, const void *d_msgs, size_t msg_len,
                                const uint8_t *dst, size_t dst_len, const void *d_sigs, void *d_ok, void *d_status,
-                               void *stream);
+                               uint32_t flags, void *stream);
 /* out[i] = gt[i] ^ scalars[i].  Replaces GTElt.Mul (kilic/gt.go:79-84 -> GT.Exp); inputs are checked
  * like GT.FromBytes (coefficients < p, order-r subgroup). */
 int kyb_bls12381_gt_mul(size_t n, const uint8_t *scalars, const uint8_t *gt, uint8_t *out, uint8_t *status);
@@ -162,9 +179,9 @@ int kyb_bls12381_gt_mul_dev(size_t n, const void *d_scalars, const void *d_gt, v
 /* ok[i] = (e(p1[i], p2[i]) == e(inv1[i], inv2[i])).  Replaces Suite.ValidatePairing
  * (pairing/pairing.go:13-15; kilic/suite.go:57-68), the core of sign/bls Verify (bls.go:82-96). */
 int kyb_bls12381_pair_check(size_t n, const uint8_t *p1, const uint8_t *p2, const uint8_t *inv1, const uint8_t *inv2,
-                            uint8_t *ok, uint8_t *status);
+                            uint8_t *ok, uint8_t *status, uint32_t flags);
 int kyb_bls12381_pair_check_dev(size_t n, const void *d_p1, const void *d_p2, const void *d_inv1, const void *d_inv2,
-                                void *d_ok, void *d_status, void *stream);
+                                void *d_ok, void *d_status, uint32_t flags, void *stream);
 
 /* ------------------------------------------------------------------ bn256
  * pairing/bn256 (dclxvi parameters; arithmetic in-tree).  Wire formats (point.go):
@@ -175,22 +192,22 @@ int kyb_bls12381_pair_check_dev(size_t n, const void *d_p1, const void *d_p2, co
  * UnmarshalBinary semantics kept: coordinates are reduced mod p (not rejected), (0,0) is
  * infinity, on-curve check only -- G2 inputs outside the order-n subgroup are accepted and
  * processed like the reference does.  status: KYB_ST_BAD_POINT, output zeroed. */
-int kyb_bn256_g1_mul(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status);
-int kyb_bn256_g2_mul(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status);
+int kyb_bn256_g1_mul(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status, uint32_t flags);
+int kyb_bn256_g2_mul(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status, uint32_t flags);
 int kyb_bn256_g1_mul_same_base(size_t n, const uint8_t *scalars, const uint8_t point[64], uint8_t *out,
-                               uint8_t *status);
+                               uint8_t *status, uint32_t flags);
 int kyb_bn256_g2_mul_same_base(size_t n, const uint8_t *scalars, const uint8_t point[128], uint8_t *out,
-                               uint8_t *status);
+                               uint8_t *status, uint32_t flags);
 int kyb_bn256_g1_mul_dev(size_t n, const void *d_scalars, const void *d_points, size_t point_stride, void *d_out,
-                         void *d_status, void *stream);
+                         void *d_status, uint32_t flags, void *stream);
 int kyb_bn256_g2_mul_dev(size_t n, const void *d_scalars, const void *d_points, size_t point_stride, void *d_out,
-                         void *d_status, void *stream);
+                         void *d_status, uint32_t flags, void *stream);
 /* out[i] = a[i] + b[i]: pointG1.Add / pointG2.Add (pairing/bn256/point.go:130-140, 381-391 -> curve.go:69). */
 int kyb_bn256_g1_add(size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out, uint8_t *status);
 int kyb_bn256_g2_add(size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out, uint8_t *status);
 /* gt[i] = e(g1[i], g2[i]): Suite.Pair (pairing/bn256/suite.go:97-103 -> optate.go:266-274). */
-int kyb_bn256_pair(size_t n, const uint8_t *g1, const uint8_t *g2, uint8_t *gt, uint8_t *status);
-int kyb_bn256_pair_dev(size_t n, const void *d_g1, const void *d_g2, void *d_gt, void *d_status, void *stream);
+int kyb_bn256_pair(size_t n, const uint8_t *g1, const uint8_t *g2, uint8_t *gt, uint8_t *status, uint32_t flags);
+int kyb_bn256_pair_dev(size_t n, const void *d_g1, const void *d_g2, void *d_gt, void *d_status, uint32_t flags, void *stream);
 /* out[i] = Hash(msgs[i]) on G1: pointG1.Hash -> hashToPoint (pairing/bn256/point.go:261-313), SHA-256 then
  * try-and-increment; the step before the pairing check in sign/bls Verify (bls.go:87-88).  All n messages
  * have the same length msg_len and are packed back to back (hash variable-length inputs down first). */
@@ -202,9 +219,9 @@ int kyb_bn256_gt_mul(size_t n, const uint8_t *scalars, const uint8_t *gt, uint8_
 int kyb_bn256_gt_mul_dev(size_t n, const void *d_scalars, const void *d_gt, void *d_out, void *d_status, void *stream);
 /* ok[i] = Pair(p1, p2).Equal(Pair(inv1, inv2)): Suite.ValidatePairing (suite.go:105-107). */
 int kyb_bn256_pair_check(size_t n, const uint8_t *p1, const uint8_t *p2, const uint8_t *inv1, const uint8_t *inv2,
-                         uint8_t *ok, uint8_t *status);
+                         uint8_t *ok, uint8_t *status, uint32_t flags);
 int kyb_bn256_pair_check_dev(size_t n, const void *d_p1, const void *d_p2, const void *d_inv1, const void *d_inv2,
-                             void *d_ok, void *d_status, void *stream);
+                             void *d_ok, void *d_status, uint32_t flags, void *stream);
 
 /* ------------------------------------------------------- multi-scalar multiplication
  * out = sum_i scalars[i] * points[i]  (one point).  The reference has no MSM function: its
@@ -217,18 +234,18 @@ int kyb_bn256_pair_check_dev(size_t n, const void *d_p1, const void *d_p2, const
 int kyb_ed25519_msm(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t out[32], uint8_t *status);
 int kyb_ed25519_msm_dev(size_t n, const void *d_scalars, const void *d_points, void *d_out, void *d_status,
                         void *stream);
-int kyb_bls12381_g1_msm(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t out[48], uint8_t *status);
-int kyb_bls12381_g2_msm(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t out[96], uint8_t *status);
+int kyb_bls12381_g1_msm(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t out[48], uint8_t *status, uint32_t flags);
+int kyb_bls12381_g2_msm(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t out[96], uint8_t *status, uint32_t flags);
 int kyb_bls12381_g1_msm_dev(size_t n, const void *d_scalars, const void *d_points, void *d_out, void *d_status,
-                            void *stream);
+                            uint32_t flags, void *stream);
 int kyb_bls12381_g2_msm_dev(size_t n, const void *d_scalars, const void *d_points, void *d_out, void *d_status,
-                            void *stream);
-int kyb_bn256_g1_msm(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t out[64], uint8_t *status);
-int kyb_bn256_g2_msm(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t out[128], uint8_t *status);
+                            uint32_t flags, void *stream);
+int kyb_bn256_g1_msm(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t out[64], uint8_t *status, uint32_t flags);
+int kyb_bn256_g2_msm(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t out[128], uint8_t *status, uint32_t flags);
 int kyb_bn256_g1_msm_dev(size_t n, const void *d_scalars, const void *d_points, void *d_out, void *d_status,
-                         void *stream);
+                         uint32_t flags, void *stream);
 int kyb_bn256_g2_msm_dev(size_t n, const void *d_scalars, const void *d_points, void *d_out, void *d_status,
-                         void *stream);
+                         uint32_t flags, void *stream);
 
 #ifdef __cplusplus
 }

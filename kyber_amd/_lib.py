@@ -40,50 +40,50 @@ SIGNATURES = {
     "kyb_ed25519_hash_dev": [_sz, _vp, _sz, _vp, _sz, _vp, _vp],
     "kyb_ed25519_msm": [_sz, _vp, _vp, _vp, _vp],
     "kyb_ed25519_msm_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
-    "kyb_bls12381_g1_msm": [_sz, _vp, _vp, _vp, _vp],
-    "kyb_bls12381_g2_msm": [_sz, _vp, _vp, _vp, _vp],
-    "kyb_bls12381_g1_msm_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
-    "kyb_bls12381_g2_msm_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
-    "kyb_bn256_g1_msm": [_sz, _vp, _vp, _vp, _vp],
-    "kyb_bn256_g2_msm": [_sz, _vp, _vp, _vp, _vp],
-    "kyb_bn256_g1_msm_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
-    "kyb_bn256_g2_msm_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
-    "kyb_bls12381_g1_mul": [_sz, _vp, _vp, _vp, _vp],
-    "kyb_bls12381_g2_mul": [_sz, _vp, _vp, _vp, _vp],
-    "kyb_bls12381_g1_mul_same_base": [_sz, _vp, _vp, _vp, _vp],
-    "kyb_bls12381_g2_mul_same_base": [_sz, _vp, _vp, _vp, _vp],
-    "kyb_bls12381_g1_mul_dev": [_sz, _vp, _vp, _sz, _vp, _vp, _vp],
-    "kyb_bls12381_g2_mul_dev": [_sz, _vp, _vp, _sz, _vp, _vp, _vp],
+    "kyb_bls12381_g1_msm": [_sz, _vp, _vp, _vp, _vp, _u32],
+    "kyb_bls12381_g2_msm": [_sz, _vp, _vp, _vp, _vp, _u32],
+    "kyb_bls12381_g1_msm_dev": [_sz, _vp, _vp, _vp, _vp, _u32, _vp],
+    "kyb_bls12381_g2_msm_dev": [_sz, _vp, _vp, _vp, _vp, _u32, _vp],
+    "kyb_bn256_g1_msm": [_sz, _vp, _vp, _vp, _vp, _u32],
+    "kyb_bn256_g2_msm": [_sz, _vp, _vp, _vp, _vp, _u32],
+    "kyb_bn256_g1_msm_dev": [_sz, _vp, _vp, _vp, _vp, _u32, _vp],
+    "kyb_bn256_g2_msm_dev": [_sz, _vp, _vp, _vp, _vp, _u32, _vp],
+    "kyb_bls12381_g1_mul": [_sz, _vp, _vp, _vp, _vp, _u32],
+    "kyb_bls12381_g2_mul": [_sz, _vp, _vp, _vp, _vp, _u32],
+    "kyb_bls12381_g1_mul_same_base": [_sz, _vp, _vp, _vp, _vp, _u32],
+    "kyb_bls12381_g2_mul_same_base": [_sz, _vp, _vp, _vp, _vp, _u32],
+    "kyb_bls12381_g1_mul_dev": [_sz, _vp, _vp, _sz, _vp, _vp, _u32, _vp],
+    "kyb_bls12381_g2_mul_dev": [_sz, _vp, _vp, _sz, _vp, _vp, _u32, _vp],
     "kyb_bls12381_g1_add": [_sz, _vp, _vp, _vp, _vp],
     "kyb_bls12381_g2_add": [_sz, _vp, _vp, _vp, _vp],
-    "kyb_bls12381_pair": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_bls12381_pair": [_sz, _vp, _vp, _vp, _vp, _u32],
     "kyb_bls12381_hash_g1": [_sz, _vp, _sz, _vp, _sz, _vp, _vp],
     "kyb_bls12381_hash_g2": [_sz, _vp, _sz, _vp, _sz, _vp, _vp],
     "kyb_bls12381_hash_g1_dev": [_sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp],
     "kyb_bls12381_hash_g2_dev": [_sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp],
-    "kyb_bls12381_verify_g1": [_sz, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp],
-    "kyb_bls12381_verify_g1_dev": [_sz, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp],
+    "kyb_bls12381_verify_g1": [_sz, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _u32],
+    "kyb_bls12381_verify_g1_dev": [_sz, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _u32, _vp],
     "kyb_bls12381_gt_mul": [_sz, _vp, _vp, _vp, _vp],
     "kyb_bls12381_gt_mul_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
-    "kyb_bls12381_pair_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
-    "kyb_bls12381_pair_check": [_sz, _vp, _vp, _vp, _vp, _vp, _vp],
-    "kyb_bls12381_pair_check_dev": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "kyb_bn256_g1_mul": [_sz, _vp, _vp, _vp, _vp],
-    "kyb_bn256_g2_mul": [_sz, _vp, _vp, _vp, _vp],
-    "kyb_bn256_g1_mul_same_base": [_sz, _vp, _vp, _vp, _vp],
-    "kyb_bn256_g2_mul_same_base": [_sz, _vp, _vp, _vp, _vp],
-    "kyb_bn256_g1_mul_dev": [_sz, _vp, _vp, _sz, _vp, _vp, _vp],
-    "kyb_bn256_g2_mul_dev": [_sz, _vp, _vp, _sz, _vp, _vp, _vp],
+    "kyb_bls12381_pair_dev": [_sz, _vp, _vp, _vp, _vp, _u32, _vp],
+    "kyb_bls12381_pair_check": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _u32],
+    "kyb_bls12381_pair_check_dev": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
+    "kyb_bn256_g1_mul": [_sz, _vp, _vp, _vp, _vp, _u32],
+    "kyb_bn256_g2_mul": [_sz, _vp, _vp, _vp, _vp, _u32],
+    "kyb_bn256_g1_mul_same_base": [_sz, _vp, _vp, _vp, _vp, _u32],
+    "kyb_bn256_g2_mul_same_base": [_sz, _vp, _vp, _vp, _vp, _u32],
+    "kyb_bn256_g1_mul_dev": [_sz, _vp, _vp, _sz, _vp, _vp, _u32, _vp],
+    "kyb_bn256_g2_mul_dev": [_sz, _vp, _vp, _sz, _vp, _vp, _u32, _vp],
     "kyb_bn256_g1_add": [_sz, _vp, _vp, _vp, _vp],
     "kyb_bn256_g2_add": [_sz, _vp, _vp, _vp, _vp],
-    "kyb_bn256_pair": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_bn256_pair": [_sz, _vp, _vp, _vp, _vp, _u32],
     "kyb_bn256_hash_g1": [_sz, _vp, _sz, _vp, _vp],
     "kyb_bn256_hash_g1_dev": [_sz, _vp, _sz, _vp, _vp, _vp],
     "kyb_bn256_gt_mul": [_sz, _vp, _vp, _vp, _vp],
     "kyb_bn256_gt_mul_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
-    "kyb_bn256_pair_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
-    "kyb_bn256_pair_check": [_sz, _vp, _vp, _vp, _vp, _vp, _vp],
-    "kyb_bn256_pair_check_dev": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "kyb_bn256_pair_dev": [_sz, _vp, _vp, _vp, _vp, _u32, _vp],
+    "kyb_bn256_pair_check": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _u32],
+    "kyb_bn256_pair_check_dev": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
 }
 _RESTYPES = {"kyb_last_error": C.c_char_p}
 

@@ -184,6 +184,97 @@ KYB_HD_NOINLINE int g2_decode(g2_aff& a, const uint8_t* in, bool check_subgroup)
     return ST_OK;
 }
 
+// ZCash uncompressed forms (x || y, 96 B for G1; x.c1 || x.c0 || y.c1 || y.c0, 192 B for G2; top bits of the first
+// byte: compression 0, infinity, sort 0) -- the `_aff` inputs of SURVEY.md section 8(b): no square root.  With
+// validate = false (KYB_F_TRUSTED_*) the curve-equation and subgroup checks are skipped as well.
+constexpr int G1_WIRE_UNC = 96, G2_WIRE_UNC = 192;
+KYB_HD_NOINLINE int g1_decode_unc(g1_aff& a, const uint8_t* in, bool validate) {
+    uint32_t wx[12], wy[12];
+    words_from_be<12>(wx, in);
+    words_from_be<12>(wy, in + 48);
+    const uint32_t top = wx[11] >> 29;
+    const bool c = top & 4, inf = top & 2, s = top & 1;
+    wx[11] &= 0x1fffffffu;
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) any |= wx[k] | wy[k];
+    fp_zero(a.x);
+    fp_zero(a.y);
+    a.inf = true;
+    if (c || s) return ST_BAD_POINT;
+    if (inf) return any ? ST_BAD_POINT : ST_OK;
+    if (!fp_words_lt_p<FC>(wx) || !fp_words_lt_p<FC>(wy)) return ST_BAD_POINT;
+    fp x, y;
+    fp_from_words<FC>(x, wx);
+    fp_from_words<FC>(y, wy);
+    if (validate) {
+        fp rhs, b, t;
+        fp_const(b, CC::B1);
+        fp_sqr(rhs, x);
+        fp_mul(rhs, rhs, x);
+        fp_add(rhs, rhs, b);
+        fp_sqr(t, y);
+        if (!fp_eq(t, rhs)) return ST_BAD_POINT;
+    }
+    a.x = x;
+    a.y = y;
+    a.inf = false;
+    if (validate && !g1_in_subgroup(a)) return ST_NOT_IN_SUBGROUP;
+    return ST_OK;
+}
+KYB_HD_NOINLINE int g2_decode_unc(g2_aff& a, const uint8_t* in, bool validate) {
+    uint32_t w[4][12];
+    uint32_t any = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) words_from_be<12>(w[j], in + 48 * j);
+    const uint32_t top = w[0][11] >> 29;
+    const bool c = top & 4, inf = top & 2, s = top & 1;
+    w[0][11] &= 0x1fffffffu;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int k = 0; k < 12; k++) any |= w[j][k];
+    fp2_zero(a.x);
+    fp2_zero(a.y);
+    a.inf = true;
+    if (c || s) return ST_BAD_POINT;
+    if (inf) return any ? ST_BAD_POINT : ST_OK;
+    bool lt = true;
+#pragma unroll
+    for (int j = 0; j < 4; j++) lt &= fp_words_lt_p<FC>(w[j]);
+    if (!lt) return ST_BAD_POINT;
+    fp2 x, y;
+    fp_from_words<FC>(x.c1, w[0]);
+    fp_from_words<FC>(x.c0, w[1]);
+    fp_from_words<FC>(y.c1, w[2]);
+    fp_from_words<FC>(y.c0, w[3]);
+    if (validate) {
+        fp2 rhs, b, t;
+        fp2_load_const<TC>(b, CC::B2);
+        fp2_sqr_c(rhs, x);
+        fp2_mul_c(rhs, rhs, x);
+        fp2_add(rhs, rhs, b);
+        fp2_sqr_c(t, y);
+        if (!fp2_eq(t, rhs)) return ST_BAD_POINT;
+    }
+    a.x = x;
+    a.y = y;
+    a.inf = false;
+    if (validate && !g2_in_subgroup(a)) return ST_NOT_IN_SUBGROUP;
+    return ST_OK;
+}
+// Input decoding as selected by the call's flags for point argument `arg`.
+KYB_HD int g1_decode_f(g1_aff& a, const uint8_t* in, uint32_t flags, int arg) {
+    const bool validate = !flag_trusted(flags, arg);
+    return (flags & FLAG_UNCOMPRESSED) ? g1_decode_unc(a, in, validate) : g1_decode(a, in, validate);
+}
+KYB_HD int g2_decode_f(g2_aff& a, const uint8_t* in, uint32_t flags, int arg) {
+    const bool validate = !flag_trusted(flags, arg);
+    return (flags & FLAG_UNCOMPRESSED) ? g2_decode_unc(a, in, validate) : g2_decode(a, in, validate);
+}
+KYB_HD size_t g1_wire_size(uint32_t flags) { return (flags & FLAG_UNCOMPRESSED) ? G1_WIRE_UNC : 48; }
+KYB_HD size_t g2_wire_size(uint32_t flags) { return (flags & FLAG_UNCOMPRESSED) ? G2_WIRE_UNC : 96; }
+
 // ------------------------------------------------------------------ encoding
 KYB_HD_NOINLINE void g1_encode(uint8_t* out, const g1_aff& a) {
     uint32_t w[12];
@@ -210,6 +301,44 @@ KYB_HD_NOINLINE void g2_encode(uint8_t* out, const g2_aff& a) {
     w1[11] |= flags;
     words_to_be<12>(out, w1);
     words_to_be<12>(out + 48, w0);
+}
+KYB_HD_NOINLINE void g1_encode_unc(uint8_t* out, const g1_aff& a) {
+    uint32_t wx[12], wy[12];
+    fp_to_words<FC>(wx, a.x);
+    fp_to_words<FC>(wy, a.y);
+    if (a.inf) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) wx[k] = wy[k] = 0;
+        wx[11] = 0x40000000u;
+    }
+    words_to_be<12>(out, wx);
+    words_to_be<12>(out + 48, wy);
+}
+KYB_HD_NOINLINE void g2_encode_unc(uint8_t* out, const g2_aff& a) {
+    uint32_t w[4][12];
+    fp_to_words<FC>(w[0], a.x.c1);
+    fp_to_words<FC>(w[1], a.x.c0);
+    fp_to_words<FC>(w[2], a.y.c1);
+    fp_to_words<FC>(w[3], a.y.c0);
+    if (a.inf) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int k = 0; k < 12; k++) w[j][k] = 0;
+        w[0][11] = 0x40000000u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) words_to_be<12>(out + 48 * j, w[j]);
+}
+KYB_HD size_t g1_out_size(uint32_t flags) { return (flags & FLAG_UNCOMPRESSED_OUT) ? G1_WIRE_UNC : 48; }
+KYB_HD size_t g2_out_size(uint32_t flags) { return (flags & FLAG_UNCOMPRESSED_OUT) ? G2_WIRE_UNC : 96; }
+KYB_HD void g1_encode_f(uint8_t* out, const g1_aff& a, uint32_t flags) {
+    if (flags & FLAG_UNCOMPRESSED_OUT) g1_encode_unc(out, a);
+    else g1_encode(out, a);
+}
+KYB_HD void g2_encode_f(uint8_t* out, const g2_aff& a, uint32_t flags) {
+    if (flags & FLAG_UNCOMPRESSED_OUT) g2_encode_unc(out, a);
+    else g2_encode(out, a);
 }
 // 576 bytes: Fp12.c1 then c0; within Fp6 c2, c1, c0; within Fp2 c1, c0; big-endian (oracle gt_to_bytes)
 KYB_HD_NOINLINE void gt_encode(uint8_t* out, const fp12& f) {
@@ -430,11 +559,11 @@ KYB_HD void zero_bytes(uint8_t* out, int n) {
     for (int k = 0; k < n / 4; k++) q[k] = 0;
 }
 // out = k * P   (G1Elt.UnmarshalBinary + Mul + MarshalBinary, kilic/g1.go:110-131)
-KYB_HD int g1_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt) {
+KYB_HD int g1_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt, uint32_t flags = 0) {
     g1_aff a;
-    const int st = g1_decode(a, pt, true);
+    const int st = g1_decode_f(a, pt, flags, 0);
     if (st != ST_OK) {
-        zero_bytes(out, 48);
+        zero_bytes(out, (int)g1_out_size(flags));
         return st;
     }
     uint32_t k[8];
@@ -443,14 +572,14 @@ KYB_HD int g1_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt
     jac_from_aff(p, a);
     jac_mul_u256(r, p, k);
     jac_to_aff(a, r);
-    g1_encode(out, a);
+    g1_encode_f(out, a, flags);
     return ST_OK;
 }
-KYB_HD int g2_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt) {
+KYB_HD int g2_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt, uint32_t flags = 0) {
     g2_aff a;
-    const int st = g2_decode(a, pt, true);
+    const int st = g2_decode_f(a, pt, flags, 0);
     if (st != ST_OK) {
-        zero_bytes(out, 96);
+        zero_bytes(out, (int)g2_out_size(flags));
         return st;
     }
     uint32_t k[8];
@@ -459,7 +588,7 @@ KYB_HD int g2_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt
     jac_from_aff(p, a);
     jac_mul_u256(r, p, k);
     jac_to_aff(a, r);
-    g2_encode(out, a);
+    g2_encode_f(out, a, flags);
     return ST_OK;
 }
 // out = a + b   (Point.Add: kilic/g1.go:90-96, pairing/bn256/point.go:130-140 -> curve.go:69)
@@ -516,11 +645,11 @@ KYB_HD int gt_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* gt
     return ST_OK;
 }
 // gt = e(P, Q)   (Suite.Pair, kilic/suite.go:70-75)
-KYB_HD int pair_wire(uint8_t* gt, const uint8_t* g1, const uint8_t* g2) {
+KYB_HD int pair_wire(uint8_t* gt, const uint8_t* g1, const uint8_t* g2, uint32_t flags = 0) {
     g1_aff p;
     g2_aff q;
-    int st = g1_decode(p, g1, true);
-    const int st2 = g2_decode(q, g2, true);
+    int st = g1_decode_f(p, g1, flags, 0);
+    const int st2 = g2_decode_f(q, g2, flags, 1);
     if (st == ST_OK) st = st2;
     if (st != ST_OK) {
         zero_bytes(gt, 576);
@@ -535,15 +664,15 @@ KYB_HD int pair_wire(uint8_t* gt, const uint8_t* g1, const uint8_t* g2) {
 // ok = (e(p1, p2) == e(inv1, inv2))   (Suite.ValidatePairing, pairing/pairing.go:13-15,
 // kilic/suite.go:57-68: AddPair(p1, p2); AddPairInv(inv1, inv2); Check())
 KYB_HD int pair_check_wire(uint8_t* ok, const uint8_t* p1, const uint8_t* p2, const uint8_t* inv1,
-                           const uint8_t* inv2) {
+                           const uint8_t* inv2, uint32_t flags = 0) {
     g1_aff a, c;
     g2_aff b, d;
-    int st = g1_decode(a, p1, true);
-    int s2 = g2_decode(b, p2, true);
+    int st = g1_decode_f(a, p1, flags, 0);
+    int s2 = g2_decode_f(b, p2, flags, 1);
     if (st == ST_OK) st = s2;
-    s2 = g1_decode(c, inv1, true);
+    s2 = g1_decode_f(c, inv1, flags, 2);
     if (st == ST_OK) st = s2;
-    s2 = g2_decode(d, inv2, true);
+    s2 = g2_decode_f(d, inv2, flags, 3);
     if (st == ST_OK) st = s2;
     *ok = 0;
     if (st != ST_OK) return st;

@@ -183,12 +183,12 @@ KYB_HD_NOINLINE void hash_g1_point(g1_jac& r, const uint8_t* msg, size_t msg_len
 // adapter's checks and H(msg) never leaves the lane -- no encode / re-decode / re-check of the hashed point, and
 // the G2 generator is a constant instead of a decoded operand.
 KYB_HD int verify_g1_wire(uint8_t* ok, const uint8_t* pk96, const uint8_t* msg, size_t msg_len, const DstArg& dst,
-                          const uint8_t* sig48) {
+                          const uint8_t* sig48, uint32_t flags = 0) {
     g1_aff s, h;
     g2_aff x, g;
     *ok = 0;
-    int st = g2_decode(x, pk96, true);
-    const int st2 = g1_decode(s, sig48, true);
+    int st = g2_decode_f(x, pk96, flags, 0);
+    const int st2 = g1_decode_f(s, sig48, flags, 1);
     if (st == ST_OK) st = st2;
     if (st != ST_OK) return st;
     g1_jac hj;

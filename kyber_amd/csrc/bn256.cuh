@@ -48,6 +48,12 @@ KYB_HD void fp_encode(uint8_t* out, const fp& a) {
     words_to_be<8>(out, w);
 }
 // pointG1.UnmarshalBinary (point.go:206-238): (0, 0) is infinity; otherwise y^2 = x^3 + 3.
+// bn256's wire format is already uncompressed affine and its UnmarshalBinary has no subgroup check
+// (point.go:206-238, 466-499), so the flags of the shared ABI change nothing here.
+KYB_HD size_t g1_wire_size(uint32_t) { return 64; }
+KYB_HD size_t g2_wire_size(uint32_t) { return 128; }
+KYB_HD size_t g1_out_size(uint32_t) { return 64; }
+KYB_HD size_t g2_out_size(uint32_t) { return 128; }
 KYB_HD_NOINLINE int g1_decode(g1_aff& a, const uint8_t* in) {
     fp_decode(a.x, in);
     fp_decode(a.y, in + 32);
@@ -357,7 +363,7 @@ KYB_HD void zero_bytes(uint8_t* out, int n) {
     uint32_t* q = reinterpret_cast<uint32_t*>(out);
     for (int k = 0; k < n / 4; k++) q[k] = 0;
 }
-KYB_HD int g1_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt) {
+KYB_HD int g1_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt, uint32_t = 0) {
     g1_aff a;
     const int st = g1_decode(a, pt);
     if (st != ST_OK) {
@@ -373,7 +379,7 @@ KYB_HD int g1_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt
     g1_encode(out, a);
     return ST_OK;
 }
-KYB_HD int g2_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt) {
+KYB_HD int g2_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt, uint32_t = 0) {
     g2_aff a;
     const int st = g2_decode(a, pt);
     if (st != ST_OK) {
@@ -462,7 +468,7 @@ KYB_HD int gt_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* gt
     return ST_OK;
 }
 // gt = e(g1, g2)   (Suite.Pair, suite.go:97-103)
-KYB_HD int pair_wire(uint8_t* gt, const uint8_t* g1, const uint8_t* g2) {
+KYB_HD int pair_wire(uint8_t* gt, const uint8_t* g1, const uint8_t* g2, uint32_t = 0) {
     g1_aff p;
     g2_aff q;
     int st = g1_decode(p, g1);
@@ -479,7 +485,7 @@ KYB_HD int pair_wire(uint8_t* gt, const uint8_t* g1, const uint8_t* g2) {
 }
 // ok = Pair(p1, p2).Equal(Pair(inv1, inv2))   (Suite.ValidatePairing, suite.go:105-107)
 KYB_HD int pair_check_wire(uint8_t* ok, const uint8_t* p1, const uint8_t* p2, const uint8_t* inv1,
-                           const uint8_t* inv2) {
+                           const uint8_t* inv2, uint32_t = 0) {
     g1_aff a, c;
     g2_aff b, d;
     int st = g1_decode(a, p1);

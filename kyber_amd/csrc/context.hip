@@ -1,7 +1,11 @@
 #include "context.h"
+#include "hd.h"
 
 #include <map>
 
+static_assert(kyb::FLAG_UNCOMPRESSED == KYB_F_UNCOMPRESSED && kyb::FLAG_UNCOMPRESSED_OUT == KYB_F_UNCOMPRESSED_OUT &&
+                  kyb::FLAG_TRUSTED0 == KYB_F_TRUSTED(0),
+              "hd.h flag constants must mirror include/kyber_hip.h");
 namespace kyb {
 
 static thread_local std::string g_err;

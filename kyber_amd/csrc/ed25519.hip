@@ -505,7 +505,8 @@ struct EdMsm {
     using Aff = ge_precomp;  // (y + x, y - x, 2dxy): one unified mixed addition = 7M
     using Acc = ge_p3;
     static constexpr int WIRE = 32, OUT = 32;
-    __device__ static int decode(Aff& a, const uint8_t* wire) {
+    __host__ __device__ static size_t wire_size(uint32_t) { return 32; }
+    __device__ static int decode(Aff& a, const uint8_t* wire, uint32_t) {
         uint32_t w[8];
         load_words8(w, reinterpret_cast<const uint32_t*>(wire));
         ge_p3 p;

@@ -16,3 +16,11 @@
 #define KYB_HD inline
 #define KYB_HD_NOINLINE __attribute__((noinline)) inline
 #endif
+
+// Per-call flags of the pairing-suite entry points (values mirror include/kyber_hip.h; context.hip static_asserts).
+namespace kyb {
+constexpr uint32_t FLAG_UNCOMPRESSED = 2u;  // BLS12-381 point inputs are ZCash uncompressed (96 / 192 B)
+constexpr uint32_t FLAG_UNCOMPRESSED_OUT = 4u;  // BLS12-381 point outputs of mul are uncompressed too
+constexpr uint32_t FLAG_TRUSTED0 = 0x100u;  // point argument i (bit 8 + i) was validated before: skip its checks
+KYB_HD bool flag_trusted(uint32_t flags, int arg) { return (flags >> (8 + arg)) & 1u; }
+}  // namespace kyb

@@ -20,7 +20,7 @@
 // Sorting instead of atomics on ~150-byte points: the only atomics are 32-bit counters.
 //
 // Adapter A: typename Aff (decoded input), Acc (accumulator); WIRE (input bytes), OUT (output bytes);
-//   decode(Aff&, const uint8_t*) -> status, scalar_words(uint32_t(&)[8], const uint8_t*),
+//   decode(Aff&, const uint8_t*, flags) -> status, wire_size(flags), scalar_words(uint32_t(&)[8], const uint8_t*),
 //   identity(Acc&), madd(Acc&, const Aff&, bool neg), add(Acc&, const Acc&, const Acc&),
 //   dbl(Acc&, const Acc&), encode(uint8_t*, const Acc&).
 #pragma once
@@ -36,11 +36,13 @@ struct Plan {
     int nb;       // buckets per window = 2^(c-1)
     int chunk;    // buckets per reduce lane
     int nchunks;  // chunks per window
+    uint32_t flags;  // the call's KYB_F_* flags (input format / trusted operands), read by the adapter's decode
 };
 
 inline Plan make_plan(size_t n) {
     Plan p;
     p.n = n;
+    p.flags = 0;
     int lg = 0;
     while ((size_t(1) << (lg + 1)) <= n) lg++;
     int c = lg - 3;
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(64) void decode_kernel(Plan p, const uint8_t* __res
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.n) return;
     typename A::Aff a;
-    const int st = A::decode(a, points + (size_t)A::WIRE * i);
+    const int st = A::decode(a, points + A::wire_size(p.flags) * i, p.flags);
     aff[i] = a;
     if (status) status[i] = (uint8_t)st;
     if (st) atomicAdd(bad, 1u);
@@ -294,7 +296,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 // Enqueue the whole MSM on `st`.  d_status may be null.  n == 0 writes the identity encoding.
 template <class A>
 int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, void* d_out, void* d_status,
-        hipStream_t st) {
+        hipStream_t st, uint32_t flags = 0) {
     if (n >= (size_t(1) << 31)) {
         set_error("msm: n too large");
         return KYB_E_ARG;
@@ -302,6 +304,7 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     const Plan p = make_plan(n ? n : 1);
     Plan pr = p;
     pr.n = n;
+    pr.flags = flags;
     const size_t nbk = (size_t)p.nwin * p.nb;
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -378,7 +381,8 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
 
 // Host-buffer wrapper: copy in, run, copy out, synchronise.
 template <class A>
-int run_host(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* out, uint8_t* status) {
+int run_host(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* out, uint8_t* status,
+             uint32_t flags = 0) {
     if ((n && (!scalars || !points)) || !out) {
         set_error("msm: bad argument");
         return KYB_E_ARG;
@@ -390,14 +394,14 @@ int run_host(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* o
     std::lock_guard<std::mutex> ws_lock(ctx->msm_mu);
     uint8_t *d_s = nullptr, *d_p = nullptr, *d_o = nullptr, *d_st = nullptr;
     KYB_HIP_CHECK(hipMalloc(&d_s, n * 32 + 1));
-    KYB_HIP_CHECK(hipMalloc(&d_p, n * A::WIRE + 1));
+    KYB_HIP_CHECK(hipMalloc(&d_p, n * A::wire_size(flags) + 1));
     KYB_HIP_CHECK(hipMalloc(&d_o, A::OUT));
     KYB_HIP_CHECK(hipMalloc(&d_st, n + 1));
     if (n) {
         KYB_HIP_CHECK(hipMemcpy(d_s, scalars, n * 32, hipMemcpyHostToDevice));
-        KYB_HIP_CHECK(hipMemcpy(d_p, points, n * A::WIRE, hipMemcpyHostToDevice));
+        KYB_HIP_CHECK(hipMemcpy(d_p, points, n * A::wire_size(flags), hipMemcpyHostToDevice));
     }
-    rc = run<A>(ctx, n, d_s, d_p, d_o, d_st, nullptr);
+    rc = run<A>(ctx, n, d_s, d_p, d_o, d_st, nullptr, flags);
     if (rc == KYB_OK) {
         hipError_t e = hipMemcpy(out, d_o, A::OUT, hipMemcpyDeviceToHost);
         if (e == hipSuccess && status && n) e = hipMemcpy(status, d_st, n, hipMemcpyDeviceToHost);

@@ -16,9 +16,10 @@ struct Weierstrass {
     };
     using Acc = Jac<F>;
     static constexpr int WIRE = Codec::WIRE, OUT = Codec::WIRE;
-    __device__ static int decode(Aff& a, const uint8_t* wire) {
+    __host__ __device__ static size_t wire_size(uint32_t flags) { return Codec::wire_size(flags); }
+    __device__ static int decode(Aff& a, const uint8_t* wire, uint32_t flags) {
         kyb::Aff<F> t;
-        const int st = Codec::decode(t, wire);
+        const int st = Codec::decode(t, wire, flags);
         a.x = t.x;
         a.y = t.y;
         a.inf = t.inf ? 1u : 0u;

@@ -45,18 +45,20 @@ struct StageBuf {
 namespace kyb { \
 __global__ __launch_bounds__(64) void PFX##_g1_mul_kernel(size_t n, const uint8_t* __restrict__ scalars, \
                                                         const uint8_t* __restrict__ pts, size_t pt_stride, \
-                                                        uint8_t* __restrict__ out, uint8_t* __restrict__ status) { \
+                                                        uint8_t* __restrict__ out, uint8_t* __restrict__ status, \
+                                                        uint32_t flags) { \
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
     if (idx >= n) return; \
-    const int st = NS::g1_mul_wire(out + G1SZ * idx, scalars + 32 * idx, pts + pt_stride * idx); \
+    const int st = NS::g1_mul_wire(out + NS::g1_out_size(flags) * idx, scalars + 32 * idx, pts + pt_stride * idx, flags); \
     if (status) status[idx] = (uint8_t)st; \
 } \
 __global__ __launch_bounds__(64) void PFX##_g2_mul_kernel(size_t n, const uint8_t* __restrict__ scalars, \
                                                         const uint8_t* __restrict__ pts, size_t pt_stride, \
-                                                        uint8_t* __restrict__ out, uint8_t* __restrict__ status) { \
+                                                        uint8_t* __restrict__ out, uint8_t* __restrict__ status, \
+                                                        uint32_t flags) { \
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
     if (idx >= n) return; \
-    const int st = NS::g2_mul_wire(out + G2SZ * idx, scalars + 32 * idx, pts + pt_stride * idx); \
+    const int st = NS::g2_mul_wire(out + NS::g2_out_size(flags) * idx, scalars + 32 * idx, pts + pt_stride * idx, flags); \
     if (status) status[idx] = (uint8_t)st; \
 } \
 __global__ __launch_bounds__(64) void PFX##_g1_add_kernel(size_t n, const uint8_t* __restrict__ a, \
@@ -78,34 +80,36 @@ __global__ __launch_bounds__(64) void PFX##_g2_add_kernel(size_t n, const uint8_
 } \
 extern "C" { \
 int kyb_##PFX##_g1_mul_dev(size_t n, const void* d_scalars, const void* d_points, size_t point_stride, \
-                            void* d_out, void* d_status, void* stream) { \
-    if ((n && (!d_scalars || !d_points || !d_out)) || (point_stride != 0 && point_stride != G1SZ)) { \
+                            void* d_out, void* d_status, uint32_t flags, void* stream) { \
+    if ((n && (!d_scalars || !d_points || !d_out)) || (point_stride != 0 && point_stride != kyb::NS::g1_wire_size(flags))) { \
         kyb::set_error("kyb_" #PFX "_g1_mul_dev: bad argument"); \
         return KYB_E_ARG; \
     } \
     if (!n) return KYB_OK; \
     hipLaunchKernelGGL(kyb::PFX##_g1_mul_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
                        (const uint8_t*)d_scalars, (const uint8_t*)d_points, point_stride, (uint8_t*)d_out, \
-                       (uint8_t*)d_status); \
+                       (uint8_t*)d_status, flags); \
     KYB_HIP_CHECK(hipGetLastError()); \
     return KYB_OK; \
 } \
 int kyb_##PFX##_g2_mul_dev(size_t n, const void* d_scalars, const void* d_points, size_t point_stride, \
-                            void* d_out, void* d_status, void* stream) { \
-    if ((n && (!d_scalars || !d_points || !d_out)) || (point_stride != 0 && point_stride != G2SZ)) { \
+                            void* d_out, void* d_status, uint32_t flags, void* stream) { \
+    if ((n && (!d_scalars || !d_points || !d_out)) || (point_stride != 0 && point_stride != kyb::NS::g2_wire_size(flags))) { \
         kyb::set_error("kyb_" #PFX "_g2_mul_dev: bad argument"); \
         return KYB_E_ARG; \
     } \
     if (!n) return KYB_OK; \
     hipLaunchKernelGGL(kyb::PFX##_g2_mul_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
                        (const uint8_t*)d_scalars, (const uint8_t*)d_points, point_stride, (uint8_t*)d_out, \
-                       (uint8_t*)d_status); \
+                       (uint8_t*)d_status, flags); \
     KYB_HIP_CHECK(hipGetLastError()); \
     return KYB_OK; \
 } \
 static int PFX##_mul_host(bool g2, size_t n, const uint8_t* scalars, const uint8_t* points, size_t stride, \
-                          uint8_t* out, uint8_t* status) { \
-    const size_t psz = g2 ? G2SZ : G1SZ; \
+                          uint8_t* out, uint8_t* status, uint32_t flags) { \
+    const size_t psz = g2 ? kyb::NS::g2_out_size(flags) : kyb::NS::g1_out_size(flags); \
+    const size_t isz = g2 ? kyb::NS::g2_wire_size(flags) : kyb::NS::g1_wire_size(flags); \
+    if (stride) stride = isz; \
     if (n && (!scalars || !points || !out)) { \
         kyb::set_error("kyb_" #PFX "_g*_mul: bad argument"); \
         return KYB_E_ARG; \
@@ -115,28 +119,30 @@ static int PFX##_mul_host(bool g2, size_t n, const uint8_t* scalars, const uint8
     KYB_TRY(kyb::get_ctx(&ctx)); \
     kyb::StageBuf s, p, o, st; \
     KYB_TRY(s.upload(scalars, n * 32)); \
-    KYB_TRY(p.upload(points, (stride ? n : 1) * psz)); \
+    KYB_TRY(p.upload(points, (stride ? n : 1) * isz)); \
     KYB_TRY(o.alloc(n * psz)); \
     KYB_TRY(st.alloc(n)); \
-    KYB_TRY(g2 ? kyb_##PFX##_g2_mul_dev(n, s.p, p.p, stride, o.p, st.p, nullptr) \
-               : kyb_##PFX##_g1_mul_dev(n, s.p, p.p, stride, o.p, st.p, nullptr)); \
+    KYB_TRY(g2 ? kyb_##PFX##_g2_mul_dev(n, s.p, p.p, stride, o.p, st.p, flags, nullptr) \
+               : kyb_##PFX##_g1_mul_dev(n, s.p, p.p, stride, o.p, st.p, flags, nullptr)); \
     KYB_TRY(o.download(out, n * psz)); \
     if (status) KYB_TRY(st.download(status, n)); \
     return KYB_OK; \
 } \
-int kyb_##PFX##_g1_mul(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* out, uint8_t* status) { \
-    return PFX##_mul_host(false, n, scalars, points, G1SZ, out, status); \
+int kyb_##PFX##_g1_mul(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* out, uint8_t* status, \
+                        uint32_t flags) { \
+    return PFX##_mul_host(false, n, scalars, points, G1SZ, out, status, flags); \
 } \
-int kyb_##PFX##_g2_mul(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* out, uint8_t* status) { \
-    return PFX##_mul_host(true, n, scalars, points, G2SZ, out, status); \
+int kyb_##PFX##_g2_mul(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* out, uint8_t* status, \
+                        uint32_t flags) { \
+    return PFX##_mul_host(true, n, scalars, points, G2SZ, out, status, flags); \
 } \
 int kyb_##PFX##_g1_mul_same_base(size_t n, const uint8_t* scalars, const uint8_t* point, uint8_t* out, \
-                                  uint8_t* status) { \
-    return PFX##_mul_host(false, n, scalars, point, 0, out, status); \
+                                  uint8_t* status, uint32_t flags) { \
+    return PFX##_mul_host(false, n, scalars, point, 0, out, status, flags); \
 } \
 int kyb_##PFX##_g2_mul_same_base(size_t n, const uint8_t* scalars, const uint8_t* point, uint8_t* out, \
-                                  uint8_t* status) { \
-    return PFX##_mul_host(true, n, scalars, point, 0, out, status); \
+                                  uint8_t* status, uint32_t flags) { \
+    return PFX##_mul_host(true, n, scalars, point, 0, out, status, flags); \
 } \
 static int PFX##_add_host(bool g2, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, uint8_t* status) { \
     const size_t psz = g2 ? G2SZ : G1SZ; \
@@ -175,10 +181,10 @@ int kyb_##PFX##_g2_add(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* ou
 namespace kyb { \
 __global__ __launch_bounds__(64) void PFX##_pair_kernel(size_t n, const uint8_t* __restrict__ g1, \
                                                       const uint8_t* __restrict__ g2, uint8_t* __restrict__ gt, \
-                                                      uint8_t* __restrict__ status) { \
+                                                      uint8_t* __restrict__ status, uint32_t flags) { \
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
     if (idx >= n) return; \
-    const int st = NS::pair_wire(gt + GTSZ * idx, g1 + G1SZ * idx, g2 + G2SZ * idx); \
+    const int st = NS::pair_wire(gt + GTSZ * idx, g1 + NS::g1_wire_size(flags) * idx, g2 + NS::g2_wire_size(flags) * idx, flags); \
     if (status) status[idx] = (uint8_t)st; \
 } \
 __global__ __launch_bounds__(64) void PFX##_gt_mul_kernel(size_t n, const uint8_t* __restrict__ scalars, \
@@ -193,24 +199,26 @@ __global__ __launch_bounds__(64) void PFX##_pair_check_kernel(size_t n, const ui
                                                             const uint8_t* __restrict__ p2, \
                                                             const uint8_t* __restrict__ i1, \
                                                             const uint8_t* __restrict__ i2, uint8_t* __restrict__ ok, \
-                                                            uint8_t* __restrict__ status) { \
+                                                            uint8_t* __restrict__ status, uint32_t flags) { \
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
     if (idx >= n) return; \
     uint8_t r = 0; \
-    const int st = NS::pair_check_wire(&r, p1 + G1SZ * idx, p2 + G2SZ * idx, i1 + G1SZ * idx, i2 + G2SZ * idx); \
+    const size_t s1 = NS::g1_wire_size(flags), s2 = NS::g2_wire_size(flags); \
+    const int st = NS::pair_check_wire(&r, p1 + s1 * idx, p2 + s2 * idx, i1 + s1 * idx, i2 + s2 * idx, flags); \
     ok[idx] = r; \
     if (status) status[idx] = (uint8_t)st; \
 } \
 } \
 extern "C" { \
-int kyb_##PFX##_pair_dev(size_t n, const void* d_g1, const void* d_g2, void* d_gt, void* d_status, void* stream) { \
+int kyb_##PFX##_pair_dev(size_t n, const void* d_g1, const void* d_g2, void* d_gt, void* d_status, uint32_t flags, \
+                          void* stream) { \
     if (n && (!d_g1 || !d_g2 || !d_gt)) { \
         kyb::set_error("kyb_" #PFX "_pair_dev: bad argument"); \
         return KYB_E_ARG; \
     } \
     if (!n) return KYB_OK; \
     hipLaunchKernelGGL(kyb::PFX##_pair_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
-                       (const uint8_t*)d_g1, (const uint8_t*)d_g2, (uint8_t*)d_gt, (uint8_t*)d_status); \
+                       (const uint8_t*)d_g1, (const uint8_t*)d_g2, (uint8_t*)d_gt, (uint8_t*)d_status, flags); \
     KYB_HIP_CHECK(hipGetLastError()); \
     return KYB_OK; \
 } \
@@ -244,7 +252,7 @@ int kyb_##PFX##_gt_mul(size_t n, const uint8_t* scalars, const uint8_t* gt, uint
     return KYB_OK; \
 } \
 int kyb_##PFX##_pair_check_dev(size_t n, const void* d_p1, const void* d_p2, const void* d_inv1, const void* d_inv2, \
-                                void* d_ok, void* d_status, void* stream) { \
+                                void* d_ok, void* d_status, uint32_t flags, void* stream) { \
     if (n && (!d_p1 || !d_p2 || !d_inv1 || !d_inv2 || !d_ok)) { \
         kyb::set_error("kyb_" #PFX "_pair_check_dev: bad argument"); \
         return KYB_E_ARG; \
@@ -252,11 +260,11 @@ int kyb_##PFX##_pair_check_dev(size_t n, const void* d_p1, const void* d_p2, con
     if (!n) return KYB_OK; \
     hipLaunchKernelGGL(kyb::PFX##_pair_check_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
                        (const uint8_t*)d_p1, (const uint8_t*)d_p2, (const uint8_t*)d_inv1, (const uint8_t*)d_inv2, \
-                       (uint8_t*)d_ok, (uint8_t*)d_status); \
+                       (uint8_t*)d_ok, (uint8_t*)d_status, flags); \
     KYB_HIP_CHECK(hipGetLastError()); \
     return KYB_OK; \
 } \
-int kyb_##PFX##_pair(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, uint8_t* status) { \
+int kyb_##PFX##_pair(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, uint8_t* status, uint32_t flags) { \
     if (n && (!g1 || !g2 || !gt)) { \
         kyb::set_error("kyb_" #PFX "_pair: bad argument"); \
         return KYB_E_ARG; \
@@ -265,17 +273,17 @@ int kyb_##PFX##_pair(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt
     kyb::DeviceCtx* ctx; \
     KYB_TRY(kyb::get_ctx(&ctx)); \
     kyb::StageBuf a, b, o, st; \
-    KYB_TRY(a.upload(g1, n * G1SZ)); \
-    KYB_TRY(b.upload(g2, n * G2SZ)); \
+    KYB_TRY(a.upload(g1, n * kyb::NS::g1_wire_size(flags))); \
+    KYB_TRY(b.upload(g2, n * kyb::NS::g2_wire_size(flags))); \
     KYB_TRY(o.alloc(n * GTSZ)); \
     KYB_TRY(st.alloc(n)); \
-    KYB_TRY(kyb_##PFX##_pair_dev(n, a.p, b.p, o.p, st.p, nullptr)); \
+    KYB_TRY(kyb_##PFX##_pair_dev(n, a.p, b.p, o.p, st.p, flags, nullptr)); \
     KYB_TRY(o.download(gt, n * GTSZ)); \
     if (status) KYB_TRY(st.download(status, n)); \
     return KYB_OK; \
 } \
 int kyb_##PFX##_pair_check(size_t n, const uint8_t* p1, const uint8_t* p2, const uint8_t* inv1, const uint8_t* inv2, \
-                            uint8_t* ok, uint8_t* status) { \
+                            uint8_t* ok, uint8_t* status, uint32_t flags) { \
     if (n && (!p1 || !p2 || !inv1 || !inv2 || !ok)) { \
         kyb::set_error("kyb_" #PFX "_pair_check: bad argument"); \
         return KYB_E_ARG; \
@@ -284,13 +292,13 @@ int kyb_##PFX##_pair_check(size_t n, const uint8_t* p1, const uint8_t* p2, const
     kyb::DeviceCtx* ctx; \
     KYB_TRY(kyb::get_ctx(&ctx)); \
     kyb::StageBuf a, b, c, d, o, st; \
-    KYB_TRY(a.upload(p1, n * G1SZ)); \
-    KYB_TRY(b.upload(p2, n * G2SZ)); \
-    KYB_TRY(c.upload(inv1, n * G1SZ)); \
-    KYB_TRY(d.upload(inv2, n * G2SZ)); \
+    KYB_TRY(a.upload(p1, n * kyb::NS::g1_wire_size(flags))); \
+    KYB_TRY(b.upload(p2, n * kyb::NS::g2_wire_size(flags))); \
+    KYB_TRY(c.upload(inv1, n * kyb::NS::g1_wire_size(flags))); \
+    KYB_TRY(d.upload(inv2, n * kyb::NS::g2_wire_size(flags))); \
     KYB_TRY(o.alloc(n)); \
     KYB_TRY(st.alloc(n)); \
-    KYB_TRY(kyb_##PFX##_pair_check_dev(n, a.p, b.p, c.p, d.p, o.p, st.p, nullptr)); \
+    KYB_TRY(kyb_##PFX##_pair_check_dev(n, a.p, b.p, c.p, d.p, o.p, st.p, flags, nullptr)); \
     KYB_TRY(o.download(ok, n)); \
     if (status) KYB_TRY(st.download(status, n)); \
     return KYB_OK; \

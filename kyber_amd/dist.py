@@ -36,16 +36,20 @@ def _unit_scalars(world: int, little_endian: bool) -> np.ndarray:
 
 
 def msm_allgather(scalars_shard, points_shard, local_msm: Callable, point_len: int, little_endian: bool,
-                  group=None):
+                  group=None, combine_msm: Callable | None = None):
     """Node-wide MSM over the shards held by the ranks of `group`.
 
     scalars_shard / points_shard: this rank's slice (host numpy/bytes, or CUDA uint8 tensors when
     the backend is nccl).  local_msm(scalars, points) -> (encoded_point, status) is the single-GPU
     MSM (e.g. ``edwards25519.msm`` or ``bls12381.g1_msm``).  Returns (encoded_point, ok) where
     ok is False iff any rank rejected an input (then the point is all-zero bytes), identical on
-    every rank."""
+    every rank.  combine_msm (default: local_msm) sums the gathered partial points; the suite wrappers below pass
+    one that marks its inputs as trusted, since the partials are outputs of this library."""
     import torch
     import torch.distributed as dist
+
+    if combine_msm is None:
+        combine_msm = local_msm
 
     world = dist.get_world_size(group)
     part, st = local_msm(scalars_shard, points_shard)
@@ -65,10 +69,10 @@ def msm_allgather(scalars_shard, points_shard, local_msm: Callable, point_len: i
     pts = allp[:, :point_len].contiguous()
     ones = _unit_scalars(world, little_endian)
     if is_t:
-        out, st2 = local_msm(torch.from_numpy(ones).to(dev), pts)
+        out, st2 = combine_msm(torch.from_numpy(ones).to(dev), pts)
         ok = not bool(st2.any().item())
     else:
-        out, st2 = local_msm(ones, pts.numpy())
+        out, st2 = combine_msm(ones, pts.numpy())
         ok = not bool(np.asarray(st2).any())
     return out, ok
 
@@ -79,25 +83,37 @@ def ed25519_msm(scalars_shard, points_shard, group=None):
     return msm_allgather(scalars_shard, points_shard, ed.msm, 32, True, group)
 
 
-def bls12381_g1_msm(scalars_shard, points_shard, group=None):
+def bls12381_g1_msm(scalars_shard, points_shard, group=None, flags: int = 0):
+    """flags: the shard's input flags (F_TRUSTED(0) / F_UNCOMPRESSED, kyber_amd.pairing._engine)."""
     from .pairing import bls12381 as m
+    from .pairing._engine import F_TRUSTED
 
-    return msm_allgather(scalars_shard, points_shard, m.g1_msm, m.G1_LEN, False, group)
+    return msm_allgather(scalars_shard, points_shard, lambda s, p: m.g1_msm(s, p, flags), m.G1_LEN, False, group,
+                         combine_msm=lambda s, p: m.g1_msm(s, p, F_TRUSTED(0)))
 
 
-def bls12381_g2_msm(scalars_shard, points_shard, group=None):
+def bls12381_g2_msm(scalars_shard, points_shard, group=None, flags: int = 0):
+    """flags: the shard's input flags (F_TRUSTED(0) / F_UNCOMPRESSED, kyber_amd.pairing._engine)."""
     from .pairing import bls12381 as m
+    from .pairing._engine import F_TRUSTED
 
-    return msm_allgather(scalars_shard, points_shard, m.g2_msm, m.G2_LEN, False, group)
+    return msm_allgather(scalars_shard, points_shard, lambda s, p: m.g2_msm(s, p, flags), m.G2_LEN, False, group,
+                         combine_msm=lambda s, p: m.g2_msm(s, p, F_TRUSTED(0)))
 
 
-def bn256_g1_msm(scalars_shard, points_shard, group=None):
+def bn256_g1_msm(scalars_shard, points_shard, group=None, flags: int = 0):
+    """flags: the shard's input flags (F_TRUSTED(0) / F_UNCOMPRESSED, kyber_amd.pairing._engine)."""
     from .pairing import bn256 as m
+    from .pairing._engine import F_TRUSTED
 
-    return msm_allgather(scalars_shard, points_shard, m.g1_msm, m.G1_LEN, False, group)
+    return msm_allgather(scalars_shard, points_shard, lambda s, p: m.g1_msm(s, p, flags), m.G1_LEN, False, group,
+                         combine_msm=lambda s, p: m.g1_msm(s, p, F_TRUSTED(0)))
 
 
-def bn256_g2_msm(scalars_shard, points_shard, group=None):
+def bn256_g2_msm(scalars_shard, points_shard, group=None, flags: int = 0):
+    """flags: the shard's input flags (F_TRUSTED(0) / F_UNCOMPRESSED, kyber_amd.pairing._engine)."""
     from .pairing import bn256 as m
+    from .pairing._engine import F_TRUSTED
 
-    return msm_allgather(scalars_shard, points_shard, m.g2_msm, m.G2_LEN, False, group)
+    return msm_allgather(scalars_shard, points_shard, lambda s, p: m.g2_msm(s, p, flags), m.G2_LEN, False, group,
+                         combine_msm=lambda s, p: m.g2_msm(s, p, F_TRUSTED(0)))

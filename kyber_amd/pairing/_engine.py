@@ -11,6 +11,17 @@ import numpy as np
 from .._lib import check, load
 
 
+# flags of the pairing-suite entry points (include/kyber_hip.h)
+F_UNCOMPRESSED = 2
+F_UNCOMPRESSED_OUT = 4
+F_TRUSTED_ALL = 0xF00
+
+
+def F_TRUSTED(i: int) -> int:
+    """Point argument i was validated before (an output of this library / of an earlier UnmarshalBinary)."""
+    return 0x100 << i
+
+
 def _is_torch(x) -> bool:
     return type(x).__module__.startswith("torch")
 
@@ -34,27 +45,37 @@ class Engine:
         self.neg = neg  # neg(group, encoding) -> encoding of the inverse point (wire-level, no curve arithmetic)
         self.G1_LEN, self.G2_LEN, self.GT_LEN, self.SCALAR_LEN = g1_len, g2_len, gt_len, 32
         self.G1_BASE, self.G2_BASE, self.G1_NULL, self.G2_NULL = g1_base, g2_base, g1_null, g2_null
+        # BLS12-381 inputs may be ZCash uncompressed (KYB_F_UNCOMPRESSED); bn256's wire format already is
+        self.unc_factor = 2 if prefix == "bls12381" else 1
+
+    def _in_len(self, group: int, flags: int) -> int:
+        w = self.G1_LEN if group == 1 else self.G2_LEN
+        return w * self.unc_factor if flags & F_UNCOMPRESSED else w
 
     def _fn(self, suffix):
         return getattr(load(), f"kyb_{self.prefix}_{suffix}"), f"kyb_{self.prefix}_{suffix}"
 
-    def mul(self, group: int, scalars, points, same_base: bool):
+    def mul(self, group: int, scalars, points, same_base: bool, flags: int = 0):
         w = self.G1_LEN if group == 1 else self.G2_LEN
+        if flags & F_UNCOMPRESSED_OUT:
+            w *= self.unc_factor
+        wi = self._in_len(group, flags)
         if _is_torch(scalars):
             import torch
 
             s = scalars.contiguous().view(-1, 32)
-            p = points.contiguous().view(-1, w)
+            p = points.contiguous().view(-1, wi)
             n = s.shape[0]
             if not same_base and p.shape[0] != n:
                 raise ValueError("scalars/points length mismatch")
             out = torch.empty((n, w), dtype=torch.uint8, device=s.device)
             st = torch.empty(n, dtype=torch.uint8, device=s.device)
             fn, nm = self._fn(f"g{group}_mul_dev")
-            check(fn(n, s.data_ptr(), p.data_ptr(), 0 if same_base else w, out.data_ptr(), st.data_ptr(), _stream()), nm)
+            check(fn(n, s.data_ptr(), p.data_ptr(), 0 if same_base else wi, out.data_ptr(), st.data_ptr(), flags,
+                     _stream()), nm)
             return out, st
         s = _host(scalars, 32)
-        p = _host(points, w)
+        p = _host(points, wi)
         n = s.shape[0]
         out = np.empty((n, w), dtype=np.uint8)
         st = np.empty(n, dtype=np.uint8)
@@ -64,22 +85,22 @@ class Engine:
             if p.shape[0] != n:
                 raise ValueError("scalars/points length mismatch")
             fn, nm = self._fn(f"g{group}_mul")
-        check(fn(n, s.ctypes.data, p.ctypes.data, out.ctypes.data, st.ctypes.data), nm)
+        check(fn(n, s.ctypes.data, p.ctypes.data, out.ctypes.data, st.ctypes.data, flags), nm)
         return out, st
 
-    def g1_batch_mul(self, scalars, points):
+    def g1_batch_mul(self, scalars, points, flags: int = 0):
         """(out, status): out[i] = scalars[i] * points[i] on G1."""
-        return self.mul(1, scalars, points, False)
+        return self.mul(1, scalars, points, False, flags)
 
-    def g2_batch_mul(self, scalars, points):
-        return self.mul(2, scalars, points, False)
+    def g2_batch_mul(self, scalars, points, flags: int = 0):
+        return self.mul(2, scalars, points, False, flags)
 
-    def g1_commit(self, scalars, base=None):
+    def g1_commit(self, scalars, base=None, flags: int = 0):
         """share.PriPoly.Commit (share/poly.go:143-149): commits[i] = coeffs[i] * base."""
-        return self.mul(1, scalars, self.G1_BASE if base is None else base, True)
+        return self.mul(1, scalars, self.G1_BASE if base is None else base, True, flags)
 
-    def g2_commit(self, scalars, base=None):
-        return self.mul(2, scalars, self.G2_BASE if base is None else base, True)
+    def g2_commit(self, scalars, base=None, flags: int = 0):
+        return self.mul(2, scalars, self.G2_BASE if base is None else base, True, flags)
 
     def add(self, group: int, a, b):
         """(out, status): out[i] = a[i] + b[i]  (N x Point.Add)."""
@@ -94,64 +115,67 @@ class Engine:
         check(fn(n, x.ctypes.data, y.ctypes.data, out.ctypes.data, st.ctypes.data), nm)
         return out, st
 
-    def msm(self, group: int, scalars, points):
+    def msm(self, group: int, scalars, points, flags: int = 0):
         """(out, status): out = sum_i scalars[i] * points[i] as ONE encoded point -- the MSM-shaped call
         sites of the reference (share/poly.go:340-348, 449-476; sign/bdn/bdn.go:126-181).  If any
-        status is non-zero the output is all-zero bytes."""
+        status is non-zero the output is all-zero bytes.  flags: F_TRUSTED(0) for points validated before (as every
+        kyber.Point of the reference's call sites is), F_UNCOMPRESSED for BLS12-381 uncompressed-affine input."""
         w = self.G1_LEN if group == 1 else self.G2_LEN
+        wi = self._in_len(group, flags)
         if _is_torch(scalars):
             import torch
 
             s = scalars.contiguous().view(-1, 32)
-            p = points.contiguous().view(-1, w)
+            p = points.contiguous().view(-1, wi)
             n = s.shape[0]
             if p.shape[0] != n:
                 raise ValueError("scalars/points length mismatch")
             out = torch.empty(w, dtype=torch.uint8, device=s.device)
             st = torch.empty(max(n, 1), dtype=torch.uint8, device=s.device)
             fn, nm = self._fn(f"g{group}_msm_dev")
-            check(fn(n, s.data_ptr(), p.data_ptr(), out.data_ptr(), st.data_ptr(), _stream()), nm)
+            check(fn(n, s.data_ptr(), p.data_ptr(), out.data_ptr(), st.data_ptr(), flags, _stream()), nm)
             return out, st[:n]
         s = _host(scalars, 32)
-        p = _host(points, w)
+        p = _host(points, wi)
         n = s.shape[0]
         if p.shape[0] != n:
             raise ValueError("scalars/points length mismatch")
         out = np.empty(w, dtype=np.uint8)
         st = np.zeros(max(n, 1), dtype=np.uint8)
         fn, nm = self._fn(f"g{group}_msm")
-        check(fn(n, s.ctypes.data, p.ctypes.data, out.ctypes.data, st.ctypes.data), nm)
+        check(fn(n, s.ctypes.data, p.ctypes.data, out.ctypes.data, st.ctypes.data, flags), nm)
         return out, st[:n]
 
-    def g1_msm(self, scalars, points):
-        return self.msm(1, scalars, points)
+    def g1_msm(self, scalars, points, flags: int = 0):
+        return self.msm(1, scalars, points, flags)
 
-    def g2_msm(self, scalars, points):
-        return self.msm(2, scalars, points)
+    def g2_msm(self, scalars, points, flags: int = 0):
+        return self.msm(2, scalars, points, flags)
 
-    def batch_pair(self, g1, g2):
+    def batch_pair(self, g1, g2, flags: int = 0):
         """(gt, status): gt[i] = e(g1[i], g2[i])  (N x Suite.Pair)."""
+        w1, w2 = self._in_len(1, flags), self._in_len(2, flags)
         if _is_torch(g1):
             import torch
 
-            a = g1.contiguous().view(-1, self.G1_LEN)
-            b = g2.contiguous().view(-1, self.G2_LEN)
+            a = g1.contiguous().view(-1, w1)
+            b = g2.contiguous().view(-1, w2)
             n = a.shape[0]
             if b.shape[0] != n:
                 raise ValueError("g1/g2 length mismatch")
             gt = torch.empty((n, self.GT_LEN), dtype=torch.uint8, device=a.device)
             st = torch.empty(n, dtype=torch.uint8, device=a.device)
             fn, nm = self._fn("pair_dev")
-            check(fn(n, a.data_ptr(), b.data_ptr(), gt.data_ptr(), st.data_ptr(), _stream()), nm)
+            check(fn(n, a.data_ptr(), b.data_ptr(), gt.data_ptr(), st.data_ptr(), flags, _stream()), nm)
             return gt, st
-        a, b = _host(g1, self.G1_LEN), _host(g2, self.G2_LEN)
+        a, b = _host(g1, w1), _host(g2, w2)
         n = a.shape[0]
         if b.shape[0] != n:
             raise ValueError("g1/g2 length mismatch")
         gt = np.empty((n, self.GT_LEN), dtype=np.uint8)
         st = np.empty(n, dtype=np.uint8)
         fn, nm = self._fn("pair")
-        check(fn(n, a.ctypes.data, b.ctypes.data, gt.ctypes.data, st.ctypes.data), nm)
+        check(fn(n, a.ctypes.data, b.ctypes.data, gt.ctypes.data, st.ctypes.data, flags), nm)
         return gt, st
 
     def gt_batch_mul(self, scalars, gts):
@@ -180,31 +204,33 @@ class Engine:
         check(fn(n, s.ctypes.data, g.ctypes.data, out.ctypes.data, st.ctypes.data), nm)
         return out, st
 
-    def batch_validate_pairing(self, p1, p2, inv1, inv2):
+    def batch_validate_pairing(self, p1, p2, inv1, inv2, flags: int = 0):
         """(ok, status): ok[i] = e(p1[i], p2[i]) == e(inv1[i], inv2[i])  (N x Suite.ValidatePairing,
-        pairing/pairing.go:13-15).  p1/inv1 are G1, p2/inv2 are G2."""
+        pairing/pairing.go:13-15).  p1/inv1 are G1, p2/inv2 are G2; F_TRUSTED(0..3) refer to p1, p2, inv1, inv2."""
+        w1, w2 = self._in_len(1, flags), self._in_len(2, flags)
         if _is_torch(p1):
             import torch
 
-            a, c = p1.contiguous().view(-1, self.G1_LEN), inv1.contiguous().view(-1, self.G1_LEN)
-            b, d = p2.contiguous().view(-1, self.G2_LEN), inv2.contiguous().view(-1, self.G2_LEN)
+            a, c = p1.contiguous().view(-1, w1), inv1.contiguous().view(-1, w1)
+            b, d = p2.contiguous().view(-1, w2), inv2.contiguous().view(-1, w2)
             n = a.shape[0]
             if not (b.shape[0] == c.shape[0] == d.shape[0] == n):
                 raise ValueError("length mismatch")
             ok = torch.empty(n, dtype=torch.uint8, device=a.device)
             st = torch.empty(n, dtype=torch.uint8, device=a.device)
             fn, nm = self._fn("pair_check_dev")
-            check(fn(n, a.data_ptr(), b.data_ptr(), c.data_ptr(), d.data_ptr(), ok.data_ptr(), st.data_ptr(), _stream()), nm)
+            check(fn(n, a.data_ptr(), b.data_ptr(), c.data_ptr(), d.data_ptr(), ok.data_ptr(), st.data_ptr(), flags,
+                     _stream()), nm)
             return ok, st
-        a, c = _host(p1, self.G1_LEN), _host(inv1, self.G1_LEN)
-        b, d = _host(p2, self.G2_LEN), _host(inv2, self.G2_LEN)
+        a, c = _host(p1, w1), _host(inv1, w1)
+        b, d = _host(p2, w2), _host(inv2, w2)
         n = a.shape[0]
         if not (b.shape[0] == c.shape[0] == d.shape[0] == n):
             raise ValueError("length mismatch")
         ok = np.empty(n, dtype=np.uint8)
         st = np.empty(n, dtype=np.uint8)
         fn, nm = self._fn("pair_check")
-        check(fn(n, a.ctypes.data, b.ctypes.data, c.ctypes.data, d.ctypes.data, ok.ctypes.data, st.ctypes.data), nm)
+        check(fn(n, a.ctypes.data, b.ctypes.data, c.ctypes.data, d.ctypes.data, ok.ctypes.data, st.ctypes.data, flags), nm)
         return ok, st
 
     # ------------------------------------------------------------ kyber interface mirrors

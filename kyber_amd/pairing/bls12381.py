@@ -8,7 +8,7 @@ G1 48-byte / G2 96-byte ZCash compressed, GT 576 bytes.
 Batch functions accept host data (bytes / numpy uint8) or device-resident ``torch.uint8`` CUDA
 tensors; device inputs are processed on the current stream and results stay on the device.
 """
-from ._engine import Engine
+from ._engine import F_TRUSTED, F_TRUSTED_ALL, F_UNCOMPRESSED, F_UNCOMPRESSED_OUT, Engine  # noqa: F401 (re-exported flags)
 
 ORDER = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001  # kilic/scalar.go:11-12
 G1_LEN, G2_LEN, GT_LEN, SCALAR_LEN = 48, 96, 576, 32
@@ -97,16 +97,20 @@ def batch_hash_g2(msgs, dst: bytes = DOMAIN_G2):
     return _batch_hash(2, msgs, dst)
 
 
-def batch_verify_g1(pubkeys, msgs, sigs, dst: bytes = DOMAIN_G1):
+def batch_verify_g1(pubkeys, msgs, sigs, dst: bytes = DOMAIN_G1, flags: int = 0):
     """(ok, status): N x bls.Verify (sign/bls/bls.go:82-96; signatures on G1, keys on G2) fused in ONE kernel:
     hash_to_curve, both unmarshal checks, two Miller loops sharing their squarings and one final exponentiation
-    per lane.  msgs: (n, msg_len) uint8 array / CUDA tensor or list of equal-length bytes."""
+    per lane.  msgs: (n, msg_len) uint8 array / CUDA tensor or list of equal-length bytes.  flags: F_TRUSTED(0) for
+    public keys validated before (the usual case: keys are unmarshalled once), F_TRUSTED(1) for the signatures,
+    F_UNCOMPRESSED for uncompressed-affine keys and signatures."""
     import ctypes
 
     import numpy as np
 
     from .._lib import check, load
-    from ._engine import _host, _is_torch, _stream
+    from ._engine import F_UNCOMPRESSED, _host, _is_torch, _stream
+
+    wk, wsig = (192, 96) if flags & F_UNCOMPRESSED else (96, 48)
 
     lib = load()
     dbuf = ctypes.create_string_buffer(bytes(dst), len(dst)) if dst else None
@@ -114,12 +118,12 @@ def batch_verify_g1(pubkeys, msgs, sigs, dst: bytes = DOMAIN_G1):
     if _is_torch(msgs):
         import torch
 
-        m, p, s = msgs.contiguous(), pubkeys.contiguous().view(-1, 96), sigs.contiguous().view(-1, 48)
+        m, p, s = msgs.contiguous(), pubkeys.contiguous().view(-1, wk), sigs.contiguous().view(-1, wsig)
         n, ln = m.shape[0], m.shape[1]
         ok = torch.empty(n, dtype=torch.uint8, device=m.device)
         st = torch.empty(n, dtype=torch.uint8, device=m.device)
         check(lib.kyb_bls12381_verify_g1_dev(n, p.data_ptr(), m.data_ptr(), ln, dptr, len(dst), s.data_ptr(), ok.data_ptr(),
-                                             st.data_ptr(), _stream()), "kyb_bls12381_verify_g1_dev")
+                                             st.data_ptr(), flags, _stream()), "kyb_bls12381_verify_g1_dev")
         return ok, st
     if isinstance(msgs, (list, tuple)):
         ln = len(msgs[0]) if msgs else 0
@@ -132,10 +136,10 @@ def batch_verify_g1(pubkeys, msgs, sigs, dst: bytes = DOMAIN_G1):
         n, ln = a.shape[0], a.shape[1]
         mb = a.reshape(-1)
     mb = np.ascontiguousarray(mb) if mb.size else np.zeros(1, dtype=np.uint8)
-    p = _host(pubkeys if not isinstance(pubkeys, (list, tuple)) else b"".join(pubkeys), 96)
-    s = _host(sigs if not isinstance(sigs, (list, tuple)) else b"".join(sigs), 48)
+    p = _host(pubkeys if not isinstance(pubkeys, (list, tuple)) else b"".join(pubkeys), wk)
+    s = _host(sigs if not isinstance(sigs, (list, tuple)) else b"".join(sigs), wsig)
     ok = np.empty(n, dtype=np.uint8)
     st = np.empty(n, dtype=np.uint8)
     check(lib.kyb_bls12381_verify_g1(n, p.ctypes.data, mb.ctypes.data, ln, dptr, len(dst), s.ctypes.data, ok.ctypes.data,
-                                     st.ctypes.data), "kyb_bls12381_verify_g1")
+                                     st.ctypes.data, flags), "kyb_bls12381_verify_g1")
     return ok, st

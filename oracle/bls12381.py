@@ -360,6 +360,65 @@ def g2_decompress(buf: bytes, subgroup_check: bool = True):
     return pt
 
 
+def g1_serialize_unc(p) -> bytes:
+    """ZCash uncompressed G1: x || y big-endian, 96 bytes; infinity = 0x40 then zeros."""
+    if p is None:
+        return bytes([0x40]) + bytes(95)
+    return p[0].to_bytes(48, "big") + p[1].to_bytes(48, "big")
+
+
+def g2_serialize_unc(p) -> bytes:
+    """ZCash uncompressed G2: x.c1 || x.c0 || y.c1 || y.c0, 192 bytes."""
+    if p is None:
+        return bytes([0x40]) + bytes(191)
+    (x0, x1), (y0, y1) = p
+    return b"".join(v.to_bytes(48, "big") for v in (x1, x0, y1, y0))
+
+
+def _unc_flags(buf, n):
+    if len(buf) != n:
+        raise DecodeError("length")
+    c, i, s = buf[0] >> 7, (buf[0] >> 6) & 1, (buf[0] >> 5) & 1
+    if c or s:
+        raise DecodeError("compression / sort flag set on an uncompressed encoding")
+    body = bytes([buf[0] & 0x1F]) + bytes(buf[1:])
+    if i and any(body):
+        raise DecodeError("bad infinity encoding")
+    return i, body
+
+
+def g1_deserialize_unc(buf: bytes, validate: bool = True):
+    inf, body = _unc_flags(buf, 96)
+    if inf:
+        return None
+    x, y = int.from_bytes(body[:48], "big"), int.from_bytes(body[48:], "big")
+    if x >= P or y >= P:
+        raise DecodeError("coordinate >= p")
+    pt = (x, y)
+    if validate:
+        if not g1_on_curve(pt):
+            raise DecodeError("not on curve")
+        if not g1_in_subgroup(pt):
+            raise DecodeError("not in G1")
+    return pt
+
+
+def g2_deserialize_unc(buf: bytes, validate: bool = True):
+    inf, body = _unc_flags(buf, 192)
+    if inf:
+        return None
+    x1, x0, y1, y0 = (int.from_bytes(body[48 * j:48 * j + 48], "big") for j in range(4))
+    if max(x0, x1, y0, y1) >= P:
+        raise DecodeError("coordinate >= p")
+    pt = ((x0, x1), (y0, y1))
+    if validate:
+        if not g2_on_curve(pt):
+            raise DecodeError("not on curve")
+        if not g2_in_subgroup(pt):
+            raise DecodeError("not in G2")
+    return pt
+
+
 def scalar_from_be(b: bytes) -> int:
     """mod.Int wire format: 32 bytes big-endian (group/mod/int.go:75,334-350)."""
     return int.from_bytes(b, "big")

@@ -54,6 +54,23 @@ int hh_bls_pair_check(const uint8_t* p1, const uint8_t* p2, const uint8_t* i1, c
     return bls::pair_check_wire(ok, p1, p2, i1, i2);
 }
 
+// flag-aware variants (KYB_F_UNCOMPRESSED / _OUT / TRUSTED): ints come before the output buffers
+int hh_bls_g1_mul_f(const uint8_t* k, const uint8_t* pt, int flags, uint8_t* out) {
+    return bls::g1_mul_wire(out, k, pt, (uint32_t)flags);
+}
+int hh_bls_g2_mul_f(const uint8_t* k, const uint8_t* pt, int flags, uint8_t* out) {
+    return bls::g2_mul_wire(out, k, pt, (uint32_t)flags);
+}
+int hh_bls_pair_f(const uint8_t* g1, const uint8_t* g2, int flags, uint8_t* gt) {
+    return bls::pair_wire(gt, g1, g2, (uint32_t)flags);
+}
+int hh_bls_pair_check_f(const uint8_t* p1, const uint8_t* p2, const uint8_t* i1, const uint8_t* i2, int flags,
+                        uint8_t* ok) {
+    return bls::pair_check_wire(ok, p1, p2, i1, i2, (uint32_t)flags);
+}
+int hh_bls_g1_decode_unc(const uint8_t* in, int validate) { bls::g1_aff a; return bls::g1_decode_unc(a, in, validate != 0); }
+int hh_bls_g2_decode_unc(const uint8_t* in, int validate) { bls::g2_aff a; return bls::g2_decode_unc(a, in, validate != 0); }
+
 // ---- bn256
 void hh_bn_fp_op(int op, const uint8_t* a32, const uint8_t* b32, uint8_t* out32) {
     bn::fp a, b, r;

@@ -254,3 +254,123 @@ def test_fused_verify_matches_hash_plus_pairing_check(bls):
     exp[::5] = False
     exp[[7, 11]] = False
     assert (ok_f.astype(bool) == exp).all()
+
+
+# ------------------------------------------------------------------ call flags (KYB_F_*)
+def _off_subgroup_g1():
+    x = 1
+    while True:
+        y = O.fp_sqrt((x * x * x + 4) % O.P)
+        if y is not None and not O.g1_in_subgroup((x, y)):
+            return (x, y)
+        x += 1
+
+
+def test_mul_uncompressed_in_out_and_trusted_flags(bls):
+    rng = random.Random(21)
+    n = 12
+    ks = [rng.randrange(O.R) for _ in range(n)]
+    hs = [rng.randrange(1, O.R) for _ in range(n)]
+    P1 = [O.g1_mul(h, O.G1_GEN) for h in hs]
+    P2 = [O.g2_mul(h, O.G2_GEN) for h in hs[:4]]
+    P1[2] = None
+    kb = b"".join(k.to_bytes(32, "big") for k in ks)
+    U, UO, T = bls.F_UNCOMPRESSED, bls.F_UNCOMPRESSED_OUT, bls.F_TRUSTED(0)
+    for flags in (0, U, UO, U | UO, U | UO | T, T):
+        ser_in = O.g1_serialize_unc if flags & U else O.g1_compress
+        ser_out = O.g1_serialize_unc if flags & UO else O.g1_compress
+        out, st = bls.g1_batch_mul(kb, b"".join(ser_in(p) for p in P1), flags)
+        assert not st.any()
+        for i in range(n):
+            assert bytes(out[i]) == ser_out(O.g1_mul(ks[i], P1[i]) if P1[i] else None), (flags, i)
+        ser_in = O.g2_serialize_unc if flags & U else O.g2_compress
+        ser_out = O.g2_serialize_unc if flags & UO else O.g2_compress
+        out, st = bls.g2_batch_mul(kb[:4 * 32], b"".join(ser_in(p) for p in P2), flags)
+        assert not st.any()
+        for i in range(4):
+            assert bytes(out[i]) == ser_out(O.g2_mul(ks[i], P2[i])), (flags, i)
+    # same-base with an uncompressed base and uncompressed outputs
+    out, st = bls.g1_commit(kb, O.g1_serialize_unc(P1[0]), U | UO)
+    assert not st.any() and bytes(out[5]) == O.g1_serialize_unc(O.g1_mul(ks[5], P1[0]))
+    # malformed uncompressed inputs and a point outside the subgroup
+    c = _off_subgroup_g1()
+    good = O.g1_serialize_unc(P1[0])
+    bad_y = good[:-1] + bytes([good[-1] ^ 1])
+    batch = good + bad_y + O.g1_serialize_unc(c) + bytes([good[0] | 0x80]) + good[1:]
+    out, st = bls.g1_batch_mul(kb[:4 * 32], batch, U)
+    assert list(st) == [0, 1, 2, 1] and not out[1:].any()
+    out, st = bls.g1_batch_mul((5).to_bytes(32, "big"), O.g1_compress(c), T)  # the caller vouched for it
+    assert st[0] == 0 and bytes(out[0]) == O.g1_compress(O.g1_mul(5, c))
+
+
+def test_pair_check_verify_and_msm_flags_agree_with_the_checked_path(bls):
+    import torch
+
+    n = 256
+    k = torch.from_numpy(_scalars(b"flags/k", n)).cuda()
+    h = torch.from_numpy(_scalars(b"flags/h", n)).cuda()
+    g1b = torch.from_numpy(np.frombuffer(bls.G1_BASE, dtype=np.uint8).copy()).cuda()
+    g2b = torch.from_numpy(np.frombuffer(bls.G2_BASE, dtype=np.uint8).copy()).cuda()
+    U, UO = bls.F_UNCOMPRESSED, bls.F_UNCOMPRESSED_OUT
+    Hc, _ = bls._mul(1, h, g1b, True)
+    Hu, _ = bls._mul(1, h, g1b, True, UO)
+    Xc, _ = bls._mul(2, k, g2b, True)
+    Xu, _ = bls._mul(2, k, g2b, True, UO)
+    sig_c, _ = bls.g1_batch_mul(k, Hc)
+    sig_u, _ = bls.g1_batch_mul(k, Hc, UO)
+    sig_c[7] = Hc[7]
+    sig_u[7] = Hu[7]  # one wrong signature
+    G2c = g2b.repeat(n, 1)
+    G2u = torch.from_numpy(np.frombuffer(O.g2_serialize_unc(O.G2_GEN), dtype=np.uint8).copy()).cuda().repeat(n, 1)
+    ok0, st0 = bls.batch_validate_pairing(Hc, Xc, sig_c, G2c)
+    exp = np.ones(n, dtype=np.uint8)
+    exp[7] = 0
+    assert not st0.any().item() and (ok0.cpu().numpy() == exp).all()
+    for flags, (a, b, c, d) in ((bls.F_TRUSTED(0) | bls.F_TRUSTED(1) | bls.F_TRUSTED(3), (Hc, Xc, sig_c, G2c)),
+                                (bls.F_TRUSTED_ALL, (Hc, Xc, sig_c, G2c)),
+                                (U, (Hu, Xu, sig_u, G2u)),
+                                (U | bls.F_TRUSTED_ALL, (Hu, Xu, sig_u, G2u))):
+        ok, st = bls.batch_validate_pairing(a, b, c, d, flags)
+        assert not st.any().item() and (ok.cpu().numpy() == exp).all(), flags
+    gt0, _ = bls.batch_pair(Hc, Xc)
+    gt1, st = bls.batch_pair(Hu, Xu, U | bls.F_TRUSTED_ALL)
+    assert not st.any().item() and torch.equal(gt0, gt1)
+    # an unvalidated operand outside the subgroup is still caught when the others are trusted
+    bad = sig_c.clone()
+    bad[3] = torch.from_numpy(np.frombuffer(O.g1_compress(_off_subgroup_g1()), dtype=np.uint8).copy()).cuda()
+    ok, st = bls.batch_validate_pairing(Hc, Xc, bad, G2c, bls.F_TRUSTED(0) | bls.F_TRUSTED(1) | bls.F_TRUSTED(3))
+    assert st[3].item() == 2 and ok[3].item() == 0 and st.sum().item() == 2
+    # fused verify: trusted keys / uncompressed keys + signatures
+    msgs = torch.from_numpy(np.frombuffer(hashlib.shake_256(b"flags/m").digest(n * 32), dtype=np.uint8).reshape(n, 32).copy()).cuda()
+    Hm, _ = bls.batch_hash_g1(msgs)
+    s_c, _ = bls.g1_batch_mul(k, Hm)
+    s_u, _ = bls.g1_batch_mul(k, Hm, UO)
+    s_c[9] = Hm[9]
+    s_u[9] = Hu[9]
+    v0, st = bls.batch_verify_g1(Xc, msgs, s_c)
+    expv = np.ones(n, dtype=np.uint8)
+    expv[9] = 0
+    assert not st.any().item() and (v0.cpu().numpy() == expv).all()
+    for flags, (kk, ss) in ((bls.F_TRUSTED(0), (Xc, s_c)), (U, (Xu, s_u)), (U | bls.F_TRUSTED(0) | bls.F_TRUSTED(1), (Xu, s_u))):
+        v, st = bls.batch_verify_g1(kk, msgs, ss, flags=flags)
+        assert not st.any().item() and (v.cpu().numpy() == expv).all(), flags
+    # MSM: validated / uncompressed inputs give the same point
+    for grp, (pc, pu) in ((1, (Hc, Hu)), (2, (Xc, Xu))):
+        r0, st = bls.ENGINE.msm(grp, k, pc)
+        assert not st.any().item()
+        for flags, p in ((bls.F_TRUSTED(0), pc), (U, pu), (U | bls.F_TRUSTED(0), pu)):
+            r, st = bls.ENGINE.msm(grp, k, p, flags)
+            assert not st.any().item() and torch.equal(r, r0), (grp, flags)
+
+
+def test_bn256_accepts_and_ignores_the_flags():
+    from kyber_amd.pairing import bn256 as bn
+
+    k = _scalars(b"bnflags/k", 8)
+    P, _ = bn.g1_commit(k)
+    a, st = bn.g1_batch_mul(k, P)
+    b, st2 = bn.g1_batch_mul(k, P, bn.F_UNCOMPRESSED | bn.F_UNCOMPRESSED_OUT | bn.F_TRUSTED_ALL)
+    assert not st.any() and not st2.any() and (a == b).all()
+    r0, _ = bn.g1_msm(k, P)
+    r1, _ = bn.g1_msm(k, P, bn.F_TRUSTED(0) | bn.F_UNCOMPRESSED)
+    assert (r0 == r1).all()

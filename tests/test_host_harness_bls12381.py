@@ -189,3 +189,105 @@ def test_fused_verify_replays_drand_fixtures(golden_dir):
                   bytes.fromhex(f["sig_g1"]), out_sizes=(1,)) == (0, bytes([1]))
     st, ok = H.call("hh_bls_verify_g1", bytes(96), msg, 32, d1, len(d1), sig, out_sizes=(1,))
     assert st == 1 and ok == bytes([0])
+
+
+# ------------------------------------------------------------------ call flags (include/kyber_hip.h)
+F_UNC, F_UNC_OUT = 2, 4
+
+
+def F_TRUSTED(i):
+    return 0x100 << i
+
+
+def _cofactor_points():
+    """On-curve points OUTSIDE the prime-order subgroups (found by trial x)."""
+    x = 1
+    while True:
+        y = O.fp_sqrt((x * x * x + 4) % O.P)
+        if y is not None and not O.g1_in_subgroup((x, y)):
+            p1 = (x, y)
+            break
+        x += 1
+    x = 1
+    while True:
+        xx = (x, 1)
+        y = O.f2_sqrt(O.f2_add(O.f2_mul(O.f2_sqr(xx), xx), (4, 4)))
+        if y is not None and not O.g2_in_subgroup((xx, y)):
+            return p1, (xx, y)
+        x += 1
+
+
+def test_uncompressed_decode_rules():
+    rng = random.Random(11)
+    k = rng.randrange(1, O.R)
+    p1, p2 = O.g1_mul(k, O.G1_GEN), O.g2_mul(k, O.G2_GEN)
+    u1, u2 = O.g1_serialize_unc(p1), O.g2_serialize_unc(p2)
+    assert O.g1_deserialize_unc(u1) == p1 and O.g2_deserialize_unc(u2) == p2
+    for fn, buf in (("hh_bls_g1_decode_unc", u1), ("hh_bls_g2_decode_unc", u2)):
+        assert H.call(fn, buf, 1)[0] == 0
+        assert H.call(fn, bytes([buf[0] | 0x80]) + buf[1:], 1)[0] == 1  # compression bit on an uncompressed form
+        assert H.call(fn, bytes([buf[0] | 0x20]) + buf[1:], 1)[0] == 1  # sort bit
+        bad = bytearray(buf)
+        bad[-1] ^= 1  # y no longer satisfies the curve equation
+        assert H.call(fn, bytes(bad), 1)[0] == 1
+        assert H.call(fn, bytes(bad), 0)[0] == 0  # trusted: not checked
+        n = len(buf)
+        inf = bytes([0x40]) + bytes(n - 1)
+        assert H.call(fn, inf, 1)[0] == 0
+        assert H.call(fn, bytes([0x40]) + bytes(n - 2) + b"\x01", 1)[0] == 1
+        big = bytes([0x1f]) + b"\xff" * 47 + buf[48:]  # x >= p
+        assert H.call(fn, big, 1)[0] == 1
+    c1, c2 = _cofactor_points()
+    assert H.call("hh_bls_g1_decode_unc", O.g1_serialize_unc(c1), 1)[0] == 2
+    assert H.call("hh_bls_g2_decode_unc", O.g2_serialize_unc(c2), 1)[0] == 2
+    assert H.call("hh_bls_g1_decode_unc", O.g1_serialize_unc(c1), 0)[0] == 0
+
+
+def test_mul_flags_uncompressed_in_out_and_trusted():
+    rng = random.Random(12)
+    for _ in range(2):
+        k, h = rng.randrange(O.R), rng.randrange(1, O.R)
+        kb = k.to_bytes(32, "big")
+        p1, p2 = O.g1_mul(h, O.G1_GEN), O.g2_mul(h, O.G2_GEN)
+        r1, r2 = O.g1_mul(k, p1), O.g2_mul(k, p2)
+        for flags in (0, F_UNC, F_UNC_OUT, F_UNC | F_UNC_OUT, F_UNC | F_UNC_OUT | F_TRUSTED(0), F_TRUSTED(0)):
+            i1 = O.g1_serialize_unc(p1) if flags & F_UNC else O.g1_compress(p1)
+            i2 = O.g2_serialize_unc(p2) if flags & F_UNC else O.g2_compress(p2)
+            e1 = O.g1_serialize_unc(r1) if flags & F_UNC_OUT else O.g1_compress(r1)
+            e2 = O.g2_serialize_unc(r2) if flags & F_UNC_OUT else O.g2_compress(r2)
+            assert H.call("hh_bls_g1_mul_f", kb, i1, flags, out_sizes=(len(e1),)) == (0, e1), flags
+            assert H.call("hh_bls_g2_mul_f", kb, i2, flags, out_sizes=(len(e2),)) == (0, e2), flags
+    # infinity round-trips in the uncompressed form
+    z = (0).to_bytes(32, "big")
+    assert H.call("hh_bls_g1_mul_f", z, O.g1_serialize_unc(p1), F_UNC | F_UNC_OUT, out_sizes=(96,)) == (0, O.g1_serialize_unc(None))
+    # a point outside the subgroup: rejected unless the caller vouches for it, then processed as plain curve arithmetic
+    c1, _ = _cofactor_points()
+    kb = (5).to_bytes(32, "big")
+    st, out = H.call("hh_bls_g1_mul_f", kb, O.g1_compress(c1), 0, out_sizes=(48,))
+    assert st == 2 and out == bytes(48)
+    st, out = H.call("hh_bls_g1_mul_f", kb, O.g1_compress(c1), F_TRUSTED(0), out_sizes=(48,))
+    assert st == 0 and out == O.g1_compress(O.g1_mul(5, c1))
+
+
+def test_pair_check_flags():
+    rng = random.Random(13)
+    x, h = rng.randrange(1, O.R), rng.randrange(1, O.R)
+    H1 = O.g1_mul(h, O.G1_GEN)
+    X = O.g2_mul(x, O.G2_GEN)
+    sig = O.g1_mul(x, H1)
+    for flags in (0, F_TRUSTED(0) | F_TRUSTED(1) | F_TRUSTED(3), 0xF00, F_UNC, F_UNC | 0xF00):
+        s1 = O.g1_serialize_unc if flags & F_UNC else O.g1_compress
+        s2 = O.g2_serialize_unc if flags & F_UNC else O.g2_compress
+        st, ok = H.call("hh_bls_pair_check_f", s1(H1), s2(X), s1(sig), s2(O.G2_GEN), flags, out_sizes=(1,))
+        assert (st, ok) == (0, b"\x01"), flags
+        st, ok = H.call("hh_bls_pair_check_f", s1(H1), s2(X), s1(O.g1_add(sig, H1)), s2(O.G2_GEN), flags, out_sizes=(1,))
+        assert (st, ok) == (0, b"\x00"), flags
+    # an untrusted operand outside its subgroup is still rejected when only the others are trusted
+    c1, _ = _cofactor_points()
+    st, ok = H.call("hh_bls_pair_check_f", O.g1_compress(H1), O.g2_compress(X), O.g1_compress(c1), O.g2_compress(O.G2_GEN),
+                    F_TRUSTED(0) | F_TRUSTED(1) | F_TRUSTED(3), out_sizes=(1,))
+    assert (st, ok) == (2, b"\x00")
+    # GT bytes do not depend on the input form
+    g_c = H.call("hh_bls_pair_f", O.g1_compress(H1), O.g2_compress(X), 0, out_sizes=(576,))
+    g_u = H.call("hh_bls_pair_f", O.g1_serialize_unc(H1), O.g2_serialize_unc(X), F_UNC | 0xF00, out_sizes=(576,))
+    assert g_c == g_u and g_c[0] == 0
