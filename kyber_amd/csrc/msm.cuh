@@ -51,9 +51,11 @@ inline Plan make_plan(size_t n) {
     p.c = c;
     p.nwin = (256 + c) / c;  // ceil(257 / c): 256 scalar bits + the recoding carry
     p.nb = 1 << (c - 1);
-    // buckets per reduce lane: enough lanes (>= ~16k) to fill the chip, between 8 and 64 buckets each
-    int chunk = 64;
-    while (chunk > 8 && (size_t)p.nwin * (p.nb / chunk) < 16384) chunk >>= 1;
+    // buckets per reduce lane: the running-sum chain of a lane is latency-bound (2 dependent additions per bucket, and
+    // a lone wave already saturates its SIMD's issue rate), so take the shortest chains that still leave every wave
+    // a SIMD of its own: at most 1024 waves = 65536 lanes, between 8 and 64 buckets each
+    int chunk = 8;
+    while (chunk < 64 && (size_t)p.nwin * (p.nb / chunk) > 65536) chunk <<= 1;
     p.chunk = p.nb < chunk ? p.nb : chunk;
     p.nchunks = p.nb / p.chunk;
     return p;
@@ -106,31 +108,70 @@ __global__ __launch_bounds__(64) void decode_kernel(Plan p, const uint8_t* __res
     }
 }
 
-// exclusive scan of hist[0..m) into offs[0..m], single workgroup
-static __global__ __launch_bounds__(1024) void scan_kernel(const uint32_t* __restrict__ hist, uint32_t* __restrict__ offs,
-                                                    size_t m) {
-    __shared__ uint32_t part[1024];
-    const size_t per = (m + 1023) / 1024;
-    const size_t lo = threadIdx.x * per, hi = lo + per < m ? lo + per : m;
+// exclusive scan of hist[0..m) into offs[0..m] in three launches: per-tile sums, a scan of the (<= a few hundred)
+// tile sums, and a per-tile rescan that adds the tile's offset.  All global accesses are coalesced or 64-B vectors.
+constexpr int SCAN_T = 256, SCAN_E = 16, SCAN_TILE = SCAN_T * SCAN_E;
+static __global__ __launch_bounds__(SCAN_T) void scan_tilesum_kernel(const uint32_t* __restrict__ hist,
+                                                                     uint32_t* __restrict__ tile, size_t m) {
+    __shared__ uint32_t red[SCAN_T];
+    const size_t base = (size_t)blockIdx.x * SCAN_TILE;
     uint32_t s = 0;
-    for (size_t j = lo; j < hi; j++) s += hist[j];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int t = 0; t < 1024; t++) {
-            const uint32_t v = part[t];
-            part[t] = run;
-            run += v;
-        }
+#pragma unroll
+    for (int e = 0; e < SCAN_E; e++) {
+        const size_t j = base + (size_t)e * SCAN_T + threadIdx.x;
+        if (j < m) s += hist[j];
     }
+    red[threadIdx.x] = s;
     __syncthreads();
-    uint32_t run = part[threadIdx.x];
-    for (size_t j = lo; j < hi; j++) {
-        offs[j] = run;
-        run += hist[j];
+    for (int off = SCAN_T / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
     }
-    if (threadIdx.x == 1023) offs[m] = run;
+    if (threadIdx.x == 0) tile[blockIdx.x] = red[0];
+}
+static __global__ __launch_bounds__(64) void scan_tiles_kernel(uint32_t* __restrict__ tile, size_t ntiles) {
+    if (threadIdx.x) return;
+    uint32_t run = 0;
+    for (size_t t = 0; t < ntiles; t++) {
+        const uint32_t v = tile[t];
+        tile[t] = run;
+        run += v;
+    }
+    tile[ntiles] = run;
+}
+static __global__ __launch_bounds__(SCAN_T) void scan_apply_kernel(const uint32_t* __restrict__ hist,
+                                                                   const uint32_t* __restrict__ tile,
+                                                                   uint32_t* __restrict__ offs, size_t m) {
+    __shared__ uint32_t sh[SCAN_T];
+    const size_t lo = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_E;
+    uint32_t v[SCAN_E];
+    uint32_t s = 0;
+#pragma unroll
+    for (int e = 0; e < SCAN_E; e++) {
+        v[e] = lo + e < m ? hist[lo + e] : 0u;
+        s += v[e];
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < SCAN_T; off <<= 1) {  // Hillis-Steele inclusive scan of the thread sums
+        const uint32_t add = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0u;
+        __syncthreads();
+        sh[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = tile[blockIdx.x] + sh[threadIdx.x] - s;
+#pragma unroll
+    for (int e = 0; e < SCAN_E; e++) {
+        if (lo + e < m) offs[lo + e] = run;
+        run += v[e];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) offs[m] = tile[gridDim.x];
+}
+static inline void launch_scan(const uint32_t* hist, uint32_t* offs, size_t m, uint32_t* tile, hipStream_t st) {
+    const unsigned ntiles = (unsigned)((m + SCAN_TILE - 1) / SCAN_TILE);
+    hipLaunchKernelGGL(scan_tilesum_kernel, dim3(ntiles), dim3(SCAN_T), 0, st, hist, tile, m);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(64), 0, st, tile, (size_t)ntiles);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(SCAN_T), 0, st, hist, (const uint32_t*)tile, offs, m);
 }
 
 static __global__ __launch_bounds__(256) void scatter_kernel(Plan p, const int32_t* __restrict__ digits,
@@ -236,57 +277,89 @@ __global__ __launch_bounds__(64) void reduce_kernel(Plan p, const typename A::Ac
     partial[t] = tot;
 }
 
-// out[w][g] = sum of in[w][g * G .. g * G + G): folds the per-window chunk partials G at a time so the
-// single-workgroup final step only has a handful of additions per window left
+// out[w][g] = sum of in[w][64 g .. 64 g + 64): one wave per group, the 64 partials summed as a tree through LDS
+// (depth 6 additions instead of a 64-long dependent chain in one lane).  Applied until one partial per window is left.
 template <class A>
-__global__ __launch_bounds__(64) void fold_kernel(int nwin, int nin, int G, const typename A::Acc* __restrict__ in,
-                                                  typename A::Acc* __restrict__ out) {
-    const int nout = (nin + G - 1) / G;
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)nwin * nout) return;
-    const size_t w = t / nout, g = t - w * nout;
+__global__ __launch_bounds__(64) void tree_fold_kernel(int nwin, int nin, const typename A::Acc* __restrict__ in,
+                                                       typename A::Acc* __restrict__ out) {
+    __shared__ typename A::Acc sh[64];
+    const int nout = (nin + 63) / 64;
+    const int w = blockIdx.x / nout, g = blockIdx.x - w * nout;
+    const int k = g * 64 + (int)threadIdx.x;
     typename A::Acc s;
     A::identity(s);
-    const int hi = (int)(g * G + G) < nin ? (int)(g * G + G) : nin;
+    if (k < nin) s = in[(size_t)w * nin + k];
 #pragma unroll 1
-    for (int k = (int)g * G; k < hi; k++) {
-        const typename A::Acc v = in[w * nin + k];
-        A::add(s, s, v);
+    for (int off = 32; off >= 1; off >>= 1) {
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        if ((int)threadIdx.x < off) {
+            const typename A::Acc v = sh[threadIdx.x + off];
+            A::add(s, s, v);
+        }
+        __syncthreads();
     }
-    out[t] = s;
+    if (threadIdx.x == 0) out[(size_t)w * nout + g] = s;
 }
 
+// Coop<A>::value: the adapter offers dbl_coop (COOP lanes per point)
+template <class A, class = void>
+struct Coop {
+    static constexpr int value = 1;
+};
 template <class A>
-__global__ __launch_bounds__(256) void final_kernel(Plan p, int nparts, const typename A::Acc* __restrict__ partial,
-                                                    typename A::Acc* __restrict__ winsum, const uint32_t* __restrict__ bad,
-                                                    uint8_t* __restrict__ out) {
-    const int w = threadIdx.x;
-    if (w < p.nwin) {
-        typename A::Acc s;
-        A::identity(s);
+struct Coop<A, decltype((void)A::COOP)> {
+    static constexpr int value = A::COOP;
+};
+
+constexpr int FINAL_T = 512;
+
+// One workgroup: window w's sum is doubled w*c times, the nwin results are added as a tree and encoded.  This tail is a
+// pure dependency chain ((nwin-1)*c doublings), so each point is held by COOP lanes that split the independent field
+// products of a doubling between them when the adapter offers dbl_coop.
+template <class A>
+__global__ __launch_bounds__(FINAL_T) void final_kernel(Plan p, const typename A::Acc* __restrict__ wsum,
+                                                        typename A::Acc* __restrict__ winsum,
+                                                        const uint32_t* __restrict__ bad, uint8_t* __restrict__ out) {
+    constexpr int L = Coop<A>::value;
+    const int t = threadIdx.x, w = t / L, r = t - w * L;
+    typename A::Acc s;
+    A::identity(s);
+    if (w < p.nwin) s = wsum[w];
+    if constexpr (L > 1) {
+        __shared__ typename A::Field sh[FINAL_T + L];
+        const int total = (p.nwin - 1) * p.c;
 #pragma unroll 1
-        for (int ch = 0; ch < nparts; ch++) {
-            const typename A::Acc v = partial[(size_t)w * nparts + ch];
-            A::add(s, s, v);
+        for (int k = 0; k < total; k++) {
+            typename A::Acc d = s;
+            A::dbl_coop(d, r, sh + w * L);
+            if (k < w * p.c) s = d;
         }
+    } else {
 #pragma unroll 1
-        for (int k = 0; k < w * p.c; k++) A::dbl(s, s);
-        winsum[w] = s;
+        for (int k = 0; k < w * p.c && w < p.nwin; k++) A::dbl(s, s);
     }
+    if (w < p.nwin && r == 0) winsum[w] = s;
     __threadfence_block();
     __syncthreads();
-    if (threadIdx.x == 0) {
-        typename A::Acc s;
-        A::identity(s);
 #pragma unroll 1
-        for (int k = 0; k < p.nwin; k++) {
-            const typename A::Acc v = winsum[k];
-            A::add(s, s, v);
+    for (int off = FINAL_T / 2; off >= 1; off >>= 1) {
+        if (off < p.nwin) {  // uniform
+            if (t < off && t + off < p.nwin) {
+                const typename A::Acc a = winsum[t], b = winsum[t + off];
+                A::add(s, a, b);
+                winsum[t] = s;
+            }
+            __threadfence_block();
+            __syncthreads();
         }
+    }
+    if (t == 0) {
         if (*bad) {
             for (int k = 0; k < A::OUT; k++) out[k] = 0;
         } else {
-            A::encode(out, s);
+            const typename A::Acc v = winsum[0];
+            A::encode(out, v);
         }
     }
 }
@@ -326,9 +399,9 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     const size_t o_pieces = take(sizeof(typename A::Acc) * max_pieces);
     const size_t o_buckets = take(sizeof(typename A::Acc) * nbk);
     const size_t o_partial = take(sizeof(typename A::Acc) * (size_t)p.nwin * p.nchunks);
-    const int fold_g = 32;
-    const int nfold = (p.nchunks + fold_g - 1) / fold_g;
+    const int nfold = (p.nchunks + 63) / 64;
     const size_t o_fold = take(sizeof(typename A::Acc) * (size_t)p.nwin * nfold);
+    const size_t o_tile = take(sizeof(uint32_t) * ((nbk + SCAN_TILE - 1) / SCAN_TILE + 2));
     const size_t o_winsum = take(sizeof(typename A::Acc) * p.nwin);
     void* ws;
     int rc = ctx_workspace(ctx, off, &ws);
@@ -348,33 +421,40 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     auto* partial = (typename A::Acc*)(base + o_partial);
     auto* winsum = (typename A::Acc*)(base + o_winsum);
     auto* folded = (typename A::Acc*)(base + o_fold);
+    auto* tile = (uint32_t*)(base + o_tile);
     KYB_HIP_CHECK(hipMemsetAsync(hist, 0, zero_end - o_hist, st));
     if (n) {
         hipLaunchKernelGGL(decode_kernel<A>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, pr, (const uint8_t*)d_scalars,
                            (const uint8_t*)d_points, aff, digits, hist, (uint8_t*)d_status, bad);
     }
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, hist, offs, nbk);
+    launch_scan(hist, offs, nbk, tile, st);
     if (n) {
         const size_t tot = n * (size_t)p.nwin;
         hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, pr, digits, offs, cursor,
                            sorted);
     }
     hipLaunchKernelGGL(subcount_kernel, dim3((unsigned)((nbk + 255) / 256)), dim3(256), 0, st, nbk, offs, nsub);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, nsub, suboffs, nbk);
+    launch_scan(nsub, suboffs, nbk, tile, st);
     hipLaunchKernelGGL(accumulate_kernel<A>, dim3((unsigned)((max_pieces + 63) / 64)), dim3(64), 0, st, nbk, max_pieces, aff,
                        offs, suboffs, sorted, pieces);
     hipLaunchKernelGGL(bucket_kernel<A>, dim3((unsigned)((nbk + 63) / 64)), dim3(64), 0, st, nbk, suboffs, pieces, buckets);
     const size_t nred = (size_t)p.nwin * p.nchunks;
     hipLaunchKernelGGL(reduce_kernel<A>, dim3((unsigned)((nred + 63) / 64)), dim3(64), 0, st, pr, buckets, partial);
-    if (p.nchunks > 16) {
-        const size_t nf = (size_t)p.nwin * nfold;
-        hipLaunchKernelGGL(fold_kernel<A>, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, st, p.nwin, p.nchunks, fold_g,
-                           partial, folded);
-        hipLaunchKernelGGL(final_kernel<A>, dim3(1), dim3(256), 0, st, pr, nfold, folded, winsum, bad, (uint8_t*)d_out);
-    } else {
-        hipLaunchKernelGGL(final_kernel<A>, dim3(1), dim3(256), 0, st, pr, p.nchunks, partial, winsum, bad,
-                           (uint8_t*)d_out);
+    // fold the per-window chunk partials 64 at a time (ping-pong between `partial` and `folded`) down to one each
+    typename A::Acc* cur = partial;
+    typename A::Acc* nxt = folded;
+    int ncur = p.nchunks;
+    while (ncur > 1) {
+        const int nout = (ncur + 63) / 64;
+        hipLaunchKernelGGL(tree_fold_kernel<A>, dim3((unsigned)(p.nwin * nout)), dim3(64), 0, st, p.nwin, ncur, cur, nxt);
+        typename A::Acc* t = cur;
+        cur = nxt;
+        nxt = t;
+        ncur = nout;
     }
+    // only as many waves as hold windows: an idle wave sharing a SIMD with a working one would halve its issue rate
+    const unsigned final_t = (unsigned)((p.nwin * Coop<A>::value + 63) / 64 * 64);
+    hipLaunchKernelGGL(final_kernel<A>, dim3(1), dim3(final_t), 0, st, pr, cur, winsum, bad, (uint8_t*)d_out);
     KYB_HIP_CHECK(hipGetLastError());
     return KYB_OK;
 }

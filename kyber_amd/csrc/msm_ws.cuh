@@ -35,6 +35,48 @@ struct Weierstrass {
     }
     __device__ static void add(Acc& r, const Acc& a, const Acc& b) { jac_add(r, a, b); }
     __device__ static void dbl(Acc& r, const Acc& a) { jac_dbl(r, a); }
+    // Cooperative doubling for the latency-bound tail of the MSM (final_kernel): COOP lanes hold the same point and
+    // each computes one of the independent field products of a level, exchanged through LDS `sh` (COOP slots of this
+    // group) -- a doubling is 3 dependent multiplications deep instead of 2M + 5S.  Every thread of the block must
+    // call it (it contains barriers); `r` is the lane's index in its group.
+    static constexpr int COOP = 3;
+    using Field = F;
+    __device__ static void dbl_coop(Acc& s, int r, F* sh) {
+        F a = s.Y, b = s.Y, m, t, E;
+        f_cmov(a, s.X, r == 0);
+        f_cmov(b, s.X, r == 0);
+        f_cmov(b, s.Z, r == 2);
+        f_mul(m, a, b);  // X^2 | Y^2 | Y Z
+        sh[r] = m;
+        __syncthreads();
+        const F A = sh[0], B = sh[1], YZ = sh[2];
+        __syncthreads();
+        f_dbl(E, A);
+        f_add(E, E, A);  // 3 X^2
+        f_add(t, s.X, B);
+        a = B;
+        f_cmov(a, t, r == 1);
+        f_cmov(a, E, r == 2);
+        f_sqr(m, a);  // Y^4 | (X + Y^2)^2 | 9 X^4
+        sh[r] = m;
+        __syncthreads();
+        F C = sh[0], T = sh[1];
+        const F G = sh[2];
+        __syncthreads();
+        F D;
+        f_sub(T, T, A);
+        f_sub(T, T, C);
+        f_dbl(D, T);  // 4 X Y^2
+        f_dbl(s.Z, YZ);
+        f_dbl(t, D);
+        f_sub(s.X, G, t);
+        f_sub(t, D, s.X);
+        f_mul(t, E, t);  // the one product of the last level, computed by every lane
+        f_dbl(C, C);
+        f_dbl(C, C);
+        f_dbl(C, C);
+        f_sub(s.Y, t, C);
+    }
     __device__ static void encode(uint8_t* out, const Acc& a) {
         kyb::Aff<F> t;
         jac_to_aff(t, a);

@@ -24,7 +24,7 @@ def test_fp_ops_random_and_edges():
         assert H.call("hh_bls_fp_op", 1, _fp(a), _fp(b), out_sizes=(48,))[1] == _fp((a + b) % O.P)
         assert H.call("hh_bls_fp_op", 2, _fp(a), _fp(b), out_sizes=(48,))[1] == _fp((a - b) % O.P)
         assert H.call("hh_bls_fp_op", 3, _fp(a), _fp(b), out_sizes=(48,))[1] == _fp(-a % O.P)
-    for a in vals[:12]:
+    for a in vals + [3, 1 << 32, (1 << 64) - 1, O.P - 3, (O.P + 1) // 2]:  # Kaliski inversion: every step count / edge
         exp = pow(a, -1, O.P) if a else 0
         assert H.call("hh_bls_fp_op", 4, _fp(a), _fp(0), out_sizes=(48,))[1] == _fp(exp)
 

@@ -27,7 +27,7 @@ def test_fp_ops():
         assert H.call("hh_bn_fp_op", 0, _fp(a), _fp(b), out_sizes=(32,))[1] == _fp(a * b % O.P)
         assert H.call("hh_bn_fp_op", 1, _fp(a), _fp(b), out_sizes=(32,))[1] == _fp((a + b) % O.P)
         assert H.call("hh_bn_fp_op", 2, _fp(a), _fp(b), out_sizes=(32,))[1] == _fp((a - b) % O.P)
-    for a in vals[:10]:
+    for a in vals + [3, 1 << 32, (1 << 64) - 1, O.P - 3, (O.P + 1) // 2]:  # Kaliski inversion: every step count / edge
         exp = pow(a, -1, O.P) if a % O.P else 0
         assert H.call("hh_bn_fp_op", 4, _fp(a), _fp(0), out_sizes=(32,))[1] == _fp(exp)
 
