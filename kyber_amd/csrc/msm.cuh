@@ -197,27 +197,76 @@ static __global__ __launch_bounds__(256) void subcount_kernel(size_t nbk, const 
     nsub[b] = (offs[b + 1] - offs[b] + SUB - 1) / SUB;
 }
 
-// One lane per bucket piece: sums up to SUB points (mixed additions).  The piece -> bucket map is a
+// Piece t -> (first index into `sorted`, length), plus a histogram of the lengths.  The piece -> bucket map is a
 // binary search in the scanned piece counts.
+static __global__ __launch_bounds__(256) void piece_kernel(size_t nbk, size_t max_pieces, const uint32_t* __restrict__ offs,
+                                                           const uint32_t* __restrict__ suboffs,
+                                                           uint32_t* __restrict__ plo, uint32_t* __restrict__ plen,
+                                                           uint32_t* __restrict__ lenhist) {
+    __shared__ uint32_t h[SUB + 1];
+    for (int i = threadIdx.x; i <= SUB; i += 256) h[i] = 0;
+    __syncthreads();
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < max_pieces && t < suboffs[nbk]) {
+        size_t lo_b = 0, hi_b = nbk;  // largest b with suboffs[b] <= t
+        while (hi_b - lo_b > 1) {
+            const size_t mid = (lo_b + hi_b) >> 1;
+            if (suboffs[mid] <= t) lo_b = mid; else hi_b = mid;
+        }
+        const size_t b = lo_b;
+        const uint32_t j = (uint32_t)(t - suboffs[b]);
+        const uint32_t lo = offs[b] + j * SUB;
+        const uint32_t end = offs[b + 1];
+        const uint32_t len = (lo + SUB < end ? lo + SUB : end) - lo;
+        plo[t] = lo;
+        plen[t] = len;
+        atomicAdd(&h[SUB - len], 1u);  // bin 0 = longest
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= SUB; i += 256)
+        if (h[i]) atomicAdd(&lenhist[i], h[i]);
+}
+// order[] = the pieces sorted by decreasing length (counting sort; ranks within a workgroup come from LDS atomics, one
+// global atomic per length per workgroup reserves the range).
+static __global__ __launch_bounds__(256) void piece_order_kernel(size_t nbk, size_t max_pieces,
+                                                                 const uint32_t* __restrict__ suboffs,
+                                                                 const uint32_t* __restrict__ plen,
+                                                                 const uint32_t* __restrict__ lenoffs,
+                                                                 uint32_t* __restrict__ lencursor,
+                                                                 uint32_t* __restrict__ order) {
+    __shared__ uint32_t h[SUB + 1], base[SUB + 1];
+    for (int i = threadIdx.x; i <= SUB; i += 256) h[i] = 0;
+    __syncthreads();
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = t < max_pieces && t < suboffs[nbk];
+    uint32_t bin = 0, rank = 0;
+    if (valid) {
+        bin = SUB - plen[t];
+        rank = atomicAdd(&h[bin], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= SUB; i += 256)
+        if (h[i]) base[i] = lenoffs[i] + atomicAdd(&lencursor[i], h[i]);
+    __syncthreads();
+    if (valid) order[base[bin] + rank] = (uint32_t)t;
+}
+
+// One lane per bucket piece: sums up to SUB points (mixed additions).  Lanes take the pieces in order of decreasing
+// length, so the lanes of a wave run the same number of additions (bucket sizes are Poisson-spread: in bucket order a
+// wave would wait for its longest piece, ~40 % above the mean at 32 points per bucket).
 template <class A>
 __global__ __launch_bounds__(64) void accumulate_kernel(size_t nbk, size_t max_pieces,
                                                         const typename A::Aff* __restrict__ aff,
-                                                        const uint32_t* __restrict__ offs,
                                                         const uint32_t* __restrict__ suboffs,
+                                                        const uint32_t* __restrict__ order,
+                                                        const uint32_t* __restrict__ plo,
+                                                        const uint32_t* __restrict__ plen,
                                                         const uint32_t* __restrict__ sorted,
                                                         typename A::Acc* __restrict__ pieces) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= max_pieces || t >= suboffs[nbk]) return;
-    size_t lo_b = 0, hi_b = nbk;  // largest b with suboffs[b] <= t
-    while (hi_b - lo_b > 1) {
-        const size_t mid = (lo_b + hi_b) >> 1;
-        if (suboffs[mid] <= t) lo_b = mid; else hi_b = mid;
-    }
-    const size_t b = lo_b;
-    const uint32_t j = (uint32_t)(t - suboffs[b]);
-    const uint32_t lo = offs[b] + j * SUB;
-    const uint32_t end = offs[b + 1];
-    const uint32_t hi = lo + SUB < end ? lo + SUB : end;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= max_pieces || i >= suboffs[nbk]) return;
+    const uint32_t t = order[i];
+    const uint32_t lo = plo[t], hi = lo + plen[t];
     typename A::Acc acc;
     A::identity(acc);
 #pragma unroll 1
@@ -390,13 +439,18 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     const size_t o_sorted = take(sizeof(uint32_t) * (n ? n : 1) * p.nwin);
     const size_t o_hist = take(sizeof(uint32_t) * nbk);
     const size_t o_cursor = take(sizeof(uint32_t) * nbk);
+    const size_t o_lenhist = take(sizeof(uint32_t) * (SUB + 2));
+    const size_t o_lencursor = take(sizeof(uint32_t) * (SUB + 2));
     const size_t o_bad = take(256);
-    const size_t zero_end = off;  // hist, cursor, bad are zeroed together
+    const size_t zero_end = off;  // hist, cursor, lenhist, lencursor, bad are zeroed together
     const size_t o_offs = take(sizeof(uint32_t) * (nbk + 1));
     const size_t o_nsub = take(sizeof(uint32_t) * nbk);
     const size_t o_suboffs = take(sizeof(uint32_t) * (nbk + 1));
     const size_t max_pieces = nbk + ((n ? n : 1) * (size_t)p.nwin + SUB - 1) / SUB;
     const size_t o_pieces = take(sizeof(typename A::Acc) * max_pieces);
+    const size_t o_plo = take(sizeof(uint32_t) * max_pieces);
+    const size_t o_plen = take(sizeof(uint32_t) * max_pieces);
+    const size_t o_order = take(sizeof(uint32_t) * max_pieces);
     const size_t o_buckets = take(sizeof(typename A::Acc) * nbk);
     const size_t o_partial = take(sizeof(typename A::Acc) * (size_t)p.nwin * p.nchunks);
     const int nfold = (p.nchunks + 63) / 64;
@@ -417,6 +471,11 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     auto* nsub = (uint32_t*)(base + o_nsub);
     auto* suboffs = (uint32_t*)(base + o_suboffs);
     auto* pieces = (typename A::Acc*)(base + o_pieces);
+    auto* plo = (uint32_t*)(base + o_plo);
+    auto* plen = (uint32_t*)(base + o_plen);
+    auto* order = (uint32_t*)(base + o_order);
+    auto* lenhist = (uint32_t*)(base + o_lenhist);
+    auto* lencursor = (uint32_t*)(base + o_lencursor);
     auto* buckets = (typename A::Acc*)(base + o_buckets);
     auto* partial = (typename A::Acc*)(base + o_partial);
     auto* winsum = (typename A::Acc*)(base + o_winsum);
@@ -435,8 +494,15 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     }
     hipLaunchKernelGGL(subcount_kernel, dim3((unsigned)((nbk + 255) / 256)), dim3(256), 0, st, nbk, offs, nsub);
     launch_scan(nsub, suboffs, nbk, tile, st);
+    const unsigned pgrid = (unsigned)((max_pieces + 255) / 256);
+    hipLaunchKernelGGL(piece_kernel, dim3(pgrid), dim3(256), 0, st, nbk, max_pieces, (const uint32_t*)offs,
+                       (const uint32_t*)suboffs, plo, plen, lenhist);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(64), 0, st, lenhist, (size_t)(SUB + 1));
+    hipLaunchKernelGGL(piece_order_kernel, dim3(pgrid), dim3(256), 0, st, nbk, max_pieces, (const uint32_t*)suboffs,
+                       (const uint32_t*)plen, (const uint32_t*)lenhist, lencursor, order);
     hipLaunchKernelGGL(accumulate_kernel<A>, dim3((unsigned)((max_pieces + 63) / 64)), dim3(64), 0, st, nbk, max_pieces, aff,
-                       offs, suboffs, sorted, pieces);
+                       (const uint32_t*)suboffs, (const uint32_t*)order, (const uint32_t*)plo, (const uint32_t*)plen,
+                       sorted, pieces);
     hipLaunchKernelGGL(bucket_kernel<A>, dim3((unsigned)((nbk + 63) / 64)), dim3(64), 0, st, nbk, suboffs, pieces, buckets);
     const size_t nred = (size_t)p.nwin * p.nchunks;
     hipLaunchKernelGGL(reduce_kernel<A>, dim3((unsigned)((nred + 63) / 64)), dim3(64), 0, st, pr, buckets, partial);
