@@ -543,6 +543,41 @@ struct EdMsm {
         ge_dbl(t, a.X, a.Y, a.Z);
         ge_p1p1_to_p3(r, t);
     }
+    // Cooperative doubling for the MSM tail (see msm_ws.cuh): four lanes hold the same point; the four squarings of
+    // ge_dbl, then the four products of p1p1 -> p3, one per lane, exchanged through LDS: 2 field operations deep
+    // instead of 8.  Every thread of the block must call it (barriers inside).
+    static constexpr int COOP = 4;
+    using Field = fe;
+    __device__ static void dbl_coop(Acc& s, int r, fe* sh) {
+        fe in = s.X, t, m;
+        fe_add(t, s.X, s.Y);
+        fe_cmov(in, s.Y, r == 1);
+        fe_cmov(in, s.Z, r == 2);
+        fe_cmov(in, t, r == 3);
+        fe_sq_sel(m, in, r == 2);  // X^2 | Y^2 | 2 Z^2 | (X + Y)^2
+        sh[r] = m;
+        __syncthreads();
+        const fe XX = sh[0], YY = sh[1], ZZ2 = sh[2], t0 = sh[3];
+        __syncthreads();
+        fe Xp, Yp, Zp, Tp;  // the completed point, as in ge_dbl
+        fe_add(Yp, YY, XX);
+        fe_sub(Zp, YY, XX);
+        fe_sub(Xp, t0, Yp);
+        fe_sub(Tp, ZZ2, Zp);
+        fe a = Xp, b = Tp;  // X3 = Xp Tp | Y3 = Yp Zp | Z3 = Zp Tp | T3 = Xp Yp
+        fe_cmov(a, Yp, r == 1);
+        fe_cmov(a, Zp, r == 2);
+        fe_cmov(b, Zp, r == 1);
+        fe_cmov(b, Yp, r == 3);
+        fe_mul(m, a, b);
+        sh[r] = m;
+        __syncthreads();
+        s.X = sh[0];
+        s.Y = sh[1];
+        s.Z = sh[2];
+        s.T = sh[3];
+        __syncthreads();
+    }
     __device__ static void encode(uint8_t* out, const Acc& a) {
         uint32_t w[8];
         ge_p3_towords(w, a);

@@ -152,6 +152,35 @@ KYB_DEV void fe_sq_t(fe& h, const fe& f) {
     }
     fe_carry_store(h, t);
 }
+// h = (dbl ? 2 : 1) * f^2 with a per-lane choice (the cooperative doubling of the MSM tail squares X, Y, X + Y and
+// 2-squares Z in the four lanes of one instruction stream)
+KYB_DEV void fe_sq_sel(fe& h, const fe& f, bool dbl) {
+    fe g = f;
+    int32_t f2[10], f19[10], f38[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        f2[i] = 2 * g.v[i];
+        f19[i] = 19 * g.v[i];
+        f38[i] = 38 * g.v[i];
+    }
+    int64_t t[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        int64_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            const int j = (k - i + 10) % 10;
+            if (i > j) continue;
+            const bool wrap = (i + j) >= 10;
+            const bool both_odd = (i & 1) && (j & 1);
+            const int32_t a = i == j ? g.v[i] : f2[i];
+            const int32_t b = wrap ? (both_odd ? f38[j] : f19[j]) : (both_odd ? f2[j] : g.v[j]);
+            acc += (int64_t)a * (int64_t)b;
+        }
+        t[k] = dbl ? (acc + acc) : acc;
+    }
+    fe_carry_store(h, t);
+}
 KYB_DEV void fe_sq(fe& h, const fe& f) { fe_sq_t<false>(h, f); }
 KYB_DEV void fe_sq2(fe& h, const fe& f) { fe_sq_t<true>(h, f); }
 

@@ -46,7 +46,7 @@ inline Plan make_plan(size_t n) {
     int lg = 0;
     while ((size_t(1) << (lg + 1)) <= n) lg++;
     int c = lg - 3;
-    if (c < 2) c = 2;
+    if (c < 3) c = 3;  // at most 86 windows: final_kernel gives each window up to 4 lanes of its 512
     if (c > 16) c = 16;
     p.c = c;
     p.nwin = (256 + c) / c;  // ceil(257 / c): 256 scalar bits + the recoding carry
