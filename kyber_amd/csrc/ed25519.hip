@@ -212,28 +212,70 @@ __global__ __launch_bounds__(256) void ed25519_mul_base_kernel(
 }
 
 // --------------------------------------------------------- variable-base mul
-// Shared ladder: h = sum_i e[i] 16^i * A using an 8-entry cached table held in
-// the lane's private (scratch) memory.
-KYB_DEV void select_cached(ge_cached& c, const ge_cached tab[8], int b) {
+// Shared ladder: h = sum_i e[i] 16^i * A using an 8-entry cached table.  The table (8 x 160 B) is per-lane state
+// that fits neither registers nor LDS at a useful occupancy.  Small batches keep it in the lane's private (scratch)
+// memory; large ones in a global slab of 1280 contiguous bytes per lane: scratch is interleaved per dword across
+// the lanes of a wave, so an *indexed* entry read drags in up to 8 rows per dword (measured: 40 GB fetched per 2^20
+// launch for 11 GB of entries), while a lane-contiguous entry is ten 16-byte loads from two or three cache lines.
+struct TabScratch {
+    ge_cached tab[8];
+    KYB_DEV void put(int j, const ge_cached& c) { tab[j] = c; }
+    KYB_DEV void get(ge_cached& c, int j) const { c = tab[j]; }
+};
+struct TabGlobal {
+    int4* base;  // this lane's 8 x 10 int4
+    KYB_DEV void put(int j, const ge_cached& c) {
+        int4* q = base + j * 10;
+        const fe* f[4] = {&c.YpX, &c.YmX, &c.Z, &c.T2d};
+        int32_t w[40];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int l = 0; l < 10; l++) w[10 * k + l] = f[k]->v[l];
+#pragma unroll
+        for (int i = 0; i < 10; i++) q[i] = make_int4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+    }
+    KYB_DEV void get(ge_cached& c, int j) const {
+        const int4* q = base + j * 10;
+        int32_t w[40];
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            const int4 x = q[i];
+            w[4 * i] = x.x;
+            w[4 * i + 1] = x.y;
+            w[4 * i + 2] = x.z;
+            w[4 * i + 3] = x.w;
+        }
+        fe* f[4] = {&c.YpX, &c.YmX, &c.Z, &c.T2d};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int l = 0; l < 10; l++) f[k]->v[l] = w[10 * k + l];
+    }
+};
+template <class Tab>
+KYB_DEV void select_cached(ge_cached& c, const Tab& tab, int b) {
     const bool neg = b < 0;
     const int babs = neg ? -b : b;
-    c = tab[babs ? babs - 1 : 0];
+    tab.get(c, babs ? babs - 1 : 0);
     if (babs == 0) ge_cached_0(c);
     ge_cached_cneg(c, neg);
 }
 
-KYB_DEV void ge_scalarmult_w4(ge_p3& h, const int8_t e[65], const ge_p3& A, bool full) {
-    ge_cached tab[8];
+template <class Tab>
+KYB_DEV void ge_scalarmult_w4(ge_p3& h, const int8_t e[65], const ge_p3& A, bool full, Tab& tab) {
     ge_p1p1 t;
     ge_p3 u;
     ge_p2 r;
     ge_cached c;
-    ge_p3_to_cached(tab[0], A);
+    ge_p3_to_cached(c, A);
+    tab.put(0, c);
 #pragma unroll 1
     for (int i = 0; i < 7; i++) {
-        ge_add(t, A, tab[i]);
+        ge_add(t, A, c);
         ge_p1p1_to_p3(u, t);
-        ge_p3_to_cached(tab[i + 1], u);
+        ge_p3_to_cached(c, u);
+        tab.put(i + 1, c);
     }
     ge_p3_0(u);
     int top = 63;
@@ -258,10 +300,11 @@ KYB_DEV void ge_scalarmult_w4(ge_p3& h, const int8_t e[65], const ge_p3& A, bool
 }
 
 // points_stride = 8 words for per-element points, 0 for one shared base
+template <bool GTAB>
 __global__ __launch_bounds__(128) void ed25519_mul_kernel(
     size_t n, const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ points,
     size_t points_stride, uint32_t* __restrict__ out, uint8_t* __restrict__ status,
-    uint32_t flags, int32_t* __restrict__ proj) {
+    uint32_t flags, int32_t* __restrict__ proj, int4* __restrict__ gtab) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     const bool full = (flags & KYB_F_VARTIME) != 0;
@@ -273,7 +316,13 @@ __global__ __launch_bounds__(128) void ed25519_mul_kernel(
     int8_t e[65];
     recode16(e, a, full);
     ge_p3 h;
-    ge_scalarmult_w4(h, e, A, full);
+    if constexpr (GTAB) {
+        TabGlobal tab{gtab + idx * 80};
+        ge_scalarmult_w4(h, e, A, full, tab);
+    } else {
+        TabScratch tab;
+        ge_scalarmult_w4(h, e, A, full, tab);
+    }
     if (proj) {  // encoding deferred to ed25519_encode_kernel (status carries the decode verdict)
         store_proj(proj, idx, h);
         if (status) status[idx] = ok ? KYB_ST_OK : KYB_ST_BAD_POINT;
@@ -313,9 +362,12 @@ constexpr size_t ENC_DEFER_MIN = 4096;
 // Grow-only per-device buffer for the parked (X, Y, Z) triples (+ a status array when the caller passes none).
 // Like the MSM workspace it is shared by all Ed25519 calls on the device: calls on one stream are ordered, and
 // concurrent streams on the same device must not interleave Ed25519 batches larger than ENC_DEFER_MIN.
-static int ed_proj_workspace(DeviceCtx* ctx, size_t n, bool need_status, int32_t** proj, uint8_t** status) {
+static int ed_proj_workspace(DeviceCtx* ctx, size_t n, bool need_status, int32_t** proj, uint8_t** status,
+                             int4** gtab = nullptr) {
     std::lock_guard<std::mutex> lk(ctx->mu);
-    const size_t want = n * 30 * sizeof(int32_t) + (need_status ? n : 0) + 256;
+    // [ window tables: n x 1280 B (variable-base only) | (X, Y, Z): n x 120 B | status: n ]
+    const size_t tab_bytes = gtab ? n * 1280 : 0;
+    const size_t want = tab_bytes + n * 30 * sizeof(int32_t) + (need_status ? n : 0) + 256;
     if (want > ctx->ed_proj_bytes) {
         if (ctx->ed_proj) {
             KYB_HIP_CHECK(hipDeviceSynchronize());
@@ -330,8 +382,9 @@ static int ed_proj_workspace(DeviceCtx* ctx, size_t n, bool need_status, int32_t
         }
         ctx->ed_proj_bytes = cap;
     }
-    *proj = (int32_t*)ctx->ed_proj;
-    if (status) *status = (uint8_t*)ctx->ed_proj + n * 30 * sizeof(int32_t);
+    if (gtab) *gtab = (int4*)ctx->ed_proj;
+    *proj = (int32_t*)((uint8_t*)ctx->ed_proj + tab_bytes);
+    if (status) *status = (uint8_t*)ctx->ed_proj + tab_bytes + n * 30 * sizeof(int32_t);
     return KYB_OK;
 }
 
@@ -363,17 +416,22 @@ static int launch_mul(size_t n, const void* d_scalars, const void* d_points, siz
     const int block = 128;
     size_t grid = (n + block - 1) / block;
     int32_t* proj = nullptr;
+    int4* gtab = nullptr;
     uint8_t* stat = (uint8_t*)d_status;
     if (n >= ENC_DEFER_MIN) {
         DeviceCtx* ctx;
         int rc = get_ctx(&ctx);
         if (rc) return rc;
-        rc = ed_proj_workspace(ctx, n, stat == nullptr, &proj, stat ? nullptr : &stat);
+        rc = ed_proj_workspace(ctx, n, stat == nullptr, &proj, stat ? nullptr : &stat, &gtab);
         if (rc) return rc;
+        hipLaunchKernelGGL(ed25519_mul_kernel<true>, dim3((unsigned)grid), dim3(block), 0, st, n,
+                           (const uint32_t*)d_scalars, (const uint32_t*)d_points, stride, (uint32_t*)d_out, stat, flags,
+                           proj, gtab);
+    } else {
+        hipLaunchKernelGGL(ed25519_mul_kernel<false>, dim3((unsigned)grid), dim3(block), 0, st, n,
+                           (const uint32_t*)d_scalars, (const uint32_t*)d_points, stride, (uint32_t*)d_out, stat, flags,
+                           proj, gtab);
     }
-    hipLaunchKernelGGL(ed25519_mul_kernel, dim3((unsigned)grid), dim3(block), 0, st, n,
-                       (const uint32_t*)d_scalars, (const uint32_t*)d_points, stride, (uint32_t*)d_out, stat, flags,
-                       proj);
     if (proj) {
         const size_t lanes = (n + ENC_CHUNK - 1) / ENC_CHUNK;
         hipLaunchKernelGGL(ed25519_encode_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, n, proj,
