@@ -42,7 +42,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # per-element inversion (254 S + 11 M) by 3 M + 1/16 of an inversion (Montgomery's trick over 16 elements).
 _INV_SAVED = (254 * 55 + 11 * 100) - (3 * 100 + (254 * 55 + 11 * 100) / 16)
 IMADS_VAR = int(1366 * 100 + 1517 * 55 - _INV_SAVED)
-IMADS_FIX = int(475 * 100 + 270 * 55 - _INV_SAVED)
+# fixed-base: 32 mixed additions from the radix-256 table (3 M + 4 M for the completed -> extended conversion each)
+# + the deferred encoding's share (3 M + 2 M + 1/16 inversion)
+IMADS_FIX = int(32 * 7 * 100 + 5 * 100 + (254 * 55 + 11 * 100) / 16)
 
 
 def shake(label: bytes, nbytes: int) -> np.ndarray:

@@ -110,7 +110,7 @@ int kyb_ed25519_hash_dev(size_t n, const void *d_msgs, size_t msg_len, const uin
 
 /* Introspection used by the tests: copy the device-built fixed-base table
  * (33 x 8 entries of (y+x, y-x, 2dxy), 10 int32 limbs each) to the host. */
-int kyb_ed25519_debug_base_table(int32_t *out /* 33*8*30 */);
+int kyb_ed25519_debug_base_table(int32_t *out /* 33*136*32: (position, |digit|-1, 30 limbs + 2 pad) */);
 
 /* --------------------------------------------------------------- BLS12-381
  * The three reference suites pairing/bls12381/{kilic,circl,gnark} are adapters over external

@@ -15,8 +15,14 @@
 
 namespace kyb {
 
-constexpr int ED_TAB_POS = 33;  // 32 byte positions + 2^256*B for the 65th digit
-constexpr int ED_TAB_WORDS = ED_TAB_POS * 8 * 30;
+// Fixed-base table: entry (pos, j) = (j + 1) * 256^pos * B in affine (y+x, y-x, 2dxy) form, j < 136: a signed
+// radix-256 digit is d0 + 16 d1 of two signed radix-16 digits in [-8, 8], so |digit| <= 136.  One entry is one
+// 128-byte line (30 limbs + 2 pad words); the 574 KB table is read through L2 -- it does not fit LDS, but it
+// halves the additions of the reference's 32 x 8 table (ge.go:373-417: 64 additions + 4 doublings) to 32.
+constexpr int ED_TAB_POS = 33;  // 32 byte positions + 2^256*B for the 65th radix-16 digit
+constexpr int ED_TAB_ENT = 136;
+constexpr int ED_TAB_STRIDE = 32;
+constexpr int ED_TAB_WORDS = ED_TAB_POS * ED_TAB_ENT * ED_TAB_STRIDE;
 
 KYB_DEV void load_words8(uint32_t w[8], const uint32_t* __restrict__ p) {
     const uint4 a = reinterpret_cast<const uint4*>(p)[0];
@@ -34,8 +40,8 @@ KYB_DEV void store_words8(uint32_t* __restrict__ p, const uint32_t w[8]) {
 // stores its affine (y+x, y-x, 2dxy).  Runs once per device.
 __global__ void ed25519_build_base_table_kernel(int32_t* __restrict__ tab) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ED_TAB_POS * 8) return;
-    const int pos = t >> 3, j = t & 7;
+    if (t >= ED_TAB_POS * ED_TAB_ENT) return;
+    const int pos = t / ED_TAB_ENT, j = t - pos * ED_TAB_ENT;
     ge_p3 B;
     B.X = fe_bx(); B.Y = fe_by(); fe_1(B.Z); B.T = fe_bt();
     ge_cached cB;
@@ -43,9 +49,9 @@ __global__ void ed25519_build_base_table_kernel(int32_t* __restrict__ tab) {
     ge_p3 acc;
     ge_p3_0(acc);
     ge_p1p1 r;
-    // multiplier = (j+1) << (8*pos): 4 significant bits then 8*pos doublings
+    // multiplier = (j+1) << (8*pos): 8 significant bits then 8*pos doublings
 #pragma unroll 1
-    for (int bit = 3; bit >= 0; bit--) {
+    for (int bit = 7; bit >= 0; bit--) {
         ge_dbl(r, acc.X, acc.Y, acc.Z);
         ge_p1p1_to_p3(acc, r);
         if (((j + 1) >> bit) & 1) {
@@ -70,13 +76,14 @@ __global__ void ed25519_build_base_table_kernel(int32_t* __restrict__ tab) {
     fe_1(z);
     fe_mul(ypx, ypx, z);
     fe_mul(ymx, ymx, z);
-    int32_t* o = tab + (size_t)t * 30;
+    int32_t* o = tab + (size_t)t * ED_TAB_STRIDE;
 #pragma unroll
     for (int l = 0; l < 10; l++) {
         o[l] = ypx.v[l];
         o[10 + l] = ymx.v[l];
         o[20 + l] = xy2d.v[l];
     }
+    o[30] = o[31] = 0;
 }
 
 // ------------------------------------------------------ deferred encoding (batched inversion)
@@ -141,18 +148,25 @@ __global__ __launch_bounds__(64) void ed25519_encode_kernel(size_t n, const int3
 }
 
 // ------------------------------------------------------------ fixed-base mul
-// LDS holds the whole 33x8 table (31,680 B); every lane gathers its own entry.
-// Entry stride is 30 dwords, so the 8 possible |digit| values of one position
-// land on 8 different banks and equal digits broadcast.
-KYB_DEV void select_precomp_lds(ge_precomp& t, const int32_t* s_tab, int pos, int b) {
+// Every lane gathers its own 128-byte entry (eight 16-byte loads from one line, served by L2).
+KYB_DEV void select_precomp_tab(ge_precomp& t, const int32_t* __restrict__ tab, int pos, int b) {
     const bool neg = b < 0;
     const int babs = neg ? -b : b;
-    const int32_t* e = s_tab + (pos * 8 + (babs ? babs - 1 : 0)) * 30;
+    const int4* e = reinterpret_cast<const int4*>(tab + (size_t)(pos * ED_TAB_ENT + (babs ? babs - 1 : 0)) * ED_TAB_STRIDE);
+    int32_t w[32];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int4 x = e[i];
+        w[4 * i] = x.x;
+        w[4 * i + 1] = x.y;
+        w[4 * i + 2] = x.z;
+        w[4 * i + 3] = x.w;
+    }
 #pragma unroll
     for (int l = 0; l < 10; l++) {
-        t.ypx.v[l] = e[l];
-        t.ymx.v[l] = e[10 + l];
-        t.xy2d.v[l] = e[20 + l];
+        t.ypx.v[l] = w[l];
+        t.ymx.v[l] = w[10 + l];
+        t.xy2d.v[l] = w[20 + l];
     }
     if (babs == 0) {  // identity: (1, 1, 0)
         fe_1(t.ypx);
@@ -162,12 +176,12 @@ KYB_DEV void select_precomp_lds(ge_precomp& t, const int32_t* s_tab, int pos, in
     ge_precomp_cneg(t, neg);
 }
 
+// h = sum_k D_k 256^k B with D_k = e[2k] + 16 e[2k+1] built from the reference's signed radix-16 digits, so the
+// value -- including the reference's behaviour for scalars >= 2^255 on the constant-time path (recode16) -- and
+// therefore the encoding is exactly that of geScalarMultBase.
 __global__ __launch_bounds__(256) void ed25519_mul_base_kernel(
     size_t n, const uint32_t* __restrict__ scalars, uint32_t* __restrict__ out,
     const int32_t* __restrict__ tab, uint32_t flags, int32_t* __restrict__ proj) {
-    __shared__ int32_t s_tab[ED_TAB_WORDS];
-    for (int i = threadIdx.x; i < ED_TAB_WORDS; i += blockDim.x) s_tab[i] = tab[i];
-    __syncthreads();
     const bool full = (flags & KYB_F_VARTIME) != 0;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
          idx += (size_t)gridDim.x * blockDim.x) {
@@ -179,25 +193,11 @@ __global__ __launch_bounds__(256) void ed25519_mul_base_kernel(
         ge_p3_0(h);
         ge_precomp t;
         ge_p1p1 r;
+        const int npos = full ? 33 : 32;  // uniform across the grid
 #pragma unroll 1
-        for (int i = 1; i < 64; i += 2) {
-            select_precomp_lds(t, s_tab, i >> 1, e[i]);
-            ge_madd(r, h, t);
-            ge_p1p1_to_p3(h, r);
-        }
-        ge_p2 s;
-        ge_dbl(r, h.X, h.Y, h.Z);
-        ge_p1p1_to_p2(s, r);
-        ge_dbl(r, s.X, s.Y, s.Z);
-        ge_p1p1_to_p2(s, r);
-        ge_dbl(r, s.X, s.Y, s.Z);
-        ge_p1p1_to_p2(s, r);
-        ge_dbl(r, s.X, s.Y, s.Z);
-        ge_p1p1_to_p3(h, r);
-        const int last = full ? 64 : 62;
-#pragma unroll 1
-        for (int i = 0; i <= last; i += 2) {
-            select_precomp_lds(t, s_tab, i >> 1, e[i]);
+        for (int k = 0; k < npos; k++) {
+            const int d = k < 32 ? (int)e[2 * k] + 16 * (int)e[2 * k + 1] : (int)e[64];
+            select_precomp_tab(t, tab, k, d);
             ge_madd(r, h, t);
             ge_p1p1_to_p3(h, r);
         }
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(128) void ed25519_mul_kernel(
 // ---------------------------------------------------------------- host side
 int ed25519_build_tables(DeviceCtx* ctx) {
     KYB_HIP_CHECK(hipMalloc(&ctx->ed_base_tab, ED_TAB_WORDS * sizeof(int32_t)));
-    hipLaunchKernelGGL(ed25519_build_base_table_kernel, dim3((ED_TAB_POS * 8 + 63) / 64), dim3(64), 0,
+    hipLaunchKernelGGL(ed25519_build_base_table_kernel, dim3((ED_TAB_POS * ED_TAB_ENT + 63) / 64), dim3(64), 0,
                        nullptr, ctx->ed_base_tab);
     KYB_HIP_CHECK(hipGetLastError());
     KYB_HIP_CHECK(hipStreamSynchronize(nullptr));
@@ -393,7 +393,7 @@ static int launch_mul_base(DeviceCtx* ctx, size_t n, const void* d_scalars, void
     if (n == 0) return KYB_OK;
     const int block = 256;
     size_t want = (n + block - 1) / block;
-    size_t cap = (size_t)ctx->num_cu * 4;  // table staging is per block: keep blocks long-lived
+    size_t cap = (size_t)ctx->num_cu * 8;  // grid-stride: two resident workgroups per SIMD row
     int grid = (int)(want < cap ? want : cap);
     int32_t* proj = nullptr;
     if (n >= ENC_DEFER_MIN) {
