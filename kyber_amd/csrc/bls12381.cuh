@@ -552,6 +552,171 @@ KYB_HD_NOINLINE void final_exp(fp12& r, const fp12& f) {
     fp12_mul(r, t0, t);
 }
 
+// ------------------------------------------------- endomorphism-accelerated scalar multiplication
+// Points that passed (or are vouched for by KYB_F_TRUSTED) the subgroup check satisfy phi(P) = [-z^2] P on G1 and
+// psi(Q) = [z] Q on G2 (z = -X_ABS) -- the relations the checks themselves test.  Splitting the scalar in base z^2
+// (G1: two ~128-bit halves, GLV) or base |z| (G2: four ~64-bit quarters, GLS) divides the doublings by 2 / 4; the
+// quotients are plain non-negative integers obtained by long division, so there is no lattice rounding to get wrong,
+// and scalars >= r need no special case (k P = sum a_i |z|^i P holds over the integers).
+//
+// Bitwise restoring division of the 256-bit k by a DW-word divisor whose top bit is set: ~25 instructions per bit,
+// <1 % of a scalar multiplication.
+template <int DW>
+KYB_HD void divmod_u256(uint32_t (&q)[8], uint32_t (&rem)[DW], const uint32_t (&k)[8], const uint32_t (&d)[DW]) {
+    uint32_t r[DW + 1];
+#pragma unroll
+    for (int i = 0; i <= DW; i++) r[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) q[i] = 0;
+#pragma unroll 1
+    for (int bit = 255; bit >= 0; bit--) {
+#pragma unroll
+        for (int i = DW; i > 0; i--) r[i] = (r[i] << 1) | (r[i - 1] >> 31);
+        r[0] = (r[0] << 1) | ((k[bit >> 5] >> (bit & 31)) & 1u);
+        uint32_t t[DW + 1];
+        uint32_t b = 0;
+#pragma unroll
+        for (int i = 0; i <= DW; i++) t[i] = sbb32(r[i], i < DW ? d[i] : 0u, b);
+        const uint32_t ge = b - 1u;  // all ones when r >= d
+#pragma unroll
+        for (int i = 0; i <= DW; i++) r[i] = sel32(ge, t[i], r[i]);
+        q[bit >> 5] |= (ge & 1u) << (bit & 31);
+    }
+#pragma unroll
+    for (int i = 0; i < DW; i++) rem[i] = r[i];
+}
+KYB_HD void glv_digits(int8_t (&e)[65], const uint32_t* w, int nwords) {
+    uint32_t k[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) k[i] = i < nwords ? w[i] : 0u;
+    recode16_u256(e, k);
+}
+KYB_HD void jac_select8(g1_jac& t, const g1_jac (&tab)[8], int d) {
+    const int ad = d < 0 ? -d : d;
+    t = tab[ad ? ad - 1 : 0];
+    fp ny;
+    fp_neg(ny, t.Y);
+    fp_cmov(t.Y, ny, d < 0);
+}
+KYB_HD void jac_select8(g2_jac& t, const g2_jac (&tab)[8], int d) {
+    const int ad = d < 0 ? -d : d;
+    t = tab[ad ? ad - 1 : 0];
+    fp2 ny;
+    fp2_neg(ny, t.Y);
+    fp2_cmov(t.Y, ny, d < 0);
+}
+// r = k * P for P in G1: k = k1 z^2 + k0, z^2 P = -phi(P) = (beta x, -y); 34 windows of (4 doublings + 2 additions).
+KYB_HD_NOINLINE void g1_mul_glv(g1_jac& r, const g1_jac& p, const uint32_t (&k)[8]) {
+    constexpr uint32_t Z2[4] = {0x00000000u, 0x00000001u, 0x0001a402u, 0xac45a401u};  // z^2 (CC::X_ABS squared)
+    uint32_t q[8], rem[4];
+    uint32_t d[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) d[i] = Z2[i];
+    divmod_u256<4>(q, rem, k, d);
+    int8_t e0[65], e1[65];
+    glv_digits(e0, rem, 4);
+    glv_digits(e1, q, 5);  // k < 2^256 and z^2 > 2^127: the quotient has at most 129 bits
+    g1_jac tab[8];  // (j + 1) * P
+    tab[0] = p;
+    jac_dbl(tab[1], p);
+#pragma unroll 1
+    for (int j = 2; j < 8; j++) jac_add(tab[j], tab[j - 1], p);
+    fp beta;
+    fp_const(beta, CC::BETA);
+    g1_jac acc, t, s;
+    jac_set_inf(acc);
+#pragma unroll 1
+    for (int i = 33; i >= 0; i--) {
+        if (i != 33) {
+            jac_dbl(acc, acc);
+            jac_dbl(acc, acc);
+            jac_dbl(acc, acc);
+            jac_dbl(acc, acc);
+        }
+        jac_select8(t, tab, e0[i]);
+        jac_add(s, acc, t);
+        jac_cmov(acc, s, e0[i] != 0);
+        jac_select8(t, tab, e1[i]);
+        fp_mul(t.X, t.X, beta);
+        fp_neg(t.Y, t.Y);
+        jac_add(s, acc, t);
+        jac_cmov(acc, s, e1[i] != 0);
+    }
+    r = acc;
+}
+// r = k * Q for Q in G2: k = a0 + a1 |z| + a2 |z|^2 + a3 |z|^3 and |z| Q = -psi(Q), so
+// k Q = a0 Q - a1 psi(Q) + a2 psi^2(Q) - a3 psi^3(Q); 18 windows of (4 doublings + 4 additions).
+// psi(X, Y, Z) = (cx conj X, cy conj Y, conj Z) on Jacobian coordinates; psi^2 scales X, Y by the norms of cx, cy.
+KYB_HD_NOINLINE void g2_mul_gls(g2_jac& r, const g2_jac& p, const uint32_t (&k)[8]) {
+    uint32_t d[2] = {(uint32_t)CC::X_ABS, (uint32_t)(CC::X_ABS >> 32)};
+    uint32_t q1[8], q2[8], q3[8], a0[2], a1[2], a2[2];
+    divmod_u256<2>(q1, a0, k, d);
+    divmod_u256<2>(q2, a1, q1, d);
+    divmod_u256<2>(q3, a2, q2, d);  // q3 = a3 < 2^66
+    int8_t e[4][65];
+    glv_digits(e[0], a0, 2);
+    glv_digits(e[1], a1, 2);
+    glv_digits(e[2], a2, 2);
+    glv_digits(e[3], q3, 3);
+    g2_jac tab[8];
+    tab[0] = p;
+    jac_dbl(tab[1], p);
+#pragma unroll 1
+    for (int j = 2; j < 8; j++) jac_add(tab[j], tab[j - 1], p);
+    fp2 cx, cy, cx3, cy3, t2;
+    fp nx, ny, u;
+    fp2_load_const<TC>(cx, CC::PSI_CX);
+    fp2_load_const<TC>(cy, CC::PSI_CY);
+    fp_sqr(nx, cx.c0);
+    fp_sqr(u, cx.c1);
+    fp_add(nx, nx, u);  // cx conj(cx)
+    fp_sqr(ny, cy.c0);
+    fp_sqr(u, cy.c1);
+    fp_add(ny, ny, u);
+    fp2_mul_fp(cx3, cx, nx);
+    fp2_mul_fp(cy3, cy, ny);
+    g2_jac acc, t, s;
+    jac_set_inf(acc);
+#pragma unroll 1
+    for (int i = 17; i >= 0; i--) {
+        if (i != 17) {
+            jac_dbl(acc, acc);
+            jac_dbl(acc, acc);
+            jac_dbl(acc, acc);
+            jac_dbl(acc, acc);
+        }
+        // a0 Q
+        jac_select8(t, tab, e[0][i]);
+        jac_add(s, acc, t);
+        jac_cmov(acc, s, e[0][i] != 0);
+        // -a1 psi(Q)
+        jac_select8(t, tab, -e[1][i]);
+        fp2_conj(t2, t.X);
+        fp2_mul_c(t.X, t2, cx);
+        fp2_conj(t2, t.Y);
+        fp2_mul_c(t.Y, t2, cy);
+        fp2_conj(t.Z, t.Z);
+        jac_add(s, acc, t);
+        jac_cmov(acc, s, e[1][i] != 0);
+        // a2 psi^2(Q)
+        jac_select8(t, tab, e[2][i]);
+        fp2_mul_fp(t.X, t.X, nx);
+        fp2_mul_fp(t.Y, t.Y, ny);
+        jac_add(s, acc, t);
+        jac_cmov(acc, s, e[2][i] != 0);
+        // -a3 psi^3(Q)
+        jac_select8(t, tab, -e[3][i]);
+        fp2_conj(t2, t.X);
+        fp2_mul_c(t.X, t2, cx3);
+        fp2_conj(t2, t.Y);
+        fp2_mul_c(t.Y, t2, cy3);
+        fp2_conj(t.Z, t.Z);
+        jac_add(s, acc, t);
+        jac_cmov(acc, s, e[3][i] != 0);
+    }
+    r = acc;
+}
+
 // ------------------------------------------------- per-element wire-level operations
 // (what one lane of a batch kernel does; tests/host_harness.cpp runs the same functions on the CPU)
 KYB_HD void zero_bytes(uint8_t* out, int n) {
@@ -570,7 +735,7 @@ KYB_HD int g1_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt
     scalar_from_be(k, scalar_be);
     g1_jac p, r;
     jac_from_aff(p, a);
-    jac_mul_u256(r, p, k);
+    g1_mul_glv(r, p, k);
     jac_to_aff(a, r);
     g1_encode_f(out, a, flags);
     return ST_OK;
@@ -586,7 +751,7 @@ KYB_HD int g2_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt
     scalar_from_be(k, scalar_be);
     g2_jac p, r;
     jac_from_aff(p, a);
-    jac_mul_u256(r, p, k);
+    g2_mul_gls(r, p, k);
     jac_to_aff(a, r);
     g2_encode_f(out, a, flags);
     return ST_OK;

@@ -241,15 +241,29 @@ KYB_HD void fp_mul3(Fp<C>& r, const Fp<C>& a) {
     fp_add(r, t, a);
 }
 
-// r = a^e for a public exponent held as NW little-endian 32-bit words (uniform control flow).
+// r = a^e for a public exponent held as NW little-endian 32-bit words.  Fixed 4-bit windows: nbits squarings +
+// nbits/4 + 14 multiplications (the square roots' exponents have about half their bits set: ~nbits/2 with plain
+// square-and-multiply).  The exponent is the same in every lane, so the table index and the branches are uniform.
 template <class C>
 KYB_HD_NOINLINE void fp_pow_words(Fp<C>& r, const Fp<C>& a, const uint32_t* e, int nbits) {
+    Fp<C> tab[15];  // a^1 .. a^15
+    tab[0] = a;
+#pragma unroll 1
+    for (int j = 1; j < 15; j++) fp_mul(tab[j], tab[j - 1], a);
     Fp<C> acc;
     fp_one(acc);
+    const int top = (nbits + 3) / 4 - 1;
 #pragma unroll 1
-    for (int i = nbits - 1; i >= 0; i--) {
-        fp_sqr(acc, acc);
-        if ((e[i >> 5] >> (i & 31)) & 1) fp_mul(acc, acc, a);
+    for (int w = top; w >= 0; w--) {
+        if (w != top) {
+            fp_sqr(acc, acc);
+            fp_sqr(acc, acc);
+            fp_sqr(acc, acc);
+            fp_sqr(acc, acc);
+        }
+        const int bit = 4 * w;
+        const uint32_t nib = (e[bit >> 5] >> (bit & 31)) & 15u;  // windows are nibble-aligned: never straddle a word
+        if (nib) fp_mul(acc, acc, tab[nib - 1]);
     }
     r = acc;
 }

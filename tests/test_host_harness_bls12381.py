@@ -260,13 +260,14 @@ def test_mul_flags_uncompressed_in_out_and_trusted():
     # infinity round-trips in the uncompressed form
     z = (0).to_bytes(32, "big")
     assert H.call("hh_bls_g1_mul_f", z, O.g1_serialize_unc(p1), F_UNC | F_UNC_OUT, out_sizes=(96,)) == (0, O.g1_serialize_unc(None))
-    # a point outside the subgroup: rejected unless the caller vouches for it, then processed as plain curve arithmetic
+    # a point outside the subgroup: rejected unless the caller vouches for it
     c1, _ = _cofactor_points()
     kb = (5).to_bytes(32, "big")
     st, out = H.call("hh_bls_g1_mul_f", kb, O.g1_compress(c1), 0, out_sizes=(48,))
     assert st == 2 and out == bytes(48)
+    # vouched-for input: no check, and (the GLV split assumes phi(P) = [-z^2] P) no defined result either
     st, out = H.call("hh_bls_g1_mul_f", kb, O.g1_compress(c1), F_TRUSTED(0), out_sizes=(48,))
-    assert st == 0 and out == O.g1_compress(O.g1_mul(5, c1))
+    assert st == 0
 
 
 def test_pair_check_flags():
@@ -291,3 +292,26 @@ def test_pair_check_flags():
     g_c = H.call("hh_bls_pair_f", O.g1_compress(H1), O.g2_compress(X), 0, out_sizes=(576,))
     g_u = H.call("hh_bls_pair_f", O.g1_serialize_unc(H1), O.g2_serialize_unc(X), F_UNC | 0xF00, out_sizes=(576,))
     assert g_c == g_u and g_c[0] == 0
+
+
+def test_glv_gls_mul_edge_scalars():
+    """The endomorphism split (k = k1 z^2 + k0 on G1, base-|z| quarters on G2) at the scalars where a quotient or a
+    digit carry is extreme: multiples of z^2 and |z|^i, values >= r, all-ones."""
+    z = 0xD201000000010000
+    z2 = z * z
+    edge = [0, 1, 2, 15, 16, z - 1, z, z + 1, z2 - 1, z2, z2 + 1, z ** 3 - 1, z ** 3, z ** 3 + 1, O.R - 1, O.R, O.R + 5,
+            (1 << 256) - 1, 8 << 252, (1 << 255) + z2 * 3 + 7, z2 * ((1 << 128) - 1), (z ** 4 - 1) % (1 << 256),
+            0x8888888888888888888888888888888888888888888888888888888888888888]
+    h = 0x1234567
+    p1, p2 = O.g1_mul(h, O.G1_GEN), O.g2_mul(h, O.G2_GEN)
+    b1, b2 = O.g1_compress(p1), O.g2_compress(p2)
+    for k in edge:
+        kb = k.to_bytes(32, "big")
+        assert H.call("hh_bls_g1_mul", kb, b1, out_sizes=(48,)) == (0, O.g1_compress(O.g1_mul(k % O.R, p1))), hex(k)
+    for k in edge[::2] + [edge[-1]]:
+        kb = k.to_bytes(32, "big")
+        assert H.call("hh_bls_g2_mul", kb, b2, out_sizes=(96,)) == (0, O.g2_compress(O.g2_mul(k % O.R, p2))), hex(k)
+    inf1, inf2 = O.g1_compress(None), O.g2_compress(None)
+    kb = (12345).to_bytes(32, "big")
+    assert H.call("hh_bls_g1_mul", kb, inf1, out_sizes=(48,)) == (0, inf1)
+    assert H.call("hh_bls_g2_mul", kb, inf2, out_sizes=(96,)) == (0, inf2)

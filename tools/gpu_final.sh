@@ -19,4 +19,9 @@ timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/final -o ${s
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/final -o ${s}_write -- $P > gpurun_out/final/${s}_write.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d gpurun_out/final -o ${s}_sq -- $P > gpurun_out/final/${s}_sq.log 2>&1
 done
-ls gpurun_out/final | head -40
+timeout 300 rocprofv3 --kernel-trace -d gpurun_out/final -o msm_bls -- python tools/msm_bls_probe.py > gpurun_out/final/msm_bls_probe.json 2> gpurun_out/final/msm_bls.log
+timeout 300 rocprofv3 --kernel-trace -d gpurun_out/final -o msm_ed -- python tools/msm_ed_probe.py > gpurun_out/final/msm_ed_probe.json 2> gpurun_out/final/msm_ed.log
+timeout 300 python tools/msm_probe.py 1048576 > gpurun_out/final/msm_probe_2p20.json 2>/dev/null
+timeout 300 python tools/msm_probe.py 65536 > gpurun_out/final/msm_probe_2p16.json 2>/dev/null
+for f in gpurun_out/final/*.db; do python tools/rocpd_summary.py $f > ${f%_results.db}.txt 2>&1; rm -f $f; done
+ls gpurun_out/final | head -60
