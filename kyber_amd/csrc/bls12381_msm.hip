@@ -19,7 +19,83 @@ struct BlsG2Codec {
     }
     __device__ static void encode(uint8_t* out, const bls::g2_aff& a) { bls::g2_encode(out, a); }
 };
-using BlsG1Msm = msm::Weierstrass<bls::fp, BlsG1Codec>;
+// G1 with a balanced GLV split: every (k, P) becomes (|k0|, +-P) and (|k1|, +-z^2 P), z^2 P = (beta x, -y), with
+// k = k1 z^2 + k0 (mod r) and |k0|, |k1| <= z^2 / 2 + 2 < 2^126.5.  Start from the long division k = q z^2 + rem, move
+// rem into (-z^2/2, z^2/2] (q += 1), then fold q with z^4 = z^2 - 1 (mod r): (q, rem) -> (q - z^2 + 1, rem - 1), at
+// most twice for k < 2^256.  Balanced halves matter: their top 16-bit window stays below 2^15, so the signed recoding
+// never carries into a ninth window -- which would put a quarter of all points into one bucket.  8 windows of 16 bits
+// replace 17 and the serial doubling chain of the tail shrinks from 256 to 112.  Valid because every accepted P is in
+// G1 (checked, or vouched for by KYB_F_TRUSTED).
+struct BlsG1Msm : msm::Weierstrass<bls::fp, BlsG1Codec> {
+    using Base = msm::Weierstrass<bls::fp, BlsG1Codec>;
+    static constexpr int SPLIT = 2, SPLIT_BITS = 127;
+    // 160-bit two's-complement helpers (five words)
+    __device__ static void add5(uint32_t (&x)[5], const uint32_t (&y)[5]) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) x[i] = adc32(x[i], y[i], c);
+    }
+    __device__ static void sub5(uint32_t (&x)[5], const uint32_t (&y)[5]) {
+        uint32_t b = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) x[i] = sbb32(x[i], y[i], b);
+    }
+    __device__ static bool gt5(const uint32_t (&x)[5], const uint32_t (&y)[5]) {  // signed x > y
+        uint32_t t[5];
+        uint32_t b = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) t[i] = sbb32(y[i], x[i], b);  // y - x < 0 ?
+        return (t[4] >> 31) != 0;  // |x|, |y| < 2^130: no overflow
+    }
+    __device__ static bool abs5(uint32_t (&x)[5]) {  // x = |x|, returns the sign
+        const bool neg = (x[4] >> 31) != 0;
+        uint32_t z[5] = {0, 0, 0, 0, 0};
+        sub5(z, x);
+#pragma unroll
+        for (int i = 0; i < 5; i++) x[i] = neg ? z[i] : x[i];
+        return neg;
+    }
+    __device__ static int decode_split(Aff (&a)[2], uint32_t (&k)[2][8], const uint8_t* pt, const uint8_t* scalar,
+                                       uint32_t flags) {
+        const int st = Base::decode(a[0], pt, flags);
+        uint32_t kk[8], q8[8], rem[4];
+        Base::scalar_words(kk, scalar);
+        uint32_t d[4] = {0x00000000u, 0x00000001u, 0x0001a402u, 0xac45a401u};  // z^2
+        bls::divmod_u256<4>(q8, rem, kk, d);
+        const uint32_t Z2[5] = {d[0], d[1], d[2], d[3], 0u};
+        const uint32_t HALF[5] = {0x80000000u, 0x00000000u, 0x8000d201u, 0x5622d200u, 0u};  // z^2 / 2
+        const uint32_t ONE[5] = {1u, 0u, 0u, 0u, 0u};
+        uint32_t q[5] = {q8[0], q8[1], q8[2], q8[3], q8[4]};  // q < 2^129
+        uint32_t r[5] = {rem[0], rem[1], rem[2], rem[3], 0u};
+        if (gt5(r, HALF)) {
+            sub5(r, Z2);
+            add5(q, ONE);
+        }
+#pragma unroll 1
+        for (int it = 0; it < 3; it++) {
+            if (gt5(q, HALF)) {  // q z^2 = (q - z^2) z^2 + z^4 and z^4 = z^2 - 1 (mod r)
+                sub5(q, Z2);
+                add5(q, ONE);
+                sub5(r, ONE);
+            }
+        }
+        const bool n0 = abs5(r), n1 = abs5(q);
+        bls::fp beta, ny;
+        bls::fp_const(beta, bls::CC::BETA);
+        fp_mul(a[1].x, a[0].x, beta);
+        a[1].y = a[0].y;
+        a[1].inf = a[0].inf;
+        fp_neg(ny, a[0].y);
+        fp_cmov(a[1].y, ny, !n1);  // z^2 P = (beta x, -y); a negative k1 flips it back
+        fp_cmov(a[0].y, ny, n0);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            k[0][i] = i < 5 ? r[i] : 0u;
+            k[1][i] = i < 5 ? q[i] : 0u;
+        }
+        return st;
+    }
+};
 using BlsG2Msm = msm::Weierstrass<bls::fp2, BlsG2Codec>;
 }  // namespace kyb
 

@@ -39,7 +39,7 @@ struct Plan {
     uint32_t flags;  // the call's KYB_F_* flags (input format / trusted operands), read by the adapter's decode
 };
 
-inline Plan make_plan(size_t n) {
+inline Plan make_plan(size_t n, int scalar_bits = 256, int cmax = 16) {
     Plan p;
     p.n = n;
     p.flags = 0;
@@ -47,9 +47,9 @@ inline Plan make_plan(size_t n) {
     while ((size_t(1) << (lg + 1)) <= n) lg++;
     int c = lg - 3;
     if (c < 3) c = 3;  // at most 86 windows: final_kernel gives each window up to 4 lanes of its 512
-    if (c > 16) c = 16;
+    if (c > cmax) c = cmax;
     p.c = c;
-    p.nwin = (256 + c) / c;  // ceil(257 / c): 256 scalar bits + the recoding carry
+    p.nwin = (scalar_bits + c) / c;  // ceil((bits + 1) / c): the scalar bits + the recoding carry
     p.nb = 1 << (c - 1);
     // buckets per reduce lane: the running-sum chain of a lane is latency-bound (2 dependent additions per bucket, and
     // a lone wave already saturates its SIMD's issue rate), so take the shortest chains that still leave every wave
@@ -84,27 +84,50 @@ __device__ __forceinline__ void recode(int32_t (&dig)[MAXWIN], const uint32_t (&
     }
 }
 
+// Split<A>: an adapter may split every input (k, P) into SPLIT pairs (k_h, P_h) with shorter scalars (SPLIT_BITS bits)
+// through an endomorphism (BLS12-381 G1: k = k1 z^2 + k0, z^2 P = (beta x, -y)).  The pipeline then runs over
+// SPLIT * n points with proportionally fewer windows -- and, what matters, a proportionally shorter doubling chain in
+// its serial tail.
+template <class A, class = void>
+struct Split {
+    static constexpr int value = 1, bits = 256, cmax = 16;
+};
 template <class A>
-__global__ __launch_bounds__(64) void decode_kernel(Plan p, const uint8_t* __restrict__ scalars,
+struct Split<A, decltype((void)A::SPLIT)> {
+    static constexpr int value = A::SPLIT, bits = A::SPLIT_BITS, cmax = 16;
+};
+
+template <class A>
+__global__ __launch_bounds__(64) void decode_kernel(Plan p, size_t n_in, const uint8_t* __restrict__ scalars,
                                                     const uint8_t* __restrict__ points,
                                                     typename A::Aff* __restrict__ aff, int32_t* __restrict__ digits,
                                                     uint32_t* __restrict__ hist, uint8_t* __restrict__ status,
                                                     uint32_t* __restrict__ bad) {
+    constexpr int S = Split<A>::value;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.n) return;
-    typename A::Aff a;
-    const int st = A::decode(a, points + A::wire_size(p.flags) * i, p.flags);
-    aff[i] = a;
+    if (i >= n_in) return;
+    typename A::Aff a[S];
+    uint32_t k[S][8];
+    int st;
+    if constexpr (S == 1) {
+        st = A::decode(a[0], points + A::wire_size(p.flags) * i, p.flags);
+        A::scalar_words(k[0], scalars + 32 * i);
+    } else {
+        st = A::decode_split(a, k, points + A::wire_size(p.flags) * i, scalars + 32 * i, p.flags);
+    }
     if (status) status[i] = (uint8_t)st;
     if (st) atomicAdd(bad, 1u);
-    uint32_t k[8];
-    A::scalar_words(k, scalars + 32 * i);
-    int32_t dig[129];
-    recode<129>(dig, k, p.c, p.nwin);
-    for (int w = 0; w < p.nwin; w++) {
-        const int d = st ? 0 : dig[w];
-        digits[(size_t)w * p.n + i] = d;
-        if (d) atomicAdd(&hist[(size_t)w * p.nb + (d < 0 ? -d : d) - 1], 1u);
+#pragma unroll
+    for (int h = 0; h < S; h++) {
+        const size_t e = (size_t)h * n_in + i;
+        aff[e] = a[h];
+        int32_t dig[129];
+        recode<129>(dig, k[h], p.c, p.nwin);
+        for (int w = 0; w < p.nwin; w++) {
+            const int d = st ? 0 : dig[w];
+            digits[(size_t)w * p.n + e] = d;
+            if (d) atomicAdd(&hist[(size_t)w * p.nb + (d < 0 ? -d : d) - 1], 1u);
+        }
     }
 }
 
@@ -189,12 +212,19 @@ static __global__ __launch_bounds__(256) void scatter_kernel(Plan p, const int32
 
 constexpr int SUB = 64;  // points per accumulate lane: a bucket longer than this is split (skewed digits)
 
-// nsub[b] = number of SUB-sized pieces of bucket b
+constexpr uint32_t LONG_PIECES = 4;  // a bucket of more pieces is joined by a workgroup (tree), not by one lane
+
+// nsub[b] = number of SUB-sized pieces of bucket b; buckets of more than LONG_PIECES pieces (skewed digits: a short top
+// window, equal or small scalars) are appended to longlist (counter in nlong[0]).
 static __global__ __launch_bounds__(256) void subcount_kernel(size_t nbk, const uint32_t* __restrict__ offs,
-                                                              uint32_t* __restrict__ nsub) {
+                                                              uint32_t* __restrict__ nsub,
+                                                              uint32_t* __restrict__ nlong,
+                                                              uint32_t* __restrict__ longlist) {
     const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nbk) return;
-    nsub[b] = (offs[b + 1] - offs[b] + SUB - 1) / SUB;
+    const uint32_t k = (offs[b + 1] - offs[b] + SUB - 1) / SUB;
+    nsub[b] = k;
+    if (k > LONG_PIECES) longlist[atomicAdd(nlong, 1u)] = (uint32_t)b;
 }
 
 // Piece t -> (first index into `sorted`, length), plus a histogram of the lengths.  The piece -> bucket map is a
@@ -278,7 +308,7 @@ __global__ __launch_bounds__(64) void accumulate_kernel(size_t nbk, size_t max_p
     pieces[t] = acc;
 }
 
-// bucket b = sum of its pieces (one piece for all but skewed buckets)
+// bucket b = sum of its pieces (one piece for all but skewed buckets; long ones are left to bucket_long_kernel)
 template <class A>
 __global__ __launch_bounds__(64) void bucket_kernel(size_t nbk, const uint32_t* __restrict__ suboffs,
                                                     const typename A::Acc* __restrict__ pieces,
@@ -286,6 +316,7 @@ __global__ __launch_bounds__(64) void bucket_kernel(size_t nbk, const uint32_t* 
     const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nbk) return;
     const uint32_t lo = suboffs[b], hi = suboffs[b + 1];
+    if (hi - lo > LONG_PIECES) return;
     typename A::Acc acc;
     A::identity(acc);
     if (hi > lo) acc = pieces[lo];
@@ -295,6 +326,47 @@ __global__ __launch_bounds__(64) void bucket_kernel(size_t nbk, const uint32_t* 
         A::add(acc, acc, v);
     }
     buckets[b] = acc;
+}
+
+// Long buckets: one workgroup each (grid-stride over longlist); every thread sums a strided share of the pieces, then
+// the workgroup adds its partial sums as a tree through LDS.  A bucket holding all 2^20 points (equal scalars) is
+// 16 384 pieces: 64 + 8 dependent additions instead of 16 383.
+template <class A>
+constexpr int long_threads() {
+    return sizeof(typename A::Acc) > 192 ? 128 : 256;  // the LDS tree must fit 64 KB
+}
+template <class A>
+__global__ __launch_bounds__(256) void bucket_long_kernel(const uint32_t* __restrict__ nlong,
+                                                          const uint32_t* __restrict__ longlist,
+                                                          const uint32_t* __restrict__ suboffs,
+                                                          const typename A::Acc* __restrict__ pieces,
+                                                          typename A::Acc* __restrict__ buckets) {
+    constexpr int T = long_threads<A>();
+    __shared__ typename A::Acc sh[T];
+    const uint32_t cnt = nlong[0];
+#pragma unroll 1
+    for (uint32_t j = blockIdx.x; j < cnt; j += gridDim.x) {
+        const uint32_t b = longlist[j];
+        const uint32_t lo = suboffs[b], hi = suboffs[b + 1];
+        typename A::Acc acc;
+        A::identity(acc);
+#pragma unroll 1
+        for (uint32_t q = lo + threadIdx.x; q < hi; q += T) {
+            const typename A::Acc v = pieces[q];
+            A::add(acc, acc, v);
+        }
+#pragma unroll 1
+        for (int off = T / 2; off >= 1; off >>= 1) {
+            sh[threadIdx.x] = acc;
+            __syncthreads();
+            if ((int)threadIdx.x < off) {
+                const typename A::Acc v = sh[threadIdx.x + off];
+                A::add(acc, acc, v);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) buckets[b] = acc;
+    }
 }
 
 // partial[w][ch] = sum_{b in chunk} (b + 1) * B_b   (b = bucket index from 0, digit value b + 1)
@@ -314,11 +386,11 @@ __global__ __launch_bounds__(64) void reduce_kernel(Plan p, const typename A::Ac
         A::add(run, run, bk);
         A::add(tot, tot, run);
     }
-    // tot = sum (b - lo + 1) B_b ; add lo * run   (lo < 2^15)
+    // tot = sum (b - lo + 1) B_b ; add lo * run   (lo < nb = 2^(c-1))
     typename A::Acc m;
     A::identity(m);
 #pragma unroll 1
-    for (int bit = 14; bit >= 0; bit--) {
+    for (int bit = p.c - 2; bit >= 0; bit--) {
         A::dbl(m, m);
         if ((lo >> bit) & 1) A::add(m, m, run);
     }
@@ -419,13 +491,14 @@ inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 template <class A>
 int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, void* d_out, void* d_status,
         hipStream_t st, uint32_t flags = 0) {
-    if (n >= (size_t(1) << 31)) {
+    if (n * Split<A>::value >= (size_t(1) << 31)) {
         set_error("msm: n too large");
         return KYB_E_ARG;
     }
-    const Plan p = make_plan(n ? n : 1);
+    const size_t ne = n * Split<A>::value;  // points after the adapter's endomorphism split
+    const Plan p = make_plan(ne ? ne : 1, Split<A>::bits, Split<A>::cmax);
     Plan pr = p;
-    pr.n = n;
+    pr.n = ne;
     pr.flags = flags;
     const size_t nbk = (size_t)p.nwin * p.nb;
     size_t off = 0;
@@ -434,23 +507,25 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
         off += align256(bytes);
         return o;
     };
-    const size_t o_aff = take(sizeof(typename A::Aff) * (n ? n : 1));
-    const size_t o_dig = take(sizeof(int32_t) * (n ? n : 1) * p.nwin);
-    const size_t o_sorted = take(sizeof(uint32_t) * (n ? n : 1) * p.nwin);
+    const size_t o_aff = take(sizeof(typename A::Aff) * (ne ? ne : 1));
+    const size_t o_dig = take(sizeof(int32_t) * (ne ? ne : 1) * p.nwin);
+    const size_t o_sorted = take(sizeof(uint32_t) * (ne ? ne : 1) * p.nwin);
     const size_t o_hist = take(sizeof(uint32_t) * nbk);
     const size_t o_cursor = take(sizeof(uint32_t) * nbk);
     const size_t o_lenhist = take(sizeof(uint32_t) * (SUB + 2));
     const size_t o_lencursor = take(sizeof(uint32_t) * (SUB + 2));
+    const size_t o_nlong = take(256);
     const size_t o_bad = take(256);
     const size_t zero_end = off;  // hist, cursor, lenhist, lencursor, bad are zeroed together
     const size_t o_offs = take(sizeof(uint32_t) * (nbk + 1));
     const size_t o_nsub = take(sizeof(uint32_t) * nbk);
     const size_t o_suboffs = take(sizeof(uint32_t) * (nbk + 1));
-    const size_t max_pieces = nbk + ((n ? n : 1) * (size_t)p.nwin + SUB - 1) / SUB;
+    const size_t max_pieces = nbk + ((ne ? ne : 1) * (size_t)p.nwin + SUB - 1) / SUB;
     const size_t o_pieces = take(sizeof(typename A::Acc) * max_pieces);
     const size_t o_plo = take(sizeof(uint32_t) * max_pieces);
     const size_t o_plen = take(sizeof(uint32_t) * max_pieces);
     const size_t o_order = take(sizeof(uint32_t) * max_pieces);
+    const size_t o_longlist = take(sizeof(uint32_t) * nbk);
     const size_t o_buckets = take(sizeof(typename A::Acc) * nbk);
     const size_t o_partial = take(sizeof(typename A::Acc) * (size_t)p.nwin * p.nchunks);
     const int nfold = (p.nchunks + 63) / 64;
@@ -476,6 +551,8 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     auto* order = (uint32_t*)(base + o_order);
     auto* lenhist = (uint32_t*)(base + o_lenhist);
     auto* lencursor = (uint32_t*)(base + o_lencursor);
+    auto* nlong = (uint32_t*)(base + o_nlong);
+    auto* longlist = (uint32_t*)(base + o_longlist);
     auto* buckets = (typename A::Acc*)(base + o_buckets);
     auto* partial = (typename A::Acc*)(base + o_partial);
     auto* winsum = (typename A::Acc*)(base + o_winsum);
@@ -483,16 +560,17 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     auto* tile = (uint32_t*)(base + o_tile);
     KYB_HIP_CHECK(hipMemsetAsync(hist, 0, zero_end - o_hist, st));
     if (n) {
-        hipLaunchKernelGGL(decode_kernel<A>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, pr, (const uint8_t*)d_scalars,
+        hipLaunchKernelGGL(decode_kernel<A>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, pr, n, (const uint8_t*)d_scalars,
                            (const uint8_t*)d_points, aff, digits, hist, (uint8_t*)d_status, bad);
     }
     launch_scan(hist, offs, nbk, tile, st);
     if (n) {
-        const size_t tot = n * (size_t)p.nwin;
+        const size_t tot = ne * (size_t)p.nwin;
         hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, pr, digits, offs, cursor,
                            sorted);
     }
-    hipLaunchKernelGGL(subcount_kernel, dim3((unsigned)((nbk + 255) / 256)), dim3(256), 0, st, nbk, offs, nsub);
+    hipLaunchKernelGGL(subcount_kernel, dim3((unsigned)((nbk + 255) / 256)), dim3(256), 0, st, nbk, offs, nsub, nlong,
+                       longlist);
     launch_scan(nsub, suboffs, nbk, tile, st);
     const unsigned pgrid = (unsigned)((max_pieces + 255) / 256);
     hipLaunchKernelGGL(piece_kernel, dim3(pgrid), dim3(256), 0, st, nbk, max_pieces, (const uint32_t*)offs,
@@ -504,6 +582,8 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
                        (const uint32_t*)suboffs, (const uint32_t*)order, (const uint32_t*)plo, (const uint32_t*)plen,
                        sorted, pieces);
     hipLaunchKernelGGL(bucket_kernel<A>, dim3((unsigned)((nbk + 63) / 64)), dim3(64), 0, st, nbk, suboffs, pieces, buckets);
+    hipLaunchKernelGGL(bucket_long_kernel<A>, dim3(1024), dim3(long_threads<A>()), 0, st, (const uint32_t*)nlong,
+                       (const uint32_t*)longlist, (const uint32_t*)suboffs, pieces, buckets);
     const size_t nred = (size_t)p.nwin * p.nchunks;
     hipLaunchKernelGGL(reduce_kernel<A>, dim3((unsigned)((nred + 63) / 64)), dim3(64), 0, st, pr, buckets, partial);
     // fold the per-window chunk partials 64 at a time (ping-pong between `partial` and `folded`) down to one each

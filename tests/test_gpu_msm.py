@@ -109,8 +109,12 @@ def test_pairing_suite_msm_vs_oracle_small(name):
     m, O = _suite(name)
     order = m.ORDER
     rng = random.Random(3)
-    n = 19
-    ks = [0, 1, order - 1, (1 << 256) - 1, 1 << 255] + [rng.randrange(order) for _ in range(n - 5)]
+    z2 = 0xD201000000010000 ** 2  # the BLS12-381 G1 split base: scalars around its multiples / half-multiples
+    extra = [z2 // 2, z2 // 2 + 1, z2 - 1, z2, z2 + 1, z2 * (z2 // 2), z2 * (z2 // 2 + 1) + z2 // 2 + 1, 3 * z2 * z2 // 2,
+             (1 << 256) - z2, order + z2 // 2]
+    n = 19 + len(extra)
+    ks = [0, 1, order - 1, (1 << 256) - 1, 1 << 255] + extra + [rng.randrange(order) for _ in range(n - 5 - len(extra))]
+    ks = [k % (1 << 256) for k in ks]
     hs = [rng.randrange(1, order) for _ in range(n)]
     kb = b"".join(k.to_bytes(32, "big") for k in ks)
     if name == "bls12381":
@@ -119,9 +123,9 @@ def test_pairing_suite_msm_vs_oracle_small(name):
         enc1, enc2, G1, G2 = O.g1_marshal, O.g2_marshal, O.G1_GEN, O.G2_GEN
     p1 = [O.g1_mul(h, G1) for h in hs]
     p2 = [O.g2_mul(h, G2) for h in hs]
-    p1[6], p2[6] = None, None  # infinity as an input
-    p1[8], p2[8] = p1[7], p2[7]
-    ks[8] = ks[7]  # equal (scalar, point) pairs: doubling inside a bucket
+    p1[16], p2[16] = None, None  # infinity as an input
+    p1[18], p2[18] = p1[17], p2[17]
+    ks[18] = ks[17]  # equal (scalar, point) pairs: doubling inside a bucket
     kb = b"".join(k.to_bytes(32, "big") for k in ks)
     acc1 = acc2 = None
     for k, a, b in zip(ks, p1, p2):
