@@ -3,8 +3,12 @@
 
 ``batch_hash`` is the suite's HashablePoint.Hash over a list of messages.  For bn256 it is the reference's
 try-and-increment over SHA-256 (pairing/bn256/point.go:261-313), run on the device (kyb_bn256_hash_g1).
-BLS12-381 hash-to-curve (RFC 9380 SSWU) is not built (isogeny constants unavailable offline, SURVEY.md
-Appendix A).
+BLS12-381 uses RFC 9380 hash_to_curve on the device (kyb_bls12381_hash_g1/g2).
+
+Operands the engine produced itself in the same call -- H(m), the group generator -- are passed with
+KYB_F_TRUSTED (they are valid by construction, exactly like the kyber.Point values the reference hands to
+ValidatePairing); public keys are too when the caller says they were unmarshalled (validated) before
+(`keys_validated=True`, the reference's situation: Verify receives a kyber.Point).  Signatures never are.
 """
 from __future__ import annotations
 
@@ -40,18 +44,19 @@ class SchemeOnG1:
             raise ValueError("bls: hash-to-point produced an invalid point")
         return bytes(out[0])
 
-    def batch_verify(self, publics, msgs, sigs):
+    def batch_verify(self, publics, msgs, sigs, keys_validated: bool = False):
         """N x Verify (bls.go:82-96) as ONE pairing-check launch: ok[i] = e(H(m_i), X_i) == e(sig_i, B2).
         Returns a bool array; an undecodable key / signature verifies false (the reference returns an error)."""
         n = len(msgs)
         H = self.batch_hash(msgs)
         X = b"".join(publics)
         S = b"".join(sigs)
-        ok, st = self.m.batch_validate_pairing(H, X, S, self.m.G2_BASE * n)
+        flags = self.m.F_TRUSTED(0) | self.m.F_TRUSTED(3) | (self.m.F_TRUSTED(1) if keys_validated else 0)
+        ok, st = self.m.batch_validate_pairing(H, X, S, self.m.G2_BASE * n, flags)
         return (np.asarray(ok) == 1) & (np.asarray(st) == 0)
 
-    def verify(self, public: bytes, msg: bytes, sig: bytes) -> bool:
-        return bool(self.batch_verify([public], [msg], [sig])[0])
+    def verify(self, public: bytes, msg: bytes, sig: bytes, keys_validated: bool = False) -> bool:
+        return bool(self.batch_verify([public], [msg], [sig], keys_validated)[0])
 
 
 def _grouped(hash_fn, width):
@@ -78,14 +83,15 @@ class _Bls12381SchemeOnG1(SchemeOnG1):
         super().__init__(suite_module, batch_hash)
         self.dst = dst
 
-    def batch_verify(self, publics, msgs, sigs):
+    def batch_verify(self, publics, msgs, sigs, keys_validated: bool = False):
         out = np.zeros(len(msgs), dtype=bool)
         by_len = {}
         for i, m in enumerate(msgs):
             by_len.setdefault(len(m), []).append(i)
+        flags = self.m.F_TRUSTED(0) if keys_validated else 0
         for _, idx in by_len.items():
             ok, st = self.m.batch_verify_g1([publics[i] for i in idx], [bytes(msgs[i]) for i in idx],
-                                            [sigs[i] for i in idx], self.dst)
+                                            [sigs[i] for i in idx], self.dst, flags)
             out[idx] = (np.asarray(ok) == 1) & (np.asarray(st) == 0)
         return out
 
@@ -112,14 +118,15 @@ class SchemeOnG2:
             raise ValueError("bls: hash-to-point produced an invalid point")
         return bytes(out[0])
 
-    def batch_verify(self, publics, msgs, sigs):
+    def batch_verify(self, publics, msgs, sigs, keys_validated: bool = False):
         n = len(msgs)
         H = self.batch_hash(msgs)
-        ok, st = self.m.batch_validate_pairing(self.m.G1_BASE * n, b"".join(sigs), b"".join(publics), H)
+        flags = self.m.F_TRUSTED(0) | self.m.F_TRUSTED(3) | (self.m.F_TRUSTED(2) if keys_validated else 0)
+        ok, st = self.m.batch_validate_pairing(self.m.G1_BASE * n, b"".join(sigs), b"".join(publics), H, flags)
         return (np.asarray(ok) == 1) & (np.asarray(st) == 0)
 
-    def verify(self, public: bytes, msg: bytes, sig: bytes) -> bool:
-        return bool(self.batch_verify([public], [msg], [sig])[0])
+    def verify(self, public: bytes, msg: bytes, sig: bytes, keys_validated: bool = False) -> bool:
+        return bool(self.batch_verify([public], [msg], [sig], keys_validated)[0])
 
 
 def NewSchemeOnG2_bls12381(dst: bytes | None = None) -> SchemeOnG2:
