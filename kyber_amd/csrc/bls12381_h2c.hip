@@ -90,6 +90,7 @@ static int hash_host(bool g2, size_t n, const uint8_t* msgs, size_t msg_len, con
     DeviceCtx* ctx;
     KYB_TRY(get_ctx(&ctx));
     const size_t osz = g2 ? 96 : 48;
+    kyb::StageScope sc_(ctx);
     StageBuf m, o, st;
     KYB_TRY(m.upload(msgs, n * msg_len));
     KYB_TRY(o.alloc(n * osz));
@@ -132,6 +133,7 @@ int kyb_bls12381_verify_g1(size_t n, const uint8_t* pks, const uint8_t* msgs, si
     if (!n) return KYB_OK;
     DeviceCtx* ctx;
     KYB_TRY(get_ctx(&ctx));
+    kyb::StageScope sc_(ctx);
     StageBuf p, m, s, o, st;
     KYB_TRY(p.upload(pks, n * bls::g2_wire_size(flags)));
     KYB_TRY(m.upload(msgs, n * msg_len));

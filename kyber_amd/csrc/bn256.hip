@@ -42,6 +42,7 @@ int kyb_bn256_hash_g1(size_t n, const uint8_t* msgs, size_t msg_len, uint8_t* ou
     if (!n) return KYB_OK;
     kyb::DeviceCtx* ctx;
     KYB_TRY(kyb::get_ctx(&ctx));
+    kyb::StageScope sc_(ctx);
     kyb::StageBuf m, o, st;
     KYB_TRY(m.upload(msgs, n * msg_len));
     KYB_TRY(o.alloc(n * 64));

@@ -34,15 +34,74 @@ struct DeviceCtx {
     // Ed25519 deferred-encoding workspace: parked (X, Y, Z) triples of the last large batch
     void* ed_proj = nullptr;
     size_t ed_proj_bytes = 0;
-    // scratch workspace (host entry points stage through it)
+    // scratch workspace (the MSM pipeline lives in it)
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    // grow-only device staging buffers of the host-buffer entry points (no hipMalloc / hipFree per call);
+    // stage_mu serialises those calls per device -- they synchronise the device anyway
+    static constexpr int NSTAGE = 8;
+    void* stage[NSTAGE] = {};
+    size_t stage_cap[NSTAGE] = {};
+    std::mutex stage_mu;
+    // streams of the chunk-pipelined host paths (H2D | compute | D2H), created on first use
+    hipStream_t pipe[3] = {};
 };
 
 // Context for the calling thread's current device (created on first use).
 int get_ctx(DeviceCtx** out);
 // Grow (never shrink) the context's workspace; caller holds no lock.
 int ctx_workspace(DeviceCtx* ctx, size_t bytes, void** out);
+
+// A host-buffer call: holds the device's staging pool for its duration and hands out slots in order.
+struct StageScope {
+    DeviceCtx* ctx;
+    std::unique_lock<std::mutex> lk;
+    int next = 0;
+    explicit StageScope(DeviceCtx* c) : ctx(c), lk(c->stage_mu) { current() = this; }
+    ~StageScope() { current() = nullptr; }
+    static StageScope*& current() {
+        static thread_local StageScope* cur = nullptr;
+        return cur;
+    }
+};
+// One device staging buffer of the current StageScope (pooled: freed only by kyb_shutdown).
+struct StageBuf {
+    void* p = nullptr;
+    int alloc(size_t bytes) {
+        StageScope* sc = StageScope::current();
+        if (!sc || sc->next >= DeviceCtx::NSTAGE) {
+            set_error("staging: no scope / too many buffers");
+            return KYB_E_ARG;
+        }
+        const int slot = sc->next++;
+        DeviceCtx* c = sc->ctx;
+        if (c->stage_cap[slot] < bytes || !c->stage[slot]) {
+            if (c->stage[slot]) {
+                hipFree(c->stage[slot]);
+                c->stage[slot] = nullptr;
+                c->stage_cap[slot] = 0;
+            }
+            const size_t cap = bytes + bytes / 4 + 256;
+            if (hipMalloc(&c->stage[slot], cap) != hipSuccess) {
+                set_error("hipMalloc failed");
+                return KYB_E_ALLOC;
+            }
+            c->stage_cap[slot] = cap;
+        }
+        p = c->stage[slot];
+        return KYB_OK;
+    }
+    int upload(const void* src, size_t bytes) {
+        int rc = alloc(bytes);
+        if (rc) return rc;
+        if (bytes) KYB_HIP_CHECK(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+        return KYB_OK;
+    }
+    int download(void* dst, size_t bytes) {
+        if (bytes) KYB_HIP_CHECK(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
+        return KYB_OK;
+    }
+};
 
 // Per-curve table builders (defined next to their kernels).
 int ed25519_build_tables(DeviceCtx* ctx);

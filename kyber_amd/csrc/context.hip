@@ -87,6 +87,10 @@ int kyb_shutdown(void) {
         hipSetDevice(c->device);
         kyb::ed25519_free_tables(c);
         if (c->ws) hipFree(c->ws);
+        for (int i = 0; i < kyb::DeviceCtx::NSTAGE; i++)
+            if (c->stage[i]) hipFree(c->stage[i]);
+        for (int i = 0; i < 3; i++)
+            if (c->pipe[i]) hipStreamDestroy(c->pipe[i]);
         delete c;
     }
     kyb::g_ctx.clear();

@@ -13,6 +13,9 @@
 #include "ed25519_h2c.cuh"
 #include <string.h>
 
+#include <algorithm>
+#include <vector>
+
 namespace kyb {
 
 // Fixed-base table: entry (pos, j) = (j + 1) * 256^pos * B in affine (y+x, y-x, 2dxy) form, j < 136: a signed
@@ -470,58 +473,110 @@ int kyb_ed25519_mul_dev(size_t n, const void* d_scalars, const void* d_points, v
     return launch_mul(n, d_scalars, d_points, 8, d_out, d_status, flags, (hipStream_t)stream);
 }
 
+static int mul_host(size_t n, const uint8_t* scalars, const uint8_t* points, size_t stride, uint8_t* out,
+                    uint8_t* status, uint32_t flags);
+
 int kyb_ed25519_mul_base(size_t n, const uint8_t* scalars, uint8_t* out, uint32_t flags) {
     if ((n && (!scalars || !out)) || (flags & ~KYB_F_VARTIME)) {
         set_error("kyb_ed25519_mul_base: bad argument");
         return KYB_E_ARG;
     }
     if (n == 0) return KYB_OK;
-    DeviceCtx* ctx;
-    int rc = get_ctx(&ctx);
-    if (rc) return rc;
-    uint8_t *d_in = nullptr, *d_out = nullptr;
-    KYB_HIP_CHECK(hipMalloc(&d_in, n * 32));
-    KYB_HIP_CHECK(hipMalloc(&d_out, n * 32));
-    KYB_HIP_CHECK(hipMemcpy(d_in, scalars, n * 32, hipMemcpyHostToDevice));
-    rc = launch_mul_base(ctx, n, d_in, d_out, flags, nullptr);
-    if (rc == KYB_OK) {
-        hipError_t e = hipMemcpy(out, d_out, n * 32, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) {
-            set_error(std::string("D2H: ") + hipGetErrorString(e));
-            rc = KYB_E_HIP;
-        }
-    }
-    hipFree(d_in);
-    hipFree(d_out);
-    return rc;
+    return mul_host(n, scalars, nullptr, 0, out, nullptr, flags);
 }
 
+// Host-buffer batches of at least 2 * PIPE_CHUNK elements are cut in chunks and software-pipelined over three
+// streams: while chunk i computes, chunk i+1 is copied in and chunk i-1 is copied out.  The copies are issued in
+// the order H2D(i+1), kernel(i+1), D2H(i), so even where the runtime makes a pageable-memory copy block the host
+// thread, the compute stream always has the next kernel queued.  (PCIe moves 97 bytes per variable-base element
+// in ~1/3 of the time the kernel needs for it: overlapped, the host path approaches the resident rate.)
+constexpr size_t PIPE_CHUNK = size_t(1) << 18;
+
+static int pipe_streams(DeviceCtx* ctx) {
+    for (int i = 0; i < 3; i++)
+        if (!ctx->pipe[i]) KYB_HIP_CHECK(hipStreamCreateWithFlags(&ctx->pipe[i], hipStreamNonBlocking));
+    return KYB_OK;
+}
+
+// points == nullptr: fixed-base (kyb_ed25519_mul_base); stride 0: one shared base point
 static int mul_host(size_t n, const uint8_t* scalars, const uint8_t* points, size_t stride, uint8_t* out,
                     uint8_t* status, uint32_t flags) {
     DeviceCtx* ctx;
     int rc = get_ctx(&ctx);
     if (rc) return rc;
-    const size_t npts = stride ? n : 1;
-    uint8_t *d_s = nullptr, *d_p = nullptr, *d_o = nullptr, *d_st = nullptr;
-    KYB_HIP_CHECK(hipMalloc(&d_s, n * 32));
-    KYB_HIP_CHECK(hipMalloc(&d_p, npts * 32));
-    KYB_HIP_CHECK(hipMalloc(&d_o, n * 32));
-    KYB_HIP_CHECK(hipMalloc(&d_st, n));
-    KYB_HIP_CHECK(hipMemcpy(d_s, scalars, n * 32, hipMemcpyHostToDevice));
-    KYB_HIP_CHECK(hipMemcpy(d_p, points, npts * 32, hipMemcpyHostToDevice));
-    rc = launch_mul(n, d_s, d_p, stride, d_o, d_st, flags, nullptr);
-    if (rc == KYB_OK) {
-        hipError_t e = hipMemcpy(out, d_o, n * 32, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && status) e = hipMemcpy(status, d_st, n, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) {
-            set_error(std::string("D2H: ") + hipGetErrorString(e));
-            rc = KYB_E_HIP;
-        }
+    const bool fixed = points == nullptr;
+    const size_t npts = fixed ? 0 : (stride ? n : 1);
+    StageScope sc_(ctx);
+    StageBuf d_s, d_p, d_o, d_st;
+    if ((rc = d_s.alloc(n * 32))) return rc;
+    if ((rc = d_p.alloc(npts * 32))) return rc;
+    if ((rc = d_o.alloc(n * 32))) return rc;
+    if ((rc = d_st.alloc(n))) return rc;
+    auto launch = [&](size_t off, size_t cnt, hipStream_t st) -> int {
+        uint8_t* s = (uint8_t*)d_s.p + off * 32;
+        uint8_t* o = (uint8_t*)d_o.p + off * 32;
+        if (fixed) return launch_mul_base(ctx, cnt, s, o, flags, st);
+        const uint8_t* p = (const uint8_t*)d_p.p + (stride ? off * 32 : 0);
+        return launch_mul(cnt, s, p, stride, o, (uint8_t*)d_st.p + off, flags, st);
+    };
+    if (n < 2 * PIPE_CHUNK) {
+        KYB_HIP_CHECK(hipMemcpy(d_s.p, scalars, n * 32, hipMemcpyHostToDevice));
+        if (npts) KYB_HIP_CHECK(hipMemcpy(d_p.p, points, npts * 32, hipMemcpyHostToDevice));
+        if ((rc = launch(0, n, nullptr))) return rc;
+        if ((rc = d_o.download(out, n * 32))) return rc;
+        if (status && !fixed) rc = d_st.download(status, n);
+        return rc;
     }
-    hipFree(d_s);
-    hipFree(d_p);
-    hipFree(d_o);
-    hipFree(d_st);
+    if ((rc = pipe_streams(ctx))) return rc;
+    hipStream_t s_in = ctx->pipe[0], s_k = ctx->pipe[1], s_out = ctx->pipe[2];
+    const size_t nchunks = (n + PIPE_CHUNK - 1) / PIPE_CHUNK;
+    std::vector<hipEvent_t> ev_in(nchunks), ev_k(nchunks);
+    for (size_t i = 0; i < nchunks; i++) {
+        KYB_HIP_CHECK(hipEventCreateWithFlags(&ev_in[i], hipEventDisableTiming));
+        KYB_HIP_CHECK(hipEventCreateWithFlags(&ev_k[i], hipEventDisableTiming));
+    }
+    auto h2d = [&](size_t i) -> int {
+        const size_t off = i * PIPE_CHUNK, cnt = std::min(PIPE_CHUNK, n - off);
+        KYB_HIP_CHECK(hipMemcpyAsync((uint8_t*)d_s.p + off * 32, scalars + off * 32, cnt * 32, hipMemcpyHostToDevice, s_in));
+        if (!fixed && stride)
+            KYB_HIP_CHECK(hipMemcpyAsync((uint8_t*)d_p.p + off * 32, points + off * 32, cnt * 32, hipMemcpyHostToDevice, s_in));
+        KYB_HIP_CHECK(hipEventRecord(ev_in[i], s_in));
+        return KYB_OK;
+    };
+    auto kern = [&](size_t i) -> int {
+        const size_t off = i * PIPE_CHUNK, cnt = std::min(PIPE_CHUNK, n - off);
+        KYB_HIP_CHECK(hipStreamWaitEvent(s_k, ev_in[i], 0));
+        int r = launch(off, cnt, s_k);
+        if (r) return r;
+        KYB_HIP_CHECK(hipEventRecord(ev_k[i], s_k));
+        return KYB_OK;
+    };
+    auto d2h = [&](size_t i) -> int {
+        const size_t off = i * PIPE_CHUNK, cnt = std::min(PIPE_CHUNK, n - off);
+        KYB_HIP_CHECK(hipStreamWaitEvent(s_out, ev_k[i], 0));
+        KYB_HIP_CHECK(hipMemcpyAsync(out + off * 32, (uint8_t*)d_o.p + off * 32, cnt * 32, hipMemcpyDeviceToHost, s_out));
+        if (status && !fixed)
+            KYB_HIP_CHECK(hipMemcpyAsync(status + off, (uint8_t*)d_st.p + off, cnt, hipMemcpyDeviceToHost, s_out));
+        return KYB_OK;
+    };
+    if (!fixed && !stride) KYB_HIP_CHECK(hipMemcpyAsync(d_p.p, points, 32, hipMemcpyHostToDevice, s_in));
+    rc = h2d(0);
+    if (rc == KYB_OK) rc = kern(0);
+    for (size_t i = 1; i < nchunks && rc == KYB_OK; i++) {
+        rc = h2d(i);
+        if (rc == KYB_OK) rc = kern(i);
+        if (rc == KYB_OK) rc = d2h(i - 1);
+    }
+    if (rc == KYB_OK) rc = d2h(nchunks - 1);
+    hipError_t e1 = hipStreamSynchronize(s_out), e2 = hipStreamSynchronize(s_k), e3 = hipStreamSynchronize(s_in);
+    for (size_t i = 0; i < nchunks; i++) {
+        hipEventDestroy(ev_in[i]);
+        hipEventDestroy(ev_k[i]);
+    }
+    if (rc == KYB_OK && (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)) {
+        set_error("ed25519 host pipeline: stream synchronisation failed");
+        rc = KYB_E_HIP;
+    }
     return rc;
 }
 
@@ -693,17 +748,12 @@ int kyb_ed25519_hash(size_t n, const uint8_t* msgs, size_t msg_len, const uint8_
     kyb::DeviceCtx* ctx;
     int rc = kyb::get_ctx(&ctx);
     if (rc) return rc;
-    uint8_t *d_m = nullptr, *d_o = nullptr;
-    KYB_HIP_CHECK(hipMalloc(&d_m, n * msg_len + 1));
-    KYB_HIP_CHECK(hipMalloc(&d_o, n * 32));
-    if (msg_len) KYB_HIP_CHECK(hipMemcpy(d_m, msgs, n * msg_len, hipMemcpyHostToDevice));
-    rc = kyb_ed25519_hash_dev(n, d_m, msg_len, dst, dst_len, d_o, nullptr);
-    if (rc == KYB_OK && hipMemcpy(out, d_o, n * 32, hipMemcpyDeviceToHost) != hipSuccess) {
-        kyb::set_error("kyb_ed25519_hash: D2H failed");
-        rc = KYB_E_HIP;
-    }
-    hipFree(d_m);
-    hipFree(d_o);
+    kyb::StageScope sc_(ctx);
+    kyb::StageBuf d_m, d_o;
+    rc = d_m.upload(msgs, n * msg_len);
+    if (rc == KYB_OK) rc = d_o.alloc(n * 32);
+    if (rc == KYB_OK) rc = kyb_ed25519_hash_dev(n, d_m.p, msg_len, dst, dst_len, d_o.p, nullptr);
+    if (rc == KYB_OK) rc = d_o.download(out, n * 32);
     return rc;
 }
 }
@@ -755,26 +805,15 @@ int kyb_ed25519_add(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, 
     kyb::DeviceCtx* ctx;
     int rc = kyb::get_ctx(&ctx);
     if (rc) return rc;
-    uint8_t *d_a = nullptr, *d_b = nullptr, *d_o = nullptr, *d_st = nullptr;
-    KYB_HIP_CHECK(hipMalloc(&d_a, n * 32));
-    KYB_HIP_CHECK(hipMalloc(&d_b, n * 32));
-    KYB_HIP_CHECK(hipMalloc(&d_o, n * 32));
-    KYB_HIP_CHECK(hipMalloc(&d_st, n));
-    KYB_HIP_CHECK(hipMemcpy(d_a, a, n * 32, hipMemcpyHostToDevice));
-    KYB_HIP_CHECK(hipMemcpy(d_b, b, n * 32, hipMemcpyHostToDevice));
-    rc = kyb_ed25519_add_dev(n, d_a, d_b, d_o, d_st, nullptr);
-    if (rc == KYB_OK) {
-        hipError_t e = hipMemcpy(out, d_o, n * 32, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && status) e = hipMemcpy(status, d_st, n, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) {
-            kyb::set_error("kyb_ed25519_add: D2H failed");
-            rc = KYB_E_HIP;
-        }
-    }
-    hipFree(d_a);
-    hipFree(d_b);
-    hipFree(d_o);
-    hipFree(d_st);
+    kyb::StageScope sc_(ctx);
+    kyb::StageBuf d_a, d_b, d_o, d_st;
+    rc = d_a.upload(a, n * 32);
+    if (rc == KYB_OK) rc = d_b.upload(b, n * 32);
+    if (rc == KYB_OK) rc = d_o.alloc(n * 32);
+    if (rc == KYB_OK) rc = d_st.alloc(n);
+    if (rc == KYB_OK) rc = kyb_ed25519_add_dev(n, d_a.p, d_b.p, d_o.p, d_st.p, nullptr);
+    if (rc == KYB_OK) rc = d_o.download(out, n * 32);
+    if (rc == KYB_OK && status) rc = d_st.download(status, n);
     return rc;
 }
 }

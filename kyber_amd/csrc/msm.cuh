@@ -618,28 +618,15 @@ int run_host(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* o
     if (rc) return rc;
     // the pipeline lives in the per-device workspace: host-buffer MSM calls on one device are serialised
     std::lock_guard<std::mutex> ws_lock(ctx->msm_mu);
-    uint8_t *d_s = nullptr, *d_p = nullptr, *d_o = nullptr, *d_st = nullptr;
-    KYB_HIP_CHECK(hipMalloc(&d_s, n * 32 + 1));
-    KYB_HIP_CHECK(hipMalloc(&d_p, n * A::wire_size(flags) + 1));
-    KYB_HIP_CHECK(hipMalloc(&d_o, A::OUT));
-    KYB_HIP_CHECK(hipMalloc(&d_st, n + 1));
-    if (n) {
-        KYB_HIP_CHECK(hipMemcpy(d_s, scalars, n * 32, hipMemcpyHostToDevice));
-        KYB_HIP_CHECK(hipMemcpy(d_p, points, n * A::wire_size(flags), hipMemcpyHostToDevice));
-    }
-    rc = run<A>(ctx, n, d_s, d_p, d_o, d_st, nullptr, flags);
-    if (rc == KYB_OK) {
-        hipError_t e = hipMemcpy(out, d_o, A::OUT, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && status && n) e = hipMemcpy(status, d_st, n, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) {
-            set_error(std::string("msm D2H: ") + hipGetErrorString(e));
-            rc = KYB_E_HIP;
-        }
-    }
-    hipFree(d_s);
-    hipFree(d_p);
-    hipFree(d_o);
-    hipFree(d_st);
+    StageScope sc_(ctx);
+    StageBuf d_s, d_p, d_o, d_st;
+    rc = d_s.upload(scalars, n * 32);
+    if (rc == KYB_OK) rc = d_p.upload(points, n * A::wire_size(flags));
+    if (rc == KYB_OK) rc = d_o.alloc(A::OUT);
+    if (rc == KYB_OK) rc = d_st.alloc(n + 1);
+    if (rc == KYB_OK) rc = run<A>(ctx, n, d_s.p, d_p.p, d_o.p, d_st.p, nullptr, flags);
+    if (rc == KYB_OK) rc = d_o.download(out, A::OUT);
+    if (rc == KYB_OK && status && n) rc = d_st.download(status, n);
     return rc;
 }
 

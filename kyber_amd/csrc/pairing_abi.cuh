@@ -9,30 +9,7 @@
 namespace kyb {
 static inline unsigned grid_for(size_t n, int block) { return (unsigned)((n + block - 1) / block); }
 
-// Host entry points stage through temporary device buffers (freed on scope exit).
-struct StageBuf {
-    void* p = nullptr;
-    ~StageBuf() {
-        if (p) hipFree(p);
-    }
-    int alloc(size_t bytes) {
-        if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
-            set_error("hipMalloc failed");
-            return KYB_E_ALLOC;
-        }
-        return KYB_OK;
-    }
-    int upload(const void* src, size_t bytes) {
-        int rc = alloc(bytes);
-        if (rc) return rc;
-        KYB_HIP_CHECK(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
-        return KYB_OK;
-    }
-    int download(void* dst, size_t bytes) {
-        KYB_HIP_CHECK(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
-        return KYB_OK;
-    }
-};
+// Host entry points stage through the per-device pool of context.h (StageScope / StageBuf).
 }  // namespace kyb
 
 #define KYB_TRY(expr)        \
@@ -117,6 +94,7 @@ static int PFX##_mul_host(bool g2, size_t n, const uint8_t* scalars, const uint8
     if (!n) return KYB_OK; \
     kyb::DeviceCtx* ctx; \
     KYB_TRY(kyb::get_ctx(&ctx)); \
+    kyb::StageScope sc_(ctx); \
     kyb::StageBuf s, p, o, st; \
     KYB_TRY(s.upload(scalars, n * 32)); \
     KYB_TRY(p.upload(points, (stride ? n : 1) * isz)); \
@@ -153,6 +131,7 @@ static int PFX##_add_host(bool g2, size_t n, const uint8_t* a, const uint8_t* b,
     if (!n) return KYB_OK; \
     kyb::DeviceCtx* ctx; \
     KYB_TRY(kyb::get_ctx(&ctx)); \
+    kyb::StageScope sc_(ctx); \
     kyb::StageBuf x, y, o, st; \
     KYB_TRY(x.upload(a, n * psz)); \
     KYB_TRY(y.upload(b, n * psz)); \
@@ -241,6 +220,7 @@ int kyb_##PFX##_gt_mul(size_t n, const uint8_t* scalars, const uint8_t* gt, uint
     if (!n) return KYB_OK; \
     kyb::DeviceCtx* ctx; \
     KYB_TRY(kyb::get_ctx(&ctx)); \
+    kyb::StageScope sc_(ctx); \
     kyb::StageBuf a, b, o, st; \
     KYB_TRY(a.upload(scalars, n * 32)); \
     KYB_TRY(b.upload(gt, n * GTSZ)); \
@@ -272,6 +252,7 @@ int kyb_##PFX##_pair(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt
     if (!n) return KYB_OK; \
     kyb::DeviceCtx* ctx; \
     KYB_TRY(kyb::get_ctx(&ctx)); \
+    kyb::StageScope sc_(ctx); \
     kyb::StageBuf a, b, o, st; \
     KYB_TRY(a.upload(g1, n * kyb::NS::g1_wire_size(flags))); \
     KYB_TRY(b.upload(g2, n * kyb::NS::g2_wire_size(flags))); \
@@ -291,6 +272,7 @@ int kyb_##PFX##_pair_check(size_t n, const uint8_t* p1, const uint8_t* p2, const
     if (!n) return KYB_OK; \
     kyb::DeviceCtx* ctx; \
     KYB_TRY(kyb::get_ctx(&ctx)); \
+    kyb::StageScope sc_(ctx); \
     kyb::StageBuf a, b, c, d, o, st; \
     KYB_TRY(a.upload(p1, n * kyb::NS::g1_wire_size(flags))); \
     KYB_TRY(b.upload(p2, n * kyb::NS::g2_wire_size(flags))); \

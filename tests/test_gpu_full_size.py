@@ -88,3 +88,32 @@ def test_pairing_suites_at_config_sizes(name, n):
     exp = torch.ones(n, dtype=torch.bool, device="cuda")
     exp[::97] = False
     assert not st3.any().item() and torch.equal(ok.bool(), exp)
+
+
+def test_ed25519_pipelined_host_path_matches_device_path():
+    """Host-buffer batches >= 2^19 elements are chunk-pipelined over three streams (H2D | compute | D2H); a ragged
+    last chunk, bad points in different chunks and the three entry points must all agree with the resident path."""
+    import torch
+
+    from kyber_amd.group import edwards25519 as ed
+
+    n = (1 << 19) + 12345
+    s = np.frombuffer(hashlib.shake_256(b"pipe/s").digest(n * 32), dtype=np.uint8).reshape(n, 32).copy()
+    h = np.frombuffer(hashlib.shake_256(b"pipe/h").digest(n * 32), dtype=np.uint8).reshape(n, 32).copy()
+    s[:, 31] &= 0x7F
+    h[:, 31] &= 0x0F
+    base_dev = ed.batch_mul_base(torch.from_numpy(h).cuda())
+    base_host = ed.batch_mul_base(h)
+    assert (base_host == base_dev.cpu().numpy()).all()
+    pts = base_host.copy()
+    bad = [5, (1 << 18) + 7, n - 1]
+    for i in bad:
+        pts[i] = 0
+        pts[i, 0] = 2  # y = 2 is not on the curve
+    out_h, st_h = ed.batch_mul(s, pts)
+    out_d, st_d = ed.batch_mul(torch.from_numpy(s).cuda(), torch.from_numpy(pts).cuda())
+    assert (st_h == st_d.cpu().numpy()).all() and sorted(np.nonzero(st_h)[0].tolist()) == sorted(bad)
+    assert (out_h == out_d.cpu().numpy()).all() and not out_h[bad].any()
+    com_h = ed.commit(s, bytes(base_host[3]))
+    com_d, _ = ed.batch_mul(torch.from_numpy(s).cuda(), torch.from_numpy(np.tile(base_host[3], (n, 1))).cuda())
+    assert (com_h == com_d.cpu().numpy()).all()
