@@ -95,6 +95,56 @@ template <class C>
 KYB_HD void fp_dbl(Fp<C>& r, const Fp<C>& a) {
     fp_add(r, a, a);
 }
+
+// ---- lazily reduced sums, for operands of a multiplication only --------------------------------------------------
+// fp_mul computes a b R^-1 mod p correctly (result < 2p before its final conditional subtraction) for any operands
+// with normalised limbs and a b < R p, i.e. values below Ka p and Kb p with Ka Kb < R / p (BLS12-381: 2^9, bn256:
+// 2^5.8).  A Karatsuba pre-addition (a0 + a1) therefore does not need fp_add's conditional subtraction (65 of its
+// ~105 instructions): the carry sweep alone leaves a valid operand.  The tower code (tower.cuh) uses these for
+// temporaries whose only use is as a multiplication operand, at nesting depths that keep the product of the bounds
+// below R / p; everything that leaves a tower function is fully reduced as before.
+// r = a + b, value < (Ka + Kb) p, limbs normalised (the top limb absorbs the excess: K p < 2^(N W) for K <= 32)
+template <class C>
+KYB_HD void fp_add_nr(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
+    constexpr uint32_t MASK = (1u << C::W) - 1;
+    uint32_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < C::N; j++) {
+        const uint32_t u = a.v[j] + b.v[j] + carry;
+        r.v[j] = j + 1 < C::N ? (u & MASK) : u;
+        carry = u >> C::W;
+    }
+}
+// limbs of K p (normalised; compile-time)
+template <class C, int K>
+struct KTimesP {
+    struct Arr {
+        uint32_t v[C::N];
+    };
+    static constexpr Arr make() {
+        Arr r{};
+        uint64_t c = 0;
+        for (int j = 0; j < C::N; j++) {
+            const uint64_t x = (uint64_t)C::P[j] * K + c;
+            r.v[j] = j + 1 < C::N ? (uint32_t)(x & ((1u << C::W) - 1)) : (uint32_t)x;
+            c = x >> C::W;
+        }
+        return r;
+    }
+    static constexpr Arr value = make();
+};
+// r = a - b + K p for b < K p: value in [0, (Ka + K) p), limbs normalised
+template <int K, class C>
+KYB_HD void fp_sub_nr(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
+    constexpr uint32_t MASK = (1u << C::W) - 1;
+    int32_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < C::N; j++) {
+        const int32_t x = (int32_t)a.v[j] - (int32_t)b.v[j] + (int32_t)KTimesP<C, K>::value.v[j] + carry;
+        r.v[j] = j + 1 < C::N ? ((uint32_t)x & MASK) : (uint32_t)x;
+        carry = x >> C::W;
+    }
+}
 template <class C>
 KYB_HD void fp_sub(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
     constexpr uint32_t MASK = (1u << C::W) - 1;

@@ -8,7 +8,12 @@
 // different variable names: gfP2{x,y} = x i + y, gfP6{x,y,z} = x v^2 + y v + z, gfP12{x,y} = x w + y)
 // and the fp2/fp6/fp12 layers of the external BLS12-381 backends (go.mod:6-8).
 //
-// A tower configuration T provides: typedef F (field config for mont.cuh), XI0, and the
+// Lazy pre-additions (mont.cuh fp_add_nr): the sums a Karatsuba step forms only to multiply them skip the conditional
+// subtraction.  Bounds, as multiples of p, of what reaches fp_mul: one level of lazy sums per tower level doubles the
+// bound, so with LAZY12 (all three levels) operands are < 8p (product 64 < R/p = 2^9 for BLS12-381); bn256 has
+// R/p = 2^5.8 and stops at two levels (LAZY12 = false, operands < 4p).  KFP2 = bound of an Fp2-level operand.
+//
+// A tower configuration T provides: typedef F (field config for mont.cuh), XI0, LAZY12, and the
 // Frobenius constants FROB[3][6][2][N] = xi^(j (p^k - 1)/6), k = 1..3, j = 0..5, as Fp2
 // Montgomery limbs.
 #pragma once
@@ -40,6 +45,8 @@ template <class T> KYB_HD void fp2_sub(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>&
 template <class T> KYB_HD void fp2_dbl(Fp2<T>& r, const Fp2<T>& a) { fp_dbl(r.c0, a.c0); fp_dbl(r.c1, a.c1); }
 template <class T> KYB_HD void fp2_neg(Fp2<T>& r, const Fp2<T>& a) { fp_neg(r.c0, a.c0); fp_neg(r.c1, a.c1); }
 template <class T> KYB_HD void fp2_conj(Fp2<T>& r, const Fp2<T>& a) { r.c0 = a.c0; fp_neg(r.c1, a.c1); }
+template <class T> KYB_HD void fp2_add_nr(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) { fp_add_nr(r.c0, a.c0, b.c0); fp_add_nr(r.c1, a.c1, b.c1); }
+template <class T> constexpr int kfp2() { return T::LAZY12 ? 4 : 2; }
 
 // Karatsuba: 3 base-field multiplications
 template <class T>
@@ -47,8 +54,8 @@ KYB_HD void fp2_mul(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) {
     Fp<typename T::F> t0, t1, t2, s0, s1;
     fp_mul(t0, a.c0, b.c0);
     fp_mul(t1, a.c1, b.c1);
-    fp_add(s0, a.c0, a.c1);
-    fp_add(s1, b.c0, b.c1);
+    fp_add_nr(s0, a.c0, a.c1);
+    fp_add_nr(s1, b.c0, b.c1);
     fp_mul(t2, s0, s1);
     fp_sub(t2, t2, t0);
     fp_sub(r.c1, t2, t1);
@@ -58,8 +65,8 @@ KYB_HD void fp2_mul(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) {
 template <class T>
 KYB_HD void fp2_sqr(Fp2<T>& r, const Fp2<T>& a) {
     Fp<typename T::F> s, d, m;
-    fp_add(s, a.c0, a.c1);
-    fp_sub(d, a.c0, a.c1);
+    fp_add_nr(s, a.c0, a.c1);
+    fp_sub_nr<kfp2<T>()>(d, a.c0, a.c1);
     fp_mul(m, a.c0, a.c1);
     fp_mul(r.c0, s, d);
     fp_dbl(r.c1, m);
@@ -122,22 +129,22 @@ KYB_HD void fp6_mul(Fp6<T>& r, const Fp6<T>& a, const Fp6<T>& b) {
     fp2_mul(v0, a.c0, b.c0);
     fp2_mul(v1, a.c1, b.c1);
     fp2_mul(v2, a.c2, b.c2);
-    fp2_add(s, a.c1, a.c2);
-    fp2_add(u, b.c1, b.c2);
+    fp2_add_nr(s, a.c1, a.c2);
+    fp2_add_nr(u, b.c1, b.c2);
     fp2_mul(t0, s, u);
     fp2_sub(t0, t0, v1);
     fp2_sub(t0, t0, v2);
     fp2_mul_xi(t0, t0);
     fp2_add(t0, t0, v0);  // c0
-    fp2_add(s, a.c0, a.c1);
-    fp2_add(u, b.c0, b.c1);
+    fp2_add_nr(s, a.c0, a.c1);
+    fp2_add_nr(u, b.c0, b.c1);
     fp2_mul(t1, s, u);
     fp2_sub(t1, t1, v0);
     fp2_sub(t1, t1, v1);
     fp2_mul_xi(s, v2);
     fp2_add(t1, t1, s);  // c1
-    fp2_add(s, a.c0, a.c2);
-    fp2_add(u, b.c0, b.c2);
+    fp2_add_nr(s, a.c0, a.c2);
+    fp2_add_nr(u, b.c0, b.c2);
     fp2_mul(t2, s, u);
     fp2_sub(t2, t2, v0);
     fp2_sub(t2, t2, v2);
@@ -178,8 +185,8 @@ KYB_HD void fp6_mul_by_01(Fp6<T>& r, const Fp6<T>& a, const Fp2<T>& b0, const Fp
     fp2_mul(t0, a.c2, b1);
     fp2_mul_xi(t0, t0);
     fp2_add(t0, t0, v0);  // c0 = xi a2 b1 + a0 b0
-    fp2_add(s, a.c0, a.c1);
-    fp2_add(u, b0, b1);
+    fp2_add_nr(s, a.c0, a.c1);
+    fp2_add_nr(u, b0, b1);
     fp2_mul(t1, s, u);
     fp2_sub(t1, t1, v0);
     fp2_sub(t1, t1, v1);  // c1 = a0 b1 + a1 b0
@@ -233,6 +240,17 @@ KYB_HD_NOINLINE void fp6_inv(Fp6<T>& r, const Fp6<T>& a) {
     fp2_mul_c(r.c2, t2, d);
 }
 
+// Fp6 sum feeding an Fp6 multiplication: lazy where the field has the headroom for a third level
+template <class T>
+KYB_HD void fp6_add_pre(Fp6<T>& r, const Fp6<T>& a, const Fp6<T>& b) {
+    if constexpr (T::LAZY12) {
+        fp2_add_nr(r.c0, a.c0, b.c0);
+        fp2_add_nr(r.c1, a.c1, b.c1);
+        fp2_add_nr(r.c2, a.c2, b.c2);
+    } else {
+        fp6_add(r, a, b);
+    }
+}
 template <class T> KYB_HD_NOINLINE void fp6_mul_c(Fp6<T>& r, const Fp6<T>& a, const Fp6<T>& b) { fp6_mul(r, a, b); }
 template <class T> KYB_HD_NOINLINE void fp6_sqr_c(Fp6<T>& r, const Fp6<T>& a) { fp6_sqr(r, a); }
 
@@ -251,8 +269,8 @@ KYB_HD_NOINLINE void fp12_mul(Fp12<T>& r, const Fp12<T>& a, const Fp12<T>& b) {
     Fp6<T> v0, v1, s, u, t;
     fp6_mul(v0, a.c0, b.c0);
     fp6_mul(v1, a.c1, b.c1);
-    fp6_add(s, a.c0, a.c1);
-    fp6_add(u, b.c0, b.c1);
+    fp6_add_pre(s, a.c0, a.c1);
+    fp6_add_pre(u, b.c0, b.c1);
     fp6_mul(t, s, u);
     fp6_sub(t, t, v0);
     fp6_sub(r.c1, t, v1);
@@ -264,9 +282,9 @@ KYB_HD_NOINLINE void fp12_sqr(Fp12<T>& r, const Fp12<T>& a) {
     // complex squaring: 2 Fp6 multiplications
     Fp6<T> ab, s, u, t;
     fp6_mul(ab, a.c0, a.c1);
-    fp6_add(s, a.c0, a.c1);
+    fp6_add_pre(s, a.c0, a.c1);
     fp6_mul_v(t, a.c1);
-    fp6_add(u, a.c0, t);
+    fp6_add_pre(u, a.c0, t);
     fp6_mul(s, s, u);  // (a0 + a1)(a0 + v a1) = a0^2 + v a1^2 + (1 + v) a0 a1
     fp6_sub(s, s, ab);
     fp6_mul_v(t, ab);
@@ -292,8 +310,8 @@ KYB_HD_NOINLINE void fp12_mul_by_014(Fp12<T>& f, const Fp2<T>& o0, const Fp2<T>&
     Fp2<T> o;
     fp6_mul_by_01(aa, f.c0, o0, o1);
     fp6_mul_by_1(bb, f.c1, o4);
-    fp2_add(o, o1, o4);
-    fp6_add(s, f.c1, f.c0);
+    if constexpr (T::LAZY12) fp2_add_nr(o, o1, o4); else fp2_add(o, o1, o4);
+    fp6_add_pre(s, f.c1, f.c0);
     fp6_mul_by_01(t, s, o0, o);
     fp6_sub(t, t, aa);
     fp6_sub(f.c1, t, bb);
