@@ -358,6 +358,131 @@ KYB_HD_NOINLINE void gt_pow_u256(fp12& r, const fp12& a, const uint32_t (&k)[8])
     r = acc;
 }
 
+// ------------------------------------------------- GLV scalar multiplication on G1
+// G1 = E(Fp) has prime order n (cofactor 1), so phi(x, y) = (beta x, y) acts as [lambda] on every accepted point and
+// k P = k1 P + k2 phi(P) for the Babai-rounded split k = k1 + k2 lambda (mod n), |k1|, |k2| < 2^130 (constants and
+// their derivation: gen_consts.py bn256()).  34 windows of (4 doublings + 2 additions) instead of 65 x (4 + 1).
+// G2 keeps the plain ladder: its UnmarshalBinary accepts twist points outside the order-n subgroup, where the
+// Frobenius eigenvalue relation does not hold and the reference's double-and-add result must be reproduced.
+//
+// r (NR low words) = a (NA words) * b (NB words)
+template <int NR, int NA, int NB>
+KYB_HD void mul_words(uint32_t (&r)[NR], const uint32_t* a, const uint32_t* b) {
+    uint64_t acc = 0, hi = 0;
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+        // column k: sum a[i] b[k - i]; 96-bit accumulation in (hi : acc)
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int j = k - i;
+            if (j < 0 || j >= NB) continue;
+            const uint64_t pr = (uint64_t)a[i] * b[j];
+            acc += pr;
+            hi += acc < pr ? 1u : 0u;
+        }
+        r[k] = (uint32_t)acc;
+        acc = (acc >> 32) | (hi << 32);
+        hi = 0;
+    }
+}
+KYB_HD bool abs_words5(uint32_t (&x)[5]) {  // 160-bit two's complement -> magnitude, returns the sign
+    const bool neg = (x[4] >> 31) != 0;
+    uint32_t b = 0, t[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) t[i] = sbb32(0u, x[i], b);
+#pragma unroll
+    for (int i = 0; i < 5; i++) x[i] = neg ? t[i] : x[i];
+    return neg;
+}
+// k -> (|k1|, sign1, |k2|, sign2)
+KYB_HD void glv_split(uint32_t (&m1)[5], bool& n1, uint32_t (&m2)[5], bool& n2, const uint32_t (&k)[8]) {
+    uint32_t g1[3], g2[5], a1[2], a2[4], b1n[4], b2[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) g1[i] = CC::GLV_G1[i];
+#pragma unroll
+    for (int i = 0; i < 5; i++) g2[i] = CC::GLV_G2[i];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        a1[i] = CC::GLV_A1[i];
+        b2[i] = CC::GLV_B2[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        a2[i] = CC::GLV_A2[i];
+        b1n[i] = CC::GLV_B1N[i];
+    }
+    uint32_t p1[11], p2[13];
+    mul_words<11, 8, 3>(p1, k, g1);
+    mul_words<13, 8, 5>(p2, k, g2);
+    uint32_t c1[3] = {p1[8], p1[9], p1[10]};
+    uint32_t c2[5] = {p2[8], p2[9], p2[10], p2[11], p2[12]};
+    uint32_t t1[5], t2[5], t3[5], t4[5];
+    mul_words<5, 3, 2>(t1, c1, a1);   // c1 A1
+    mul_words<5, 5, 4>(t2, c2, a2);   // c2 A2
+    mul_words<5, 3, 4>(t3, c1, b1n);  // c1 |B1|
+    mul_words<5, 5, 2>(t4, c2, b2);   // c2 B2
+    uint32_t b = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) m1[i] = sbb32(k[i], t1[i], b);
+    b = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) m1[i] = sbb32(m1[i], t2[i], b);  // k1 = k - c1 A1 - c2 A2   (mod 2^160, |k1| < 2^130)
+    b = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) m2[i] = sbb32(t3[i], t4[i], b);  // k2 = c1 |B1| - c2 B2
+    n1 = abs_words5(m1);
+    n2 = abs_words5(m2);
+}
+KYB_HD_NOINLINE void g1_mul_glv(g1_jac& r, const g1_jac& p, const uint32_t (&k)[8]) {
+    uint32_t m1[5], m2[5];
+    bool n1, n2;
+    glv_split(m1, n1, m2, n2, k);
+    uint32_t w1[8], w2[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        w1[i] = i < 5 ? m1[i] : 0u;
+        w2[i] = i < 5 ? m2[i] : 0u;
+    }
+    int8_t e1[65], e2[65];
+    recode16_u256(e1, w1);
+    recode16_u256(e2, w2);
+    g1_jac tab[8];  // (j + 1) * P
+    tab[0] = p;
+    jac_dbl(tab[1], p);
+#pragma unroll 1
+    for (int j = 2; j < 8; j++) jac_add(tab[j], tab[j - 1], p);
+    fp beta;
+    fp_const(beta, CC::BETA);
+    g1_jac acc, t, s;
+    jac_set_inf(acc);
+#pragma unroll 1
+    for (int i = 33; i >= 0; i--) {
+        if (i != 33) {
+            jac_dbl(acc, acc);
+            jac_dbl(acc, acc);
+            jac_dbl(acc, acc);
+            jac_dbl(acc, acc);
+        }
+        int d = n1 ? -e1[i] : e1[i];
+        int ad = d < 0 ? -d : d;
+        t = tab[ad ? ad - 1 : 0];
+        fp ny;
+        fp_neg(ny, t.Y);
+        fp_cmov(t.Y, ny, d < 0);
+        jac_add(s, acc, t);
+        jac_cmov(acc, s, d != 0);
+        d = n2 ? -e2[i] : e2[i];
+        ad = d < 0 ? -d : d;
+        t = tab[ad ? ad - 1 : 0];
+        fp_neg(ny, t.Y);
+        fp_cmov(t.Y, ny, d < 0);
+        fp_mul(t.X, t.X, beta);
+        jac_add(s, acc, t);
+        jac_cmov(acc, s, d != 0);
+    }
+    r = acc;
+}
+
 // ------------------------------------------------- per-element wire-level operations
 KYB_HD void zero_bytes(uint8_t* out, int n) {
     uint32_t* q = reinterpret_cast<uint32_t*>(out);
@@ -374,7 +499,7 @@ KYB_HD int g1_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt
     words_from_be<8>(k, scalar_be);
     g1_jac p, r;
     jac_from_aff(p, a);
-    jac_mul_u256(r, p, k);
+    g1_mul_glv(r, p, k);
     jac_to_aff(a, r);
     g1_encode(out, a);
     return ST_OK;

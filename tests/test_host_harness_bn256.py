@@ -126,3 +126,24 @@ def test_hash_g1_reference_fixtures_and_lengths(G):
     for ln in (0, 1, 54, 55, 56, 57, 63, 64, 65, 119, 120, 121, 200):
         msg = bytes((7 * i + ln) & 0xFF for i in range(ln))
         assert H.call("hh_bn_hash_g1", msg or b"\\x00", ln, out_sizes=(64,))[1] == O.g1_marshal(O.hash_to_g1(msg)), ln
+
+
+def test_g1_glv_split_edge_scalars():
+    """G1 multiplication goes through the GLV split k = k1 + k2 lambda (Babai rounding with 2^256 fixed-point
+    constants): scalars at the rounding boundaries, >= n, and random ones, against the plain big-int oracle."""
+    rng = random.Random(9)
+    n = O.ORDER
+    u = 1868033 ** 3
+    lam = 36 * u ** 3 + 18 * u ** 2 + 6 * u + 1
+    a2 = 254952053719217182022156415784332439563
+    edge = [0, 1, 2, 15, 16, n - 1, n, n + 1, lam - 1, lam, lam + 1, a2 - 1, a2, a2 + 1, (1 << 128) - 1, 1 << 128,
+            (1 << 256) - 1, 1 << 255, (1 << 256) - n, 3 * lam, n // 2, n // 2 + 1, a2 * a2 % (1 << 256)]
+    ks = edge + [rng.randrange(1 << 256) for _ in range(60)]
+    h = 0xABCDEF123
+    P = O.g1_mul(h, O.G1_GEN)
+    pb = O.g1_marshal(P)
+    for k in ks:
+        kb = k.to_bytes(32, "big")
+        assert H.call("hh_bn_g1_mul", kb, pb, out_sizes=(64,)) == (0, O.g1_marshal(O.g1_mul(k % n, P))), hex(k)
+    inf = O.g1_marshal(None)
+    assert H.call("hh_bn_g1_mul", (77).to_bytes(32, "big"), inf, out_sizes=(64,)) == (0, inf)
