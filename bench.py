@@ -288,7 +288,21 @@ def main():
     if world > 1 or os.environ.get("KYB_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner on stdout when its first communicator comes up: keep stdout for the one JSON
+        # line by pointing fd 1 at stderr until a first collective has run
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            warm = torch.zeros(1, device="cuda")
+            dist.all_reduce(warm)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from kyber_amd.group import edwards25519 as ed

@@ -35,16 +35,30 @@ def _unit_scalars(world: int, little_endian: bool) -> np.ndarray:
     return s
 
 
+def _tree_sum(points: np.ndarray, add_fn: Callable):
+    """Sum the rows of `points` (encoded group elements) with log2(n) batched Point.Add calls.  Returns (enc, ok)."""
+    pts = np.ascontiguousarray(points)
+    ok = True
+    while pts.shape[0] > 1:
+        m = pts.shape[0] // 2
+        out, st = add_fn(pts[0:2 * m:2].copy(), pts[1:2 * m:2].copy())
+        ok = ok and not bool(np.asarray(st).any())
+        out = np.asarray(out).reshape(m, -1)
+        pts = np.concatenate([out, pts[2 * m:]], axis=0) if pts.shape[0] % 2 else out
+    return pts[0], ok
+
+
 def msm_allgather(scalars_shard, points_shard, local_msm: Callable, point_len: int, little_endian: bool,
-                  group=None, combine_msm: Callable | None = None):
+                  group=None, combine_msm: Callable | None = None, combine_add: Callable | None = None):
     """Node-wide MSM over the shards held by the ranks of `group`.
 
     scalars_shard / points_shard: this rank's slice (host numpy/bytes, or CUDA uint8 tensors when
     the backend is nccl).  local_msm(scalars, points) -> (encoded_point, status) is the single-GPU
     MSM (e.g. ``edwards25519.msm`` or ``bls12381.g1_msm``).  Returns (encoded_point, ok) where
     ok is False iff any rank rejected an input (then the point is all-zero bytes), identical on
-    every rank.  combine_msm (default: local_msm) sums the gathered partial points; the suite wrappers below pass
-    one that marks its inputs as trusted, since the partials are outputs of this library."""
+    every rank.  The gathered partial points (one per rank) are summed by combine_add -- a batched Point.Add used as a
+    log2(world) tree, ~0.1 ms -- when given, else by combine_msm (default: local_msm) with unit scalars (a full
+    pipeline launch: ~2 ms of fixed latency for a handful of points)."""
     import torch
     import torch.distributed as dist
 
@@ -67,6 +81,9 @@ def msm_allgather(scalars_shard, points_shard, local_msm: Callable, point_len: i
         zero = torch.zeros(point_len, dtype=torch.uint8, device=dev)
         return (zero if is_t else zero.numpy()), False
     pts = allp[:, :point_len].contiguous()
+    if combine_add is not None:
+        enc, ok = _tree_sum(pts.cpu().numpy(), combine_add)
+        return (torch.from_numpy(np.ascontiguousarray(enc)).to(dev) if is_t else enc), ok
     ones = _unit_scalars(world, little_endian)
     if is_t:
         out, st2 = combine_msm(torch.from_numpy(ones).to(dev), pts)
@@ -80,40 +97,36 @@ def msm_allgather(scalars_shard, points_shard, local_msm: Callable, point_len: i
 def ed25519_msm(scalars_shard, points_shard, group=None):
     from .group import edwards25519 as ed
 
-    return msm_allgather(scalars_shard, points_shard, ed.msm, 32, True, group)
+    return msm_allgather(scalars_shard, points_shard, ed.msm, 32, True, group, combine_add=ed.batch_add)
 
 
 def bls12381_g1_msm(scalars_shard, points_shard, group=None, flags: int = 0):
     """flags: the shard's input flags (F_TRUSTED(0) / F_UNCOMPRESSED, kyber_amd.pairing._engine)."""
     from .pairing import bls12381 as m
-    from .pairing._engine import F_TRUSTED
 
     return msm_allgather(scalars_shard, points_shard, lambda s, p: m.g1_msm(s, p, flags), m.G1_LEN, False, group,
-                         combine_msm=lambda s, p: m.g1_msm(s, p, F_TRUSTED(0)))
+                         combine_add=lambda a, b: m.ENGINE.add(1, a, b))
 
 
 def bls12381_g2_msm(scalars_shard, points_shard, group=None, flags: int = 0):
     """flags: the shard's input flags (F_TRUSTED(0) / F_UNCOMPRESSED, kyber_amd.pairing._engine)."""
     from .pairing import bls12381 as m
-    from .pairing._engine import F_TRUSTED
 
     return msm_allgather(scalars_shard, points_shard, lambda s, p: m.g2_msm(s, p, flags), m.G2_LEN, False, group,
-                         combine_msm=lambda s, p: m.g2_msm(s, p, F_TRUSTED(0)))
+                         combine_add=lambda a, b: m.ENGINE.add(2, a, b))
 
 
 def bn256_g1_msm(scalars_shard, points_shard, group=None, flags: int = 0):
     """flags: the shard's input flags (F_TRUSTED(0) / F_UNCOMPRESSED, kyber_amd.pairing._engine)."""
     from .pairing import bn256 as m
-    from .pairing._engine import F_TRUSTED
 
     return msm_allgather(scalars_shard, points_shard, lambda s, p: m.g1_msm(s, p, flags), m.G1_LEN, False, group,
-                         combine_msm=lambda s, p: m.g1_msm(s, p, F_TRUSTED(0)))
+                         combine_add=lambda a, b: m.ENGINE.add(1, a, b))
 
 
 def bn256_g2_msm(scalars_shard, points_shard, group=None, flags: int = 0):
     """flags: the shard's input flags (F_TRUSTED(0) / F_UNCOMPRESSED, kyber_amd.pairing._engine)."""
     from .pairing import bn256 as m
-    from .pairing._engine import F_TRUSTED
 
     return msm_allgather(scalars_shard, points_shard, lambda s, p: m.g2_msm(s, p, flags), m.G2_LEN, False, group,
-                         combine_msm=lambda s, p: m.g2_msm(s, p, F_TRUSTED(0)))
+                         combine_add=lambda a, b: m.ENGINE.add(2, a, b))

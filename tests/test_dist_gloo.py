@@ -50,6 +50,27 @@ def _oracle_bls_g1_msm(scalars, points):
     return np.frombuffer(out, dtype=np.uint8).copy(), st
 
 
+def _oracle_bls_g1_add(a, b):
+    """Batched Point.Add stand-in (what Engine.add does on the device) for the tree combine."""
+    from oracle import bls12381 as O
+
+    a = np.asarray(a, dtype=np.uint8).reshape(-1, 48)
+    b = np.asarray(b, dtype=np.uint8).reshape(-1, 48)
+    out = np.stack([np.frombuffer(O.g1_compress(O.g1_add(O.g1_decompress(bytes(x)), O.g1_decompress(bytes(y)))),
+                                  dtype=np.uint8) for x, y in zip(a, b)])
+    return out, np.zeros(len(a), dtype=np.uint8)
+
+
+def test_tree_sum_odd_and_even_counts():
+    from oracle import bls12381 as O
+
+    pts = [O.g1_mul(k, O.G1_GEN) for k in (3, 5, 7, 11, 13, 17, 19)]
+    enc = np.stack([np.frombuffer(O.g1_compress(p), dtype=np.uint8) for p in pts])
+    for m in (1, 2, 3, 4, 7):
+        out, ok = kd._tree_sum(enc[:m], _oracle_bls_g1_add)
+        assert ok and bytes(out) == O.g1_compress(O.g1_mul(sum((3, 5, 7, 11, 13, 17, 19)[:m]), O.G1_GEN))
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -84,6 +105,9 @@ def _worker(rank, world, port, q):
         out, ok = kd.msm_allgather(kb[lo:hi], pb[lo:hi], _oracle_bls_g1_msm, 48, False)
         exp = OB.g1_msm_bytes([k.to_bytes(32, "big") for k in ks], pts)
         res["bls_ok"] = bool(ok) and bytes(out) == exp
+        # the same exchange with the partial points combined by the batched-add tree (what the suite wrappers use)
+        out, ok = kd.msm_allgather(kb[lo:hi], pb[lo:hi], _oracle_bls_g1_msm, 48, False, combine_add=_oracle_bls_g1_add)
+        res["bls_tree_ok"] = bool(ok) and bytes(out) == exp
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
