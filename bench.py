@@ -274,6 +274,9 @@ def main():
     ap.add_argument("--n", type=int, default=N_PER_GPU, help="elements per GPU (default 2^20)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other", action="store_true", help="skip the pairing / MSM side measurements")
+    ap.add_argument("--no-host-path", action="store_true",
+                    help="skip the host-buffer (PCIe-inclusive) measurement, whose chunked launches of the same "
+                         "kernels would blur per-kernel averages in a rocprofv3 trace")
     args = ap.parse_args()
 
     import torch
@@ -357,7 +360,7 @@ def main():
 
     # PCIe-inclusive rate of the host-buffer entry points (allocate, H2D, kernels, D2H, free): reported, never `value`
     host_rate = None
-    if rank == 0:
+    if rank == 0 and not args.no_host_path:
         t0 = time.perf_counter()
         o1 = ed.batch_mul_base(s_h)
         o2, st_h = ed.batch_mul(s_h, o1)

@@ -7,9 +7,9 @@ python -c "
 import sys, os; sys.path.insert(0, os.getcwd())
 import __graft_entry__ as g; g.smoke()" > gpurun_out/final/smoke.log 2>&1; tail -1 gpurun_out/final/smoke.log
 timeout 900 python bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err; tail -2 gpurun_out/final/bench.err; cat gpurun_out/final/bench.json
-B="python bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+B="python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-host-path"
 timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/final -o bench_trace -- $B > gpurun_out/final/bench_trace.log 2>&1
-B2="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other"
+B2="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other --no-host-path"
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/final -o ed_fetch -- $B2 > gpurun_out/final/ed_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/final -o ed_write -- $B2 > gpurun_out/final/ed_write.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -d gpurun_out/final -o ed_sq -- $B2 > gpurun_out/final/ed_sq.log 2>&1
