@@ -28,9 +28,9 @@ using g2_jac = Jac<fp2>;
 
 constexpr int ST_OK = 0, ST_BAD_POINT = 1, ST_NOT_IN_SUBGROUP = 2;
 
-KYB_HD void fp_const(fp& r, const uint32_t (&c)[FC::N]) {
+KYB_HD void fp_const(fp& r, const uint32_t (&c)[FC::NWORDS]) {
 #pragma unroll
-    for (int l = 0; l < FC::N; l++) r.v[l] = c[l];
+    for (int l = 0; l < FC::NWORDS; l++) r.v[l] = c[l];
 }
 
 // y > (p - 1) / 2 on the canonical value

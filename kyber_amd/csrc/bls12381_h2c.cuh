@@ -125,7 +125,7 @@ KYB_HD_NOINLINE void g1_sswu(fp& x, fp& y, const fp& u) {
     x = x1;
 }
 template <int LEN>
-KYB_HD void fp_horner(fp& r, const uint32_t (&c)[LEN][13], const fp& x) {
+KYB_HD void fp_horner(fp& r, const uint32_t (&c)[LEN][FC::NWORDS], const fp& x) {
     fp acc, k;
     fp_const(acc, c[LEN - 1]);
 #pragma unroll 1
@@ -244,7 +244,7 @@ KYB_HD_NOINLINE void g2_sswu(fp2& x, fp2& y, const fp2& u) {
     x = x1;
 }
 template <int LEN>
-KYB_HD void fp2_horner(fp2& r, const uint32_t (&c)[LEN][2][13], const fp2& x) {
+KYB_HD void fp2_horner(fp2& r, const uint32_t (&c)[LEN][2][FC::NWORDS], const fp2& x) {
     fp2 acc, k;
     fp2_load_const<TC>(acc, c[LEN - 1]);
 #pragma unroll 1

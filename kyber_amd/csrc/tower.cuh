@@ -326,9 +326,9 @@ KYB_HD Fp2<T>& fp12_coeff(Fp12<T>& a, int j) {
     return (j >> 1) == 0 ? h.c0 : ((j >> 1) == 1 ? h.c1 : h.c2);
 }
 template <class T>
-KYB_HD void fp2_load_const(Fp2<T>& r, const uint32_t (&c)[2][T::F::N]) {
+KYB_HD void fp2_load_const(Fp2<T>& r, const uint32_t (&c)[2][T::F::NWORDS]) {
 #pragma unroll
-    for (int l = 0; l < T::F::N; l++) {
+    for (int l = 0; l < T::F::NWORDS; l++) {
         r.c0.v[l] = c[0][l];
         r.c1.v[l] = c[1][l];
     }

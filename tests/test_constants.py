@@ -53,16 +53,18 @@ def _check_field(P, fname):
     R = 1 << (n * w)
     assert _val(arr["P"][0], w) == P
     assert all(l < (1 << w) for l in arr["P"][0])
-    assert _val(arr["ONE"][0], w) == R % P
-    assert _val(arr["R2"][0], w) == R * R % P
+    # elements are stored as NWORDS saturated 32-bit words (the multiplier alone works on the W-bit limbs of P)
+    assert _val(arr["PW"][0], 32) == P and len(arr["PW"][0]) == nwords
+    assert _val(arr["ONE"][0], 32) == R % P
+    assert _val(arr["R2"][0], 32) == R * R % P
     ninv = int(re.search(r"NINV = (0x[0-9a-f]+)u", open(os.path.join(CSRC, fname)).read()).group(1), 16)
     assert (ninv * P + 1) % (1 << w) == 0
     assert _val(arr["PM2"][0], 32) == P - 2
     assert _val(arr["HALF"][0], 32) == (P - 1) // 2
     assert _val(arr["SQRT_EXP"][0], 32) == (P + 1) // 4
     assert _val(arr["PM3D4"][0], 32) == (P - 3) // 4
-    assert _val(arr["INV2"][0], w) * 2 % P == R % P
-    return arr, R, w, n
+    assert _val(arr["INV2"][0], 32) * 2 % P == R % P
+    return arr, R, 32, nwords
 
 
 def test_bls12381_params():

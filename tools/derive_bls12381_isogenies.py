@@ -228,25 +228,25 @@ def main():
          "namespace kyb {", "struct Bls12381H2c {"]
     neg_b_over_a = (-g1["B"] * pow(g1["A"], -1, p)) % p
     b_over_za = g1["B"] * pow(g1["Z"] * g1["A"], -1, p) % p
-    H += [f"    static constexpr uint32_t TWO384[13] = {m1(pow(2, 384, p))};  // 2^384 mod p (hash_to_field: 512-bit -> Fp)",
-          f"    static constexpr uint32_t G1_A[13] = {m1(g1['A'])};",
-          f"    static constexpr uint32_t G1_B[13] = {m1(g1['B'])};",
-          f"    static constexpr uint32_t G1_Z[13] = {m1(g1['Z'])};",
-          f"    static constexpr uint32_t G1_NEG_B_OVER_A[13] = {m1(neg_b_over_a)};",
-          f"    static constexpr uint32_t G1_B_OVER_ZA[13] = {m1(b_over_za)};"]
+    H += [f"    static constexpr uint32_t TWO384[12] = {m1(pow(2, 384, p))};  // 2^384 mod p (hash_to_field: 512-bit -> Fp)",
+          f"    static constexpr uint32_t G1_A[12] = {m1(g1['A'])};",
+          f"    static constexpr uint32_t G1_B[12] = {m1(g1['B'])};",
+          f"    static constexpr uint32_t G1_Z[12] = {m1(g1['Z'])};",
+          f"    static constexpr uint32_t G1_NEG_B_OVER_A[12] = {m1(neg_b_over_a)};",
+          f"    static constexpr uint32_t G1_B_OVER_ZA[12] = {m1(b_over_za)};"]
     for nm, c in zip(names, g1["maps"]):
         H.append(f"    static constexpr int G1_{nm}_LEN = {len(c)};")
-        H.append(f"    static constexpr uint32_t G1_{nm}[{len(c)}][13] = {{" + ", ".join(m1(v) for v in c) + "};")
+        H.append(f"    static constexpr uint32_t G1_{nm}[{len(c)}][12] = {{" + ", ".join(m1(v) for v in c) + "};")
     nba2 = O.f2_mul(O.f2_neg(g2["B"]), O.f2_inv(g2["A"]))
     bza2 = O.f2_mul(g2["B"], O.f2_inv(O.f2_mul(g2["Z"], g2["A"])))
-    H += [f"    static constexpr uint32_t G2_A[2][13] = {m2(g2['A'])};",
-          f"    static constexpr uint32_t G2_B[2][13] = {m2(g2['B'])};",
-          f"    static constexpr uint32_t G2_Z[2][13] = {m2(g2['Z'])};",
-          f"    static constexpr uint32_t G2_NEG_B_OVER_A[2][13] = {m2(nba2)};",
-          f"    static constexpr uint32_t G2_B_OVER_ZA[2][13] = {m2(bza2)};"]
+    H += [f"    static constexpr uint32_t G2_A[2][12] = {m2(g2['A'])};",
+          f"    static constexpr uint32_t G2_B[2][12] = {m2(g2['B'])};",
+          f"    static constexpr uint32_t G2_Z[2][12] = {m2(g2['Z'])};",
+          f"    static constexpr uint32_t G2_NEG_B_OVER_A[2][12] = {m2(nba2)};",
+          f"    static constexpr uint32_t G2_B_OVER_ZA[2][12] = {m2(bza2)};"]
     for nm, c in zip(names, g2["maps"]):
         H.append(f"    static constexpr int G2_{nm}_LEN = {len(c)};")
-        H.append(f"    static constexpr uint32_t G2_{nm}[{len(c)}][2][13] = {{" + ", ".join(m2(v) for v in c) + "};")
+        H.append(f"    static constexpr uint32_t G2_{nm}[{len(c)}][2][12] = {{" + ", ".join(m2(v) for v in c) + "};")
     H += ["};", "}  // namespace kyb", ""]
     open(os.path.join(ROOT, "kyber_amd", "csrc", "bls12381_h2c_params.h"), "w").write("\n".join(H))
     print("wrote oracle/bls12381_h2c_consts.py and kyber_amd/csrc/bls12381_h2c_params.h",
