@@ -98,7 +98,7 @@ struct Split<A, decltype((void)A::SPLIT)> {
 };
 
 template <class A>
-__global__ __launch_bounds__(64) void decode_kernel(Plan p, size_t n_in, const uint8_t* __restrict__ scalars,
+__global__ __launch_bounds__(64, 2) void decode_kernel(Plan p, size_t n_in, const uint8_t* __restrict__ scalars,
                                                     const uint8_t* __restrict__ points,
                                                     typename A::Aff* __restrict__ aff, int32_t* __restrict__ digits,
                                                     uint32_t* __restrict__ hist, uint8_t* __restrict__ status,
