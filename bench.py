@@ -405,7 +405,7 @@ def main():
                                   "peak": imad_peak, "unit": "v_mad_i64_i32 lane-ops/s",
                                   "frac": (IMADS_VAR * n / var_s / imad_peak) if imad_peak else None,
                                   "peak_source": "tools/valu_peak.hip measured on MI355X (profiles/r01_valu_peak_v2.json, pure v_mad_u64_u32 chains)",
-                                  "valu_busy_frac_profiled": 0.87}},
+                                  "valu_busy_frac_profiled": 0.99}},
         }
         if other is not None:
             res["other_workloads"] = other
