@@ -230,7 +230,7 @@ int kyb_bn256_pair_check_dev(size_t n, const void *d_p1, const void *d_p2, const
  * (sign/bdn/bdn.go:126-181, mask.go:57-61).  Encodings are canonical, so the Pippenger result is
  * byte-identical to that sequential sum.  status[i] reports undecodable inputs; if any input is
  * rejected the output is all-zero bytes.  n == 0 yields the encoding of the identity.
- * The _dev variants use the per-device workspace: one MSM in flight per device at a time.        */
+ * The _dev variants work in a grow-only workspace per (device, stream).                            */
 int kyb_ed25519_msm(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t out[32], uint8_t *status);
 int kyb_ed25519_msm_dev(size_t n, const void *d_scalars, const void *d_points, void *d_out, void *d_status,
                         void *stream);

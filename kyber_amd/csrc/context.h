@@ -5,8 +5,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <map>
 #include <mutex>
 #include <string>
+#include <utility>
 
 #include "../../include/kyber_hip.h"
 
@@ -31,12 +33,14 @@ struct DeviceCtx {
     std::mutex msm_mu;  // serialises host-buffer MSM calls (they share the workspace)
     // Ed25519 fixed-base table: [33][8][3][10] int32 (built on device at init)
     int32_t* ed_base_tab = nullptr;
-    // Ed25519 deferred-encoding workspace: parked (X, Y, Z) triples of the last large batch
-    void* ed_proj = nullptr;
-    size_t ed_proj_bytes = 0;
-    // scratch workspace (the MSM pipeline lives in it)
-    void* ws = nullptr;
-    size_t ws_bytes = 0;
+    // Grow-only device workspaces, one per (kind, stream): calls enqueued on one stream are ordered and reuse their
+    // stream's buffer; calls on different streams never share one.  Kinds: WS_MSM (the Pippenger pipeline's arrays),
+    // WS_ED (Ed25519 parked (X, Y, Z) triples and per-lane window tables of a large batch).
+    struct StreamBuf {
+        void* p = nullptr;
+        size_t cap = 0;
+    };
+    std::map<std::pair<int, hipStream_t>, StreamBuf> sws;
     // grow-only device staging buffers of the host-buffer entry points (no hipMalloc / hipFree per call);
     // stage_mu serialises those calls per device -- they synchronise the device anyway
     static constexpr int NSTAGE = 8;
@@ -49,8 +53,9 @@ struct DeviceCtx {
 
 // Context for the calling thread's current device (created on first use).
 int get_ctx(DeviceCtx** out);
-// Grow (never shrink) the context's workspace; caller holds no lock.
-int ctx_workspace(DeviceCtx* ctx, size_t bytes, void** out);
+enum { WS_MSM = 0, WS_ED = 1 };
+// Grow (never shrink) the (kind, stream) workspace; caller holds no lock.
+int ctx_workspace(DeviceCtx* ctx, int kind, hipStream_t stream, size_t bytes, void** out);
 
 // A host-buffer call: holds the device's staging pool for its duration and hands out slots in order.
 struct StageScope {

@@ -42,23 +42,24 @@ int get_ctx(DeviceCtx** out) {
     return KYB_OK;
 }
 
-int ctx_workspace(DeviceCtx* ctx, size_t bytes, void** out) {
+int ctx_workspace(DeviceCtx* ctx, int kind, hipStream_t stream, size_t bytes, void** out) {
     std::lock_guard<std::mutex> lk(ctx->mu);
-    if (bytes > ctx->ws_bytes) {
-        if (ctx->ws) {
+    DeviceCtx::StreamBuf& b = ctx->sws[std::make_pair(kind, stream)];
+    if (bytes > b.cap) {
+        if (b.p) {
             KYB_HIP_CHECK(hipDeviceSynchronize());
-            KYB_HIP_CHECK(hipFree(ctx->ws));
-            ctx->ws = nullptr;
-            ctx->ws_bytes = 0;
+            KYB_HIP_CHECK(hipFree(b.p));
+            b.p = nullptr;
+            b.cap = 0;
         }
-        size_t want = bytes + bytes / 4;
-        if (hipMalloc(&ctx->ws, want) != hipSuccess) {
+        const size_t want = bytes + bytes / 4 + 256;
+        if (hipMalloc(&b.p, want) != hipSuccess) {
             set_error("workspace hipMalloc failed");
             return KYB_E_ALLOC;
         }
-        ctx->ws_bytes = want;
+        b.cap = want;
     }
-    *out = ctx->ws;
+    *out = b.p;
     return KYB_OK;
 }
 
@@ -86,7 +87,8 @@ int kyb_shutdown(void) {
         kyb::DeviceCtx* c = kv.second;
         hipSetDevice(c->device);
         kyb::ed25519_free_tables(c);
-        if (c->ws) hipFree(c->ws);
+        for (auto& w : c->sws)
+            if (w.second.p) hipFree(w.second.p);
         for (int i = 0; i < kyb::DeviceCtx::NSTAGE; i++)
             if (c->stage[i]) hipFree(c->stage[i]);
         for (int i = 0; i < 3; i++)

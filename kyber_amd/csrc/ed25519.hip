@@ -355,41 +355,25 @@ int ed25519_build_tables(DeviceCtx* ctx) {
 void ed25519_free_tables(DeviceCtx* ctx) {
     if (ctx->ed_base_tab) hipFree(ctx->ed_base_tab);
     ctx->ed_base_tab = nullptr;
-    if (ctx->ed_proj) hipFree(ctx->ed_proj);
-    ctx->ed_proj = nullptr;
-    ctx->ed_proj_bytes = 0;
 }
 
 // Batches of at least this many elements take the deferred-encoding path (below it the extra launch costs
 // more than the inversions it saves).
 constexpr size_t ENC_DEFER_MIN = 4096;
 
-// Grow-only per-device buffer for the parked (X, Y, Z) triples (+ a status array when the caller passes none).
-// Like the MSM workspace it is shared by all Ed25519 calls on the device: calls on one stream are ordered, and
-// concurrent streams on the same device must not interleave Ed25519 batches larger than ENC_DEFER_MIN.
-static int ed_proj_workspace(DeviceCtx* ctx, size_t n, bool need_status, int32_t** proj, uint8_t** status,
-                             int4** gtab = nullptr) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+// Grow-only per-stream buffer (context.h WS_ED) for the window tables, the parked (X, Y, Z) triples and a status
+// array when the caller passes none: calls on one stream are ordered and reuse it, other streams have their own.
+static int ed_proj_workspace(DeviceCtx* ctx, hipStream_t st, size_t n, bool need_status, int32_t** proj,
+                             uint8_t** status, int4** gtab = nullptr) {
     // [ window tables: n x 1280 B (variable-base only) | (X, Y, Z): n x 120 B | status: n ]
     const size_t tab_bytes = gtab ? n * 1280 : 0;
     const size_t want = tab_bytes + n * 30 * sizeof(int32_t) + (need_status ? n : 0) + 256;
-    if (want > ctx->ed_proj_bytes) {
-        if (ctx->ed_proj) {
-            KYB_HIP_CHECK(hipDeviceSynchronize());
-            KYB_HIP_CHECK(hipFree(ctx->ed_proj));
-            ctx->ed_proj = nullptr;
-            ctx->ed_proj_bytes = 0;
-        }
-        const size_t cap = want + want / 4;
-        if (hipMalloc(&ctx->ed_proj, cap) != hipSuccess) {
-            set_error("ed25519: projective workspace allocation failed");
-            return KYB_E_ALLOC;
-        }
-        ctx->ed_proj_bytes = cap;
-    }
-    if (gtab) *gtab = (int4*)ctx->ed_proj;
-    *proj = (int32_t*)((uint8_t*)ctx->ed_proj + tab_bytes);
-    if (status) *status = (uint8_t*)ctx->ed_proj + tab_bytes + n * 30 * sizeof(int32_t);
+    void* base;
+    int rc = ctx_workspace(ctx, WS_ED, st, want, &base);
+    if (rc) return rc;
+    if (gtab) *gtab = (int4*)base;
+    *proj = (int32_t*)((uint8_t*)base + tab_bytes);
+    if (status) *status = (uint8_t*)base + tab_bytes + n * 30 * sizeof(int32_t);
     return KYB_OK;
 }
 
@@ -402,7 +386,7 @@ static int launch_mul_base(DeviceCtx* ctx, size_t n, const void* d_scalars, void
     int grid = (int)(want < cap ? want : cap);
     int32_t* proj = nullptr;
     if (n >= ENC_DEFER_MIN) {
-        int rc = ed_proj_workspace(ctx, n, false, &proj, nullptr);
+        int rc = ed_proj_workspace(ctx, st, n, false, &proj, nullptr);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(ed25519_mul_base_kernel, dim3(grid), dim3(block), 0, st, n,
@@ -427,7 +411,7 @@ static int launch_mul(size_t n, const void* d_scalars, const void* d_points, siz
         DeviceCtx* ctx;
         int rc = get_ctx(&ctx);
         if (rc) return rc;
-        rc = ed_proj_workspace(ctx, n, stat == nullptr, &proj, stat ? nullptr : &stat, &gtab);
+        rc = ed_proj_workspace(ctx, st, n, stat == nullptr, &proj, stat ? nullptr : &stat, &gtab);
         if (rc) return rc;
         hipLaunchKernelGGL(ed25519_mul_kernel<true>, dim3((unsigned)grid), dim3(block), 0, st, n,
                            (const uint32_t*)d_scalars, (const uint32_t*)d_points, stride, (uint32_t*)d_out, stat, flags,

@@ -533,7 +533,7 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     const size_t o_tile = take(sizeof(uint32_t) * ((nbk + SCAN_TILE - 1) / SCAN_TILE + 2));
     const size_t o_winsum = take(sizeof(typename A::Acc) * p.nwin);
     void* ws;
-    int rc = ctx_workspace(ctx, off, &ws);
+    int rc = ctx_workspace(ctx, WS_MSM, st, off, &ws);
     if (rc) return rc;
     uint8_t* base = (uint8_t*)ws;
     auto* aff = (typename A::Aff*)(base + o_aff);

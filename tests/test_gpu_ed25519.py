@@ -210,3 +210,37 @@ def test_hash_to_curve_rfc9380_vectors(ed):
         assert bytes(out[i]) == O.hash_to_curve(msgs[i], b"kyber-test-DST")
     with pytest.raises(Exception):
         ed.batch_hash(msgs[:1], b"")  # the reference rejects an empty domain separator (point.go:365)
+
+
+def test_two_streams_do_not_share_workspaces(ed):
+    """Large batches park window tables / projective results (and MSMs their pipeline arrays) in per-(device, stream)
+    workspaces: the same calls issued back to back on two streams, without synchronising in between, must give what
+    they give one after the other."""
+    import torch
+
+    n = 1 << 14
+    rng = np.random.default_rng(11)
+    sa = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    sb = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    sa[:, 31] &= 0x7F
+    sb[:, 31] &= 0x7F
+    ha = sa.copy()
+    ha[:, 31] &= 0x0F
+    dsa, dsb = torch.from_numpy(sa).cuda(), torch.from_numpy(sb).cuda()
+    pts = ed.batch_mul_base(torch.from_numpy(ha).cuda())
+    ref_a, _ = ed.batch_mul(dsa, pts)
+    ref_b, _ = ed.batch_mul(dsb, pts)
+    ref_ma, _ = ed.msm(dsa, pts)
+    ref_mb, _ = ed.msm(dsb, pts)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            out_a, _ = ed.batch_mul(dsa, pts)
+            m_a, _ = ed.msm(dsa, pts)
+        with torch.cuda.stream(s2):
+            out_b, _ = ed.batch_mul(dsb, pts)
+            m_b, _ = ed.msm(dsb, pts)
+        torch.cuda.synchronize()
+        assert torch.equal(out_a, ref_a) and torch.equal(out_b, ref_b)
+        assert torch.equal(m_a, ref_ma) and torch.equal(m_b, ref_mb)
