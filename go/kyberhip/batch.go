@@ -1,0 +1,184 @@
+// Batch helpers over kyber's own interfaces: they marshal []kyber.Scalar / []kyber.Point of ANY suite whose
+// encodings are the reference's (group/edwards25519, pairing/bls12381/*, pairing/bn256), run one engine call, and
+// unmarshal the results back into points of that same suite -- so every other method of the returned values is the
+// reference's own.  This is the smallest possible integration: the MSM-shaped loops of share/poly.go and
+// sign/bdn/bdn.go call these instead of n x (Mul + Add); see INTEGRATION.md for the patches.
+//
+// NOT COMPILED in the repository that ships it (no Go toolchain there).
+//
+//go:build hip
+
+package kyberhip
+
+import (
+	"errors"
+	"fmt"
+
+	"go.dedis.ch/kyber/v4"
+)
+
+// Kind selects the engine entry points for a kyber.Group.
+type Kind int
+
+const (
+	Ed25519 Kind = iota
+	Bls12381G1
+	Bls12381G2
+	Bn256G1
+	Bn256G2
+)
+
+func marshalAll[T interface{ MarshalBinary() ([]byte, error) }](xs []T, size int) ([]byte, error) {
+	buf := make([]byte, 0, size*len(xs))
+	for _, x := range xs {
+		b, err := x.MarshalBinary()
+		if err != nil {
+			return nil, err
+		}
+		if len(b) != size {
+			return nil, fmt.Errorf("kyberhip: %d-byte encoding, want %d", len(b), size)
+		}
+		buf = append(buf, b...)
+	}
+	return buf, nil
+}
+
+func pointLen(k Kind) int { return [...]int{32, 48, 96, 64, 128}[k] }
+
+func firstBad(status []byte) error {
+	for i, s := range status {
+		if s != 0 {
+			return fmt.Errorf("kyberhip: element %d does not unmarshal (status %d)", i, s)
+		}
+	}
+	return nil
+}
+
+// points handed in as kyber.Point values were validated when they were unmarshalled: the engine need not re-check
+func trusted(k Kind) uint32 {
+	if k == Bls12381G1 || k == Bls12381G2 {
+		return Trusted(0)
+	}
+	return 0
+}
+
+// BatchMul returns out[i] = scalars[i] * points[i] as points of group g (N x Point.Mul, group.go:128-130).
+func BatchMul(k Kind, g kyber.Group, scalars []kyber.Scalar, points []kyber.Point) ([]kyber.Point, error) {
+	if len(scalars) != len(points) {
+		return nil, errors.New("kyberhip: length mismatch")
+	}
+	sb, err := marshalAll(scalars, 32)
+	if err != nil {
+		return nil, err
+	}
+	pb, err := marshalAll(points, pointLen(k))
+	if err != nil {
+		return nil, err
+	}
+	var out, st []byte
+	switch k {
+	case Ed25519:
+		out, st, err = Ed25519Mul(sb, pb, 0)
+	case Bls12381G1:
+		out, st, err = Bls12381G1Mul(sb, pb, trusted(k))
+	case Bls12381G2:
+		out, st, err = Bls12381G2Mul(sb, pb, trusted(k))
+	case Bn256G1:
+		out, st, err = Bn256G1Mul(sb, pb)
+	case Bn256G2:
+		out, st, err = Bn256G2Mul(sb, pb)
+	}
+	if err != nil {
+		return nil, err
+	}
+	if err = firstBad(st); err != nil {
+		return nil, err
+	}
+	return unmarshalAll(g, out, pointLen(k))
+}
+
+// MSM returns sum_i scalars[i] * points[i]: what PubPoly.Eval (share/poly.go:340-348), RecoverCommit (:449-476) and
+// bdn.AggregateSignatures / AggregatePublicKeys (sign/bdn/bdn.go:126-181) compute with n x (Mul + Add).
+func MSM(k Kind, g kyber.Group, scalars []kyber.Scalar, points []kyber.Point) (kyber.Point, error) {
+	if len(scalars) != len(points) {
+		return nil, errors.New("kyberhip: length mismatch")
+	}
+	sb, err := marshalAll(scalars, 32)
+	if err != nil {
+		return nil, err
+	}
+	pb, err := marshalAll(points, pointLen(k))
+	if err != nil {
+		return nil, err
+	}
+	var out, st []byte
+	switch k {
+	case Ed25519:
+		out, st, err = Ed25519MSM(sb, pb)
+	case Bls12381G1:
+		out, st, err = Bls12381G1MSM(sb, pb, trusted(k))
+	case Bls12381G2:
+		out, st, err = Bls12381G2MSM(sb, pb, trusted(k))
+	case Bn256G1:
+		out, st, err = Bn256G1MSM(sb, pb)
+	case Bn256G2:
+		out, st, err = Bn256G2MSM(sb, pb)
+	}
+	if err != nil {
+		return nil, err
+	}
+	if err = firstBad(st); err != nil {
+		return nil, err
+	}
+	p := g.Point()
+	return p, p.UnmarshalBinary(out)
+}
+
+// Commit returns coeffs[i] * base: the loop of share.PriPoly.Commit (share/poly.go:143-149); base == nil is the
+// group's standard base, as poly.go:144 passes nil through.
+func Commit(k Kind, g kyber.Group, coeffs []kyber.Scalar, base kyber.Point) ([]kyber.Point, error) {
+	sb, err := marshalAll(coeffs, 32)
+	if err != nil {
+		return nil, err
+	}
+	if base == nil {
+		base = g.Point().Base()
+	}
+	bb, err := base.MarshalBinary()
+	if err != nil {
+		return nil, err
+	}
+	var out, st []byte
+	switch k {
+	case Ed25519:
+		out, st, err = Ed25519MulSameBase(sb, bb, 0)
+	case Bls12381G1:
+		out, st, err = Bls12381G1MulSameBase(sb, bb, trusted(k))
+	case Bls12381G2:
+		out, st, err = Bls12381G2MulSameBase(sb, bb, trusted(k))
+	default:
+		pts := make([]kyber.Point, len(coeffs))
+		for i := range pts {
+			pts[i] = base
+		}
+		return BatchMul(k, g, coeffs, pts)
+	}
+	if err != nil {
+		return nil, err
+	}
+	if err = firstBad(st); err != nil {
+		return nil, err
+	}
+	return unmarshalAll(g, out, pointLen(k))
+}
+
+func unmarshalAll(g kyber.Group, buf []byte, size int) ([]kyber.Point, error) {
+	out := make([]kyber.Point, len(buf)/size)
+	for i := range out {
+		out[i] = g.Point()
+		if err := out[i].UnmarshalBinary(buf[i*size : (i+1)*size]); err != nil {
+			return nil, err
+		}
+	}
+	return out, nil
+}

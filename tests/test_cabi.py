@@ -51,3 +51,33 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         assert "no CPU fallback" in str(e).replace("There is no", "no")
     else:
         raise AssertionError("load() must raise when the HIP library is missing")
+
+
+def test_go_binding_stays_in_step_with_the_header():
+    """go/kyberhip/hip.go cannot be compiled here (no Go toolchain): at least every C function it calls must be
+    declared in include/kyber_hip.h with the same number of arguments."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = open(os.path.join(root, "include", "kyber_hip.h")).read()
+    g = open(os.path.join(root, "go", "kyberhip", "hip.go")).read()
+    decl = {}
+    for m in re.finditer(r"\b(?:int|const char \*)\s*(kyb_\w+)\s*\(([^;]*?)\);", h, re.S):
+        args = [a for a in m.group(2).split(",") if a.strip() and a.strip() != "void"]
+        decl[m.group(1)] = len(args)
+    calls = 0
+    for m in re.finditer(r"C\.(kyb_\w+)\(", g):
+        name, i, depth = m.group(1), m.end(), 1
+        j = i
+        while depth:
+            depth += {"(": 1, ")": -1}.get(g[j], 0)
+            j += 1
+        body = g[i:j - 1]
+        n, d = (1 if body.strip() else 0), 0
+        for ch in body:
+            d += {"(": 1, ")": -1}.get(ch, 0)
+            n += ch == "," and d == 0
+        assert name in decl, name
+        assert decl[name] == n, (name, decl[name], n)
+        calls += 1
+    assert calls >= 25
