@@ -31,7 +31,7 @@ struct DeviceCtx {
     bool ready = false;
     std::mutex mu;
     std::mutex msm_mu;  // serialises host-buffer MSM calls (they share the workspace)
-    // Ed25519 fixed-base table: [33][8][3][10] int32 (built on device at init)
+    // Ed25519 fixed-base table: [33][136] entries of 32 int32 (30 limbs + 2 pad), built on device at init
     int32_t* ed_base_tab = nullptr;
     // Grow-only device workspaces, one per (kind, stream): calls enqueued on one stream are ordered and reuse their
     // stream's buffer; calls on different streams never share one.  Kinds: WS_MSM (the Pippenger pipeline's arrays),
