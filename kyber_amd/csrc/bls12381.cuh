@@ -511,19 +511,30 @@ KYB_HD_NOINLINE void miller_loop2(fp12& f, const g1_aff& p1, const g2_aff& q1, c
 // a^|x| then conjugate (x < 0); a in the cyclotomic subgroup
 KYB_HD_NOINLINE void cyclo_pow_x(fp12& r, const fp12& a) {
     fp12 acc = a;
+    int run = 0;
 #pragma unroll 1
     for (int i = 62; i >= 0; i--) {
-        fp12_cyclo_sqr(acc, acc);
-        if ((CC::X_ABS >> i) & 1) fp12_mul(acc, acc, a);
+        run++;
+        if (((CC::X_ABS >> i) & 1) || i == 0) {  // |x| has 6 set bits: 5 multiplications, runs of up to 32 squarings
+            fp12_cyclo_sqr_n(acc, acc, run);
+            run = 0;
+            if ((CC::X_ABS >> i) & 1) fp12_mul(acc, acc, a);
+        }
     }
     fp12_conj(r, acc);
 }
 KYB_HD_NOINLINE void cyclo_pow_words(fp12& r, const fp12& a, const uint32_t* e, int nbits) {
     fp12 acc = a;
+    int run = 0;
 #pragma unroll 1
     for (int i = nbits - 2; i >= 0; i--) {
-        fp12_cyclo_sqr(acc, acc);
-        if ((e[i >> 5] >> (i & 31)) & 1) fp12_mul(acc, acc, a);
+        run++;
+        const bool bit = (e[i >> 5] >> (i & 31)) & 1;
+        if (bit || i == 0) {
+            fp12_cyclo_sqr_n(acc, acc, run);
+            run = 0;
+            if (bit) fp12_mul(acc, acc, a);
+        }
     }
     r = acc;
 }

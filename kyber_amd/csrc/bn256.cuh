@@ -124,7 +124,7 @@ struct twist_pt {  // Jacobian with t = z^2 cached, as twistPoint (twist.go:12-1
 };
 
 // ret *= (a tau + b) omega + c        (mulLine, optate.go:96-115; 13 Fp2 multiplications)
-KYB_HD_NOINLINE void mul_line(fp12& ret, const fp2& a, const fp2& b, const fp2& c) {
+KYB_HD void mul_line_inl(fp12& ret, const fp2& a, const fp2& b, const fp2& c) {
     fp6 a2, t3, t2, s;
     fp2 t;
     fp6_mul_by_01(a2, ret.c1, b, a);
@@ -137,6 +137,7 @@ KYB_HD_NOINLINE void mul_line(fp12& ret, const fp2& a, const fp2& b, const fp2& 
     fp6_mul_v(a2, a2);
     fp6_add(ret.c0, t3, a2);
 }
+KYB_HD_NOINLINE void mul_line(fp12& ret, const fp2& a, const fp2& b, const fp2& c) { mul_line_inl(ret, a, b, c); }
 // lineFunctionDouble (optate.go:54-94): r <- 2r, line coefficients (a, b, c)
 KYB_HD_NOINLINE void line_double(fp2& a, fp2& b, fp2& c, twist_pt& r, const fp& qx, const fp& qy) {
     fp2 A, B, C, D, E, G, t;
@@ -277,10 +278,15 @@ KYB_HD_NOINLINE void miller(fp12& ret, const g2_aff& q, const g1_aff& p) {
 // gfP12.Exp(a, u) (gfp12.go:177-192), u = 6518589491078791937 (63 bits)
 KYB_HD_NOINLINE void pow_u(fp12& r, const fp12& a) {
     fp12 acc = a;
+    int run = 0;
 #pragma unroll 1
     for (int i = 61; i >= 0; i--) {
-        fp12_cyclo_sqr(acc, acc);  // inputs are in the cyclotomic subgroup: equals gfP12.Square there
-        if ((CC::U >> i) & 1) fp12_mul(acc, acc, a);
+        run++;  // squarings (inputs are in the cyclotomic subgroup: equal to gfP12.Square there) batched per run
+        if (((CC::U >> i) & 1) || i == 0) {
+            fp12_cyclo_sqr_n(acc, acc, run);
+            run = 0;
+            if ((CC::U >> i) & 1) fp12_mul(acc, acc, a);
+        }
     }
     r = acc;
 }

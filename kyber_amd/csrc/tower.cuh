@@ -278,7 +278,7 @@ KYB_HD_NOINLINE void fp12_mul(Fp12<T>& r, const Fp12<T>& a, const Fp12<T>& b) {
     fp6_add(r.c0, v0, t);
 }
 template <class T>
-KYB_HD_NOINLINE void fp12_sqr(Fp12<T>& r, const Fp12<T>& a) {
+KYB_HD void fp12_sqr_inl(Fp12<T>& r, const Fp12<T>& a) {
     // complex squaring: 2 Fp6 multiplications
     Fp6<T> ab, s, u, t;
     fp6_mul(ab, a.c0, a.c1);
@@ -290,6 +290,10 @@ KYB_HD_NOINLINE void fp12_sqr(Fp12<T>& r, const Fp12<T>& a) {
     fp6_mul_v(t, ab);
     fp6_sub(r.c0, s, t);
     fp6_add(r.c1, ab, ab);
+}
+template <class T>
+KYB_HD_NOINLINE void fp12_sqr(Fp12<T>& r, const Fp12<T>& a) {
+    fp12_sqr_inl(r, a);
 }
 template <class T>
 KYB_HD_NOINLINE void fp12_inv(Fp12<T>& r, const Fp12<T>& a) {
@@ -305,7 +309,7 @@ KYB_HD_NOINLINE void fp12_inv(Fp12<T>& r, const Fp12<T>& a) {
 }
 // f * (o0 + o1 v + o4 v w): the sparse line value of an M-type twist (BLS12-381); 13 Fp2 mults
 template <class T>
-KYB_HD_NOINLINE void fp12_mul_by_014(Fp12<T>& f, const Fp2<T>& o0, const Fp2<T>& o1, const Fp2<T>& o4) {
+KYB_HD void fp12_mul_by_014_inl(Fp12<T>& f, const Fp2<T>& o0, const Fp2<T>& o1, const Fp2<T>& o4) {
     Fp6<T> aa, bb, s, t;
     Fp2<T> o;
     fp6_mul_by_01(aa, f.c0, o0, o1);
@@ -317,6 +321,10 @@ KYB_HD_NOINLINE void fp12_mul_by_014(Fp12<T>& f, const Fp2<T>& o0, const Fp2<T>&
     fp6_sub(f.c1, t, bb);
     fp6_mul_v(t, bb);
     fp6_add(f.c0, t, aa);
+}
+template <class T>
+KYB_HD_NOINLINE void fp12_mul_by_014(Fp12<T>& f, const Fp2<T>& o0, const Fp2<T>& o1, const Fp2<T>& o4) {
+    fp12_mul_by_014_inl(f, o0, o1, o4);
 }
 
 // w-basis coefficient j of an Fp12 element: a = sum_j coeff_j w^j
@@ -357,17 +365,18 @@ KYB_HD void fp4_sqr(Fp2<T>& t0, Fp2<T>& t1, const Fp2<T>& a, const Fp2<T>& b) {
     // (a + b y)^2 with y^2 = xi:  t0 = a^2 + xi b^2,  t1 = 2ab
     Fp2<T> ab, s, u;
     fp2_mul(ab, a, b);
-    fp2_add(s, a, b);
+    fp2_add_nr(s, a, b);  // operands of the multiplication below only
     fp2_mul_xi(u, b);
-    fp2_add(u, u, a);
+    fp2_add_nr(u, u, a);
     fp2_mul(s, s, u);  // a^2 + xi b^2 + (1 + xi) ab
     fp2_sub(s, s, ab);
     fp2_mul_xi(u, ab);
     fp2_sub(t0, s, u);
     fp2_dbl(t1, ab);
 }
+// (r may alias a: every output coefficient depends on the t's and on the same input coefficient only)
 template <class T>
-KYB_HD_NOINLINE void fp12_cyclo_sqr(Fp12<T>& r, const Fp12<T>& a) {
+KYB_HD void fp12_cyclo_sqr_inl(Fp12<T>& r, const Fp12<T>& a) {
     Fp2<T> t0, t1, t2, t3, t4, t5, z, u;
     fp4_sqr(t0, t1, a.c0.c0, a.c1.c1);
     fp4_sqr(t2, t3, a.c1.c0, a.c0.c2);
@@ -397,6 +406,19 @@ KYB_HD_NOINLINE void fp12_cyclo_sqr(Fp12<T>& r, const Fp12<T>& a) {
     fp2_add(z, t3, a.c1.c2);
     fp2_dbl(z, z);
     fp2_add(r.c1.c2, z, t3);
+}
+template <class T>
+KYB_HD_NOINLINE void fp12_cyclo_sqr(Fp12<T>& r, const Fp12<T>& a) {
+    fp12_cyclo_sqr_inl(r, a);
+}
+// r = a^(2^n): the runs of squarings between the set bits of a final-exponentiation exponent.  One call keeps the
+// element in registers across the whole run; n calls of fp12_cyclo_sqr move it through scratch 2n times.
+template <class T>
+KYB_HD_NOINLINE void fp12_cyclo_sqr_n(Fp12<T>& r, const Fp12<T>& a, int n) {
+    Fp12<T> x = a;
+#pragma unroll 1
+    for (int i = 0; i < n; i++) fp12_cyclo_sqr_inl(x, x);
+    r = x;
 }
 
 }  // namespace kyb
