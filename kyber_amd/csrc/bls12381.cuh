@@ -638,12 +638,7 @@ KYB_HD_NOINLINE void g1_mul_glv(g1_jac& r, const g1_jac& p, const uint32_t (&k)[
     jac_set_inf(acc);
 #pragma unroll 1
     for (int i = 33; i >= 0; i--) {
-        if (i != 33) {
-            jac_dbl(acc, acc);
-            jac_dbl(acc, acc);
-            jac_dbl(acc, acc);
-            jac_dbl(acc, acc);
-        }
+        if (i != 33) jac_dbl_n(acc, acc, 4);
         jac_select8(t, tab, e0[i]);
         jac_add(s, acc, t);
         jac_cmov(acc, s, e0[i] != 0);
@@ -690,12 +685,7 @@ KYB_HD_NOINLINE void g2_mul_gls(g2_jac& r, const g2_jac& p, const uint32_t (&k)[
     jac_set_inf(acc);
 #pragma unroll 1
     for (int i = 17; i >= 0; i--) {
-        if (i != 17) {
-            jac_dbl(acc, acc);
-            jac_dbl(acc, acc);
-            jac_dbl(acc, acc);
-            jac_dbl(acc, acc);
-        }
+        if (i != 17) jac_dbl_n(acc, acc, 4);
         // a0 Q
         jac_select8(t, tab, e[0][i]);
         jac_add(s, acc, t);

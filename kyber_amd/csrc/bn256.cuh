@@ -463,12 +463,7 @@ KYB_HD_NOINLINE void g1_mul_glv(g1_jac& r, const g1_jac& p, const uint32_t (&k)[
     jac_set_inf(acc);
 #pragma unroll 1
     for (int i = 33; i >= 0; i--) {
-        if (i != 33) {
-            jac_dbl(acc, acc);
-            jac_dbl(acc, acc);
-            jac_dbl(acc, acc);
-            jac_dbl(acc, acc);
-        }
+        if (i != 33) jac_dbl_n(acc, acc, 4);
         int d = n1 ? -e1[i] : e1[i];
         int ad = d < 0 ? -d : d;
         t = tab[ad ? ad - 1 : 0];

@@ -65,7 +65,7 @@ template <class F> KYB_HD void jac_neg(Jac<F>& r, const Jac<F>& p) { r.X = p.X; 
 
 // dbl-2009-l (a = 0): 2M + 5S.  Maps infinity to infinity and 2-torsion points (Y = 0) to infinity.
 template <class F>
-KYB_HD_NOINLINE void jac_dbl(Jac<F>& r, const Jac<F>& p) {
+KYB_HD void jac_dbl_inl(Jac<F>& r, const Jac<F>& p) {
     F A, B, C, D, E, G, t;
     f_sqr(A, p.X);
     f_sqr(B, p.Y);
@@ -88,6 +88,20 @@ KYB_HD_NOINLINE void jac_dbl(Jac<F>& r, const Jac<F>& p) {
     f_dbl(C, C);
     f_dbl(C, C);
     f_sub(r.Y, t, C);
+}
+template <class F>
+KYB_HD_NOINLINE void jac_dbl(Jac<F>& r, const Jac<F>& p) {
+    jac_dbl_inl(r, p);
+}
+// r = 2^n p: a run of doublings inside ONE out-of-line call, so the point stays in registers across the run
+// instead of crossing the call boundary (scratch) 2n times -- the window steps of the scalar multiplications (n = 4)
+// and the zero runs of the sparse curve parameter in the subgroup checks (up to 32).
+template <class F>
+KYB_HD_NOINLINE void jac_dbl_n(Jac<F>& r, const Jac<F>& p, int n) {
+    Jac<F> x = p;
+#pragma unroll 1
+    for (int i = 0; i < n; i++) jac_dbl_inl(x, x);
+    r = x;
 }
 
 // add-2007-bl with the exceptional cases handled (either operand infinity, P = Q, P = -Q).
@@ -216,12 +230,7 @@ KYB_HD_NOINLINE void jac_mul_u256(Jac<F>& r, const Jac<F>& p, const uint32_t (&k
     jac_set_inf(acc);
 #pragma unroll 1
     for (int i = 64; i >= 0; i--) {
-        if (i != 64) {
-            jac_dbl(acc, acc);
-            jac_dbl(acc, acc);
-            jac_dbl(acc, acc);
-            jac_dbl(acc, acc);
-        }
+        if (i != 64) jac_dbl_n(acc, acc, 4);
         const int d = e[i];
         const int ad = d < 0 ? -d : d;
         t = tab[ad ? ad - 1 : 0];
@@ -238,10 +247,15 @@ template <class F>
 KYB_HD_NOINLINE void jac_mul_u64(Jac<F>& r, const Jac<F>& p, uint64_t k) {
     Jac<F> acc;
     jac_set_inf(acc);
+    int run = 0;
 #pragma unroll 1
     for (int i = 63; i >= 0; i--) {
-        jac_dbl(acc, acc);
-        if ((k >> i) & 1) jac_add(acc, acc, p);
+        run++;
+        if (((k >> i) & 1) || i == 0) {
+            jac_dbl_n(acc, acc, run);
+            run = 0;
+            if ((k >> i) & 1) jac_add(acc, acc, p);
+        }
     }
     r = acc;
 }
