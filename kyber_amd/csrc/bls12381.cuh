@@ -602,19 +602,21 @@ KYB_HD void glv_digits(int8_t (&e)[65], const uint32_t* w, int nwords) {
     for (int i = 0; i < 8; i++) k[i] = i < nwords ? w[i] : 0u;
     recode16_u256(e, k);
 }
-KYB_HD void jac_select8(g1_jac& t, const g1_jac (&tab)[8], int d) {
-    const int ad = d < 0 ? -d : d;
-    t = tab[ad ? ad - 1 : 0];
-    fp ny;
-    fp_neg(ny, t.Y);
-    fp_cmov(t.Y, ny, d < 0);
-}
-KYB_HD void jac_select8(g2_jac& t, const g2_jac (&tab)[8], int d) {
-    const int ad = d < 0 ? -d : d;
-    t = tab[ad ? ad - 1 : 0];
-    fp2 ny;
-    fp2_neg(ny, t.Y);
-    fp2_cmov(t.Y, ny, d < 0);
+// One GLV window on G1 in one out-of-line call: acc = 16 acc (when dbl) + d0 P + d1 z^2 P, z^2 P = (beta x, -y).
+KYB_HD_NOINLINE void g1_glv_step(g1_jac& acc, const g1_jac (&tab)[8], int d0, int d1, const fp& beta, bool dbl) {
+    g1_jac x = acc, t, s;
+    if (dbl) {  // uniform across the grid
+#pragma unroll 1
+        for (int i = 0; i < 4; i++) jac_dbl_inl(x, x);
+    }
+    jac_select8(t, tab, d0);
+    jac_add_inl(s, x, t);
+    jac_cmov(x, s, d0 != 0);
+    jac_select8(t, tab, -d1);  // -y
+    fp_mul(t.X, t.X, beta);
+    jac_add_inl(s, x, t);
+    jac_cmov(x, s, d1 != 0);
+    acc = x;
 }
 // r = k * P for P in G1: k = k1 z^2 + k0, z^2 P = -phi(P) = (beta x, -y); 34 windows of (4 doublings + 2 additions).
 KYB_HD_NOINLINE void g1_mul_glv(g1_jac& r, const g1_jac& p, const uint32_t (&k)[8]) {
@@ -634,20 +636,10 @@ KYB_HD_NOINLINE void g1_mul_glv(g1_jac& r, const g1_jac& p, const uint32_t (&k)[
     for (int j = 2; j < 8; j++) jac_add(tab[j], tab[j - 1], p);
     fp beta;
     fp_const(beta, CC::BETA);
-    g1_jac acc, t, s;
+    g1_jac acc;
     jac_set_inf(acc);
 #pragma unroll 1
-    for (int i = 33; i >= 0; i--) {
-        if (i != 33) jac_dbl_n(acc, acc, 4);
-        jac_select8(t, tab, e0[i]);
-        jac_add(s, acc, t);
-        jac_cmov(acc, s, e0[i] != 0);
-        jac_select8(t, tab, e1[i]);
-        fp_mul(t.X, t.X, beta);
-        fp_neg(t.Y, t.Y);
-        jac_add(s, acc, t);
-        jac_cmov(acc, s, e1[i] != 0);
-    }
+    for (int i = 33; i >= 0; i--) g1_glv_step(acc, tab, e0[i], e1[i], beta, i != 33);
     r = acc;
 }
 // r = k * Q for Q in G2: k = a0 + a1 |z| + a2 |z|^2 + a3 |z|^3 and |z| Q = -psi(Q), so

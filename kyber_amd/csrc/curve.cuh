@@ -106,7 +106,7 @@ KYB_HD_NOINLINE void jac_dbl_n(Jac<F>& r, const Jac<F>& p, int n) {
 
 // add-2007-bl with the exceptional cases handled (either operand infinity, P = Q, P = -Q).
 template <class F>
-KYB_HD_NOINLINE void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
+KYB_HD void jac_add_inl(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
     const bool pinf = jac_is_inf(p), qinf = jac_is_inf(q);
     F Z1Z1, Z2Z2, U1, U2, S1, S2, H, I, J, rr, V, t;
     f_sqr(Z1Z1, p.Z);
@@ -150,6 +150,34 @@ KYB_HD_NOINLINE void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
     jac_cmov(o, q, pinf);
     jac_cmov(o, p, qinf);
     r = o;
+}
+template <class F>
+KYB_HD_NOINLINE void jac_add(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
+    jac_add_inl(r, p, q);
+}
+// t = d * P from the table tab[j] = (j + 1) P, d a signed radix-16 digit (|d| <= 8; d = 0 returns tab[0], unused)
+template <class F>
+KYB_HD void jac_select8(Jac<F>& t, const Jac<F> (&tab)[8], int d) {
+    const int ad = d < 0 ? -d : d;
+    t = tab[ad ? ad - 1 : 0];
+    F ny;
+    f_neg(ny, t.Y);
+    f_cmov(t.Y, ny, d < 0);
+}
+// One window of a fixed-window scalar multiplication in ONE out-of-line call: acc = 16 acc (when dbl) + d P.
+// The accumulator stays in registers through the four doublings, the addition and the select that keeps or drops
+// it; as separate calls it crossed the call boundary (scratch) after each of them.
+template <class F>
+KYB_HD_NOINLINE void jac_window_step(Jac<F>& acc, const Jac<F> (&tab)[8], int d, bool dbl) {
+    Jac<F> x = acc, t, s;
+    if (dbl) {  // uniform across the grid
+#pragma unroll 1
+        for (int i = 0; i < 4; i++) jac_dbl_inl(x, x);
+    }
+    jac_select8(t, tab, d);
+    jac_add_inl(s, x, t);
+    jac_cmov(x, s, d != 0);
+    acc = x;
 }
 
 // Mixed addition r = p + (x2, y2) with the second operand affine (madd-2007-bl, 7M + 4S), exceptional
@@ -226,20 +254,10 @@ KYB_HD_NOINLINE void jac_mul_u256(Jac<F>& r, const Jac<F>& p, const uint32_t (&k
     for (int j = 2; j < 8; j++) jac_add(tab[j], tab[j - 1], p);
     int8_t e[65];
     recode16_u256(e, k);
-    Jac<F> acc, t, s;
+    Jac<F> acc;
     jac_set_inf(acc);
 #pragma unroll 1
-    for (int i = 64; i >= 0; i--) {
-        if (i != 64) jac_dbl_n(acc, acc, 4);
-        const int d = e[i];
-        const int ad = d < 0 ? -d : d;
-        t = tab[ad ? ad - 1 : 0];
-        F ny;
-        f_neg(ny, t.Y);
-        f_cmov(t.Y, ny, d < 0);
-        jac_add(s, acc, t);
-        jac_cmov(acc, s, d != 0);
-    }
+    for (int i = 64; i >= 0; i--) jac_window_step(acc, tab, e[i], i != 64);
     r = acc;
 }
 // Short public multiplier (e.g. the curve parameter |x|), MSB-first double-and-add; uniform.
