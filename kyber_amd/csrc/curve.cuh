@@ -183,7 +183,7 @@ KYB_HD_NOINLINE void jac_window_step(Jac<F>& acc, const Jac<F> (&tab)[8], int d,
 // Mixed addition r = p + (x2, y2) with the second operand affine (madd-2007-bl, 7M + 4S), exceptional
 // cases handled: p at infinity, q at infinity (q_inf), p = q (doubling), p = -q (infinity).
 template <class F>
-KYB_HD_NOINLINE void jac_madd(Jac<F>& r, const Jac<F>& p, const F& x2, const F& y2, bool q_inf) {
+KYB_HD void jac_madd_inl(Jac<F>& r, const Jac<F>& p, const F& x2, const F& y2, bool q_inf) {
     const bool pinf = jac_is_inf(p);
     F Z1Z1, U2, S2, H, HH, I, J, rr, V, t;
     f_sqr(Z1Z1, p.Z);
@@ -227,6 +227,10 @@ KYB_HD_NOINLINE void jac_madd(Jac<F>& r, const Jac<F>& p, const F& x2, const F& 
     jac_cmov(o, q, pinf);
     jac_cmov(o, p, q_inf);
     r = o;
+}
+template <class F>
+KYB_HD_NOINLINE void jac_madd(Jac<F>& r, const Jac<F>& p, const F& x2, const F& y2, bool q_inf) {
+    jac_madd_inl(r, p, x2, y2, q_inf);
 }
 
 // Signed radix-16 digits of a 256-bit scalar given as eight little-endian words:

@@ -31,10 +31,12 @@ struct Weierstrass {
         F y = p.y, ny;
         f_neg(ny, p.y);
         f_cmov(y, ny, neg);
-        jac_madd(acc, acc, p.x, y, p.inf != 0);
+        jac_madd_inl(acc, acc, p.x, y, p.inf != 0);
     }
-    __device__ static void add(Acc& r, const Acc& a, const Acc& b) { jac_add(r, a, b); }
-    __device__ static void dbl(Acc& r, const Acc& a) { jac_dbl(r, a); }
+    // inline bodies: the accumulators of the pipeline's loops (bucket pieces, running sums, folds) stay in registers
+    // from one group operation to the next instead of crossing a call boundary (scratch) each time
+    __device__ static void add(Acc& r, const Acc& a, const Acc& b) { jac_add_inl(r, a, b); }
+    __device__ static void dbl(Acc& r, const Acc& a) { jac_dbl_inl(r, a); }
     // Cooperative doubling for the latency-bound tail of the MSM (final_kernel): COOP lanes hold the same point and
     // each computes one of the independent field products of a level, exchanged through LDS `sh` (COOP slots of this
     // group) -- a doubling is 3 dependent multiplications deep instead of 2M + 5S.  Every thread of the block must
