@@ -285,7 +285,7 @@ static __global__ __launch_bounds__(256) void piece_order_kernel(size_t nbk, siz
 // length, so the lanes of a wave run the same number of additions (bucket sizes are Poisson-spread: in bucket order a
 // wave would wait for its longest piece, ~40 % above the mean at 32 points per bucket).
 template <class A>
-__global__ __launch_bounds__(64) void accumulate_kernel(size_t nbk, size_t max_pieces,
+__global__ __launch_bounds__(64, 2) void accumulate_kernel(size_t nbk, size_t max_pieces,
                                                         const typename A::Aff* __restrict__ aff,
                                                         const uint32_t* __restrict__ suboffs,
                                                         const uint32_t* __restrict__ order,
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64) void accumulate_kernel(size_t nbk, size_t max_p
 
 // bucket b = sum of its pieces (one piece for all but skewed buckets; long ones are left to bucket_long_kernel)
 template <class A>
-__global__ __launch_bounds__(64) void bucket_kernel(size_t nbk, const uint32_t* __restrict__ suboffs,
+__global__ __launch_bounds__(64, 2) void bucket_kernel(size_t nbk, const uint32_t* __restrict__ suboffs,
                                                     const typename A::Acc* __restrict__ pieces,
                                                     typename A::Acc* __restrict__ buckets) {
     const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
