@@ -97,8 +97,19 @@ struct Split<A, decltype((void)A::SPLIT)> {
     static constexpr int value = A::SPLIT, bits = A::SPLIT_BITS, cmax = 16;
 };
 
+// Register budget of the decode kernel in waves per SIMD: it is bound by its histogram atomics and digit stores, so
+// co-resident waves pay (two for the Weierstrass adapters: 1.27 -> 0.98 ms; an adapter may ask for more).
+template <class A, class = void>
+struct DecodeWaves {
+    static constexpr int value = 2;
+};
 template <class A>
-__global__ __launch_bounds__(64, 2) void decode_kernel(Plan p, size_t n_in, const uint8_t* __restrict__ scalars,
+struct DecodeWaves<A, decltype((void)A::DECODE_WAVES)> {
+    static constexpr int value = A::DECODE_WAVES;
+};
+
+template <class A>
+__global__ __launch_bounds__(64, DecodeWaves<A>::value) void decode_kernel(Plan p, size_t n_in, const uint8_t* __restrict__ scalars,
                                                     const uint8_t* __restrict__ points,
                                                     typename A::Aff* __restrict__ aff, int32_t* __restrict__ digits,
                                                     uint32_t* __restrict__ hist, uint8_t* __restrict__ status,
