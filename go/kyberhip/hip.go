@@ -91,6 +91,18 @@ func Ed25519Add(a, b []byte) (out, status []byte, err error) {
 	return
 }
 
+// Ed25519PolyEval: out[i] = sum_j commits[j] * (idx[i] + 1)^j  (share.PubPoly.Eval for many indices).
+func Ed25519PolyEval(idx []uint32, commits []byte) (out, status []byte, err error) {
+	n, t := len(idx), len(commits)/32
+	out, status = make([]byte, 32*n), make([]byte, t)
+	var ip *C.uint32_t
+	if n > 0 {
+		ip = (*C.uint32_t)(unsafe.Pointer(&idx[0]))
+	}
+	err = check(C.kyb_ed25519_poly_eval(C.size_t(n), ip, C.size_t(t), ptr(commits), ptr(out), ptr(status)))
+	return
+}
+
 // Ed25519Hash: n equal-length messages packed back to back -> n points (RFC 9380 edwards25519_XMD:SHA-512_ELL2_RO_).
 func Ed25519Hash(msgs []byte, msgLen int, dst []byte) (out []byte, err error) {
 	n := 0
@@ -159,6 +171,19 @@ func Bls12381G2MSM(scalars, points []byte, flags uint32) (out, status []byte, er
 	n := len(scalars) / 32
 	out, status = make([]byte, 96), make([]byte, n)
 	err = check(C.kyb_bls12381_g2_msm(C.size_t(n), ptr(scalars), ptr(points), ptr(out), ptr(status), C.uint32_t(flags)))
+	return
+}
+
+// Bls12381G1PolyEval: share.PubPoly.Eval over G1 for many indices in one launch.
+func Bls12381G1PolyEval(idx []uint32, commits []byte, flags uint32) (out, status []byte, err error) {
+	n, t := len(idx), len(commits)/g1in(flags)
+	out, status = make([]byte, 48*n), make([]byte, t)
+	var ip *C.uint32_t
+	if n > 0 {
+		ip = (*C.uint32_t)(unsafe.Pointer(&idx[0]))
+	}
+	err = check(C.kyb_bls12381_g1_poly_eval(C.size_t(n), ip, C.size_t(t), ptr(commits), ptr(out), ptr(status),
+		C.uint32_t(flags)))
 	return
 }
 

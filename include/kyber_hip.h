@@ -247,6 +247,33 @@ int kyb_bn256_g1_msm_dev(size_t n, const void *d_scalars, const void *d_points, 
 int kyb_bn256_g2_msm_dev(size_t n, const void *d_scalars, const void *d_points, void *d_out, void *d_status,
                          uint32_t flags, void *stream);
 
+/* --------------------------------------------------------- batched public-polynomial evaluation
+ * out[i] = sum_j commits[j] * (idx[i] + 1)^j  (n points).  share.PubPoly.Eval (share/poly.go:340-348: xi = 1 + i,
+ * Horner from the top coefficient with t x (Mul + Add)) for many indices in one launch -- the per-participant loop of
+ * PubPoly.Shares / Check and of the DKG / VSS share verification (share/dkg/pedersen/dkg.go:294, 489-490, 825-826).
+ * commits: t encoded points (coefficient 0 first); status[j] reports an undecodable commitment, and then every
+ * output is all-zero bytes.  t == 0 yields identities.  flags as for the MSM (KYB_F_TRUSTED(0) = the commitments).  */
+int kyb_ed25519_poly_eval(size_t n, const uint32_t *idx, size_t t, const uint8_t *commits, uint8_t *out,
+                          uint8_t *status);
+int kyb_ed25519_poly_eval_dev(size_t n, const void *d_idx, size_t t, const void *d_commits, void *d_out,
+                              void *d_status, void *stream);
+int kyb_bls12381_g1_poly_eval(size_t n, const uint32_t *idx, size_t t, const uint8_t *commits, uint8_t *out,
+                              uint8_t *status, uint32_t flags);
+int kyb_bls12381_g2_poly_eval(size_t n, const uint32_t *idx, size_t t, const uint8_t *commits, uint8_t *out,
+                              uint8_t *status, uint32_t flags);
+int kyb_bls12381_g1_poly_eval_dev(size_t n, const void *d_idx, size_t t, const void *d_commits, void *d_out,
+                                  void *d_status, uint32_t flags, void *stream);
+int kyb_bls12381_g2_poly_eval_dev(size_t n, const void *d_idx, size_t t, const void *d_commits, void *d_out,
+                                  void *d_status, uint32_t flags, void *stream);
+int kyb_bn256_g1_poly_eval(size_t n, const uint32_t *idx, size_t t, const uint8_t *commits, uint8_t *out,
+                           uint8_t *status, uint32_t flags);
+int kyb_bn256_g2_poly_eval(size_t n, const uint32_t *idx, size_t t, const uint8_t *commits, uint8_t *out,
+                           uint8_t *status, uint32_t flags);
+int kyb_bn256_g1_poly_eval_dev(size_t n, const void *d_idx, size_t t, const void *d_commits, void *d_out,
+                               void *d_status, uint32_t flags, void *stream);
+int kyb_bn256_g2_poly_eval_dev(size_t n, const void *d_idx, size_t t, const void *d_commits, void *d_out,
+                               void *d_status, uint32_t flags, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -84,6 +84,16 @@ SIGNATURES = {
     "kyb_bn256_pair_dev": [_sz, _vp, _vp, _vp, _vp, _u32, _vp],
     "kyb_bn256_pair_check": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _u32],
     "kyb_bn256_pair_check_dev": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
+    "kyb_ed25519_poly_eval": [_sz, _vp, _sz, _vp, _vp, _vp],
+    "kyb_ed25519_poly_eval_dev": [_sz, _vp, _sz, _vp, _vp, _vp, _vp],
+    "kyb_bls12381_g1_poly_eval": [_sz, _vp, _sz, _vp, _vp, _vp, _u32],
+    "kyb_bls12381_g2_poly_eval": [_sz, _vp, _sz, _vp, _vp, _vp, _u32],
+    "kyb_bls12381_g1_poly_eval_dev": [_sz, _vp, _sz, _vp, _vp, _vp, _u32, _vp],
+    "kyb_bls12381_g2_poly_eval_dev": [_sz, _vp, _sz, _vp, _vp, _vp, _u32, _vp],
+    "kyb_bn256_g1_poly_eval": [_sz, _vp, _sz, _vp, _vp, _vp, _u32],
+    "kyb_bn256_g2_poly_eval": [_sz, _vp, _sz, _vp, _vp, _vp, _u32],
+    "kyb_bn256_g1_poly_eval_dev": [_sz, _vp, _sz, _vp, _vp, _vp, _u32, _vp],
+    "kyb_bn256_g2_poly_eval_dev": [_sz, _vp, _sz, _vp, _vp, _vp, _u32, _vp],
 }
 _RESTYPES = {"kyb_last_error": C.c_char_p}
 
@@ -99,6 +109,13 @@ def load() -> C.CDLL:
         raise KyberHipError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # PyTorch-ROCm ships its own HIP runtime.  If libkyberhip.so pulled in the system one first, a later
+    # `import torch` would find a HIP runtime it did not initialise and report no usable device
+    # (torch.cuda.is_available() == False): let torch's copy load first whenever torch is installed.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pure host-buffer use without torch
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         try:

@@ -120,4 +120,24 @@ int kyb_bls12381_g2_msm_dev(size_t n, const void* d_scalars, const void* d_point
     KYB_TRY(kyb::get_ctx(&ctx));
     return kyb::msm::run<kyb::BlsG2Msm>(ctx, n, d_scalars, d_points, d_out, d_status, (hipStream_t)stream, flags);
 }
+int kyb_bls12381_g1_poly_eval(size_t n, const uint32_t* idx, size_t t, const uint8_t* commits, uint8_t* out, uint8_t* status,
+                       uint32_t flags) {
+    return kyb::msm::poly_eval_host<kyb::BlsG1Msm>(n, idx, t, commits, out, status, flags);
+}
+int kyb_bls12381_g1_poly_eval_dev(size_t n, const void* d_idx, size_t t, const void* d_commits, void* d_out, void* d_status,
+                           uint32_t flags, void* stream) {
+    kyb::DeviceCtx* ctx;
+    KYB_TRY(kyb::get_ctx(&ctx));
+    return kyb::msm::poly_eval_run<kyb::BlsG1Msm>(ctx, n, d_idx, t, d_commits, d_out, d_status, flags, (hipStream_t)stream);
+}
+int kyb_bls12381_g2_poly_eval(size_t n, const uint32_t* idx, size_t t, const uint8_t* commits, uint8_t* out, uint8_t* status,
+                       uint32_t flags) {
+    return kyb::msm::poly_eval_host<kyb::BlsG2Msm>(n, idx, t, commits, out, status, flags);
+}
+int kyb_bls12381_g2_poly_eval_dev(size_t n, const void* d_idx, size_t t, const void* d_commits, void* d_out, void* d_status,
+                           uint32_t flags, void* stream) {
+    kyb::DeviceCtx* ctx;
+    KYB_TRY(kyb::get_ctx(&ctx));
+    return kyb::msm::poly_eval_run<kyb::BlsG2Msm>(ctx, n, d_idx, t, d_commits, d_out, d_status, flags, (hipStream_t)stream);
+}
 }

@@ -690,6 +690,16 @@ extern "C" {
 int kyb_ed25519_msm(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t out[32], uint8_t* status) {
     return kyb::msm::run_host<kyb::EdMsm>(n, scalars, points, out, status);
 }
+int kyb_ed25519_poly_eval(size_t n, const uint32_t* idx, size_t t, const uint8_t* commits, uint8_t* out, uint8_t* status) {
+    return kyb::msm::poly_eval_host<kyb::EdMsm>(n, idx, t, commits, out, status, 0);
+}
+int kyb_ed25519_poly_eval_dev(size_t n, const void* d_idx, size_t t, const void* d_commits, void* d_out, void* d_status,
+                              void* stream) {
+    kyb::DeviceCtx* ctx;
+    int rc = kyb::get_ctx(&ctx);
+    if (rc) return rc;
+    return kyb::msm::poly_eval_run<kyb::EdMsm>(ctx, n, d_idx, t, d_commits, d_out, d_status, 0, (hipStream_t)stream);
+}
 int kyb_ed25519_msm_dev(size_t n, const void* d_scalars, const void* d_points, void* d_out, void* d_status,
                         void* stream) {
     kyb::DeviceCtx* ctx;

@@ -641,5 +641,103 @@ int run_host(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* o
     return rc;
 }
 
+// ----------------------------------------------------------------------------------------- batched PubPoly.Eval
+// out[i] = sum_j commits[j] x_i^j with x_i = idx[i] + 1, by Horner from the top coefficient -- share.PubPoly.Eval
+// (share/poly.go:340-348: xi = 1 + i; v = v * xi + commits[j]) for many indices at once: what PubPoly.Shares / Check
+// and the DKG / VSS verification loops evaluate once per participant.  One launch decodes the t commitments (one lane
+// each, the adapter's UnmarshalBinary checks), one launch evaluates: a lane per index, t - 1 steps of
+// [x] acc (33-bit double-and-add: x <= 2^32) + one mixed addition.  If any commitment is rejected every output is
+// all-zero bytes and status[j] names it.
+template <class A>
+__global__ __launch_bounds__(64) void poly_decode_kernel(size_t t, const uint8_t* __restrict__ commits,
+                                                         typename A::Aff* __restrict__ aff, uint8_t* __restrict__ status,
+                                                         uint32_t* __restrict__ bad, uint32_t flags) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= t) return;
+    typename A::Aff a;
+    const int st = A::decode(a, commits + A::wire_size(flags) * j, flags);
+    aff[j] = a;
+    if (status) status[j] = (uint8_t)st;
+    if (st) atomicAdd(bad, 1u);
+}
+template <class A>
+__global__ __launch_bounds__(64) void poly_eval_kernel(size_t n, const uint32_t* __restrict__ idx, size_t t,
+                                                       const typename A::Aff* __restrict__ aff,
+                                                       const uint32_t* __restrict__ bad, uint8_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t* o = out + (size_t)A::OUT * i;
+    if (*bad) {
+        for (int k = 0; k < A::OUT; k++) o[k] = 0;
+        return;
+    }
+    const uint64_t x = (uint64_t)idx[i] + 1;
+    typename A::Acc acc;
+    A::identity(acc);
+    if (t) {
+        const typename A::Aff top = aff[t - 1];
+        A::madd(acc, top, false);
+    }
+#pragma unroll 1
+    for (size_t j = t; j-- > 1;) {
+        typename A::Acc r;  // r = x * acc, MSB first
+        A::identity(r);
+#pragma unroll 1
+        for (int b = 32; b >= 0; b--) {
+            A::dbl(r, r);
+            if ((x >> b) & 1) A::add(r, r, acc);
+        }
+        const typename A::Aff c = aff[j - 1];
+        A::madd(r, c, false);
+        acc = r;
+    }
+    A::encode(o, acc);
+}
+// Enqueue on `st`; d_status may be null.
+template <class A>
+int poly_eval_run(DeviceCtx* ctx, size_t n, const void* d_idx, size_t t, const void* d_commits, void* d_out,
+                  void* d_status, uint32_t flags, hipStream_t st) {
+    if (t >= (size_t(1) << 24)) {
+        set_error("poly_eval: threshold too large");
+        return KYB_E_ARG;
+    }
+    void* ws;
+    int rc = ctx_workspace(ctx, WS_MSM, st, sizeof(typename A::Aff) * (t ? t : 1) + 512, &ws);
+    if (rc) return rc;
+    uint32_t* bad = (uint32_t*)ws;
+    auto* aff = (typename A::Aff*)((uint8_t*)ws + 256);
+    KYB_HIP_CHECK(hipMemsetAsync(bad, 0, 256, st));
+    if (t)
+        hipLaunchKernelGGL(poly_decode_kernel<A>, dim3((unsigned)((t + 63) / 64)), dim3(64), 0, st, t,
+                           (const uint8_t*)d_commits, aff, (uint8_t*)d_status, bad, flags);
+    if (n)
+        hipLaunchKernelGGL(poly_eval_kernel<A>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, (const uint32_t*)d_idx, t,
+                           aff, (const uint32_t*)bad, (uint8_t*)d_out);
+    KYB_HIP_CHECK(hipGetLastError());
+    return KYB_OK;
+}
+template <class A>
+int poly_eval_host(size_t n, const uint32_t* idx, size_t t, const uint8_t* commits, uint8_t* out, uint8_t* status,
+                   uint32_t flags) {
+    if ((n && (!idx || !out)) || (t && !commits)) {
+        set_error("poly_eval: bad argument");
+        return KYB_E_ARG;
+    }
+    DeviceCtx* ctx;
+    int rc = get_ctx(&ctx);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> ws_lock(ctx->msm_mu);
+    StageScope sc_(ctx);
+    StageBuf d_i, d_c, d_o, d_st;
+    rc = d_i.upload(idx, n * 4);
+    if (rc == KYB_OK) rc = d_c.upload(commits, t * A::wire_size(flags));
+    if (rc == KYB_OK) rc = d_o.alloc(n * A::OUT);
+    if (rc == KYB_OK) rc = d_st.alloc(t + 1);
+    if (rc == KYB_OK) rc = poly_eval_run<A>(ctx, n, d_i.p, t, d_c.p, d_o.p, d_st.p, flags, nullptr);
+    if (rc == KYB_OK) rc = d_o.download(out, n * A::OUT);
+    if (rc == KYB_OK && status && t) rc = d_st.download(status, t);
+    return rc;
+}
+
 }  // namespace msm
 }  // namespace kyb

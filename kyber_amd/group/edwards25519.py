@@ -149,6 +149,20 @@ def msm(scalars, points):
     return out, st[:n]
 
 
+def poly_eval(commits, indices):
+    """(out, status): out[i] = sum_j commits[j] * (indices[i] + 1)^j -- share.PubPoly.Eval (share/poly.go:340-348) for
+    many indices in one launch (host buffers).  status has one entry per commitment."""
+    lib = load()
+    c = _as_host(commits, 32)
+    idx = np.ascontiguousarray(np.asarray(indices, dtype=np.uint32))
+    n, t = idx.shape[0], c.shape[0]
+    out = np.empty((n, 32), dtype=np.uint8)
+    st = np.zeros(max(t, 1), dtype=np.uint8)
+    check(lib.kyb_ed25519_poly_eval(n, idx.ctypes.data, t, c.ctypes.data, out.ctypes.data, st.ctypes.data),
+          "kyb_ed25519_poly_eval")
+    return out, st[:t]
+
+
 def batch_add(a, b):
     """(out, status): out[i] = a[i] + b[i]  (N x Point.Add, point.go:216-223)."""
     lib = load()

@@ -146,6 +146,19 @@ class Engine:
         check(fn(n, s.ctypes.data, p.ctypes.data, out.ctypes.data, st.ctypes.data, flags), nm)
         return out, st[:n]
 
+    def poly_eval(self, group: int, commits, indices, flags: int = 0):
+        """(out, status): out[i] = sum_j commits[j] * (indices[i] + 1)^j -- share.PubPoly.Eval (share/poly.go:340-348)
+        for many indices in one launch (host buffers); status has one entry per commitment."""
+        w = self.G1_LEN if group == 1 else self.G2_LEN
+        c = _host(commits, self._in_len(group, flags))
+        idx = np.ascontiguousarray(np.asarray(indices, dtype=np.uint32))
+        n, t = idx.shape[0], c.shape[0]
+        out = np.empty((n, w), dtype=np.uint8)
+        st = np.zeros(max(t, 1), dtype=np.uint8)
+        fn, nm = self._fn(f"g{group}_poly_eval")
+        check(fn(n, idx.ctypes.data, t, c.ctypes.data, out.ctypes.data, st.ctypes.data, flags), nm)
+        return out, st[:t]
+
     def g1_msm(self, scalars, points, flags: int = 0):
         return self.msm(1, scalars, points, flags)
 

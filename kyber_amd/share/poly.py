@@ -2,6 +2,7 @@
 
   PriPoly.Commit   share/poly.go:143-149   t x Mul(coeffs[i], b)        -> ONE same-base batch call
   PubPoly.Eval     share/poly.go:340-348   Horner: t x (Mul + Add)      -> ONE MSM with scalars x^j
+  PubPoly.Shares   share/poly.go:350-357   n x Eval                     -> ONE batched evaluation (poly_eval kernel)
   PubPoly.Check    share/poly.go:405-409   Eval + one Mul
   RecoverCommit    share/poly.go:449-476   Lagrange: t x (Mul + Add)    -> ONE MSM with the Lagrange coefficients
 
@@ -100,6 +101,32 @@ class PubPoly:
         if st.any():
             raise ValueError("share: invalid commitment")
         return PubShare(i, type(self.g.Point())(bytes(out)))
+
+    def EvalMany(self, indices) -> list:
+        """[Eval(i) for i in indices] in ONE launch: a lane per index runs the reference's Horner loop
+        (kyb_*_poly_eval).  PubPoly.Shares(n) (poly.go:350-357) and the per-participant checks of DKG / VSS have
+        this shape."""
+        pt = self.g.Point()
+        cb = b"".join(c.MarshalBinary() for c in self.commits)
+        if type(pt).__module__.endswith("edwards25519"):
+            from ..group import edwards25519 as ed
+
+            out, st = ed.poly_eval(cb, list(indices))
+        else:
+            from ..pairing import bls12381, bn256
+
+            for m in (bls12381, bn256):
+                if isinstance(pt, (m.G1Elt, m.G2Elt)):
+                    out, st = m.ENGINE.poly_eval(1 if isinstance(pt, m.G1Elt) else 2, cb, list(indices))
+                    break
+            else:
+                raise TypeError("not an engine-backed group")
+        if st.any():
+            raise ValueError("share: invalid commitment")
+        return [PubShare(i, type(pt)(bytes(row))) for i, row in zip(indices, out)]
+
+    def Shares(self, n: int) -> list:  # poly.go:350-357
+        return self.EvalMany(range(n))
 
     def Check(self, s: PriShare) -> bool:  # poly.go:405-409
         pv = self.Eval(s.I)

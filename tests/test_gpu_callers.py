@@ -169,3 +169,38 @@ def test_batch_add_all_groups():
         assert not st.any()
         for i in range(4):
             assert bytes(out[i]) == e2(OR.g2_add(a2[i], b2[i])), (m.__name__, i)
+
+
+@pytest.mark.parametrize("name", ["Ed25519", "bls12381.G1", "bls12381.G2", "bn256.G1", "bn256.G2"])
+def test_pubpoly_batched_eval_matches_per_index_eval(name):
+    """PubPoly.EvalMany / Shares (one kyb_*_poly_eval launch: a lane per index runs the reference's Horner loop) ==
+    PubPoly.Eval per index (one MSM each) == the private shares times the base; indices at the edges of the 32-bit
+    range; t = 1 and an undecodable commitment."""
+    from kyber_amd.group import edwards25519 as ed
+    from kyber_amd.pairing import bls12381 as bls, bn256 as bn
+    from kyber_amd.share import poly
+
+    g = {"Ed25519": ed.NewSuite(), "bls12381.G1": bls.NewSuite().G1(), "bls12381.G2": bls.NewSuite().G2(),
+         "bn256.G1": bn.NewSuite().G1(), "bn256.G2": bn.NewSuite().G2()}[name]
+    rng = random.Random(17)
+    rand = lambda n: bytes(rng.randrange(256) for _ in range(n))
+    t = 7
+    pri = poly.PriPoly.new(g, t, rand=rand)
+    pub = pri.Commit(None)
+    idx = [0, 1, 2, 5, 63, 64, 255, 65535, 65536, (1 << 31) - 1, (1 << 32) - 2, (1 << 32) - 1] + [rng.randrange(1 << 32) for _ in range(20)]
+    many = pub.EvalMany(idx)
+    assert [s.I for s in many] == idx
+    for s in many[:6] + many[9:14]:
+        assert s.V.Equal(pub.Eval(s.I).V), s.I
+    for s in many[6:9]:
+        assert s.V.Equal(g.Point().Mul(pri.Eval(s.I).V, None)), s.I
+    shares = pub.Shares(9)
+    assert all(sh.V.Equal(pub.Eval(i).V) for i, sh in enumerate(shares))
+    # constant polynomial: every evaluation is the commitment itself
+    one = poly.PubPoly(g, None, pub.commits[:1])
+    assert all(s.V.Equal(pub.commits[0]) for s in one.EvalMany([0, 7, (1 << 32) - 1]))
+    # an undecodable commitment is reported (the reference fails in UnmarshalBinary before it gets this far)
+    bad = list(pub.commits)
+    bad[3] = type(g.Point())(b"\x02" + bytes(g.PointLen() - 1) if name == "Ed25519" else b"\x05" * g.PointLen())
+    with pytest.raises(ValueError):
+        poly.PubPoly(g, None, bad).EvalMany([1, 2])
