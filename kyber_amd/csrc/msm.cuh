@@ -648,8 +648,10 @@ int run_host(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* o
 // each, the adapter's UnmarshalBinary checks), one launch evaluates: a lane per index, t - 1 steps of
 // [x] acc (33-bit double-and-add: x <= 2^32) + one mixed addition.  If any commitment is rejected every output is
 // all-zero bytes and status[j] names it.
+// (same register budget as decode_kernel: the two share their out-of-line callees, and a callee reachable from a
+// kernel without the budget is compiled without it -- which silently cost decode_kernel its second wave)
 template <class A>
-__global__ __launch_bounds__(64) void poly_decode_kernel(size_t t, const uint8_t* __restrict__ commits,
+__global__ __launch_bounds__(64, DecodeWaves<A>::value) void poly_decode_kernel(size_t t, const uint8_t* __restrict__ commits,
                                                          typename A::Aff* __restrict__ aff, uint8_t* __restrict__ status,
                                                          uint32_t* __restrict__ bad, uint32_t flags) {
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,0 +1,52 @@
+"""Register budgets of the kernels whose occupancy was tuned, read from the code-object
+metadata of the built objects -- no GPU needed.  The budget of a kernel is silently lost when one of its out-of-line
+callees becomes reachable from another kernel that does not carry it (this happened to the MSM decode kernel when
+poly_decode_kernel was added), so the numbers are pinned here."""
+import glob
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "kyber_amd", "csrc")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def _kernel_regs(obj):
+    """{demangled-ish kernel name: total VGPR allocation (arch + acc)} of one fat object file."""
+    with tempfile.TemporaryDirectory() as tmp:
+        local = os.path.join(tmp, os.path.basename(obj))
+        shutil.copy(obj, local)
+        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", local], cwd=tmp, check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        cos = glob.glob(os.path.join(tmp, "*gfx950*"))
+        assert cos, "no gfx950 code object in " + obj
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", cos[0]], check=True, capture_output=True,
+                               text=True).stdout
+    out = {}
+    for blk in notes.split("- .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        out[name] = int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1))
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-readelf")), reason="no llvm-readelf")
+def test_tuned_kernels_keep_their_register_budget():
+    ed = _kernel_regs(os.path.join(CSRC, "ed25519.o"))
+    msm = _kernel_regs(os.path.join(CSRC, "bls12381_msm.o"))
+
+    def find(table, *parts):
+        hits = [v for k, v in table.items() if all(p in k for p in parts)]
+        assert len(hits) == 1, (parts, [k for k in table if parts[0] in k])
+        return hits[0]
+
+    # three waves per SIMD: <= 170 registers
+    assert find(ed, "ed25519_mul_kernelILb1E") <= 170
+    assert find(ed, "13decode_kernel", "EdMsm") <= 170
+    # two waves per SIMD: <= 256
+    assert find(msm, "13decode_kernel", "BlsG1Msm") <= 256
+    assert find(msm, "17accumulate_kernel", "BlsG1Msm") <= 256
