@@ -2,8 +2,9 @@
 
   Sign           tbls.go:72-86     uint16 big-endian share index || x_i * H(m)
   VerifyPartial  tbls.go:99-106    Verify(public.Eval(i).V, msg, sig)
-  Recover        tbls.go:118-151   verify partials (ONE pairing-check launch for all of them), then
-                                   share.RecoverCommit over the first t valid ones (ONE MSM)
+  Recover        tbls.go:118-151   public.Eval(i) for every partial (ONE poly_eval launch), verify them (ONE
+                                   pairing-check launch), then share.RecoverCommit over the first t valid ones
+                                   (ONE MSM)
 """
 from __future__ import annotations
 
@@ -37,8 +38,9 @@ class Scheme:
                 cand.append((self.index_of(s), s[2:]))
             except ValueError:
                 continue
-        keys = [public.Eval(i).V.MarshalBinary() for i, _ in cand]
-        ok = self.bls.batch_verify(keys, [msg] * len(cand), [v for _, v in cand]) if cand else []
+        keys = [s.V.MarshalBinary() for s in public.EvalMany([i for i, _ in cand])] if cand else []
+        # the evaluated keys are the engine's own outputs: validated by construction
+        ok = self.bls.batch_verify(keys, [msg] * len(cand), [v for _, v in cand], keys_validated=True) if cand else []
         shares = []
         for (i, v), good in zip(cand, ok):
             if not good:
