@@ -71,6 +71,25 @@ int hh_bls_pair_check_f(const uint8_t* p1, const uint8_t* p2, const uint8_t* i1,
 int hh_bls_g1_decode_unc(const uint8_t* in, int validate) { bls::g1_aff a; return bls::g1_decode_unc(a, in, validate != 0); }
 int hh_bls_g2_decode_unc(const uint8_t* in, int validate) { bls::g2_aff a; return bls::g2_decode_unc(a, in, validate != 0); }
 
+// Fp12 operations on GT-encoded operands (576 bytes, coefficients < p): the tower arithmetic at chosen magnitudes
+// (all coefficients p - 1 drives the lazy Karatsuba sums to their 2p / 4p / 8p bounds)
+int hh_bls_fp12_op(int op, const uint8_t* a576, const uint8_t* b576, uint8_t* out576) {
+    bls::fp12 a, b, r;
+    int st = bls::gt_decode(a, a576);
+    if (st) return st;
+    st = bls::gt_decode(b, b576);
+    if (st) return st;
+    switch (op) {
+        case 0: fp12_mul(r, a, b); break;
+        case 1: fp12_sqr(r, a); break;
+        case 2: fp12_cyclo_sqr(r, a); break;
+        case 3: fp12_cyclo_sqr_n(r, a, 5); break;
+        default: r = a; fp12_mul_by_014(r, b.c0.c0, b.c0.c1, b.c1.c1); break;
+    }
+    bls::gt_encode(out576, r);
+    return 0;
+}
+
 // ---- bn256
 void hh_bn_fp_op(int op, const uint8_t* a32, const uint8_t* b32, uint8_t* out32) {
     bn::fp a, b, r;

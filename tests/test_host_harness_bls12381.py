@@ -315,3 +315,32 @@ def test_glv_gls_mul_edge_scalars():
     kb = (12345).to_bytes(32, "big")
     assert H.call("hh_bls_g1_mul", kb, inf1, out_sizes=(48,)) == (0, inf1)
     assert H.call("hh_bls_g2_mul", kb, inf2, out_sizes=(96,)) == (0, inf2)
+
+
+def test_fp12_ops_at_extreme_magnitudes():
+    """The tower multiplications form their Karatsuba operands with lazily reduced sums (up to 8p before a base-field
+    multiplication): operands whose coefficients are all p - 1 (or alternate 0 / p - 1) drive every such sum to its
+    bound.  Against the big-integer oracle."""
+    rng = random.Random(31)
+    top = (O.P - 1, O.P - 1)
+    cases = [[top] * 6,
+             [top if k % 2 else (0, 0) for k in range(6)],
+             [(O.P - 1, 0) if k % 2 else (0, O.P - 1) for k in range(6)],
+             [(rng.randrange(O.P), rng.randrange(O.P)) for _ in range(6)],
+             [(O.P - 1 - rng.randrange(4), O.P - 1 - rng.randrange(4)) for _ in range(6)]]
+    for a in cases:
+        for b in cases[:3] + cases[3:4]:
+            ab, bb = O.gt_to_bytes(a), O.gt_to_bytes(b)
+            assert H.call("hh_bls_fp12_op", 0, ab, bb, out_sizes=(576,)) == (0, O.gt_to_bytes(O.f12_mul(a, b)))
+            sparse = [b[0], (0, 0), b[2], b[3], (0, 0), (0, 0)]
+            assert H.call("hh_bls_fp12_op", 9, ab, bb, out_sizes=(576,)) == (0, O.gt_to_bytes(O.f12_mul(a, sparse)))
+        ab = O.gt_to_bytes(a)
+        assert H.call("hh_bls_fp12_op", 1, ab, ab, out_sizes=(576,)) == (0, O.gt_to_bytes(O.f12_sqr(a)))
+    # cyclotomic squaring (valid on pairing outputs): one step and a run of five
+    g = O.pair(O.g1_mul(5, O.G1_GEN), O.g2_mul(7, O.G2_GEN))
+    gb = O.gt_to_bytes(g)
+    assert H.call("hh_bls_fp12_op", 2, gb, gb, out_sizes=(576,)) == (0, O.gt_to_bytes(O.f12_sqr(g)))
+    g5 = g
+    for _ in range(5):
+        g5 = O.f12_sqr(g5)
+    assert H.call("hh_bls_fp12_op", 3, gb, gb, out_sizes=(576,)) == (0, O.gt_to_bytes(g5))
