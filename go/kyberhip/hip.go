@@ -228,6 +228,15 @@ func Bls12381VerifyG1(pubkeys, msgs []byte, msgLen int, dst, sigs []byte, flags 
 	return
 }
 
+// Bls12381VerifyG2: the same for signatures on G2 and keys on G1 (NewSchemeOnG2); Trusted(0) = keys.
+func Bls12381VerifyG2(pubkeys, msgs []byte, msgLen int, dst, sigs []byte, flags uint32) (ok, status []byte, err error) {
+	n := len(sigs) / g2in(flags)
+	ok, status = make([]byte, n), make([]byte, n)
+	err = check(C.kyb_bls12381_verify_g2(C.size_t(n), ptr(pubkeys), ptr(msgs), C.size_t(msgLen), ptr(dst),
+		C.size_t(len(dst)), ptr(sigs), ptr(ok), ptr(status), C.uint32_t(flags)))
+	return
+}
+
 // ---------------------------------------------------------------- bn256 (32-byte BE scalars; G1 64 B, G2 128 B, GT 384 B)
 
 func Bn256G1Mul(scalars, points []byte) (out, status []byte, err error) {

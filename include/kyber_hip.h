@@ -171,6 +171,13 @@ int kyb_bls12381_verify_g1(size_t n, const uint8_t *pubkeys, const uint8_t *msgs
 int kyb_bls12381_verify_g1_dev(size_t n, const void *d_pubkeys, const void *d_msgs, size_t msg_len,
                                const uint8_t *dst, size_t dst_len, const void *d_sigs, void *d_ok, void *d_status,
                                uint32_t flags, void *stream);
+/* The same for the scheme with signatures on G2 and keys on G1 (NewSchemeOnG2, sign/bls/bls.go:48-58:
+ * ValidatePairing(G1.Base(), sig, X, H(msg)) with H = hash_to_curve on G2): pubkeys 48 B, sigs 96 B. */
+int kyb_bls12381_verify_g2(size_t n, const uint8_t *pubkeys, const uint8_t *msgs, size_t msg_len, const uint8_t *dst,
+                           size_t dst_len, const uint8_t *sigs, uint8_t *ok, uint8_t *status, uint32_t flags);
+int kyb_bls12381_verify_g2_dev(size_t n, const void *d_pubkeys, const void *d_msgs, size_t msg_len,
+                               const uint8_t *dst, size_t dst_len, const void *d_sigs, void *d_ok, void *d_status,
+                               uint32_t flags, void *stream);
 /* out[i] = gt[i] ^ scalars[i].  Replaces GTElt.Mul (kilic/gt.go:79-84 -> GT.Exp); inputs are checked
  * like GT.FromBytes (coefficients < p, order-r subgroup). */
 int kyb_bls12381_gt_mul(size_t n, const uint8_t *scalars, const uint8_t *gt, uint8_t *out, uint8_t *status);

@@ -304,10 +304,11 @@ KYB_HD_NOINLINE void g2_clear_cofactor(g2_jac& q, const g2_jac& p) {
     jac_neg(n, p);
     jac_add(q, t3, n);
 }
-KYB_HD int hash_g2_wire(uint8_t* out, const uint8_t* msg, size_t msg_len, const DstArg& dst) {
+// hash_to_curve(msg, dst) on G2 as a Jacobian point: shared by hash_g2_wire and verify_g2_wire
+KYB_HD_NOINLINE void hash_g2_point(g2_jac& r, const uint8_t* msg, size_t msg_len, const DstArg& dst) {
     uint32_t ub[64];
     expand_message_xmd<8>(ub, msg, msg_len, dst);
-    g2_jac q0, q1, r;
+    g2_jac q0, q1;
     fp2 u, x, y;
     fp_from_be512(u.c0, ub);
     fp_from_be512(u.c1, ub + 16);
@@ -319,6 +320,35 @@ KYB_HD int hash_g2_wire(uint8_t* out, const uint8_t* msg, size_t msg_len, const 
     g2_iso_map(q1, x, y);
     jac_add(r, q0, q1);
     g2_clear_cofactor(r, r);
+}
+// One whole sign/bls Verify for the scheme with signatures on G2 and keys on G1 (NewSchemeOnG2, sign/bls/bls.go:48-58:
+// ValidatePairing(G1.Base(), sig, X, H(msg))): ok = e(G1.Base(), sig) == e(X, H(msg)), hashing, both unmarshal checks,
+// two Miller loops sharing their squarings and one final exponentiation per lane.  Trusted(0) = keys, (1) = signatures.
+KYB_HD int verify_g2_wire(uint8_t* ok, const uint8_t* pk48, const uint8_t* msg, size_t msg_len, const DstArg& dst,
+                          const uint8_t* sig96, uint32_t flags = 0) {
+    g1_aff x, g;
+    g2_aff s, h;
+    *ok = 0;
+    int st = g1_decode_f(x, pk48, flags, 0);
+    const int st2 = g2_decode_f(s, sig96, flags, 1);
+    if (st == ST_OK) st = st2;
+    if (st != ST_OK) return st;
+    g2_jac hj;
+    hash_g2_point(hj, msg, msg_len, dst);
+    jac_to_aff(h, hj);
+    fp_const(g.x, CC::G1X);
+    fp_const(g.y, CC::G1Y);
+    g.inf = false;
+    fp_neg(x.y, x.y);  // e(G1, sig) * e(-X, H) == 1
+    fp12 f;
+    miller_loop2(f, g, s, x, h);
+    final_exp(f, f);
+    *ok = fp12_is_one(f) ? 1 : 0;
+    return ST_OK;
+}
+KYB_HD int hash_g2_wire(uint8_t* out, const uint8_t* msg, size_t msg_len, const DstArg& dst) {
+    g2_jac r;
+    hash_g2_point(r, msg, msg_len, dst);
     g2_aff a;
     jac_to_aff(a, r);
     g2_encode(out, a);

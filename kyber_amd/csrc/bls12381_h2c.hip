@@ -36,6 +36,19 @@ __global__ __launch_bounds__(64) void bls12381_verify_g1_kernel(size_t n, const 
     ok[idx] = r;
     if (status) status[idx] = (uint8_t)st;
 }
+__global__ __launch_bounds__(64) void bls12381_verify_g2_kernel(size_t n, const uint8_t* __restrict__ pks,
+                                                                const uint8_t* __restrict__ msgs, size_t msg_len,
+                                                                bls::DstArg dst, const uint8_t* __restrict__ sigs,
+                                                                uint8_t* __restrict__ ok, uint8_t* __restrict__ status,
+                                                                uint32_t flags) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    uint8_t r = 0;
+    const int st = bls::verify_g2_wire(&r, pks + bls::g1_wire_size(flags) * idx, msgs + msg_len * idx, msg_len, dst,
+                                       sigs + bls::g2_wire_size(flags) * idx, flags);
+    ok[idx] = r;
+    if (status) status[idx] = (uint8_t)st;
+}
 }  // namespace kyb
 
 using namespace kyb;
@@ -141,6 +154,42 @@ int kyb_bls12381_verify_g1(size_t n, const uint8_t* pks, const uint8_t* msgs, si
     KYB_TRY(o.alloc(n));
     KYB_TRY(st.alloc(n));
     KYB_TRY(kyb_bls12381_verify_g1_dev(n, p.p, m.p, msg_len, dst, dst_len, s.p, o.p, st.p, flags, nullptr));
+    KYB_TRY(o.download(ok, n));
+    if (status) KYB_TRY(st.download(status, n));
+    return KYB_OK;
+}
+int kyb_bls12381_verify_g2_dev(size_t n, const void* d_pks, const void* d_msgs, size_t msg_len, const uint8_t* dst,
+                               size_t dst_len, const void* d_sigs, void* d_ok, void* d_status, uint32_t flags, void* stream) {
+    if (n && (!d_pks || (!d_msgs && msg_len) || !d_sigs || !d_ok)) {
+        set_error("kyb_bls12381_verify_g2_dev: bad argument");
+        return KYB_E_ARG;
+    }
+    bls::DstArg d;
+    KYB_TRY(make_dst(d, dst, dst_len));
+    if (!n) return KYB_OK;
+    hipLaunchKernelGGL(bls12381_verify_g2_kernel, dim3(grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n,
+                       (const uint8_t*)d_pks, (const uint8_t*)d_msgs, msg_len, d, (const uint8_t*)d_sigs, (uint8_t*)d_ok,
+                       (uint8_t*)d_status, flags);
+    KYB_HIP_CHECK(hipGetLastError());
+    return KYB_OK;
+}
+int kyb_bls12381_verify_g2(size_t n, const uint8_t* pks, const uint8_t* msgs, size_t msg_len, const uint8_t* dst,
+                           size_t dst_len, const uint8_t* sigs, uint8_t* ok, uint8_t* status, uint32_t flags) {
+    if (n && (!pks || (!msgs && msg_len) || !sigs || !ok)) {
+        set_error("kyb_bls12381_verify_g2: bad argument");
+        return KYB_E_ARG;
+    }
+    if (!n) return KYB_OK;
+    DeviceCtx* ctx;
+    KYB_TRY(get_ctx(&ctx));
+    kyb::StageScope sc_(ctx);
+    StageBuf p, m, s, o, st;
+    KYB_TRY(p.upload(pks, n * bls::g1_wire_size(flags)));
+    KYB_TRY(m.upload(msgs, n * msg_len));
+    KYB_TRY(s.upload(sigs, n * bls::g2_wire_size(flags)));
+    KYB_TRY(o.alloc(n));
+    KYB_TRY(st.alloc(n));
+    KYB_TRY(kyb_bls12381_verify_g2_dev(n, p.p, m.p, msg_len, dst, dst_len, s.p, o.p, st.p, flags, nullptr));
     KYB_TRY(o.download(ok, n));
     if (status) KYB_TRY(st.download(status, n));
     return KYB_OK;

@@ -98,6 +98,15 @@ def batch_hash_g2(msgs, dst: bytes = DOMAIN_G2):
 
 
 def batch_verify_g1(pubkeys, msgs, sigs, dst: bytes = DOMAIN_G1, flags: int = 0):
+    return _batch_verify(1, pubkeys, msgs, sigs, dst, flags)
+
+
+def batch_verify_g2(pubkeys, msgs, sigs, dst: bytes = DOMAIN_G2, flags: int = 0):
+    """As batch_verify_g1 for the scheme with signatures on G2 and keys on G1 (NewSchemeOnG2, bls.go:48-58)."""
+    return _batch_verify(2, pubkeys, msgs, sigs, dst, flags)
+
+
+def _batch_verify(sig_group: int, pubkeys, msgs, sigs, dst: bytes, flags: int):
     """(ok, status): N x bls.Verify (sign/bls/bls.go:82-96; signatures on G1, keys on G2) fused in ONE kernel:
     hash_to_curve, both unmarshal checks, two Miller loops sharing their squarings and one final exponentiation
     per lane.  msgs: (n, msg_len) uint8 array / CUDA tensor or list of equal-length bytes.  flags: F_TRUSTED(0) for
@@ -110,7 +119,10 @@ def batch_verify_g1(pubkeys, msgs, sigs, dst: bytes = DOMAIN_G1, flags: int = 0)
     from .._lib import check, load
     from ._engine import F_UNCOMPRESSED, _host, _is_torch, _stream
 
-    wk, wsig = (192, 96) if flags & F_UNCOMPRESSED else (96, 48)
+    wk, wsig = (96, 48) if sig_group == 1 else (48, 96)
+    if flags & F_UNCOMPRESSED:
+        wk, wsig = 2 * wk, 2 * wsig
+    name = f"kyb_bls12381_verify_g{sig_group}"
 
     lib = load()
     dbuf = ctypes.create_string_buffer(bytes(dst), len(dst)) if dst else None
@@ -122,13 +134,13 @@ def batch_verify_g1(pubkeys, msgs, sigs, dst: bytes = DOMAIN_G1, flags: int = 0)
         n, ln = m.shape[0], m.shape[1]
         ok = torch.empty(n, dtype=torch.uint8, device=m.device)
         st = torch.empty(n, dtype=torch.uint8, device=m.device)
-        check(lib.kyb_bls12381_verify_g1_dev(n, p.data_ptr(), m.data_ptr(), ln, dptr, len(dst), s.data_ptr(), ok.data_ptr(),
-                                             st.data_ptr(), flags, _stream()), "kyb_bls12381_verify_g1_dev")
+        check(getattr(lib, name + "_dev")(n, p.data_ptr(), m.data_ptr(), ln, dptr, len(dst), s.data_ptr(), ok.data_ptr(),
+                                          st.data_ptr(), flags, _stream()), name + "_dev")
         return ok, st
     if isinstance(msgs, (list, tuple)):
         ln = len(msgs[0]) if msgs else 0
         if any(len(x) != ln for x in msgs):
-            raise ValueError("batch_verify_g1: messages must have equal length")
+            raise ValueError("batch_verify: messages must have equal length")
         mb = np.frombuffer(b"".join(msgs), dtype=np.uint8)
         n = len(msgs)
     else:
@@ -140,6 +152,6 @@ def batch_verify_g1(pubkeys, msgs, sigs, dst: bytes = DOMAIN_G1, flags: int = 0)
     s = _host(sigs if not isinstance(sigs, (list, tuple)) else b"".join(sigs), wsig)
     ok = np.empty(n, dtype=np.uint8)
     st = np.empty(n, dtype=np.uint8)
-    check(lib.kyb_bls12381_verify_g1(n, p.ctypes.data, mb.ctypes.data, ln, dptr, len(dst), s.ctypes.data, ok.ctypes.data,
-                                     st.ctypes.data, flags), "kyb_bls12381_verify_g1")
+    check(getattr(lib, name)(n, p.ctypes.data, mb.ctypes.data, ln, dptr, len(dst), s.ctypes.data, ok.ctypes.data,
+                             st.ctypes.data, flags), name)
     return ok, st

@@ -129,11 +129,31 @@ class SchemeOnG2:
         return bool(self.batch_verify([public], [msg], [sig], keys_validated)[0])
 
 
+class _Bls12381SchemeOnG2(SchemeOnG2):
+    """Same interface, batch_verify through the fused kernel (kyb_bls12381_verify_g2)."""
+
+    def __init__(self, suite_module, batch_hash, dst):
+        super().__init__(suite_module, batch_hash)
+        self.dst = dst
+
+    def batch_verify(self, publics, msgs, sigs, keys_validated: bool = False):
+        out = np.zeros(len(msgs), dtype=bool)
+        by_len = {}
+        for i, m in enumerate(msgs):
+            by_len.setdefault(len(m), []).append(i)
+        flags = self.m.F_TRUSTED(0) if keys_validated else 0
+        for _, idx in by_len.items():
+            ok, st = self.m.batch_verify_g2([publics[i] for i in idx], [bytes(msgs[i]) for i in idx],
+                                            [sigs[i] for i in idx], self.dst, flags)
+            out[idx] = (np.asarray(ok) == 1) & (np.asarray(st) == 0)
+        return out
+
+
 def NewSchemeOnG2_bls12381(dst: bytes | None = None) -> SchemeOnG2:
     from ..pairing import bls12381
 
     d = bls12381.DOMAIN_G2 if dst is None else dst
-    return SchemeOnG2(bls12381, _grouped(lambda m: bls12381.batch_hash_g2(m, d), 96))
+    return _Bls12381SchemeOnG2(bls12381, _grouped(lambda m: bls12381.batch_hash_g2(m, d), 96), d)
 
 
 def NewSchemeOnG1_bn256() -> SchemeOnG1:

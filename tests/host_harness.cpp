@@ -129,6 +129,10 @@ int hh_bls_hash_g1(const uint8_t* msg, int len, const uint8_t* dst, int dlen, ui
 int hh_bls_hash_g2(const uint8_t* msg, int len, const uint8_t* dst, int dlen, uint8_t* out) {
     return bls::hash_g2_wire(out, msg, (size_t)len, mk_dst(dst, dlen));
 }
+int hh_bls_verify_g2(const uint8_t* pk, const uint8_t* msg, int len, const uint8_t* dst, int dlen, const uint8_t* sig,
+                     uint8_t* ok) {
+    return bls::verify_g2_wire(ok, pk, msg, (size_t)len, mk_dst(dst, dlen), sig);
+}
 int hh_bls_verify_g1(const uint8_t* pk, const uint8_t* msg, int len, const uint8_t* dst, int dlen, const uint8_t* sig,
                      uint8_t* ok) {
     return bls::verify_g1_wire(ok, pk, msg, (size_t)len, mk_dst(dst, dlen), sig);

@@ -374,3 +374,32 @@ def test_bn256_accepts_and_ignores_the_flags():
     r0, _ = bn.g1_msm(k, P)
     r1, _ = bn.g1_msm(k, P, bn.F_TRUSTED(0) | bn.F_UNCOMPRESSED)
     assert (r0 == r1).all()
+
+
+def test_fused_verify_g2_matches_hash_plus_pairing_check(bls):
+    """kyb_bls12381_verify_g2 (signatures on G2, keys on G1) == batch_hash_g2 + batch_validate_pairing with the
+    argument order of bls.go:51-53, with forged and undecodable entries."""
+    n = 256
+    x = _scalars(b"fv2/x", n)
+    msgs = np.frombuffer(hashlib.shake_256(b"fv2/m").digest(n * 32), dtype=np.uint8).reshape(n, 32).copy()
+    X, _ = bls.g1_commit(x)
+    Hm, st = bls.batch_hash_g2(msgs)
+    assert not st.any()
+    sig, _ = bls.g2_batch_mul(x, Hm)
+    sig = sig.copy()
+    sig[::7] = Hm[::7]  # forged: valid point, wrong value
+    sig[5] = 0
+    X = X.copy()
+    X[9] = 0xFF
+    ok_f, st_f = bls.batch_verify_g2(X, msgs, sig)
+    G1 = np.tile(np.frombuffer(bls.G1_BASE, dtype=np.uint8), (n, 1))
+    ok_r, st_r = bls.batch_validate_pairing(G1, sig, X, Hm)
+    assert ((st_f != 0) == (st_r != 0)).all() and st_f[5] != 0 and st_f[9] != 0
+    assert (ok_f == ok_r).all()
+    exp = np.ones(n, dtype=bool)
+    exp[::7] = False
+    exp[[5, 9]] = False
+    assert (ok_f.astype(bool) == exp).all()
+    ok_t, st_t = bls.batch_verify_g2(X, msgs, sig, flags=bls.F_TRUSTED(0))
+    exp_t = exp.copy()
+    assert (ok_t.astype(bool)[np.arange(n) != 9] == exp_t[np.arange(n) != 9]).all()

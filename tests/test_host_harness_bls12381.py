@@ -189,6 +189,15 @@ def test_fused_verify_replays_drand_fixtures(golden_dir):
                   bytes.fromhex(f["sig_g1"]), out_sizes=(1,)) == (0, bytes([1]))
     st, ok = H.call("hh_bls_verify_g1", bytes(96), msg, 32, d1, len(d1), sig, out_sizes=(1,))
     assert st == 1 and ok == bytes([0])
+    # signatures on G2, keys on G1 (kilic/suite_test.go:48-72, gnark/suite_test.go:16-40: chained drand beacon)
+    f = D["sig_on_g2"]
+    msg = hashlib.sha256(bytes.fromhex(f["prev_sig"]) + struct.pack(">Q", f["round"])).digest()
+    pk, sig = bytes.fromhex(f["pk_g1"]), bytes.fromhex(f["sig_g2"])
+    assert H.call("hh_bls_verify_g2", pk, msg, 32, d2, len(d2), sig, out_sizes=(1,)) == (0, bytes([1]))
+    assert H.call("hh_bls_verify_g2", pk, msg, 32, d1, len(d1), sig, out_sizes=(1,)) == (0, bytes([0]))
+    assert H.call("hh_bls_verify_g2", pk, msg[::-1], 32, d2, len(d2), sig, out_sizes=(1,)) == (0, bytes([0]))
+    st, ok = H.call("hh_bls_verify_g2", pk, msg, 32, d2, len(d2), bytes(96), out_sizes=(1,))
+    assert st == 1 and ok == bytes([0])
 
 
 # ------------------------------------------------------------------ call flags (include/kyber_hip.h)
