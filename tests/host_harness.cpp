@@ -113,6 +113,20 @@ int hh_bn_pair(const uint8_t* g1, const uint8_t* g2, uint8_t* gt) { return bn::p
 int hh_bn_pair_check(const uint8_t* p1, const uint8_t* p2, const uint8_t* i1, const uint8_t* i2, uint8_t* ok) {
     return bn::pair_check_wire(ok, p1, p2, i1, i2);
 }
+// Fp12 operations on GT-encoded operands (384 bytes): the shared tower code at bn256's parameters (two lazy levels)
+int hh_bn_fp12_op(int op, const uint8_t* a384, const uint8_t* b384, uint8_t* out384) {
+    bn::fp12 a, b, r;
+    bn::gt_decode(a, a384);
+    bn::gt_decode(b, b384);
+    switch (op) {
+        case 0: fp12_mul(r, a, b); break;
+        case 1: fp12_sqr(r, a); break;
+        case 2: fp12_cyclo_sqr(r, a); break;
+        default: fp12_cyclo_sqr_n(r, a, 5); break;
+    }
+    bn::gt_encode(out384, r);
+    return 0;
+}
 int hh_bn_gt_mul(const uint8_t* k, const uint8_t* gt, uint8_t* out) { return bn::gt_mul_wire(out, k, gt); }
 int hh_bls_gt_mul(const uint8_t* k, const uint8_t* gt, uint8_t* out) { return bls::gt_mul_wire(out, k, gt); }
 int hh_bn_hash_g1(const uint8_t* msg, int len, uint8_t* out) { return bn::hash_g1_wire(out, msg, (size_t)len); }

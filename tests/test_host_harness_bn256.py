@@ -147,3 +147,28 @@ def test_g1_glv_split_edge_scalars():
         assert H.call("hh_bn_g1_mul", kb, pb, out_sizes=(64,)) == (0, O.g1_marshal(O.g1_mul(k % n, P))), hex(k)
     inf = O.g1_marshal(None)
     assert H.call("hh_bn_g1_mul", (77).to_bytes(32, "big"), inf, out_sizes=(64,)) == (0, inf)
+
+
+def test_fp12_ops_at_extreme_magnitudes():
+    """The shared tower code at bn256's parameters (lazy Karatsuba sums at the Fp2 and Fp6 levels only, and -- the
+    modulus filling its 256 bits -- carried out exactly in the packed representation): operands whose coefficients are
+    all p - 1 or alternate 0 / p - 1, against the oracle."""
+    rng = random.Random(33)
+    top = (O.P - 1, O.P - 1)
+    cases = [[top] * 6,
+             [top if k % 2 else (0, 0) for k in range(6)],
+             [(O.P - 1, 0) if k % 2 else (0, O.P - 1) for k in range(6)],
+             [(rng.randrange(O.P), rng.randrange(O.P)) for _ in range(6)]]
+    for a in cases:
+        ab = O.gt_marshal(a)
+        for b in cases:
+            bb = O.gt_marshal(b)
+            assert H.call("hh_bn_fp12_op", 0, ab, bb, out_sizes=(384,)) == (0, O.gt_marshal(O.f12_mul(a, b)))
+        assert H.call("hh_bn_fp12_op", 1, ab, ab, out_sizes=(384,)) == (0, O.gt_marshal(O.f12_sqr(a)))
+    g = O.pair(O.g1_mul(5, O.G1_GEN), O.g2_mul(7, O.G2_GEN))
+    gb = O.gt_marshal(g)
+    assert H.call("hh_bn_fp12_op", 2, gb, gb, out_sizes=(384,)) == (0, O.gt_marshal(O.f12_sqr(g)))
+    g5 = g
+    for _ in range(5):
+        g5 = O.f12_sqr(g5)
+    assert H.call("hh_bn_fp12_op", 3, gb, gb, out_sizes=(384,)) == (0, O.gt_marshal(g5))
