@@ -91,6 +91,15 @@ func Ed25519Add(a, b []byte) (out, status []byte, err error) {
 	return
 }
 
+// Ed25519Unmarshal: batch (*point).UnmarshalBinary; status[i] != 0 where the reference returns an error, out[i] is
+// the canonical re-encoding.
+func Ed25519Unmarshal(points []byte) (out, status []byte, err error) {
+	n := len(points) / 32
+	out, status = make([]byte, 32*n), make([]byte, n)
+	err = check(C.kyb_ed25519_unmarshal(C.size_t(n), ptr(points), ptr(out), ptr(status)))
+	return
+}
+
 // Ed25519PolyEval: out[i] = sum_j commits[j] * (idx[i] + 1)^j  (share.PubPoly.Eval for many indices).
 func Ed25519PolyEval(idx []uint32, commits []byte) (out, status []byte, err error) {
 	n, t := len(idx), len(commits)/32
@@ -187,6 +196,22 @@ func Bls12381G1PolyEval(idx []uint32, commits []byte, flags uint32) (out, status
 	return
 }
 
+// Bls12381G1Unmarshal / G2Unmarshal: batch UnmarshalBinary (ZCash rules + subgroup check).  With UncompressedOut the
+// result is the affine form later calls accept under Uncompressed | Trusted(i).
+func Bls12381G1Unmarshal(points []byte, flags uint32) (out, status []byte, err error) {
+	n := len(points) / g1in(flags)
+	out, status = make([]byte, g1out(flags)*n), make([]byte, n)
+	err = check(C.kyb_bls12381_g1_unmarshal(C.size_t(n), ptr(points), ptr(out), ptr(status), C.uint32_t(flags)))
+	return
+}
+
+func Bls12381G2Unmarshal(points []byte, flags uint32) (out, status []byte, err error) {
+	n := len(points) / g2in(flags)
+	out, status = make([]byte, 2*g1out(flags)*n), make([]byte, n)
+	err = check(C.kyb_bls12381_g2_unmarshal(C.size_t(n), ptr(points), ptr(out), ptr(status), C.uint32_t(flags)))
+	return
+}
+
 func Bls12381Pair(g1, g2 []byte, flags uint32) (gt, status []byte, err error) {
 	n := len(g1) / g1in(flags)
 	gt, status = make([]byte, 576*n), make([]byte, n)
@@ -264,6 +289,21 @@ func Bn256G2MSM(scalars, points []byte) (out, status []byte, err error) {
 	n := len(scalars) / 32
 	out, status = make([]byte, 128), make([]byte, n)
 	err = check(C.kyb_bn256_g2_msm(C.size_t(n), ptr(scalars), ptr(points), ptr(out), ptr(status), 0))
+	return
+}
+
+// Bn256G1Unmarshal / G2Unmarshal: batch UnmarshalBinary (on-curve check only, as the reference).
+func Bn256G1Unmarshal(points []byte) (out, status []byte, err error) {
+	n := len(points) / 64
+	out, status = make([]byte, 64*n), make([]byte, n)
+	err = check(C.kyb_bn256_g1_unmarshal(C.size_t(n), ptr(points), ptr(out), ptr(status), 0))
+	return
+}
+
+func Bn256G2Unmarshal(points []byte) (out, status []byte, err error) {
+	n := len(points) / 128
+	out, status = make([]byte, 128*n), make([]byte, n)
+	err = check(C.kyb_bn256_g2_unmarshal(C.size_t(n), ptr(points), ptr(out), ptr(status), 0))
 	return
 }
 

@@ -101,6 +101,13 @@ int kyb_ed25519_mul_same_base(size_t n, const uint8_t *scalars, const uint8_t po
 int kyb_ed25519_add(size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out, uint8_t *status);
 int kyb_ed25519_add_dev(size_t n, const void *d_a, const void *d_b, void *d_out, void *d_status, void *stream);
 
+/* out[i] = MarshalBinary(UnmarshalBinary(points[i])), status[i] = the error UnmarshalBinary would return:
+ * (*point).UnmarshalBinary (group/edwards25519/point.go:65-70 -> ge.go:110-150; bit 255 of y is only the sign of x,
+ * y >= p is accepted, no subgroup check) followed by MarshalBinary (point.go:54-58), i.e. the canonical encoding.
+ * Rejected slots give 32 zero bytes. */
+int kyb_ed25519_unmarshal(size_t n, const uint8_t *points, uint8_t *out, uint8_t *status);
+int kyb_ed25519_unmarshal_dev(size_t n, const void *d_points, void *d_out, void *d_status, void *stream);
+
 /* out[i] = Hash(msgs[i], dst): (*point).Hash (group/edwards25519/point.go:325-334), RFC 9380 suite
  * edwards25519_XMD:SHA-512_ELL2_RO_ (hashToField :336-360, expandMessageXMD :362-430, Elligator 2, cofactor 8).
  * Equal-length messages packed back to back; dst is a HOST pointer of 1..255 bytes. */
@@ -145,6 +152,16 @@ int kyb_bls12381_g2_mul_dev(size_t n, const void *d_scalars, const void *d_point
 /* out[i] = a[i] + b[i]: G1Elt.Add / G2Elt.Add (kilic/g1.go:90-96, g2.go). */
 int kyb_bls12381_g1_add(size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out, uint8_t *status);
 int kyb_bls12381_g2_add(size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out, uint8_t *status);
+
+/* Batch UnmarshalBinary: status[i] = what G1Elt / G2Elt.UnmarshalBinary would decide (kilic/g1.go:127-131, g2.go:
+ * ZCash flag rules, x < p, on the curve, in the r-torsion subgroup -- the 34 fixtures of
+ * pairing/bls12381/deserialization_tests), out[i] = the point re-encoded (48 / 96 B, or 96 / 192 B affine with
+ * KYB_F_UNCOMPRESSED_OUT; zero bytes when rejected).  Input is compressed unless KYB_F_UNCOMPRESSED.  This is the
+ * call that earns KYB_F_TRUSTED(i) | KYB_F_UNCOMPRESSED on later calls with the same points. */
+int kyb_bls12381_g1_unmarshal(size_t n, const uint8_t *points, uint8_t *out, uint8_t *status, uint32_t flags);
+int kyb_bls12381_g2_unmarshal(size_t n, const uint8_t *points, uint8_t *out, uint8_t *status, uint32_t flags);
+int kyb_bls12381_g1_unmarshal_dev(size_t n, const void *d_points, void *d_out, void *d_status, uint32_t flags, void *stream);
+int kyb_bls12381_g2_unmarshal_dev(size_t n, const void *d_points, void *d_out, void *d_status, uint32_t flags, void *stream);
 
 /* gt[i] = e(g1[i], g2[i]).  Replaces Suite.Pair (pairing/pairing.go:12; kilic/suite.go:70-75). */
 int kyb_bls12381_pair(size_t n, const uint8_t *g1, const uint8_t *g2, uint8_t *gt, uint8_t *status, uint32_t flags);
@@ -212,6 +229,14 @@ int kyb_bn256_g2_mul_dev(size_t n, const void *d_scalars, const void *d_points, 
 /* out[i] = a[i] + b[i]: pointG1.Add / pointG2.Add (pairing/bn256/point.go:130-140, 381-391 -> curve.go:69). */
 int kyb_bn256_g1_add(size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out, uint8_t *status);
 int kyb_bn256_g2_add(size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out, uint8_t *status);
+/* Batch UnmarshalBinary: pointG1 / pointG2.UnmarshalBinary (pairing/bn256/point.go:206-238, 466-499): on the curve
+ * (G2: on the twist, NO subgroup check, as the reference), 64 / 128 zero bytes = infinity; out[i] = MarshalBinary of
+ * the accepted point (zero bytes when rejected).  flags are accepted and ignored. */
+int kyb_bn256_g1_unmarshal(size_t n, const uint8_t *points, uint8_t *out, uint8_t *status, uint32_t flags);
+int kyb_bn256_g2_unmarshal(size_t n, const uint8_t *points, uint8_t *out, uint8_t *status, uint32_t flags);
+int kyb_bn256_g1_unmarshal_dev(size_t n, const void *d_points, void *d_out, void *d_status, uint32_t flags, void *stream);
+int kyb_bn256_g2_unmarshal_dev(size_t n, const void *d_points, void *d_out, void *d_status, uint32_t flags, void *stream);
+
 /* gt[i] = e(g1[i], g2[i]): Suite.Pair (pairing/bn256/suite.go:97-103 -> optate.go:266-274). */
 int kyb_bn256_pair(size_t n, const uint8_t *g1, const uint8_t *g2, uint8_t *gt, uint8_t *status, uint32_t flags);
 int kyb_bn256_pair_dev(size_t n, const void *d_g1, const void *d_g2, void *d_gt, void *d_status, uint32_t flags, void *stream);

@@ -86,6 +86,16 @@ SIGNATURES = {
     "kyb_bn256_pair_dev": [_sz, _vp, _vp, _vp, _vp, _u32, _vp],
     "kyb_bn256_pair_check": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _u32],
     "kyb_bn256_pair_check_dev": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
+    "kyb_ed25519_unmarshal": [_sz, _vp, _vp, _vp],
+    "kyb_ed25519_unmarshal_dev": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_bls12381_g1_unmarshal": [_sz, _vp, _vp, _vp, _u32],
+    "kyb_bls12381_g1_unmarshal_dev": [_sz, _vp, _vp, _vp, _u32, _vp],
+    "kyb_bls12381_g2_unmarshal": [_sz, _vp, _vp, _vp, _u32],
+    "kyb_bls12381_g2_unmarshal_dev": [_sz, _vp, _vp, _vp, _u32, _vp],
+    "kyb_bn256_g1_unmarshal": [_sz, _vp, _vp, _vp, _u32],
+    "kyb_bn256_g1_unmarshal_dev": [_sz, _vp, _vp, _vp, _u32, _vp],
+    "kyb_bn256_g2_unmarshal": [_sz, _vp, _vp, _vp, _u32],
+    "kyb_bn256_g2_unmarshal_dev": [_sz, _vp, _vp, _vp, _u32, _vp],
     "kyb_ed25519_poly_eval": [_sz, _vp, _sz, _vp, _vp, _vp],
     "kyb_ed25519_poly_eval_dev": [_sz, _vp, _sz, _vp, _vp, _vp, _vp],
     "kyb_bls12381_g1_poly_eval": [_sz, _vp, _sz, _vp, _vp, _vp, _u32],

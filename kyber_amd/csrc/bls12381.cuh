@@ -749,6 +749,29 @@ KYB_HD int g2_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt
     g2_encode_f(out, a, flags);
     return ST_OK;
 }
+// out = Marshal(Unmarshal(in)): the validation step of G1Elt/G2Elt.UnmarshalBinary (kilic/g1.go:127-131, g2.go) as a
+// batch operation -- ZCash flag rules, on-curve, r-torsion -- followed by the re-encoding the flags ask for, so that
+// a caller validates once and afterwards passes KYB_F_UNCOMPRESSED | KYB_F_TRUSTED(i).
+KYB_HD int g1_unmarshal_wire(uint8_t* out, const uint8_t* pt, uint32_t flags = 0) {
+    g1_aff a;
+    const int st = g1_decode_f(a, pt, flags, 0);
+    if (st != ST_OK) {
+        zero_bytes(out, (int)g1_out_size(flags));
+        return st;
+    }
+    g1_encode_f(out, a, flags);
+    return ST_OK;
+}
+KYB_HD int g2_unmarshal_wire(uint8_t* out, const uint8_t* pt, uint32_t flags = 0) {
+    g2_aff a;
+    const int st = g2_decode_f(a, pt, flags, 0);
+    if (st != ST_OK) {
+        zero_bytes(out, (int)g2_out_size(flags));
+        return st;
+    }
+    g2_encode_f(out, a, flags);
+    return ST_OK;
+}
 // out = a + b   (Point.Add: kilic/g1.go:90-96, pairing/bn256/point.go:130-140 -> curve.go:69)
 KYB_HD int g1_add_wire(uint8_t* out, const uint8_t* pa, const uint8_t* pb) {
     g1_aff a, b;

@@ -513,6 +513,28 @@ KYB_HD int g2_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt
     g2_encode(out, a);
     return ST_OK;
 }
+// out = Marshal(Unmarshal(in)): pointG1/pointG2.UnmarshalBinary (pairing/bn256/point.go:206-238, 466-499): coordinates
+// < p, on the curve (G2: on the twist, no subgroup check), all-zero bytes = infinity.
+KYB_HD int g1_unmarshal_wire(uint8_t* out, const uint8_t* pt, uint32_t = 0) {
+    g1_aff a;
+    const int st = g1_decode(a, pt);
+    if (st != ST_OK) {
+        zero_bytes(out, 64);
+        return st;
+    }
+    g1_encode(out, a);
+    return ST_OK;
+}
+KYB_HD int g2_unmarshal_wire(uint8_t* out, const uint8_t* pt, uint32_t = 0) {
+    g2_aff a;
+    const int st = g2_decode(a, pt);
+    if (st != ST_OK) {
+        zero_bytes(out, 128);
+        return st;
+    }
+    g2_encode(out, a);
+    return ST_OK;
+}
 // out = a + b   (Point.Add: kilic/g1.go:90-96, pairing/bn256/point.go:130-140 -> curve.go:69)
 KYB_HD int g1_add_wire(uint8_t* out, const uint8_t* pa, const uint8_t* pb) {
     g1_aff a, b;

@@ -780,8 +780,58 @@ __global__ __launch_bounds__(128) void ed25519_add_kernel(size_t n, const uint32
     store_words8(out + idx * 8, w);
     if (status) status[idx] = ok ? KYB_ST_OK : KYB_ST_BAD_POINT;
 }
+// out = Marshal(Unmarshal(in)): (*point).UnmarshalBinary (group/edwards25519/point.go:65-70 -> ge.go:110-150) as a batch
+// validity check -- bit 255 of y ignored for the field element, y >= p accepted, fails only when x^2 has no root --
+// followed by the canonical encoding MarshalBinary (ge.go:99-107) would give back.
+__global__ __launch_bounds__(128) void ed25519_unmarshal_kernel(size_t n, const uint32_t* __restrict__ in,
+                                                                uint32_t* __restrict__ out,
+                                                                uint8_t* __restrict__ status) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    uint32_t w[8];
+    load_words8(w, in + idx * 8);
+    ge_p3 A;
+    const bool ok = ge_p3_fromwords(A, w);
+    ge_p3_towords(w, A);
+    if (!ok) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = 0;
+    }
+    store_words8(out + idx * 8, w);
+    if (status) status[idx] = ok ? KYB_ST_OK : KYB_ST_BAD_POINT;
+}
 }  // namespace kyb
 extern "C" {
+int kyb_ed25519_unmarshal_dev(size_t n, const void* d_points, void* d_out, void* d_status, void* stream) {
+    if (n && (!d_points || !d_out)) {
+        kyb::set_error("kyb_ed25519_unmarshal_dev: bad argument");
+        return KYB_E_ARG;
+    }
+    if (!n) return KYB_OK;
+    hipLaunchKernelGGL(kyb::ed25519_unmarshal_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0,
+                       (hipStream_t)stream, n, (const uint32_t*)d_points, (uint32_t*)d_out, (uint8_t*)d_status);
+    KYB_HIP_CHECK(hipGetLastError());
+    return KYB_OK;
+}
+int kyb_ed25519_unmarshal(size_t n, const uint8_t* points, uint8_t* out, uint8_t* status) {
+    if (n && (!points || !out)) {
+        kyb::set_error("kyb_ed25519_unmarshal: bad argument");
+        return KYB_E_ARG;
+    }
+    if (!n) return KYB_OK;
+    kyb::DeviceCtx* ctx;
+    int rc = kyb::get_ctx(&ctx);
+    if (rc) return rc;
+    kyb::StageScope sc_(ctx);
+    kyb::StageBuf d_p, d_o, d_st;
+    rc = d_p.upload(points, n * 32);
+    if (rc == KYB_OK) rc = d_o.alloc(n * 32);
+    if (rc == KYB_OK) rc = d_st.alloc(n);
+    if (rc == KYB_OK) rc = kyb_ed25519_unmarshal_dev(n, d_p.p, d_o.p, d_st.p, nullptr);
+    if (rc == KYB_OK) rc = d_o.download(out, n * 32);
+    if (rc == KYB_OK && status) rc = d_st.download(status, n);
+    return rc;
+}
 int kyb_ed25519_add_dev(size_t n, const void* d_a, const void* d_b, void* d_out, void* d_status, void* stream) {
     if (n && (!d_a || !d_b || !d_out)) {
         kyb::set_error("kyb_ed25519_add_dev: bad argument");

@@ -38,6 +38,22 @@ __global__ __launch_bounds__(64) void PFX##_g2_mul_kernel(size_t n, const uint8_
     const int st = NS::g2_mul_wire(out + NS::g2_out_size(flags) * idx, scalars + 32 * idx, pts + pt_stride * idx, flags); \
     if (status) status[idx] = (uint8_t)st; \
 } \
+__global__ __launch_bounds__(64) void PFX##_g1_unmarshal_kernel(size_t n, const uint8_t* __restrict__ pts, \
+                                                              uint8_t* __restrict__ out, uint8_t* __restrict__ status, \
+                                                              uint32_t flags) { \
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
+    if (idx >= n) return; \
+    const int st = NS::g1_unmarshal_wire(out + NS::g1_out_size(flags) * idx, pts + NS::g1_wire_size(flags) * idx, flags); \
+    if (status) status[idx] = (uint8_t)st; \
+} \
+__global__ __launch_bounds__(64) void PFX##_g2_unmarshal_kernel(size_t n, const uint8_t* __restrict__ pts, \
+                                                              uint8_t* __restrict__ out, uint8_t* __restrict__ status, \
+                                                              uint32_t flags) { \
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
+    if (idx >= n) return; \
+    const int st = NS::g2_unmarshal_wire(out + NS::g2_out_size(flags) * idx, pts + NS::g2_wire_size(flags) * idx, flags); \
+    if (status) status[idx] = (uint8_t)st; \
+} \
 __global__ __launch_bounds__(64) void PFX##_g1_add_kernel(size_t n, const uint8_t* __restrict__ a, \
                                                         const uint8_t* __restrict__ b, uint8_t* __restrict__ out, \
                                                         uint8_t* __restrict__ status) { \
@@ -121,6 +137,58 @@ int kyb_##PFX##_g1_mul_same_base(size_t n, const uint8_t* scalars, const uint8_t
 int kyb_##PFX##_g2_mul_same_base(size_t n, const uint8_t* scalars, const uint8_t* point, uint8_t* out, \
                                   uint8_t* status, uint32_t flags) { \
     return PFX##_mul_host(true, n, scalars, point, 0, out, status, flags); \
+} \
+int kyb_##PFX##_g1_unmarshal_dev(size_t n, const void* d_points, void* d_out, void* d_status, uint32_t flags, \
+                                  void* stream) { \
+    if (n && (!d_points || !d_out)) { \
+        kyb::set_error("kyb_" #PFX "_g1_unmarshal_dev: bad argument"); \
+        return KYB_E_ARG; \
+    } \
+    if (!n) return KYB_OK; \
+    hipLaunchKernelGGL(kyb::PFX##_g1_unmarshal_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
+                       (const uint8_t*)d_points, (uint8_t*)d_out, (uint8_t*)d_status, flags); \
+    KYB_HIP_CHECK(hipGetLastError()); \
+    return KYB_OK; \
+} \
+int kyb_##PFX##_g2_unmarshal_dev(size_t n, const void* d_points, void* d_out, void* d_status, uint32_t flags, \
+                                  void* stream) { \
+    if (n && (!d_points || !d_out)) { \
+        kyb::set_error("kyb_" #PFX "_g2_unmarshal_dev: bad argument"); \
+        return KYB_E_ARG; \
+    } \
+    if (!n) return KYB_OK; \
+    hipLaunchKernelGGL(kyb::PFX##_g2_unmarshal_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
+                       (const uint8_t*)d_points, (uint8_t*)d_out, (uint8_t*)d_status, flags); \
+    KYB_HIP_CHECK(hipGetLastError()); \
+    return KYB_OK; \
+} \
+static int PFX##_unmarshal_host(bool g2, size_t n, const uint8_t* points, uint8_t* out, uint8_t* status, \
+                                uint32_t flags) { \
+    const size_t psz = g2 ? kyb::NS::g2_out_size(flags) : kyb::NS::g1_out_size(flags); \
+    const size_t isz = g2 ? kyb::NS::g2_wire_size(flags) : kyb::NS::g1_wire_size(flags); \
+    if (n && (!points || !out)) { \
+        kyb::set_error("kyb_" #PFX "_g*_unmarshal: bad argument"); \
+        return KYB_E_ARG; \
+    } \
+    if (!n) return KYB_OK; \
+    kyb::DeviceCtx* ctx; \
+    KYB_TRY(kyb::get_ctx(&ctx)); \
+    kyb::StageScope sc_(ctx); \
+    kyb::StageBuf p, o, st; \
+    KYB_TRY(p.upload(points, n * isz)); \
+    KYB_TRY(o.alloc(n * psz)); \
+    KYB_TRY(st.alloc(n)); \
+    KYB_TRY(g2 ? kyb_##PFX##_g2_unmarshal_dev(n, p.p, o.p, st.p, flags, nullptr) \
+               : kyb_##PFX##_g1_unmarshal_dev(n, p.p, o.p, st.p, flags, nullptr)); \
+    KYB_TRY(o.download(out, n * psz)); \
+    if (status) KYB_TRY(st.download(status, n)); \
+    return KYB_OK; \
+} \
+int kyb_##PFX##_g1_unmarshal(size_t n, const uint8_t* points, uint8_t* out, uint8_t* status, uint32_t flags) { \
+    return PFX##_unmarshal_host(false, n, points, out, status, flags); \
+} \
+int kyb_##PFX##_g2_unmarshal(size_t n, const uint8_t* points, uint8_t* out, uint8_t* status, uint32_t flags) { \
+    return PFX##_unmarshal_host(true, n, points, out, status, flags); \
 } \
 static int PFX##_add_host(bool g2, size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, uint8_t* status) { \
     const size_t psz = g2 ? G2SZ : G1SZ; \

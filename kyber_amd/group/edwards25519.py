@@ -163,6 +163,27 @@ def poly_eval(commits, indices):
     return out, st[:t]
 
 
+def batch_unmarshal(points):
+    """(out, status): N x (*point).UnmarshalBinary (point.go:65-70 -> ge.go:110-150): status[i] != 0 where the reference
+    returns an error; out[i] = MarshalBinary of the accepted point (canonical y, point.go:54-58)."""
+    lib = load()
+    if _is_torch(points):
+        import torch
+
+        p = points.contiguous().view(-1, 32)
+        out = torch.empty_like(p)
+        st = torch.empty(max(p.shape[0], 1), dtype=torch.uint8, device=p.device)
+        check(lib.kyb_ed25519_unmarshal_dev(p.shape[0], p.data_ptr(), out.data_ptr(), st.data_ptr(), _stream_ptr()),
+              "kyb_ed25519_unmarshal_dev")
+        return out, st[:p.shape[0]]
+    p = _as_host(points, 32)
+    n = p.shape[0]
+    out = np.empty((n, 32), dtype=np.uint8)
+    st = np.zeros(max(n, 1), dtype=np.uint8)
+    check(lib.kyb_ed25519_unmarshal(n, p.ctypes.data, out.ctypes.data, st.ctypes.data), "kyb_ed25519_unmarshal")
+    return out, st[:n]
+
+
 def batch_add(a, b):
     """(out, status): out[i] = a[i] + b[i]  (N x Point.Add, point.go:216-223)."""
     lib = load()

@@ -115,6 +115,34 @@ class Engine:
         check(fn(n, x.ctypes.data, y.ctypes.data, out.ctypes.data, st.ctypes.data), nm)
         return out, st
 
+    def _out_len(self, group: int, flags: int) -> int:
+        w = self.G1_LEN if group == 1 else self.G2_LEN
+        return w * self.unc_factor if flags & F_UNCOMPRESSED_OUT else w
+
+    def batch_unmarshal(self, group: int, points, flags: int = 0):
+        """(out, status): N x Point.UnmarshalBinary (kilic/g1.go:127-131; pairing/bn256/point.go:206-238, 466-499):
+        status[i] != 0 where the reference returns an error, out[i] = the accepted point re-encoded (uncompressed
+        affine with F_UNCOMPRESSED_OUT on BLS12-381).  Host buffers or torch device tensors.  Points that pass may
+        be handed to later calls with F_TRUSTED(i) (| F_UNCOMPRESSED)."""
+        wi, wo = self._in_len(group, flags), self._out_len(group, flags)
+        if _is_torch(points):
+            import torch
+
+            p = points.contiguous().view(-1, wi)
+            n = p.shape[0]
+            out = torch.empty((n, wo), dtype=torch.uint8, device=p.device)
+            st = torch.empty(max(n, 1), dtype=torch.uint8, device=p.device)
+            fn, nm = self._fn(f"g{group}_unmarshal_dev")
+            check(fn(n, p.data_ptr(), out.data_ptr(), st.data_ptr(), flags, _stream()), nm)
+            return out, st[:n]
+        p = _host(points, wi)
+        n = p.shape[0]
+        out = np.empty((n, wo), dtype=np.uint8)
+        st = np.zeros(max(n, 1), dtype=np.uint8)
+        fn, nm = self._fn(f"g{group}_unmarshal")
+        check(fn(n, p.ctypes.data, out.ctypes.data, st.ctypes.data, flags), nm)
+        return out, st[:n]
+
     def msm(self, group: int, scalars, points, flags: int = 0):
         """(out, status): out = sum_i scalars[i] * points[i] as ONE encoded point -- the MSM-shaped call
         sites of the reference (share/poly.go:340-348, 449-476; sign/bdn/bdn.go:126-181).  If any

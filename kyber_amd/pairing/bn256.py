@@ -39,6 +39,8 @@ g1_msm, g2_msm = ENGINE.g1_msm, ENGINE.g2_msm
 gt_batch_mul = ENGINE.gt_batch_mul
 g1_batch_add = lambda a, b: ENGINE.add(1, a, b)
 g2_batch_add = lambda a, b: ENGINE.add(2, a, b)
+g1_batch_unmarshal = lambda pts, flags=0: ENGINE.batch_unmarshal(1, pts, flags)
+g2_batch_unmarshal = lambda pts, flags=0: ENGINE.batch_unmarshal(2, pts, flags)
 Scalar, G1Elt, G2Elt, GTElt, Suite = ENGINE.make_types()
 
 

@@ -68,6 +68,8 @@ int hh_bls_pair_check_f(const uint8_t* p1, const uint8_t* p2, const uint8_t* i1,
                         uint8_t* ok) {
     return bls::pair_check_wire(ok, p1, p2, i1, i2, (uint32_t)flags);
 }
+int hh_bls_g1_unmarshal(const uint8_t* in, int flags, uint8_t* out) { return bls::g1_unmarshal_wire(out, in, (uint32_t)flags); }
+int hh_bls_g2_unmarshal(const uint8_t* in, int flags, uint8_t* out) { return bls::g2_unmarshal_wire(out, in, (uint32_t)flags); }
 int hh_bls_g1_decode_unc(const uint8_t* in, int validate) { bls::g1_aff a; return bls::g1_decode_unc(a, in, validate != 0); }
 int hh_bls_g2_decode_unc(const uint8_t* in, int validate) { bls::g2_aff a; return bls::g2_decode_unc(a, in, validate != 0); }
 
@@ -107,6 +109,8 @@ void hh_bn_fp_op(int op, const uint8_t* a32, const uint8_t* b32, uint8_t* out32)
 }
 int hh_bn_g1_decode(const uint8_t* in) { bn::g1_aff a; return bn::g1_decode(a, in); }
 int hh_bn_g2_decode(const uint8_t* in) { bn::g2_aff a; return bn::g2_decode(a, in); }
+int hh_bn_g1_unmarshal(const uint8_t* in, uint8_t* out) { return bn::g1_unmarshal_wire(out, in); }
+int hh_bn_g2_unmarshal(const uint8_t* in, uint8_t* out) { return bn::g2_unmarshal_wire(out, in); }
 int hh_bn_g1_mul(const uint8_t* k, const uint8_t* pt, uint8_t* out) { return bn::g1_mul_wire(out, k, pt); }
 int hh_bn_g2_mul(const uint8_t* k, const uint8_t* pt, uint8_t* out) { return bn::g2_mul_wire(out, k, pt); }
 int hh_bn_pair(const uint8_t* g1, const uint8_t* g2, uint8_t* gt) { return bn::pair_wire(gt, g1, g2); }

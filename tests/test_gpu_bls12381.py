@@ -403,3 +403,51 @@ def test_fused_verify_g2_matches_hash_plus_pairing_check(bls):
     ok_t, st_t = bls.batch_verify_g2(X, msgs, sig, flags=bls.F_TRUSTED(0))
     exp_t = exp.copy()
     assert (ok_t.astype(bool)[np.arange(n) != 9] == exp_t[np.arange(n) != 9]).all()
+
+
+def test_batch_unmarshal_zcash_fixtures_flags_and_device_path(bls, golden_dir):
+    """kyb_bls12381_g*_unmarshal = N x UnmarshalBinary (+ MarshalBinary): the reference's 34 deserialization fixtures in
+    one batch per group, the uncompressed output feeding a later trusted call, and the device-tensor entry point."""
+    import torch
+
+    d = json.load(open(os.path.join(golden_dir, "bls12381_zcash.json")))
+    U, UO, T = bls.F_UNCOMPRESSED, bls.F_UNCOMPRESSED_OUT, bls.F_TRUSTED(0)
+    for grp, fn, size, dec, unc in (("G1", bls.g1_batch_unmarshal, 48, O.g1_decompress, O.g1_serialize_unc),
+                                    ("G2", bls.g2_batch_unmarshal, 96, O.g2_decompress, O.g2_serialize_unc)):
+        cases = [e for e in d[grp] if len(bytes.fromhex(e["hex"])) == size]
+        assert len(cases) >= 12
+        batch = b"".join(bytes.fromhex(e["hex"]) for e in cases)
+        out, st = fn(batch)
+        out_u, st_u = fn(batch, UO)
+        assert out.shape == (len(cases), size) and out_u.shape == (len(cases), 2 * size)
+        assert (st == st_u).all()
+        for i, e in enumerate(cases):
+            buf = bytes.fromhex(e["hex"])
+            assert (st[i] == 0) == e["valid"], (grp, e["name"], st[i])
+            if e["valid"]:
+                assert bytes(out[i]) == buf and bytes(out_u[i]) == unc(dec(buf))
+            else:
+                assert not out[i].any() and not out_u[i].any()
+        # device tensors, same answers
+        t = torch.frombuffer(bytearray(batch), dtype=torch.uint8).cuda()
+        out_d, st_d = fn(t, UO)
+        assert bytes(out_d.cpu().numpy().tobytes()) == out_u.tobytes() and bytes(st_d.cpu().numpy().tobytes()) == st_u.tobytes()
+    # validate once, then multiply the uncompressed affine points without re-checking them
+    rng = random.Random(77)
+    n = 64
+    hs = [rng.randrange(1, O.R) for _ in range(n)]
+    comp = bls.g1_commit(b"".join(h.to_bytes(32, "big") for h in hs))[0]
+    aff, st = bls.g1_batch_unmarshal(comp, UO)
+    assert not st.any()
+    ks = _scalars(b"unmarshal-then-mul", n)
+    a, sa = bls.g1_batch_mul(ks, comp)
+    b, sb = bls.g1_batch_mul(ks, aff, U | T)
+    assert not sa.any() and not sb.any() and (a == b).all()
+    # off-subgroup: rejected with status 2, let through only when the caller vouches for it
+    c = O.g1_compress(_off_subgroup_g1())
+    out, st = bls.g1_batch_unmarshal(c + comp[0].tobytes())
+    assert list(st) == [2, 0] and not out[0].any() and bytes(out[1]) == comp[0].tobytes()
+    out, st = bls.g1_batch_unmarshal(c, T)
+    assert st[0] == 0 and bytes(out[0]) == c
+    out, st = bls.g1_batch_unmarshal(b"")
+    assert out.shape == (0, 48) and st.shape == (0,)

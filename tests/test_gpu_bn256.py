@@ -179,3 +179,31 @@ def test_hash_g1_fixtures_and_batch(bn, G):
         m = bytes((3 * i + ln) & 0xFF for i in range(ln))
         out, st = bn.batch_hash_g1([m, m])
         assert bytes(out[1]) == O.g1_marshal(O.hash_to_g1(m)), ln
+
+
+def test_batch_unmarshal(bn):
+    """kyb_bn256_g*_unmarshal = N x UnmarshalBinary + MarshalBinary (pairing/bn256/point.go:206-238, 466-499)."""
+    rng = random.Random(41)
+    x, y = O.G1_GEN
+    fp = lambda v: v.to_bytes(32, "big")
+    g1 = [O.g1_marshal(O.g1_mul(rng.randrange(1, O.ORDER), O.G1_GEN)) for _ in range(5)]
+    batch = g1 + [bytes(64), fp(5) + fp(5), fp(x + O.P) + fp(y)]
+    out, st = bn.g1_batch_unmarshal(b"".join(batch))
+    assert list(st) == [0] * 6 + [1, 0]
+    for i in range(6):
+        assert bytes(out[i]) == batch[i]
+    assert not out[6].any() and bytes(out[7]) == O.g1_marshal(O.G1_GEN)
+    g2 = [O.g2_marshal(O.g2_mul(rng.randrange(1, O.ORDER), O.G2_GEN)) for _ in range(3)]
+    # on the twist, outside the order-r subgroup: accepted, as the reference does
+    while True:
+        X = (rng.randrange(O.P), rng.randrange(O.P))
+        Y = O.f2_sqrt(O.f2_add(O.f2_mul(O.f2_sqr(X), X), O.TWIST_B))
+        if Y is not None:
+            break
+    assert O.g2_mul(O.ORDER, (X, Y)) is not None
+    batch = g2 + [bytes(128), fp(1) * 4, O.g2_marshal((X, Y))]
+    out, st = bn.g2_batch_unmarshal(b"".join(batch), bn.F_TRUSTED_ALL)  # flags ignored
+    assert list(st) == [0, 0, 0, 0, 1, 0]
+    for i in (0, 1, 2, 3, 5):
+        assert bytes(out[i]) == batch[i]
+    assert not out[4].any()

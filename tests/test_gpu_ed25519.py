@@ -244,3 +244,31 @@ def test_two_streams_do_not_share_workspaces(ed):
         torch.cuda.synchronize()
         assert torch.equal(out_a, ref_a) and torch.equal(out_b, ref_b)
         assert torch.equal(m_a, ref_ma) and torch.equal(m_b, ref_mb)
+
+
+def test_batch_unmarshal_vs_oracle(ed):
+    """kyb_ed25519_unmarshal = N x UnmarshalBinary + MarshalBinary (point.go:54-70, ge.go:99-150): non-canonical y and
+    "-0" are accepted and come back canonical, a y with no x is status 1, host and device entry points agree."""
+    import json
+    import torch
+
+    misc = json.load(open(os.path.join(G, "ed25519_misc.json")))
+    pts = [O.encode(O.B), b"\x01" + bytes(31)] + [bytes.fromhex(h) for h in misc["small_order"]]
+    pts += [(O.P + 1).to_bytes(32, "little"), ((O.P + 1) | (1 << 255)).to_bytes(32, "little"),
+            (1 | (1 << 255)).to_bytes(32, "little"), (2).to_bytes(32, "little"), bytes([0xFF] * 32)]
+    pts += [bytes(KAT[i, 1]) for i in range(200)]
+    raw = hashlib.shake_256(b"ed25519-unmarshal").digest(32 * 300)
+    pts += [raw[32 * i:32 * i + 32] for i in range(300)]  # about half of random strings decode
+    out, st = ed.batch_unmarshal(b"".join(pts))
+    bad = 0
+    for i, p in enumerate(pts):
+        dec = O.decode(p)
+        if dec is None:
+            bad += 1
+            assert st[i] == 1 and not out[i].any(), i
+        else:
+            assert st[i] == 0 and bytes(out[i]) == O.encode(dec), i
+    assert 100 < bad < 250
+    t = torch.frombuffer(bytearray(b"".join(pts)), dtype=torch.uint8).cuda()
+    out_d, st_d = ed.batch_unmarshal(t)
+    assert out_d.cpu().numpy().tobytes() == out.tobytes() and st_d.cpu().numpy().tobytes() == st.tobytes()

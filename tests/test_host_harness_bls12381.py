@@ -353,3 +353,31 @@ def test_fp12_ops_at_extreme_magnitudes():
     for _ in range(5):
         g5 = O.f12_sqr(g5)
     assert H.call("hh_bls_fp12_op", 3, gb, gb, out_sizes=(576,)) == (0, O.gt_to_bytes(g5))
+
+
+def test_unmarshal_wire_on_the_zcash_fixtures_and_flags(golden_dir):
+    """g*_unmarshal_wire = UnmarshalBinary + MarshalBinary (kilic/g1.go:119-131): every fixture of the right length,
+    both output encodings, uncompressed input, and what F_TRUSTED lets through."""
+    d = json.load(open(os.path.join(golden_dir, "bls12381_zcash.json")))
+    U, UO = 2, 4
+    for grp, fn, size, dec, unc in (("G1", "hh_bls_g1_unmarshal", 48, O.g1_decompress, O.g1_serialize_unc),
+                                    ("G2", "hh_bls_g2_unmarshal", 96, O.g2_decompress, O.g2_serialize_unc)):
+        for e in d[grp]:
+            buf = bytes.fromhex(e["hex"])
+            if len(buf) != size:
+                continue
+            st, out = H.call(fn, buf, 0, out_sizes=(size,))
+            assert (st == 0) == e["valid"], (grp, e["name"])
+            assert out == (buf if e["valid"] else bytes(size))
+            st2, out2 = H.call(fn, buf, UO, out_sizes=(2 * size,))
+            assert st2 == st
+            if e["valid"]:
+                assert out2 == unc(dec(buf))
+                assert H.call(fn, out2, U, out_sizes=(size,)) == (0, buf)  # and back
+            else:
+                assert out2 == bytes(2 * size)
+    c1, c2 = _cofactor_points()
+    assert H.call("hh_bls_g1_unmarshal", O.g1_compress(c1), 0, out_sizes=(48,)) == (2, bytes(48))
+    assert H.call("hh_bls_g2_unmarshal", O.g2_compress(c2), 0, out_sizes=(96,)) == (2, bytes(96))
+    assert H.call("hh_bls_g1_unmarshal", O.g1_compress(c1), F_TRUSTED(0), out_sizes=(48,)) == (0, O.g1_compress(c1))
+    assert H.call("hh_bls_g1_unmarshal", O.g1_compress(None), UO, out_sizes=(96,)) == (0, O.g1_serialize_unc(None))

@@ -172,3 +172,29 @@ def test_fp12_ops_at_extreme_magnitudes():
     for _ in range(5):
         g5 = O.f12_sqr(g5)
     assert H.call("hh_bn_fp12_op", 3, gb, gb, out_sizes=(384,)) == (0, O.gt_marshal(g5))
+
+
+def test_unmarshal_wire():
+    """g*_unmarshal_wire = UnmarshalBinary + MarshalBinary (pairing/bn256/point.go:170-238, 423-499)."""
+    rng = random.Random(31)
+    x, y = O.G1_GEN
+    for _ in range(4):
+        p1, p2 = O.g1_mul(rng.randrange(1, O.ORDER), O.G1_GEN), O.g2_mul(rng.randrange(1, O.ORDER), O.G2_GEN)
+        assert H.call("hh_bn_g1_unmarshal", O.g1_marshal(p1), out_sizes=(64,)) == (0, O.g1_marshal(p1))
+        assert H.call("hh_bn_g2_unmarshal", O.g2_marshal(p2), out_sizes=(128,)) == (0, O.g2_marshal(p2))
+    assert H.call("hh_bn_g1_unmarshal", bytes(64), out_sizes=(64,)) == (0, bytes(64))
+    assert H.call("hh_bn_g2_unmarshal", bytes(128), out_sizes=(128,)) == (0, bytes(128))
+    assert H.call("hh_bn_g1_unmarshal", _fp(5) + _fp(5), out_sizes=(64,)) == (1, bytes(64))
+    assert H.call("hh_bn_g2_unmarshal", _fp(1) * 4, out_sizes=(128,)) == (1, bytes(128))
+    # a non-canonical coordinate is accepted and comes back reduced
+    assert H.call("hh_bn_g1_unmarshal", _fp(x + O.P) + _fp(y), out_sizes=(64,)) == (0, O.g1_marshal(O.G1_GEN))
+    # G2: on the twist but outside the order-r subgroup is accepted, as in the reference (no subgroup check)
+    xx = 1
+    while True:
+        X = (xx, 1)
+        y2 = O.f2_sqrt(O.f2_add(O.f2_mul(O.f2_sqr(X), X), O.TWIST_B))
+        if y2 is not None and O.g2_mul(O.ORDER, (X, y2)) is not None:
+            break
+        xx += 1
+    buf = O.g2_marshal((X, y2))
+    assert H.call("hh_bn_g2_unmarshal", buf, out_sizes=(128,)) == (0, buf)
