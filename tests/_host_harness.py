@@ -1,5 +1,6 @@
 """Build + load tests/host_harness.cpp (the device headers compiled for the CPU; test infrastructure)."""
 import ctypes as C
+import hashlib
 import os
 import subprocess
 
@@ -9,14 +10,28 @@ OUT = os.path.join(ROOT, "tests", "_build", "libhostharness.so")
 _lib = None
 
 
+def _deps_digest() -> str:
+    """Content hash of the harness source + every device header (mtimes do not survive a snapshot copy)."""
+    csrc = os.path.join(ROOT, "kyber_amd", "csrc")
+    deps = [SRC] + sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".cuh", ".h")))
+    h = hashlib.sha256()
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def lib():
     global _lib
     if _lib is None:
-        deps = [SRC] + [os.path.join(ROOT, "kyber_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "kyber_amd", "csrc"))
-                        if f.endswith((".cuh", ".h"))]
-        if not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(d) for d in deps):
+        stamp, digest = OUT + ".sha256", _deps_digest()
+        fresh = os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read().strip() == digest
+        if not fresh:
             os.makedirs(os.path.dirname(OUT), exist_ok=True)
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", OUT, SRC])
+            with open(stamp, "w") as f:
+                f.write(digest)
         _lib = C.CDLL(OUT)
     return _lib
 
