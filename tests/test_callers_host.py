@@ -10,3 +10,94 @@ def test_bdn_coefficients_match_reference_fixture(golden_dir):
     G = json.load(open(os.path.join(golden_dir, "bn256.json")))
     pubs = [O.g2_marshal(O.g2_mul(i, O.G2_GEN)) for i in (1, 2, 3)]
     assert [f"{c:032x}" for c in bdn.hash_point_to_r(pubs)] == G["bdn_coefs"]
+
+
+def _oracle_backed_ed25519(monkeypatch):
+    """share/poly over the Ed25519 mirror types with every engine call answered by the Python oracle (no GPU): the
+    host logic -- share selection, Lagrange bases, which scalars meet which points -- is what is under test."""
+    import numpy as np
+
+    from kyber_amd.group import edwards25519 as ed
+    from kyber_amd.share import poly
+    from oracle import ed25519 as E
+
+    def rows(bs):
+        return np.frombuffer(b"".join(bs), dtype=np.uint8).reshape(len(bs), 32)
+
+    def mul_same_base(scal, base):
+        pt = E.encode(E.B) if base is None else bytes(base)
+        return rows([E.mul(scal[i:i + 32], pt, vartime=True) for i in range(0, len(scal), 32)])
+
+    def msm(scal, pts):
+        acc = E.IDENTITY
+        for i in range(0, len(scal), 32):
+            acc = E.add(acc, E.mul_int(int.from_bytes(scal[i:i + 32], "little"), E.decode(pts[i:i + 32])))
+        n = len(scal) // 32
+        return np.frombuffer(E.encode(acc), dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+
+    def batch_add(a, b):
+        out = [E.encode(E.add(E.decode(a[i:i + 32]), E.decode(b[i:i + 32]))) for i in range(0, len(a), 32)]
+        return rows(out), np.zeros(len(out), dtype=np.uint8)
+
+    monkeypatch.setattr(poly, "_ops", lambda group: (mul_same_base, msm, 32))
+    monkeypatch.setattr(poly, "_add_op", lambda group: batch_add)
+    return ed.NewSuite(), poly, E
+
+
+def test_share_poly_recover_pub_poly_and_scalar_side(monkeypatch):
+    """RecoverPubPoly as t MSMs over the same shares (poly.go:480-508), PubPoly.Add / Equal, and the scalar-field
+    routines (RecoverSecret, RecoverPriPoly, PriPoly.Mul / Add, lagrangeBasis) of poly.go:96-283, 513-536."""
+    import random
+
+    import pytest
+
+    g, poly, E = _oracle_backed_ed25519(monkeypatch)
+    rng = random.Random(12)
+    rand = lambda n: bytes(rng.randrange(256) for _ in range(n))
+    t, n = 4, 7
+    pri = poly.PriPoly.new(g, t, rand=rand)
+    pub = pri.Commit(None)
+    for c, A in zip(pri.coeffs, pub.commits):  # Commit: coeffs[i] * B
+        assert A.MarshalBinary() == E.mul(c.MarshalBinary(), E.encode(E.B), vartime=True)
+    # scalar side
+    pshares = pri.Shares(n)
+    assert [s.I for s in pshares] == list(range(n))
+    some = list(pshares)
+    some[0] = None
+    rng.shuffle(some)
+    assert poly.recover_secret(g, some, t, n).Equal(pri.coeffs[0])
+    assert poly.recover_pri_poly(g, some, t, n).Equal(pri)
+    with pytest.raises(ValueError):
+        poly.recover_secret(g, some[:0] + [s for s in some if s is not None][:t - 1], t, n)
+    xs = {i: g.Scalar().SetInt64(i + 1) for i in (1, 2, 5, 6)}
+    for i in xs:  # L_i(x_m) = [i == m]
+        L = poly.lagrange_basis(g, i, xs)
+        assert L.Threshold() == len(xs)
+        for m in xs:
+            assert L.Eval(m).V.Equal(g.Scalar().One() if m == i else g.Scalar().Zero())
+    q = poly.PriPoly.new(g, t, rand=rand)
+    s5 = g.Scalar().SetInt64(6)
+    prod = pri.Mul(q)  # (p q)(x) = p(x) q(x), degree 2t - 2
+    assert prod.Threshold() == 2 * t - 1
+    assert prod.Eval(5).V.Equal(g.Scalar().Mul(pri.Eval(5).V, q.Eval(5).V))
+    assert pri.Add(q).Eval(5).V.Equal(g.Scalar().Add(pri.Eval(5).V, q.Eval(5).V))
+    with pytest.raises(ValueError):
+        pri.Add(prod)
+    del s5
+    # point side: any t public shares give back every commitment
+    shares = [pub.Eval(i) for i in range(n)]
+    for s, ps in zip(shares, pshares):  # Eval(i) = p(i) * B
+        assert s.V.MarshalBinary() == E.mul(ps.V.MarshalBinary(), E.encode(E.B), vartime=True)
+    shares[2] = None
+    rng.shuffle(shares)
+    rec = poly.recover_pub_poly(g, shares, t, n)
+    assert rec.Equal(pub) and rec.Threshold() == t
+    assert poly.recover_commit(g, shares, t, n).Equal(pub.Commit())
+    with pytest.raises(ValueError):
+        poly.recover_pub_poly(g, [s for s in shares if s is not None][:t - 1], t, n)
+    # PubPoly.Add commutes with PriPoly.Add
+    qpub = q.Commit(None)
+    assert pub.Add(qpub).Equal(pri.Add(q).Commit(None))
+    assert not pub.Equal(qpub)
+    with pytest.raises(ValueError):
+        pub.Add(poly.PubPoly(g, None, qpub.commits[:2]))

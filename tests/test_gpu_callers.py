@@ -204,3 +204,33 @@ def test_pubpoly_batched_eval_matches_per_index_eval(name):
     bad[3] = type(g.Point())(b"\x02" + bytes(g.PointLen() - 1) if name == "Ed25519" else b"\x05" * g.PointLen())
     with pytest.raises(ValueError):
         poly.PubPoly(g, None, bad).EvalMany([1, 2])
+
+
+@pytest.mark.parametrize("name", ["Ed25519", "bls12381.G1", "bn256.G2"])
+def test_share_recover_pub_poly_and_pubpoly_add(name):
+    """RecoverPubPoly (poly.go:480-508) as t MSMs over the same shares gives back every commitment; PubPoly.Add
+    (poly.go:365-380, one batch add) commutes with PriPoly.Add; the recovered polynomial evaluates like the original."""
+    from kyber_amd.share import poly
+
+    g = _groups()[name]
+    rng = random.Random(23)
+    rand = lambda n: bytes(rng.randrange(256) for _ in range(n))
+    t, n = 4, 8
+    pri, q = poly.PriPoly.new(g, t, rand=rand), poly.PriPoly.new(g, t, rand=rand)
+    pub, qpub = pri.Commit(None), q.Commit(None)
+    shares = pub.Shares(n)
+    shares[0] = None
+    shares[5] = None
+    rng.shuffle(shares)
+    rec = poly.recover_pub_poly(g, shares, t, n)
+    assert rec.Threshold() == t and rec.Equal(pub)
+    assert rec.Eval(6).V.Equal(pub.Eval(6).V)
+    with pytest.raises(ValueError):
+        poly.recover_pub_poly(g, [s for s in shares if s is not None][:t - 1], t, n)
+    s = pub.Add(qpub)
+    assert s.Equal(pri.Add(q).Commit(None)) and not s.Equal(pub)
+    for a, b, c in zip(pub.commits, qpub.commits, s.commits):
+        assert g.Point().Add(a, b).Equal(c)
+    # scalar side against the same polynomial
+    assert poly.recover_secret(g, pri.Shares(n)[2:], t, n).Equal(pri.coeffs[0])
+    assert poly.recover_pri_poly(g, pri.Shares(n)[3:3 + t], t, n).Equal(pri)
