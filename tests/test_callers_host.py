@@ -44,6 +44,51 @@ def _oracle_backed_ed25519(monkeypatch):
     return ed.NewSuite(), poly, E
 
 
+def test_share_poly_recover_pub_poly_pairing_group_scalars(monkeypatch):
+    """The same host logic with the pairing suites' scalar mirror (mod.Int, big-endian) on bn256 G1, engine calls
+    answered by the bn256 oracle."""
+    import random
+
+    import numpy as np
+
+    from kyber_amd.pairing import bn256
+    from kyber_amd.share import poly
+
+    def rows(bs):
+        return np.frombuffer(b"".join(bs), dtype=np.uint8).reshape(len(bs), 64)
+
+    def mul_same_base(scal, base):
+        pt = O.G1_GEN if base is None else O.g1_unmarshal(bytes(base))
+        return rows([O.g1_marshal(O.g1_mul(int.from_bytes(scal[i:i + 32], "big"), pt)) for i in range(0, len(scal), 32)])
+
+    def msm(scal, pts):
+        acc = None
+        for i in range(len(scal) // 32):
+            acc = O.g1_add(acc, O.g1_mul(int.from_bytes(scal[32 * i:32 * i + 32], "big"), O.g1_unmarshal(pts[64 * i:64 * i + 64])))
+        return np.frombuffer(O.g1_marshal(acc), dtype=np.uint8), np.zeros(len(scal) // 32, dtype=np.uint8)
+
+    def batch_add(a, b):
+        out = [O.g1_marshal(O.g1_add(O.g1_unmarshal(a[i:i + 64]), O.g1_unmarshal(b[i:i + 64]))) for i in range(0, len(a), 64)]
+        return rows(out), np.zeros(len(out), dtype=np.uint8)
+
+    monkeypatch.setattr(poly, "_ops", lambda group: (mul_same_base, msm, 64))
+    monkeypatch.setattr(poly, "_add_op", lambda group: batch_add)
+    g = bn256.NewSuite().G1()
+    rng = random.Random(5)
+    rand = lambda n: bytes(rng.randrange(256) for _ in range(n))
+    t, n = 3, 6
+    pri, q = poly.PriPoly.new(g, t, rand=rand), poly.PriPoly.new(g, t, rand=rand)
+    pub = pri.Commit(None)
+    shares = [pub.Eval(i) for i in range(n)]
+    shares[1] = None
+    rng.shuffle(shares)
+    assert poly.recover_pub_poly(g, shares, t, n).Equal(pub)
+    assert poly.recover_commit(g, shares, t, n).Equal(pub.Commit())
+    assert pub.Add(q.Commit(None)).Equal(pri.Add(q).Commit(None))
+    assert poly.recover_secret(g, pri.Shares(n)[1:], t, n).Equal(pri.coeffs[0])
+    assert poly.recover_pri_poly(g, pri.Shares(n)[2:2 + t], t, n).Equal(pri)
+
+
 def test_share_poly_recover_pub_poly_and_scalar_side(monkeypatch):
     """RecoverPubPoly as t MSMs over the same shares (poly.go:480-508), PubPoly.Add / Equal, and the scalar-field
     routines (RecoverSecret, RecoverPriPoly, PriPoly.Mul / Add, lagrangeBasis) of poly.go:96-283, 513-536."""
