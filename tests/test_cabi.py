@@ -81,3 +81,63 @@ def test_go_binding_stays_in_step_with_the_header():
         assert decl[name] == n, (name, decl[name], n)
         calls += 1
     assert calls >= 25
+
+
+def test_empty_batches_and_argument_errors_never_touch_the_device():
+    """n = 0 returns KYB_OK and a null / ill-sized argument returns KYB_E_ARG before any device work, so both are
+    checkable without a GPU; a real call without a GPU must fail loudly (no CPU fallback behind the ABI)."""
+    import numpy as np
+    import torch
+
+    lib = _lib.load()
+    buf = (ctypes.c_uint8 * 4096)()
+    p = ctypes.addressof(buf)
+    zero_ok = [
+        ("kyb_ed25519_mul_base", (0, p, p, 0)),
+        ("kyb_ed25519_mul", (0, p, p, p, p, 0)),
+        ("kyb_ed25519_unmarshal", (0, p, p, p)),
+        ("kyb_ed25519_add", (0, p, p, p, p)),
+        ("kyb_bls12381_g1_mul", (0, p, p, p, p, 0)),
+        ("kyb_bls12381_g2_unmarshal", (0, p, p, p, 0)),
+        ("kyb_bls12381_pair", (0, p, p, p, p, 0)),
+        ("kyb_bls12381_pair_check", (0, p, p, p, p, p, p, 0)),
+        ("kyb_bn256_g1_unmarshal", (0, p, p, p, 0)),
+        ("kyb_bn256_pair", (0, p, p, p, p, 0)),
+        ("kyb_bn256_gt_mul", (0, p, p, p, p)),
+    ]
+    for name, args in zero_ok:
+        assert getattr(lib, name)(*args) == 0, name
+    bad = [
+        ("kyb_ed25519_mul", (4, None, p, p, p, 0)),
+        ("kyb_ed25519_unmarshal", (4, p, None, p)),
+        ("kyb_bls12381_g1_mul", (4, p, None, p, p, 0)),
+        ("kyb_bls12381_g1_unmarshal", (4, None, p, p, 0)),
+        ("kyb_bls12381_g1_mul_dev", (4, p, p, 47, p, p, 0, None)),  # stride that is neither 0 nor the wire size
+        ("kyb_bn256_g2_unmarshal_dev", (4, p, None, p, 0, None)),
+        ("kyb_bn256_pair_dev", (4, p, p, None, p, 0, None)),
+    ]
+    for name, args in bad:
+        rc = getattr(lib, name)(*args)
+        assert rc != 0, name
+        assert name.encode() in lib.kyb_last_error() or b"bad argument" in lib.kyb_last_error()
+    # the Python mirrors shape-check before calling in
+    from kyber_amd.pairing import bls12381 as bls
+
+    out, st = bls.g1_batch_unmarshal(b"")
+    assert out.shape == (0, 48) and st.shape == (0,)
+    out, st = bls.g1_batch_unmarshal(b"", bls.F_UNCOMPRESSED_OUT)
+    assert out.shape == (0, 96)
+    try:
+        bls.g1_batch_mul(bytes(64), bytes(48))  # 2 scalars, 1 point
+    except ValueError:
+        pass
+    else:
+        raise AssertionError("length mismatch must raise")
+    if not torch.cuda.is_available():
+        try:
+            bls.g1_batch_mul(bytes(32), bytes(48))
+        except _lib.KyberHipError as e:
+            assert "rc=" in str(e)
+        else:
+            raise AssertionError("a compute call without a GPU must fail loudly")
+    del np
