@@ -53,6 +53,10 @@ func check(rc C.int) error {
 // Init creates the context of the calling thread's current HIP device (tables, pools); optional.
 func Init() error { return check(C.kyb_init()) }
 
+// StreamRelease frees the per-stream device workspaces tied to a HIP stream handle; call it before destroying a
+// stream that was passed to the *_dev entry points.
+func StreamRelease(stream unsafe.Pointer) error { return check(C.kyb_stream_release(stream)) }
+
 // ---------------------------------------------------------------- Ed25519 (32-byte LE scalars, 32-byte points)
 
 func Ed25519MulBase(scalars []byte, flags uint32) (out []byte, err error) {

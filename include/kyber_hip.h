@@ -71,6 +71,10 @@ int kyb_device_count(void);
 int kyb_init(void);
 /* Release every per-device context. */
 int kyb_shutdown(void);
+/* The `_dev` entry points keep one grow-only device workspace per (kind of call, stream) so that calls on different
+ * streams never share scratch.  A caller that destroys a stream calls this first (current device): waits for the
+ * stream and frees the workspaces tied to that handle.  Never needed for long-lived streams or the host-buffer calls. */
+int kyb_stream_release(void *stream);
 
 /* ------------------------------------------------------------------ Ed25519
  * scalars: 32-byte little-endian, taken as plain 256-bit integers (never

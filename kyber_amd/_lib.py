@@ -28,6 +28,7 @@ SIGNATURES = {
     "kyb_device_count": [],
     "kyb_init": [],
     "kyb_shutdown": [],
+    "kyb_stream_release": [_vp],
     "kyb_ed25519_mul_base": [_sz, _vp, _vp, _u32],
     "kyb_ed25519_mul_base_dev": [_sz, _vp, _vp, _u32, _vp],
     "kyb_ed25519_mul": [_sz, _vp, _vp, _vp, _vp, _u32],

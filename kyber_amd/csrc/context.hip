@@ -76,6 +76,35 @@ int kyb_device_count(void) {
     return n;
 }
 
+int kyb_stream_release(void* stream) {
+    int dev = 0;
+    KYB_HIP_CHECK(hipGetDevice(&dev));
+    kyb::DeviceCtx* ctx = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(kyb::g_mu);
+        auto it = kyb::g_ctx.find(dev);
+        if (it == kyb::g_ctx.end()) return KYB_OK;  // nothing was ever allocated on this device
+        ctx = it->second;
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    bool synced = false;
+    for (auto it = ctx->sws.begin(); it != ctx->sws.end();) {
+        if (it->first.second != (hipStream_t)stream) {
+            ++it;
+            continue;
+        }
+        if (it->second.p) {
+            if (!synced) {
+                KYB_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));  // work enqueued on it may still use the buffer
+                synced = true;
+            }
+            KYB_HIP_CHECK(hipFree(it->second.p));
+        }
+        it = ctx->sws.erase(it);
+    }
+    return KYB_OK;
+}
+
 int kyb_init(void) {
     kyb::DeviceCtx* ctx;
     return kyb::get_ctx(&ctx);
@@ -83,6 +112,8 @@ int kyb_init(void) {
 
 int kyb_shutdown(void) {
     std::lock_guard<std::mutex> lk(kyb::g_mu);
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;  // the caller's current device is restored below
     for (auto& kv : kyb::g_ctx) {
         kyb::DeviceCtx* c = kv.second;
         hipSetDevice(c->device);
@@ -96,6 +127,7 @@ int kyb_shutdown(void) {
         delete c;
     }
     kyb::g_ctx.clear();
+    if (prev >= 0) hipSetDevice(prev);
     return KYB_OK;
 }
 }

@@ -141,3 +141,14 @@ def test_empty_batches_and_argument_errors_never_touch_the_device():
         else:
             raise AssertionError("a compute call without a GPU must fail loudly")
     del np
+
+
+def test_stream_release_without_a_device_reports_an_error_code():
+    import torch
+
+    lib = _lib.load()
+    rc = lib.kyb_stream_release(None)
+    if torch.cuda.is_available():
+        assert rc == 0
+    else:
+        assert rc != 0 and lib.kyb_last_error()

@@ -272,3 +272,34 @@ def test_batch_unmarshal_vs_oracle(ed):
     t = torch.frombuffer(bytearray(b"".join(pts)), dtype=torch.uint8).cuda()
     out_d, st_d = ed.batch_unmarshal(t)
     assert out_d.cpu().numpy().tobytes() == out.tobytes() and st_d.cpu().numpy().tobytes() == st.tobytes()
+
+
+def test_stream_release_frees_and_the_stream_stays_usable(ed):
+    """kyb_stream_release: the workspaces tied to a stream handle go away (after the stream drains); the next call on
+    the same stream simply allocates again, and releasing a stream that never had one is a no-op."""
+    import torch
+
+    import kyber_amd
+
+    n = 1 << 13
+    rng = np.random.default_rng(3)
+    s = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    s[:, 31] &= 0x0F
+    d = torch.from_numpy(s).cuda()
+    pts = ed.batch_mul_base(d)
+    ref, _ = ed.msm(d, pts)
+    st = torch.cuda.Stream()
+    kyber_amd.release_stream(st)  # nothing allocated yet
+    for _ in range(2):
+        with torch.cuda.stream(st):
+            out, _ = ed.msm(d, pts)
+            mul, _ = ed.batch_mul(d, pts)
+        kyber_amd.release_stream(st)  # waits for the stream itself
+        assert torch.equal(out, ref)
+    with torch.cuda.stream(st):
+        out, _ = ed.msm(d, pts)
+    st.synchronize()
+    before = torch.cuda.mem_get_info()[0]
+    kyber_amd.release_stream(st)
+    assert torch.cuda.mem_get_info()[0] >= before  # the MSM workspace went back to the driver
+    assert torch.equal(out, ref)
