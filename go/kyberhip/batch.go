@@ -182,3 +182,27 @@ func unmarshalAll(g kyber.Group, buf []byte, size int) ([]kyber.Point, error) {
 	}
 	return out, nil
 }
+
+// BatchValidate runs N x Point.UnmarshalBinary on the device and reports, per element, whether the reference would
+// accept the encoding (0) or return an error (non-zero): ZCash flag rules, on-curve and subgroup checks for
+// BLS12-381; on-curve for bn256; "has a square root" for Ed25519.  The engine-backed suite of INTEGRATION.md
+// section 3 stores encodings, so a batch of received points (DKG deals, bdn public keys, beacon signatures) is
+// validated by ONE call and carried as Trusted afterwards.
+func BatchValidate(k Kind, encodings []byte) (status []byte, err error) {
+	if len(encodings)%pointLen(k) != 0 {
+		return nil, errors.New("kyberhip: ragged encoding buffer")
+	}
+	switch k {
+	case Ed25519:
+		_, status, err = Ed25519Unmarshal(encodings)
+	case Bls12381G1:
+		_, status, err = Bls12381G1Unmarshal(encodings, 0)
+	case Bls12381G2:
+		_, status, err = Bls12381G2Unmarshal(encodings, 0)
+	case Bn256G1:
+		_, status, err = Bn256G1Unmarshal(encodings)
+	case Bn256G2:
+		_, status, err = Bn256G2Unmarshal(encodings)
+	}
+	return status, err
+}
