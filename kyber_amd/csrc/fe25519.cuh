@@ -59,35 +59,57 @@ KYB_DEV void fe_cswap(fe& f, fe& g, bool b) {
     }
 }
 
-// One carry step: move the rounded high part of t[i] (limb width w) into t[i+1].
-#define KYB_CARRY(t, i, w)                                                  \
-    {                                                                       \
-        int64_t c_ = ((t)[i] + ((int64_t)1 << ((w) - 1))) >> (w);          \
-        (t)[(i) + 1] += c_;                                                 \
-        (t)[i] -= c_ << (w);                                                \
+// Column accumulators carry a BIAS of half a limb: T[i] = t[i] + 2^(w_i - 1), w_i = 26 (even i) / 25 (odd i).  The
+// rounded carry of the reference (fe.go:348 ff: c = (t + 2^(w-1)) >> w, t -= c << w) is then one shift, and the
+// remainder is the low w bits minus the bias -- two 32-bit operations instead of a 64-bit add and a shift/subtract.
+// The compiler adds the bias (a scalar-register constant) to the finished column: one 64-bit add, where the rounding
+// add used to be; pinning it as the addend of the first product instead (an empty asm after it) removes that add
+// too but pushed the window loop of ed25519_mul_kernel over its 168-register budget (32 scratch accesses per
+// window), so it is not done.
+KYB_DEV constexpr int64_t fe_bias(int i) { return (int64_t)1 << ((i & 1) ? 24 : 25); }
+
+#define KYB_LOW(x, w) ((uint32_t)(x) & ((1u << (w)) - 1u))
+// carry column i (biased, 64-bit) into column i + 1 (biased, 64-bit); r[i] = the reference's remainder
+#define KYB_CARRY(T, r, i, w)                                        \
+    {                                                                \
+        const int64_t c_ = (T)[i] >> (w);                            \
+        (T)[(i) + 1] += c_;                                          \
+        (r)[i] = (int32_t)KYB_LOW((T)[i], w) - (1 << ((w) - 1));     \
     }
 
-// Reduce ten 64-bit columns to limbs; two interleaved chains (0..4 / 4..9) keep
-// the dependent-shift chain short.
-KYB_DEV void fe_carry_store(fe& h, int64_t t[10]) {
-    KYB_CARRY(t, 0, 26);
-    KYB_CARRY(t, 4, 26);
-    KYB_CARRY(t, 1, 25);
-    KYB_CARRY(t, 5, 25);
-    KYB_CARRY(t, 2, 26);
-    KYB_CARRY(t, 6, 26);
-    KYB_CARRY(t, 3, 25);
-    KYB_CARRY(t, 7, 25);
-    KYB_CARRY(t, 4, 26);
-    KYB_CARRY(t, 8, 26);
-    {
-        int64_t c = (t[9] + ((int64_t)1 << 24)) >> 25;
-        t[0] += c * 19;
-        t[9] -= c << 25;
-    }
-    KYB_CARRY(t, 0, 26);
+// Reduce ten biased 64-bit columns to limbs, in the reference's carry order (0, 4, 1, 5, 2, 6, 3, 7, 4, 8, 9, 0; fe.go
+// feMul tail): limb values are identical to the reference's.  Columns 0 and 4 are visited twice: their first
+// remainder stays biased (b0, b4), so the second visit needs no rounding add either, and the carries of the second
+// visits are small enough to be added to the finished limbs 1 and 5 in 32 bits.
+KYB_DEV void fe_carry_store(fe& h, int64_t T[10]) {
+    int32_t r[10];
+    int64_t c;
+    c = T[0] >> 26;
+    T[1] += c;
+    const uint32_t b0 = KYB_LOW(T[0], 26);
+    c = T[4] >> 26;
+    T[5] += c;
+    const uint32_t b4 = KYB_LOW(T[4], 26);
+    KYB_CARRY(T, r, 1, 25);
+    KYB_CARRY(T, r, 5, 25);
+    KYB_CARRY(T, r, 2, 26);
+    KYB_CARRY(T, r, 6, 26);
+    c = T[3] >> 25;
+    r[3] = (int32_t)KYB_LOW(T[3], 25) - (1 << 24);
+    const int64_t t4 = (int64_t)b4 + c;  // r4 + 2^25 + carry: biased again
+    KYB_CARRY(T, r, 7, 25);
+    c = t4 >> 26;
+    r[4] = (int32_t)KYB_LOW(t4, 26) - (1 << 25);
+    r[5] += (int32_t)c;
+    KYB_CARRY(T, r, 8, 26);
+    c = T[9] >> 25;
+    r[9] = (int32_t)KYB_LOW(T[9], 25) - (1 << 24);
+    const int64_t t0 = (int64_t)b0 + c * 19;
+    c = t0 >> 26;
+    r[0] = (int32_t)KYB_LOW(t0, 26) - (1 << 25);
+    r[1] += (int32_t)c;
 #pragma unroll
-    for (int i = 0; i < 10; i++) h.v[i] = (int32_t)t[i];
+    for (int i = 0; i < 10; i++) h.v[i] = r[i];
 }
 
 // h = f * g
@@ -101,7 +123,7 @@ KYB_DEV void fe_mul(fe& h, const fe& f, const fe& g) {
     int64_t t[10];
 #pragma unroll
     for (int k = 0; k < 10; k++) {
-        int64_t acc = 0;
+        int64_t acc = fe_bias(k);
 #pragma unroll
         for (int i = 0; i < 10; i++) {
             const int j = (k - i + 10) % 10;
@@ -129,7 +151,7 @@ KYB_DEV void fe_sq_t(fe& h, const fe& f) {
     int64_t t[10];
 #pragma unroll
     for (int k = 0; k < 10; k++) {
-        int64_t acc = 0;
+        int64_t acc = DBL ? 0 : fe_bias(k);  // 2 acc + bias is one shift-add
 #pragma unroll
         for (int i = 0; i < 10; i++) {
             const int j = (k - i + 10) % 10;
@@ -148,7 +170,7 @@ KYB_DEV void fe_sq_t(fe& h, const fe& f) {
             }
             acc += (int64_t)a * (int64_t)b;
         }
-        t[k] = DBL ? (acc + acc) : acc;
+        t[k] = DBL ? (acc + acc) + fe_bias(k) : acc;
     }
     fe_carry_store(h, t);
 }
@@ -177,7 +199,7 @@ KYB_DEV void fe_sq_sel(fe& h, const fe& f, bool dbl) {
             const int32_t b = wrap ? (both_odd ? f38[j] : f19[j]) : (both_odd ? f2[j] : g.v[j]);
             acc += (int64_t)a * (int64_t)b;
         }
-        t[k] = dbl ? (acc + acc) : acc;
+        t[k] = (dbl ? (acc + acc) : acc) + fe_bias(k);
     }
     fe_carry_store(h, t);
 }

@@ -155,6 +155,68 @@ int hh_bls_verify_g1(const uint8_t* pk, const uint8_t* msg, int len, const uint8
                      uint8_t* ok) {
     return bls::verify_g1_wire(ok, pk, msg, (size_t)len, mk_dst(dst, dlen), sig);
 }
+// Raw-limb access to the GF(2^255 - 19) routines (ten int32 limbs, radix 2^25.5): op 0 = mul, 1 = sq, 2 = sq2,
+// 3 = sq_sel(dbl = false), 4 = sq_sel(dbl = true).  The tests drive the limbs to the input bounds of fe25519.cuh.
+void hh_ed_fe_op(int op, const uint8_t* f40, const uint8_t* g40, uint8_t* out40) {
+    fe f, g, h;
+    memcpy(f.v, f40, 40);
+    memcpy(g.v, g40, 40);
+    switch (op) {
+        case 0: fe_mul(h, f, g); break;
+        case 1: fe_sq(h, f); break;
+        case 2: fe_sq2(h, f); break;
+        case 3: fe_sq_sel(h, f, false); break;
+        default: fe_sq_sel(h, f, true); break;
+    }
+    memcpy(out40, h.v, 40);
+}
+// out = k * P with the kernels' own building blocks: decode, signed radix-16 recoding, 8-entry cached table,
+// 4 doublings + 1 addition per window (the walk of ed25519_mul_kernel, ge.go:443-502), encode.  vartime = the
+// all-256-bits semantics of ge_mult_vartime.go.  Returns 0, or 1 when P does not decode.
+int hh_ed_mul(const uint8_t* k32, const uint8_t* p32, int vartime, uint8_t* out32) {
+    uint32_t kw[8], pw[8], ow[8];
+    memcpy(kw, k32, 32);
+    memcpy(pw, p32, 32);
+    ge_p3 P;
+    if (!ge_p3_fromwords(P, pw)) {
+        memset(out32, 0, 32);
+        return 1;
+    }
+    int8_t e[65];
+    recode16(e, kw, vartime != 0);
+    ge_cached tab[8];
+    ge_p3 cur = P;
+    ge_p1p1 t;
+    ge_p3_to_cached(tab[0], P);
+    for (int i = 1; i < 8; i++) {
+        ge_add(t, cur, tab[0]);
+        ge_p1p1_to_p3(cur, t);
+        ge_p3_to_cached(tab[i], cur);
+    }
+    ge_p3 acc;
+    ge_p3_0(acc);
+    for (int i = 64; i >= 0; i--) {
+        if (i != 64) {
+            ge_p2 d;
+            ge_dbl(t, acc.X, acc.Y, acc.Z);
+            for (int r = 0; r < 3; r++) {
+                ge_p1p1_to_p2(d, t);
+                ge_dbl(t, d.X, d.Y, d.Z);
+            }
+            ge_p1p1_to_p3(acc, t);
+        }
+        const int dgt = e[i];
+        if (dgt != 0) {
+            ge_cached c = tab[(dgt < 0 ? -dgt : dgt) - 1];
+            ge_cached_cneg(c, dgt < 0);
+            ge_add(t, acc, c);
+            ge_p1p1_to_p3(acc, t);
+        }
+    }
+    ge_p3_towords(ow, acc);
+    memcpy(out32, ow, 32);
+    return 0;
+}
 void hh_ed_hash(const uint8_t* msg, int len, const uint8_t* dst, int dlen, uint8_t* out) {
     EdDstArg d;
     memset(&d, 0, sizeof d);
