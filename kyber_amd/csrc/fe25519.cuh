@@ -59,14 +59,16 @@ KYB_DEV void fe_cswap(fe& f, fe& g, bool b) {
     }
 }
 
-// Column accumulators carry a BIAS of half a limb: T[i] = t[i] + 2^(w_i - 1), w_i = 26 (even i) / 25 (odd i).  The
-// rounded carry of the reference (fe.go:348 ff: c = (t + 2^(w-1)) >> w, t -= c << w) is then one shift, and the
-// remainder is the low w bits minus the bias -- two 32-bit operations instead of a 64-bit add and a shift/subtract.
-// The compiler adds the bias (a scalar-register constant) to the finished column: one 64-bit add, where the rounding
-// add used to be; pinning it as the addend of the first product instead (an empty asm after it) removes that add
-// too but pushed the window loop of ed25519_mul_kernel over its 168-register budget (32 scratch accesses per
-// window), so it is not done.
-KYB_DEV constexpr int64_t fe_bias(int i) { return (int64_t)1 << ((i & 1) ? 24 : 25); }
+// Column accumulators carry a BIAS of half a limb into the carry chain: T[i] = t[i] + 2^(w_i - 1), w_i = 26 (even i)
+// / 25 (odd i).  The rounded carry of the reference (fe.go:348 ff: c = (t + 2^(w-1)) >> w, t -= c << w) is then one
+// shift, and the remainder is the low w bits minus the bias -- two 32-bit operations instead of a 64-bit add and a
+// shift/subtract.  (The compiler adds the bias, a scalar-register constant, to the finished column; pinning it as the
+// addend of the column's first product with an empty asm removes that add too, but pushed the window loop of
+// ed25519_mul_kernel over its 168-register budget -- 32 scratch accesses per window -- so it is not done.)
+// Only the even columns are handed their bias explicitly, and they carry the next (odd) column's with them:
+// 2^25 + (2^24 << 26).  The second term is a multiple of 2^26, so it leaves the remainder alone and arrives in the odd
+// column as exactly 2^24 on top of the carry -- one 64-bit add less per pair of columns.
+KYB_DEV constexpr int64_t fe_bias(int i) { return (i & 1) ? 0 : ((int64_t)1 << 25) + ((int64_t)1 << 50); }
 
 #define KYB_LOW(x, w) ((uint32_t)(x) & ((1u << (w)) - 1u))
 // carry column i (biased, 64-bit) into column i + 1 (biased, 64-bit); r[i] = the reference's remainder
@@ -77,30 +79,25 @@ KYB_DEV constexpr int64_t fe_bias(int i) { return (int64_t)1 << ((i & 1) ? 24 : 
         (r)[i] = (int32_t)KYB_LOW((T)[i], w) - (1 << ((w) - 1));     \
     }
 
-// Reduce ten biased 64-bit columns to limbs, in the reference's carry order (0, 4, 1, 5, 2, 6, 3, 7, 4, 8, 9, 0; fe.go
-// feMul tail): limb values are identical to the reference's.  Columns 0 and 4 are visited twice: their first
-// remainder stays biased (b0, b4), so the second visit needs no rounding add either, and the carries of the second
-// visits are small enough to be added to the finished limbs 1 and 5 in 32 bits.
+// Reduce ten biased 64-bit columns to limbs with ONE carry chain 0 -> 1 -> ... -> 9 -> (x19) 0 -> 1.  The
+// reference (fe.go feMul tail) interleaves two chains (0, 4, 1, 5, ...) for the benefit of an out-of-order CPU and
+// pays for it with a second visit of column 4; here three waves per SIMD hide the longer dependency chain and the
+// visit is saved (11 carries instead of 12).  Limbs 4 and 5 may differ from the reference's by a carry unit -- the
+// same field element, and within the same bounds: every limb is a rounded remainder, limbs 0 and 1 as in the reference.
+// Column 0 is visited twice: its first remainder stays biased (b0), so the second visit needs no rounding add, and
+// that last carry is small enough to be added to the finished limb 1 in 32 bits.
 KYB_DEV void fe_carry_store(fe& h, int64_t T[10]) {
     int32_t r[10];
-    int64_t c;
-    c = T[0] >> 26;
+    int64_t c = T[0] >> 26;
     T[1] += c;
     const uint32_t b0 = KYB_LOW(T[0], 26);
-    c = T[4] >> 26;
-    T[5] += c;
-    const uint32_t b4 = KYB_LOW(T[4], 26);
     KYB_CARRY(T, r, 1, 25);
-    KYB_CARRY(T, r, 5, 25);
     KYB_CARRY(T, r, 2, 26);
+    KYB_CARRY(T, r, 3, 25);
+    KYB_CARRY(T, r, 4, 26);
+    KYB_CARRY(T, r, 5, 25);
     KYB_CARRY(T, r, 6, 26);
-    c = T[3] >> 25;
-    r[3] = (int32_t)KYB_LOW(T[3], 25) - (1 << 24);
-    const int64_t t4 = (int64_t)b4 + c;  // r4 + 2^25 + carry: biased again
     KYB_CARRY(T, r, 7, 25);
-    c = t4 >> 26;
-    r[4] = (int32_t)KYB_LOW(t4, 26) - (1 << 25);
-    r[5] += (int32_t)c;
     KYB_CARRY(T, r, 8, 26);
     c = T[9] >> 25;
     r[9] = (int32_t)KYB_LOW(T[9], 25) - (1 << 24);
