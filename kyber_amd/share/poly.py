@@ -25,8 +25,6 @@ def _ops(group):
         from ..group import edwards25519 as ed
 
         return (lambda scalars, base: ed.commit(scalars, base)), ed.msm, 32
-    import importlib
-
     from ..pairing import bls12381, bn256
 
     for m in (bls12381, bn256):

@@ -86,7 +86,6 @@ def test_go_binding_stays_in_step_with_the_header():
 def test_empty_batches_and_argument_errors_never_touch_the_device():
     """n = 0 returns KYB_OK and a null / ill-sized argument returns KYB_E_ARG before any device work, so both are
     checkable without a GPU; a real call without a GPU must fail loudly (no CPU fallback behind the ABI)."""
-    import numpy as np
     import torch
 
     lib = _lib.load()
@@ -140,7 +139,6 @@ def test_empty_batches_and_argument_errors_never_touch_the_device():
             assert "rc=" in str(e)
         else:
             raise AssertionError("a compute call without a GPU must fail loudly")
-    del np
 
 
 def test_stream_release_without_a_device_reports_an_error_code():

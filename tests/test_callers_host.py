@@ -121,14 +121,12 @@ def test_share_poly_recover_pub_poly_and_scalar_side(monkeypatch):
         for m in xs:
             assert L.Eval(m).V.Equal(g.Scalar().One() if m == i else g.Scalar().Zero())
     q = poly.PriPoly.new(g, t, rand=rand)
-    s5 = g.Scalar().SetInt64(6)
     prod = pri.Mul(q)  # (p q)(x) = p(x) q(x), degree 2t - 2
     assert prod.Threshold() == 2 * t - 1
     assert prod.Eval(5).V.Equal(g.Scalar().Mul(pri.Eval(5).V, q.Eval(5).V))
     assert pri.Add(q).Eval(5).V.Equal(g.Scalar().Add(pri.Eval(5).V, q.Eval(5).V))
     with pytest.raises(ValueError):
         pri.Add(prod)
-    del s5
     # point side: any t public shares give back every commitment
     shares = [pub.Eval(i) for i in range(n)]
     for s, ps in zip(shares, pshares):  # Eval(i) = p(i) * B
