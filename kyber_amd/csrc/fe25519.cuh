@@ -62,14 +62,22 @@ KYB_DEV void fe_cswap(fe& f, fe& g, bool b) {
 // Column accumulators carry a BIAS of half a limb into the carry chain: T[i] = t[i] + 2^(w_i - 1), w_i = 26 (even i)
 // / 25 (odd i).  The rounded carry of the reference (fe.go:348 ff: c = (t + 2^(w-1)) >> w, t -= c << w) is then one
 // shift, and the remainder is the low w bits minus the bias -- two 32-bit operations instead of a 64-bit add and a
-// shift/subtract.  (The compiler adds the bias, a scalar-register constant, to the finished column; pinning it as the
-// addend of the column's first product with an empty asm removes that add too, but pushed the window loop of
-// ed25519_mul_kernel over its 168-register budget -- 32 scratch accesses per window -- so it is not done.)
+// shift/subtract.
 // Only the even columns are handed their bias explicitly, and they carry the next (odd) column's with them:
 // 2^25 + (2^24 << 26).  The second term is a multiple of 2^26, so it leaves the remainder alone and arrives in the odd
 // column as exactly 2^24 on top of the carry -- one 64-bit add less per pair of columns.
 KYB_DEV constexpr int64_t fe_bias(int i) { return (i & 1) ? 0 : ((int64_t)1 << 25) + ((int64_t)1 << 50); }
 
+// The compiler reassociates bias + a0 b0 + a1 b1 + ... so that the constant is added last, as a separate 64-bit
+// add.  An empty asm after the first product pins (bias + a0 b0) as one value -- one v_mad_i64_i32 with the bias (a
+// scalar-register pair) as its addend -- and emits nothing itself, so it cannot change a result.  Used on the even
+// columns only, the ones that are handed a bias (window loop of ed25519_mul_kernel: 5 480 -> 5 357 instructions, 7
+// reloads of spilled loop invariants per window instead of 3).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KYB_PIN64(x) asm("" : "+v"(x))
+#else
+#define KYB_PIN64(x) ((void)0)
+#endif
 #define KYB_LOW(x, w) ((uint32_t)(x) & ((1u << (w)) - 1u))
 // carry column i (biased, 64-bit) into column i + 1 (biased, 64-bit); r[i] = the reference's remainder
 #define KYB_CARRY(T, r, i, w)                                        \
@@ -129,6 +137,7 @@ KYB_DEV void fe_mul(fe& h, const fe& f, const fe& g) {
             const int32_t a = both_odd ? f2[i] : f.v[i];
             const int32_t b = wrap ? g19[j] : g.v[j];
             acc += (int64_t)a * (int64_t)b;
+            if (i == 0 && !(k & 1)) KYB_PIN64(acc);
         }
         t[k] = acc;
     }
@@ -166,6 +175,7 @@ KYB_DEV void fe_sq_t(fe& h, const fe& f) {
                 b = wrap ? (both_odd ? f38[j] : f19[j]) : (both_odd ? f2[j] : f.v[j]);
             }
             acc += (int64_t)a * (int64_t)b;
+            if (!DBL && i == 0 && !(k & 1)) KYB_PIN64(acc);
         }
         t[k] = DBL ? (acc + acc) + fe_bias(k) : acc;
     }
