@@ -227,6 +227,26 @@ KYB_HD void fp_neg(Fp<C>& r, const Fp<C>& a) {
     fp_sub(r, z, a);
 }
 
+// Tail of a multiplication: normalised limbs s (value < 2p) -> the packed, fully reduced element.  Where 2p fits the
+// words (BLS12-381) the value is packed first and the conditional subtraction runs on 12 words with a borrow chain
+// (12 subtract-with-borrow + 12 selects) instead of on 13 limbs (subtract, shift, mask per limb, then the selects).
+template <class C>
+KYB_HD void fp_finish(Fp<C>& r, uint32_t (&s)[C::N]) {
+    if constexpr (fp_has_headroom<C>()) {
+        uint32_t w[C::NWORDS], d[C::NWORDS];
+        fp_pack<C>(w, s);
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int j = 0; j < C::NWORDS; j++) d[j] = sbb32(w[j], C::PW[j], borrow);
+        const uint32_t keep = 0u - borrow;  // all ones when the value was already below p
+#pragma unroll
+        for (int j = 0; j < C::NWORDS; j++) r.v[j] = sel32(keep, w[j], d[j]);
+    } else {
+        fp_reduce_once<C>(s);
+        fp_pack<C>(r.v, s);
+    }
+}
+
 // r = a * b * R^-1 mod p
 template <class C>
 KYB_HD void fp_mul(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
@@ -272,8 +292,7 @@ KYB_HD void fp_mul(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
         s[j] = (uint32_t)t[j] & MASK;
     }
     s[N - 1] = (uint32_t)t[N - 1];
-    fp_reduce_once<C>(s);
-    fp_pack<C>(r.v, s);
+    fp_finish<C>(r, s);
 }
 // r = a^2 * R^-1 mod p.  Same interleaved product/reduction walk as fp_mul, but row i only adds
 // a_i^2 and the doubled cross products 2 a_i a_j (j > i): N(N+1)/2 + N^2 MADs instead of 2 N^2
@@ -337,8 +356,7 @@ KYB_HD void fp_sqr(Fp<C>& r, const Fp<C>& a) {
         s[j] = (uint32_t)t[j] & MASK;
     }
     s[N - 1] = (uint32_t)t[N - 1];
-    fp_reduce_once<C>(s);
-    fp_pack<C>(r.v, s);
+    fp_finish<C>(r, s);
 }
 
 // Small-constant multiples
