@@ -116,22 +116,6 @@ KYB_HD void fp_pack(uint32_t (&w)[C::NWORDS], const uint32_t (&l)[C::N]) {
     }
 }
 
-// s (normalised limbs, value < 2p) -> s mod p
-template <class C>
-KYB_HD void fp_reduce_once(uint32_t (&s)[C::N]) {
-    constexpr uint32_t MASK = (1u << C::W) - 1;
-    uint32_t d[C::N];
-    uint32_t borrow = 0;
-#pragma unroll
-    for (int j = 0; j < C::N; j++) {
-        const uint32_t x = s[j] - C::P[j] - borrow;
-        borrow = x >> 31;
-        d[j] = x & MASK;
-    }
-#pragma unroll
-    for (int j = 0; j < C::N; j++) s[j] = borrow ? s[j] : d[j];
-}
-
 template <class C>
 KYB_HD void fp_add(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
     constexpr int NW = C::NWORDS;
@@ -227,9 +211,9 @@ KYB_HD void fp_neg(Fp<C>& r, const Fp<C>& a) {
     fp_sub(r, z, a);
 }
 
-// Tail of a multiplication: normalised limbs s (value < 2p) -> the packed, fully reduced element.  Where 2p fits the
-// words (BLS12-381) the value is packed first and the conditional subtraction runs on 12 words with a borrow chain
-// (12 subtract-with-borrow + 12 selects) instead of on 13 limbs (subtract, shift, mask per limb, then the selects).
+// Tail of a multiplication: normalised limbs s (value < 2p) -> the packed, fully reduced element.  The value is packed
+// first and the conditional subtraction runs on the words with a borrow chain (NWORDS subtract-with-borrow + NWORDS
+// selects) instead of on the limbs (subtract, shift, mask per limb, then the selects).
 template <class C>
 KYB_HD void fp_finish(Fp<C>& r, uint32_t (&s)[C::N]) {
     if constexpr (fp_has_headroom<C>()) {
@@ -242,8 +226,18 @@ KYB_HD void fp_finish(Fp<C>& r, uint32_t (&s)[C::N]) {
 #pragma unroll
         for (int j = 0; j < C::NWORDS; j++) r.v[j] = sel32(keep, w[j], d[j]);
     } else {
-        fp_reduce_once<C>(s);
-        fp_pack<C>(r.v, s);
+        // 2p exceeds the words by at most one bit (bn256: 2p < 2^257): that bit comes out of the top limb, the low
+        // words take the same borrow chain, and the value is below p exactly when the bit is clear and the chain borrowed
+        static_assert(C::N * C::W > 32 * C::NWORDS, "top limb must reach past the words");
+        uint32_t w[C::NWORDS], d[C::NWORDS];
+        fp_pack<C>(w, s);
+        const uint32_t top = s[C::N - 1] >> (32 * C::NWORDS - (C::N - 1) * C::W);  // 0 or 1
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int j = 0; j < C::NWORDS; j++) d[j] = sbb32(w[j], C::PW[j], borrow);
+        const uint32_t keep = (0u - borrow) & (top - 1u);
+#pragma unroll
+        for (int j = 0; j < C::NWORDS; j++) r.v[j] = sel32(keep, w[j], d[j]);
     }
 }
 
