@@ -70,6 +70,7 @@ KYB_DEV void fe_from_be384(fe& r, const uint64_t* be) {
     fe_fromwords(fhi, hi);
     fe_0(c19);
     c19.v[0] = 19;
+    KYB_FE_MAG_SET(c19, 19.0 / (1 << 25));
     fe_mul(fhi, fhi, c19);
     fe_add(r, flo, fhi);
     fe one;
@@ -101,6 +102,7 @@ KYB_DEV void ed_map_to_curve(ge_p3& q, const fe& u) {
     fe J, one, t, den, x1, gx, y, xm, nJ;
     fe_0(J);
     J.v[0] = 486662;
+    KYB_FE_MAG_SET(J, 486662.0 / (1 << 25));
     fe_1(one);
     fe_neg(nJ, J);
     fe_sq2(t, u);  // 2 u^2

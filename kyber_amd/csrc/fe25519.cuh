@@ -17,7 +17,40 @@ namespace kyb {
 
 struct fe {
     int32_t v[10];
+#if defined(KYB_FE_AUDIT)
+    // Host-only bound audit (tests/test_fe_bounds.py): `mag` bounds the limbs in units of 2^25 (even) / 2^24 (odd).
+    // Carried results have 1.01, canonical constants and decoded values 2 (limbs below 2^26 / 2^25), sums add up.
+    double mag = 2.0;
+#endif
 };
+
+#if defined(KYB_FE_AUDIT)
+// A 64-bit column of a product is at most 124.5 E_f E_g for even limbs below E (odd below E / 2): column 0 collects
+// a0 b0 + 19 (4 even x even + 5 doubled odd x odd terms).  With E = mag * 2^25 that stays below 2^63 while
+// mag_f * mag_g < 2^13 / 124.5 = 65.8; the audit records the largest product it meets (doubled for 2 f^2).
+inline double& fe_audit_max() {
+    static double m = 0;
+    return m;
+}
+// The operand whose limbs are pre-multiplied by 19 / 38 in 32 bits (g of fe_mul, f of a squaring) must keep
+// 19 * mag * 2^25 below 2^31: mag < 3.36 -- the constraint that makes the reference round its carries to signed limbs.
+inline double& fe_audit_max19() {
+    static double m = 0;
+    return m;
+}
+inline void fe_audit_note(double pf, double pg, double scale) {
+    const double x = pf * pg * scale;
+    if (x > fe_audit_max()) fe_audit_max() = x;
+    if (pg > fe_audit_max19()) fe_audit_max19() = pg;
+}
+#define KYB_FE_MAG_SET(h, x) ((h).mag = (x))
+#define KYB_FE_MAG(f) ((f).mag)
+#define KYB_FE_NOTE(pf, pg, scale) fe_audit_note(pf, pg, scale)
+#else
+#define KYB_FE_MAG_SET(h, x) ((void)0)
+#define KYB_FE_MAG(f) 0.0
+#define KYB_FE_NOTE(pf, pg, scale) ((void)0)
+#endif
 
 #if defined(__HIPCC__)
 #define KYB_DEV __device__ __forceinline__
@@ -28,27 +61,36 @@ struct fe {
 KYB_DEV void fe_0(fe& h) {
 #pragma unroll
     for (int i = 0; i < 10; i++) h.v[i] = 0;
+    KYB_FE_MAG_SET(h, 0.0);
 }
 KYB_DEV void fe_1(fe& h) {
     fe_0(h);
     h.v[0] = 1;
+    KYB_FE_MAG_SET(h, 1.0 / (1 << 25));
 }
 KYB_DEV void fe_add(fe& h, const fe& f, const fe& g) {
+    const double m_ = KYB_FE_MAG(f) + KYB_FE_MAG(g);
 #pragma unroll
     for (int i = 0; i < 10; i++) h.v[i] = f.v[i] + g.v[i];
+    KYB_FE_MAG_SET(h, m_);
 }
 KYB_DEV void fe_sub(fe& h, const fe& f, const fe& g) {
+    const double m_ = KYB_FE_MAG(f) + KYB_FE_MAG(g);
 #pragma unroll
     for (int i = 0; i < 10; i++) h.v[i] = f.v[i] - g.v[i];
+    KYB_FE_MAG_SET(h, m_);
 }
 KYB_DEV void fe_neg(fe& h, const fe& f) {
+    const double m_ = KYB_FE_MAG(f);
 #pragma unroll
     for (int i = 0; i < 10; i++) h.v[i] = -f.v[i];
+    KYB_FE_MAG_SET(h, m_);
 }
 // f = b ? g : f
 KYB_DEV void fe_cmov(fe& f, const fe& g, bool b) {
 #pragma unroll
     for (int i = 0; i < 10; i++) f.v[i] = b ? g.v[i] : f.v[i];
+    KYB_FE_MAG_SET(f, KYB_FE_MAG(f) > KYB_FE_MAG(g) ? KYB_FE_MAG(f) : KYB_FE_MAG(g));  // either operand, whatever b
 }
 KYB_DEV void fe_cswap(fe& f, fe& g, bool b) {
 #pragma unroll
@@ -57,6 +99,10 @@ KYB_DEV void fe_cswap(fe& f, fe& g, bool b) {
         f.v[i] = b ? y : x;
         g.v[i] = b ? x : y;
     }
+    const double m_ = KYB_FE_MAG(f) > KYB_FE_MAG(g) ? KYB_FE_MAG(f) : KYB_FE_MAG(g);
+    KYB_FE_MAG_SET(f, m_);
+    KYB_FE_MAG_SET(g, m_);
+    (void)m_;
 }
 
 // Column accumulators carry a BIAS of half a limb into the carry chain: T[i] = t[i] + 2^(w_i - 1), w_i = 26 (even i)
@@ -119,6 +165,7 @@ KYB_DEV void fe_carry_store(fe& h, int64_t T[10]) {
 
 // h = f * g
 KYB_DEV void fe_mul(fe& h, const fe& f, const fe& g) {
+    KYB_FE_NOTE(KYB_FE_MAG(f), KYB_FE_MAG(g), 1.0);
     int32_t g19[10], f2[10];
 #pragma unroll
     for (int i = 0; i < 10; i++) {
@@ -142,11 +189,13 @@ KYB_DEV void fe_mul(fe& h, const fe& f, const fe& g) {
         t[k] = acc;
     }
     fe_carry_store(h, t);
+    KYB_FE_MAG_SET(h, 1.01);
 }
 
 // h = (DBL ? 2 : 1) * f^2   (55 products)
 template <bool DBL>
 KYB_DEV void fe_sq_t(fe& h, const fe& f) {
+    KYB_FE_NOTE(KYB_FE_MAG(f), KYB_FE_MAG(f), DBL ? 2.0 : 1.0);
     int32_t f2[10], f19[10], f38[10];
 #pragma unroll
     for (int i = 0; i < 10; i++) {
@@ -180,10 +229,12 @@ KYB_DEV void fe_sq_t(fe& h, const fe& f) {
         t[k] = DBL ? (acc + acc) + fe_bias(k) : acc;
     }
     fe_carry_store(h, t);
+    KYB_FE_MAG_SET(h, 1.01);
 }
 // h = (dbl ? 2 : 1) * f^2 with a per-lane choice (the cooperative doubling of the MSM tail squares X, Y, X + Y and
 // 2-squares Z in the four lanes of one instruction stream)
 KYB_DEV void fe_sq_sel(fe& h, const fe& f, bool dbl) {
+    KYB_FE_NOTE(KYB_FE_MAG(f), KYB_FE_MAG(f), 2.0);
     fe g = f;
     int32_t f2[10], f19[10], f38[10];
 #pragma unroll
@@ -209,6 +260,7 @@ KYB_DEV void fe_sq_sel(fe& h, const fe& f, bool dbl) {
         t[k] = (dbl ? (acc + acc) : acc) + fe_bias(k);
     }
     fe_carry_store(h, t);
+    KYB_FE_MAG_SET(h, 1.01);
 }
 KYB_DEV void fe_sq(fe& h, const fe& f) { fe_sq_t<false>(h, f); }
 KYB_DEV void fe_sq2(fe& h, const fe& f) { fe_sq_t<true>(h, f); }
@@ -303,6 +355,7 @@ KYB_DEV void fe_fromwords(fe& h, const uint32_t w[8]) {
     h.v[7] = (int32_t)(((w[5] >> 19) | (w[6] << 13)) & 0x1ffffff);
     h.v[8] = (int32_t)(((w[6] >> 12) | (w[7] << 20)) & 0x3ffffff);
     h.v[9] = (int32_t)((w[7] >> 6) & 0x1ffffff);
+    KYB_FE_MAG_SET(h, 2.0);
 }
 KYB_DEV bool fe_isnegative(const fe& f) {
     uint32_t w[8];

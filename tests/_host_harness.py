@@ -36,13 +36,28 @@ def lib():
     return _lib
 
 
-def call(name, *bufs_and_ints, out_sizes=()):
+_lib_audit = None
+
+
+def lib_audit():
+    """The same harness built with -DKYB_FE_AUDIT: Ed25519 field elements carry a magnitude bound that every
+    multiplication checks in with (fe25519.cuh).  Rebuilt on every first use (a few seconds)."""
+    global _lib_audit
+    if _lib_audit is None:
+        out = OUT.replace("libhostharness.so", "libhostharness_audit.so")
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-DKYB_FE_AUDIT", "-shared", "-fPIC", "-o", out, SRC])
+        _lib_audit = C.CDLL(out)
+    return _lib_audit
+
+
+def call(name, *bufs_and_ints, out_sizes=(), audit=False):
     """Call harness function `name`; bytes args are inputs, ints pass through, outputs appended."""
     outs = [C.create_string_buffer(n) for n in out_sizes]
     args = []
     for a in bufs_and_ints:
         args.append(C.c_int(a) if isinstance(a, int) else C.c_char_p(bytes(a)))
-    fn = getattr(lib(), name)
+    fn = getattr(lib_audit() if audit else lib(), name)
     fn.restype = C.c_int
     rc = fn(*args, *outs)
     return (rc, *[o.raw for o in outs])
