@@ -178,7 +178,7 @@ def other_workloads(rank, world, dist):
         trust = m.F_TRUSTED(0) | m.F_TRUSTED(1) | m.F_TRUSTED(3)
         ok_t, st_t = m.batch_validate_pairing(P, Q, sig, G2, trust)
         ms_chk_t = timed(lambda: m.batch_validate_pairing(P, Q, sig, G2, trust), 2)
-        ms_pair_t = timed(lambda: m.batch_pair(P, Q, m.F_TRUSTED_ALL), 2)
+        ms_pair_t = timed(lambda: m.batch_pair(P, Q, m.F_TRUSTED(0) | m.F_TRUSTED(1)), 2)
         t = torch.tensor([ms_pair, ms_chk, ms_g1, ms_g2, ms_chk_t, ms_pair_t], dtype=torch.float64, device="cuda")
         if dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -60,7 +60,7 @@ extern "C" {
 #define KYB_F_UNCOMPRESSED_OUT 4u /* g1/g2 mul and mul_same_base: write uncompressed outputs (96 / 192 B) as well, so a
                                      pipeline can keep points in the form that needs no square root; bn256: no-op */
 #define KYB_F_TRUSTED(i) (0x100u << (i))
-#define KYB_F_TRUSTED_ALL 0xF00u
+#define KYB_F_TRUSTED_ALL 0xF00u /* the four point arguments of pair_check; calls with fewer point arguments reject the extra bits */
 
 int kyb_version(void);
 const char *kyb_last_error(void);

@@ -128,6 +128,7 @@ int kyb_bls12381_verify_g1_dev(size_t n, const void* d_pks, const void* d_msgs, 
         set_error("kyb_bls12381_verify_g1_dev: bad argument");
         return KYB_E_ARG;
     }
+    KYB_TRY(check_flags(flags, 2, false, "kyb_bls12381_verify_g1_dev"));
     bls::DstArg d;
     KYB_TRY(make_dst(d, dst, dst_len));
     if (!n) return KYB_OK;
@@ -143,6 +144,7 @@ int kyb_bls12381_verify_g1(size_t n, const uint8_t* pks, const uint8_t* msgs, si
         set_error("kyb_bls12381_verify_g1: bad argument");
         return KYB_E_ARG;
     }
+    KYB_TRY(check_flags(flags, 2, false, "kyb_bls12381_verify_g1"));
     if (!n) return KYB_OK;
     DeviceCtx* ctx;
     KYB_TRY(get_ctx(&ctx));
@@ -164,6 +166,7 @@ int kyb_bls12381_verify_g2_dev(size_t n, const void* d_pks, const void* d_msgs, 
         set_error("kyb_bls12381_verify_g2_dev: bad argument");
         return KYB_E_ARG;
     }
+    KYB_TRY(check_flags(flags, 2, false, "kyb_bls12381_verify_g2_dev"));
     bls::DstArg d;
     KYB_TRY(make_dst(d, dst, dst_len));
     if (!n) return KYB_OK;
@@ -179,6 +182,7 @@ int kyb_bls12381_verify_g2(size_t n, const uint8_t* pks, const uint8_t* msgs, si
         set_error("kyb_bls12381_verify_g2: bad argument");
         return KYB_E_ARG;
     }
+    KYB_TRY(check_flags(flags, 2, false, "kyb_bls12381_verify_g2"));
     if (!n) return KYB_OK;
     DeviceCtx* ctx;
     KYB_TRY(get_ctx(&ctx));

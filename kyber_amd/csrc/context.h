@@ -30,7 +30,12 @@ struct DeviceCtx {
     int num_cu = 0;
     bool ready = false;
     std::mutex mu;
-    std::mutex msm_mu;  // serialises host-buffer MSM calls (they share the workspace)
+    // Held for the whole enqueue sequence of every call that takes a (kind, stream) workspace below -- the ~20 kernels of
+    // the MSM pipeline, the Ed25519 batch kernels with their parked triples: two host threads that use the same stream
+    // (including the null stream) therefore enqueue one whole call after the other, which the stream then runs in that
+    // order, and a workspace is never grown (freed) while another thread is still enqueueing kernels on the old
+    // pointer.  Recursive: the host-buffer wrappers hold it around upload / enqueue / download.
+    std::recursive_mutex enq_mu;
     // Ed25519 fixed-base table: [33][136] entries of 32 int32 (30 limbs + 2 pad), built on device at init
     int32_t* ed_base_tab = nullptr;
     // Grow-only device workspaces, one per (kind, stream): calls enqueued on one stream are ordered and reuse their
@@ -50,6 +55,19 @@ struct DeviceCtx {
     // streams of the chunk-pipelined host paths (H2D | compute | D2H), created on first use
     hipStream_t pipe[3] = {};
 };
+
+// Flag validation of the pairing-suite entry points: only the documented bits of include/kyber_hip.h for a call with
+// `npoint` point arguments (KYB_F_TRUSTED(i), i < npoint), uncompressed input, and -- where the call writes points --
+// uncompressed output.  A stray bit (say KYB_F_TRUSTED(2) on a one-point call) is an error, not silently ignored:
+// TRUSTED skips checks the GLV / GLS paths rely on.
+inline int check_flags(uint32_t flags, int npoint, bool point_out, const char* who) {
+    const uint32_t allowed = KYB_F_UNCOMPRESSED | (point_out ? KYB_F_UNCOMPRESSED_OUT : 0u) | (((1u << npoint) - 1u) << 8);
+    if (flags & ~allowed) {
+        set_error(std::string(who) + ": unknown or inapplicable flag bits");
+        return KYB_E_ARG;
+    }
+    return KYB_OK;
+}
 
 // Context for the calling thread's current device (created on first use).
 int get_ctx(DeviceCtx** out);

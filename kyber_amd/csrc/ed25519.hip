@@ -385,6 +385,7 @@ static int launch_mul_base(DeviceCtx* ctx, size_t n, const void* d_scalars, void
     size_t cap = (size_t)ctx->num_cu * 8;  // grid-stride: two resident workgroups per SIMD row
     int grid = (int)(want < cap ? want : cap);
     int32_t* proj = nullptr;
+    std::lock_guard<std::recursive_mutex> enq_lock(ctx->enq_mu);  // context.h: workspace + its kernels as one unit
     if (n >= ENC_DEFER_MIN) {
         int rc = ed_proj_workspace(ctx, st, n, false, &proj, nullptr);
         if (rc) return rc;
@@ -407,10 +408,11 @@ static int launch_mul(size_t n, const void* d_scalars, const void* d_points, siz
     int32_t* proj = nullptr;
     int4* gtab = nullptr;
     uint8_t* stat = (uint8_t*)d_status;
+    DeviceCtx* ctx;
+    int rc = get_ctx(&ctx);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> enq_lock(ctx->enq_mu);
     if (n >= ENC_DEFER_MIN) {
-        DeviceCtx* ctx;
-        int rc = get_ctx(&ctx);
-        if (rc) return rc;
         rc = ed_proj_workspace(ctx, st, n, stat == nullptr, &proj, stat ? nullptr : &stat, &gtab);
         if (rc) return rc;
         hipLaunchKernelGGL(ed25519_mul_kernel<true>, dim3((unsigned)grid), dim3(block), 0, st, n,

@@ -506,6 +506,12 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
         set_error("msm: n too large");
         return KYB_E_ARG;
     }
+    if ((n && (!d_scalars || !d_points)) || !d_out) {
+        set_error("msm: bad argument");
+        return KYB_E_ARG;
+    }
+    if (int frc = check_flags(flags, 1, false, "msm")) return frc;
+    std::lock_guard<std::recursive_mutex> enq_lock(ctx->enq_mu);  // context.h: one whole pipeline at a time per device
     const size_t ne = n * Split<A>::value;  // points after the adapter's endomorphism split
     const Plan p = make_plan(ne ? ne : 1, Split<A>::bits, Split<A>::cmax);
     Plan pr = p;
@@ -624,11 +630,12 @@ int run_host(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* o
         set_error("msm: bad argument");
         return KYB_E_ARG;
     }
+    if (int frc = check_flags(flags, 1, false, "msm")) return frc;
     DeviceCtx* ctx;
     int rc = get_ctx(&ctx);
     if (rc) return rc;
     // the pipeline lives in the per-device workspace: host-buffer MSM calls on one device are serialised
-    std::lock_guard<std::mutex> ws_lock(ctx->msm_mu);
+    std::lock_guard<std::recursive_mutex> ws_lock(ctx->enq_mu);
     StageScope sc_(ctx);
     StageBuf d_s, d_p, d_o, d_st;
     rc = d_s.upload(scalars, n * 32);
@@ -703,6 +710,12 @@ int poly_eval_run(DeviceCtx* ctx, size_t n, const void* d_idx, size_t t, const v
         set_error("poly_eval: threshold too large");
         return KYB_E_ARG;
     }
+    if ((n && (!d_idx || !d_out)) || (t && !d_commits)) {
+        set_error("poly_eval: bad argument");
+        return KYB_E_ARG;
+    }
+    if (int frc = check_flags(flags, 1, false, "poly_eval")) return frc;
+    std::lock_guard<std::recursive_mutex> enq_lock(ctx->enq_mu);
     void* ws;
     int rc = ctx_workspace(ctx, WS_MSM, st, sizeof(typename A::Aff) * (t ? t : 1) + 512, &ws);
     if (rc) return rc;
@@ -725,10 +738,11 @@ int poly_eval_host(size_t n, const uint32_t* idx, size_t t, const uint8_t* commi
         set_error("poly_eval: bad argument");
         return KYB_E_ARG;
     }
+    if (int frc = check_flags(flags, 1, false, "poly_eval")) return frc;
     DeviceCtx* ctx;
     int rc = get_ctx(&ctx);
     if (rc) return rc;
-    std::lock_guard<std::mutex> ws_lock(ctx->msm_mu);
+    std::lock_guard<std::recursive_mutex> ws_lock(ctx->enq_mu);
     StageScope sc_(ctx);
     StageBuf d_i, d_c, d_o, d_st;
     rc = d_i.upload(idx, n * 4);

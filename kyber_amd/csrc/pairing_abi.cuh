@@ -74,6 +74,7 @@ __global__ __launch_bounds__(64) void PFX##_g2_add_kernel(size_t n, const uint8_
 extern "C" { \
 int kyb_##PFX##_g1_mul_dev(size_t n, const void* d_scalars, const void* d_points, size_t point_stride, \
                             void* d_out, void* d_status, uint32_t flags, void* stream) { \
+    KYB_TRY(kyb::check_flags(flags, 1, true, "kyb_" #PFX "_g1_mul_dev")); \
     if ((n && (!d_scalars || !d_points || !d_out)) || (point_stride != 0 && point_stride != kyb::NS::g1_wire_size(flags))) { \
         kyb::set_error("kyb_" #PFX "_g1_mul_dev: bad argument"); \
         return KYB_E_ARG; \
@@ -87,6 +88,7 @@ int kyb_##PFX##_g1_mul_dev(size_t n, const void* d_scalars, const void* d_points
 } \
 int kyb_##PFX##_g2_mul_dev(size_t n, const void* d_scalars, const void* d_points, size_t point_stride, \
                             void* d_out, void* d_status, uint32_t flags, void* stream) { \
+    KYB_TRY(kyb::check_flags(flags, 1, true, "kyb_" #PFX "_g2_mul_dev")); \
     if ((n && (!d_scalars || !d_points || !d_out)) || (point_stride != 0 && point_stride != kyb::NS::g2_wire_size(flags))) { \
         kyb::set_error("kyb_" #PFX "_g2_mul_dev: bad argument"); \
         return KYB_E_ARG; \
@@ -100,6 +102,7 @@ int kyb_##PFX##_g2_mul_dev(size_t n, const void* d_scalars, const void* d_points
 } \
 static int PFX##_mul_host(bool g2, size_t n, const uint8_t* scalars, const uint8_t* points, size_t stride, \
                           uint8_t* out, uint8_t* status, uint32_t flags) { \
+    KYB_TRY(kyb::check_flags(flags, 1, true, "kyb_" #PFX "_g*_mul")); \
     const size_t psz = g2 ? kyb::NS::g2_out_size(flags) : kyb::NS::g1_out_size(flags); \
     const size_t isz = g2 ? kyb::NS::g2_wire_size(flags) : kyb::NS::g1_wire_size(flags); \
     if (stride) stride = isz; \
@@ -140,6 +143,7 @@ int kyb_##PFX##_g2_mul_same_base(size_t n, const uint8_t* scalars, const uint8_t
 } \
 int kyb_##PFX##_g1_unmarshal_dev(size_t n, const void* d_points, void* d_out, void* d_status, uint32_t flags, \
                                   void* stream) { \
+    KYB_TRY(kyb::check_flags(flags, 1, true, "kyb_" #PFX "_g1_unmarshal_dev")); \
     if (n && (!d_points || !d_out)) { \
         kyb::set_error("kyb_" #PFX "_g1_unmarshal_dev: bad argument"); \
         return KYB_E_ARG; \
@@ -152,6 +156,7 @@ int kyb_##PFX##_g1_unmarshal_dev(size_t n, const void* d_points, void* d_out, vo
 } \
 int kyb_##PFX##_g2_unmarshal_dev(size_t n, const void* d_points, void* d_out, void* d_status, uint32_t flags, \
                                   void* stream) { \
+    KYB_TRY(kyb::check_flags(flags, 1, true, "kyb_" #PFX "_g2_unmarshal_dev")); \
     if (n && (!d_points || !d_out)) { \
         kyb::set_error("kyb_" #PFX "_g2_unmarshal_dev: bad argument"); \
         return KYB_E_ARG; \
@@ -164,6 +169,7 @@ int kyb_##PFX##_g2_unmarshal_dev(size_t n, const void* d_points, void* d_out, vo
 } \
 static int PFX##_unmarshal_host(bool g2, size_t n, const uint8_t* points, uint8_t* out, uint8_t* status, \
                                 uint32_t flags) { \
+    KYB_TRY(kyb::check_flags(flags, 1, true, "kyb_" #PFX "_g*_unmarshal")); \
     const size_t psz = g2 ? kyb::NS::g2_out_size(flags) : kyb::NS::g1_out_size(flags); \
     const size_t isz = g2 ? kyb::NS::g2_wire_size(flags) : kyb::NS::g1_wire_size(flags); \
     if (n && (!points || !out)) { \
@@ -259,6 +265,7 @@ __global__ __launch_bounds__(64) void PFX##_pair_check_kernel(size_t n, const ui
 extern "C" { \
 int kyb_##PFX##_pair_dev(size_t n, const void* d_g1, const void* d_g2, void* d_gt, void* d_status, uint32_t flags, \
                           void* stream) { \
+    KYB_TRY(kyb::check_flags(flags, 2, false, "kyb_" #PFX "_pair_dev")); \
     if (n && (!d_g1 || !d_g2 || !d_gt)) { \
         kyb::set_error("kyb_" #PFX "_pair_dev: bad argument"); \
         return KYB_E_ARG; \
@@ -301,6 +308,7 @@ int kyb_##PFX##_gt_mul(size_t n, const uint8_t* scalars, const uint8_t* gt, uint
 } \
 int kyb_##PFX##_pair_check_dev(size_t n, const void* d_p1, const void* d_p2, const void* d_inv1, const void* d_inv2, \
                                 void* d_ok, void* d_status, uint32_t flags, void* stream) { \
+    KYB_TRY(kyb::check_flags(flags, 4, false, "kyb_" #PFX "_pair_check_dev")); \
     if (n && (!d_p1 || !d_p2 || !d_inv1 || !d_inv2 || !d_ok)) { \
         kyb::set_error("kyb_" #PFX "_pair_check_dev: bad argument"); \
         return KYB_E_ARG; \
@@ -313,6 +321,7 @@ int kyb_##PFX##_pair_check_dev(size_t n, const void* d_p1, const void* d_p2, con
     return KYB_OK; \
 } \
 int kyb_##PFX##_pair(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, uint8_t* status, uint32_t flags) { \
+    KYB_TRY(kyb::check_flags(flags, 2, false, "kyb_" #PFX "_pair")); \
     if (n && (!g1 || !g2 || !gt)) { \
         kyb::set_error("kyb_" #PFX "_pair: bad argument"); \
         return KYB_E_ARG; \
@@ -333,6 +342,7 @@ int kyb_##PFX##_pair(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt
 } \
 int kyb_##PFX##_pair_check(size_t n, const uint8_t* p1, const uint8_t* p2, const uint8_t* inv1, const uint8_t* inv2, \
                             uint8_t* ok, uint8_t* status, uint32_t flags) { \
+    KYB_TRY(kyb::check_flags(flags, 4, false, "kyb_" #PFX "_pair_check")); \
     if (n && (!p1 || !p2 || !inv1 || !inv2 || !ok)) { \
         kyb::set_error("kyb_" #PFX "_pair_check: bad argument"); \
         return KYB_E_ARG; \

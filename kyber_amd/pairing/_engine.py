@@ -31,6 +31,23 @@ def _host(buf, width: int) -> np.ndarray:
     return np.ascontiguousarray(a).reshape(-1, width)
 
 
+def pack_fixed(items, width: int):
+    """Pack a list of per-element encodings into an (n, width) array.  Elements of the wrong length are replaced by
+    `width` zero bytes (which no suite decodes) and their indices returned, so that one malformed element neither
+    shifts the elements after it nor makes the native call read past the buffer: the caller reports those lanes as
+    ok = False / status = BAD_POINT, the way the reference's UnmarshalBinary rejects only the offending element."""
+    n = len(items)
+    out = np.zeros((n, width), dtype=np.uint8)
+    bad = []
+    for i, it in enumerate(items):
+        b = bytes(it)
+        if len(b) != width:
+            bad.append(i)
+        else:
+            out[i] = np.frombuffer(b, dtype=np.uint8)
+    return out, bad
+
+
 def _stream():
     import torch
 

@@ -119,7 +119,7 @@ def _batch_verify(sig_group: int, pubkeys, msgs, sigs, dst: bytes, flags: int):
     import numpy as np
 
     from .._lib import check, load
-    from ._engine import F_UNCOMPRESSED, _host, _is_torch, _stream
+    from ._engine import F_UNCOMPRESSED, _host, _is_torch, _stream, pack_fixed
 
     wk, wsig = (96, 48) if sig_group == 1 else (48, 96)
     if flags & F_UNCOMPRESSED:
@@ -134,6 +134,8 @@ def _batch_verify(sig_group: int, pubkeys, msgs, sigs, dst: bytes, flags: int):
 
         m, p, s = msgs.contiguous(), pubkeys.contiguous().view(-1, wk), sigs.contiguous().view(-1, wsig)
         n, ln = m.shape[0], m.shape[1]
+        if p.shape[0] != n or s.shape[0] != n:
+            raise ValueError(f"batch_verify: {n} messages, {p.shape[0]} public keys, {s.shape[0]} signatures")
         ok = torch.empty(n, dtype=torch.uint8, device=m.device)
         st = torch.empty(n, dtype=torch.uint8, device=m.device)
         check(getattr(lib, name + "_dev")(n, p.data_ptr(), m.data_ptr(), ln, dptr, len(dst), s.data_ptr(), ok.data_ptr(),
@@ -150,10 +152,15 @@ def _batch_verify(sig_group: int, pubkeys, msgs, sigs, dst: bytes, flags: int):
         n, ln = a.shape[0], a.shape[1]
         mb = a.reshape(-1)
     mb = np.ascontiguousarray(mb) if mb.size else np.zeros(1, dtype=np.uint8)
-    p = _host(pubkeys if not isinstance(pubkeys, (list, tuple)) else b"".join(pubkeys), wk)
-    s = _host(sigs if not isinstance(sigs, (list, tuple)) else b"".join(sigs), wsig)
+    # per-element lists are packed element by element: a wrong-length key / signature (attacker-supplied) fails alone
+    p, bad_p = pack_fixed(pubkeys, wk) if isinstance(pubkeys, (list, tuple)) else (_host(pubkeys, wk), [])
+    s, bad_s = pack_fixed(sigs, wsig) if isinstance(sigs, (list, tuple)) else (_host(sigs, wsig), [])
+    if p.shape[0] != n or s.shape[0] != n:
+        raise ValueError(f"batch_verify: {n} messages, {p.shape[0]} public keys, {s.shape[0]} signatures")
     ok = np.empty(n, dtype=np.uint8)
     st = np.empty(n, dtype=np.uint8)
     check(getattr(lib, name)(n, p.ctypes.data, mb.ctypes.data, ln, dptr, len(dst), s.ctypes.data, ok.ctypes.data,
                              st.ctypes.data, flags), name)
+    for i in bad_p + bad_s:
+        ok[i], st[i] = 0, 1  # KYB_ST_BAD_POINT
     return ok, st

@@ -14,6 +14,8 @@ from __future__ import annotations
 
 import numpy as np
 
+from ..pairing._engine import pack_fixed
+
 
 def bn256_batch_hash_g1(msgs) -> np.ndarray:
     """HashablePoint.Hash for a list of messages through the engine (kyb_bn256_hash_g1: SHA-256 +
@@ -48,12 +50,17 @@ class SchemeOnG1:
         """N x Verify (bls.go:82-96) as ONE pairing-check launch: ok[i] = e(H(m_i), X_i) == e(sig_i, B2).
         Returns a bool array; an undecodable key / signature verifies false (the reference returns an error)."""
         n = len(msgs)
+        if len(publics) != n or len(sigs) != n:
+            raise ValueError(f"batch_verify: {n} messages, {len(publics)} public keys, {len(sigs)} signatures")
         H = self.batch_hash(msgs)
-        X = b"".join(publics)
-        S = b"".join(sigs)
+        # element by element: a wrong-length key / signature fails alone instead of shifting the rest of the batch
+        X, bad_x = pack_fixed(publics, self.m.G2_LEN)
+        S, bad_s = pack_fixed(sigs, self.m.G1_LEN)
         flags = self.m.F_TRUSTED(0) | self.m.F_TRUSTED(3) | (self.m.F_TRUSTED(1) if keys_validated else 0)
         ok, st = self.m.batch_validate_pairing(H, X, S, self.m.G2_BASE * n, flags)
-        return (np.asarray(ok) == 1) & (np.asarray(st) == 0)
+        res = (np.asarray(ok) == 1) & (np.asarray(st) == 0)
+        res[bad_x + bad_s] = False
+        return res
 
     def verify(self, public: bytes, msg: bytes, sig: bytes, keys_validated: bool = False) -> bool:
         return bool(self.batch_verify([public], [msg], [sig], keys_validated)[0])
@@ -120,10 +127,16 @@ class SchemeOnG2:
 
     def batch_verify(self, publics, msgs, sigs, keys_validated: bool = False):
         n = len(msgs)
+        if len(publics) != n or len(sigs) != n:
+            raise ValueError(f"batch_verify: {n} messages, {len(publics)} public keys, {len(sigs)} signatures")
         H = self.batch_hash(msgs)
+        S, bad_s = pack_fixed(sigs, self.m.G2_LEN)
+        X, bad_x = pack_fixed(publics, self.m.G1_LEN)
         flags = self.m.F_TRUSTED(0) | self.m.F_TRUSTED(3) | (self.m.F_TRUSTED(2) if keys_validated else 0)
-        ok, st = self.m.batch_validate_pairing(self.m.G1_BASE * n, b"".join(sigs), b"".join(publics), H, flags)
-        return (np.asarray(ok) == 1) & (np.asarray(st) == 0)
+        ok, st = self.m.batch_validate_pairing(self.m.G1_BASE * n, S, X, H, flags)
+        res = (np.asarray(ok) == 1) & (np.asarray(st) == 0)
+        res[bad_x + bad_s] = False
+        return res
 
     def verify(self, public: bytes, msg: bytes, sig: bytes, keys_validated: bool = False) -> bool:
         return bool(self.batch_verify([public], [msg], [sig], keys_validated)[0])

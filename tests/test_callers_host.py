@@ -144,3 +144,21 @@ def test_share_poly_recover_pub_poly_and_scalar_side(monkeypatch):
     assert not pub.Equal(qpub)
     with pytest.raises(ValueError):
         pub.Add(poly.PubPoly(g, None, qpub.commits[:2]))
+
+
+def test_pack_fixed_isolates_wrong_length_elements():
+    """Packing of per-element encodings for the batch entry points: a wrong-length element becomes a row of zeros
+    and is reported, every other element stays in its own row."""
+    import numpy as np
+
+    from kyber_amd.pairing._engine import pack_fixed
+
+    items = [bytes([i + 1]) * 48 for i in range(5)]
+    items[1] = b""
+    items[2] = items[2][:-1]
+    items[3] = items[3] + b"\x00"
+    arr, bad = pack_fixed(items, 48)
+    assert arr.shape == (5, 48) and bad == [1, 2, 3]
+    assert bytes(arr[0]) == items[0] and bytes(arr[4]) == items[4] and not arr[1:4].any()
+    arr, bad = pack_fixed([], 96)
+    assert arr.shape == (0, 96) and bad == []

@@ -256,6 +256,41 @@ def test_fused_verify_matches_hash_plus_pairing_check(bls):
     assert (ok_f.astype(bool) == exp).all()
 
 
+def test_wrong_length_key_or_signature_fails_alone(bls):
+    """A signature / key of the wrong length (attacker-supplied bytes) is rejected by itself -- it neither shifts the
+    elements packed after it nor makes the native call read past the buffer (sigs = [48 B, b""] used to
+    reshape to one row).  The reference's Verify fails only the offending signature (bls.go:82-96)."""
+    from kyber_amd.sign import bls as sbls
+
+    n = 9
+    xs = _scalars(b"wl/x", n)
+    msgs = [b"msg-%02d" % i for i in range(n)]
+    for sch, commit in ((sbls.NewSchemeOnG1_bls12381(), bls.g2_commit), (sbls.NewSchemeOnG2_bls12381(), bls.g1_commit)):
+        pubs = [bytes(r) for r in commit(xs)[0]]
+        sigs = [sch.sign(bytes(xs[i]), msgs[i]) for i in range(n)]
+        assert sch.batch_verify(pubs, msgs, sigs).all()
+        bad = list(sigs)
+        bad[3] = b""                 # empty
+        bad[5] = sigs[5][:-1]        # one byte short ...
+        bad[6] = sigs[6] + b"\x00"   # ... one byte long: the lengths compensate, nothing may shift
+        res = sch.batch_verify(pubs, msgs, bad)
+        assert list(res) == [i not in (3, 5, 6) for i in range(n)]
+        badk = list(pubs)
+        badk[0] = pubs[0][:-2]
+        res = sch.batch_verify(badk, msgs, sigs)
+        assert list(res) == [i != 0 for i in range(n)]
+    # the low-level entry point reports the lane as BAD_POINT and leaves the others alone
+    sch = sbls.NewSchemeOnG1_bls12381()
+    pubs = [bytes(r) for r in bls.g2_commit(xs)[0]]
+    m32 = [hashlib.sha256(m).digest() for m in msgs]
+    sigs = [sch.sign(bytes(xs[i]), m32[i]) for i in range(n)]
+    sigs[4] = sigs[4][:10]
+    ok, st = bls.batch_verify_g1(pubs, m32, sigs)
+    assert st[4] == 1 and ok[4] == 0 and ok.sum() == n - 1 and not np.delete(st, 4).any()
+    with pytest.raises(ValueError):
+        bls.batch_verify_g1(pubs[:-1], m32, sigs)
+
+
 # ------------------------------------------------------------------ call flags (KYB_F_*)
 def _off_subgroup_g1():
     x = 1
@@ -333,7 +368,7 @@ def test_pair_check_verify_and_msm_flags_agree_with_the_checked_path(bls):
         ok, st = bls.batch_validate_pairing(a, b, c, d, flags)
         assert not st.any().item() and (ok.cpu().numpy() == exp).all(), flags
     gt0, _ = bls.batch_pair(Hc, Xc)
-    gt1, st = bls.batch_pair(Hu, Xu, U | bls.F_TRUSTED_ALL)
+    gt1, st = bls.batch_pair(Hu, Xu, U | bls.F_TRUSTED(0) | bls.F_TRUSTED(1))
     assert not st.any().item() and torch.equal(gt0, gt1)
     # an unvalidated operand outside the subgroup is still caught when the others are trusted
     bad = sig_c.clone()
@@ -363,17 +398,28 @@ def test_pair_check_verify_and_msm_flags_agree_with_the_checked_path(bls):
             assert not st.any().item() and torch.equal(r, r0), (grp, flags)
 
 
-def test_bn256_accepts_and_ignores_the_flags():
+def test_bn256_accepts_the_documented_flags_and_rejects_stray_bits():
+    """bn256 accepts (and has nothing to do for) the documented flags of a call; bits that do not apply to the call --
+    KYB_F_TRUSTED(i) beyond its point arguments, undefined bits -- are KYB_E_ARG on both suites."""
     from kyber_amd.pairing import bn256 as bn
 
     k = _scalars(b"bnflags/k", 8)
     P, _ = bn.g1_commit(k)
     a, st = bn.g1_batch_mul(k, P)
-    b, st2 = bn.g1_batch_mul(k, P, bn.F_UNCOMPRESSED | bn.F_UNCOMPRESSED_OUT | bn.F_TRUSTED_ALL)
+    b, st2 = bn.g1_batch_mul(k, P, bn.F_UNCOMPRESSED | bn.F_UNCOMPRESSED_OUT | bn.F_TRUSTED(0))
     assert not st.any() and not st2.any() and (a == b).all()
     r0, _ = bn.g1_msm(k, P)
     r1, _ = bn.g1_msm(k, P, bn.F_TRUSTED(0) | bn.F_UNCOMPRESSED)
     assert (r0 == r1).all()
+    from kyber_amd.pairing import bls12381 as bl
+
+    Q, _ = bn.g2_commit(k)
+    for call in (lambda: bn.g1_batch_mul(k, P, bn.F_TRUSTED(1)), lambda: bn.g1_batch_mul(k, P, 0x10000),
+                 lambda: bn.g1_msm(k, P, bn.F_TRUSTED_ALL), lambda: bn.batch_pair(P, Q, bn.F_TRUSTED(2)),
+                 lambda: bn.batch_pair(P, Q, bn.F_UNCOMPRESSED_OUT), lambda: bn.g1_batch_unmarshal(P, 1),
+                 lambda: bl.g1_commit(k, None, bl.F_TRUSTED(3)), lambda: bl.g1_msm(k, bl.g1_commit(k)[0], 0x8)):
+        with pytest.raises(RuntimeError):
+            call()
 
 
 def test_fused_verify_g2_matches_hash_plus_pairing_check(bls):

@@ -202,7 +202,7 @@ def test_batch_unmarshal(bn):
             break
     assert O.g2_mul(O.ORDER, (X, Y)) is not None
     batch = g2 + [bytes(128), fp(1) * 4, O.g2_marshal((X, Y))]
-    out, st = bn.g2_batch_unmarshal(b"".join(batch), bn.F_TRUSTED_ALL)  # flags ignored
+    out, st = bn.g2_batch_unmarshal(b"".join(batch), bn.F_TRUSTED(0))  # bn256 has no check to skip
     assert list(st) == [0, 0, 0, 0, 1, 0]
     for i in (0, 1, 2, 3, 5):
         assert bytes(out[i]) == batch[i]

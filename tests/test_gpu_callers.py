@@ -234,3 +234,24 @@ def test_share_recover_pub_poly_and_pubpoly_add(name):
     # scalar side against the same polynomial
     assert poly.recover_secret(g, pri.Shares(n)[2:], t, n).Equal(pri.coeffs[0])
     assert poly.recover_pri_poly(g, pri.Shares(n)[3:3 + t], t, n).Equal(pri)
+
+
+def test_bn256_wrong_length_signature_fails_alone():
+    """Generic SchemeOnG1.batch_verify (bn256): one malformed-length signature is one false entry, not a shifted batch
+    or a ValueError for everybody."""
+    from kyber_amd.pairing import bn256 as bn
+    from kyber_amd.sign import bls as sbls
+
+    sch = sbls.NewSchemeOnG1_bn256()
+    n = 6
+    xs = [((i + 2) * 0x9E3779B97F4A7C15F39CC0605CEDC835 % bn.ORDER).to_bytes(32, "big") for i in range(n)]
+    pubs = [bytes(bn.g2_commit(x)[0][0]) for x in xs]
+    msgs = [b"bn-msg-%d" % i for i in range(n)]
+    sigs = [sch.sign(xs[i], msgs[i]) for i in range(n)]
+    assert sch.batch_verify(pubs, msgs, sigs).all()
+    bad = list(sigs)
+    bad[1] = sigs[1][:-1]
+    bad[2] = sigs[2] + b"\x07"
+    assert list(sch.batch_verify(pubs, msgs, bad)) == [True, False, False, True, True, True]
+    with pytest.raises(ValueError):
+        sch.batch_verify(pubs, msgs, sigs[:-1])
