@@ -90,6 +90,68 @@ def test_pairing_suites_at_config_sizes(name, n):
     assert not st3.any().item() and torch.equal(ok.bool(), exp)
 
 
+@pytest.mark.parametrize("name,n", [("bls12381", 1 << 16), ("bn256", 1 << 18)])
+def test_pairing_known_answers_inside_config_size_batches(name, n, golden_dir):
+    """The oracle's known answers (tests/golden/<suite>_pair_kat.npz, written by make_golden_pair_kat.py: 384 pairs with
+    infinity rows and, for bn256, G2 points outside the order-n subgroup) scattered through a configs[3] / configs[4]
+    size batch: Suite.Pair bytes, ValidatePairing booleans and G1 / G2 scalar-mul outputs compared BYTE FOR BYTE at
+    the KAT lanes -- first lane, last lane and a stride in between -- so at-scale parity is against the oracle, not
+    self-consistency (reference pattern: pairing/bn256/suite_test.go:231-259)."""
+    import importlib
+    import os
+
+    import torch
+
+    m = importlib.import_module("kyber_amd.pairing." + name)
+    K = np.load(os.path.join(golden_dir, name + "_pair_kat.npz"))
+    nk = K["g1"].shape[0]
+    pos = np.unique(np.concatenate([[0, n - 1], np.linspace(1, n - 2, nk - 2).astype(np.int64)]))
+    assert len(pos) == nk
+    # filler lanes: valid points produced by the engine itself
+    raw = _shake(b"kat-fill/" + name.encode(), 2 * n * 32).reshape(2, n, 32).copy()
+    raw[:, :, 0] &= 0x3F
+    a, b = (torch.from_numpy(x).cuda() for x in raw)
+    g1b = torch.from_numpy(np.frombuffer(m.G1_BASE, dtype=np.uint8).copy()).cuda()
+    g2b = torch.from_numpy(np.frombuffer(m.G2_BASE, dtype=np.uint8).copy()).cuda()
+    P, st = m._mul(1, a, g1b, True)
+    Q, st2 = m._mul(2, b, g2b, True)
+    assert not st.any().item() and not st2.any().item()
+    dpos = torch.from_numpy(pos).cuda()
+    P[dpos] = torch.from_numpy(K["g1"]).cuda()
+    Q[dpos] = torch.from_numpy(K["g2"]).cuda()
+    gt, st = m.batch_pair(P, Q)
+    assert not st.any().item()
+    got = gt[dpos].cpu().numpy()
+    bad = np.nonzero((got != K["gt"]).any(axis=1))[0]
+    assert bad.size == 0, f"GT bytes differ from the oracle at KAT rows {bad[:8]}"
+    # operands the caller vouches for take the unchecked path: same bytes
+    gt2, st = m.batch_pair(P, Q, m.F_TRUSTED(0) | m.F_TRUSTED(1))
+    if name == "bls12381":  # (bn256's KAT holds off-subgroup G2 points: nothing to vouch for there, flags are a no-op)
+        assert not st.any().item() and torch.equal(gt2, gt)
+    # ValidatePairing(P_i, Q_i, P_j, Q_j) at lanes spread over the batch
+    ci, ck = K["chk_idx"], K["chk_ok"]
+    cpos = np.unique(np.concatenate([[0, n - 1], np.linspace(1, n - 2, len(ck) - 2).astype(np.int64)]))
+    A1, A2, B1, B2 = P.clone(), Q.clone(), P.clone(), Q.clone()  # filler lanes: (P, Q) against itself -> ok
+    dc = torch.from_numpy(cpos).cuda()
+    A1[dc] = torch.from_numpy(K["g1"][ci[:, 0]]).cuda()
+    A2[dc] = torch.from_numpy(K["g2"][ci[:, 0]]).cuda()
+    B1[dc] = torch.from_numpy(K["g1"][ci[:, 1]]).cuda()
+    B2[dc] = torch.from_numpy(K["g2"][ci[:, 1]]).cuda()
+    ok, st = m.batch_validate_pairing(A1, A2, B1, B2)
+    assert not st.any().item()
+    exp = torch.ones(n, dtype=torch.uint8, device="cuda")
+    exp[dc] = torch.from_numpy(ck).cuda()
+    assert torch.equal(ok, exp), "ValidatePairing booleans differ from the oracle"
+    # scalar multiplication answers inside the batch
+    k = torch.from_numpy(_shake(b"kat-k/" + name.encode(), n * 32).reshape(n, 32).copy()).cuda()
+    k[dpos] = torch.from_numpy(K["k"]).cuda()
+    r1, st = m.g1_batch_mul(k, P)
+    r2, st2 = m.g2_batch_mul(k, Q)
+    assert not st.any().item() and not st2.any().item()
+    assert (r1[dpos].cpu().numpy() == K["g1k"]).all(), "G1 scalar-mul bytes differ from the oracle"
+    assert (r2[dpos].cpu().numpy() == K["g2k"]).all(), "G2 scalar-mul bytes differ from the oracle"
+
+
 def test_ed25519_pipelined_host_path_matches_device_path():
     """Host-buffer batches >= 2^19 elements are chunk-pipelined over three streams (H2D | compute | D2H); a ragged
     last chunk, bad points in different chunks and the three entry points must all agree with the resident path."""
