@@ -71,7 +71,7 @@ inline int check_flags(uint32_t flags, int npoint, bool point_out, const char* w
 
 // Context for the calling thread's current device (created on first use).
 int get_ctx(DeviceCtx** out);
-enum { WS_MSM = 0, WS_ED = 1 };
+enum { WS_MSM = 0, WS_ED = 1, WS_PAIR = 2 };
 // Grow (never shrink) the (kind, stream) workspace; caller holds no lock.
 int ctx_workspace(DeviceCtx* ctx, int kind, hipStream_t stream, size_t bytes, void** out);
 

@@ -230,16 +230,13 @@ int kyb_##PFX##_g2_add(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* ou
 } \
 }
 
-#define KYB_DEFINE_PAIR_ABI(PFX, NS, G1SZ, G2SZ, GTSZ) \
+// ---- pairing entry points, in three parts so that a suite can supply its own device implementation of Pair /
+// ValidatePairing (BLS12-381: the cooperative tower machine, bls12381_pair.hip) and still share the rest:
+//   KYB_DEFINE_GT_ABI         GT exponentiation, one element per lane (kernel + _dev + host entry points)
+//   KYB_DEFINE_PAIR_LANE_DEV  Pair / ValidatePairing with one pairing per lane: kernels + the `_dev` entry points
+//   KYB_DEFINE_PAIR_HOST      the host-buffer entry points, which stage and call the `_dev` ones
+#define KYB_DEFINE_GT_ABI(PFX, NS, GTSZ) \
 namespace kyb { \
-__global__ __launch_bounds__(64) void PFX##_pair_kernel(size_t n, const uint8_t* __restrict__ g1, \
-                                                      const uint8_t* __restrict__ g2, uint8_t* __restrict__ gt, \
-                                                      uint8_t* __restrict__ status, uint32_t flags) { \
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
-    if (idx >= n) return; \
-    const int st = NS::pair_wire(gt + GTSZ * idx, g1 + NS::g1_wire_size(flags) * idx, g2 + NS::g2_wire_size(flags) * idx, flags); \
-    if (status) status[idx] = (uint8_t)st; \
-} \
 __global__ __launch_bounds__(64) void PFX##_gt_mul_kernel(size_t n, const uint8_t* __restrict__ scalars, \
                                                         const uint8_t* __restrict__ gts, uint8_t* __restrict__ out, \
                                                         uint8_t* __restrict__ status) { \
@@ -248,34 +245,8 @@ __global__ __launch_bounds__(64) void PFX##_gt_mul_kernel(size_t n, const uint8_
     const int st = NS::gt_mul_wire(out + GTSZ * idx, scalars + 32 * idx, gts + GTSZ * idx); \
     if (status) status[idx] = (uint8_t)st; \
 } \
-__global__ __launch_bounds__(64) void PFX##_pair_check_kernel(size_t n, const uint8_t* __restrict__ p1, \
-                                                            const uint8_t* __restrict__ p2, \
-                                                            const uint8_t* __restrict__ i1, \
-                                                            const uint8_t* __restrict__ i2, uint8_t* __restrict__ ok, \
-                                                            uint8_t* __restrict__ status, uint32_t flags) { \
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
-    if (idx >= n) return; \
-    uint8_t r = 0; \
-    const size_t s1 = NS::g1_wire_size(flags), s2 = NS::g2_wire_size(flags); \
-    const int st = NS::pair_check_wire(&r, p1 + s1 * idx, p2 + s2 * idx, i1 + s1 * idx, i2 + s2 * idx, flags); \
-    ok[idx] = r; \
-    if (status) status[idx] = (uint8_t)st; \
-} \
 } \
 extern "C" { \
-int kyb_##PFX##_pair_dev(size_t n, const void* d_g1, const void* d_g2, void* d_gt, void* d_status, uint32_t flags, \
-                          void* stream) { \
-    KYB_TRY(kyb::check_flags(flags, 2, false, "kyb_" #PFX "_pair_dev")); \
-    if (n && (!d_g1 || !d_g2 || !d_gt)) { \
-        kyb::set_error("kyb_" #PFX "_pair_dev: bad argument"); \
-        return KYB_E_ARG; \
-    } \
-    if (!n) return KYB_OK; \
-    hipLaunchKernelGGL(kyb::PFX##_pair_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
-                       (const uint8_t*)d_g1, (const uint8_t*)d_g2, (uint8_t*)d_gt, (uint8_t*)d_status, flags); \
-    KYB_HIP_CHECK(hipGetLastError()); \
-    return KYB_OK; \
-} \
 int kyb_##PFX##_gt_mul_dev(size_t n, const void* d_scalars, const void* d_gt, void* d_out, void* d_status, void* stream) { \
     if (n && (!d_scalars || !d_gt || !d_out)) { \
         kyb::set_error("kyb_" #PFX "_gt_mul_dev: bad argument"); \
@@ -306,6 +277,46 @@ int kyb_##PFX##_gt_mul(size_t n, const uint8_t* scalars, const uint8_t* gt, uint
     if (status) KYB_TRY(st.download(status, n)); \
     return KYB_OK; \
 } \
+}
+
+#define KYB_DEFINE_PAIR_LANE_DEV(PFX, NS, GTSZ) \
+namespace kyb { \
+__global__ __launch_bounds__(64) void PFX##_pair_kernel(size_t n, const uint8_t* __restrict__ g1, \
+                                                      const uint8_t* __restrict__ g2, uint8_t* __restrict__ gt, \
+                                                      uint8_t* __restrict__ status, uint32_t flags) { \
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
+    if (idx >= n) return; \
+    const int st = NS::pair_wire(gt + GTSZ * idx, g1 + NS::g1_wire_size(flags) * idx, g2 + NS::g2_wire_size(flags) * idx, flags); \
+    if (status) status[idx] = (uint8_t)st; \
+} \
+__global__ __launch_bounds__(64) void PFX##_pair_check_kernel(size_t n, const uint8_t* __restrict__ p1, \
+                                                            const uint8_t* __restrict__ p2, \
+                                                            const uint8_t* __restrict__ i1, \
+                                                            const uint8_t* __restrict__ i2, uint8_t* __restrict__ ok, \
+                                                            uint8_t* __restrict__ status, uint32_t flags) { \
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
+    if (idx >= n) return; \
+    uint8_t r = 0; \
+    const size_t s1 = NS::g1_wire_size(flags), s2 = NS::g2_wire_size(flags); \
+    const int st = NS::pair_check_wire(&r, p1 + s1 * idx, p2 + s2 * idx, i1 + s1 * idx, i2 + s2 * idx, flags); \
+    ok[idx] = r; \
+    if (status) status[idx] = (uint8_t)st; \
+} \
+} \
+extern "C" { \
+int kyb_##PFX##_pair_dev(size_t n, const void* d_g1, const void* d_g2, void* d_gt, void* d_status, uint32_t flags, \
+                          void* stream) { \
+    KYB_TRY(kyb::check_flags(flags, 2, false, "kyb_" #PFX "_pair_dev")); \
+    if (n && (!d_g1 || !d_g2 || !d_gt)) { \
+        kyb::set_error("kyb_" #PFX "_pair_dev: bad argument"); \
+        return KYB_E_ARG; \
+    } \
+    if (!n) return KYB_OK; \
+    hipLaunchKernelGGL(kyb::PFX##_pair_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
+                       (const uint8_t*)d_g1, (const uint8_t*)d_g2, (uint8_t*)d_gt, (uint8_t*)d_status, flags); \
+    KYB_HIP_CHECK(hipGetLastError()); \
+    return KYB_OK; \
+} \
 int kyb_##PFX##_pair_check_dev(size_t n, const void* d_p1, const void* d_p2, const void* d_inv1, const void* d_inv2, \
                                 void* d_ok, void* d_status, uint32_t flags, void* stream) { \
     KYB_TRY(kyb::check_flags(flags, 4, false, "kyb_" #PFX "_pair_check_dev")); \
@@ -320,6 +331,10 @@ int kyb_##PFX##_pair_check_dev(size_t n, const void* d_p1, const void* d_p2, con
     KYB_HIP_CHECK(hipGetLastError()); \
     return KYB_OK; \
 } \
+}
+
+#define KYB_DEFINE_PAIR_HOST(PFX, NS, GTSZ) \
+extern "C" { \
 int kyb_##PFX##_pair(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt, uint8_t* status, uint32_t flags) { \
     KYB_TRY(kyb::check_flags(flags, 2, false, "kyb_" #PFX "_pair")); \
     if (n && (!g1 || !g2 || !gt)) { \
@@ -364,3 +379,8 @@ int kyb_##PFX##_pair_check(size_t n, const uint8_t* p1, const uint8_t* p2, const
     return KYB_OK; \
 } \
 }
+
+#define KYB_DEFINE_PAIR_ABI(PFX, NS, G1SZ, G2SZ, GTSZ) \
+    KYB_DEFINE_GT_ABI(PFX, NS, GTSZ) \
+    KYB_DEFINE_PAIR_LANE_DEV(PFX, NS, GTSZ) \
+    KYB_DEFINE_PAIR_HOST(PFX, NS, GTSZ)

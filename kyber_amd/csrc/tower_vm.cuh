@@ -1,0 +1,363 @@
+// Cooperative tower machine: the pairing (Miller loop + final exponentiation) of 64 (pairs of) points per workgroup,
+// computed by TWELVE waves -- one per Fp coefficient of an Fp12 element -- out of the CU's LDS.
+//
+// Replaces the per-lane pairing of round 1 (pairing/bn256 optate.go:126-274 miller / finalExponentiation / optimalAte,
+// and the Pair / ValidatePairing of the BLS12-381 backends behind pairing/bls12381/kilic/suite.go:57-75), which held a
+// whole Fp12 accumulator per lane: 512 registers, one wave per SIMD, every Fp12 operand through scratch (0.27 of the
+// integer-MAD peak, 29 GB of scratch traffic per 65 536 pairings).  Here:
+//
+//   * lane l of every wave works on pairing l of the workgroup; wave w owns ONE Fp coefficient of whatever Fp12 /
+//     Fp2-tuple value an instruction produces.  All live values (f, T, the line, temporaries) sit in LDS as `slots`
+//     [slot][limb quad][lane] -- 16-byte ds_read_b128 per lane, consecutive lanes consecutive, conflict-free.
+//   * one instruction = for every wave, out = MontgomeryReduce( sum_t X_t * Y_t  +  R * sum_t Z_t ) with up to 24 terms,
+//     X, Y, Z = small-integer combinations c1 S[a] + c2 S[b] of slots (Karatsuba-free schoolbook over the tower: the
+//     products accumulate UNREDUCED in 27 64-bit columns, one reduction per output coefficient instead of one per
+//     multiplication), then a workgroup barrier.  An Fp12 multiplication is ONE instruction of 12 products per wave;
+//     the code a wave executes is ~6 KB -- instruction-cache resident -- and about 110 VGPRs: three waves per SIMD.
+//   * Fp elements are 14 signed 28-bit limbs (balanced digits, |limb| <= 2^27, Montgomery radix R = 2^392) so that
+//     v_mad_i64_i32 is the whole inner loop, subtraction is limb-wise, and there is no conditional subtraction anywhere:
+//     values are only bounded (|v| < B p, B tracked by the program generator), canonical form is produced once, at the
+//     output.  (bn256: 10 limbs, R = 2^280.)
+//   * the program (which slots, which coefficients) is data: gen_tower_vm.py emits it, tests/test_tower_vm_program.py
+//     replays it in exact integer arithmetic against the oracle's pairing, and proves the column / limb bounds.
+#pragma once
+#include "hd.h"
+
+namespace kyb {
+namespace tvm {
+
+constexpr int WAVES = 12;
+constexpr int LANES = 64;
+constexpr int THREADS = WAVES * LANES;
+constexpr int REC_WORDS = 64;  // one (instruction, wave) record: header + up to 31 two-word terms
+
+// header word
+//   0-5 out slot | 6-11 n terms | 12 barrier before the store (an input slot of some wave is overwritten) |
+//   13 raw: no products, no Montgomery reduction -- the linear terms are normalised as they are |
+//   14-18 post scale (0 = 1) | 19-20 store mask (0 none, 1 lanes live in pair A, 2 pair B) | 21-24 opcode
+enum Op : uint32_t { OP_DOT = 0, OP_IDLE = 1, OP_GLOAD = 2, OP_INV = 3, OP_GT_STORE = 4, OP_IS_ONE = 5, OP_CLOAD = 6, OP_SPILL = 7, OP_FILL = 8 };
+//   GLOAD: slot <- input[word 1] of this pairing (packed words of the per-lane field code, taken as an integer)
+//   CLOAD: slot <- constant[word 1];  INV: slot <- Inv(slot[word 1]);  SPILL / FILL: slot <-> global scratch (word 1, wave)
+//   GT_STORE: canonical big-endian bytes of the slot at byte offset (word 1 & 0xffff) of the pairing's output
+//   IS_ONE: record slot != (word 1 >> 16) in the workgroup's result flags
+// term words
+//   w0: 0-5 x1 | 6-11 x2 | 12-17 y1 | 18-23 y2 | 24-25 kind (0 product, 1 linear: x only, 2 product with y = CONST[y1 + 64 y2])
+//   w1: int8 cx1 | cx2 | cy1 | cy2          operand = c1 S[s1] + c2 S[s2]  (c2 = 0: one slot)
+enum Kind : uint32_t { K_PROD = 0, K_LIN = 1, K_PROD_CONST = 2 };
+
+struct Sched {
+    uint32_t start, len, repeat, pad;
+};
+
+// Arguments of one launch.
+struct Args {
+    const uint32_t* prog;    // [instructions][WAVES][REC_WORDS]
+    const Sched* sched;      // blocks of instructions and their repeat counts, executed in order
+    uint32_t nsched;
+    const int32_t* consts;   // [index][16] balanced limbs (Montgomery form unless the program says otherwise)
+    const uint32_t* in;      // inputs: [input index][pairing][WORDS_IN] packed Montgomery words of the per-lane field code
+    const uint8_t* flags;    // per pairing: bit 0 pair A dead (an operand at infinity), bit 1 pair B dead, bit 7 rejected
+    uint8_t* out;            // GT bytes or result booleans
+    size_t n;                // pairings
+    uint32_t out_stride;     // bytes per pairing in `out`
+    uint32_t check;          // 1: the program ends in IS_ONE and `out` takes one boolean per pairing
+    uint32_t* gspill;        // global scratch: [workgroup][global slot][wave][slot image]
+    uint32_t ngslots;
+};
+
+template <class F>
+struct Lds {
+    static constexpr int N = F::N;
+    static constexpr int NQ = N / 4, TW = N - 4 * NQ;  // 16-byte quads + a tail of 0 or 2 words
+    static_assert(TW == 0 || TW == 2, "limb count must be 0 or 2 mod 4");
+    static constexpr int SLOT_WORDS = N * LANES;
+    __device__ static void load(int32_t (&v)[N], const uint32_t* lds, uint32_t slot, int lane) {
+        const uint32_t* b = lds + slot * SLOT_WORDS;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int4 t = *reinterpret_cast<const int4*>(b + (q * LANES + lane) * 4);
+            v[4 * q] = t.x;
+            v[4 * q + 1] = t.y;
+            v[4 * q + 2] = t.z;
+            v[4 * q + 3] = t.w;
+        }
+        if constexpr (TW == 2) {
+            const int2 t = *reinterpret_cast<const int2*>(b + NQ * LANES * 4 + lane * 2);
+            v[4 * NQ] = t.x;
+            v[4 * NQ + 1] = t.y;
+        }
+    }
+    __device__ static void store(uint32_t* lds, uint32_t slot, int lane, const int32_t (&v)[N]) {
+        uint32_t* b = lds + slot * SLOT_WORDS;
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+            *reinterpret_cast<int4*>(b + (q * LANES + lane) * 4) = make_int4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        if constexpr (TW == 2) *reinterpret_cast<int2*>(b + NQ * LANES * 4 + lane * 2) = make_int2(v[4 * NQ], v[4 * NQ + 1]);
+    }
+};
+
+KYB_HD int32_t sext28(uint32_t x) { return (int32_t)(x << 4) >> 4; }
+
+// v = c1 S[s1] + c2 S[s2]; the coefficients are wave-uniform, so the branches are scalar
+template <class F>
+__device__ __forceinline__ void operand(int32_t (&v)[F::N], const uint32_t* lds, uint32_t s1, int c1, uint32_t s2, int c2,
+                                        int lane) {
+    constexpr int N = F::N;
+    Lds<F>::load(v, lds, s1, lane);
+    if (c2 == 0) {
+        if (c1 != 1) {
+#pragma unroll
+            for (int i = 0; i < N; i++) v[i] *= c1;
+        }
+        return;
+    }
+    int32_t b[N];
+    Lds<F>::load(b, lds, s2, lane);
+    if (c1 == 1 && c2 == 1) {
+#pragma unroll
+        for (int i = 0; i < N; i++) v[i] += b[i];
+    } else if (c1 == 1 && c2 == -1) {
+#pragma unroll
+        for (int i = 0; i < N; i++) v[i] -= b[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; i++) v[i] = v[i] * c1 + b[i] * c2;
+    }
+}
+
+// Columns t[N .. 2N-1] (after the reduction) or any N columns -> balanced 28-bit limbs.  The top limb absorbs the last
+// carry (the generator bounds the value so that it fits).
+template <int N>
+__device__ __forceinline__ void normalise(int32_t (&r)[N], const int64_t* t) {
+    int64_t carry = 0;
+#pragma unroll
+    for (int c = 0; c < N - 1; c++) {
+        const int64_t v = t[c] + carry;
+        carry = (v + (int64_t(1) << 27)) >> 28;
+        r[c] = sext28((uint32_t)v);
+    }
+    r[N - 1] = (int32_t)(t[N - 1] + carry);
+}
+
+// t[0 .. 2N-2] (+ a spare t[2N-1] = 0): signed 64-bit columns of a double-width value T, |T| < R p * 2^8.  Leaves
+// T R^-1 mod p (|.| < |T| / R + p/2 + small) in t[N .. 2N-1].
+template <class F>
+__device__ __forceinline__ void mont_reduce(int64_t (&t)[2 * F::N]) {
+    constexpr int N = F::N;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int32_t m = sext28((uint32_t)t[i] * F::NINV);
+#pragma unroll
+        for (int j = 0; j < N; j++) t[i + j] += (int64_t)m * F::P[j];
+        t[i + 1] += t[i] >> 28;  // exact: the low 28 bits are zero
+    }
+}
+
+// Non-negative canonical words of a bounded balanced value: v + 4p in (0, 8p) -> [0, p) by three conditional
+// subtractions.  Requires |v| < 4p.  NW 32-bit words (value < 2^(32 NW)).
+template <class F>
+__device__ void canon_words(uint32_t (&w)[F::NW], const int32_t (&l)[F::N]) {
+    constexpr int N = F::N, NW = F::NW;
+    // unsigned 28-bit digits of v + 4p
+    uint32_t d[N + 1];
+    int64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const int64_t x = (int64_t)l[i] + (int64_t)F::P4[i] + carry;
+        d[i] = (uint32_t)x & 0x0fffffffu;
+        carry = x >> 28;
+    }
+    d[N] = (uint32_t)carry;  // zero for values in range (28 N bits hold 8p)
+    // pack to words
+    uint32_t x[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        const int bit = 32 * k, j = bit / 28, o = bit - 28 * j;
+        uint32_t v = d[j] >> o;
+        if (j + 1 <= N) v |= d[j + 1] << (28 - o);
+        if (56 - o < 32 && j + 2 <= N) v |= d[j + 2] << (56 - o);
+        x[k] = v;
+    }
+    // conditional subtractions of 4p, 2p, p
+#pragma unroll
+    for (int s = 2; s >= 0; s--) {
+        uint32_t y[NW];
+        uint32_t borrow = 0;
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            const uint32_t pk = s == 2 ? F::PW4[k] : (s == 1 ? F::PW2[k] : F::PW[k]);
+            const uint64_t z = (uint64_t)x[k] - pk - borrow;
+            y[k] = (uint32_t)z;
+            borrow = (uint32_t)(z >> 63);
+        }
+        const uint32_t keep = 0u - borrow;  // all ones: x < k p, keep x
+#pragma unroll
+        for (int k = 0; k < NW; k++) x[k] = (x[k] & keep) | (y[k] & ~keep);
+    }
+#pragma unroll
+    for (int k = 0; k < NW; k++) w[k] = x[k];
+}
+
+// NW packed words (a value in [0, 2^(32 NW))) -> N unsigned 28-bit digits, normalised to balanced ones
+template <class F>
+__device__ void words_to_limbs(int32_t (&r)[F::N], const uint32_t (&w)[F::NW]) {
+    constexpr int N = F::N, NW = F::NW;
+    int64_t t[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        const int bit = 28 * j, idx = bit >> 5, sh = bit & 31;
+        uint32_t x = idx < NW ? (w[idx] >> sh) : 0u;
+        if (sh + 28 > 32 && idx + 1 < NW) x |= w[idx + 1] << (32 - sh);
+        t[j] = (int64_t)(x & 0x0fffffffu);
+    }
+    normalise<N>(r, t);
+}
+
+// The interpreter.  `Inv` supplies the base-field inversion on packed words (the per-lane field code's Kaliski inverse).
+// Workgroups are persistent: workgroup b takes the batches b, b + gridDim.x, ... of 64 pairings.
+template <class F, class Inv>
+__device__ void run(const Args& a, uint32_t* lds, uint32_t* misc) {
+    constexpr int N = F::N;
+    constexpr int SW = Lds<F>::SLOT_WORDS;
+    const int lane = threadIdx.x & (LANES - 1);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t* gs = a.gspill + (size_t)blockIdx.x * a.ngslots * WAVES * SW;
+    for (size_t batch = blockIdx.x; batch * LANES < a.n; batch += gridDim.x) {
+        const size_t pairing = batch * LANES + lane;
+        const bool valid = pairing < a.n;
+        const size_t pidx = valid ? pairing : a.n - 1;  // out-of-range lanes recompute the last pairing, store nothing
+        const uint32_t fl = a.flags ? a.flags[pidx] : 0u;
+        if (wave == 0) misc[lane] = 0;
+        __syncthreads();
+        for (uint32_t e = 0; e < a.nsched; e++) {
+            const Sched sc = a.sched[e];
+#pragma unroll 1
+            for (uint32_t rep = 0; rep < sc.repeat; rep++) {
+#pragma unroll 1
+                for (uint32_t ins = sc.start; ins < sc.start + sc.len; ins++) {
+                    const uint32_t recw = a.prog[((size_t)ins * WAVES + wave) * REC_WORDS + lane];
+                    const uint32_t hdr = __builtin_amdgcn_readlane(recw, 0);
+                    const uint32_t arg = __builtin_amdgcn_readlane(recw, 1);
+                    const uint32_t out_slot = hdr & 63u, nterm = (hdr >> 6) & 63u, op = (hdr >> 21) & 15u;
+                    int32_t r[N];
+                    bool have = false;
+                    if (op == OP_DOT) {
+                        int64_t t[2 * N];
+#pragma unroll
+                        for (int i = 0; i < 2 * N; i++) t[i] = 0;
+#pragma unroll 1
+                        for (uint32_t k = 0; k < nterm; k++) {
+                            const uint32_t w0 = __builtin_amdgcn_readlane(recw, 1 + 2 * k);
+                            const uint32_t w1 = __builtin_amdgcn_readlane(recw, 2 + 2 * k);
+                            const uint32_t kind = (w0 >> 24) & 3u;
+                            const int cx1 = (int8_t)(w1 & 0xff), cx2 = (int8_t)((w1 >> 8) & 0xff);
+                            int32_t x[N];
+                            operand<F>(x, lds, w0 & 63u, cx1, (w0 >> 6) & 63u, cx2, lane);
+                            if (kind == K_LIN) {
+#pragma unroll
+                                for (int i = 0; i < N; i++) t[N + i] += (int64_t)x[i];
+                            } else if (kind == K_PROD) {
+                                const int cy1 = (int8_t)((w1 >> 16) & 0xff), cy2 = (int8_t)(w1 >> 24);
+                                int32_t y[N];
+                                operand<F>(y, lds, (w0 >> 12) & 63u, cy1, (w0 >> 18) & 63u, cy2, lane);
+#pragma unroll
+                                for (int i = 0; i < N; i++)
+#pragma unroll
+                                    for (int j = 0; j < N; j++) t[i + j] += (int64_t)x[i] * y[j];
+                            } else {  // constant y: wave-uniform limbs
+                                const int32_t* c = a.consts + 16 * ((w0 >> 12) & 0xfffu);
+#pragma unroll
+                                for (int i = 0; i < N; i++)
+#pragma unroll
+                                    for (int j = 0; j < N; j++) t[i + j] += (int64_t)x[i] * c[j];
+                            }
+                        }
+                        if (!((hdr >> 13) & 1u)) mont_reduce<F>(t);
+                        normalise<N>(r, t + N);
+                        const int scale = (hdr >> 14) & 31u;
+                        if (scale > 1) {  // small factor (<= 15) on the normalised limbs, normalised again
+#pragma unroll
+                            for (int i = 0; i < N; i++) t[i] = (int64_t)r[i] * scale;
+                            normalise<N>(r, t);
+                        }
+                        const uint32_t mask = (hdr >> 19) & 3u;
+                        if (mask) {  // lanes whose pair is dead keep the old value of the output slot
+                            int32_t old[N];
+                            Lds<F>::load(old, lds, out_slot, lane);
+                            const bool dead = (fl >> (mask - 1)) & 1u;
+#pragma unroll
+                            for (int i = 0; i < N; i++) r[i] = dead ? old[i] : r[i];
+                        }
+                        have = true;
+                    } else if (op == OP_GLOAD) {
+                        const uint32_t* src = a.in + ((size_t)arg * a.n + pidx) * F::NW;
+                        uint32_t w[F::NW];
+#pragma unroll
+                        for (int k = 0; k < F::NW; k++) w[k] = src[k];
+                        words_to_limbs<F>(r, w);
+                        have = true;
+                    } else if (op == OP_CLOAD) {
+                        const int32_t* c = a.consts + 16 * arg;
+#pragma unroll
+                        for (int i = 0; i < N; i++) r[i] = c[i];
+                        have = true;
+                    } else if (op == OP_INV) {
+                        int32_t v[N];
+                        Lds<F>::load(v, lds, arg & 63u, lane);
+                        uint32_t w[F::NW];
+                        canon_words<F>(w, v);
+                        Inv::inv(w);
+                        words_to_limbs<F>(r, w);
+                        have = true;
+                    } else if (op == OP_SPILL || op == OP_FILL) {
+                        // the slot image [quad][lane][4 words] goes to / comes from global scratch as it is: 16 bytes per
+                        // lane, consecutive lanes consecutive
+                        uint32_t* g = gs + ((size_t)arg * WAVES + wave) * SW;
+                        if (op == OP_SPILL) {
+                            int32_t v[N];
+                            Lds<F>::load(v, lds, out_slot, lane);
+                            Lds<F>::store(g, 0, lane, v);
+                        } else {
+                            Lds<F>::load(r, g, 0, lane);
+                            have = true;
+                        }
+                    } else if (op == OP_GT_STORE || op == OP_IS_ONE) {
+                        // the slot holds the PLAIN coefficient (the program multiplied by the constant 1): canonical form
+                        int32_t v[N];
+                        Lds<F>::load(v, lds, out_slot, lane);
+                        uint32_t w[F::NW];
+                        canon_words<F>(w, v);
+                        if (op == OP_GT_STORE) {
+                            const bool one = (fl & 3u) != 0;  // an operand at infinity: e = 1
+                            const bool rejected = fl >> 7;
+                            if (valid) {
+                                uint32_t* q = reinterpret_cast<uint32_t*>(a.out + pairing * a.out_stride + (arg & 0xffffu));
+                                const uint32_t is_c0 = arg >> 16;  // this coefficient is the 1 of the identity
+#pragma unroll
+                                for (int k = 0; k < F::NW; k++) {
+                                    uint32_t x = w[F::NW - 1 - k];
+                                    if (one) x = (is_c0 && k == F::NW - 1) ? 1u : 0u;
+                                    if (rejected) x = 0;
+                                    q[k] = __builtin_bswap32(x);
+                                }
+                            }
+                        } else {
+                            uint32_t diff = 0;
+#pragma unroll
+                            for (int k = 0; k < F::NW; k++) diff |= w[k] ^ (((arg >> 16) && k == 0) ? 1u : 0u);
+                            if (diff) atomicOr(&misc[lane], 1u);
+                        }
+                    }
+                    if ((hdr >> 12) & 1u) __syncthreads();
+                    if (have) Lds<F>::store(lds, out_slot, lane, r);
+                    __syncthreads();
+                }
+            }
+        }
+        if (a.check && wave == 0 && valid) a.out[pairing * a.out_stride] = (misc[lane] == 0 && !(fl >> 7)) ? 1 : 0;
+        __syncthreads();
+    }
+}
+
+}  // namespace tvm
+}  // namespace kyb

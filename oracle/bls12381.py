@@ -500,10 +500,47 @@ HARD_EXP = (P**4 - P**2 + 1) // R
 
 
 def final_exp(f):
-    """f^((p^12-1)/r): easy part by conjugate / inverse / Frobenius, hard part as one big power."""
+    """f^(3 (p^12-1)/r): easy part by conjugate / inverse / Frobenius, hard part as one big power.
+
+    The factor 3: the reference's default backend (github.com/kilic/bls12-381 v0.1.0, go.mod:8, not vendored) runs the
+    five-exponentiation chain of final_exp_kilic_chain() below, which is NOT the canonical exponent (p^4-p^2+1)/r but
+    three times it -- test_oracle_bls12381.py checks that the chain, restated from the published code, equals exactly
+    this cube (gnark-crypto documents the same cofactor 3 for its FinalExponentiation).  ValidatePairing is unaffected
+    (gcd(3, r) = 1); Suite.Pair's GT value is the cube of the canonical reduced pairing.  GT bytes remain unpinned by
+    the reference's own tests; round 1 of this repo used the canonical exponent."""
     f = f12_mul(f12_conj(f), f12_inv(f))  # ^(p^6 - 1)
     f = f12_mul(f12_frob(f, 2), f)  # ^(p^2 + 1)
-    return f12_pow(f, HARD_EXP)
+    return f12_pow(f, 3 * HARD_EXP)
+
+
+def final_exp_kilic_chain(f):
+    """kilic/bls12-381 pairing.go finalExp as published (exp(a) = conj(cyclotomicExp(a, |x|)); frobeniusMap(., 6) is the
+    conjugation), restated step by step.  Equals final_exp(f); kept separate as the evidence for its exponent."""
+    def exp(a):
+        return f12_conj(f12_pow(a, X_ABS))
+
+    t = [None] * 7
+    t[0] = f12_conj(f)
+    t[1] = f12_inv(f)
+    t[2] = f12_mul(t[0], t[1])
+    t[1] = t[2]
+    t[2] = f12_mul(f12_frob(t[2], 2), t[1])
+    t[1] = f12_conj(f12_sqr(t[2]))
+    t[3] = exp(t[2])
+    t[4] = f12_sqr(t[3])
+    t[5] = f12_mul(t[1], t[3])
+    t[1] = exp(t[5])
+    t[0] = exp(t[1])
+    t[6] = exp(t[0])
+    t[6] = f12_mul(t[6], t[4])
+    t[4] = exp(t[6])
+    t[5] = f12_conj(t[5])
+    t[4] = f12_mul(f12_mul(t[4], t[5]), t[2])
+    t[5] = f12_conj(t[2])
+    t[1] = f12_frob(f12_mul(t[1], t[2]), 3)
+    t[6] = f12_frob(f12_mul(t[6], t[5]), 1)
+    t[3] = f12_frob(f12_mul(t[3], t[0]), 2)
+    return f12_mul(f12_mul(f12_mul(t[3], t[1]), t[6]), t[4])
 
 
 def pair(p, q):

@@ -88,3 +88,17 @@ def test_pair_check_truth_table():
     assert not O.pair_check(H, X, O.g1_add(sig, O.G1_GEN), O.G2_GEN)
     assert O.pair_check(None, X, None, O.G2_GEN)
     assert len(O.gt_to_bytes(O.pair(H, X))) == 576
+
+
+def test_final_exponent_is_the_kilic_chain():
+    """The oracle's final exponent 3 (p^12 - 1)/r is what the reference's kilic backend computes: its five-exponentiation
+    chain (restated in final_exp_kilic_chain) gives exactly that power, and its cube root, the canonical reduced
+    pairing, differs.  Pairing-check semantics do not depend on the factor."""
+    p, q = O.g1_mul(0x1234567, O.G1_GEN), O.g2_mul(0x89ABCDE, O.G2_GEN)
+    f = O.miller_loop(p, q)
+    e = O.final_exp(f)
+    assert O.final_exp_kilic_chain(f) == e
+    easy = O.f12_mul(O.f12_frob(O.f12_mul(O.f12_conj(f), O.f12_inv(f)), 2), O.f12_mul(O.f12_conj(f), O.f12_inv(f)))
+    canon = O.f12_pow(easy, O.HARD_EXP)
+    assert canon != e and O.f12_mul(O.f12_sqr(canon), canon) == e
+    assert O.f12_pow(e, O.R) == O.F12_ONE and e != O.F12_ONE
