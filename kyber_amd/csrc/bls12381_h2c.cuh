@@ -346,6 +346,53 @@ KYB_HD int verify_g2_wire(uint8_t* ok, const uint8_t* pk48, const uint8_t* msg, 
     *ok = fp12_is_one(f) ? 1 : 0;
     return ST_OK;
 }
+// The operand side of a whole sign/bls Verify for the batch engine: unmarshal key and signature with the adapter's
+// checks, hash the message, and hand the two pairs of the product check
+//   signatures on G1:  e(H(m), X) e(-sig, G2.Base()) == 1        signatures on G2:  e(G1.Base(), sig) e(-X, H(m)) == 1
+// to the cooperative tower machine (bls12381_pair.hip CHECK program) as affine points.  Returns the status; on
+// rejection the points are left at infinity.
+KYB_HD int verify_g1_operands(g1_aff& a1, g2_aff& a2, g1_aff& b1, g2_aff& b2, const uint8_t* pk96, const uint8_t* msg,
+                              size_t msg_len, const DstArg& dst, const uint8_t* sig48, uint32_t flags) {
+    int st = g2_decode_f(a2, pk96, flags, 0);
+    const int st2 = g1_decode_f(b1, sig48, flags, 1);
+    if (st == ST_OK) st = st2;
+    fp_zero(a1.x);
+    fp_zero(a1.y);
+    a1.inf = true;
+    fp2_zero(b2.x);
+    fp2_zero(b2.y);
+    b2.inf = true;
+    if (st != ST_OK) return st;
+    g1_jac hj;
+    hash_g1_point(hj, msg, msg_len, dst);
+    jac_to_aff(a1, hj);
+    fp2_load_const<TC>(b2.x, CC::G2X);
+    fp2_load_const<TC>(b2.y, CC::G2Y);
+    b2.inf = false;
+    fp_neg(b1.y, b1.y);
+    return ST_OK;
+}
+KYB_HD int verify_g2_operands(g1_aff& a1, g2_aff& a2, g1_aff& b1, g2_aff& b2, const uint8_t* pk48, const uint8_t* msg,
+                              size_t msg_len, const DstArg& dst, const uint8_t* sig96, uint32_t flags) {
+    int st = g1_decode_f(b1, pk48, flags, 0);
+    const int st2 = g2_decode_f(a2, sig96, flags, 1);
+    if (st == ST_OK) st = st2;
+    fp_zero(a1.x);
+    fp_zero(a1.y);
+    a1.inf = true;
+    fp2_zero(b2.x);
+    fp2_zero(b2.y);
+    b2.inf = true;
+    if (st != ST_OK) return st;
+    g2_jac hj;
+    hash_g2_point(hj, msg, msg_len, dst);
+    jac_to_aff(b2, hj);
+    fp_const(a1.x, CC::G1X);
+    fp_const(a1.y, CC::G1Y);
+    a1.inf = false;
+    fp_neg(b1.y, b1.y);
+    return ST_OK;
+}
 KYB_HD int hash_g2_wire(uint8_t* out, const uint8_t* msg, size_t msg_len, const DstArg& dst) {
     g2_jac r;
     hash_g2_point(r, msg, msg_len, dst);

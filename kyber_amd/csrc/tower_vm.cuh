@@ -30,6 +30,7 @@ constexpr int WAVES = 12;
 constexpr int LANES = 64;
 constexpr int THREADS = WAVES * LANES;
 constexpr int REC_WORDS = 64;  // one (instruction, wave) record: header + up to 31 two-word terms
+constexpr int MAX_CONSTS = 32;
 
 // header word
 //   0-5 out slot | 6-11 n terms | 12 barrier before the store (an input slot of some wave is overwritten) |
@@ -54,7 +55,9 @@ struct Args {
     const uint32_t* prog;    // [instructions][WAVES][REC_WORDS]
     const Sched* sched;      // blocks of instructions and their repeat counts, executed in order
     uint32_t nsched;
-    const int32_t* consts;   // [index][16] balanced limbs (Montgomery form unless the program says otherwise)
+    const int32_t* consts;   // [index][16] balanced limbs (Montgomery form unless the program says otherwise); the kernel
+                             // copies them into LDS (MAX_CONSTS)
+    uint32_t nconsts;
     const uint32_t* in;      // inputs: [input index][pairing][WORDS_IN] packed Montgomery words of the per-lane field code
     const uint8_t* flags;    // per pairing: bit 0 pair A dead (an operand at infinity), bit 1 pair B dead, bit 7 rejected
     uint8_t* out;            // GT bytes or result booleans
@@ -216,7 +219,7 @@ __device__ void words_to_limbs(int32_t (&r)[F::N], const uint32_t (&w)[F::NW]) {
 // The interpreter.  `Inv` supplies the base-field inversion on packed words (the per-lane field code's Kaliski inverse).
 // Workgroups are persistent: workgroup b takes the batches b, b + gridDim.x, ... of 64 pairings.
 template <class F, class Inv>
-__device__ void run(const Args& a, uint32_t* lds, uint32_t* misc) {
+__device__ void run(const Args& a, uint32_t* lds, uint32_t* misc, const int32_t* clds) {
     constexpr int N = F::N;
     constexpr int SW = Lds<F>::SLOT_WORDS;
     const int lane = threadIdx.x & (LANES - 1);
@@ -229,13 +232,31 @@ __device__ void run(const Args& a, uint32_t* lds, uint32_t* misc) {
         const uint32_t fl = a.flags ? a.flags[pidx] : 0u;
         if (wave == 0) misc[lane] = 0;
         __syncthreads();
-        for (uint32_t e = 0; e < a.nsched; e++) {
-            const Sched sc = a.sched[e];
-#pragma unroll 1
-            for (uint32_t rep = 0; rep < sc.repeat; rep++) {
-#pragma unroll 1
-                for (uint32_t ins = sc.start; ins < sc.start + sc.len; ins++) {
-                    const uint32_t recw = a.prog[((size_t)ins * WAVES + wave) * REC_WORDS + lane];
+        // The schedule is walked one instruction AHEAD: the record of the next instruction is requested before the
+        // current one executes, so its L2 latency (all twelve waves would otherwise sit on it after every barrier)
+        // hides behind a few thousand multiply-adds.
+        uint32_t e = 0, rep = 0;
+        Sched sc = a.sched[0];
+        uint32_t ins = sc.start;
+        bool more = a.nsched > 0;
+        uint32_t recw = a.prog[((size_t)ins * WAVES + wave) * REC_WORDS + lane];
+        while (more) {
+            uint32_t e2 = e, rep2 = rep, ins2 = ins + 1;
+            Sched sc2 = sc;
+            if (ins2 == sc.start + sc.len) {
+                ins2 = sc.start;
+                if (++rep2 == sc.repeat) {
+                    rep2 = 0;
+                    if (++e2 < a.nsched) {
+                        sc2 = a.sched[e2];
+                        ins2 = sc2.start;
+                    }
+                }
+            }
+            const bool more2 = e2 < a.nsched;
+            const uint32_t rec_next = more2 ? a.prog[((size_t)ins2 * WAVES + wave) * REC_WORDS + lane] : 0u;
+            {
+                {
                     const uint32_t hdr = __builtin_amdgcn_readlane(recw, 0);
                     const uint32_t arg = __builtin_amdgcn_readlane(recw, 1);
                     const uint32_t out_slot = hdr & 63u, nterm = (hdr >> 6) & 63u, op = (hdr >> 21) & 15u;
@@ -265,7 +286,7 @@ __device__ void run(const Args& a, uint32_t* lds, uint32_t* misc) {
 #pragma unroll
                                     for (int j = 0; j < N; j++) t[i + j] += (int64_t)x[i] * y[j];
                             } else {  // constant y: wave-uniform limbs
-                                const int32_t* c = a.consts + 16 * ((w0 >> 12) & 0xfffu);
+                                const int32_t* c = clds + 16 * ((w0 >> 12) & 0xfffu);
 #pragma unroll
                                 for (int i = 0; i < N; i++)
 #pragma unroll
@@ -297,7 +318,7 @@ __device__ void run(const Args& a, uint32_t* lds, uint32_t* misc) {
                         words_to_limbs<F>(r, w);
                         have = true;
                     } else if (op == OP_CLOAD) {
-                        const int32_t* c = a.consts + 16 * arg;
+                        const int32_t* c = clds + 16 * arg;
 #pragma unroll
                         for (int i = 0; i < N; i++) r[i] = c[i];
                         have = true;
@@ -353,6 +374,12 @@ __device__ void run(const Args& a, uint32_t* lds, uint32_t* misc) {
                     __syncthreads();
                 }
             }
+            e = e2;
+            rep = rep2;
+            ins = ins2;
+            sc = sc2;
+            recw = rec_next;
+            more = more2;
         }
         if (a.check && wave == 0 && valid) a.out[pairing * a.out_stride] = (misc[lane] == 0 && !(fl >> 7)) ? 1 : 0;
         __syncthreads();

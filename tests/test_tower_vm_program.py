@@ -1,0 +1,102 @@
+"""The generated programs of the cooperative tower machine (kyber_amd/csrc/gen_tower_vm.py -> tower_vm.cuh) replayed on
+the CPU against the oracle: the exact meaning of every instruction on residues mod p, the device's own arithmetic
+(balanced 28-bit limbs, 64-bit columns, signed Montgomery reduction) with overflow assertions, and the worst-case
+bounds for ANY input.  The GPU tests then only have to show that the kernel executes these instructions."""
+import os
+import random
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kyber_amd", "csrc"))
+import gen_tower_vm as G  # noqa: E402
+
+from oracle import bls12381 as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def pair_prog():
+    return G.build_bls12381_pair()
+
+
+@pytest.fixture(scope="module")
+def check_prog():
+    return G.build_bls12381_check()
+
+
+def _inputs(f, p, q):
+    vals = [p[0], p[1], q[0][0], q[0][1], q[1][0], q[1][1]]
+    return [v * f.R1 % f.p for v in vals]  # what the per-lane decode leaves: Montgomery residues, radix 2^390
+
+
+def _gt_bytes(res):
+    out = bytearray(576)
+    for off, (v, _) in res["gt"].items():
+        out[off:off + 48] = v.to_bytes(48, "big")
+    return bytes(out)
+
+
+def test_pair_program_equals_the_oracle_pairing(pair_prog):
+    rng = random.Random(11)
+    f = pair_prog.f
+    for k in range(4):
+        a, b = (1, 1) if k == 0 else (rng.randrange(1, O.R), rng.randrange(1, O.R))
+        p, q = O.g1_mul(a, O.G1_GEN), O.g2_mul(b, O.G2_GEN)
+        _, res = pair_prog.simulate(_inputs(f, p, q))
+        assert _gt_bytes(res) == O.gt_to_bytes(O.pair(p, q)), k
+        assert len(res["gt"]) == 12 and sum(c0 for _, c0 in res["gt"].values()) == 1
+
+
+def test_pair_program_in_device_arithmetic(pair_prog):
+    """limb for limb what the kernel does; asserts no column / limb / top-limb overflow on the way"""
+    f = pair_prog.f
+    p, q = O.g1_mul(0xC0FFEE, O.G1_GEN), O.g2_mul(0xBADC0DE, O.G2_GEN)
+    _, res = pair_prog.simulate_limbs(_inputs(f, p, q))
+    assert _gt_bytes(res) == O.gt_to_bytes(O.pair(p, q))
+    # extreme residues (p - 1 everywhere): garbage in, but nothing may overflow
+    pair_prog.simulate_limbs([f.p - 1] * 6)
+
+
+def test_check_program_truth_table(check_prog):
+    f = check_prog.f
+    p1, q1 = O.g1_mul(5, O.G1_GEN), O.g2_mul(7, O.G2_GEN)
+
+    def run(p2, q2, flags=0, pair_a=True):
+        ins = (_inputs(f, p1, q1) if pair_a else [0] * 6) + (_inputs(f, O.g1_neg(p2), q2) if p2 else [0] * 6)
+        return not check_prog.simulate(ins, flags)[1]["not_one"]
+
+    assert run(O.g1_mul(35, O.G1_GEN), O.G2_GEN)            # e(5P, 7Q) == e(35P, Q)
+    assert not run(O.g1_mul(36, O.G1_GEN), O.G2_GEN)
+    assert run(O.g1_mul(7, O.G1_GEN), O.g2_mul(5, O.G2_GEN))
+    assert not run(None, None, flags=2)                       # pair B at infinity: e(5P, 7Q) == 1 is false
+    assert run(None, None, flags=3, pair_a=False)             # both at infinity: 1 == 1
+    _, res = check_prog.simulate_limbs(_inputs(f, p1, q1) + _inputs(f, O.g1_neg(O.g1_mul(35, O.G1_GEN)), O.G2_GEN))
+    assert not res["not_one"]
+
+
+def test_worst_case_bounds(pair_prog, check_prog):
+    """for ANY residues: operand limbs < 2^31, accumulator columns < 2^63, |value| < 1024 p, canonicaliser inputs < 4p"""
+    for prog in (pair_prog, check_prog):
+        col, val = prog.check_bounds()
+        assert col < 63 and val < 1024
+        st = prog.stats()
+        assert st["executed"] < 1000
+
+
+def test_encoding_round_trip(pair_prog):
+    """the emitted words decode back to the instruction stream (header fields, term operands, schedule lengths)"""
+    words, sched = pair_prog.encode()
+    assert len(words) % (G.WAVES * G.REC_WORDS) == 0
+    assert sum(ln * rep for _, ln, rep in sched) == pair_prog.stats()["executed"]
+    nins = len(words) // (G.WAVES * G.REC_WORDS)
+    for start, ln, rep in sched:
+        assert 0 <= start and start + ln <= nins and rep >= 1
+    for i in range(0, len(words), G.REC_WORDS):
+        hdr = words[i]
+        op, nterm = (hdr >> 21) & 15, (hdr >> 6) & 63
+        assert op <= G.OP_FILL and nterm <= 31
+        if op == G.OP_DOT:
+            for k in range(nterm):
+                w0 = words[i + 1 + 2 * k]
+                assert (w0 >> 24) & 3 in (G.K_PROD, G.K_LIN, G.K_PROD_CONST)
+                assert (w0 & 63) < pair_prog.nslots
