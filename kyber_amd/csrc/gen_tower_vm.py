@@ -26,7 +26,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 WAVES = 12
 W = 28
 REC_WORDS = 64
-OP_DOT, OP_IDLE, OP_GLOAD, OP_INV, OP_GT_STORE, OP_IS_ONE, OP_CLOAD, OP_SPILL, OP_FILL = range(9)
+OP_DOT, OP_IDLE, OP_GLOAD, OP_INV, OP_GT_STORE, OP_IS_ONE, OP_CLOAD, OP_SPILL, OP_FILL, OP_CMP_EQ = range(10)
 K_PROD, K_LIN, K_PROD_CONST = 0, 1, 2
 
 
@@ -233,11 +233,11 @@ class Prog:
         reads = [self._reads(r) for r in recs]
         prebar = False
         for w, r in enumerate(recs):
-            if "dst" in r and r["op"] not in (OP_GT_STORE, OP_IS_ONE, OP_SPILL):
+            if "dst" in r and r["op"] not in (OP_GT_STORE, OP_IS_ONE, OP_SPILL, OP_CMP_EQ):
                 for v, rd in enumerate(reads):
                     if v != w and r["dst"] in rd:
                         prebar = True
-        dsts = [r["dst"] for r in recs if "dst" in r and r["op"] not in (OP_GT_STORE, OP_IS_ONE, OP_SPILL)]
+        dsts = [r["dst"] for r in recs if "dst" in r and r["op"] not in (OP_GT_STORE, OP_IS_ONE, OP_SPILL, OP_CMP_EQ)]
         assert len(dsts) == len(set(dsts)), "two waves write one slot: " + name
         for r in recs:
             r["prebar"] = prebar
@@ -290,6 +290,8 @@ class Prog:
             s.add(r["src"])
         elif r["op"] in (OP_GT_STORE, OP_IS_ONE, OP_SPILL):
             s.add(r["dst"])
+        elif r["op"] == OP_CMP_EQ:
+            s.update((r["dst"], r["arg"]))
         return s
 
     def dot(self, outs, name=""):
@@ -354,6 +356,9 @@ class Prog:
                             res["gt"][r["arg"] & 0xffff] = (S[r["dst"]], r["arg"] >> 16)
                         elif op == OP_IS_ONE:
                             if S[r["dst"]] != (1 if r["arg"] >> 16 else 0):
+                                res["not_one"] = True
+                        elif op == OP_CMP_EQ:
+                            if S[r["dst"]] != S[r["arg"]]:
                                 res["not_one"] = True
                     for k, v in new.items():
                         S[k] = v
@@ -449,6 +454,9 @@ class Prog:
                         elif op == OP_IS_ONE:
                             if canon(S[r["dst"]]) != (1 if r["arg"] >> 16 else 0):
                                 res["not_one"] = True
+                        elif op == OP_CMP_EQ:
+                            if canon(S[r["dst"]]) != canon(S[r["arg"]]):
+                                res["not_one"] = True
                     for k, v in new.items():
                         S[k] = v
         return S, res
@@ -468,10 +476,32 @@ class Prog:
         GB = {}
         worst_col, worst_val = 0.0, 0.0
 
+        top_unit = p / 2.0 ** (W * (N - 1))  # top limb of a value v is v >> 28(N-1): at most |v| / that + 1
+
         def opnd(lin):
             limb = sum(abs(c) for c in lin.d.values()) * lb
             assert limb < 2.0 ** 31, ("operand limbs", lin)
             return limb, sum(abs(c) * B[s] for s, c in lin.d.items())
+
+        def top(lin):
+            return sum(abs(c) * (B[s] * top_unit + 1) for s, c in lin.d.items())
+
+        def pair_coef(x, y):
+            """sum over slot pairs of the magnitude of the coefficient of S[a]_i S[b]_j in a column of x * y: operands
+            over the same slots combine -- (a + b)(a - b) has the antisymmetric cross terms cancel inside every
+            column, leaving 2, not 4 (intermediate 64-bit sums may wrap; only the completed column has to fit)"""
+            tot, seen = 0.0, set()
+            for a, ca in x.d.items():
+                for b, cb in y.d.items():
+                    if (a, b) in seen:
+                        continue
+                    if a != b and b in x.d and a in y.d:
+                        tot += abs(ca * cb + x.d[b] * y.d[a])  # a_i b_j and b_i a_j sum to the same column form
+                        seen.add((b, a))
+                    else:
+                        tot += abs(ca * cb)
+                    seen.add((a, b))
+            return tot
 
         for start, ln, rep in self.sched:
             for _ in range(rep):
@@ -489,9 +519,13 @@ class Prog:
                                 else:
                                     if t[0] == "p":
                                         ly, by = opnd(t[2])
+                                        # column N-2 has N-1 products of full limbs; column N-1 has N-2 of them and two
+                                        # products with a top limb (v >> 28(N-1), small): the larger of the two
+                                        full = pair_coef(t[1], t[2]) * lb * lb
+                                        col += max((N - 1) * full, (N - 2) * full + lx * top(t[2]) + top(t[1]) * ly)
                                     else:
                                         ly, by = lb, 1.0
-                                    col += N * lx * ly
+                                        col += N * lx * ly
                                     val_prod += bx * by
                             if not r["raw"]:
                                 col += N * lb * lb + 2.0 ** 36
@@ -517,6 +551,8 @@ class Prog:
                             new[r["dst"]] = GB[(r["arg"], w)]
                         elif op in (OP_GT_STORE, OP_IS_ONE):
                             assert B[r["dst"]] < 4, "canonicaliser input bound"
+                        elif op == OP_CMP_EQ:
+                            assert B[r["dst"]] < 4 and B[r["arg"]] < 4, "canonicaliser input bound"
                     for k, v in new.items():
                         B[k] = v
         return math.log2(worst_col), worst_val
@@ -649,10 +685,10 @@ class Tower:
             outs += outs2(dst + 2 * k, dst + 2 * k + 1, acc)
         self.P.dot(outs, name)
 
-    def mul_sparse(self, dst, a, l0, l2, l3, mask=0, name="mul_sparse"):
-        """a * (l0 + l2 w^2 + l3 w^3)"""
+    def mul_sparse(self, dst, a, ls, mask=0, name="mul_sparse"):
+        """a * sum_j ls[j] w^j for a line with three non-zero coefficients (M-type twist: w^0, w^2, w^3; D-type:
+        w^0, w^1, w^3)"""
         outs = []
-        ls = {0: l0, 2: l2, 3: l3}
         for k in range(6):
             acc = Acc2()
             for j, l in ls.items():
@@ -674,17 +710,18 @@ class Tower:
 
         def fp4(x, y):
             t0, t1 = Acc2(), Acc2()
-            # 3 t0 = 3 x^2 + 3 xi y^2
+            # 3 t0 = 3 x^2 + 3 xi y^2; the integer factors are split between the two operands of a product so that
+            # no operand limb exceeds 2^31 (xi0 = 3 for bn256)
             sx, dx = x.re + x.im, x.re - x.im
             t0.re.append(("p", sx.scale(3), dx))
             t0.im.append(("p", x.re.scale(6), x.im))
             sy, dy = y.re + y.im, y.re - y.im
-            t0.re.append(("p", sy.scale(3 * xi0), dy))
+            t0.re.append(("p", sy.scale(xi0), dy.scale(3)))
             t0.re.append(("p", y.re.scale(-6), y.im))
             t0.im.append(("p", sy.scale(3), dy))
-            t0.im.append(("p", y.re.scale(6 * xi0), y.im))
+            t0.im.append(("p", y.re.scale(6), y.im.scale(xi0)))
             # 3 t1 = 6 x y
-            t1.prod(x.scale(6), y)
+            t1.prod(x.scale(3), y.scale(2))
             return t0, t1
 
         # tower positions: c0 = (a0, a2, a4), c1 = (a1, a3, a5) in the w-basis
@@ -693,7 +730,7 @@ class Tower:
         t2, t3 = fp4(c10, c02)
         t4, t5 = fp4(c01, c12)
         # 3 xi t5: multiply the operands of t5's product by xi
-        t5x = Acc2().prod(c01.scale(6).mul_xi(xi0), c12)
+        t5x = Acc2().prod(c01.mul_xi(xi0).scale(2), c12.scale(3))
         res = {0: (t0, c00, -2), 3: (t1, c11, 2), 1: (t5x, c10, 2), 4: (t4, c02, -2), 2: (t2, c01, -2), 5: (t3, c12, 2)}
         outs = []
         one = (self.P.c_one, self.P.consts[self.P.c_one])
@@ -826,7 +863,7 @@ def bls_dbl_step(P, T, TX, TY, TZ, tmp, L, PX, PY, fset, mask):
     o += outs2(L[4], L[5], Acc2().prod_fp(YZ.scale(2), Lin.slot(PY)))                       # l3 = 2 Y Z yP
     P.dot(o, "dbl/b")
     f = Tower.reg(fset)
-    T.mul_sparse(fset, f, E2.slots(L[0], L[1]), E2.slots(L[2], L[3]), E2.slots(L[4], L[5]), mask=mask, name="dbl/line")
+    T.mul_sparse(fset, f, {0: E2.slots(L[0], L[1]), 2: E2.slots(L[2], L[3]), 3: E2.slots(L[4], L[5])}, mask=mask, name="dbl/line")
 
 
 def bls_add_step(P, T, TX, TY, TZ, Q, tmp, L, PX, PY, fset, mask):
@@ -858,12 +895,13 @@ def bls_add_step(P, T, TX, TY, TZ, Q, tmp, L, PX, PY, fset, mask):
     o += outs2(TZ[0], TZ[1], Acc2().prod(Z, Ee))                                                    # Z3 = Z E
     P.dot(o, "add/d")
     f = Tower.reg(fset)
-    T.mul_sparse(fset, f, E2.slots(L[0], L[1]), E2.slots(L[2], L[3]), E2.slots(L[4], L[5]), mask=mask, name="add/line")
+    T.mul_sparse(fset, f, {0: E2.slots(L[0], L[1]), 2: E2.slots(L[2], L[3]), 3: E2.slots(L[4], L[5])}, mask=mask, name="add/line")
 
 
-def bls_final_exp(P, T, f, gammas):
-    """F <- f^((p^12 - 1) / r) for the symbolic Fp12 value f held in register set F (possibly with signs).
-    Uses G, H, the spare slots and two global spill slots.  Returns the symbolic result (in F)."""
+def tower_easy_part(P, T, f, gamma2, F_, G_, H_, SPARE):
+    """F <- f^((p^6 - 1)(p^2 + 1)) for the symbolic Fp12 value f held in register set F (possibly with signs): the
+    inverse through the tower (one base-field inversion), conj(f) f^-1, then times its p^2-Frobenius.  Uses the
+    register sets G, H and six spare slots.  The result is in the cyclotomic subgroup."""
     xi0 = P.xi0
     FF = T.reg(F_)
     # ---- easy part: f^(p^6 - 1) = conj(f) / f
@@ -925,8 +963,16 @@ def bls_final_exp(P, T, f, gammas):
     P.dot(o, "inv/finv")
     GG, HH = T.reg(G_), T.reg(H_)
     T.mul12(F_, T.conj12(f), GG, "easy/conj_times_inv")                                     # g1 = conj(f) f^-1  (in F)
-    T.frob12(G_, FF, 2, gammas[2], "easy/frob2")
+    T.frob12(G_, FF, 2, gamma2, "easy/frob2")
     T.mul12(F_, GG, FF, "easy/mul")                                                         # g = g1^(p^2) g1: cyclotomic
+    return FF
+
+
+def bls_final_exp(P, T, f, gammas):
+    """F <- f^(3 (p^12 - 1) / r) for the symbolic Fp12 value f held in register set F (possibly with signs).
+    Uses G, H, the spare slots and four global spill slots.  Returns the symbolic result (in F)."""
+    FF = tower_easy_part(P, T, f, gammas[2], F_, G_, H_, SPARE)
+    GG, HH = T.reg(G_), T.reg(H_)
     # ---- hard part, exponent 3 (p^4 - p^2 + 1) / r: the five-exponentiation chain of the reference's kilic backend
     # (github.com/kilic/bls12-381 v0.1.0 finalExp, the zkcrypto chain; restated from memory and confirmed numerically to
     # be exactly the cube of the canonical reduced pairing -- tests/test_oracle_bls12381.py).  With g the easy-part
@@ -1078,6 +1124,241 @@ def build_bls12381_check():
     return P
 
 
+# ------------------------------------------------------------------------------------------------ bn256
+# pairing/bn256 (dclxvi parameters): p = 36u^4 + 36u^3 + 24u^2 + 6u + 1, xi = 3 + i, D-type twist y^2 = x^3 + 3/xi,
+# optimal ate loop over the NAF of 6u + 2 with the two Frobenius steps (optate.go:126-213) and the final
+# exponentiation's addition chain (optate.go:215-264) -- the GT bytes must equal the reference's, so the exponent is
+# exactly the chain's; the line functions are free (any Fp2 multiple of a line dies in the final exponentiation).
+BN_U = 6518589491078791937
+BN_NAF = [0, 0, 0, 1, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0, 0, 0, -1, 0, 1, 0,
+          1, 0, 0, 0, 0, 1, 0, 1, 0, 0, 0, -1, 0, 1, 0, 0, 0, 1, 0, -1,
+          0, 0, 0, -1, 0, 1, 0, 0, 0, 0, 0, 1, 0, 0, -1, 0, -1, 0, 0, 0,
+          0, 1, 0, 0, 0, 1]
+assert sum(d << i for i, d in enumerate(BN_NAF)) == 6 * BN_U + 2
+BN_NSLOTS = 63
+BN_A, BN_B, BN_C, BN_D, BN_E = 0, 12, 24, 36, 48   # five Fp12 register sets; slots 60..62 spare
+
+
+def bn256_field():
+    u = BN_U
+    p = 36 * u ** 4 + 36 * u ** 3 + 24 * u ** 2 + 6 * u + 1
+    return VmField("bn256", p, 10, 8, 261)
+
+
+def bn_dbl_step(P, T, TX, TY, TZ, tmp, L, PX, PY, fset, mask):
+    """T <- 2T on the D-type twist (b' = 3 / xi), f <- f * tangent(P).  With Bh = 10 Y^2 and Ep = 9 conj(xi) Z^2
+    (10 = norm(xi): Bh / 10 = Y^2, Ep / 10 = 3 b' Z^2) the point, scaled by 100, is
+      X3 = 10 [2 XY (Bh - 3 Ep)],  Y3 = Bh^2 + 3 Ep (2 Bh - Ep),  Z3 = 10 [8 Bh YZ]
+    and the tangent, scaled by 10:  l0 = 10 [2 YZ yP],  l1 = 10 [-3 X^2 xP],  l3 = Bh - Ep."""
+    xi0 = P.xi0
+    X, Y, Z = E2.slots(*TX), E2.slots(*TY), E2.slots(*TZ)
+    XY, Bh, Ep, YZ, A3 = (E2.slots(tmp[2 * i], tmp[2 * i + 1]) for i in range(5))
+    o = []
+    o += outs2(tmp[0], tmp[1], Acc2().prod(X, Y))
+    o += outs2(tmp[2], tmp[3], Acc2().sqr(Y), scale=xi0 * xi0 + 1)
+    zz = Acc2()  # conj(xi) Z^2 = (xi0 u + v) + (xi0 v - u) i with Z^2 = u + v i
+    s, d = Z.re + Z.im, Z.re - Z.im
+    zz.re += [("p", s.scale(xi0), d), ("p", Z.re.scale(2), Z.im)]
+    zz.im += [("p", Z.re.scale(2 * xi0), Z.im), ("p", -s, d)]
+    o += outs2(tmp[4], tmp[5], zz, scale=9)
+    o += outs2(tmp[6], tmp[7], Acc2().prod(Y, Z))
+    o += outs2(tmp[8], tmp[9], Acc2().sqr(X), scale=3)
+    P.dot(o, "dbl/a")
+    o = []
+    o += outs2(TX[0], TX[1], Acc2().prod(XY.scale(2), Bh - Ep.scale(3)), scale=10)
+    o += outs2(TY[0], TY[1], Acc2().sqr(Bh).prod(Ep.scale(3), Bh.scale(2) - Ep))
+    o += outs2(TZ[0], TZ[1], Acc2().prod(Bh.scale(8), YZ), scale=10)
+    o += outs2(L[0], L[1], Acc2().prod_fp(YZ.scale(2), Lin.slot(PY)), scale=10)      # l0
+    o += outs2(L[2], L[3], Acc2().prod_fp(-A3, Lin.slot(PX)), scale=10)             # l1
+    o += outs2(L[4], L[5], Acc2().lin(Bh - Ep), raw=True)                           # l3
+    P.dot(o, "dbl/b")
+    f = Tower.reg(fset)
+    T.mul_sparse(fset, f, {0: E2.slots(L[0], L[1]), 1: E2.slots(L[2], L[3]), 3: E2.slots(L[4], L[5])}, mask=mask, name="dbl/line")
+
+
+def bn_add_step(P, T, TX, TY, TZ, Q, sign, tmp, L, PX, PY, fset, mask):
+    """T <- T + sign Q (Q = four slots, affine; they are recycled), f <- f * chord(P), D-type line placement:
+    l0 = lambda yP, l1 = -theta xP, l3 = theta xQ - lambda yQ."""
+    X, Y, Z = E2.slots(*TX), E2.slots(*TY), E2.slots(*TZ)
+    xQ, yQ = E2.slots(Q[0], Q[1]), E2.slots(Q[2], Q[3]).scale(sign)
+    TH, LA = E2.slots(tmp[0], tmp[1]), E2.slots(tmp[2], tmp[3])
+    o = []
+    o += outs2(tmp[0], tmp[1], Acc2().lin(Y).prod(-yQ, Z))
+    o += outs2(tmp[2], tmp[3], Acc2().lin(X).prod(-xQ, Z))
+    P.dot(o, "add/a")
+    C, D = E2.slots(Q[0], Q[1]), E2.slots(Q[2], Q[3])
+    o = []
+    o += outs2(L[0], L[1], Acc2().prod_fp(LA, Lin.slot(PY)))
+    o += outs2(L[2], L[3], Acc2().prod_fp(-TH, Lin.slot(PX)))
+    o += outs2(L[4], L[5], Acc2().prod(TH, xQ).prod(-LA, yQ))
+    o += outs2(Q[0], Q[1], Acc2().sqr(TH))
+    o += outs2(Q[2], Q[3], Acc2().sqr(LA))
+    P.dot(o, "add/b")
+    Ee, Ff, Gg = C, D, E2.slots(tmp[4], tmp[5])
+    o = []
+    o += outs2(Q[0], Q[1], Acc2().prod(LA, D))
+    o += outs2(Q[2], Q[3], Acc2().prod(Z, C))
+    o += outs2(tmp[4], tmp[5], Acc2().prod(X, D))
+    P.dot(o, "add/c")
+    o = []
+    o += outs2(TX[0], TX[1], Acc2().prod(LA, Ee).prod(LA, Ff).prod(LA.scale(-2), Gg))
+    o += outs2(TY[0], TY[1], Acc2().prod(TH.scale(3), Gg).prod(-TH, Ee).prod(-TH, Ff).prod(-Ee, Y))
+    o += outs2(TZ[0], TZ[1], Acc2().prod(Z, Ee))
+    P.dot(o, "add/d")
+    f = Tower.reg(fset)
+    T.mul_sparse(fset, f, {0: E2.slots(L[0], L[1]), 1: E2.slots(L[2], L[3]), 3: E2.slots(L[4], L[5])}, mask=mask, name="add/line")
+
+
+def bn_miller(P, T, f, first_input, mask):
+    """F (set A) <- miller(Q, P) of optate.go:126-213 up to factors that the final exponentiation removes.
+    Inputs first_input .. +5: P.x, P.y, Q.x.re, Q.x.im, Q.y.re, Q.y.im."""
+    p = f.p
+    xi = (3, 1)
+    TX, TY, TZ = (12, 13), (14, 15), (16, 17)
+    tmp = list(range(18, 28))
+    L = list(range(28, 34))
+    PX, PY = 34, 35
+    Q = [36, 37, 38, 39]
+    QT = [40, 41, 42, 43]
+    bls_load_inputs(P, f, [PX, PY] + Q, first_input)
+    P.misc([dict(op=OP_CLOAD, dst=BN_A + i, arg=P.c_one if i == 0 else P.c_zero) for i in range(12)], "f=1")
+    P.misc([dict(op=OP_DOT, dst=d, terms=[("l", Lin.slot(q))], scale=1, mask=0, raw=True) for d, q in
+            ((TX[0], Q[0]), (TX[1], Q[1]), (TY[0], Q[2]), (TY[1], Q[3]))]
+           + [dict(op=OP_CLOAD, dst=TZ[0], arg=P.c_one), dict(op=OP_CLOAD, dst=TZ[1], arg=P.c_zero)], "T=Q")
+    FF = T.reg(BN_A)
+
+    def step():
+        T.sqr12(BN_A, FF, "miller/sqr")
+        bn_dbl_step(P, T, TX, TY, TZ, tmp, L, PX, PY, BN_A, mask)
+
+    def add(src, sign):
+        P.dot([Out(QT[i], [("l", Lin.slot(src[i]))], raw=True) for i in range(4)], "add/copyQ")
+        bn_add_step(P, T, TX, TY, TZ, QT, sign, tmp, L, PX, PY, BN_A, mask)
+
+    n = len(BN_NAF)
+    run = 0
+    for i in range(n - 1, 0, -1):
+        run += 1
+        d = BN_NAF[i - 1]
+        if d:
+            with P.repeat(run):
+                step()
+            run = 0
+            add(Q, d)
+    if run:
+        with P.repeat(run):
+            step()
+    # Q1 = pi(Q) = (conj(x) xi^((p-1)/3), conj(y) xi^((p-1)/2)),  -Q2 = -pi^2(Q) = (x xi^((p^2-1)/3), y)
+    k1x, k1y = _f2_pow(xi, (p - 1) // 3, p), _f2_pow(xi, (p - 1) // 2, p)
+    k2x = _f2_pow(xi, (p * p - 1) // 3, p)
+    assert k2x[1] == 0
+    Q1 = [44, 45, 46, 47]
+    xQ, yQ = E2.slots(Q[0], Q[1]), E2.slots(Q[2], Q[3])
+    o = outs2(Q1[0], Q1[1], Acc2().prod_const(xQ.conj(), P.mont(k1x[0]), P.mont(k1x[1])))
+    o += outs2(Q1[2], Q1[3], Acc2().prod_const(yQ.conj(), P.mont(k1y[0]), P.mont(k1y[1])))
+    P.dot(o, "frobQ1")
+    add(Q1, 1)
+    o = outs2(Q1[0], Q1[1], Acc2().prod_const(xQ, P.mont(k2x[0]), None))
+    o += outs2(Q1[2], Q1[3], Acc2().prod_const(yQ, (P.c_one, P.consts[P.c_one]), None))
+    P.dot(o, "frobQ2")
+    add(Q1, 1)
+    return FF
+
+
+def bn_final_exp(P, T, fval, gam):
+    """set A <- finalExponentiation(f) (optate.go:215-264), the same exponent: with g the easy-part output and
+    fu = g^u, fu2 = fu^u, fu3 = fu2^u
+      y0 = g^p g^(p^2) g^(p^3), y1 = conj(g), y2 = fu2^(p^2), y3 = conj(fu^p), y4 = conj(fu fu2^p), y5 = conj(fu2),
+      y6 = conj(fu3 fu3^p);  t0 = y6^2 y4 y5, t1 = y3 y5 t0, t0 = t0 y2, t1 = (t1^2 t0)^2, t0 = t1 y1, t1 = t1 y0,
+      result = t0^2 t1.
+    Every element after the easy part is in the cyclotomic subgroup, where Granger-Scott squaring equals the squaring.
+    Five register sets, four global slots; `X~`: the slots hold conj(X)."""
+    A_, B_, C_, D_, E_ = BN_A, BN_B, BN_C, BN_D, BN_E
+    AA = tower_easy_part(P, T, fval, gam[2], A_, B_, C_, D_)   # spare slots: the first six of set D
+    BB, CC, DD, EE = T.reg(B_), T.reg(C_), T.reg(D_), T.reg(E_)
+    U = BN_U
+    T.frob12(B_, AA, 1, gam[1], "hard/gp")
+    T.frob12(C_, AA, 2, gam[2], "hard/gp2")
+    T.mul12(B_, BB, CC, "hard/y0a")
+    T.frob12(C_, AA, 3, gam[3], "hard/gp3")
+    T.mul12(B_, BB, CC, "hard/y0")
+    T.spill12(B_, 0)                                        # gs0 = y0
+    T.pow_cyclo(B_, AA, U, "hard/fu")                       # B = fu
+    T.frob12(C_, BB, 1, gam[1], "hard/fup")                 # C = fu^p = y3~
+    T.spill12(C_, 1)                                        # gs1 = y3~
+    T.pow_cyclo(C_, BB, U, "hard/fu2")                      # C = fu2 = y5~
+    T.frob12(D_, CC, 1, gam[1], "hard/fu2p")
+    T.mul12(D_, BB, DD, "hard/y4")                          # D = fu fu2^p = y4~
+    T.spill12(D_, 2)                                        # gs2 = y4~
+    T.frob12(B_, CC, 2, gam[2], "hard/y2")                  # B = y2
+    T.spill12(B_, 3)                                        # gs3 = y2
+    T.pow_cyclo(B_, CC, U, "hard/fu3")                      # B = fu3
+    T.frob12(D_, BB, 1, gam[1], "hard/fu3p")
+    T.mul12(D_, BB, DD, "hard/y6")                          # D = y6~
+    T.cyclo_sqr(E_, DD, "hard/y6sq", refresh=True)          # E = (y6^2)~
+    T.fill12(D_, 2)
+    T.mul12(E_, EE, DD, "hard/t0a")                         # E = (y6^2 y4)~
+    T.mul12(E_, EE, CC, "hard/t0b")                         # E = t0~ = (y6^2 y4 y5)~
+    T.fill12(D_, 1)
+    T.mul12(D_, DD, CC, "hard/t1a")                         # D = (y3 y5)~
+    T.mul12(D_, DD, EE, "hard/t1b")                         # D = t1~
+    T.fill12(B_, 3)
+    T.mul12(E_, T.conj12(EE), BB, "hard/t0c")               # E = t0 y2
+    T.cyclo_sqr(D_, DD, "hard/t1sq", refresh=True)          # D = (t1^2)~
+    T.mul12(D_, T.conj12(DD), EE, "hard/t1c")               # D = t1^2 t0
+    T.cyclo_sqr(D_, DD, "hard/t1d", refresh=True)           # D = t1 (new)
+    T.mul12(E_, DD, T.conj12(AA), "hard/t0d")               # E = t1 y1
+    T.fill12(B_, 0)
+    T.mul12(D_, DD, BB, "hard/t1e")                         # D = t1 y0
+    T.cyclo_sqr(E_, EE, "hard/t0sq", refresh=True)
+    T.mul12(A_, EE, DD, "hard/out")
+    return AA
+
+
+def gt_layout_bn(j, c):
+    """byte offset of coefficient (w^j, c) in pointGT.MarshalBinary (point.go:630-662; oracle gt_marshal)"""
+    h, m = j & 1, j >> 1
+    return ((1 - h) * 3 + (2 - m)) * 64 + (0 if c == 1 else 32)
+
+
+def build_bn256_pair():
+    f = bn256_field()
+    P = Prog(f, BN_NSLOTS, 3, n_inputs=6, n_gslots=4)
+    T = Tower(P)
+    gam = {K: frob_gammas(f.p, (3, 1), K) for K in (1, 2, 3)}
+    FF = bn_miller(P, T, f, 0, 0)
+    res = bn_final_exp(P, T, FF, gam)
+    one = (P.c_plain_one, 1)
+    P.dot(sum((outs2(BN_A + 2 * j, BN_A + 2 * j + 1, Acc2().prod_const(res[j], one, None)) for j in range(6)), []), "to_plain")
+    P.misc([dict(op=OP_GT_STORE, dst=BN_A + 2 * j + c, arg=gt_layout_bn(j, c) | ((1 if (j == 0 and c == 0) else 0) << 16))
+            for j in range(6) for c in range(2)], "gt_store")
+    return P
+
+
+def build_bn256_check():
+    """Suite.ValidatePairing (suite.go:105-107): Pair(p1, p2).Equal(Pair(inv1, inv2)) -- two whole pairings compared
+    coefficient by coefficient (the reference accepts G2 points outside the order-n subgroup, for which the product
+    form e(p1, p2) e(-inv1, inv2) == 1 need not be equivalent).  Inputs 0..5: pair A, 6..11: pair B.  Flag bit 0 / 1:
+    pair A / B has an operand at infinity and pairs to one (optate.go:270-272)."""
+    f = bn256_field()
+    P = Prog(f, BN_NSLOTS, 3, n_inputs=12, n_gslots=5)
+    T = Tower(P)
+    gam = {K: frob_gammas(f.p, (3, 1), K) for K in (1, 2, 3)}
+    one = (P.c_plain_one, 1)
+    for k in range(2):
+        FF = bn_miller(P, T, f, 6 * k, 0)
+        res = bn_final_exp(P, T, FF, gam)
+        # plain residues into set E preloaded with the identity; lanes whose pair is dead keep the identity
+        P.misc([dict(op=OP_CLOAD, dst=BN_E + i, arg=P.c_plain_one if i == 0 else P.c_zero) for i in range(12)], "one")
+        P.dot(sum((outs2(BN_E + 2 * j, BN_E + 2 * j + 1, Acc2().prod_const(res[j], one, None), mask=k + 1) for j in range(6)), []),
+              "to_plain")
+        if k == 0:
+            T.spill12(BN_E, 4)
+    T.fill12(BN_D, 4)
+    P.misc([dict(op=OP_CMP_EQ, dst=BN_E + i, arg=BN_D + i) for i in range(12)], "equal")
+    return P
+
+
 # ------------------------------------------------------------------------------------------------ emission
 def _carr(vals, fmt="0x%xu", per=16):
     lines = []
@@ -1089,21 +1370,21 @@ def _carr(vals, fmt="0x%xu", per=16):
 def emit_field(f, struct_name):
     p = f.p
 
-    def words(x):
-        return [(x >> (32 * i)) & 0xffffffff for i in range(f.NW)]
-
     def digits(x):
-        return [(x >> (W * i)) & ((1 << W) - 1) for i in range(f.N)]
+        assert x >> (W * (f.N + 1)) == 0
+        return [(x >> (W * i)) & ((1 << W) - 1) for i in range(f.N + 1)]
+
+    def arr(v):
+        return ", ".join("0x%xu" % d for d in v)
 
     return "\n".join([
         f"struct {struct_name} {{",
         f"    static constexpr int N = {f.N}, NW = {f.NW};",
         f"    static constexpr int32_t P[{f.N}] = {{{', '.join(str(d) for d in f.balanced(p))}}};  // balanced 28-bit digits of p",
         f"    static constexpr uint32_t NINV = 0x{f.ninv:x}u;  // -p^-1 mod 2^28",
-        f"    static constexpr uint32_t P4[{f.N}] = {{{', '.join('0x%xu' % d for d in digits(4 * p))}}};  // 4p, unsigned digits",
-        f"    static constexpr uint32_t PW[{f.NW}] = {{{', '.join('0x%xu' % d for d in words(p))}}};",
-        f"    static constexpr uint32_t PW2[{f.NW}] = {{{', '.join('0x%xu' % d for d in words(2 * p))}}};",
-        f"    static constexpr uint32_t PW4[{f.NW}] = {{{', '.join('0x%xu' % d for d in words(4 * p))}}};",
+        f"    static constexpr uint32_t P1[{f.N + 1}] = {{{arr(digits(p))}}};  // p, 2p, 4p: unsigned 28-bit digits",
+        f"    static constexpr uint32_t P2[{f.N + 1}] = {{{arr(digits(2 * p))}}};",
+        f"    static constexpr uint32_t P4[{f.N + 1}] = {{{arr(digits(4 * p))}}};",
         "};"])
 
 
@@ -1127,13 +1408,16 @@ def emit_prog(P, name):
 
 
 def main():
-    pair, check = build_bls12381_pair(), build_bls12381_check()
-    out = ["// generated by gen_tower_vm.py -- do not edit", "#pragma once", "#include <stdint.h>", "namespace kyb {",
-           emit_field(pair.f, "Bls12381Vm"), emit_prog(pair, "BLS12381_PAIR"), emit_prog(check, "BLS12381_CHECK"),
-           "}  // namespace kyb", ""]
-    open(os.path.join(HERE, "tower_vm_bls12381.inc"), "w").write("\n".join(out))
-    for n, P in (("pair", pair), ("check", check)):
-        print(n, P.stats(), "bounds (log2 column, value/p):", P.check_bounds())
+    for suite, struct, builders in (("bls12381", "Bls12381Vm", (build_bls12381_pair, build_bls12381_check)),
+                                    ("bn256", "Bn256Vm", (build_bn256_pair, build_bn256_check))):
+        pair, check = builders[0](), builders[1]()
+        up = suite.upper()
+        out = ["// generated by gen_tower_vm.py -- do not edit", "#pragma once", "#include <stdint.h>", "namespace kyb {",
+               emit_field(pair.f, struct), emit_prog(pair, up + "_PAIR"), emit_prog(check, up + "_CHECK"),
+               "}  // namespace kyb", ""]
+        open(os.path.join(HERE, "tower_vm_%s.inc" % suite), "w").write("\n".join(out))
+        for n, P in (("pair", pair), ("check", check)):
+            print(suite, n, P.stats(), "bounds (log2 column, value/p):", P.check_bounds())
 
 
 if __name__ == "__main__":

@@ -36,11 +36,11 @@ constexpr int MAX_CONSTS = 32;
 //   0-5 out slot | 6-11 n terms | 12 barrier before the store (an input slot of some wave is overwritten) |
 //   13 raw: no products, no Montgomery reduction -- the linear terms are normalised as they are |
 //   14-18 post scale (0 = 1) | 19-20 store mask (0 none, 1 lanes live in pair A, 2 pair B) | 21-24 opcode
-enum Op : uint32_t { OP_DOT = 0, OP_IDLE = 1, OP_GLOAD = 2, OP_INV = 3, OP_GT_STORE = 4, OP_IS_ONE = 5, OP_CLOAD = 6, OP_SPILL = 7, OP_FILL = 8 };
+enum Op : uint32_t { OP_DOT = 0, OP_IDLE = 1, OP_GLOAD = 2, OP_INV = 3, OP_GT_STORE = 4, OP_IS_ONE = 5, OP_CLOAD = 6, OP_SPILL = 7, OP_FILL = 8, OP_CMP_EQ = 9 };
 //   GLOAD: slot <- input[word 1] of this pairing (packed words of the per-lane field code, taken as an integer)
 //   CLOAD: slot <- constant[word 1];  INV: slot <- Inv(slot[word 1]);  SPILL / FILL: slot <-> global scratch (word 1, wave)
 //   GT_STORE: canonical big-endian bytes of the slot at byte offset (word 1 & 0xffff) of the pairing's output
-//   IS_ONE: record slot != (word 1 >> 16) in the workgroup's result flags
+//   IS_ONE: record slot != (word 1 >> 16) in the workgroup's result flags;  CMP_EQ: record slot != slot[word 1]
 // term words
 //   w0: 0-5 x1 | 6-11 x2 | 12-17 y1 | 18-23 y2 | 24-25 kind (0 product, 1 linear: x only, 2 product with y = CONST[y1 + 64 y2])
 //   w1: int8 cx1 | cx2 | cy1 | cy2          operand = c1 S[s1] + c2 S[s2]  (c2 = 0: one slot)
@@ -156,13 +156,12 @@ __device__ __forceinline__ void mont_reduce(int64_t (&t)[2 * F::N]) {
     }
 }
 
-// Non-negative canonical words of a bounded balanced value: v + 4p in (0, 8p) -> [0, p) by three conditional
-// subtractions.  Requires |v| < 4p.  NW 32-bit words (value < 2^(32 NW)).
+// Canonical words of a bounded balanced value: v + 4p in (0, 8p), as N + 1 unsigned 28-bit digits, brought into [0, p)
+// by three conditional subtractions (4p, 2p, p), then packed into NW 32-bit words.  Requires |v| < 4p.
 template <class F>
 __device__ void canon_words(uint32_t (&w)[F::NW], const int32_t (&l)[F::N]) {
-    constexpr int N = F::N, NW = F::NW;
-    // unsigned 28-bit digits of v + 4p
-    uint32_t d[N + 1];
+    constexpr int N = F::N, NW = F::NW, ND = N + 1;
+    uint32_t d[ND];
     int64_t carry = 0;
 #pragma unroll
     for (int i = 0; i < N; i++) {
@@ -170,35 +169,30 @@ __device__ void canon_words(uint32_t (&w)[F::NW], const int32_t (&l)[F::N]) {
         d[i] = (uint32_t)x & 0x0fffffffu;
         carry = x >> 28;
     }
-    d[N] = (uint32_t)carry;  // zero for values in range (28 N bits hold 8p)
-    // pack to words
-    uint32_t x[NW];
-#pragma unroll
-    for (int k = 0; k < NW; k++) {
-        const int bit = 32 * k, j = bit / 28, o = bit - 28 * j;
-        uint32_t v = d[j] >> o;
-        if (j + 1 <= N) v |= d[j + 1] << (28 - o);
-        if (56 - o < 32 && j + 2 <= N) v |= d[j + 2] << (56 - o);
-        x[k] = v;
-    }
-    // conditional subtractions of 4p, 2p, p
+    d[N] = (uint32_t)(carry + (int64_t)F::P4[N]);
 #pragma unroll
     for (int s = 2; s >= 0; s--) {
-        uint32_t y[NW];
-        uint32_t borrow = 0;
+        uint32_t y[ND];
+        int32_t borrow = 0;
 #pragma unroll
-        for (int k = 0; k < NW; k++) {
-            const uint32_t pk = s == 2 ? F::PW4[k] : (s == 1 ? F::PW2[k] : F::PW[k]);
-            const uint64_t z = (uint64_t)x[k] - pk - borrow;
-            y[k] = (uint32_t)z;
-            borrow = (uint32_t)(z >> 63);
+        for (int i = 0; i < ND; i++) {
+            const uint32_t k = s == 2 ? F::P4[i] : (s == 1 ? F::P2[i] : F::P1[i]);
+            const int32_t z = (int32_t)d[i] - (int32_t)k - borrow;
+            y[i] = (uint32_t)z & 0x0fffffffu;
+            borrow = (z >> 31) & 1;
         }
-        const uint32_t keep = 0u - borrow;  // all ones: x < k p, keep x
+        const uint32_t keep = 0u - (uint32_t)borrow;  // all ones: d < k p, keep d
 #pragma unroll
-        for (int k = 0; k < NW; k++) x[k] = (x[k] & keep) | (y[k] & ~keep);
+        for (int i = 0; i < ND; i++) d[i] = (d[i] & keep) | (y[i] & ~keep);
     }
 #pragma unroll
-    for (int k = 0; k < NW; k++) w[k] = x[k];
+    for (int k = 0; k < NW; k++) {
+        const int bit = 32 * k, jj = bit / 28, o = bit - 28 * jj;
+        uint32_t v = d[jj] >> o;
+        if (jj + 1 <= N) v |= d[jj + 1] << (28 - o);
+        if (56 - o < 32 && jj + 2 <= N) v |= d[jj + 2] << (56 - o);
+        w[k] = v;
+    }
 }
 
 // NW packed words (a value in [0, 2^(32 NW))) -> N unsigned 28-bit digits, normalised to balanced ones
@@ -368,6 +362,18 @@ __device__ void run(const Args& a, uint32_t* lds, uint32_t* misc, const int32_t*
                             for (int k = 0; k < F::NW; k++) diff |= w[k] ^ (((arg >> 16) && k == 0) ? 1u : 0u);
                             if (diff) atomicOr(&misc[lane], 1u);
                         }
+                    }
+                    else if (op == OP_CMP_EQ) {
+                        int32_t v[N];
+                        uint32_t wa[F::NW], wb[F::NW];
+                        Lds<F>::load(v, lds, out_slot, lane);
+                        canon_words<F>(wa, v);
+                        Lds<F>::load(v, lds, arg & 63u, lane);
+                        canon_words<F>(wb, v);
+                        uint32_t diff = 0;
+#pragma unroll
+                        for (int k = 0; k < F::NW; k++) diff |= wa[k] ^ wb[k];
+                        if (diff) atomicOr(&misc[lane], 1u);
                     }
                     if ((hdr >> 12) & 1u) __syncthreads();
                     if (have) Lds<F>::store(lds, out_slot, lane, r);
