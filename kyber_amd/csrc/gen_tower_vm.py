@@ -778,19 +778,44 @@ class Tower:
     def fill12(self, base, g, name="fill"):
         self.P.misc([dict(op=OP_FILL, dst=base + w, arg=g) for w in range(12)], name)
 
-    def pow_cyclo(self, acc_base, base_val, exponent, name="pow"):
-        """S[acc_base..] = base_val^exponent for base_val in the cyclotomic subgroup (square-and-multiply from the top
-        bit, squarings in runs); base_val must not live in the acc register set."""
-        self.copy12(acc_base, base_val, name + "/init")
+    def pow_cyclo(self, acc_base, base_val, exponent, name="pow", cube_base=None):
+        """S[acc_base..] = base_val^exponent for base_val in the cyclotomic subgroup, squarings in runs; base_val must
+        not live in the acc register set.  Plain square-and-multiply from the top bit, or -- when a register set
+        `cube_base` is free to hold base_val^3 -- width-3 NAF digits {+-1, +-3} (inversion is conjugation here, free):
+        the result is the same power whatever the chain."""
         acc = self.reg(acc_base)
-        bits = bin(exponent)[3:]
+        if cube_base is None:
+            digits = [int(b) for b in bin(exponent)[2:]]
+            table = {1: base_val}
+        else:
+            k, naf = exponent, []
+            while k:
+                if k & 1:
+                    d = k % 8
+                    if d > 4:
+                        d -= 8
+                    if d in (3, -3, 1, -1):
+                        pass
+                    naf.append(d)
+                    k -= d
+                else:
+                    naf.append(0)
+                k >>= 1
+            assert sum(d << i for i, d in enumerate(naf)) == exponent and all(d in (0, 1, -1, 3, -3) for d in naf)
+            digits = naf[::-1]
+            cube = self.reg(cube_base)
+            self.cyclo_sqr(cube_base, base_val, name + "/cube_sq", refresh=True)
+            self.mul12(cube_base, cube, base_val, name + "/cube")
+            table = {1: base_val, -1: self.conj12(base_val), 3: cube, -3: self.conj12(cube)}
+        assert digits[0] in (1, 3)
+        self.copy12(acc_base, table[digits[0]], name + "/init")
         run = 0
-        for b in bits:
+        for d in digits[1:]:
             run += 1
-            if b == "1":
+            if d:
                 self.cyclo_sqr_run(acc_base, acc, run, name + "/sqr")
                 run = 0
-                self.mul12(acc_base, acc, base_val, name + "/mul")
+                self.mul12(acc_base, acc, table[d], name + "/mul")
         if run:
             self.cyclo_sqr_run(acc_base, acc, run, name + "/sqr")
 
@@ -1283,16 +1308,16 @@ def bn_final_exp(P, T, fval, gam):
     T.frob12(C_, AA, 3, gam[3], "hard/gp3")
     T.mul12(B_, BB, CC, "hard/y0")
     T.spill12(B_, 0)                                        # gs0 = y0
-    T.pow_cyclo(B_, AA, U, "hard/fu")                       # B = fu
+    T.pow_cyclo(B_, AA, U, "hard/fu", cube_base=E_)          # B = fu
     T.frob12(C_, BB, 1, gam[1], "hard/fup")                 # C = fu^p = y3~
     T.spill12(C_, 1)                                        # gs1 = y3~
-    T.pow_cyclo(C_, BB, U, "hard/fu2")                      # C = fu2 = y5~
+    T.pow_cyclo(C_, BB, U, "hard/fu2", cube_base=E_)         # C = fu2 = y5~
     T.frob12(D_, CC, 1, gam[1], "hard/fu2p")
     T.mul12(D_, BB, DD, "hard/y4")                          # D = fu fu2^p = y4~
     T.spill12(D_, 2)                                        # gs2 = y4~
     T.frob12(B_, CC, 2, gam[2], "hard/y2")                  # B = y2
     T.spill12(B_, 3)                                        # gs3 = y2
-    T.pow_cyclo(B_, CC, U, "hard/fu3")                      # B = fu3
+    T.pow_cyclo(B_, CC, U, "hard/fu3", cube_base=E_)         # B = fu3
     T.frob12(D_, BB, 1, gam[1], "hard/fu3p")
     T.mul12(D_, BB, DD, "hard/y6")                          # D = y6~
     T.cyclo_sqr(E_, DD, "hard/y6sq", refresh=True)          # E = (y6^2)~
