@@ -71,6 +71,22 @@ int kyb_device_count(void);
 int kyb_init(void);
 /* Release every per-device context. */
 int kyb_shutdown(void);
+
+/* ---- several GPUs of one node behind the same calls (the reference's callers are single-process
+ * loops -- share/poly.go:143-149, sign/bdn/bdn.go:126-161 -- so they need ONE call, not one process per GPU).
+ * After kyb_init_devices(ndev) (devices 0 .. ndev-1) or kyb_set_devices(list) every HOST-BUFFER batch entry point of
+ * at least kyb_set_shard_threshold() units (default 16384) is cut into `ndev` contiguous slices by the rule of
+ * kyb_shard_range (sizes differ by at most one), one host thread + device context per slice, no traffic between
+ * devices; kyb_*_msm shards the points, runs the whole Pippenger pipeline per device and adds the ndev encoded partial
+ * points at the end (<= 129 bytes per device cross the host, bucket arrays never move).  A device may be listed more
+ * than once (its slices then run one after the other; used by the tests on a one-GPU box).  ndev = 0 / an empty list
+ * restores single-device behaviour.  The `_dev` entry points are unaffected.  Results do not depend on the device
+ * set. */
+int kyb_init_devices(int ndev);
+int kyb_set_devices(const int *devices, int ndev);
+int kyb_get_devices(int *out, int cap); /* returns the number of shards configured (0: single device) */
+int kyb_set_shard_threshold(size_t min_units);
+void kyb_shard_range(size_t n, int rank, int world, size_t *lo, size_t *hi);
 /* The `_dev` entry points keep one grow-only device workspace per (kind of call, stream) so that calls on different
  * streams never share scratch.  A caller that destroys a stream calls this first (current device): waits for the
  * stream and frees the workspaces tied to that handle.  Never needed for long-lived streams or the host-buffer calls. */

@@ -29,6 +29,11 @@ SIGNATURES = {
     "kyb_init": [],
     "kyb_shutdown": [],
     "kyb_stream_release": [_vp],
+    "kyb_init_devices": [_int],
+    "kyb_set_devices": [_vp, _int],
+    "kyb_get_devices": [_vp, _int],
+    "kyb_set_shard_threshold": [_sz],
+    "kyb_shard_range": [_sz, _int, _int, _vp, _vp],
     "kyb_ed25519_mul_base": [_sz, _vp, _vp, _u32],
     "kyb_ed25519_mul_base_dev": [_sz, _vp, _vp, _u32, _vp],
     "kyb_ed25519_mul": [_sz, _vp, _vp, _vp, _vp, _u32],
@@ -108,7 +113,7 @@ SIGNATURES = {
     "kyb_bn256_g1_poly_eval_dev": [_sz, _vp, _sz, _vp, _vp, _vp, _u32, _vp],
     "kyb_bn256_g2_poly_eval_dev": [_sz, _vp, _sz, _vp, _vp, _vp, _u32, _vp],
 }
-_RESTYPES = {"kyb_last_error": C.c_char_p}
+_RESTYPES = {"kyb_last_error": C.c_char_p, "kyb_shard_range": None}
 
 _lib = None
 

@@ -176,6 +176,11 @@ int kyb_bls12381_verify_g1(size_t n, const uint8_t* pks, const uint8_t* msgs, si
     }
     KYB_TRY(check_flags(flags, 2, false, "kyb_bls12381_verify_g1"));
     if (!n) return KYB_OK;
+    if (md_active(n))
+        return md_run(n, [&](int, size_t lo, size_t hi) {
+            return kyb_bls12381_verify_g1(hi - lo, pks + bls::g2_wire_size(flags) * lo, msgs + msg_len * lo, msg_len, dst, dst_len,
+                                         sigs + bls::g1_wire_size(flags) * lo, ok + lo, status ? status + lo : nullptr, flags);
+        });
     DeviceCtx* ctx;
     KYB_TRY(get_ctx(&ctx));
     kyb::StageScope sc_(ctx);
@@ -218,6 +223,11 @@ int kyb_bls12381_verify_g2(size_t n, const uint8_t* pks, const uint8_t* msgs, si
     }
     KYB_TRY(check_flags(flags, 2, false, "kyb_bls12381_verify_g2"));
     if (!n) return KYB_OK;
+    if (md_active(n))
+        return md_run(n, [&](int, size_t lo, size_t hi) {
+            return kyb_bls12381_verify_g2(hi - lo, pks + bls::g1_wire_size(flags) * lo, msgs + msg_len * lo, msg_len, dst, dst_len,
+                                         sigs + bls::g2_wire_size(flags) * lo, ok + lo, status ? status + lo : nullptr, flags);
+        });
     DeviceCtx* ctx;
     KYB_TRY(get_ctx(&ctx));
     kyb::StageScope sc_(ctx);

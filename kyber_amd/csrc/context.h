@@ -69,6 +69,24 @@ inline int check_flags(uint32_t flags, int npoint, bool point_out, const char* w
     return KYB_OK;
 }
 
+// ---- multi-device host calls --------------------------------------------------------
+// kyb_set_devices() names the HIP devices the HOST-BUFFER entry points may use.  A call with n units is cut into
+// contiguous slices by the shard_range rule (sizes differ by at most one -- the rule kyber_amd/dist.py uses between
+// processes), each slice runs on its own host thread bound to its device (own context, staging pool and streams),
+// nothing crosses devices except, for an MSM, the encoded partial points that the calling thread adds up at the end.
+// The `_dev` entry points are untouched: device pointers belong to the caller's current device.
+int md_count();  // shards a host call is cut into; 1 inside a shard and when no device set was given
+size_t md_threshold();
+void shard_range(size_t n, int rank, int world, size_t* lo, size_t* hi);
+// f(shard, lo, hi) -> status code, once per shard, on a thread whose current device is the shard's; returns the first
+// non-zero code (its error message becomes the caller's kyb_last_error()).
+int md_run_impl(size_t n, int (*thunk)(void*, int, size_t, size_t), void* arg);
+template <class F>
+int md_run(size_t n, F&& f) {
+    return md_run_impl(n, [](void* a, int s, size_t lo, size_t hi) -> int { return (*static_cast<F*>(a))(s, lo, hi); }, &f);
+}
+inline bool md_active(size_t n) { return md_count() > 1 && n >= md_threshold() && n >= (size_t)md_count(); }
+
 // Context for the calling thread's current device (created on first use).
 int get_ctx(DeviceCtx** out);
 enum { WS_MSM = 0, WS_ED = 1, WS_PAIR = 2 };

@@ -2,6 +2,8 @@
 #include "hd.h"
 
 #include <map>
+#include <thread>
+#include <vector>
 
 static_assert(kyb::FLAG_UNCOMPRESSED == KYB_F_UNCOMPRESSED && kyb::FLAG_UNCOMPRESSED_OUT == KYB_F_UNCOMPRESSED_OUT &&
                   kyb::FLAG_TRUSTED0 == KYB_F_TRUSTED(0),
@@ -63,11 +65,115 @@ int ctx_workspace(DeviceCtx* ctx, int kind, hipStream_t stream, size_t bytes, vo
     return KYB_OK;
 }
 
+// ---- multi-device host calls
+static std::mutex g_md_mu;
+static std::vector<int> g_md_devs;          // logical shard -> HIP device (entries may repeat)
+static size_t g_md_threshold = 16384;       // smaller host batches stay on the caller's device
+static thread_local bool t_in_shard = false;
+
+int md_count() {
+    if (t_in_shard) return 1;
+    std::lock_guard<std::mutex> lk(g_md_mu);
+    return g_md_devs.empty() ? 1 : (int)g_md_devs.size();
+}
+size_t md_threshold() {
+    std::lock_guard<std::mutex> lk(g_md_mu);
+    return g_md_threshold;
+}
+void shard_range(size_t n, int rank, int world, size_t* lo, size_t* hi) {
+    const size_t base = n / (size_t)world, rem = n % (size_t)world, r = (size_t)rank;
+    *lo = r * base + (r < rem ? r : rem);
+    *hi = *lo + base + (r < rem ? 1 : 0);
+}
+int md_run_impl(size_t n, int (*thunk)(void*, int, size_t, size_t), void* arg) {
+    std::vector<int> devs;
+    {
+        std::lock_guard<std::mutex> lk(g_md_mu);
+        devs = g_md_devs;
+    }
+    const int w = (int)devs.size();
+    std::vector<int> rcs(w, KYB_OK);
+    std::vector<std::string> errs(w);
+    std::vector<std::thread> th;
+    th.reserve(w);
+    for (int s = 0; s < w; s++) {
+        th.emplace_back([&, s]() {
+            t_in_shard = true;  // the slice runs the ordinary single-device path
+            size_t lo, hi;
+            shard_range(n, s, w, &lo, &hi);
+            if (hipSetDevice(devs[s]) != hipSuccess) {
+                rcs[s] = KYB_E_HIP;
+                errs[s] = "hipSetDevice failed for shard " + std::to_string(s);
+                return;
+            }
+            if (hi > lo) rcs[s] = thunk(arg, s, lo, hi);
+            if (rcs[s]) errs[s] = g_err;
+        });
+    }
+    for (auto& t : th) t.join();
+    for (int s = 0; s < w; s++)
+        if (rcs[s]) {
+            set_error("shard " + std::to_string(s) + " (device " + std::to_string(devs[s]) + "): " + errs[s]);
+            return rcs[s];
+        }
+    return KYB_OK;
+}
+
 }  // namespace kyb
 
 extern "C" {
 
-int kyb_version(void) { return 1; }
+int kyb_version(void) { return 2; }
+
+int kyb_set_devices(const int* devices, int ndev) {
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess) have = 0;
+    if (ndev < 0 || (ndev && !devices)) {
+        kyb::set_error("kyb_set_devices: bad argument");
+        return KYB_E_ARG;
+    }
+    for (int i = 0; i < ndev; i++)
+        if (devices[i] < 0 || devices[i] >= have) {
+            kyb::set_error("kyb_set_devices: no such device");
+            return KYB_E_NODEV;
+        }
+    std::lock_guard<std::mutex> lk(kyb::g_md_mu);
+    kyb::g_md_devs.assign(devices, devices + ndev);
+    return KYB_OK;
+}
+int kyb_init_devices(int ndev) {
+    if (ndev < 1) {
+        kyb::set_error("kyb_init_devices: ndev must be at least 1");
+        return KYB_E_ARG;
+    }
+    std::vector<int> devs(ndev);
+    for (int i = 0; i < ndev; i++) devs[i] = i;
+    int rc = kyb_set_devices(devs.data(), ndev);
+    if (rc) return rc;
+    // eager contexts (tables, staging pools) so that the first batch does not pay for them
+    return kyb::md_run_impl((size_t)ndev, [](void*, int, size_t, size_t) -> int {
+        kyb::DeviceCtx* ctx;
+        return kyb::get_ctx(&ctx);
+    }, nullptr);
+}
+int kyb_get_devices(int* out, int cap) {
+    std::lock_guard<std::mutex> lk(kyb::g_md_mu);
+    const int n = (int)kyb::g_md_devs.size();
+    for (int i = 0; i < n && i < cap; i++) out[i] = kyb::g_md_devs[i];
+    return n;
+}
+int kyb_set_shard_threshold(size_t n) {
+    std::lock_guard<std::mutex> lk(kyb::g_md_mu);
+    kyb::g_md_threshold = n ? n : 1;
+    return KYB_OK;
+}
+void kyb_shard_range(size_t n, int rank, int world, size_t* lo, size_t* hi) {
+    if (world < 1 || rank < 0 || rank >= world) {
+        *lo = *hi = 0;
+        return;
+    }
+    kyb::shard_range(n, rank, world, lo, hi);
+}
 const char* kyb_last_error(void) { return kyb::g_err.c_str(); }
 
 int kyb_device_count(void) {

@@ -470,6 +470,8 @@ int kyb_ed25519_mul_base(size_t n, const uint8_t* scalars, uint8_t* out, uint32_
         return KYB_E_ARG;
     }
     if (n == 0) return KYB_OK;
+    if (md_active(n))
+        return md_run(n, [&](int, size_t lo, size_t hi) { return kyb_ed25519_mul_base(hi - lo, scalars + 32 * lo, out + 32 * lo, flags); });
     return mul_host(n, scalars, nullptr, 0, out, nullptr, flags);
 }
 
@@ -575,6 +577,10 @@ int kyb_ed25519_mul(size_t n, const uint8_t* scalars, const uint8_t* points, uin
         return KYB_E_ARG;
     }
     if (n == 0) return KYB_OK;
+    if (md_active(n))
+        return md_run(n, [&](int, size_t lo, size_t hi) {
+            return kyb_ed25519_mul(hi - lo, scalars + 32 * lo, points + 32 * lo, out + 32 * lo, status ? status + lo : nullptr, flags);
+        });
     return mul_host(n, scalars, points, 8, out, status, flags);
 }
 
@@ -585,6 +591,10 @@ int kyb_ed25519_mul_same_base(size_t n, const uint8_t* scalars, const uint8_t po
         return KYB_E_ARG;
     }
     if (n == 0) return KYB_OK;
+    if (md_active(n))
+        return md_run(n, [&](int, size_t lo, size_t hi) {
+            return kyb_ed25519_mul_same_base(hi - lo, scalars + 32 * lo, point, out + 32 * lo, status ? status + lo : nullptr, flags);
+        });
     return mul_host(n, scalars, point, 0, out, status, flags);
 }
 
@@ -606,6 +616,8 @@ struct EdMsm {
     using Aff = ge_precomp;  // (y + x, y - x, 2dxy): one unified mixed addition = 7M
     using Acc = ge_p3;
     static constexpr int WIRE = 32, OUT = 32;
+    static constexpr bool SCALAR_BE = false;
+    static constexpr uint32_t COMBINE_FLAGS = 0;
     static constexpr int DECODE_WAVES = 3;  // 1.73 ms at two waves, 1.34 at three, 1.38 at four (spills)
     __host__ __device__ static size_t wire_size(uint32_t) { return 32; }
     __device__ static int decode(Aff& a, const uint8_t* wire, uint32_t) {

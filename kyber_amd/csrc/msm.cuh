@@ -24,6 +24,7 @@
 //   identity(Acc&), madd(Acc&, const Aff&, bool neg), add(Acc&, const Acc&, const Acc&),
 //   dbl(Acc&, const Acc&), encode(uint8_t*, const Acc&).
 #pragma once
+#include <vector>
 #include "context.h"
 
 namespace kyb {
@@ -622,10 +623,10 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     return KYB_OK;
 }
 
-// Host-buffer wrapper: copy in, run, copy out, synchronise.
+// Host-buffer wrapper on the calling thread's device: copy in, run, copy out, synchronise.
 template <class A>
-int run_host(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* out, uint8_t* status,
-             uint32_t flags = 0) {
+int run_host_single(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* out, uint8_t* status,
+                    uint32_t flags = 0) {
     if ((n && (!scalars || !points)) || !out) {
         set_error("msm: bad argument");
         return KYB_E_ARG;
@@ -646,6 +647,45 @@ int run_host(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* o
     if (rc == KYB_OK) rc = d_o.download(out, A::OUT);
     if (rc == KYB_OK && status && n) rc = d_st.download(status, n);
     return rc;
+}
+
+// Host-buffer entry: with several devices configured (context.h md_*), the POINTS are sharded -- every device runs the
+// whole pipeline on its slice and yields one encoded partial point; the calling thread then adds the partials (an
+// MSM of `devices` points with unit scalars on its own device).  Bucket arrays never leave a device; what crosses the
+// host is devices x (point bytes) -- the exchange SURVEY.md section 8e prescribes, without a collective because one
+// process owns all the devices here (kyber_amd/dist.py is the one-process-per-GPU variant with an RCCL all-gather).
+template <class A>
+int run_host(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* out, uint8_t* status,
+             uint32_t flags = 0) {
+    if (!md_active(n)) return run_host_single<A>(n, scalars, points, out, status, flags);
+    if (!scalars || !points || !out) {
+        set_error("msm: bad argument");
+        return KYB_E_ARG;
+    }
+    if (int frc = check_flags(flags, 1, false, "msm")) return frc;
+    const int w = md_count();
+    std::vector<uint8_t> partial((size_t)w * A::OUT), st_tmp;
+    uint8_t* stp = status;
+    if (!stp) {
+        st_tmp.assign(n, 0);
+        stp = st_tmp.data();
+    }
+    const size_t wire = A::wire_size(flags);
+    int rc = md_run(n, [&](int s, size_t lo, size_t hi) {
+        return run_host_single<A>(hi - lo, scalars + 32 * lo, points + wire * lo, partial.data() + (size_t)s * A::OUT, stp + lo,
+                                  flags);
+    });
+    if (rc) return rc;
+    bool bad = false;
+    for (size_t i = 0; i < n; i++) bad |= stp[i] != 0;
+    if (bad) {  // the single-device contract: any rejected point -> all-zero output, status names it
+        for (int k = 0; k < A::OUT; k++) out[k] = 0;
+        return KYB_OK;
+    }
+    std::vector<uint8_t> unit((size_t)w * 32, 0);
+    for (int s = 0; s < w; s++) unit[(size_t)s * 32 + (A::SCALAR_BE ? 31 : 0)] = 1;
+    // the partials are this library's own encodings: validated by construction
+    return run_host_single<A>((size_t)w, unit.data(), partial.data(), out, nullptr, A::COMBINE_FLAGS);
 }
 
 // ----------------------------------------------------------------------------------------- batched PubPoly.Eval

@@ -16,6 +16,8 @@ struct Weierstrass {
     };
     using Acc = Jac<F>;
     static constexpr int WIRE = Codec::WIRE, OUT = Codec::WIRE;
+    static constexpr bool SCALAR_BE = true;                    // mod.Int wire format (group/mod/int.go:334-350)
+    static constexpr uint32_t COMBINE_FLAGS = KYB_F_TRUSTED(0);  // partial points of the multi-device MSM are our own
     __host__ __device__ static size_t wire_size(uint32_t flags) { return Codec::wire_size(flags); }
     __device__ static int decode(Aff& a, const uint8_t* wire, uint32_t flags) {
         kyb::Aff<F> t;

@@ -111,6 +111,11 @@ static int PFX##_mul_host(bool g2, size_t n, const uint8_t* scalars, const uint8
         return KYB_E_ARG; \
     } \
     if (!n) return KYB_OK; \
+    if (kyb::md_active(n)) \
+        return kyb::md_run(n, [&](int, size_t lo, size_t hi) { \
+            return PFX##_mul_host(g2, hi - lo, scalars + 32 * lo, points + (stride ? isz * lo : 0), stride, out + psz * lo, \
+                                  status ? status + lo : nullptr, flags); \
+        }); \
     kyb::DeviceCtx* ctx; \
     KYB_TRY(kyb::get_ctx(&ctx)); \
     kyb::StageScope sc_(ctx); \
@@ -342,6 +347,11 @@ int kyb_##PFX##_pair(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt
         return KYB_E_ARG; \
     } \
     if (!n) return KYB_OK; \
+    if (kyb::md_active(n)) \
+        return kyb::md_run(n, [&](int, size_t lo, size_t hi) { \
+            return kyb_##PFX##_pair(hi - lo, g1 + kyb::NS::g1_wire_size(flags) * lo, g2 + kyb::NS::g2_wire_size(flags) * lo, \
+                                    gt + (size_t)GTSZ * lo, status ? status + lo : nullptr, flags); \
+        }); \
     kyb::DeviceCtx* ctx; \
     KYB_TRY(kyb::get_ctx(&ctx)); \
     kyb::StageScope sc_(ctx); \
@@ -363,6 +373,12 @@ int kyb_##PFX##_pair_check(size_t n, const uint8_t* p1, const uint8_t* p2, const
         return KYB_E_ARG; \
     } \
     if (!n) return KYB_OK; \
+    if (kyb::md_active(n)) \
+        return kyb::md_run(n, [&](int, size_t lo, size_t hi) { \
+            const size_t s1 = kyb::NS::g1_wire_size(flags), s2 = kyb::NS::g2_wire_size(flags); \
+            return kyb_##PFX##_pair_check(hi - lo, p1 + s1 * lo, p2 + s2 * lo, inv1 + s1 * lo, inv2 + s2 * lo, ok + lo, \
+                                          status ? status + lo : nullptr, flags); \
+        }); \
     kyb::DeviceCtx* ctx; \
     KYB_TRY(kyb::get_ctx(&ctx)); \
     kyb::StageScope sc_(ctx); \

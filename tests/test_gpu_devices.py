@@ -1,0 +1,128 @@
+"""Several devices behind ONE host-buffer call (kyb_set_devices): the GPU box has one MI355X, so the device set lists
+it three times -- every slice runs the real single-device path on its own host thread and the partition, the per-slice
+pointer arithmetic, the status bytes and the MSM's combination of the partial points are all exercised; results must
+equal the single-device call byte for byte."""
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _shake(label, n):
+    return np.frombuffer(hashlib.shake_256(label).digest(n), dtype=np.uint8)
+
+
+@pytest.fixture()
+def three_shards():
+    from kyber_amd import devices
+
+    devices.set_devices([0, 0, 0])
+    devices.set_shard_threshold(1)
+    assert devices.get_devices() == [0, 0, 0]
+    yield devices
+    devices.set_devices([])
+    devices.set_shard_threshold(16384)
+
+
+def _both(devices, fn):
+    """fn() with the device set cleared (reference) and with it active"""
+    cur = devices.get_devices()
+    devices.set_devices([])
+    ref = fn()
+    devices.set_devices(cur)
+    return ref, fn()
+
+
+def _same(a, b):
+    a = a if isinstance(a, tuple) else (a,)
+    b = b if isinstance(b, tuple) else (b,)
+    return all((np.asarray(x) == np.asarray(y)).all() for x, y in zip(a, b))
+
+
+def test_ed25519_host_calls_sharded(three_shards):
+    from kyber_amd.group import edwards25519 as ed
+
+    n = 1000  # 334 + 333 + 333
+    s = _shake(b"md/ed/s", n * 32).reshape(n, 32).copy()
+    h = _shake(b"md/ed/h", n * 32).reshape(n, 32).copy()
+    s[:, 31] &= 0x7F
+    h[:, 31] &= 0x0F
+    ref, got = _both(three_shards, lambda: ed.batch_mul_base(h))
+    assert _same(ref, got)
+    pts = ref.copy()
+    for i in (0, 334, 999):  # a rejected point in every slice
+        pts[i] = 0
+        pts[i, 0] = 2
+    ref, got = _both(three_shards, lambda: ed.batch_mul(s, pts))
+    assert _same(ref, got) and sorted(np.nonzero(got[1])[0].tolist()) == [0, 334, 999]
+    ref, got = _both(three_shards, lambda: ed.commit(s, bytes(pts[5])))
+    assert _same(ref, got)
+    good = ed.batch_mul_base(h)
+    ref, got = _both(three_shards, lambda: ed.msm(s, good))
+    assert _same(ref, got) and not np.asarray(got[1]).any()
+    ref, got = _both(three_shards, lambda: ed.msm(s, pts))  # rejected points: zero output, statuses in place
+    assert _same(ref, got) and not np.asarray(got[0]).any() and np.asarray(got[1]).sum() == 3
+    # fewer units than shards, and the threshold: both stay on one device and still agree
+    ref, got = _both(three_shards, lambda: ed.batch_mul(s[:2], good[:2]))
+    assert _same(ref, got)
+    three_shards.set_shard_threshold(5000)
+    assert _same(ref, ed.batch_mul(s[:2], good[:2]))
+
+
+@pytest.mark.parametrize("name", ["bls12381", "bn256"])
+def test_pairing_suite_host_calls_sharded(three_shards, name):
+    import importlib
+
+    m = importlib.import_module("kyber_amd.pairing." + name)
+    n = 200
+    k = _shake(b"md/k/" + name.encode(), n * 32).reshape(n, 32).copy()
+    a = _shake(b"md/a/" + name.encode(), n * 32).reshape(n, 32).copy()
+    k[:, 0] &= 0x3F
+    a[:, 0] &= 0x3F
+    ref, got = _both(three_shards, lambda: m.g1_commit(a))
+    assert _same(ref, got)
+    P = np.asarray(got[0])
+    Q = np.asarray(m.g2_commit(k)[0])
+    ref, got = _both(three_shards, lambda: m.g1_batch_mul(k, P))
+    assert _same(ref, got)
+    ref, got = _both(three_shards, lambda: m.g2_batch_mul(a, Q))
+    assert _same(ref, got)
+    Pbad = P.copy()
+    Pbad[[3, 70, 199]] = 0xFF
+    ref, got = _both(three_shards, lambda: m.batch_pair(Pbad, Q))
+    assert _same(ref, got) and sorted(np.nonzero(got[1])[0].tolist()) == [3, 70, 199]
+    kP = np.asarray(m.g1_batch_mul(k, P)[0])
+    G2 = np.tile(np.frombuffer(m.G2_BASE, dtype=np.uint8), (n, 1))
+    forged = kP.copy()
+    forged[::7] = P[::7]
+    ref, got = _both(three_shards, lambda: m.batch_validate_pairing(P, Q, forged, G2))
+    assert _same(ref, got)
+    exp = np.ones(n, dtype=bool)
+    exp[::7] = False
+    assert (np.asarray(got[0]).astype(bool) == exp).all()
+    ref, got = _both(three_shards, lambda: m.g1_msm(k, P))
+    assert _same(ref, got) and np.asarray(got[0]).any()
+    ref, got = _both(three_shards, lambda: m.g2_msm(k, Q))
+    assert _same(ref, got)
+    ref, got = _both(three_shards, lambda: m.g1_msm(k, Pbad))
+    assert _same(ref, got) and not np.asarray(got[0]).any()
+
+
+def test_bls_verify_sharded(three_shards):
+    from kyber_amd.pairing import bls12381 as bls
+
+    n = 96
+    x = _shake(b"md/v/x", n * 32).reshape(n, 32).copy()
+    x[:, 0] &= 0x3F
+    msgs = _shake(b"md/v/m", n * 32).reshape(n, 32).copy()
+    X = np.asarray(bls.g2_commit(x)[0])
+    Hm = np.asarray(bls.batch_hash_g1(msgs)[0])
+    sig = np.asarray(bls.g1_batch_mul(x, Hm)[0]).copy()
+    sig[::5] = Hm[::5]
+    ref, got = _both(three_shards, lambda: bls.batch_verify_g1(X, msgs, sig))
+    assert _same(ref, got)
+    exp = np.ones(n, dtype=bool)
+    exp[::5] = False
+    assert (np.asarray(got[0]).astype(bool) == exp).all()
