@@ -59,6 +59,11 @@ extern "C" {
 #define KYB_F_UNCOMPRESSED 2u
 #define KYB_F_UNCOMPRESSED_OUT 4u /* g1/g2 mul and mul_same_base: write uncompressed outputs (96 / 192 B) as well, so a
                                      pipeline can keep points in the form that needs no square root; bn256: no-op */
+#define KYB_F_SCALAR_BITS(b) ((uint32_t)(b) << 16) /* *_msm only: every scalar is below 2^b (1 <= b <= 256) -- the
+                                     128-bit coefficients of sign/bdn (bdn.go:29-63) run half the windows.  Bits at
+                                     and above b are IGNORED (the result is sum (k_i mod 2^b) P_i).  BLS12-381 G1,
+                                     which already splits scalars into 127-bit halves, takes no notice. */
+#define KYB_F_SCALAR_BITS_MASK (0x1ffu << 16)
 #define KYB_F_TRUSTED(i) (0x100u << (i))
 #define KYB_F_TRUSTED_ALL 0xF00u /* the four point arguments of pair_check; calls with fewer point arguments reject the extra bits */
 
@@ -284,6 +289,9 @@ int kyb_bn256_pair_check_dev(size_t n, const void *d_p1, const void *d_p2, const
  * rejected the output is all-zero bytes.  n == 0 yields the encoding of the identity.
  * The _dev variants work in a grow-only workspace per (device, stream).                            */
 int kyb_ed25519_msm(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t out[32], uint8_t *status);
+/* the same with flags (KYB_F_SCALAR_BITS) */
+int kyb_ed25519_msm_flags(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t out[32], uint8_t *status,
+                          uint32_t flags);
 int kyb_ed25519_msm_dev(size_t n, const void *d_scalars, const void *d_points, void *d_out, void *d_status,
                         void *stream);
 int kyb_bls12381_g1_msm(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t out[48], uint8_t *status, uint32_t flags);

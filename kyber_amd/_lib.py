@@ -45,6 +45,7 @@ SIGNATURES = {
     "kyb_ed25519_hash": [_sz, _vp, _sz, _vp, _sz, _vp],
     "kyb_ed25519_hash_dev": [_sz, _vp, _sz, _vp, _sz, _vp, _vp],
     "kyb_ed25519_msm": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_ed25519_msm_flags": [_sz, _vp, _vp, _vp, _vp, _u32],
     "kyb_ed25519_msm_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
     "kyb_bls12381_g1_msm": [_sz, _vp, _vp, _vp, _vp, _u32],
     "kyb_bls12381_g2_msm": [_sz, _vp, _vp, _vp, _vp, _u32],

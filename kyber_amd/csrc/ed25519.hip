@@ -200,6 +200,7 @@ __global__ __launch_bounds__(256) void ed25519_mul_base_kernel(
 #pragma unroll 1
         for (int k = 0; k < npos; k++) {
             const int d = k < 32 ? (int)e[2 * k] + 16 * (int)e[2 * k + 1] : (int)e[64];
+            if (full && __ballot(d != 0) == 0) continue;  // variable-time: nothing to add at this position in any lane
             select_precomp_tab(t, tab, k, d);
             ge_madd(r, h, t);
             ge_p1p1_to_p3(h, r);
@@ -265,8 +266,35 @@ KYB_DEV void select_cached(ge_cached& c, const Tab& tab, int b) {
     ge_cached_cneg(c, neg);
 }
 
+// Highest radix-16 digit position that can be non-zero for ANY lane of the wave (the recoding may carry one digit past
+// the scalar's top nibble).  Wave-uniform by construction: the variable-time path below starts its ladder there.
+KYB_DEV int wave_top_digit(const uint32_t a[8]) {
+    int bits = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if (a[i]) bits = 32 * i + 32 - __builtin_clz(a[i]);
+    int t = (bits + 3) >> 2;  // digits 0 .. t may be non-zero (t: the carry)
+    if (t > 64) t = 64;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const int o = __shfl_xor(t, off, 64);
+        t = o > t ? o : t;
+    }
+    t = __builtin_amdgcn_readfirstlane(t);
+#endif
+    return t;
+}
+
+// KYB_F_VARTIME (geScalarMultVartime, ge_mult_vartime.go:11-73: every scalar bit counts, running time depends on the
+// scalar).  The reference's sliding-window NAF has its non-zero digits at scalar-dependent positions; 64 lanes in
+// lock step would execute the union of all of them -- an addition at nearly every bit.  What IS data-dependent and
+// still wave-uniform: the ladder starts at the highest digit any lane of the wave needs (`top`: short scalars -- the
+// 128-bit coefficients of sign/bdn, small Lagrange indices -- run proportionally fewer windows) and a window whose
+// digit is zero in EVERY lane skips its addition and the conversion that feeds it.  Random 253-bit scalars take the
+// same 64 windows as the constant-structure path.
 template <class Tab>
-KYB_DEV void ge_scalarmult_w4(ge_p3& h, const int8_t e[65], const ge_p3& A, bool full, Tab& tab) {
+KYB_DEV void ge_scalarmult_w4(ge_p3& h, const int8_t e[65], const ge_p3& A, bool full, Tab& tab, int vt_top) {
     ge_p1p1 t;
     ge_p3 u;
     ge_p2 r;
@@ -282,7 +310,7 @@ KYB_DEV void ge_scalarmult_w4(ge_p3& h, const int8_t e[65], const ge_p3& A, bool
     }
     ge_p3_0(u);
     int top = 63;
-    if (full) top = 64;  // uniform across the grid
+    if (full) top = vt_top;  // uniform across the wave
     select_cached(c, tab, e[top]);
     ge_add(t, u, c);
 #pragma unroll 1
@@ -295,6 +323,9 @@ KYB_DEV void ge_scalarmult_w4(ge_p3& h, const int8_t e[65], const ge_p3& A, bool
         ge_dbl(t, r.X, r.Y, r.Z);
         ge_p1p1_to_p2(r, t);
         ge_dbl(t, r.X, r.Y, r.Z);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (full && __ballot(e[i] != 0) == 0) continue;  // no lane adds anything in this window
+#endif
         ge_p1p1_to_p3(u, t);
         select_cached(c, tab, e[i]);
         ge_add(t, u, c);
@@ -321,12 +352,13 @@ __global__ __launch_bounds__(128, 3) void ed25519_mul_kernel(
     int8_t e[65];
     recode16(e, a, full);
     ge_p3 h;
+    const int vt_top = full ? wave_top_digit(a) : 63;
     if constexpr (GTAB) {
         TabGlobal tab{gtab + idx * 80};
-        ge_scalarmult_w4(h, e, A, full, tab);
+        ge_scalarmult_w4(h, e, A, full, tab, vt_top);
     } else {
         TabScratch tab;
-        ge_scalarmult_w4(h, e, A, full, tab);
+        ge_scalarmult_w4(h, e, A, full, tab, vt_top);
     }
     if (proj) {  // encoding deferred to ed25519_encode_kernel (status carries the decode verdict)
         store_proj(proj, idx, h);
@@ -703,6 +735,14 @@ struct EdMsm {
 extern "C" {
 int kyb_ed25519_msm(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t out[32], uint8_t* status) {
     return kyb::msm::run_host<kyb::EdMsm>(n, scalars, points, out, status);
+}
+int kyb_ed25519_msm_flags(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t out[32], uint8_t* status,
+                          uint32_t flags) {
+    if (flags & ~KYB_F_SCALAR_BITS_MASK) {
+        kyb::set_error("kyb_ed25519_msm_flags: only KYB_F_SCALAR_BITS applies");
+        return KYB_E_ARG;
+    }
+    return kyb::msm::run_host<kyb::EdMsm>(n, scalars, points, out, status, flags);
 }
 int kyb_ed25519_poly_eval(size_t n, const uint32_t* idx, size_t t, const uint8_t* commits, uint8_t* out, uint8_t* status) {
     return kyb::msm::poly_eval_host<kyb::EdMsm>(n, idx, t, commits, out, status, 0);

@@ -38,12 +38,14 @@ struct Plan {
     int chunk;    // buckets per reduce lane
     int nchunks;  // chunks per window
     uint32_t flags;  // the call's KYB_F_* flags (input format / trusted operands), read by the adapter's decode
+    int bits;        // scalar bits that count (KYB_F_SCALAR_BITS: bdn's 128-bit coefficients); higher bits are ignored
 };
 
 inline Plan make_plan(size_t n, int scalar_bits = 256, int cmax = 16) {
     Plan p;
     p.n = n;
     p.flags = 0;
+    p.bits = scalar_bits;
     int lg = 0;
     while ((size_t(1) << (lg + 1)) <= n) lg++;
     int c = lg - 3;
@@ -66,17 +68,17 @@ inline Plan make_plan(size_t n, int scalar_bits = 256, int cmax = 16) {
 // digit = raw_w + carry_in(w) - (carry_out << c), carry_in(w) = 1 iff the lower part, recoded, overflowed.
 // Sequential recoding is cheap (<= 129 steps), so each lane recodes its whole scalar once.
 template <int MAXWIN>
-__device__ __forceinline__ void recode(int32_t (&dig)[MAXWIN], const uint32_t (&k)[8], int c, int nwin) {
+__device__ __forceinline__ void recode(int32_t (&dig)[MAXWIN], const uint32_t (&k)[8], int c, int nwin, int bits = 256) {
     int carry = 0;
     const int half = 1 << (c - 1);
     for (int w = 0; w < nwin; w++) {
         const int bit = w * c;
         uint32_t raw = 0;
-        if (bit < 256) {
+        if (bit < bits) {
             const int idx = bit >> 5, sh = bit & 31;
             raw = k[idx] >> sh;
             if (sh + c > 32 && idx + 1 < 8) raw |= k[idx + 1] << (32 - sh);
-            raw &= (1u << c) - 1;
+            raw &= (1u << (bits - bit < c ? bits - bit : c)) - 1;  // the window, clipped at the last bit that counts
         }
         int d = (int)raw + carry;
         carry = d > half ? 1 : 0;
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(64, DecodeWaves<A>::value) void decode_kernel(Plan 
         const size_t e = (size_t)h * n_in + i;
         aff[e] = a[h];
         int32_t dig[129];
-        recode<129>(dig, k[h], p.c, p.nwin);
+        recode<129>(dig, k[h], p.c, p.nwin, p.bits);
         for (int w = 0; w < p.nwin; w++) {
             const int d = st ? 0 : dig[w];
             digits[(size_t)w * p.n + e] = d;
@@ -511,10 +513,15 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
         set_error("msm: bad argument");
         return KYB_E_ARG;
     }
-    if (int frc = check_flags(flags, 1, false, "msm")) return frc;
+    if (int frc = check_flags(flags & ~KYB_F_SCALAR_BITS_MASK, 1, false, "msm")) return frc;
     std::lock_guard<std::recursive_mutex> enq_lock(ctx->enq_mu);  // context.h: one whole pipeline at a time per device
     const size_t ne = n * Split<A>::value;  // points after the adapter's endomorphism split
-    const Plan p = make_plan(ne ? ne : 1, Split<A>::bits, Split<A>::cmax);
+    // KYB_F_SCALAR_BITS(b): only the low b bits of every scalar count (proportionally fewer windows); adapters that
+    // split their scalars through an endomorphism already work on halves and ignore it
+    int bits = Split<A>::bits;
+    const int want = (int)((flags >> 16) & 0x1ffu);
+    if (Split<A>::value == 1 && want && want < bits) bits = want;
+    const Plan p = make_plan(ne ? ne : 1, bits, Split<A>::cmax);
     Plan pr = p;
     pr.n = ne;
     pr.flags = flags;
@@ -631,7 +638,7 @@ int run_host_single(size_t n, const uint8_t* scalars, const uint8_t* points, uin
         set_error("msm: bad argument");
         return KYB_E_ARG;
     }
-    if (int frc = check_flags(flags, 1, false, "msm")) return frc;
+    if (int frc = check_flags(flags & ~KYB_F_SCALAR_BITS_MASK, 1, false, "msm")) return frc;
     DeviceCtx* ctx;
     int rc = get_ctx(&ctx);
     if (rc) return rc;
@@ -662,7 +669,7 @@ int run_host(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* o
         set_error("msm: bad argument");
         return KYB_E_ARG;
     }
-    if (int frc = check_flags(flags, 1, false, "msm")) return frc;
+    if (int frc = check_flags(flags & ~KYB_F_SCALAR_BITS_MASK, 1, false, "msm")) return frc;
     const int w = md_count();
     std::vector<uint8_t> partial((size_t)w * A::OUT), st_tmp;
     uint8_t* stp = status;

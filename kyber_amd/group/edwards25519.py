@@ -119,11 +119,12 @@ def commit(scalars, base=None, vartime: bool = False):
     return out
 
 
-def msm(scalars, points):
+def msm(scalars, points, scalar_bits: int = 256):
     """(out, status): out = sum_i scalars[i] * points[i] as one 32-byte point -- what PubPoly.Eval /
     RecoverCommit (share/poly.go:340-348, 449-476) compute with N x (Mul + Add).  Scalars are plain
     256-bit little-endian integers (never reduced mod l).  If any status is non-zero the output is
-    all-zero bytes."""
+    all-zero bytes.  scalar_bits < 256 (host buffers): every scalar is below 2^scalar_bits, higher bits are ignored
+    (KYB_F_SCALAR_BITS: proportionally fewer windows)."""
     lib = load()
     if _is_torch(scalars):
         import torch
@@ -145,6 +146,10 @@ def msm(scalars, points):
     n = s.shape[0]
     out = np.empty(32, dtype=np.uint8)
     st = np.zeros(max(n, 1), dtype=np.uint8)
+    if scalar_bits != 256:
+        check(lib.kyb_ed25519_msm_flags(n, s.ctypes.data, p.ctypes.data, out.ctypes.data, st.ctypes.data,
+                                        scalar_bits << 16), "kyb_ed25519_msm_flags")
+        return out, st[:n]
     check(lib.kyb_ed25519_msm(n, s.ctypes.data, p.ctypes.data, out.ctypes.data, st.ctypes.data), "kyb_ed25519_msm")
     return out, st[:n]
 

@@ -17,6 +17,13 @@ F_UNCOMPRESSED_OUT = 4
 F_TRUSTED_ALL = 0xF00
 
 
+def F_SCALAR_BITS(b: int) -> int:
+    """*_msm only: every scalar is below 2^b (KYB_F_SCALAR_BITS); higher bits are ignored."""
+    if not 1 <= b <= 256:
+        raise ValueError("scalar bits must be in 1..256")
+    return b << 16
+
+
 def F_TRUSTED(i: int) -> int:
     """Point argument i was validated before (an output of this library / of an earlier UnmarshalBinary)."""
     return 0x100 << i

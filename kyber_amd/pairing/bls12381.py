@@ -8,7 +8,7 @@ G1 48-byte / G2 96-byte ZCash compressed, GT 576 bytes.
 Batch functions accept host data (bytes / numpy uint8) or device-resident ``torch.uint8`` CUDA
 tensors; device inputs are processed on the current stream and results stay on the device.
 """
-from ._engine import F_TRUSTED, F_TRUSTED_ALL, F_UNCOMPRESSED, F_UNCOMPRESSED_OUT, Engine  # noqa: F401 (re-exported flags)
+from ._engine import F_SCALAR_BITS, F_TRUSTED, F_TRUSTED_ALL, F_UNCOMPRESSED, F_UNCOMPRESSED_OUT, Engine  # noqa: F401 (re-exported flags)
 
 ORDER = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001  # kilic/scalar.go:11-12
 G1_LEN, G2_LEN, GT_LEN, SCALAR_LEN = 48, 96, 576, 32

@@ -4,7 +4,7 @@ pairing/bn256/suite.go:22-107; point.go), backed by the HIP engine through the C
 Wire formats (pairing/bn256/point.go): scalars 32-byte big-endian (mod.Int), G1 64 bytes x || y,
 G2 128 bytes x.x || x.y || y.x || y.y, GT 384 bytes; infinity is all-zero bytes.
 """
-from ._engine import F_TRUSTED, F_TRUSTED_ALL, F_UNCOMPRESSED, F_UNCOMPRESSED_OUT, Engine  # noqa: F401 (re-exported flags)
+from ._engine import F_SCALAR_BITS, F_TRUSTED, F_TRUSTED_ALL, F_UNCOMPRESSED, F_UNCOMPRESSED_OUT, Engine  # noqa: F401 (re-exported flags)
 
 # constants.go:25
 ORDER = 65000549695646603732796438742359905742570406053903786389881062969044166799969

@@ -30,7 +30,8 @@ class Scheme:
     def aggregate_public_keys(self, publics, mask_bits) -> bytes:
         coefs = hash_point_to_r(publics)
         enabled = [i for i, b in enumerate(mask_bits) if b]
-        out, st = self.m.g2_msm(self._scalars(coefs, enabled), b"".join(publics[i] for i in enabled))
+        # c_i + 1 <= 2^128: the MSM runs 129-bit scalars (half the windows of a 256-bit one)
+        out, st = self.m.g2_msm(self._scalars(coefs, enabled), b"".join(publics[i] for i in enabled), self.m.F_SCALAR_BITS(129))
         if st.any():
             raise ValueError("bdn: invalid public key")
         return bytes(out)
@@ -41,7 +42,7 @@ class Scheme:
         enabled = [i for i, b in enumerate(mask_bits) if b]
         if len(sigs) != len(enabled):
             raise ValueError("bdn: length of signatures and public keys must match")
-        out, st = self.m.g1_msm(self._scalars(coefs, enabled), b"".join(sigs))
+        out, st = self.m.g1_msm(self._scalars(coefs, enabled), b"".join(sigs), self.m.F_SCALAR_BITS(129))
         if st.any():
             raise ValueError("bdn: invalid signature")
         return bytes(out)

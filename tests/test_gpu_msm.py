@@ -189,3 +189,60 @@ def test_ed25519_msm_all_equal_scalars_skew(ed):
     tot, _ = ed.msm(ones, P)
     exp, st2 = ed.batch_mul(s[0], tot)
     assert bytes(out) == bytes(exp[0])
+
+
+def test_short_scalar_msm_and_wave_uniform_vartime():
+    """KYB_F_SCALAR_BITS: an MSM over scalars below 2^b run with the flag equals the plain one (and bits at and above
+    b are ignored); KYB_F_VARTIME on Ed25519: short scalars, sparse digits and full-length ones all match the oracle."""
+    import hashlib
+
+    from kyber_amd.group import edwards25519 as ed
+    from kyber_amd.pairing import bls12381 as bls, bn256 as bn
+    from oracle import ed25519 as O
+
+    n = 3000
+    raw = np.frombuffer(hashlib.shake_256(b"short/k").digest(n * 32), dtype=np.uint8).reshape(n, 32).copy()
+    for m in (bn, bls):
+        k = raw.copy()
+        k[:, :15] = 0           # big-endian: 136 bits left ...
+        k[:, 15] &= 1           # ... 129
+        for grp, commit, msm in ((1, m.g1_commit, m.g1_msm), (2, m.g2_commit, m.g2_msm)):
+            P = np.asarray(commit(raw[:n] & 0x3F)[0])
+            full, st = msm(k, P)
+            short, st2 = msm(k, P, m.F_SCALAR_BITS(129))
+            assert not np.asarray(st).any() and not np.asarray(st2).any()
+            assert bytes(np.asarray(full)) == bytes(np.asarray(short)), (m.__name__, grp)
+            if not (m is bls and grp == 1):  # BLS12-381 G1 splits its scalars anyway and takes no notice of the flag
+                junk = k.copy()
+                junk[:, 0] = 0xA5   # bits above 2^129 are ignored
+                ign, _ = msm(junk, P, m.F_SCALAR_BITS(129))
+                assert bytes(np.asarray(ign)) == bytes(np.asarray(short))
+    # Ed25519 (little-endian scalars)
+    s = raw.copy()
+    s[:, 17:] = 0
+    s[:, 16] &= 1
+    h = raw.copy()
+    h[:, 31] &= 0x0F
+    P = ed.batch_mul_base(h)
+    full, _ = ed.msm(s, P)
+    short, _ = ed.msm(s, P, scalar_bits=129)
+    assert bytes(full) == bytes(short)
+    # variable-time multiplication: short / sparse / full scalars against the oracle
+    m = 256
+    sc = np.zeros((m, 32), dtype=np.uint8)
+    sc[:64, :16] = raw[:64, :16]                 # 128-bit scalars: the wave starts at digit 32
+    sc[64:128, 3] = raw[64:128, 3]               # one non-zero byte: most windows add nothing in any lane
+    sc[128:192] = raw[128:192]                   # all 256 bits (geScalarMultVartime honours them)
+    sc[192:, 0] = np.arange(64, dtype=np.uint8)  # tiny scalars incl. 0
+    out, st = ed.batch_mul(sc, P[:m], vartime=True)
+    base = ed.batch_mul_base(sc, vartime=True)
+    assert not np.asarray(st).any()
+    for i in list(range(0, m, 7)) + [192, 193, 255]:
+        assert bytes(out[i]) == O.mul(bytes(sc[i]), bytes(P[i]), vartime=True), i
+        # (fixed-base with the flag: the plain 256-bit multiple -- the reference itself always takes geScalarMultBase)
+        assert bytes(base[i]) == O.encode(O.mul_int(int.from_bytes(bytes(sc[i]), "little"), O.B)), i
+    # mixed lengths inside one wave
+    mix = sc[[0, 70, 130, 200] * 16]
+    out2, _ = ed.batch_mul(mix, P[:64], vartime=True)
+    for i in range(0, 64, 5):
+        assert bytes(out2[i]) == O.mul(bytes(mix[i]), bytes(P[i]), vartime=True), i
