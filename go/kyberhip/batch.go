@@ -100,6 +100,15 @@ func BatchMul(k Kind, g kyber.Group, scalars []kyber.Scalar, points []kyber.Poin
 // MSM returns sum_i scalars[i] * points[i]: what PubPoly.Eval (share/poly.go:340-348), RecoverCommit (:449-476) and
 // bdn.AggregateSignatures / AggregatePublicKeys (sign/bdn/bdn.go:126-181) compute with n x (Mul + Add).
 func MSM(k Kind, g kyber.Group, scalars []kyber.Scalar, points []kyber.Point) (kyber.Point, error) {
+	return MSMBits(k, g, scalars, points, 0)
+}
+
+// MSMBits is MSM for scalars known to be below 2^bits (sign/bdn's coefficients: bits = 129); bits = 0: full length.
+func MSMBits(k Kind, g kyber.Group, scalars []kyber.Scalar, points []kyber.Point, bits uint) (kyber.Point, error) {
+	fl := uint32(0)
+	if bits != 0 {
+		fl = ScalarBits(bits)
+	}
 	if len(scalars) != len(points) {
 		return nil, errors.New("kyberhip: length mismatch")
 	}
@@ -114,15 +123,15 @@ func MSM(k Kind, g kyber.Group, scalars []kyber.Scalar, points []kyber.Point) (k
 	var out, st []byte
 	switch k {
 	case Ed25519:
-		out, st, err = Ed25519MSM(sb, pb)
+		out, st, err = Ed25519MSM(sb, pb, fl)
 	case Bls12381G1:
-		out, st, err = Bls12381G1MSM(sb, pb, trusted(k))
+		out, st, err = Bls12381G1MSM(sb, pb, trusted(k)|fl)
 	case Bls12381G2:
-		out, st, err = Bls12381G2MSM(sb, pb, trusted(k))
+		out, st, err = Bls12381G2MSM(sb, pb, trusted(k)|fl)
 	case Bn256G1:
-		out, st, err = Bn256G1MSM(sb, pb)
+		out, st, err = Bn256G1MSM(sb, pb, fl)
 	case Bn256G2:
-		out, st, err = Bn256G2MSM(sb, pb)
+		out, st, err = Bn256G2MSM(sb, pb, fl)
 	}
 	if err != nil {
 		return nil, err
@@ -156,12 +165,10 @@ func Commit(k Kind, g kyber.Group, coeffs []kyber.Scalar, base kyber.Point) ([]k
 		out, st, err = Bls12381G1MulSameBase(sb, bb, trusted(k))
 	case Bls12381G2:
 		out, st, err = Bls12381G2MulSameBase(sb, bb, trusted(k))
-	default:
-		pts := make([]kyber.Point, len(coeffs))
-		for i := range pts {
-			pts[i] = base
-		}
-		return BatchMul(k, g, coeffs, pts)
+	case Bn256G1:
+		out, st, err = Bn256G1MulSameBase(sb, bb)
+	case Bn256G2:
+		out, st, err = Bn256G2MulSameBase(sb, bb)
 	}
 	if err != nil {
 		return nil, err

@@ -150,3 +150,64 @@ def test_stream_release_without_a_device_reports_an_error_code():
         assert rc == 0
     else:
         assert rc != 0 and lib.kyb_last_error()
+
+
+# Method sets of the reference's interfaces, as of /root/reference (dedis/kyber v4): group.go:23-131 (Scalar, Point),
+# :175-183 (Group), encoding.go:15-32 (Marshaling), pairing/pairing.go:8-20 (Suite with the embedded Encoding,
+# HashFactory, XOFFactory, Random).  When the reference tree is present they are re-extracted and compared.
+_POINT = ["Equal", "Null", "Base", "Pick", "Set", "Clone", "EmbedLen", "Embed", "Data", "Add", "Sub", "Neg", "Mul"]
+_MARSHALING = ["MarshalBinary", "UnmarshalBinary", "String", "MarshalSize", "MarshalTo", "UnmarshalFrom"]
+_GROUP = ["String", "ScalarLen", "Scalar", "PointLen", "Point"]
+_PAIRING = ["G1", "G2", "GT", "Pair", "ValidatePairing", "New", "Read", "Write", "Hash", "XOF", "RandomStream"]
+
+
+def _go_methods(src: str, recv: str):
+    import re
+
+    return set(re.findall(r"^func \(\w+ \*" + recv + r"\) (\w+)\(", src, re.M))
+
+
+def test_go_suite_implements_every_method_of_the_kyber_interfaces():
+    """go/kyberhip/suite cannot be compiled here: at least every method kyber.Point (+ Marshaling), kyber.Group and
+    pairing.Suite declare must exist on the engine's types, and the hot ones must reach the engine."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "go", "kyberhip", "suite")
+    point = open(os.path.join(d, "point.go")).read()
+    group = open(os.path.join(d, "group.go")).read()
+    pairing = open(os.path.join(d, "pairing.go")).read()
+    suites = open(os.path.join(d, "suites.go")).read()
+    assert set(_POINT + _MARSHALING) <= _go_methods(point, "Point")
+    assert {"AllowVarTime", "Hash", "IsInCorrectGroup"} <= _go_methods(point, "Point")
+    assert set(_GROUP) <= _go_methods(group, "Group")
+    assert {"BatchMul", "Commit", "MSM", "Validate"} <= _go_methods(group, "Group")
+    assert set(_PAIRING) <= _go_methods(pairing, "PairingSuite")
+    assert {"BatchPair", "BatchValidatePairing", "BatchVerify", "BatchGTMul"} <= _go_methods(pairing, "PairingSuite")
+    # the hot methods call the binding, not the reference
+    mul = point[point.index("func (P *Point) Mul("):point.index("// AllowVarTime")]
+    assert "P.g.mul(" in mul and "P.g.mulBase(" in mul and "P.p.Mul(" not in mul
+    assert "hip.Bls12381Pair(" in pairing and "hip.Bn256ValidatePairing(" in pairing and "hip.Bls12381VerifyG1(" in pairing
+    # the suites are declared variable-time and registered with the variable-time suites only
+    patch = open(os.path.join(root, "go", "patches", "suites_all_vartime.patch")).read()
+    assert "!constantTime" in patch and "RequireConstantTime" in patch and "register(hipsuite." in patch
+    assert "ariable-time" in point
+    for ctor in ("NewBlakeSHA256Ed25519HIP", "NewSuiteBLS12381", "NewSuiteBn256", "NewGroupSuiteBLS12381"):
+        assert "func " + ctor + "(" in suites
+    # every hip.X the suite uses exists in the binding
+    binding = open(os.path.join(root, "go", "kyberhip", "hip.go")).read() + open(os.path.join(root, "go", "kyberhip", "batch.go")).read()
+    for name in set(re.findall(r"\bhip\.([A-Z]\w+)", point + group + pairing + suites)):
+        assert re.search(r"\b(func|type) " + name + r"\b|^\s+" + name + r"\b", binding, re.M), name
+    ref = "/root/reference"
+    if os.path.isdir(ref):  # the build container: re-extract the interfaces and compare
+        g = open(os.path.join(ref, "group.go")).read()
+
+        def iface(src, name):
+            body = src[src.index("type %s interface {" % name):]
+            body = body[:body.index("\n}")]
+            return [m for m in re.findall(r"^\t(\w+)\(", body, re.M)]
+
+        assert iface(g, "Point") == _POINT
+        assert iface(g, "Group") == _GROUP
+        assert iface(open(os.path.join(ref, "encoding.go")).read(), "Marshaling") == ["String", "MarshalSize", "MarshalTo", "UnmarshalFrom"]
+        assert iface(open(os.path.join(ref, "pairing", "pairing.go")).read(), "Suite") == ["G1", "G2", "GT", "Pair", "ValidatePairing"]
