@@ -115,7 +115,7 @@ template <class A>
 __global__ __launch_bounds__(64, DecodeWaves<A>::value) void decode_kernel(Plan p, size_t n_in, const uint8_t* __restrict__ scalars,
                                                     const uint8_t* __restrict__ points,
                                                     typename A::Aff* __restrict__ aff, int32_t* __restrict__ digits,
-                                                    uint32_t* __restrict__ hist, uint8_t* __restrict__ status,
+                                                    uint8_t* __restrict__ status,
                                                     uint32_t* __restrict__ bad) {
     constexpr int S = Split<A>::value;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -139,8 +139,7 @@ __global__ __launch_bounds__(64, DecodeWaves<A>::value) void decode_kernel(Plan 
         recode<129>(dig, k[h], p.c, p.nwin, p.bits);
         for (int w = 0; w < p.nwin; w++) {
             const int d = st ? 0 : dig[w];
-            digits[(size_t)w * p.n + e] = d;
-            if (d) atomicAdd(&hist[(size_t)w * p.nb + (d < 0 ? -d : d) - 1], 1u);
+            digits[(size_t)w * p.n + e] = d;  // histogrammed per (window, tile) out of LDS: hist_lds_kernel
         }
     }
 }
@@ -166,15 +165,29 @@ static __global__ __launch_bounds__(SCAN_T) void scan_tilesum_kernel(const uint3
     }
     if (threadIdx.x == 0) tile[blockIdx.x] = red[0];
 }
-static __global__ __launch_bounds__(64) void scan_tiles_kernel(uint32_t* __restrict__ tile, size_t ntiles) {
-    if (threadIdx.x) return;
-    uint32_t run = 0;
-    for (size_t t = 0; t < ntiles; t++) {
+// in-place exclusive scan of tile[0..ntiles) (+ the total in tile[ntiles]) by ONE workgroup: every thread sums a
+// contiguous chunk, the chunk sums are scanned through LDS, the chunks are rewritten.  (A single lane walking the
+// array was fine for 64 tile sums; the LDS-staged sort scans nwin x buckets x tiles counters = thousands of tiles.)
+static __global__ __launch_bounds__(SCAN_T) void scan_tiles_kernel(uint32_t* __restrict__ tile, size_t ntiles) {
+    __shared__ uint32_t sh[SCAN_T];
+    const size_t per = (ntiles + SCAN_T - 1) / SCAN_T, lo = per * threadIdx.x, hi = lo + per < ntiles ? lo + per : ntiles;
+    uint32_t s = 0;
+    for (size_t t = lo; t < hi; t++) s += tile[t];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < SCAN_T; off <<= 1) {
+        const uint32_t add = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0u;
+        __syncthreads();
+        sh[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = sh[threadIdx.x] - s;
+    for (size_t t = lo; t < hi; t++) {
         const uint32_t v = tile[t];
         tile[t] = run;
         run += v;
     }
-    tile[ntiles] = run;
+    if (threadIdx.x == SCAN_T - 1) tile[ntiles] = sh[SCAN_T - 1];
 }
 static __global__ __launch_bounds__(SCAN_T) void scan_apply_kernel(const uint32_t* __restrict__ hist,
                                                                    const uint32_t* __restrict__ tile,
@@ -207,21 +220,61 @@ static __global__ __launch_bounds__(SCAN_T) void scan_apply_kernel(const uint32_
 static inline void launch_scan(const uint32_t* hist, uint32_t* offs, size_t m, uint32_t* tile, hipStream_t st) {
     const unsigned ntiles = (unsigned)((m + SCAN_TILE - 1) / SCAN_TILE);
     hipLaunchKernelGGL(scan_tilesum_kernel, dim3(ntiles), dim3(SCAN_T), 0, st, hist, tile, m);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(64), 0, st, tile, (size_t)ntiles);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_T), 0, st, tile, (size_t)ntiles);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(SCAN_T), 0, st, hist, (const uint32_t*)tile, offs, m);
 }
 
-static __global__ __launch_bounds__(256) void scatter_kernel(Plan p, const int32_t* __restrict__ digits,
-                                                      const uint32_t* __restrict__ offs,
-                                                      uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= p.n * (size_t)p.nwin) return;
-    const size_t w = t / p.n, i = t - w * p.n;
-    const int d = digits[t];
-    if (!d) return;
-    const size_t b = w * p.nb + (d < 0 ? -d : d) - 1;
-    const uint32_t pos = atomicAdd(&cursor[b], 1u);
-    sorted[offs[b] + pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+// Counting sort of the (point, window) digits by bucket, staged in LDS -- no global atomics.  A workgroup owns one
+// (window, tile of points) pair and a counter per bucket of that window in LDS (2^15 buckets x 4 B = 128 KB of the
+// CU's 160 KB):
+//   hist_lds_kernel     counts its tile with ds_add_u32 and stores the counters bucket-major, tile-minor
+//                       (hist2[(w nb + b) T + tile]), so that one exclusive scan of that array ...
+//   scatter_lds_kernel  ... is, for every (bucket, tile), the first output slot of the tile's points of that bucket:
+//                       the workgroup loads its row into the same LDS array and every point takes its slot with one
+//                       returning ds_add (rank within the bucket = arrival order, any order is a valid sort)
+//   bucket_offs_kernel  picks offs[b] = offs2[b T] -- what the rest of the pipeline indexes buckets by.
+// (Round 1 paid one global atomicAdd per digit in the decode kernel and another in the scatter: 2 x 16.8 M for
+// 2^20 BLS12-381 G1 points; with 2^15 buckets per window two lanes of a wave rarely meet in a bucket, so wave-level
+// ballot aggregation would save nothing on top of the LDS counters.)
+constexpr int HIST_T = 1024;
+constexpr int HIST_MAX_NB = 1 << 15;
+static __global__ __launch_bounds__(HIST_T) void hist_lds_kernel(Plan p, int tiles, const int32_t* __restrict__ digits,
+                                                                 uint32_t* __restrict__ hist2) {
+    __shared__ uint32_t h[HIST_MAX_NB];
+    const int w = blockIdx.y, tile = blockIdx.x;
+    for (int b = threadIdx.x; b < p.nb; b += HIST_T) h[b] = 0;
+    __syncthreads();
+    const size_t per = (p.n + tiles - 1) / tiles, lo = per * tile, hi = lo + per < p.n ? lo + per : p.n;
+    const int32_t* dw = digits + (size_t)w * p.n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += HIST_T) {
+        const int d = dw[i];
+        if (d) atomicAdd(&h[(d < 0 ? -d : d) - 1], 1u);
+    }
+    __syncthreads();
+    uint32_t* row = hist2 + (size_t)w * p.nb * tiles + tile;
+    for (int b = threadIdx.x; b < p.nb; b += HIST_T) row[(size_t)b * tiles] = h[b];
+}
+static __global__ __launch_bounds__(HIST_T) void scatter_lds_kernel(Plan p, int tiles, const int32_t* __restrict__ digits,
+                                                                    const uint32_t* __restrict__ offs2,
+                                                                    uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t cur[HIST_MAX_NB];
+    const int w = blockIdx.y, tile = blockIdx.x;
+    const uint32_t* row = offs2 + (size_t)w * p.nb * tiles + tile;
+    for (int b = threadIdx.x; b < p.nb; b += HIST_T) cur[b] = row[(size_t)b * tiles];
+    __syncthreads();
+    const size_t per = (p.n + tiles - 1) / tiles, lo = per * tile, hi = lo + per < p.n ? lo + per : p.n;
+    const int32_t* dw = digits + (size_t)w * p.n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += HIST_T) {
+        const int d = dw[i];
+        if (!d) continue;
+        const uint32_t pos = atomicAdd(&cur[(d < 0 ? -d : d) - 1], 1u);
+        sorted[pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+    }
+}
+static __global__ __launch_bounds__(256) void bucket_offs_kernel(size_t nbk, int tiles, const uint32_t* __restrict__ offs2,
+                                                                 uint32_t* __restrict__ offs) {
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b <= nbk) offs[b] = offs2[b * (size_t)tiles];  // b == nbk: the total (offs2 has one entry past the end)
 }
 
 constexpr int SUB = 64;  // points per accumulate lane: a bucket longer than this is split (skewed digits)
@@ -535,13 +588,18 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     const size_t o_aff = take(sizeof(typename A::Aff) * (ne ? ne : 1));
     const size_t o_dig = take(sizeof(int32_t) * (ne ? ne : 1) * p.nwin);
     const size_t o_sorted = take(sizeof(uint32_t) * (ne ? ne : 1) * p.nwin);
-    const size_t o_hist = take(sizeof(uint32_t) * nbk);
-    const size_t o_cursor = take(sizeof(uint32_t) * nbk);
+    // tiles per window of the LDS-staged sort: about two workgroups per CU in total, a tile of at least two points per
+    // bucket (the per-tile flush and the scan are per bucket)
+    int tiles = (int)((size_t)(2 * ctx->num_cu + p.nwin - 1) / p.nwin);
+    while (tiles > 1 && (ne ? ne : 1) / tiles < 2 * (size_t)p.nb) tiles--;
+    const size_t m2 = nbk * (size_t)tiles;
+    const size_t o_hist = take(sizeof(uint32_t) * m2);
+    const size_t o_cursor = take(sizeof(uint32_t) * (m2 + 1));  // offs2: the scanned hist2
     const size_t o_lenhist = take(sizeof(uint32_t) * (SUB + 2));
     const size_t o_lencursor = take(sizeof(uint32_t) * (SUB + 2));
     const size_t o_nlong = take(256);
     const size_t o_bad = take(256);
-    const size_t zero_end = off;  // hist, cursor, lenhist, lencursor, bad are zeroed together
+    const size_t zero_end = off;  // lenhist, lencursor, nlong, bad are zeroed together
     const size_t o_offs = take(sizeof(uint32_t) * (nbk + 1));
     const size_t o_nsub = take(sizeof(uint32_t) * nbk);
     const size_t o_suboffs = take(sizeof(uint32_t) * (nbk + 1));
@@ -555,7 +613,7 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     const size_t o_partial = take(sizeof(typename A::Acc) * (size_t)p.nwin * p.nchunks);
     const int nfold = (p.nchunks + 63) / 64;
     const size_t o_fold = take(sizeof(typename A::Acc) * (size_t)p.nwin * nfold);
-    const size_t o_tile = take(sizeof(uint32_t) * ((nbk + SCAN_TILE - 1) / SCAN_TILE + 2));
+    const size_t o_tile = take(sizeof(uint32_t) * ((m2 + SCAN_TILE - 1) / SCAN_TILE + 2));
     const size_t o_winsum = take(sizeof(typename A::Acc) * p.nwin);
     void* ws;
     int rc = ctx_workspace(ctx, WS_MSM, st, off, &ws);
@@ -565,7 +623,7 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     auto* digits = (int32_t*)(base + o_dig);
     auto* sorted = (uint32_t*)(base + o_sorted);
     auto* hist = (uint32_t*)(base + o_hist);
-    auto* cursor = (uint32_t*)(base + o_cursor);
+    auto* offs2 = (uint32_t*)(base + o_cursor);
     auto* bad = (uint32_t*)(base + o_bad);
     auto* offs = (uint32_t*)(base + o_offs);
     auto* nsub = (uint32_t*)(base + o_nsub);
@@ -583,24 +641,28 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     auto* winsum = (typename A::Acc*)(base + o_winsum);
     auto* folded = (typename A::Acc*)(base + o_fold);
     auto* tile = (uint32_t*)(base + o_tile);
-    KYB_HIP_CHECK(hipMemsetAsync(hist, 0, zero_end - o_hist, st));
+    KYB_HIP_CHECK(hipMemsetAsync(base + o_lenhist, 0, zero_end - o_lenhist, st));
     if (n) {
         hipLaunchKernelGGL(decode_kernel<A>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, pr, n, (const uint8_t*)d_scalars,
-                           (const uint8_t*)d_points, aff, digits, hist, (uint8_t*)d_status, bad);
+                           (const uint8_t*)d_points, aff, digits, (uint8_t*)d_status, bad);
     }
-    launch_scan(hist, offs, nbk, tile, st);
-    if (n) {
-        const size_t tot = ne * (size_t)p.nwin;
-        hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, pr, digits, offs, cursor,
-                           sorted);
+    if (p.nb > HIST_MAX_NB) {
+        set_error("msm: window too wide for the LDS-staged sort");
+        return KYB_E_ARG;
     }
+    hipLaunchKernelGGL(hist_lds_kernel, dim3(tiles, p.nwin), dim3(HIST_T), 0, st, pr, tiles, (const int32_t*)digits, hist);
+    launch_scan(hist, offs2, m2, tile, st);
+    hipLaunchKernelGGL(scatter_lds_kernel, dim3(tiles, p.nwin), dim3(HIST_T), 0, st, pr, tiles, (const int32_t*)digits,
+                       (const uint32_t*)offs2, sorted);
+    hipLaunchKernelGGL(bucket_offs_kernel, dim3((unsigned)((nbk + 256) / 256)), dim3(256), 0, st, nbk, tiles,
+                       (const uint32_t*)offs2, offs);
     hipLaunchKernelGGL(subcount_kernel, dim3((unsigned)((nbk + 255) / 256)), dim3(256), 0, st, nbk, offs, nsub, nlong,
                        longlist);
     launch_scan(nsub, suboffs, nbk, tile, st);
     const unsigned pgrid = (unsigned)((max_pieces + 255) / 256);
     hipLaunchKernelGGL(piece_kernel, dim3(pgrid), dim3(256), 0, st, nbk, max_pieces, (const uint32_t*)offs,
                        (const uint32_t*)suboffs, plo, plen, lenhist);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(64), 0, st, lenhist, (size_t)(SUB + 1));
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_T), 0, st, lenhist, (size_t)(SUB + 1));
     hipLaunchKernelGGL(piece_order_kernel, dim3(pgrid), dim3(256), 0, st, nbk, max_pieces, (const uint32_t*)suboffs,
                        (const uint32_t*)plen, (const uint32_t*)lenhist, lencursor, order);
     hipLaunchKernelGGL(accumulate_kernel<A>, dim3((unsigned)((max_pieces + 63) / 64)), dim3(64), 0, st, nbk, max_pieces, aff,
