@@ -40,13 +40,24 @@ KYB_DEV void store_words8(uint32_t* __restrict__ p, const uint32_t w[8]) {
 
 // ---------------------------------------------------------------- table build
 // Thread (i, j) computes (j+1) * 256^i * B by MSB-first double-and-add and
-// stores its affine (y+x, y-x, 2dxy).  Runs once per device.
-__global__ void ed25519_build_base_table_kernel(int32_t* __restrict__ tab) {
+// stores its affine (y+x, y-x, 2dxy).  Runs once per device for the standard base (point == nullptr), and once per
+// call for the shared base of a large kyb_ed25519_mul_same_base batch (share.PriPoly.Commit with b != nil,
+// share/poly.go:143-149): the table costs 4 544 short multiplications, after which every coefficient is 32 mixed
+// additions instead of a 64-window ladder on a freshly decoded point.  *ok = 0 when `point` does not decode.
+__global__ void ed25519_build_base_table_kernel(int32_t* __restrict__ tab, const uint32_t* __restrict__ point,
+                                                uint32_t* __restrict__ ok) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ED_TAB_POS * ED_TAB_ENT) return;
     const int pos = t / ED_TAB_ENT, j = t - pos * ED_TAB_ENT;
     ge_p3 B;
-    B.X = fe_bx(); B.Y = fe_by(); fe_1(B.Z); B.T = fe_bt();
+    if (point) {
+        uint32_t pw[8];
+        load_words8(pw, point);
+        const bool good = ge_p3_fromwords(B, pw);
+        if (t == 0) *ok = good ? 1u : 0u;
+    } else {
+        B.X = fe_bx(); B.Y = fe_by(); fe_1(B.Z); B.T = fe_bt();
+    }
     ge_cached cB;
     ge_p3_to_cached(cB, B);
     ge_p3 acc;
@@ -379,7 +390,7 @@ __global__ __launch_bounds__(128, 3) void ed25519_mul_kernel(
 int ed25519_build_tables(DeviceCtx* ctx) {
     KYB_HIP_CHECK(hipMalloc(&ctx->ed_base_tab, ED_TAB_WORDS * sizeof(int32_t)));
     hipLaunchKernelGGL(ed25519_build_base_table_kernel, dim3((ED_TAB_POS * ED_TAB_ENT + 63) / 64), dim3(64), 0,
-                       nullptr, ctx->ed_base_tab);
+                       nullptr, ctx->ed_base_tab, (const uint32_t*)nullptr, (uint32_t*)nullptr);
     KYB_HIP_CHECK(hipGetLastError());
     KYB_HIP_CHECK(hipStreamSynchronize(nullptr));
     return KYB_OK;
@@ -410,7 +421,8 @@ static int ed_proj_workspace(DeviceCtx* ctx, hipStream_t st, size_t n, bool need
 }
 
 static int launch_mul_base(DeviceCtx* ctx, size_t n, const void* d_scalars, void* d_out, uint32_t flags,
-                           hipStream_t st) {
+                           hipStream_t st, const int32_t* tab = nullptr) {
+    if (!tab) tab = ctx->ed_base_tab;
     if (n == 0) return KYB_OK;
     const int block = 256;
     size_t want = (n + block - 1) / block;
@@ -423,7 +435,7 @@ static int launch_mul_base(DeviceCtx* ctx, size_t n, const void* d_scalars, void
         if (rc) return rc;
     }
     hipLaunchKernelGGL(ed25519_mul_base_kernel, dim3(grid), dim3(block), 0, st, n,
-                       (const uint32_t*)d_scalars, (uint32_t*)d_out, ctx->ed_base_tab, flags, proj);
+                       (const uint32_t*)d_scalars, (uint32_t*)d_out, tab, flags, proj);
     if (proj) {
         const size_t lanes = (n + ENC_CHUNK - 1) / ENC_CHUNK;
         hipLaunchKernelGGL(ed25519_encode_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, n, proj,
@@ -513,6 +525,7 @@ int kyb_ed25519_mul_base(size_t n, const uint8_t* scalars, uint8_t* out, uint32_
 // thread, the compute stream always has the next kernel queued.  (PCIe moves 97 bytes per variable-base element
 // in ~1/3 of the time the kernel needs for it: overlapped, the host path approaches the resident rate.)
 constexpr size_t PIPE_CHUNK = size_t(1) << 18;
+constexpr size_t SAME_BASE_TABLE_MIN = 16384;  // below this the table (4 544 short multiplications) does not pay
 
 static int pipe_streams(DeviceCtx* ctx) {
     for (int i = 0; i < 3; i++)
@@ -526,18 +539,37 @@ static int mul_host(size_t n, const uint8_t* scalars, const uint8_t* points, siz
     DeviceCtx* ctx;
     int rc = get_ctx(&ctx);
     if (rc) return rc;
-    const bool fixed = points == nullptr;
+    bool fixed = points == nullptr;
     const size_t npts = fixed ? 0 : (stride ? n : 1);
     StageScope sc_(ctx);
-    StageBuf d_s, d_p, d_o, d_st;
+    StageBuf d_s, d_p, d_o, d_st, d_tab;
     if ((rc = d_s.alloc(n * 32))) return rc;
     if ((rc = d_p.alloc(npts * 32))) return rc;
     if ((rc = d_o.alloc(n * 32))) return rc;
     if ((rc = d_st.alloc(n))) return rc;
+    const int32_t* tab = nullptr;  // nullptr: the device's table of the standard base
+    if (!fixed && !stride && n >= SAME_BASE_TABLE_MIN) {
+        // one shared base and many coefficients: give the base a radix-256 table of its own and take the fixed-base path
+        if ((rc = d_tab.alloc(ED_TAB_WORDS * sizeof(int32_t) + 256))) return rc;
+        uint32_t* d_ok = (uint32_t*)((uint8_t*)d_tab.p + ED_TAB_WORDS * sizeof(int32_t));
+        KYB_HIP_CHECK(hipMemcpy(d_p.p, points, 32, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(ed25519_build_base_table_kernel, dim3((ED_TAB_POS * ED_TAB_ENT + 63) / 64), dim3(64), 0, nullptr,
+                           (int32_t*)d_tab.p, (const uint32_t*)d_p.p, d_ok);
+        uint32_t ok = 0;
+        KYB_HIP_CHECK(hipMemcpy(&ok, d_ok, 4, hipMemcpyDeviceToHost));
+        if (!ok) {  // the reference's UnmarshalBinary fails once, for every coefficient
+            memset(out, 0, n * 32);
+            if (status) memset(status, KYB_ST_BAD_POINT, n);
+            return KYB_OK;
+        }
+        if (status) memset(status, 0, n);
+        tab = (const int32_t*)d_tab.p;
+        fixed = true;
+    }
     auto launch = [&](size_t off, size_t cnt, hipStream_t st) -> int {
         uint8_t* s = (uint8_t*)d_s.p + off * 32;
         uint8_t* o = (uint8_t*)d_o.p + off * 32;
-        if (fixed) return launch_mul_base(ctx, cnt, s, o, flags, st);
+        if (fixed) return launch_mul_base(ctx, cnt, s, o, flags, st, tab);
         const uint8_t* p = (const uint8_t*)d_p.p + (stride ? off * 32 : 0);
         return launch_mul(cnt, s, p, stride, o, (uint8_t*)d_st.p + off, flags, st);
     };

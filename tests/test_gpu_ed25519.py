@@ -303,3 +303,29 @@ def test_stream_release_frees_and_the_stream_stays_usable(ed):
     kyber_amd.release_stream(st)
     assert torch.cuda.mem_get_info()[0] >= before  # the MSM workspace went back to the driver
     assert torch.equal(out, ref)
+
+
+def test_same_base_commit_through_its_own_table(ed):
+    """kyb_ed25519_mul_same_base with >= 16384 coefficients builds a radix-256 table for the shared base and takes the
+    fixed-base path (share.PriPoly.Commit with b != nil, share/poly.go:143-149): same bytes as the per-element ladder,
+    including scalars >= 2^255, the var-time flag, and a base that does not decode."""
+    import hashlib
+
+    import torch
+
+    n = 20000
+    s = np.frombuffer(hashlib.shake_256(b"commit/s").digest(n * 32), dtype=np.uint8).reshape(n, 32).copy()  # all 256 bits
+    base = ed.batch_mul_base(np.frombuffer(hashlib.sha256(b"commit/base").digest(), dtype=np.uint8).reshape(1, 32) & 0x7F)[0]
+    tiled = torch.from_numpy(np.tile(base, (n, 1))).cuda()
+    for vt in (False, True):
+        got = ed.commit(s, bytes(base), vartime=vt)
+        ref, st = ed.batch_mul(torch.from_numpy(s).cuda(), tiled, vartime=vt)
+        assert not st.any().item() and (got == ref.cpu().numpy()).all(), vt
+    for i in (0, 1, n - 1):
+        assert bytes(got[i]) == O.mul(bytes(s[i]), bytes(base), vartime=True)
+    small = ed.commit(s[:100], bytes(base))  # below the threshold: the ladder
+    assert (small == ed.commit(s, bytes(base))[:100]).all()
+    bad = bytearray(32)
+    bad[0] = 2  # y = 2 is not on the curve
+    with pytest.raises(ValueError):
+        ed.commit(s, bytes(bad))
