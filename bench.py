@@ -36,6 +36,7 @@ N_PER_GPU = 1 << 20
 # algorithmic bytes per unit: var-base 32+32 in, 32 out; fixed-base 32 in, 32 out
 BYTES_VAR, BYTES_FIX = 96, 64
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+REF_SINGLE_CORE_PER_S = 2.0 / (349399e-9 + 60658e-9)
 # 64-bit integer multiply-adds (v_mad_i64_i32) per scalar multiplication as built:
 # a field multiplication is 100 MADs, a squaring 55.  With an in-kernel ToBytes, variable-base = 1366 M + 1517 S
 # and fixed-base = 475 M + 270 S; batches >= 4096 defer the encoding to ed25519_encode_kernel, which replaces the
@@ -135,18 +136,50 @@ def cpu_baseline_pairings():
                                       f"the host with g++ -O2 (tests/host_harness.cpp)"}
 
 
-def timed(fn, reps):
+def timed(fn, reps=20, warm=5):
+    """median of `reps` HIP-event timings (ms) after `warm` untimed calls"""
     import torch
 
-    fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
+    for _ in range(warm):
         fn()
-    e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2]
+
+
+def _prof():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "roofline_inputs.json")))
+    except Exception:
+        return {}
+
+
+def _tvm_mads():
+    """integer MADs per pairing / pairing check of the tower-machine programs, counted from the generated programs
+    themselves (kyber_amd/csrc/gen_tower_vm.py is product tooling, not the oracle)"""
+    sys.path.insert(0, os.path.join(ROOT, "kyber_amd", "csrc"))
+    import gen_tower_vm as G
+
+    return {"bls12381": (G.build_bls12381_pair().mads(), G.build_bls12381_check().mads()),
+            "bn256": (G.build_bn256_pair().mads(), G.build_bn256_check().mads())}
+
+
+def _roof(units_per_s, mads_per_unit, alg_bytes_per_unit, prof, key):
+    """roofline object of a side workload: integer-MAD issue is the binding resource, HBM figures alongside"""
+    peak = prof.get("imad_peak_lane_ops_per_s")
+    k = prof.get("kernels", {}).get(key, {})
+    return {"bound": "valu-imad", "mads_per_unit": mads_per_unit, "achieved": units_per_s * mads_per_unit, "peak": peak,
+            "unit": "lane-MAD/s", "frac": (units_per_s * mads_per_unit / peak) if peak else None,
+            "hbm": {"algorithmic_bytes_per_unit": alg_bytes_per_unit, "achieved_GBps": units_per_s * alg_bytes_per_unit / 1e9,
+                    "peak_GBps": HBM_PEAK_GBS, "frac": units_per_s * alg_bytes_per_unit / 1e9 / HBM_PEAK_GBS},
+            "traffic": k.get("hbm_bytes_per_launch"), "traffic_units_per_launch": k.get("units_per_launch"),
+            "valu_busy_profiled": k.get("valu_busy"), "profile": k.get("source")}
 
 
 def other_workloads(rank, world, dist):
@@ -157,28 +190,29 @@ def other_workloads(rank, world, dist):
     from kyber_amd.pairing import bls12381 as bls, bn256 as bn
 
     out = {}
-    npair = 1 << 16
-    for name, m in (("bls12381", bls), ("bn256", bn)):
+    prof = _prof()
+    mads = _tvm_mads()
+    for name, m, npair in (("bls12381", bls, 1 << 16), ("bn256", bn, 1 << 18)):  # configs[3] / configs[4] sizes
         k = torch.from_numpy(be_scalars(b"kyberhip/v1/%s/k/%d" % (name.encode(), rank), npair)).cuda()
         h = torch.from_numpy(be_scalars(b"kyberhip/v1/%s/h/%d" % (name.encode(), rank), npair)).cuda()
         g1b = torch.from_numpy(np.frombuffer(m.G1_BASE, dtype=np.uint8).copy()).cuda()
         g2b = torch.from_numpy(np.frombuffer(m.G2_BASE, dtype=np.uint8).copy()).cuda()
         P, st1 = m._mul(1, h, g1b, True)
         Q, st2 = m._mul(2, k, g2b, True)
-        ms_pair = timed(lambda: m.batch_pair(P, Q), 2)
+        ms_pair = timed(lambda: m.batch_pair(P, Q))
         # valid BLS-verify shaped quadruples: e(H, X) == e(sig, G2) with sig = x H  (sign/bls/bls.go:36-38)
         sig, _ = m.g1_batch_mul(k, P)
         G2 = g2b.repeat(npair, 1)
         ok, st3 = m.batch_validate_pairing(P, Q, sig, G2)
-        ms_chk = timed(lambda: m.batch_validate_pairing(P, Q, sig, G2), 2)
-        ms_g1 = timed(lambda: m.g1_batch_mul(k, P), 2)
-        ms_g2 = timed(lambda: m.g2_batch_mul(k, Q), 2)
+        ms_chk = timed(lambda: m.batch_validate_pairing(P, Q, sig, G2))
+        ms_g1 = timed(lambda: m.g1_batch_mul(k, P))
+        ms_g2 = timed(lambda: m.g2_batch_mul(k, Q))
         # the same check as sign/bls Verify meets it: H(m) is the library's own output, the key X was unmarshalled
         # (validated) once when it was registered and G2.Base() is a constant -- only the signature is new input
         trust = m.F_TRUSTED(0) | m.F_TRUSTED(1) | m.F_TRUSTED(3)
         ok_t, st_t = m.batch_validate_pairing(P, Q, sig, G2, trust)
-        ms_chk_t = timed(lambda: m.batch_validate_pairing(P, Q, sig, G2, trust), 2)
-        ms_pair_t = timed(lambda: m.batch_pair(P, Q, m.F_TRUSTED(0) | m.F_TRUSTED(1)), 2)
+        ms_chk_t = timed(lambda: m.batch_validate_pairing(P, Q, sig, G2, trust))
+        ms_pair_t = timed(lambda: m.batch_pair(P, Q, m.F_TRUSTED(0) | m.F_TRUSTED(1)))
         t = torch.tensor([ms_pair, ms_chk, ms_g1, ms_g2, ms_chk_t, ms_pair_t], dtype=torch.float64, device="cuda")
         if dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -190,7 +224,15 @@ def other_workloads(rank, world, dist):
                      "pairings_per_s_validated_inputs": world * npair / ms_pair_t * 1e3,
                      "pairing_checks_per_s_only_sig_unvalidated": world * npair / ms_chk_t * 1e3,
                      "g1_muls_per_s": world * npair / ms_g1 * 1e3, "g2_muls_per_s": world * npair / ms_g2 * 1e3,
-                     "all_checks_true": good}
+                     "all_checks_true": good, "timing": "median of 20 launches after 5 warm-ups, HIP events"}
+        g1b_, g2b_ = m.G1_LEN, m.G2_LEN
+        # roofline of the pairing entry points: the MADs of the tower-machine program (operand unmarshalling and
+        # its subgroup checks are extra work inside the measured time, so the fraction is a lower bound for the
+        # machine itself; the validated-input figure is the machine alone plus a 5 % operand kernel)
+        out[name]["roofline"] = {
+            "pair": _roof(npair / ms_pair * 1e3, mads[name][0], g1b_ + g2b_ + m.GT_LEN, prof, name + "_pair"),
+            "pair_validated_inputs": _roof(npair / ms_pair_t * 1e3, mads[name][0], g1b_ + g2b_ + m.GT_LEN, prof, name + "_pair"),
+            "pair_check": _roof(npair / ms_chk * 1e3, mads[name][1], 2 * (g1b_ + g2b_) + 1, prof, name + "_check")}
         if True:
             # the whole sign/bls Verify pipeline on the device: Hash(msg) (bn256: SHA-256 + try-and-increment;
             # BLS12-381: RFC 9380 hash_to_curve) then the pairing check (sign/bls/bls.go:82-96), 32-byte messages
@@ -208,8 +250,8 @@ def other_workloads(rank, world, dist):
                 Hm, _ = m.batch_hash_g1(msgs)
                 return m.batch_validate_pairing(Hm, Q, sig, G2, trust)
 
-            ms_v = timed(verify, 2)
-            ms_vk = timed(verify_known_keys, 2)
+            ms_v = timed(verify)
+            ms_vk = timed(verify_known_keys)
             tv = torch.tensor([ms_v, ms_vk], dtype=torch.float64, device="cuda")
             if dist:
                 dist.all_reduce(tv, op=dist.ReduceOp.MAX)
@@ -226,7 +268,7 @@ def other_workloads(rank, world, dist):
                 fn = lambda: kd.bls12381_g1_msm(ks, pts)
             else:
                 fn = lambda: m.g1_msm(ks, pts)
-            ms = timed(fn, 2)
+            ms = timed(fn)
             # the reference's MSM-shaped call sites (PubPoly.Eval, bdn aggregation) sum kyber.Points that were
             # validated when unmarshalled: same MSM with the per-point subgroup re-check off, and with the points
             # kept in the uncompressed form (no square root either)
@@ -239,7 +281,7 @@ def other_workloads(rank, world, dist):
                 fn_t = lambda: m.g1_msm(ks, pts, tr)
                 fn_u = lambda: m.g1_msm(ks, pts_u, tr | m.F_UNCOMPRESSED)
             same = bytes(fn()[0].cpu().numpy()) == bytes(fn_t()[0].cpu().numpy()) == bytes(fn_u()[0].cpu().numpy())
-            ms_t, ms_u = timed(fn_t, 2), timed(fn_u, 2)
+            ms_t, ms_u = timed(fn_t), timed(fn_u)
             t = torch.tensor([ms, ms_t, ms_u], dtype=torch.float64, device="cuda")
             if dist:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -258,7 +300,7 @@ def other_workloads(rank, world, dist):
     ks = torch.from_numpy(s_all[lo:hi].copy()).cuda()
     pts = ed.batch_mul_base(torch.from_numpy(h_all[lo:hi].copy()).cuda())
     fn = (lambda: kd.ed25519_msm(ks, pts)) if dist else (lambda: ed.msm(ks, pts))
-    ms = timed(fn, 2)
+    ms = timed(fn)
     t = torch.tensor([ms], dtype=torch.float64, device="cuda")
     if dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -373,19 +415,21 @@ def main():
     if rank == 0:
         total_ops = 2 * n * args.steps * world
         var_s = var_ms_avg * 1e-3
-        try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "roofline_inputs.json")))
-        except Exception:
-            prof = {}
+        prof = _prof()
         imad_peak = prof.get("imad_peak_lane_ops_per_s")
-        traffic = prof.get("ed25519_mul_kernel_hbm_bytes_per_launch")
+        ked = prof.get("kernels", {}).get("ed25519_mul", {})
         res = {
             "metric": "scalar-muls/s + pairings/s per node; MSM sec at 2^20 points",
             "value": total_ops / elapsed,
             "unit": "scalar-muls/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak",
+            # BASELINE.md section 1 (docs/benchmark-app data.json:38-40, 14-16): one variable-base + one fixed-base
+            # Point.Mul cost the reference 349 399 + 60 658 ns on ONE core of unstated hardware = 4 877 scalar-muls/s
+            "vs_baseline": total_ops / elapsed / REF_SINGLE_CORE_PER_S,
+            "vs_baseline_note": "reference: 2 / (349399 ns + 60658 ns) = 4877 scalar-muls/s, single core, hardware "
+                                "unstated (BASELINE.md section 1); per node the reference publishes nothing",
             "dtype": "int32 limbs (radix 2^25.5), int64 accumulate", "data": "synthetic",
             "config": {"workload": "Ed25519 batched fixed-base + var-base scalar-mul, 2^20 scalars per GPU "
                                    "(BASELINE.json configs[1])",
@@ -395,17 +439,17 @@ def main():
                        "var_base_kernel_ms": var_ms_avg, "fixed_base_kernel_ms": fix_ms_avg,
                        "all_status_ok": ok,
                        "host_buffer_path_scalar_muls_per_s": host_rate},
-            "roofline": {"bound": "hbm", "kernel": "ed25519_mul_kernel (variable-base, dominant: ~80% of a step)",
-                         "achieved": BYTES_VAR * n / var_s / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": BYTES_VAR * n / var_s / 1e9 / HBM_PEAK_GBS,
-                         "traffic": traffic,
-                         "binding_resource": "integer VALU issue (v_mad_i64_i32), not HBM and not MFMA: "
-                                             "96 algorithmic bytes per 2.06e5 integer MADs -- see 'valu'",
-                         "valu": {"imads_per_op": IMADS_VAR, "achieved": IMADS_VAR * n / var_s,
-                                  "peak": imad_peak, "unit": "v_mad_i64_i32 lane-ops/s",
-                                  "frac": (IMADS_VAR * n / var_s / imad_peak) if imad_peak else None,
-                                  "peak_source": "tools/valu_peak.hip measured on MI355X (profiles/r01_valu_peak_v2.json, pure v_mad_u64_u32 chains)",
-                                  "valu_busy_frac_profiled": 0.99}},
+            "roofline": {"bound": "valu-imad",
+                         "kernel": "ed25519_mul_kernel (variable-base, dominant: ~85% of a step)",
+                         "binding_resource": "integer VALU issue (v_mad_i64_i32 at half rate): 96 algorithmic bytes per "
+                                             "2.06e5 integer MADs, no dense contraction for MFMA",
+                         "imads_per_op": IMADS_VAR, "achieved": IMADS_VAR * n / var_s, "peak": imad_peak,
+                         "unit": "lane-MAD/s", "frac": (IMADS_VAR * n / var_s / imad_peak) if imad_peak else None,
+                         "peak_source": prof.get("imad_peak_source"),
+                         "valu_busy_profiled": ked.get("valu_busy"), "valu_insts_per_op_profiled": ked.get("valu_insts_per_unit"),
+                         "traffic": ked.get("hbm_bytes_per_launch"), "profile": ked.get("source"),
+                         "hbm": {"achieved": BYTES_VAR * n / var_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": BYTES_VAR * n / var_s / 1e9 / HBM_PEAK_GBS}},
         }
         if other is not None:
             res["other_workloads"] = other

@@ -617,6 +617,18 @@ class Prog:
                 merged.append(s)
         return prog, merged
 
+    def mads(self):
+        """64-bit integer multiply-adds (v_mad_i64_i32) one pairing costs on the machine, summed over the twelve waves:
+        N^2 per product term, N^2 per Montgomery reduction (the algorithmic count the roofline is priced with)."""
+        n2 = self.f.N * self.f.N
+        total = 0
+        for start, ln, rep in self.sched:
+            for ins in self.ins[start:start + ln]:
+                for r in ins:
+                    if r["op"] == OP_DOT:
+                        total += rep * n2 * (sum(1 for t in r["terms"] if t[0] != "l") + (0 if r["raw"] else 1))
+        return total
+
     def stats(self):
         n_exec = sum(ln * rep for _, ln, rep in self.sched)
         prods = 0
@@ -1429,6 +1441,7 @@ def emit_prog(P, name):
         f"static __device__ const uint32_t TVM_{name}_CONSTS[{len(consts)}] = {_carr(consts)};",
         f"static constexpr uint32_t TVM_{name}_NCONSTS = {len(P.consts)};",
         f"static constexpr uint32_t TVM_{name}_NGSLOTS = {P.n_gslots}, TVM_{name}_NINPUTS = {P.n_inputs}, TVM_{name}_NSLOTS = {P.nslots};",
+        f"static constexpr uint64_t TVM_{name}_MADS_PER_UNIT = {P.mads()}ull;  // integer MADs per pairing (check), all waves",
         ""])
 
 
