@@ -24,57 +24,6 @@ __global__ __launch_bounds__(64) void bls12381_hash_g2_kernel(size_t n, const ui
     const int st = bls::hash_g2_wire(out + 96 * idx, msgs + msg_len * idx, msg_len, dst);
     if (status) status[idx] = (uint8_t)st;
 }
-// Operand kernels of the fused verification: one (key, message, signature) per lane -> the CHECK program's twelve
-// field elements + flag byte in the tower machine's workspace (bls12381_tvm.h).
-__device__ __forceinline__ void put_fp(uint32_t* in, size_t n, int idx, size_t i, const bls::fp& x) {
-    uint32_t* d = in + ((size_t)idx * n + i) * blsvm::FP_WORDS;
-#pragma unroll
-    for (int k = 0; k < blsvm::FP_WORDS; k += 4) *reinterpret_cast<uint4*>(d + k) = make_uint4(x.v[k], x.v[k + 1], x.v[k + 2], x.v[k + 3]);
-}
-__device__ __forceinline__ void put_operands(uint32_t* in, size_t n, size_t i, const bls::g1_aff& a1, const bls::g2_aff& a2,
-                                             const bls::g1_aff& b1, const bls::g2_aff& b2, uint8_t* fl, int st) {
-    const bls::g1_aff* p[2] = {&a1, &b1};
-    const bls::g2_aff* q[2] = {&a2, &b2};
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        put_fp(in, n, 6 * k, i, p[k]->x);
-        put_fp(in, n, 6 * k + 1, i, p[k]->y);
-        put_fp(in, n, 6 * k + 2, i, q[k]->x.c0);
-        put_fp(in, n, 6 * k + 3, i, q[k]->x.c1);
-        put_fp(in, n, 6 * k + 4, i, q[k]->y.c0);
-        put_fp(in, n, 6 * k + 5, i, q[k]->y.c1);
-    }
-    fl[i] = (uint8_t)(((a1.inf | a2.inf) ? blsvm::FL_DEAD_A : 0) | ((b1.inf | b2.inf) ? blsvm::FL_DEAD_B : 0) |
-                      (st ? blsvm::FL_REJECTED : 0));
-}
-__global__ __launch_bounds__(64) void bls12381_verify_g1_prep_kernel(size_t n, const uint8_t* __restrict__ pks,
-                                                                     const uint8_t* __restrict__ msgs, size_t msg_len,
-                                                                     bls::DstArg dst, const uint8_t* __restrict__ sigs,
-                                                                     uint32_t* __restrict__ in, uint8_t* __restrict__ fl,
-                                                                     uint8_t* __restrict__ status, uint32_t flags) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
-    bls::g1_aff a1, b1;
-    bls::g2_aff a2, b2;
-    const int st = bls::verify_g1_operands(a1, a2, b1, b2, pks + bls::g2_wire_size(flags) * idx, msgs + msg_len * idx, msg_len,
-                                           dst, sigs + bls::g1_wire_size(flags) * idx, flags);
-    put_operands(in, n, idx, a1, a2, b1, b2, fl, st);
-    if (status) status[idx] = (uint8_t)st;
-}
-__global__ __launch_bounds__(64) void bls12381_verify_g2_prep_kernel(size_t n, const uint8_t* __restrict__ pks,
-                                                                     const uint8_t* __restrict__ msgs, size_t msg_len,
-                                                                     bls::DstArg dst, const uint8_t* __restrict__ sigs,
-                                                                     uint32_t* __restrict__ in, uint8_t* __restrict__ fl,
-                                                                     uint8_t* __restrict__ status, uint32_t flags) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
-    bls::g1_aff a1, b1;
-    bls::g2_aff a2, b2;
-    const int st = bls::verify_g2_operands(a1, a2, b1, b2, pks + bls::g1_wire_size(flags) * idx, msgs + msg_len * idx, msg_len,
-                                           dst, sigs + bls::g2_wire_size(flags) * idx, flags);
-    put_operands(in, n, idx, a1, a2, b1, b2, fl, st);
-    if (status) status[idx] = (uint8_t)st;
-}
 }  // namespace kyb
 
 using namespace kyb;
@@ -163,10 +112,13 @@ int kyb_bls12381_verify_g1_dev(size_t n, const void* d_pks, const void* d_msgs, 
     std::lock_guard<std::recursive_mutex> enq_lock(ctx->enq_mu);
     blsvm::Work w;
     KYB_TRY(blsvm::workspace(ctx, (hipStream_t)stream, n, blsvm::CHECK_INPUTS, &w));
-    hipLaunchKernelGGL(bls12381_verify_g1_prep_kernel, dim3(grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n,
-                       (const uint8_t*)d_pks, (const uint8_t*)d_msgs, msg_len, d, (const uint8_t*)d_sigs, w.in, w.flags,
-                       (uint8_t*)d_status, flags);
-    return blsvm::launch_check(w, n, (uint8_t*)d_ok, (hipStream_t)stream);
+    // signatures on G1, keys on G2:  e(H(m), X) e(-sig, G2.Base()) == 1   (status precedence: key, then signature)
+    const blsvm::Operand ops[4] = {{(const uint8_t*)d_msgs, blsvm::OPND_G1_HASH, (uint32_t)msg_len, 0, 0, 0},
+                                   {(const uint8_t*)d_pks, blsvm::OPND_G2, (uint32_t)bls::g2_wire_size(flags), 2, 0, 0},
+                                   {(const uint8_t*)d_sigs, blsvm::OPND_G1, (uint32_t)bls::g1_wire_size(flags), 6, 1, 1},
+                                   {nullptr, blsvm::OPND_G2_GEN, 0, 8, 0, 0}};
+    KYB_TRY(blsvm::launch_prep(w, n, ops, 4, flags, dst, dst_len, (hipStream_t)stream));
+    return blsvm::launch_check(w, n, (uint8_t*)d_ok, (uint8_t*)d_status, (hipStream_t)stream);
 }
 int kyb_bls12381_verify_g1(size_t n, const uint8_t* pks, const uint8_t* msgs, size_t msg_len, const uint8_t* dst,
                            size_t dst_len, const uint8_t* sigs, uint8_t* ok, uint8_t* status, uint32_t flags) {
@@ -210,10 +162,13 @@ int kyb_bls12381_verify_g2_dev(size_t n, const void* d_pks, const void* d_msgs, 
     std::lock_guard<std::recursive_mutex> enq_lock(ctx->enq_mu);
     blsvm::Work w;
     KYB_TRY(blsvm::workspace(ctx, (hipStream_t)stream, n, blsvm::CHECK_INPUTS, &w));
-    hipLaunchKernelGGL(bls12381_verify_g2_prep_kernel, dim3(grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n,
-                       (const uint8_t*)d_pks, (const uint8_t*)d_msgs, msg_len, d, (const uint8_t*)d_sigs, w.in, w.flags,
-                       (uint8_t*)d_status, flags);
-    return blsvm::launch_check(w, n, (uint8_t*)d_ok, (hipStream_t)stream);
+    // signatures on G2, keys on G1:  e(G1.Base(), sig) e(-X, H(m)) == 1
+    const blsvm::Operand ops[4] = {{nullptr, blsvm::OPND_G1_GEN, 0, 0, 0, 0},
+                                   {(const uint8_t*)d_sigs, blsvm::OPND_G2, (uint32_t)bls::g2_wire_size(flags), 2, 0, 1},
+                                   {(const uint8_t*)d_pks, blsvm::OPND_G1, (uint32_t)bls::g1_wire_size(flags), 6, 1, 0},
+                                   {(const uint8_t*)d_msgs, blsvm::OPND_G2_HASH, (uint32_t)msg_len, 8, 0, 0}};
+    KYB_TRY(blsvm::launch_prep(w, n, ops, 4, flags, dst, dst_len, (hipStream_t)stream));
+    return blsvm::launch_check(w, n, (uint8_t*)d_ok, (uint8_t*)d_status, (hipStream_t)stream);
 }
 int kyb_bls12381_verify_g2(size_t n, const uint8_t* pks, const uint8_t* msgs, size_t msg_len, const uint8_t* dst,
                            size_t dst_len, const uint8_t* sigs, uint8_t* ok, uint8_t* status, uint32_t flags) {

@@ -8,22 +8,41 @@ namespace blsvm {
 constexpr int FP_WORDS = 12;          // packed Montgomery words of the per-lane field code (mont.cuh)
 constexpr int PAIR_INPUTS = 6;        // P.x, P.y, Q.x.c0, Q.x.c1, Q.y.c0, Q.y.c1
 constexpr int CHECK_INPUTS = 12;      // pair A, then pair B with P_B already negated
-// flag byte per pairing: bit 0 pair A has an operand at infinity, bit 1 pair B, bit 7 an input was rejected
-constexpr uint8_t FL_DEAD_A = 1, FL_DEAD_B = 2, FL_REJECTED = 0x80;
 
-// Workspace of one call: operand arrays [input][n][FP_WORDS], the flag bytes, and the machine's global scratch.
+// One point argument of a batch call, prepared by its own lanes (bls12381_prep.hip): n lanes per operand, so that the
+// G1 and G2 decompressions, subgroup checks and hashes of one pairing run side by side instead of one after the other
+// in a single lane (65 536 pairings are only one wave per SIMD; four operands are four).
+enum OperandKind : uint32_t { OPND_G1 = 0, OPND_G2 = 1, OPND_G1_HASH = 2, OPND_G2_HASH = 3, OPND_G1_GEN = 4, OPND_G2_GEN = 5 };
+struct Operand {
+    const uint8_t* src;  // wire encodings (messages for the hash kinds; unused for the generators)
+    uint32_t kind;
+    uint32_t stride;     // bytes per element of src (hash kinds: the message length)
+    uint32_t first;      // first input index it fills: a G1 point takes 2 field elements, a G2 point 4
+    uint32_t negate;     // store -P (the second pair of a product check)
+    uint32_t arg;        // position among the call's point arguments (KYB_F_TRUSTED bit) for the decode kinds
+};
+constexpr int MAX_OPERANDS = 4;
+// status byte per (operand, pairing): bits 0-6 the UnmarshalBinary status, bit 7 the point is at infinity.  The
+// machine derives its lane flags from them: operands 0, 1 form pair A, operands 2, 3 pair B.
+constexpr uint8_t PST_INF = 0x80;
+
+// Workspace of one call: operand arrays [input][n][FP_WORDS], the per-operand status bytes, the machine's global scratch.
 struct Work {
     uint32_t* in;
-    uint8_t* flags;
+    uint8_t* pst;
     uint32_t* gspill;
     unsigned grid;
 };
+// Enqueue the operand kernel: ops[0 .. nops) -> w.in / w.pst.  dst: the hash-to-curve tag of the hash kinds.
+int launch_prep(const Work& w, size_t n, const Operand* ops, int nops, uint32_t flags, const uint8_t* dst, size_t dst_len,
+                hipStream_t st);
 // Takes the (WS_PAIR, stream) workspace for n pairings with `ninputs` operands each.  The caller holds ctx->enq_mu
 // from here until the machine is enqueued.
 int workspace(DeviceCtx* ctx, hipStream_t st, size_t n, int ninputs, Work* w);
-// Enqueue the PAIR program: GT bytes (576 per pairing) from the operands in `w`.
-int launch_pair(const Work& w, size_t n, uint8_t* d_gt, hipStream_t st);
+// Enqueue the PAIR program: GT bytes (576 per pairing) from the operands in `w`; d_status (may be null) receives the
+// first non-zero operand status of every pairing.
+int launch_pair(const Work& w, size_t n, uint8_t* d_gt, uint8_t* d_status, hipStream_t st);
 // Enqueue the CHECK program: one boolean per pairing.
-int launch_check(const Work& w, size_t n, uint8_t* d_ok, hipStream_t st);
+int launch_check(const Work& w, size_t n, uint8_t* d_ok, uint8_t* d_status, hipStream_t st);
 }  // namespace blsvm
 }  // namespace kyb

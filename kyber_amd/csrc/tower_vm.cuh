@@ -59,7 +59,10 @@ struct Args {
                              // copies them into LDS (MAX_CONSTS)
     uint32_t nconsts;
     const uint32_t* in;      // inputs: [input index][pairing][WORDS_IN] packed Montgomery words of the per-lane field code
-    const uint8_t* flags;    // per pairing: bit 0 pair A dead (an operand at infinity), bit 1 pair B dead, bit 7 rejected
+    const uint8_t* pst;      // [operand][pairing] status bytes of the operand kernel: bits 0-6 UnmarshalBinary status, bit 7
+                             // the point is at infinity; operands 0, 1 = pair A, 2, 3 = pair B
+    uint32_t npst;
+    uint8_t* status;         // out, may be null: first non-zero operand status per pairing
     uint8_t* out;            // GT bytes or result booleans
     size_t n;                // pairings
     uint32_t out_stride;     // bytes per pairing in `out`
@@ -223,7 +226,15 @@ __device__ void run(const Args& a, uint32_t* lds, uint32_t* misc, const int32_t*
         const size_t pairing = batch * LANES + lane;
         const bool valid = pairing < a.n;
         const size_t pidx = valid ? pairing : a.n - 1;  // out-of-range lanes recompute the last pairing, store nothing
-        const uint32_t fl = a.flags ? a.flags[pidx] : 0u;
+        // lane flags: bit 0 pair A dead (an operand at infinity), bit 1 pair B dead, bit 7 an operand was rejected
+        uint32_t fl = 0, first_st = 0;
+        for (uint32_t k = 0; k < a.npst; k++) {
+            const uint32_t b = a.pst[(size_t)k * a.n + pidx];
+            if ((b & 0x7fu) && !first_st) first_st = b & 0x7fu;
+            if (b & 0x80u) fl |= k < 2 ? 1u : 2u;
+        }
+        if (first_st) fl |= 0x80u;
+        if (a.status && wave == 0 && valid) a.status[pairing] = (uint8_t)first_st;
         if (wave == 0) misc[lane] = 0;
         __syncthreads();
         // The schedule is walked one instruction AHEAD: the record of the next instruction is requested before the
