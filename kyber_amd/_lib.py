@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libkyberhip.so")
+LIB_PATH = os.environ.get("KYBER_HIP_LIB") or os.path.join(_HERE, "lib", "libkyberhip.so")  # override: A/B builds
 
 KYB_F_VARTIME = 1
 ST_OK, ST_BAD_POINT, ST_NOT_IN_SUBGROUP = 0, 1, 2
