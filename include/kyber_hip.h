@@ -20,6 +20,15 @@
  *     and synchronise.
  *   - all entry points are thread-safe; state is a per-device context that is
  *     created on first use on the calling thread's current HIP device.
+ *
+ * TIMING: NOTHING IN THIS LIBRARY IS CONSTANT-TIME.  Results equal the
+ * reference's on every input, but window tables are indexed by scalar digits
+ * (through L2), exceptional additions branch, field inversion is a
+ * data-dependent loop and KYB_F_VARTIME skips leading zero windows.  A suite
+ * built on it belongs in suites/all_vartime.go only and must not be offered
+ * where suites.RequireConstantTime (suites/suites.go:67) is expected to hold
+ * (the reference's default Ed25519 Mul scans its table with CMove,
+ * group/edwards25519/ge.go:419-435).  See INTEGRATION.md section 2b.
  */
 #ifndef KYBER_HIP_H
 #define KYBER_HIP_H
@@ -43,8 +52,9 @@ extern "C" {
 
 /* flags */
 #define KYB_F_VARTIME 1u /* Ed25519: geScalarMultVartime semantics (all 256 scalar bits honoured,
-                            group/edwards25519/ge_mult_vartime.go:11). Default = constant-time
-                            path semantics of ge.go:443 incl. its >= 2^255 behaviour. */
+                            group/edwards25519/ge_mult_vartime.go:11) and leading zero
+                            windows skipped per wave. Default = the VALUE semantics of the reference's
+                            constant-time path ge.go:443 incl. its >= 2^255 behaviour (not its timing). */
 
 /* Pairing-suite calls (trailing `flags` argument of mul / msm / pair / pair_check / verify):
  *  KYB_F_UNCOMPRESSED  BLS12-381 point INPUTS are ZCash uncompressed affine (G1 96 B x||y, G2 192 B
