@@ -390,183 +390,6 @@ KYB_HD_NOINLINE void gt_pow_u256(fp12& r, const fp12& a, const uint32_t (&k)[8])
 // 32-byte big-endian scalar (mod.Int wire format, group/mod/int.go:334-350) -> little-endian words
 KYB_HD void scalar_from_be(uint32_t (&k)[8], const uint8_t* in) { words_from_be<8>(k, in); }
 
-// ------------------------------------------------------------------- pairing
-// One step of the Miller loop works on T in Jacobian coordinates on the twist and returns the
-// line through T (tangent, or chord to Q) evaluated at P as the sparse element
-//   o0 + (o1 xP) v + (o4 yP) v w       (w-basis positions 0, 2, 3), scaled by a factor in Fp2.
-KYB_HD_NOINLINE void miller_dbl_line(fp2& o0, fp2& o1, fp2& o4, g2_jac& t, const fp& xp, const fp& yp) {
-    fp2 A, B, C, D, E, G, Z2, u;
-    fp2_sqr(A, t.X);
-    fp2_sqr(B, t.Y);
-    fp2_sqr(C, B);
-    fp2_add(u, t.X, B);
-    fp2_sqr(u, u);
-    fp2_sub(u, u, A);
-    fp2_sub(u, u, C);
-    fp2_dbl(D, u);
-    fp2_dbl(E, A);
-    fp2_add(E, E, A);
-    fp2_sqr(G, E);
-    fp2_sqr(Z2, t.Z);
-    // line: (3X^3 - 2Y^2) , -(3X^2 Z^2) xP , (Z3 Z^2) yP
-    fp2_mul(o0, E, t.X);
-    fp2_dbl(u, B);
-    fp2_sub(o0, o0, u);
-    fp2_mul(o1, E, Z2);
-    fp2_neg(o1, o1);
-    fp2_mul_fp(o1, o1, xp);
-    // T = 2T
-    fp2_add(u, t.Y, t.Z);
-    fp2_sqr(u, u);
-    fp2_sub(u, u, B);
-    fp2_sub(t.Z, u, Z2);  // 2 Y Z
-    fp2_dbl(u, D);
-    fp2_sub(t.X, G, u);
-    fp2_sub(u, D, t.X);
-    fp2_mul(u, E, u);
-    fp2_dbl(C, C);
-    fp2_dbl(C, C);
-    fp2_dbl(C, C);
-    fp2_sub(t.Y, u, C);
-    fp2_mul(o4, t.Z, Z2);
-    fp2_mul_fp(o4, o4, yp);
-}
-KYB_HD_NOINLINE void miller_add_line(fp2& o0, fp2& o1, fp2& o4, g2_jac& t, const g2_aff& q, const fp& xp,
-                                     const fp& yp) {
-    fp2 Z2, U2, S2, H, rr, Z3, HH, HHH, V, u;
-    fp2_sqr(Z2, t.Z);
-    fp2_mul(U2, q.x, Z2);
-    fp2_mul(S2, Z2, t.Z);
-    fp2_mul(S2, q.y, S2);
-    fp2_sub(H, U2, t.X);
-    fp2_sub(rr, S2, t.Y);
-    fp2_mul(Z3, t.Z, H);
-    // line: rr x2 - y2 Z3 , -rr xP , Z3 yP
-    fp2_mul(o0, rr, q.x);
-    fp2_mul(u, q.y, Z3);
-    fp2_sub(o0, o0, u);
-    fp2_neg(o1, rr);
-    fp2_mul_fp(o1, o1, xp);
-    fp2_mul_fp(o4, Z3, yp);
-    // T = T + Q
-    fp2_sqr(HH, H);
-    fp2_mul(HHH, H, HH);
-    fp2_mul(V, t.X, HH);
-    fp2_sqr(u, rr);
-    fp2_sub(u, u, HHH);
-    fp2_sub(u, u, V);
-    fp2_sub(u, u, V);
-    fp2 y3;
-    fp2_sub(y3, V, u);
-    fp2_mul(y3, rr, y3);
-    fp2_mul(HHH, t.Y, HHH);
-    fp2_sub(t.Y, y3, HHH);
-    t.X = u;
-    t.Z = Z3;
-}
-// f_{|x|,Q}(P), conjugated because x < 0.  P or Q at infinity gives one.
-KYB_HD_NOINLINE void miller_loop(fp12& f, const g1_aff& p, const g2_aff& q) {
-    fp12_one(f);
-    g2_jac t;
-    jac_from_aff(t, q);
-    fp2 o0, o1, o4;
-#pragma unroll 1
-    for (int i = 62; i >= 0; i--) {
-        miller_dbl_line(o0, o1, o4, t, p.x, p.y);
-        if (i != 62) fp12_sqr(f, f);  // f = 1 before the first step
-        fp12_mul_by_014(f, o0, o1, o4);
-        if ((CC::X_ABS >> i) & 1) {
-            miller_add_line(o0, o1, o4, t, q, p.x, p.y);
-            fp12_mul_by_014(f, o0, o1, o4);
-        }
-    }
-    fp12_conj(f, f);
-    if (p.inf | q.inf) fp12_one(f);
-}
-// f_{|x|,Q1}(P1) * f_{|x|,Q2}(P2) with the squarings shared (one Fp12 squaring per bit for both
-// pairs), conjugated.  A pair with an operand at infinity contributes one.
-KYB_HD_NOINLINE void miller_loop2(fp12& f, const g1_aff& p1, const g2_aff& q1, const g1_aff& p2, const g2_aff& q2) {
-    fp12_one(f);
-    g2_jac t1, t2;
-    jac_from_aff(t1, q1);
-    jac_from_aff(t2, q2);
-    const bool live1 = !(p1.inf | q1.inf), live2 = !(p2.inf | q2.inf);
-    fp2 o0, o1, o4;
-#pragma unroll 1
-    for (int i = 62; i >= 0; i--) {
-        if (i != 62) fp12_sqr(f, f);
-        miller_dbl_line(o0, o1, o4, t1, p1.x, p1.y);
-        if (live1) fp12_mul_by_014(f, o0, o1, o4);
-        miller_dbl_line(o0, o1, o4, t2, p2.x, p2.y);
-        if (live2) fp12_mul_by_014(f, o0, o1, o4);
-        if ((CC::X_ABS >> i) & 1) {
-            miller_add_line(o0, o1, o4, t1, q1, p1.x, p1.y);
-            if (live1) fp12_mul_by_014(f, o0, o1, o4);
-            miller_add_line(o0, o1, o4, t2, q2, p2.x, p2.y);
-            if (live2) fp12_mul_by_014(f, o0, o1, o4);
-        }
-    }
-    fp12_conj(f, f);
-}
-// a^|x| then conjugate (x < 0); a in the cyclotomic subgroup
-KYB_HD_NOINLINE void cyclo_pow_x(fp12& r, const fp12& a) {
-    fp12 acc = a;
-    int run = 0;
-#pragma unroll 1
-    for (int i = 62; i >= 0; i--) {
-        run++;
-        if (((CC::X_ABS >> i) & 1) || i == 0) {  // |x| has 6 set bits: 5 multiplications, runs of up to 32 squarings
-            fp12_cyclo_sqr_n(acc, acc, run);
-            run = 0;
-            if ((CC::X_ABS >> i) & 1) fp12_mul(acc, acc, a);
-        }
-    }
-    fp12_conj(r, acc);
-}
-KYB_HD_NOINLINE void cyclo_pow_words(fp12& r, const fp12& a, const uint32_t* e, int nbits) {
-    fp12 acc = a;
-    int run = 0;
-#pragma unroll 1
-    for (int i = nbits - 2; i >= 0; i--) {
-        run++;
-        const bool bit = (e[i >> 5] >> (i & 31)) & 1;
-        if (bit || i == 0) {
-            fp12_cyclo_sqr_n(acc, acc, run);
-            run = 0;
-            if (bit) fp12_mul(acc, acc, a);
-        }
-    }
-    r = acc;
-}
-// f^(3 (p^12 - 1) / r): the exponent of the reference's kilic backend (three times the canonical one, see
-// oracle/bls12381.py final_exp and gen_tower_vm.py; the batch entry points run the five-exponentiation chain on the
-// tower machine -- this per-lane form serves the fused verification kernels and the host test harness).
-// Hard part: (p^4 - p^2 + 1)/r = l0 + l1 p + l2 p^2 + l3 p^3 with l3 = (x-1)^2/3, l2 = x l3,
-// l1 = x l2 - l3, l0 = x l1 + 1 (checked in gen_consts.py), then the cube.
-KYB_HD_NOINLINE void final_exp(fp12& r, const fp12& f) {
-    fp12 g, t, t3, t2, t1, t0;
-    fp12_conj(g, f);
-    fp12_inv(t, f);
-    fp12_mul(g, g, t);  // f^(p^6 - 1)
-    fp12_frob<TC, 2>(t, g);
-    fp12_mul(g, t, g);  // ^(p^2 + 1): now in the cyclotomic subgroup
-    cyclo_pow_words(t3, g, CC::LAMBDA3, CC::LAMBDA3_BITS);
-    cyclo_pow_x(t2, t3);
-    cyclo_pow_x(t1, t2);
-    fp12_conj(t, t3);
-    fp12_mul(t1, t1, t);
-    cyclo_pow_x(t0, t1);
-    fp12_mul(t0, t0, g);
-    fp12_frob<TC, 1>(t, t1);
-    fp12_mul(t0, t0, t);
-    fp12_frob<TC, 2>(t, t2);
-    fp12_mul(t0, t0, t);
-    fp12_frob<TC, 3>(t, t3);
-    fp12_mul(t0, t0, t);
-    fp12_cyclo_sqr(t, t0);
-    fp12_mul(r, t, t0);
-}
-
 // ------------------------------------------------- endomorphism-accelerated scalar multiplication
 // Points that passed (or are vouched for by KYB_F_TRUSTED) the subgroup check satisfy phi(P) = [-z^2] P on G1 and
 // psi(Q) = [z] Q on G2 (z = -X_ABS) -- the relations the checks themselves test.  Splitting the scalar in base z^2
@@ -829,45 +652,5 @@ KYB_HD int gt_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* gt
     gt_encode(out, f);
     return ST_OK;
 }
-// gt = e(P, Q)   (Suite.Pair, kilic/suite.go:70-75)
-KYB_HD int pair_wire(uint8_t* gt, const uint8_t* g1, const uint8_t* g2, uint32_t flags = 0) {
-    g1_aff p;
-    g2_aff q;
-    int st = g1_decode_f(p, g1, flags, 0);
-    const int st2 = g2_decode_f(q, g2, flags, 1);
-    if (st == ST_OK) st = st2;
-    if (st != ST_OK) {
-        zero_bytes(gt, 576);
-        return st;
-    }
-    fp12 f;
-    miller_loop(f, p, q);
-    final_exp(f, f);
-    gt_encode(gt, f);
-    return ST_OK;
-}
-// ok = (e(p1, p2) == e(inv1, inv2))   (Suite.ValidatePairing, pairing/pairing.go:13-15,
-// kilic/suite.go:57-68: AddPair(p1, p2); AddPairInv(inv1, inv2); Check())
-KYB_HD int pair_check_wire(uint8_t* ok, const uint8_t* p1, const uint8_t* p2, const uint8_t* inv1,
-                           const uint8_t* inv2, uint32_t flags = 0) {
-    g1_aff a, c;
-    g2_aff b, d;
-    int st = g1_decode_f(a, p1, flags, 0);
-    int s2 = g2_decode_f(b, p2, flags, 1);
-    if (st == ST_OK) st = s2;
-    s2 = g1_decode_f(c, inv1, flags, 2);
-    if (st == ST_OK) st = s2;
-    s2 = g2_decode_f(d, inv2, flags, 3);
-    if (st == ST_OK) st = s2;
-    *ok = 0;
-    if (st != ST_OK) return st;
-    fp_neg(c.y, c.y);
-    fp12 f;
-    miller_loop2(f, a, b, c, d);
-    final_exp(f, f);
-    *ok = fp12_is_one(f) ? 1 : 0;
-    return ST_OK;
-}
-
 }  // namespace bls
 }  // namespace kyb

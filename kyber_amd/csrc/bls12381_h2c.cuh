@@ -178,32 +178,6 @@ KYB_HD_NOINLINE void hash_g1_point(g1_jac& r, const uint8_t* msg, size_t msg_len
     jac_add(r, q0, q1);
     jac_mul_u64(r, r, 0xd201000000010001ull);
 }
-// One whole sign/bls Verify (scheme with signatures on G1, keys on G2; sign/bls/bls.go:82-96 with the pairing
-// closure of bls.go:36-38): ok = e(H(msg), X) == e(sig, G2.Base()), where X and sig are unmarshalled with the
-// adapter's checks and H(msg) never leaves the lane -- no encode / re-decode / re-check of the hashed point, and
-// the G2 generator is a constant instead of a decoded operand.
-KYB_HD int verify_g1_wire(uint8_t* ok, const uint8_t* pk96, const uint8_t* msg, size_t msg_len, const DstArg& dst,
-                          const uint8_t* sig48, uint32_t flags = 0) {
-    g1_aff s, h;
-    g2_aff x, g;
-    *ok = 0;
-    int st = g2_decode_f(x, pk96, flags, 0);
-    const int st2 = g1_decode_f(s, sig48, flags, 1);
-    if (st == ST_OK) st = st2;
-    if (st != ST_OK) return st;
-    g1_jac hj;
-    hash_g1_point(hj, msg, msg_len, dst);
-    jac_to_aff(h, hj);
-    fp2_load_const<TC>(g.x, CC::G2X);
-    fp2_load_const<TC>(g.y, CC::G2Y);
-    g.inf = false;
-    fp_neg(s.y, s.y);
-    fp12 f;
-    miller_loop2(f, h, x, s, g);
-    final_exp(f, f);
-    *ok = fp12_is_one(f) ? 1 : 0;
-    return ST_OK;
-}
 
 // ------------------------------------------------------------------ G2
 KYB_HD void g2_curve_rhs(fp2& g, const fp2& x) {
@@ -320,31 +294,6 @@ KYB_HD_NOINLINE void hash_g2_point(g2_jac& r, const uint8_t* msg, size_t msg_len
     g2_iso_map(q1, x, y);
     jac_add(r, q0, q1);
     g2_clear_cofactor(r, r);
-}
-// One whole sign/bls Verify for the scheme with signatures on G2 and keys on G1 (NewSchemeOnG2, sign/bls/bls.go:48-58:
-// ValidatePairing(G1.Base(), sig, X, H(msg))): ok = e(G1.Base(), sig) == e(X, H(msg)), hashing, both unmarshal checks,
-// two Miller loops sharing their squarings and one final exponentiation per lane.  Trusted(0) = keys, (1) = signatures.
-KYB_HD int verify_g2_wire(uint8_t* ok, const uint8_t* pk48, const uint8_t* msg, size_t msg_len, const DstArg& dst,
-                          const uint8_t* sig96, uint32_t flags = 0) {
-    g1_aff x, g;
-    g2_aff s, h;
-    *ok = 0;
-    int st = g1_decode_f(x, pk48, flags, 0);
-    const int st2 = g2_decode_f(s, sig96, flags, 1);
-    if (st == ST_OK) st = st2;
-    if (st != ST_OK) return st;
-    g2_jac hj;
-    hash_g2_point(hj, msg, msg_len, dst);
-    jac_to_aff(h, hj);
-    fp_const(g.x, CC::G1X);
-    fp_const(g.y, CC::G1Y);
-    g.inf = false;
-    fp_neg(x.y, x.y);  // e(G1, sig) * e(-X, H) == 1
-    fp12 f;
-    miller_loop2(f, g, s, x, h);
-    final_exp(f, f);
-    *ok = fp12_is_one(f) ? 1 : 0;
-    return ST_OK;
 }
 // The operand side of a whole sign/bls Verify for the batch engine: unmarshal key and signature with the adapter's
 // checks, hash the message, and hand the two pairs of the product check

@@ -118,226 +118,6 @@ KYB_HD_NOINLINE void gt_encode(uint8_t* out, const fp12& f) {
     }
 }
 
-// ------------------------------------------------------------------- pairing
-struct twist_pt {  // Jacobian with t = z^2 cached, as twistPoint (twist.go:12-14)
-    fp2 x, y, z, t;
-};
-
-// ret *= (a tau + b) omega + c        (mulLine, optate.go:96-115; 13 Fp2 multiplications)
-KYB_HD void mul_line_inl(fp12& ret, const fp2& a, const fp2& b, const fp2& c) {
-    fp6 a2, t3, t2, s;
-    fp2 t;
-    fp6_mul_by_01(a2, ret.c1, b, a);
-    fp6_mul_fp2(t3, ret.c0, c);
-    fp2_add(t, b, c);
-    fp6_add(s, ret.c1, ret.c0);
-    fp6_mul_by_01(t2, s, t, a);
-    fp6_sub(t2, t2, a2);
-    fp6_sub(ret.c1, t2, t3);
-    fp6_mul_v(a2, a2);
-    fp6_add(ret.c0, t3, a2);
-}
-KYB_HD_NOINLINE void mul_line(fp12& ret, const fp2& a, const fp2& b, const fp2& c) { mul_line_inl(ret, a, b, c); }
-// lineFunctionDouble (optate.go:54-94): r <- 2r, line coefficients (a, b, c)
-KYB_HD_NOINLINE void line_double(fp2& a, fp2& b, fp2& c, twist_pt& r, const fp& qx, const fp& qy) {
-    fp2 A, B, C, D, E, G, t;
-    twist_pt o;
-    fp2_sqr(A, r.x);
-    fp2_sqr(B, r.y);
-    fp2_sqr(C, B);
-    fp2_add(D, r.x, B);
-    fp2_sqr(D, D);
-    fp2_sub(D, D, A);
-    fp2_sub(D, D, C);
-    fp2_dbl(D, D);
-    fp2_dbl(E, A);
-    fp2_add(E, E, A);
-    fp2_sqr(G, E);
-    fp2_sub(o.x, G, D);
-    fp2_sub(o.x, o.x, D);
-    fp2_add(o.z, r.y, r.z);
-    fp2_sqr(o.z, o.z);
-    fp2_sub(o.z, o.z, B);
-    fp2_sub(o.z, o.z, r.t);
-    fp2_sub(o.y, D, o.x);
-    fp2_mul(o.y, o.y, E);
-    fp2_dbl(t, C);
-    fp2_dbl(t, t);
-    fp2_dbl(t, t);
-    fp2_sub(o.y, o.y, t);
-    fp2_sqr(o.t, o.z);
-    fp2_mul(t, E, r.t);
-    fp2_dbl(t, t);
-    fp2_neg(b, t);
-    fp2_mul_fp(b, b, qx);
-    fp2_add(a, r.x, E);
-    fp2_sqr(a, a);
-    fp2_sub(a, a, A);
-    fp2_sub(a, a, G);
-    fp2_dbl(t, B);
-    fp2_dbl(t, t);
-    fp2_sub(a, a, t);
-    fp2_mul(c, o.z, r.t);
-    fp2_dbl(c, c);
-    fp2_mul_fp(c, c, qy);
-    r = o;
-}
-// lineFunctionAdd (optate.go:5-52): r <- r + p (p affine on the twist, r2 = p.y^2)
-KYB_HD_NOINLINE void line_add(fp2& a, fp2& b, fp2& c, twist_pt& r, const fp2& px, const fp2& py, const fp2& r2,
-                              const fp& qx, const fp& qy) {
-    fp2 B, D, H, I, E, J, L1, V, t, t2;
-    twist_pt o;
-    fp2_mul(B, px, r.t);
-    fp2_add(D, py, r.z);
-    fp2_sqr(D, D);
-    fp2_sub(D, D, r2);
-    fp2_sub(D, D, r.t);
-    fp2_mul(D, D, r.t);
-    fp2_sub(H, B, r.x);
-    fp2_sqr(I, H);
-    fp2_dbl(E, I);
-    fp2_dbl(E, E);
-    fp2_mul(J, H, E);
-    fp2_sub(L1, D, r.y);
-    fp2_sub(L1, L1, r.y);
-    fp2_mul(V, r.x, E);
-    fp2_sqr(o.x, L1);
-    fp2_sub(o.x, o.x, J);
-    fp2_sub(o.x, o.x, V);
-    fp2_sub(o.x, o.x, V);
-    fp2_add(o.z, r.z, H);
-    fp2_sqr(o.z, o.z);
-    fp2_sub(o.z, o.z, r.t);
-    fp2_sub(o.z, o.z, I);
-    fp2_sub(t, V, o.x);
-    fp2_mul(t, t, L1);
-    fp2_mul(t2, r.y, J);
-    fp2_dbl(t2, t2);
-    fp2_sub(o.y, t, t2);
-    fp2_sqr(o.t, o.z);
-    fp2_add(t, py, o.z);
-    fp2_sqr(t, t);
-    fp2_sub(t, t, r2);
-    fp2_sub(t, t, o.t);
-    fp2_mul(t2, L1, px);
-    fp2_dbl(t2, t2);
-    fp2_sub(a, t2, t);
-    fp2_mul_fp(c, o.z, qy);
-    fp2_dbl(c, c);
-    fp2_neg(b, L1);
-    fp2_mul_fp(b, b, qx);
-    fp2_dbl(b, b);
-    r = o;
-}
-// miller (optate.go:126-213); q, p affine and finite
-KYB_HD_NOINLINE void miller(fp12& ret, const g2_aff& q, const g1_aff& p) {
-    fp12_one(ret);
-    twist_pt r;
-    r.x = q.x;
-    r.y = q.y;
-    fp2_one(r.z);
-    fp2_one(r.t);
-    fp2 r2, a, b, c, my;
-    fp2_sqr(r2, q.y);
-    fp2_neg(my, q.y);
-#pragma unroll 1
-    for (int i = CC::NAF_LEN - 1; i > 0; i--) {
-        line_double(a, b, c, r, p.x, p.y);
-        if (i != CC::NAF_LEN - 1) fp12_sqr(ret, ret);
-        mul_line(ret, a, b, c);
-        const int k = i - 1;
-        const bool plus = k < 64 ? ((CC::NAF_PLUS_LO >> k) & 1) : ((CC::NAF_PLUS_HI >> (k - 64)) & 1);
-        const bool minus = k < 64 ? ((CC::NAF_MINUS_LO >> k) & 1) : ((CC::NAF_MINUS_HI >> (k - 64)) & 1);
-        if (plus) {
-            line_add(a, b, c, r, q.x, q.y, r2, p.x, p.y);
-            mul_line(ret, a, b, c);
-        } else if (minus) {
-            line_add(a, b, c, r, q.x, my, r2, p.x, p.y);
-            mul_line(ret, a, b, c);
-        }
-    }
-    // Q1 = Frobenius(Q), -Q2 = -Frobenius^2(Q) on the twist (optate.go:182-207)
-    fp2 q1x, q1y, k;
-    fp2_conj(q1x, q.x);
-    fp2_load_const<TC>(k, CC::Q1X);
-    fp2_mul_c(q1x, q1x, k);
-    fp2_conj(q1y, q.y);
-    fp2_load_const<TC>(k, CC::Q1Y);
-    fp2_mul_c(q1y, q1y, k);
-    fp2_sqr_c(r2, q1y);
-    line_add(a, b, c, r, q1x, q1y, r2, p.x, p.y);
-    mul_line(ret, a, b, c);
-    fp q2k;
-    fp_const(q2k, CC::Q2X);
-    fp2 q2x;
-    fp2_mul_fp(q2x, q.x, q2k);
-    fp2_sqr_c(r2, q.y);
-    line_add(a, b, c, r, q2x, q.y, r2, p.x, p.y);
-    mul_line(ret, a, b, c);
-}
-// gfP12.Exp(a, u) (gfp12.go:177-192), u = 6518589491078791937 (63 bits)
-KYB_HD_NOINLINE void pow_u(fp12& r, const fp12& a) {
-    fp12 acc = a;
-    int run = 0;
-#pragma unroll 1
-    for (int i = 61; i >= 0; i--) {
-        run++;  // squarings (inputs are in the cyclotomic subgroup: equal to gfP12.Square there) batched per run
-        if (((CC::U >> i) & 1) || i == 0) {
-            fp12_cyclo_sqr_n(acc, acc, run);
-            run = 0;
-            if ((CC::U >> i) & 1) fp12_mul(acc, acc, a);
-        }
-    }
-    r = acc;
-}
-// finalExponentiation (optate.go:215-264), same addition chain
-KYB_HD_NOINLINE void final_exp(fp12& out, const fp12& in) {
-    fp12 t1, t2, inv, fp_, fp2_, fp3_, fu, fu2, fu3, y0, y1, y2, y3, y4, y5, y6, fu2p, fu3p, t0;
-    fp12_conj(t1, in);
-    fp12_inv(inv, in);
-    fp12_mul(t1, t1, inv);
-    fp12_frob<TC, 2>(t2, t1);
-    fp12_mul(t1, t1, t2);
-    fp12_frob<TC, 1>(fp_, t1);
-    fp12_frob<TC, 2>(fp2_, t1);
-    fp12_frob<TC, 1>(fp3_, fp2_);
-    pow_u(fu, t1);
-    pow_u(fu2, fu);
-    pow_u(fu3, fu2);
-    fp12_frob<TC, 1>(y3, fu);
-    fp12_frob<TC, 1>(fu2p, fu2);
-    fp12_frob<TC, 1>(fu3p, fu3);
-    fp12_frob<TC, 2>(y2, fu2);
-    fp12_mul(y0, fp_, fp2_);
-    fp12_mul(y0, y0, fp3_);
-    fp12_conj(y1, t1);
-    fp12_conj(y5, fu2);
-    fp12_conj(y3, y3);
-    fp12_mul(y4, fu, fu2p);
-    fp12_conj(y4, y4);
-    fp12_mul(y6, fu3, fu3p);
-    fp12_conj(y6, y6);
-    fp12_sqr(t0, y6);
-    fp12_mul(t0, t0, y4);
-    fp12_mul(t0, t0, y5);
-    fp12_mul(t1, y3, y5);
-    fp12_mul(t1, t1, t0);
-    fp12_mul(t0, t0, y2);
-    fp12_sqr(t1, t1);
-    fp12_mul(t1, t1, t0);
-    fp12_sqr(t1, t1);
-    fp12_mul(t0, t1, y1);
-    fp12_mul(t1, t1, y0);
-    fp12_sqr(t0, t0);
-    fp12_mul(out, t0, t1);
-}
-// optimalAte (optate.go:266-274)
-KYB_HD void optimal_ate(fp12& f, const g2_aff& q, const g1_aff& p) {
-    miller(f, q, p);
-    final_exp(f, f);
-    if (q.inf | p.inf) fp12_one(f);
-}
-
 // pointGT.UnmarshalBinary (point.go:664-716): twelve coefficients reduced mod p, no membership check
 KYB_HD_NOINLINE void gt_decode(fp12& f, const uint8_t* in) {
 #pragma unroll
@@ -607,42 +387,5 @@ KYB_HD int gt_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* gt
     gt_encode(out, f);
     return ST_OK;
 }
-// gt = e(g1, g2)   (Suite.Pair, suite.go:97-103)
-KYB_HD int pair_wire(uint8_t* gt, const uint8_t* g1, const uint8_t* g2, uint32_t = 0) {
-    g1_aff p;
-    g2_aff q;
-    int st = g1_decode(p, g1);
-    const int st2 = g2_decode(q, g2);
-    if (st == ST_OK) st = st2;
-    if (st != ST_OK) {
-        zero_bytes(gt, 384);
-        return st;
-    }
-    fp12 f;
-    optimal_ate(f, q, p);
-    gt_encode(gt, f);
-    return ST_OK;
-}
-// ok = Pair(p1, p2).Equal(Pair(inv1, inv2))   (Suite.ValidatePairing, suite.go:105-107)
-KYB_HD int pair_check_wire(uint8_t* ok, const uint8_t* p1, const uint8_t* p2, const uint8_t* inv1,
-                           const uint8_t* inv2, uint32_t = 0) {
-    g1_aff a, c;
-    g2_aff b, d;
-    int st = g1_decode(a, p1);
-    int s2 = g2_decode(b, p2);
-    if (st == ST_OK) st = s2;
-    s2 = g1_decode(c, inv1);
-    if (st == ST_OK) st = s2;
-    s2 = g2_decode(d, inv2);
-    if (st == ST_OK) st = s2;
-    *ok = 0;
-    if (st != ST_OK) return st;
-    fp12 f, g;
-    optimal_ate(f, b, a);
-    optimal_ate(g, d, c);
-    *ok = fp12_eq(f, g) ? 1 : 0;
-    return ST_OK;
-}
-
 }  // namespace bn
 }  // namespace kyb

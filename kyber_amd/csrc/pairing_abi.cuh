@@ -1,8 +1,9 @@
 // Batch kernels + C-ABI entry points shared by the pairing suites (BLS12-381, bn256).
-// KYB_DEFINE_MUL_ABI / KYB_DEFINE_PAIR_ABI(PFX, NS, G1SZ, G2SZ[, GTSZ]) stamp out, for the curve library in
-// namespace kyb::NS (g1_mul_wire / g2_mul_wire / pair_wire / pair_check_wire), one kernel per
-// operation -- one group operation / pairing per lane, one wave per workgroup -- and the host /
-// device-pointer entry points kyb_<PFX>_* declared in include/kyber_hip.h.
+// KYB_DEFINE_MUL_ABI(PFX, NS, G1SZ, G2SZ) / KYB_DEFINE_GT_ABI(PFX, NS, GTSZ) stamp out, for the curve library in
+// namespace kyb::NS (g1_mul_wire / g2_mul_wire / gt_mul_wire ...), one kernel per operation -- one group operation
+// per lane, one wave per workgroup -- and the host / device-pointer entry points kyb_<PFX>_* declared in
+// include/kyber_hip.h.  Pair / ValidatePairing are NOT per-lane code: each suite's *_pair.hip supplies the `_dev`
+// entry points on the cooperative tower machine (tower_vm.cuh) and KYB_DEFINE_PAIR_HOST adds the host-buffer ones.
 #pragma once
 #include "context.h"
 
@@ -235,11 +236,10 @@ int kyb_##PFX##_g2_add(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* ou
 } \
 }
 
-// ---- pairing entry points, in three parts so that a suite can supply its own device implementation of Pair /
-// ValidatePairing (BLS12-381: the cooperative tower machine, bls12381_pair.hip) and still share the rest:
+// ---- pairing entry points:
 //   KYB_DEFINE_GT_ABI         GT exponentiation, one element per lane (kernel + _dev + host entry points)
-//   KYB_DEFINE_PAIR_LANE_DEV  Pair / ValidatePairing with one pairing per lane: kernels + the `_dev` entry points
-//   KYB_DEFINE_PAIR_HOST      the host-buffer entry points, which stage and call the `_dev` ones
+//   KYB_DEFINE_PAIR_HOST      the host-buffer Pair / ValidatePairing entry points, which stage and call the suite's
+//                             own `_dev` ones (the tower machine)
 #define KYB_DEFINE_GT_ABI(PFX, NS, GTSZ) \
 namespace kyb { \
 __global__ __launch_bounds__(64) void PFX##_gt_mul_kernel(size_t n, const uint8_t* __restrict__ scalars, \
@@ -280,60 +280,6 @@ int kyb_##PFX##_gt_mul(size_t n, const uint8_t* scalars, const uint8_t* gt, uint
     KYB_TRY(kyb_##PFX##_gt_mul_dev(n, a.p, b.p, o.p, st.p, nullptr)); \
     KYB_TRY(o.download(out, n * GTSZ)); \
     if (status) KYB_TRY(st.download(status, n)); \
-    return KYB_OK; \
-} \
-}
-
-#define KYB_DEFINE_PAIR_LANE_DEV(PFX, NS, GTSZ) \
-namespace kyb { \
-__global__ __launch_bounds__(64) void PFX##_pair_kernel(size_t n, const uint8_t* __restrict__ g1, \
-                                                      const uint8_t* __restrict__ g2, uint8_t* __restrict__ gt, \
-                                                      uint8_t* __restrict__ status, uint32_t flags) { \
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
-    if (idx >= n) return; \
-    const int st = NS::pair_wire(gt + GTSZ * idx, g1 + NS::g1_wire_size(flags) * idx, g2 + NS::g2_wire_size(flags) * idx, flags); \
-    if (status) status[idx] = (uint8_t)st; \
-} \
-__global__ __launch_bounds__(64) void PFX##_pair_check_kernel(size_t n, const uint8_t* __restrict__ p1, \
-                                                            const uint8_t* __restrict__ p2, \
-                                                            const uint8_t* __restrict__ i1, \
-                                                            const uint8_t* __restrict__ i2, uint8_t* __restrict__ ok, \
-                                                            uint8_t* __restrict__ status, uint32_t flags) { \
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
-    if (idx >= n) return; \
-    uint8_t r = 0; \
-    const size_t s1 = NS::g1_wire_size(flags), s2 = NS::g2_wire_size(flags); \
-    const int st = NS::pair_check_wire(&r, p1 + s1 * idx, p2 + s2 * idx, i1 + s1 * idx, i2 + s2 * idx, flags); \
-    ok[idx] = r; \
-    if (status) status[idx] = (uint8_t)st; \
-} \
-} \
-extern "C" { \
-int kyb_##PFX##_pair_dev(size_t n, const void* d_g1, const void* d_g2, void* d_gt, void* d_status, uint32_t flags, \
-                          void* stream) { \
-    KYB_TRY(kyb::check_flags(flags, 2, false, "kyb_" #PFX "_pair_dev")); \
-    if (n && (!d_g1 || !d_g2 || !d_gt)) { \
-        kyb::set_error("kyb_" #PFX "_pair_dev: bad argument"); \
-        return KYB_E_ARG; \
-    } \
-    if (!n) return KYB_OK; \
-    hipLaunchKernelGGL(kyb::PFX##_pair_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
-                       (const uint8_t*)d_g1, (const uint8_t*)d_g2, (uint8_t*)d_gt, (uint8_t*)d_status, flags); \
-    KYB_HIP_CHECK(hipGetLastError()); \
-    return KYB_OK; \
-} \
-int kyb_##PFX##_pair_check_dev(size_t n, const void* d_p1, const void* d_p2, const void* d_inv1, const void* d_inv2, \
-                                void* d_ok, void* d_status, uint32_t flags, void* stream) { \
-    KYB_TRY(kyb::check_flags(flags, 4, false, "kyb_" #PFX "_pair_check_dev")); \
-    if (n && (!d_p1 || !d_p2 || !d_inv1 || !d_inv2 || !d_ok)) { \
-        kyb::set_error("kyb_" #PFX "_pair_check_dev: bad argument"); \
-        return KYB_E_ARG; \
-    } \
-    if (!n) return KYB_OK; \
-    hipLaunchKernelGGL(kyb::PFX##_pair_check_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
-                       (const uint8_t*)d_p1, (const uint8_t*)d_p2, (const uint8_t*)d_inv1, (const uint8_t*)d_inv2, \
-                       (uint8_t*)d_ok, (uint8_t*)d_status, flags); \
-    KYB_HIP_CHECK(hipGetLastError()); \
     return KYB_OK; \
 } \
 }
@@ -395,8 +341,3 @@ int kyb_##PFX##_pair_check(size_t n, const uint8_t* p1, const uint8_t* p2, const
     return KYB_OK; \
 } \
 }
-
-#define KYB_DEFINE_PAIR_ABI(PFX, NS, G1SZ, G2SZ, GTSZ) \
-    KYB_DEFINE_GT_ABI(PFX, NS, GTSZ) \
-    KYB_DEFINE_PAIR_LANE_DEV(PFX, NS, GTSZ) \
-    KYB_DEFINE_PAIR_HOST(PFX, NS, GTSZ)

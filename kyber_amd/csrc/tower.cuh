@@ -1,5 +1,5 @@
 // Extension-field tower Fp2 / Fp6 / Fp12 over a Montgomery base field (mont.cuh), shared by the
-// BLS12-381 and bn256 pairings:
+// BLS12-381 and BN suites (G2 arithmetic over Fp2, GT exponentiation over Fp12):
 //   Fp2  = Fp[i]/(i^2 + 1)            elements c0 + c1 i
 //   Fp6  = Fp2[v]/(v^3 - xi)          xi = XI0 + i   (BLS12-381: 1 + i, bn256: 3 + i)
 //   Fp12 = Fp6[w]/(w^2 - v)
@@ -13,9 +13,7 @@
 // bound, so with LAZY12 (all three levels) operands are < 8p (product 64 < R/p = 2^9 for BLS12-381); bn256 has
 // R/p = 2^5.8 and stops at two levels (LAZY12 = false, operands < 4p).  KFP2 = bound of an Fp2-level operand.
 //
-// A tower configuration T provides: typedef F (field config for mont.cuh), XI0, LAZY12, and the
-// Frobenius constants FROB[3][6][2][N] = xi^(j (p^k - 1)/6), k = 1..3, j = 0..5, as Fp2
-// Montgomery limbs.
+// A tower configuration T provides: typedef F (field config for mont.cuh), XI0, LAZY12.
 #pragma once
 #include "mont.cuh"
 
@@ -176,69 +174,6 @@ KYB_HD void fp6_sqr(Fp6<T>& r, const Fp6<T>& a) {
     fp2_sub(t, t, s0);
     fp2_sub(r.c2, t, s4);
 }
-// a * (b0 + b1 v)   -- 5 Fp2 multiplications
-template <class T>
-KYB_HD void fp6_mul_by_01(Fp6<T>& r, const Fp6<T>& a, const Fp2<T>& b0, const Fp2<T>& b1) {
-    Fp2<T> v0, v1, t0, t1, t2, s, u;
-    fp2_mul(v0, a.c0, b0);
-    fp2_mul(v1, a.c1, b1);
-    fp2_mul(t0, a.c2, b1);
-    fp2_mul_xi(t0, t0);
-    fp2_add(t0, t0, v0);  // c0 = xi a2 b1 + a0 b0
-    fp2_add_nr(s, a.c0, a.c1);
-    fp2_add_nr(u, b0, b1);
-    fp2_mul(t1, s, u);
-    fp2_sub(t1, t1, v0);
-    fp2_sub(t1, t1, v1);  // c1 = a0 b1 + a1 b0
-    fp2_mul(t2, a.c2, b0);
-    fp2_add(t2, t2, v1);  // c2 = a2 b0 + a1 b1
-    r.c0 = t0;
-    r.c1 = t1;
-    r.c2 = t2;
-}
-// a * (b1 v)   -- 3 Fp2 multiplications
-template <class T>
-KYB_HD void fp6_mul_by_1(Fp6<T>& r, const Fp6<T>& a, const Fp2<T>& b1) {
-    Fp2<T> t0, t1, t2;
-    fp2_mul(t0, a.c2, b1);
-    fp2_mul_xi(t0, t0);
-    fp2_mul(t1, a.c0, b1);
-    fp2_mul(t2, a.c1, b1);
-    r.c0 = t0;
-    r.c1 = t1;
-    r.c2 = t2;
-}
-template <class T>
-KYB_HD void fp6_mul_fp2(Fp6<T>& r, const Fp6<T>& a, const Fp2<T>& b) {
-    fp2_mul(r.c0, a.c0, b);
-    fp2_mul(r.c1, a.c1, b);
-    fp2_mul(r.c2, a.c2, b);
-}
-template <class T>
-KYB_HD_NOINLINE void fp6_inv(Fp6<T>& r, const Fp6<T>& a) {
-    Fp2<T> t0, t1, t2, d, s;
-    fp2_sqr_c(t0, a.c0);
-    fp2_mul_c(s, a.c1, a.c2);
-    fp2_mul_xi(s, s);
-    fp2_sub(t0, t0, s);  // a0^2 - xi a1 a2
-    fp2_sqr_c(t1, a.c2);
-    fp2_mul_xi(t1, t1);
-    fp2_mul_c(s, a.c0, a.c1);
-    fp2_sub(t1, t1, s);  // xi a2^2 - a0 a1
-    fp2_sqr_c(t2, a.c1);
-    fp2_mul_c(s, a.c0, a.c2);
-    fp2_sub(t2, t2, s);  // a1^2 - a0 a2
-    fp2_mul_c(d, a.c2, t1);
-    fp2_mul_c(s, a.c1, t2);
-    fp2_add(d, d, s);
-    fp2_mul_xi(d, d);
-    fp2_mul_c(s, a.c0, t0);
-    fp2_add(d, d, s);
-    fp2_inv(d, d);
-    fp2_mul_c(r.c0, t0, d);
-    fp2_mul_c(r.c1, t1, d);
-    fp2_mul_c(r.c2, t2, d);
-}
 
 // Fp6 sum feeding an Fp6 multiplication: lazy where the field has the headroom for a third level
 template <class T>
@@ -255,9 +190,10 @@ template <class T> KYB_HD_NOINLINE void fp6_mul_c(Fp6<T>& r, const Fp6<T>& a, co
 template <class T> KYB_HD_NOINLINE void fp6_sqr_c(Fp6<T>& r, const Fp6<T>& a) { fp6_sqr(r, a); }
 
 // ---------------------------------------------------------------------- Fp12
+// (what GT exponentiation needs; Pair / ValidatePairing run on the tower machine, tower_vm.cuh, which expands the
+//  tower into base-field bilinear forms in its generator and shares nothing with this file)
 template <class T> KYB_HD void fp12_one(Fp12<T>& r) { fp6_one(r.c0); fp6_zero(r.c1); }
 template <class T> KYB_HD bool fp12_eq(const Fp12<T>& a, const Fp12<T>& b) { return fp6_eq(a.c0, b.c0) & fp6_eq(a.c1, b.c1); }
-template <class T> KYB_HD void fp12_conj(Fp12<T>& r, const Fp12<T>& a) { r.c0 = a.c0; fp6_neg(r.c1, a.c1); }
 template <class T>
 KYB_HD bool fp12_is_one(const Fp12<T>& a) {
     Fp12<T> o;
@@ -295,44 +231,7 @@ template <class T>
 KYB_HD_NOINLINE void fp12_sqr(Fp12<T>& r, const Fp12<T>& a) {
     fp12_sqr_inl(r, a);
 }
-template <class T>
-KYB_HD_NOINLINE void fp12_inv(Fp12<T>& r, const Fp12<T>& a) {
-    Fp6<T> t0, t1;
-    fp6_sqr_c(t0, a.c0);
-    fp6_sqr_c(t1, a.c1);
-    fp6_mul_v(t1, t1);
-    fp6_sub(t0, t0, t1);
-    fp6_inv(t0, t0);
-    fp6_mul_c(r.c0, a.c0, t0);
-    fp6_mul_c(t1, a.c1, t0);
-    fp6_neg(r.c1, t1);
-}
-// f * (o0 + o1 v + o4 v w): the sparse line value of an M-type twist (BLS12-381); 13 Fp2 mults
-template <class T>
-KYB_HD void fp12_mul_by_014_inl(Fp12<T>& f, const Fp2<T>& o0, const Fp2<T>& o1, const Fp2<T>& o4) {
-    Fp6<T> aa, bb, s, t;
-    Fp2<T> o;
-    fp6_mul_by_01(aa, f.c0, o0, o1);
-    fp6_mul_by_1(bb, f.c1, o4);
-    if constexpr (T::LAZY12) fp2_add_nr(o, o1, o4); else fp2_add(o, o1, o4);
-    fp6_add_pre(s, f.c1, f.c0);
-    fp6_mul_by_01(t, s, o0, o);
-    fp6_sub(t, t, aa);
-    fp6_sub(f.c1, t, bb);
-    fp6_mul_v(t, bb);
-    fp6_add(f.c0, t, aa);
-}
-template <class T>
-KYB_HD_NOINLINE void fp12_mul_by_014(Fp12<T>& f, const Fp2<T>& o0, const Fp2<T>& o1, const Fp2<T>& o4) {
-    fp12_mul_by_014_inl(f, o0, o1, o4);
-}
 
-// w-basis coefficient j of an Fp12 element: a = sum_j coeff_j w^j
-template <class T>
-KYB_HD Fp2<T>& fp12_coeff(Fp12<T>& a, int j) {
-    Fp6<T>& h = (j & 1) ? a.c1 : a.c0;
-    return (j >> 1) == 0 ? h.c0 : ((j >> 1) == 1 ? h.c1 : h.c2);
-}
 template <class T>
 KYB_HD void fp2_load_const(Fp2<T>& r, const uint32_t (&c)[2][T::F::NWORDS]) {
 #pragma unroll
@@ -340,85 +239,6 @@ KYB_HD void fp2_load_const(Fp2<T>& r, const uint32_t (&c)[2][T::F::NWORDS]) {
         r.c0.v[l] = c[0][l];
         r.c1.v[l] = c[1][l];
     }
-}
-// r = a^(p^K), K = 1, 2, 3
-template <class T, int K>
-KYB_HD_NOINLINE void fp12_frob(Fp12<T>& r, const Fp12<T>& a) {
-    Fp12<T> x = a;
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-        Fp2<T>& c = fp12_coeff(x, j);
-        if (K & 1) fp2_conj(c, c);
-        if (j > 0) {
-            Fp2<T> g;
-            fp2_load_const<T>(g, T::FROB[K - 1][j]);
-            fp2_mul_c(c, c, g);
-        }
-    }
-    r = x;
-}
-// Squaring in the cyclotomic subgroup (elements of order dividing p^4 - p^2 + 1, i.e. everything
-// after the easy part of the final exponentiation): Granger-Scott, three Fp4 squarings = 6 Fp2
-// multiplications instead of the 12 of a general Fp12 squaring.  Same result as fp12_sqr there.
-template <class T>
-KYB_HD void fp4_sqr(Fp2<T>& t0, Fp2<T>& t1, const Fp2<T>& a, const Fp2<T>& b) {
-    // (a + b y)^2 with y^2 = xi:  t0 = a^2 + xi b^2,  t1 = 2ab
-    Fp2<T> ab, s, u;
-    fp2_mul(ab, a, b);
-    fp2_add_nr(s, a, b);  // operands of the multiplication below only
-    fp2_mul_xi(u, b);
-    fp2_add_nr(u, u, a);
-    fp2_mul(s, s, u);  // a^2 + xi b^2 + (1 + xi) ab
-    fp2_sub(s, s, ab);
-    fp2_mul_xi(u, ab);
-    fp2_sub(t0, s, u);
-    fp2_dbl(t1, ab);
-}
-// (r may alias a: every output coefficient depends on the t's and on the same input coefficient only)
-template <class T>
-KYB_HD void fp12_cyclo_sqr_inl(Fp12<T>& r, const Fp12<T>& a) {
-    Fp2<T> t0, t1, t2, t3, t4, t5, z, u;
-    fp4_sqr(t0, t1, a.c0.c0, a.c1.c1);
-    fp4_sqr(t2, t3, a.c1.c0, a.c0.c2);
-    fp4_sqr(t4, t5, a.c0.c1, a.c1.c2);
-    // z0 = 3 t0 - 2 z0
-    fp2_sub(z, t0, a.c0.c0);
-    fp2_dbl(z, z);
-    fp2_add(r.c0.c0, z, t0);
-    // z1 = 3 t1 + 2 z1
-    fp2_add(z, t1, a.c1.c1);
-    fp2_dbl(z, z);
-    fp2_add(r.c1.c1, z, t1);
-    // z2 = 3 xi t5 + 2 z2
-    fp2_mul_xi(u, t5);
-    fp2_add(z, u, a.c1.c0);
-    fp2_dbl(z, z);
-    fp2_add(r.c1.c0, z, u);
-    // z3 = 3 t4 - 2 z3
-    fp2_sub(z, t4, a.c0.c2);
-    fp2_dbl(z, z);
-    fp2_add(r.c0.c2, z, t4);
-    // z4 = 3 t2 - 2 z4
-    fp2_sub(z, t2, a.c0.c1);
-    fp2_dbl(z, z);
-    fp2_add(r.c0.c1, z, t2);
-    // z5 = 3 t3 + 2 z5
-    fp2_add(z, t3, a.c1.c2);
-    fp2_dbl(z, z);
-    fp2_add(r.c1.c2, z, t3);
-}
-template <class T>
-KYB_HD_NOINLINE void fp12_cyclo_sqr(Fp12<T>& r, const Fp12<T>& a) {
-    fp12_cyclo_sqr_inl(r, a);
-}
-// r = a^(2^n): the runs of squarings between the set bits of a final-exponentiation exponent.  One call keeps the
-// element in registers across the whole run; n calls of fp12_cyclo_sqr move it through scratch 2n times.
-template <class T>
-KYB_HD_NOINLINE void fp12_cyclo_sqr_n(Fp12<T>& r, const Fp12<T>& a, int n) {
-    Fp12<T> x = a;
-#pragma unroll 1
-    for (int i = 0; i < n; i++) fp12_cyclo_sqr_inl(x, x);
-    r = x;
 }
 
 }  // namespace kyb

@@ -49,10 +49,6 @@ int hh_bls_g2_recode(const uint8_t* in, uint8_t* out) {
 }
 int hh_bls_g1_mul(const uint8_t* k, const uint8_t* pt, uint8_t* out) { return bls::g1_mul_wire(out, k, pt); }
 int hh_bls_g2_mul(const uint8_t* k, const uint8_t* pt, uint8_t* out) { return bls::g2_mul_wire(out, k, pt); }
-int hh_bls_pair(const uint8_t* g1, const uint8_t* g2, uint8_t* gt) { return bls::pair_wire(gt, g1, g2); }
-int hh_bls_pair_check(const uint8_t* p1, const uint8_t* p2, const uint8_t* i1, const uint8_t* i2, uint8_t* ok) {
-    return bls::pair_check_wire(ok, p1, p2, i1, i2);
-}
 
 // flag-aware variants (KYB_F_UNCOMPRESSED / _OUT / TRUSTED): ints come before the output buffers
 int hh_bls_g1_mul_f(const uint8_t* k, const uint8_t* pt, int flags, uint8_t* out) {
@@ -60,13 +56,6 @@ int hh_bls_g1_mul_f(const uint8_t* k, const uint8_t* pt, int flags, uint8_t* out
 }
 int hh_bls_g2_mul_f(const uint8_t* k, const uint8_t* pt, int flags, uint8_t* out) {
     return bls::g2_mul_wire(out, k, pt, (uint32_t)flags);
-}
-int hh_bls_pair_f(const uint8_t* g1, const uint8_t* g2, int flags, uint8_t* gt) {
-    return bls::pair_wire(gt, g1, g2, (uint32_t)flags);
-}
-int hh_bls_pair_check_f(const uint8_t* p1, const uint8_t* p2, const uint8_t* i1, const uint8_t* i2, int flags,
-                        uint8_t* ok) {
-    return bls::pair_check_wire(ok, p1, p2, i1, i2, (uint32_t)flags);
 }
 int hh_bls_g1_unmarshal(const uint8_t* in, int flags, uint8_t* out) { return bls::g1_unmarshal_wire(out, in, (uint32_t)flags); }
 int hh_bls_g2_unmarshal(const uint8_t* in, int flags, uint8_t* out) { return bls::g2_unmarshal_wire(out, in, (uint32_t)flags); }
@@ -83,10 +72,7 @@ int hh_bls_fp12_op(int op, const uint8_t* a576, const uint8_t* b576, uint8_t* ou
     if (st) return st;
     switch (op) {
         case 0: fp12_mul(r, a, b); break;
-        case 1: fp12_sqr(r, a); break;
-        case 2: fp12_cyclo_sqr(r, a); break;
-        case 3: fp12_cyclo_sqr_n(r, a, 5); break;
-        default: r = a; fp12_mul_by_014(r, b.c0.c0, b.c0.c1, b.c1.c1); break;
+        default: fp12_sqr(r, a); break;
     }
     bls::gt_encode(out576, r);
     return 0;
@@ -113,10 +99,6 @@ int hh_bn_g1_unmarshal(const uint8_t* in, uint8_t* out) { return bn::g1_unmarsha
 int hh_bn_g2_unmarshal(const uint8_t* in, uint8_t* out) { return bn::g2_unmarshal_wire(out, in); }
 int hh_bn_g1_mul(const uint8_t* k, const uint8_t* pt, uint8_t* out) { return bn::g1_mul_wire(out, k, pt); }
 int hh_bn_g2_mul(const uint8_t* k, const uint8_t* pt, uint8_t* out) { return bn::g2_mul_wire(out, k, pt); }
-int hh_bn_pair(const uint8_t* g1, const uint8_t* g2, uint8_t* gt) { return bn::pair_wire(gt, g1, g2); }
-int hh_bn_pair_check(const uint8_t* p1, const uint8_t* p2, const uint8_t* i1, const uint8_t* i2, uint8_t* ok) {
-    return bn::pair_check_wire(ok, p1, p2, i1, i2);
-}
 // Fp12 operations on GT-encoded operands (384 bytes): the shared tower code at bn256's parameters (two lazy levels)
 int hh_bn_fp12_op(int op, const uint8_t* a384, const uint8_t* b384, uint8_t* out384) {
     bn::fp12 a, b, r;
@@ -124,9 +106,7 @@ int hh_bn_fp12_op(int op, const uint8_t* a384, const uint8_t* b384, uint8_t* out
     bn::gt_decode(b, b384);
     switch (op) {
         case 0: fp12_mul(r, a, b); break;
-        case 1: fp12_sqr(r, a); break;
-        case 2: fp12_cyclo_sqr(r, a); break;
-        default: fp12_cyclo_sqr_n(r, a, 5); break;
+        default: fp12_sqr(r, a); break;
     }
     bn::gt_encode(out384, r);
     return 0;
@@ -146,14 +126,6 @@ int hh_bls_hash_g1(const uint8_t* msg, int len, const uint8_t* dst, int dlen, ui
 }
 int hh_bls_hash_g2(const uint8_t* msg, int len, const uint8_t* dst, int dlen, uint8_t* out) {
     return bls::hash_g2_wire(out, msg, (size_t)len, mk_dst(dst, dlen));
-}
-int hh_bls_verify_g2(const uint8_t* pk, const uint8_t* msg, int len, const uint8_t* dst, int dlen, const uint8_t* sig,
-                     uint8_t* ok) {
-    return bls::verify_g2_wire(ok, pk, msg, (size_t)len, mk_dst(dst, dlen), sig);
-}
-int hh_bls_verify_g1(const uint8_t* pk, const uint8_t* msg, int len, const uint8_t* dst, int dlen, const uint8_t* sig,
-                     uint8_t* ok) {
-    return bls::verify_g1_wire(ok, pk, msg, (size_t)len, mk_dst(dst, dlen), sig);
 }
 // Raw-limb access to the GF(2^255 - 19) routines (ten int32 limbs, radix 2^25.5): op 0 = mul, 1 = sq, 2 = sq2,
 // 3 = sq_sel(dbl = false), 4 = sq_sel(dbl = true).  The tests drive the limbs to the input bounds of fe25519.cuh.

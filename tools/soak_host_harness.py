@@ -56,13 +56,4 @@ for i in range(400):
     st, out = H.call("hh_ed_mul", s, p, vt, out_sizes=(32,))
     if (st, out) != (0, exp): bad += 1; print("ed mismatch", s.hex(), vt)
 print("ed done", round(time.time() - t0, 1), bad)
-# pairings: bilinearity bytes vs oracle
-for i in range(4):
-    a, b = rng.randrange(1, B.R), rng.randrange(1, B.R)
-    g1, g2 = B.g1_compress(B.g1_mul(a, B.G1_GEN)), B.g2_compress(B.g2_mul(b, B.G2_GEN))
-    st, out = H.call("hh_bls_pair", g1, g2, out_sizes=(576,))
-    if (st, out) != (0, B.pair_bytes(g1, g2)): bad += 1; print("bls pair mismatch")
-    g1, g2 = N.g1_marshal(N.g1_mul(a % N.ORDER, N.G1_GEN)), N.g2_marshal(N.g2_mul(b % N.ORDER, N.G2_GEN))
-    st, out = H.call("hh_bn_pair", g1, g2, out_sizes=(384,))
-    if (st, out) != (0, N.pair_bytes(g1, g2)): bad += 1; print("bn pair mismatch")
 print("TOTAL BAD", bad, "time", round(time.time() - t0, 1))
