@@ -14,11 +14,7 @@ namespace kyb {
 namespace bls {
 
 using HC = Bls12381H2c;
-
-struct DstArg {  // domain separation tag, passed by value to the kernels (RFC 9380: at most 255 bytes)
-    uint8_t b[256];
-    uint32_t len;
-};
+using kyb::DstArg;  // hd.h
 
 // uniform_bytes = expand_message_xmd(msg, DST, 32 * ELL) as big-endian words out[8 * ELL]
 template <int ELL>

@@ -24,7 +24,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 WAVES = 12
-W = 28
+W = 28  # default limb width; a field may choose a narrower one (VmField.W)
 REC_WORDS = 64
 OP_DOT, OP_IDLE, OP_GLOAD, OP_INV, OP_GT_STORE, OP_IS_ONE, OP_CLOAD, OP_SPILL, OP_FILL, OP_CMP_EQ = range(10)
 K_PROD, K_LIN, K_PROD_CONST = 0, 1, 2
@@ -32,15 +32,16 @@ K_PROD, K_LIN, K_PROD_CONST = 0, 1, 2
 
 # ------------------------------------------------------------------------------------------------ field
 class VmField:
-    def __init__(self, name, p, n, nw, r1_bits):
-        self.name, self.p, self.N, self.NW = name, p, n, nw
-        self.R = 1 << (W * n)
+    def __init__(self, name, p, n, nw, r1_bits, w=W):
+        self.name, self.p, self.N, self.NW, self.W = name, p, n, nw, w
+        self.R = 1 << (w * n)
         self.R1 = 1 << r1_bits  # Montgomery radix of the per-lane field code (mont.cuh) that decodes the inputs
-        self.ninv = (-pow(p, -1, 1 << W)) % (1 << W)
-        assert self.R > 256 * p
+        self.ninv = (-pow(p, -1, 1 << w)) % (1 << w)
+        assert self.R > 256 * p and 32 * nw <= w * n + 31
 
     def balanced(self, x):
-        """signed digits d_i in [-2^27, 2^27) (top digit unbounded) with sum d_i 2^(28 i) = x"""
+        """signed digits d_i in [-2^(W-1), 2^(W-1)) (top digit unbounded) with sum d_i 2^(W i) = x"""
+        W = self.W
         out = []
         for _ in range(self.N - 1):
             d = x & ((1 << W) - 1)
@@ -53,7 +54,7 @@ class VmField:
         return out
 
     def value(self, limbs):
-        return sum(d << (W * i) for i, d in enumerate(limbs))
+        return sum(d << (self.W * i) for i, d in enumerate(limbs))
 
 
 # ------------------------------------------------------------------------------------------------ symbolic layer
@@ -371,16 +372,18 @@ class Prog:
         pl = f.balanced(p)
         lim63 = 1 << 63
 
-        def sext28(x):
-            x &= (1 << 28) - 1
-            return x - (1 << 28) if x >> 27 else x
+        W = f.W
+
+        def sext28(x):  # (sign extension from the field's limb width)
+            x &= (1 << W) - 1
+            return x - (1 << W) if x >> (W - 1) else x
 
         def normalise(cols):
             r, carry = [], 0
             for c in range(N - 1):
                 v = cols[c] + carry
                 assert abs(v) < lim63
-                carry = (v + (1 << 27)) >> 28
+                carry = (v + (1 << (W - 1))) >> W
                 r.append(sext28(v))
             top = cols[N - 1] + carry
             assert abs(top) < 1 << 31, "top limb overflow"
@@ -400,7 +403,7 @@ class Prog:
             return v % p
 
         def from_words(x):
-            return normalise([(x >> (28 * j)) & ((1 << 28) - 1) for j in range(N)])
+            return normalise([(x >> (W * j)) & ((1 << W) - 1) for j in range(N)])
 
         S = [[0] * N for _ in range(self.nslots)]
         G = {}
@@ -430,8 +433,8 @@ class Prog:
                                     for j in range(N):
                                         t[i + j] += m * pl[j]
                                     assert all(abs(c) < lim63 for c in t), "column overflow in the reduction"
-                                    assert t[i] & ((1 << 28) - 1) == 0
-                                    t[i + 1] += t[i] >> 28
+                                    assert t[i] & ((1 << W) - 1) == 0
+                                    t[i + 1] += t[i] >> W
                             v = normalise(t[N:])
                             if r["scale"] > 1:  # the scale is applied to the normalised limbs, then normalised again
                                 v = normalise([c * r["scale"] for c in v])
@@ -469,8 +472,8 @@ class Prog:
         import math
 
         f = self.f
-        N, p = f.N, f.p
-        lb = float(1 << 27)
+        N, p, W = f.N, f.p, f.W
+        lb = float(1 << (W - 1))
         pR = p / f.R
         B = [0.0] * self.nslots
         GB = {}
@@ -533,7 +536,7 @@ class Prog:
                             else:
                                 val = val_lin
                             assert col < 2.0 ** 63, ("column bound", self.names[start + ii], math.log2(col))
-                            assert r["scale"] <= 15  # scaled normalised limbs stay below 2^31
+                            assert r["scale"] * lb < 2.0 ** 31  # scaled normalised limbs stay below 2^31
                             worst_col = max(worst_col, col)
                             val *= r["scale"]
                             if r["mask"]:
@@ -1161,25 +1164,39 @@ def build_bls12381_check():
     return P
 
 
-# ------------------------------------------------------------------------------------------------ bn256
-# pairing/bn256 (dclxvi parameters): p = 36u^4 + 36u^3 + 24u^2 + 6u + 1, xi = 3 + i, D-type twist y^2 = x^3 + 3/xi,
-# optimal ate loop over the NAF of 6u + 2 with the two Frobenius steps (optate.go:126-213) and the final
-# exponentiation's addition chain (optate.go:215-264) -- the GT bytes must equal the reference's, so the exponent is
-# exactly the chain's; the line functions are free (any Fp2 multiple of a line dies in the final exponentiation).
-BN_U = 6518589491078791937
-BN_NAF = [0, 0, 0, 1, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0, 0, 0, -1, 0, 1, 0,
-          1, 0, 0, 0, 0, 1, 0, 1, 0, 0, 0, -1, 0, 1, 0, 0, 0, 1, 0, -1,
-          0, 0, 0, -1, 0, 1, 0, 0, 0, 0, 0, 1, 0, 0, -1, 0, -1, 0, 0, 0,
-          0, 1, 0, 0, 0, 1]
-assert sum(d << i for i, d in enumerate(BN_NAF)) == 6 * BN_U + 2
+# ------------------------------------------------------------------------------------------------ BN curves
+# pairing/bn256 (dclxvi parameters, xi = 3 + i) and pairing/bn254 (alt_bn128, xi = 9 + i; the same package with other
+# constants): p = 36u^4 + 36u^3 + 24u^2 + 6u + 1, D-type twist y^2 = x^3 + 3/xi, optimal ate loop over the reference's
+# signed digits of 6u + 2 with the two Frobenius steps (optate.go:126-213) and the final exponentiation's addition chain
+# (optate.go:215-264) -- the GT bytes must equal the reference's, so the exponent is exactly the chain's; the line
+# functions and the digit form are free (any Fp2 multiple of a line dies in the final exponentiation).
+class BnCurve:
+    def __init__(self, name, u, xi0, digits, w=W):
+        self.name, self.u, self.xi0, self.digits, self.w = name, u, xi0, digits, w
+        self.p = 36 * u ** 4 + 36 * u ** 3 + 24 * u ** 2 + 6 * u + 1
+        assert sum(d << i for i, d in enumerate(digits)) == 6 * u + 2
+
+    def field(self):
+        return VmField(self.name, self.p, 10, 8, 261, self.w)
+
+
+BN256 = BnCurve("bn256", 6518589491078791937, 3,   # constants.go:17, optate.go:117-122
+                [0, 0, 0, 1, 0, 0, 0, 0, 0, 1, 0, 0, 1, 0, 0, 0, -1, 0, 1, 0,
+                 1, 0, 0, 0, 0, 1, 0, 1, 0, 0, 0, -1, 0, 1, 0, 0, 0, 1, 0, -1,
+                 0, 0, 0, -1, 0, 1, 0, 0, 0, 0, 0, 1, 0, 0, -1, 0, -1, 0, 0, 0,
+                 0, 1, 0, 0, 0, 1])
+BN254 = BnCurve("bn254", 4965661367192848881, 9,   # pairing/bn254/constants.go:17, optate.go:117-120
+                [0, 0, 0, 1, 0, 1, 0, -1, 0, 0, 1, -1, 0, 0, 1, 0,
+                 0, 1, 1, 0, -1, 0, 0, 1, 0, -1, 0, 0, 0, 0, 1, 1,
+                 1, 0, 0, -1, 0, 0, 1, 0, 0, 0, 0, 0, -1, 0, 0, 1,
+                 1, 0, 0, -1, 0, 0, 0, 1, 1, 0, -1, 0, 0, 1, 0, 1, 1],
+                w=27)  # xi0 = 9 puts sums of 10-fold coefficients into the unreduced columns: 27-bit limbs keep them below 2^63
 BN_NSLOTS = 63
 BN_A, BN_B, BN_C, BN_D, BN_E = 0, 12, 24, 36, 48   # five Fp12 register sets; slots 60..62 spare
 
 
 def bn256_field():
-    u = BN_U
-    p = 36 * u ** 4 + 36 * u ** 3 + 24 * u ** 2 + 6 * u + 1
-    return VmField("bn256", p, 10, 8, 261)
+    return BN256.field()
 
 
 def bn_dbl_step(P, T, TX, TY, TZ, tmp, L, PX, PY, fset, mask):
@@ -1190,6 +1207,8 @@ def bn_dbl_step(P, T, TX, TY, TZ, tmp, L, PX, PY, fset, mask):
     xi0 = P.xi0
     X, Y, Z = E2.slots(*TX), E2.slots(*TY), E2.slots(*TZ)
     XY, Bh, Ep, YZ, A3 = (E2.slots(tmp[2 * i], tmp[2 * i + 1]) for i in range(5))
+    if xi0 * xi0 + 1 > 15:
+        return bn_dbl_step_xi(P, T, TX, TY, TZ, tmp, L, PX, PY, fset, mask)
     o = []
     o += outs2(tmp[0], tmp[1], Acc2().prod(X, Y))
     o += outs2(tmp[2], tmp[3], Acc2().sqr(Y), scale=xi0 * xi0 + 1)
@@ -1208,6 +1227,36 @@ def bn_dbl_step(P, T, TX, TY, TZ, tmp, L, PX, PY, fset, mask):
     o += outs2(L[0], L[1], Acc2().prod_fp(YZ.scale(2), Lin.slot(PY)), scale=10)      # l0
     o += outs2(L[2], L[3], Acc2().prod_fp(-A3, Lin.slot(PX)), scale=10)             # l1
     o += outs2(L[4], L[5], Acc2().lin(Bh - Ep), raw=True)                           # l3
+    P.dot(o, "dbl/b")
+    f = Tower.reg(fset)
+    T.mul_sparse(fset, f, {0: E2.slots(L[0], L[1]), 1: E2.slots(L[2], L[3]), 3: E2.slots(L[4], L[5])}, mask=mask, name="dbl/line")
+
+
+def bn_dbl_step_xi(P, T, TX, TY, TZ, tmp, L, PX, PY, fset, mask):
+    """The doubling step when norm(xi) = xi0^2 + 1 exceeds the post-scale range (bn254: 82).  3 b' = 9 / xi, so with
+    Bt = xi Y^2 and Et = 9 Z^2 (B = Bt / xi, E = 3 b' Z^2 = Et / xi) the point, scaled by xi^2, is
+      X3 = 2 (xi XY) (Bt - 3 Et),  Y3 = Bt^2 + 3 Et (2 Bt - Et),  Z3 = 8 Bt (xi YZ)
+    and the tangent, scaled by xi:  l0 = 2 (xi YZ) yP,  l1 = -3 (xi X^2) xP,  l3 = Bt - Et.
+    The multiplications by xi cost nothing: xi Y (xi X) is an OPERAND -- the slot combination (xi0 y0 - y1, y0 + xi0 y1) --
+    of the products X (xi Y), Y (xi Y), (xi Y) Z, X (xi X)."""
+    xi0 = P.xi0
+    X, Y, Z = E2.slots(*TX), E2.slots(*TY), E2.slots(*TZ)
+    XY, Bt, Et, YZ, A3 = (E2.slots(tmp[2 * i], tmp[2 * i + 1]) for i in range(5))
+    xiY, xiX = Y.mul_xi(xi0), X.mul_xi(xi0)
+    o = []
+    o += outs2(tmp[0], tmp[1], Acc2().prod(X, xiY))
+    o += outs2(tmp[2], tmp[3], Acc2().prod(Y, xiY))
+    o += outs2(tmp[4], tmp[5], Acc2().sqr(Z), scale=9)
+    o += outs2(tmp[6], tmp[7], Acc2().prod(xiY, Z))
+    o += outs2(tmp[8], tmp[9], Acc2().prod(X, xiX), scale=3)
+    P.dot(o, "dbl/a")
+    o = []
+    o += outs2(TX[0], TX[1], Acc2().prod(XY.scale(2), Bt - Et.scale(3)))
+    o += outs2(TY[0], TY[1], Acc2().sqr(Bt).prod(Et.scale(3), Bt.scale(2) - Et))
+    o += outs2(TZ[0], TZ[1], Acc2().prod(Bt.scale(8), YZ))
+    o += outs2(L[0], L[1], Acc2().prod_fp(YZ.scale(2), Lin.slot(PY)))              # l0
+    o += outs2(L[2], L[3], Acc2().prod_fp(-A3, Lin.slot(PX)))                     # l1
+    o += outs2(L[4], L[5], Acc2().lin(Bt - Et), raw=True)                         # l3
     P.dot(o, "dbl/b")
     f = Tower.reg(fset)
     T.mul_sparse(fset, f, {0: E2.slots(L[0], L[1]), 1: E2.slots(L[2], L[3]), 3: E2.slots(L[4], L[5])}, mask=mask, name="dbl/line")
@@ -1246,11 +1295,13 @@ def bn_add_step(P, T, TX, TY, TZ, Q, sign, tmp, L, PX, PY, fset, mask):
     T.mul_sparse(fset, f, {0: E2.slots(L[0], L[1]), 1: E2.slots(L[2], L[3]), 3: E2.slots(L[4], L[5])}, mask=mask, name="add/line")
 
 
-def bn_miller(P, T, f, first_input, mask):
+def bn_miller(P, T, f, first_input, mask, curve=None):
     """F (set A) <- miller(Q, P) of optate.go:126-213 up to factors that the final exponentiation removes.
     Inputs first_input .. +5: P.x, P.y, Q.x.re, Q.x.im, Q.y.re, Q.y.im."""
+    curve = curve or BN256
     p = f.p
-    xi = (3, 1)
+    xi = (curve.xi0, 1)
+    digits = curve.digits
     TX, TY, TZ = (12, 13), (14, 15), (16, 17)
     tmp = list(range(18, 28))
     L = list(range(28, 34))
@@ -1272,11 +1323,11 @@ def bn_miller(P, T, f, first_input, mask):
         P.dot([Out(QT[i], [("l", Lin.slot(src[i]))], raw=True) for i in range(4)], "add/copyQ")
         bn_add_step(P, T, TX, TY, TZ, QT, sign, tmp, L, PX, PY, BN_A, mask)
 
-    n = len(BN_NAF)
+    n = len(digits)
     run = 0
     for i in range(n - 1, 0, -1):
         run += 1
-        d = BN_NAF[i - 1]
+        d = digits[i - 1]
         if d:
             with P.repeat(run):
                 step()
@@ -1302,7 +1353,7 @@ def bn_miller(P, T, f, first_input, mask):
     return FF
 
 
-def bn_final_exp(P, T, fval, gam):
+def bn_final_exp(P, T, fval, gam, curve=None):
     """set A <- finalExponentiation(f) (optate.go:215-264), the same exponent: with g the easy-part output and
     fu = g^u, fu2 = fu^u, fu3 = fu2^u
       y0 = g^p g^(p^2) g^(p^3), y1 = conj(g), y2 = fu2^(p^2), y3 = conj(fu^p), y4 = conj(fu fu2^p), y5 = conj(fu2),
@@ -1313,7 +1364,7 @@ def bn_final_exp(P, T, fval, gam):
     A_, B_, C_, D_, E_ = BN_A, BN_B, BN_C, BN_D, BN_E
     AA = tower_easy_part(P, T, fval, gam[2], A_, B_, C_, D_)   # spare slots: the first six of set D
     BB, CC, DD, EE = T.reg(B_), T.reg(C_), T.reg(D_), T.reg(E_)
-    U = BN_U
+    U = (curve or BN256).u
     T.frob12(B_, AA, 1, gam[1], "hard/gp")
     T.frob12(C_, AA, 2, gam[2], "hard/gp2")
     T.mul12(B_, BB, CC, "hard/y0a")
@@ -1358,13 +1409,13 @@ def gt_layout_bn(j, c):
     return ((1 - h) * 3 + (2 - m)) * 64 + (0 if c == 1 else 32)
 
 
-def build_bn256_pair():
-    f = bn256_field()
-    P = Prog(f, BN_NSLOTS, 3, n_inputs=6, n_gslots=4)
+def build_bn_pair(curve):
+    f = curve.field()
+    P = Prog(f, BN_NSLOTS, curve.xi0, n_inputs=6, n_gslots=4)
     T = Tower(P)
-    gam = {K: frob_gammas(f.p, (3, 1), K) for K in (1, 2, 3)}
-    FF = bn_miller(P, T, f, 0, 0)
-    res = bn_final_exp(P, T, FF, gam)
+    gam = {K: frob_gammas(f.p, (curve.xi0, 1), K) for K in (1, 2, 3)}
+    FF = bn_miller(P, T, f, 0, 0, curve)
+    res = bn_final_exp(P, T, FF, gam, curve)
     one = (P.c_plain_one, 1)
     P.dot(sum((outs2(BN_A + 2 * j, BN_A + 2 * j + 1, Acc2().prod_const(res[j], one, None)) for j in range(6)), []), "to_plain")
     P.misc([dict(op=OP_GT_STORE, dst=BN_A + 2 * j + c, arg=gt_layout_bn(j, c) | ((1 if (j == 0 and c == 0) else 0) << 16))
@@ -1372,19 +1423,19 @@ def build_bn256_pair():
     return P
 
 
-def build_bn256_check():
-    """Suite.ValidatePairing (suite.go:105-107): Pair(p1, p2).Equal(Pair(inv1, inv2)) -- two whole pairings compared
-    coefficient by coefficient (the reference accepts G2 points outside the order-n subgroup, for which the product
-    form e(p1, p2) e(-inv1, inv2) == 1 need not be equivalent).  Inputs 0..5: pair A, 6..11: pair B.  Flag bit 0 / 1:
-    pair A / B has an operand at infinity and pairs to one (optate.go:270-272)."""
-    f = bn256_field()
-    P = Prog(f, BN_NSLOTS, 3, n_inputs=12, n_gslots=5)
+def build_bn_check(curve):
+    """Suite.ValidatePairing (bn256 suite.go:105-107, bn254 suite.go:134-140): Pair(p1, p2).Equal(Pair(inv1, inv2)) -- two
+    whole pairings compared coefficient by coefficient (bn256 accepts G2 points outside the order-n subgroup, for which
+    the product form e(p1, p2) e(-inv1, inv2) == 1 need not be equivalent).  Inputs 0..5: pair A, 6..11: pair B.  Flag bit
+    0 / 1: pair A / B has an operand at infinity and pairs to one (optate.go:270-272)."""
+    f = curve.field()
+    P = Prog(f, BN_NSLOTS, curve.xi0, n_inputs=12, n_gslots=5)
     T = Tower(P)
-    gam = {K: frob_gammas(f.p, (3, 1), K) for K in (1, 2, 3)}
+    gam = {K: frob_gammas(f.p, (curve.xi0, 1), K) for K in (1, 2, 3)}
     one = (P.c_plain_one, 1)
     for k in range(2):
-        FF = bn_miller(P, T, f, 6 * k, 0)
-        res = bn_final_exp(P, T, FF, gam)
+        FF = bn_miller(P, T, f, 6 * k, 0, curve)
+        res = bn_final_exp(P, T, FF, gam, curve)
         # plain residues into set E preloaded with the identity; lanes whose pair is dead keep the identity
         P.misc([dict(op=OP_CLOAD, dst=BN_E + i, arg=P.c_plain_one if i == 0 else P.c_zero) for i in range(12)], "one")
         P.dot(sum((outs2(BN_E + 2 * j, BN_E + 2 * j + 1, Acc2().prod_const(res[j], one, None), mask=k + 1) for j in range(6)), []),
@@ -1394,6 +1445,12 @@ def build_bn256_check():
     T.fill12(BN_D, 4)
     P.misc([dict(op=OP_CMP_EQ, dst=BN_E + i, arg=BN_D + i) for i in range(12)], "equal")
     return P
+
+
+def build_bn256_pair(): return build_bn_pair(BN256)
+def build_bn256_check(): return build_bn_check(BN256)
+def build_bn254_pair(): return build_bn_pair(BN254)
+def build_bn254_check(): return build_bn_check(BN254)
 
 
 # ------------------------------------------------------------------------------------------------ emission
@@ -1408,18 +1465,18 @@ def emit_field(f, struct_name):
     p = f.p
 
     def digits(x):
-        assert x >> (W * (f.N + 1)) == 0
-        return [(x >> (W * i)) & ((1 << W) - 1) for i in range(f.N + 1)]
+        assert x >> (f.W * (f.N + 1)) == 0
+        return [(x >> (f.W * i)) & ((1 << f.W) - 1) for i in range(f.N + 1)]
 
     def arr(v):
         return ", ".join("0x%xu" % d for d in v)
 
     return "\n".join([
         f"struct {struct_name} {{",
-        f"    static constexpr int N = {f.N}, NW = {f.NW};",
-        f"    static constexpr int32_t P[{f.N}] = {{{', '.join(str(d) for d in f.balanced(p))}}};  // balanced 28-bit digits of p",
-        f"    static constexpr uint32_t NINV = 0x{f.ninv:x}u;  // -p^-1 mod 2^28",
-        f"    static constexpr uint32_t P1[{f.N + 1}] = {{{arr(digits(p))}}};  // p, 2p, 4p: unsigned 28-bit digits",
+        f"    static constexpr int N = {f.N}, NW = {f.NW}, W = {f.W};  // limbs, packed words, bits per limb",
+        f"    static constexpr int32_t P[{f.N}] = {{{', '.join(str(d) for d in f.balanced(p))}}};  // balanced W-bit digits of p",
+        f"    static constexpr uint32_t NINV = 0x{f.ninv:x}u;  // -p^-1 mod 2^W",
+        f"    static constexpr uint32_t P1[{f.N + 1}] = {{{arr(digits(p))}}};  // p, 2p, 4p: unsigned W-bit digits",
         f"    static constexpr uint32_t P2[{f.N + 1}] = {{{arr(digits(2 * p))}}};",
         f"    static constexpr uint32_t P4[{f.N + 1}] = {{{arr(digits(4 * p))}}};",
         "};"])
@@ -1447,7 +1504,8 @@ def emit_prog(P, name):
 
 def main():
     for suite, struct, builders in (("bls12381", "Bls12381Vm", (build_bls12381_pair, build_bls12381_check)),
-                                    ("bn256", "Bn256Vm", (build_bn256_pair, build_bn256_check))):
+                                    ("bn256", "Bn256Vm", (build_bn256_pair, build_bn256_check)),
+                                    ("bn254", "Bn254Vm", (build_bn254_pair, build_bn254_check))):
         pair, check = builders[0](), builders[1]()
         up = suite.upper()
         out = ["// generated by gen_tower_vm.py -- do not edit", "#pragma once", "#include <stdint.h>", "namespace kyb {",

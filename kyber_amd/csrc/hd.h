@@ -25,4 +25,9 @@ constexpr uint32_t FLAG_UNCOMPRESSED = 2u;  // BLS12-381 point inputs are ZCash 
 constexpr uint32_t FLAG_UNCOMPRESSED_OUT = 4u;  // BLS12-381 point outputs of mul are uncompressed too
 constexpr uint32_t FLAG_TRUSTED0 = 0x100u;  // point argument i (bit 8 + i) was validated before: skip its checks
 KYB_HD bool flag_trusted(uint32_t flags, int arg) { return (flags >> (8 + arg)) & 1u; }
+
+struct DstArg {  // hash-to-curve domain separation tag, passed by value to the kernels (RFC 9380: at most 255 bytes)
+    uint8_t b[256];
+    uint32_t len;
+};
 }  // namespace kyb

@@ -17,7 +17,7 @@
 //   * Fp elements are 14 signed 28-bit limbs (balanced digits, |limb| <= 2^27, Montgomery radix R = 2^392) so that
 //     v_mad_i64_i32 is the whole inner loop, subtraction is limb-wise, and there is no conditional subtraction anywhere:
 //     values are only bounded (|v| < B p, B tracked by the program generator), canonical form is produced once, at the
-//     output.  (bn256: 10 limbs, R = 2^280.)
+//     output.  (bn256: 10 limbs, R = 2^280; bn254: 10 limbs of 27 bits, R = 2^270.)
 //   * the program (which slots, which coefficients) is data: gen_tower_vm.py emits it, tests/test_tower_vm_program.py
 //     replays it in exact integer arithmetic against the oracle's pairing, and proves the column / limb bounds.
 #pragma once
@@ -102,7 +102,9 @@ struct Lds {
     }
 };
 
-KYB_HD int32_t sext28(uint32_t x) { return (int32_t)(x << 4) >> 4; }
+// sign extension from a W-bit digit (W = F::W: 28 bits, 27 for bn254 -- gen_tower_vm.py says why)
+template <int W>
+KYB_HD int32_t sext(uint32_t x) { return (int32_t)(x << (32 - W)) >> (32 - W); }
 
 // v = c1 S[s1] + c2 S[s2]; the coefficients are wave-uniform, so the branches are scalar
 template <class F>
@@ -131,16 +133,16 @@ __device__ __forceinline__ void operand(int32_t (&v)[F::N], const uint32_t* lds,
     }
 }
 
-// Columns t[N .. 2N-1] (after the reduction) or any N columns -> balanced 28-bit limbs.  The top limb absorbs the last
+// Columns t[N .. 2N-1] (after the reduction) or any N columns -> balanced W-bit limbs.  The top limb absorbs the last
 // carry (the generator bounds the value so that it fits).
-template <int N>
+template <int N, int W>
 __device__ __forceinline__ void normalise(int32_t (&r)[N], const int64_t* t) {
     int64_t carry = 0;
 #pragma unroll
     for (int c = 0; c < N - 1; c++) {
         const int64_t v = t[c] + carry;
-        carry = (v + (int64_t(1) << 27)) >> 28;
-        r[c] = sext28((uint32_t)v);
+        carry = (v + (int64_t(1) << (W - 1))) >> W;
+        r[c] = sext<W>((uint32_t)v);
     }
     r[N - 1] = (int32_t)(t[N - 1] + carry);
 }
@@ -149,28 +151,29 @@ __device__ __forceinline__ void normalise(int32_t (&r)[N], const int64_t* t) {
 // T R^-1 mod p (|.| < |T| / R + p/2 + small) in t[N .. 2N-1].
 template <class F>
 __device__ __forceinline__ void mont_reduce(int64_t (&t)[2 * F::N]) {
-    constexpr int N = F::N;
+    constexpr int N = F::N, W = F::W;
 #pragma unroll
     for (int i = 0; i < N; i++) {
-        const int32_t m = sext28((uint32_t)t[i] * F::NINV);
+        const int32_t m = sext<W>((uint32_t)t[i] * F::NINV);
 #pragma unroll
         for (int j = 0; j < N; j++) t[i + j] += (int64_t)m * F::P[j];
-        t[i + 1] += t[i] >> 28;  // exact: the low 28 bits are zero
+        t[i + 1] += t[i] >> W;  // exact: the low W bits are zero
     }
 }
 
-// Canonical words of a bounded balanced value: v + 4p in (0, 8p), as N + 1 unsigned 28-bit digits, brought into [0, p)
+// Canonical words of a bounded balanced value: v + 4p in (0, 8p), as N + 1 unsigned W-bit digits, brought into [0, p)
 // by three conditional subtractions (4p, 2p, p), then packed into NW 32-bit words.  Requires |v| < 4p.
 template <class F>
 __device__ void canon_words(uint32_t (&w)[F::NW], const int32_t (&l)[F::N]) {
-    constexpr int N = F::N, NW = F::NW, ND = N + 1;
+    constexpr int N = F::N, NW = F::NW, ND = N + 1, W = F::W;
+    constexpr uint32_t MASK = (1u << W) - 1;
     uint32_t d[ND];
     int64_t carry = 0;
 #pragma unroll
     for (int i = 0; i < N; i++) {
         const int64_t x = (int64_t)l[i] + (int64_t)F::P4[i] + carry;
-        d[i] = (uint32_t)x & 0x0fffffffu;
-        carry = x >> 28;
+        d[i] = (uint32_t)x & MASK;
+        carry = x >> W;
     }
     d[N] = (uint32_t)(carry + (int64_t)F::P4[N]);
 #pragma unroll
@@ -181,7 +184,7 @@ __device__ void canon_words(uint32_t (&w)[F::NW], const int32_t (&l)[F::N]) {
         for (int i = 0; i < ND; i++) {
             const uint32_t k = s == 2 ? F::P4[i] : (s == 1 ? F::P2[i] : F::P1[i]);
             const int32_t z = (int32_t)d[i] - (int32_t)k - borrow;
-            y[i] = (uint32_t)z & 0x0fffffffu;
+            y[i] = (uint32_t)z & MASK;
             borrow = (z >> 31) & 1;
         }
         const uint32_t keep = 0u - (uint32_t)borrow;  // all ones: d < k p, keep d
@@ -190,27 +193,27 @@ __device__ void canon_words(uint32_t (&w)[F::NW], const int32_t (&l)[F::N]) {
     }
 #pragma unroll
     for (int k = 0; k < NW; k++) {
-        const int bit = 32 * k, jj = bit / 28, o = bit - 28 * jj;
+        const int bit = 32 * k, jj = bit / W, o = bit - W * jj;
         uint32_t v = d[jj] >> o;
-        if (jj + 1 <= N) v |= d[jj + 1] << (28 - o);
-        if (56 - o < 32 && jj + 2 <= N) v |= d[jj + 2] << (56 - o);
+        if (jj + 1 <= N) v |= d[jj + 1] << (W - o);
+        if (2 * W - o < 32 && jj + 2 <= N) v |= d[jj + 2] << (2 * W - o);
         w[k] = v;
     }
 }
 
-// NW packed words (a value in [0, 2^(32 NW))) -> N unsigned 28-bit digits, normalised to balanced ones
+// NW packed words (a value in [0, 2^(32 NW))) -> N unsigned W-bit digits, normalised to balanced ones
 template <class F>
 __device__ void words_to_limbs(int32_t (&r)[F::N], const uint32_t (&w)[F::NW]) {
-    constexpr int N = F::N, NW = F::NW;
+    constexpr int N = F::N, NW = F::NW, W = F::W;
     int64_t t[N];
 #pragma unroll
     for (int j = 0; j < N; j++) {
-        const int bit = 28 * j, idx = bit >> 5, sh = bit & 31;
+        const int bit = W * j, idx = bit >> 5, sh = bit & 31;
         uint32_t x = idx < NW ? (w[idx] >> sh) : 0u;
-        if (sh + 28 > 32 && idx + 1 < NW) x |= w[idx + 1] << (32 - sh);
-        t[j] = (int64_t)(x & 0x0fffffffu);
+        if (sh + W > 32 && idx + 1 < NW) x |= w[idx + 1] << (32 - sh);
+        t[j] = (int64_t)(x & ((1u << W) - 1));
     }
-    normalise<N>(r, t);
+    normalise<N, W>(r, t);
 }
 
 // The interpreter.  `Inv` supplies the base-field inversion on packed words (the per-lane field code's Kaliski inverse).
@@ -299,12 +302,12 @@ __device__ void run(const Args& a, uint32_t* lds, uint32_t* misc, const int32_t*
                             }
                         }
                         if (!((hdr >> 13) & 1u)) mont_reduce<F>(t);
-                        normalise<N>(r, t + N);
+                        normalise<N, F::W>(r, t + N);
                         const int scale = (hdr >> 14) & 31u;
                         if (scale > 1) {  // small factor (<= 15) on the normalised limbs, normalised again
 #pragma unroll
                             for (int i = 0; i < N; i++) t[i] = (int64_t)r[i] * scale;
-                            normalise<N>(r, t);
+                            normalise<N, F::W>(r, t);
                         }
                         const uint32_t mask = (hdr >> 19) & 3u;
                         if (mask) {  // lanes whose pair is dead keep the old value of the output slot

@@ -13,7 +13,7 @@ _lib = None
 def _deps_digest() -> str:
     """Content hash of the harness source + every device header (mtimes do not survive a snapshot copy)."""
     csrc = os.path.join(ROOT, "kyber_amd", "csrc")
-    deps = [SRC] + sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".cuh", ".h")))
+    deps = [SRC] + sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".cuh", ".h", ".inc")) and not f.startswith("tower_vm_"))
     h = hashlib.sha256()
     for d in deps:
         h.update(os.path.basename(d).encode())

@@ -7,6 +7,7 @@
 
 #include "../kyber_amd/csrc/bls12381.cuh"
 #include "../kyber_amd/csrc/bls12381_h2c.cuh"
+#include "../kyber_amd/csrc/bn254.cuh"
 #include "../kyber_amd/csrc/bn256.cuh"
 #include "../kyber_amd/csrc/ed25519_h2c.cuh"
 
@@ -114,12 +115,49 @@ int hh_bn_fp12_op(int op, const uint8_t* a384, const uint8_t* b384, uint8_t* out
 int hh_bn_gt_mul(const uint8_t* k, const uint8_t* gt, uint8_t* out) { return bn::gt_mul_wire(out, k, gt); }
 int hh_bls_gt_mul(const uint8_t* k, const uint8_t* gt, uint8_t* out) { return bls::gt_mul_wire(out, k, gt); }
 int hh_bn_hash_g1(const uint8_t* msg, int len, uint8_t* out) { return bn::hash_g1_wire(out, msg, (size_t)len); }
-static bls::DstArg mk_dst(const uint8_t* dst, int len) {
-    bls::DstArg d;
+// bn254: the same library at alt_bn128's constants with the strict decoding rules, and its Keccak / SvdW hash
+int hh_bn4_g1_decode(const uint8_t* in) { bn4::g1_aff a; return bn4::g1_decode(a, in); }
+int hh_bn4_g2_decode(const uint8_t* in, int check) { bn4::g2_aff a; return bn4::g2_decode(a, in, check != 0); }
+int hh_bn4_g1_mul(const uint8_t* k, const uint8_t* pt, uint8_t* out) { return bn4::g1_mul_wire(out, k, pt); }
+int hh_bn4_g2_mul(const uint8_t* k, const uint8_t* pt, int flags, uint8_t* out) { return bn4::g2_mul_wire(out, k, pt, (uint32_t)flags); }
+int hh_bn4_g1_add(const uint8_t* a, const uint8_t* b, uint8_t* out) { return bn4::g1_add_wire(out, a, b); }
+int hh_bn4_g2_add(const uint8_t* a, const uint8_t* b, uint8_t* out) { return bn4::g2_add_wire(out, a, b); }
+int hh_bn4_gt_mul(const uint8_t* k, const uint8_t* gt, uint8_t* out) { return bn4::gt_mul_wire(out, k, gt); }
+int hh_bn4_fp12_op(int op, const uint8_t* a384, const uint8_t* b384, uint8_t* out384) {
+    bn4::fp12 a, b, r;
+    bn4::gt_decode(a, a384);
+    bn4::gt_decode(b, b384);
+    if (op == 0) fp12_mul(r, a, b);
+    else fp12_sqr(r, a);
+    bn4::gt_encode(out384, r);
+    return 0;
+}
+void hh_bn4_keccak256(const uint8_t* msg, int len, uint8_t* out32) {
+    Keccak256 c;
+    c.init();
+    c.update(msg, (size_t)len);
+    uint8_t d[32];
+    c.finish(d);
+    memcpy(out32, d, 32);
+}
+void hh_bn4_map_to_point(const uint8_t* u32, uint8_t* out64) {
+    bn4::fp u;
+    bn4::fp_decode(u, u32);
+    bn4::g1_jac r;
+    bn4::map_to_point(r, u);
+    bn4::g1_aff a;
+    jac_to_aff(a, r);
+    bn4::g1_encode(out64, a);
+}
+static DstArg mk_dst(const uint8_t* dst, int len) {
+    DstArg d;
     memset(&d, 0, sizeof d);
     memcpy(d.b, dst, (size_t)len);
     d.len = (uint32_t)len;
     return d;
+}
+int hh_bn4_hash_g1(const uint8_t* msg, int len, const uint8_t* dst, int dlen, uint8_t* out) {
+    return bn4::hash_g1_wire(out, msg, (size_t)len, mk_dst(dst, dlen));
 }
 int hh_bls_hash_g1(const uint8_t* msg, int len, const uint8_t* dst, int dlen, uint8_t* out) {
     return bls::hash_g1_wire(out, msg, (size_t)len, mk_dst(dst, dlen));

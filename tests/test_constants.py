@@ -2,6 +2,8 @@
 import os
 import re
 
+import pytest
+
 from oracle import ed25519 as O
 
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kyber_amd", "csrc")
@@ -75,30 +77,18 @@ def test_bls12381_params():
     mont = lambda limbs: _val(limbs, w) * ri % B.P
     assert mont(arr["B1"][0]) == 4
     assert (mont(arr["G1X"][0]), mont(arr["G1Y"][0])) == B.G1_GEN
-    # FROB[k-1][j] = xi^(j (p^k - 1) / 6): flattened 3 x 6 x 2 limb arrays
-    frob = arr["FROB"][0]
-    flat = [frob[i * n:(i + 1) * n] for i in range(len(frob) // n)]
-    for k in (1, 2, 3):
-        for j in range(6):
-            c0, c1 = flat[((k - 1) * 6 + j) * 2], flat[((k - 1) * 6 + j) * 2 + 1]
-            assert (mont(c0), mont(c1)) == B.f2_pow(B.XI, j * (B.P**k - 1) // 6)
     # beta: phi(P) = (beta x, y) acts as [-x^2] on G1
     beta = mont(arr["BETA"][0])
     g = B.G1_GEN
     assert (g[0] * beta % B.P, g[1]) == B.g1_mul((-B.X_ABS**2) % B.R, g)
-    lam3 = _val(arr["LAMBDA3"][0], 32)
-    x = -B.X_ABS
-    assert lam3 * 3 == (x - 1) ** 2
-    l2 = x * lam3
-    l1 = x * l2 - lam3
-    l0 = x * l1 + 1
-    assert l0 + l1 * B.P + l2 * B.P**2 + lam3 * B.P**3 == (B.P**4 - B.P**2 + 1) // B.R
 
 
-def test_bn256_params():
-    from oracle import bn256 as N
+@pytest.mark.parametrize("name", ["bn256", "bn254"])
+def test_bn_params(name):
+    import importlib
 
-    arr, R, w, n = _check_field(N.P, "bn256_params.h")
+    N = importlib.import_module("oracle." + name)
+    arr, R, w, n = _check_field(N.P, name + "_params.h")
     ri = pow(R, -1, N.P)
     mont = lambda limbs: _val(limbs, w) * ri % N.P
     assert mont(arr["B1"][0]) == 3
@@ -108,6 +98,17 @@ def test_bn256_params():
     assert (mont(b2[0]), mont(b2[1])) == N.TWIST_B
     gx, gy = flat(arr["G2X"][0]), flat(arr["G2Y"][0])
     assert ((mont(gx[0]), mont(gx[1])), (mont(gy[0]), mont(gy[1]))) == N.G2_GEN
-    q1x = flat(arr["Q1X"][0])
-    assert (mont(q1x[0]), mont(q1x[1])) == N.f2_pow(N.XI, (N.P - 1) // 3)
-    assert mont(arr["Q2X"][0]) == N.f2_pow(N.XI, (N.P * N.P - 1) // 3)[0]
+    assert _val(arr["ORDER"][0], 32) == N.ORDER
+    # GLV: phi(x, y) = (beta x, y) is [lambda] on G1 and the split reproduces k for edge scalars
+    beta = mont(arr["BETA"][0])
+    lam = 36 * N.U**3 + 18 * N.U**2 + 6 * N.U + 1
+    g = N.G1_GEN
+    assert (g[0] * beta % N.P, g[1]) == N.g1_mul(lam, g)
+    a1, b1n, a2, b2v = (_val(arr[k][0], 32) for k in ("GLV_A1", "GLV_B1N", "GLV_A2", "GLV_B2"))
+    g1, g2 = _val(arr["GLV_G1"][0], 32), _val(arr["GLV_G2"][0], 32)
+    for k in (0, 1, N.ORDER - 1, N.ORDER, (1 << 256) - 1, lam, 0xDEADBEEF << 200):
+        c1, c2 = (k * g1) >> 256, (k * g2) >> 256
+        k1, k2 = k - c1 * a1 - c2 * a2, c1 * b1n - c2 * b2v
+        assert (k1 + k2 * lam - k) % N.ORDER == 0 and abs(k1) < 1 << 130 and abs(k2) < 1 << 130
+    if name == "bn254":
+        assert [mont(arr["SVDW_C%d" % i][0]) for i in (1, 2, 3, 4)] == [N.SVDW_C1, N.SVDW_C2, N.SVDW_C3, N.SVDW_C4]

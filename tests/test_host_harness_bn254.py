@@ -1,0 +1,92 @@
+"""The BN device library instantiated at pairing/bn254's constants (kyber_amd/csrc/bn254.cuh), compiled for the host,
+against the bn254 oracle and the reference's own vectors (tests/golden/bn254.json)."""
+import json
+import os
+import random
+
+import pytest
+
+from oracle import bn254 as O
+from tests import _host_harness as H
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "bn254.json")))
+
+
+def _be(v):
+    return v.to_bytes(32, "big")
+
+
+def test_keccak_expand_and_hash_vectors(G):
+    for n in (0, 1, 55, 135, 136, 137, 272, 500):
+        m = bytes((i * 7 + 3) & 0xFF for i in range(n))
+        assert H.call("hh_bn4_keccak256", m, n, out_sizes=(32,))[1] == O.keccak256(m)
+    dst = G["hash_g1_dst"].encode()
+    for h in G["hash_g1"]:                                   # point_test.go:14-48
+        m = bytes.fromhex(h["msg_hex"])
+        assert H.call("hh_bn4_hash_g1", m, len(m), dst, len(dst), out_sizes=(64,)) == (0, bytes.fromhex(h["point"]))
+    d2 = G["h2f_dst"].encode()
+    for v in G["hash_to_field"][:12]:                        # hash_to_field feeds the map: compare whole hashes with the oracle
+        m = bytes.fromhex(v["msg"])
+        assert H.call("hh_bn4_hash_g1", m, len(m), d2, len(d2), out_sizes=(64,)) == (0, O.g1_marshal(O.hash_to_g1(m, d2)))
+
+
+def test_map_to_point_vectors(G):
+    for u, x, y in G["map_to_point"][::5]:                   # 200 of the 1000 reference vectors
+        assert H.call("hh_bn4_map_to_point", _be(int(u)), out_sizes=(64,))[1] == _be(int(x)) + _be(int(y))
+    for u in (0, 1, O.P - 1):
+        assert H.call("hh_bn4_map_to_point", _be(u), out_sizes=(64,))[1] == O.g1_marshal(O.map_to_point(u))
+
+
+def test_scalar_multiplication_and_strict_decoding():
+    rng = random.Random(41)
+    g1, g2 = O.g1_marshal(O.G1_GEN), O.g2_marshal(O.G2_GEN)
+    for k in [0, 1, 2, O.ORDER - 1, O.ORDER, O.ORDER + 5, (1 << 256) - 1] + [rng.getrandbits(256) for _ in range(6)]:
+        kb = k.to_bytes(32, "big")
+        assert H.call("hh_bn4_g1_mul", kb, g1, out_sizes=(64,)) == (0, O.g1_marshal(O.g1_mul(k, O.G1_GEN)))
+    for k in [0, 1, O.ORDER - 1, rng.getrandbits(256), rng.getrandbits(255)]:
+        kb = k.to_bytes(32, "big")
+        assert H.call("hh_bn4_g2_mul", kb, g2, 0, out_sizes=(128,)) == (0, O.g2_marshal(O.g2_mul(k, O.G2_GEN)))
+    p = O.g1_mul(rng.getrandbits(200), O.G1_GEN)
+    q = O.g2_mul(rng.getrandbits(200), O.G2_GEN)
+    assert H.call("hh_bn4_g1_add", O.g1_marshal(p), g1, out_sizes=(64,)) == (0, O.g1_marshal(O.g1_add(p, O.G1_GEN)))
+    assert H.call("hh_bn4_g1_add", O.g1_marshal(p), O.g1_marshal(p), out_sizes=(64,)) == (0, O.g1_marshal(O.g1_add(p, p)))
+    assert H.call("hh_bn4_g2_add", O.g2_marshal(q), g2, out_sizes=(128,)) == (0, O.g2_marshal(O.g2_add(q, O.G2_GEN)))
+    # infinity, coordinates >= p (gfp.go:101-118), off the curve
+    x, y = O.G1_GEN
+    assert H.call("hh_bn4_g1_decode", bytes(64))[0] == 0
+    assert H.call("hh_bn4_g1_decode", _be(x + O.P) + _be(y))[0] == 1
+    assert H.call("hh_bn4_g1_decode", _be(O.P) + _be(O.P))[0] == 1
+    assert H.call("hh_bn4_g1_decode", _be(5) + _be(5))[0] == 1
+    assert H.call("hh_bn4_g1_mul", _be(7), bytes(64), out_sizes=(64,)) == (0, bytes(64))
+    assert H.call("hh_bn4_g1_mul", _be(7), _be(x + O.P) + _be(y), out_sizes=(64,)) == (1, bytes(64))
+    assert H.call("hh_bn4_g2_decode", bytes(128), 1)[0] == 0
+    assert H.call("hh_bn4_g2_decode", _be(O.P) + g2[32:], 1)[0] == 1
+    # a twist point outside the order-n subgroup: rejected (twist.go:62-65) unless the caller vouches for the operand
+    while True:
+        xx = (rng.randrange(O.P), rng.randrange(O.P))
+        yy = O.f2_sqrt(O.f2_add(O.f2_mul(O.f2_sqr(xx), xx), O.TWIST_B))
+        if yy is not None:
+            break
+    off = O.g2_marshal((xx, yy))
+    assert H.call("hh_bn4_g2_decode", off, 1)[0] == 2 and H.call("hh_bn4_g2_decode", off, 0)[0] == 0
+    assert H.call("hh_bn4_g2_mul", _be(3), off, 0, out_sizes=(128,)) == (2, bytes(128))
+    assert H.call("hh_bn4_g2_mul", _be(3), off, 0x100, out_sizes=(128,)) == (0, O.g2_marshal(O.g2_mul(3, (xx, yy))))
+
+
+def test_gt_exponentiation_and_tower():
+    g = O.pair(O.g1_mul(5, O.G1_GEN), O.g2_mul(7, O.G2_GEN))
+    gb = O.gt_marshal(g)
+    for k in (0, 1, 0xC0FFEE, O.ORDER - 1):
+        assert H.call("hh_bn4_gt_mul", _be(k), gb, out_sizes=(384,)) == (0, O.gt_marshal(O.f12_pow(g, k)))
+    assert H.call("hh_bn4_gt_mul", _be(3), _be(O.P) + gb[32:], out_sizes=(384,)) == (1, bytes(384))
+    top = (O.P - 1, O.P - 1)
+    rng = random.Random(43)
+    cases = [[top] * 6, [top if k % 2 else (0, 0) for k in range(6)], [(rng.randrange(O.P), rng.randrange(O.P)) for _ in range(6)]]
+    for a in cases:                                          # xi = 9 + i in the lazy Karatsuba sums of the shared tower code
+        ab = O.gt_marshal(a)
+        for b in cases:
+            assert H.call("hh_bn4_fp12_op", 0, ab, O.gt_marshal(b), out_sizes=(384,)) == (0, O.gt_marshal(O.f12_mul(a, b)))
+        assert H.call("hh_bn4_fp12_op", 1, ab, ab, out_sizes=(384,)) == (0, O.gt_marshal(O.f12_sqr(a)))
