@@ -290,6 +290,49 @@ int kyb_bn256_pair_check(size_t n, const uint8_t *p1, const uint8_t *p2, const u
 int kyb_bn256_pair_check_dev(size_t n, const void *d_p1, const void *d_p2, const void *d_inv1, const void *d_inv2,
                              void *d_ok, void *d_status, uint32_t flags, void *stream);
 
+/* ------------------------------------------------------------------ bn254
+ * pairing/bn254 (Ethereum's alt_bn128; the bn256 package over other constants, xi = 9 + i).  Wire formats and entry
+ * points as bn256 (scalars 32-byte big-endian, G1 64, G2 128, GT 384 bytes; point.go:127-200, 431-520, 617-735), with
+ * this suite's stricter UnmarshalBinary kept:
+ *   - a coordinate >= p is an error (gfp.go:101-118), not reduced                      -> KYB_ST_BAD_POINT
+ *   - G2 points must lie in the order-n subgroup (twist.go:47-66: [Order]Q = infinity)  -> KYB_ST_NOT_IN_SUBGROUP
+ *     KYB_F_TRUSTED(i) on a G2 operand skips that check (the caller unmarshalled the point before), as on BLS12-381.
+ *   - GT coefficients >= p are rejected by gt_mul (point.go:662-735).
+ * pointG1.Mul walks a GLV lattice decomposition (curve.go:196-222); the multiple is the same group element.
+ * ValidatePairing = two pairings + Equal (suite.go:134-140).  No Hash on G2 (the reference has none). */
+int kyb_bn254_g1_mul(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status, uint32_t flags);
+int kyb_bn254_g2_mul(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status, uint32_t flags);
+int kyb_bn254_g1_mul_same_base(size_t n, const uint8_t *scalars, const uint8_t point[64], uint8_t *out,
+                               uint8_t *status, uint32_t flags);
+int kyb_bn254_g2_mul_same_base(size_t n, const uint8_t *scalars, const uint8_t point[128], uint8_t *out,
+                               uint8_t *status, uint32_t flags);
+int kyb_bn254_g1_mul_dev(size_t n, const void *d_scalars, const void *d_points, size_t point_stride, void *d_out,
+                         void *d_status, uint32_t flags, void *stream);
+int kyb_bn254_g2_mul_dev(size_t n, const void *d_scalars, const void *d_points, size_t point_stride, void *d_out,
+                         void *d_status, uint32_t flags, void *stream);
+int kyb_bn254_g1_add(size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out, uint8_t *status);
+int kyb_bn254_g2_add(size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out, uint8_t *status);
+int kyb_bn254_g1_unmarshal(size_t n, const uint8_t *points, uint8_t *out, uint8_t *status, uint32_t flags);
+int kyb_bn254_g2_unmarshal(size_t n, const uint8_t *points, uint8_t *out, uint8_t *status, uint32_t flags);
+int kyb_bn254_g1_unmarshal_dev(size_t n, const void *d_points, void *d_out, void *d_status, uint32_t flags, void *stream);
+int kyb_bn254_g2_unmarshal_dev(size_t n, const void *d_points, void *d_out, void *d_status, uint32_t flags, void *stream);
+int kyb_bn254_pair(size_t n, const uint8_t *g1, const uint8_t *g2, uint8_t *gt, uint8_t *status, uint32_t flags);
+int kyb_bn254_pair_dev(size_t n, const void *d_g1, const void *d_g2, void *d_gt, void *d_status, uint32_t flags, void *stream);
+int kyb_bn254_gt_mul(size_t n, const uint8_t *scalars, const uint8_t *gt, uint8_t *out, uint8_t *status);
+int kyb_bn254_gt_mul_dev(size_t n, const void *d_scalars, const void *d_gt, void *d_out, void *d_status, void *stream);
+int kyb_bn254_pair_check(size_t n, const uint8_t *p1, const uint8_t *p2, const uint8_t *inv1, const uint8_t *inv2,
+                         uint8_t *ok, uint8_t *status, uint32_t flags);
+int kyb_bn254_pair_check_dev(size_t n, const void *d_p1, const void *d_p2, const void *d_inv1, const void *d_inv2,
+                             void *d_ok, void *d_status, uint32_t flags, void *stream);
+/* out[i] = Hash(msgs[i]) on G1: pointG1.Hash -> hashToPoint (point.go:207-285): RFC 9380 hash_to_curve with
+ * expand_message_xmd over legacy Keccak-256, the Shallue-van de Woestijne map (constants.go:72-84), no cofactor.
+ * dst = the suite's domain separation tag (suite.go:42-44: "BN254G1_XMD:KECCAK-256_SVDW_RO_" unless SetDomainG1), at
+ * most 255 bytes.  All n messages have the same length msg_len and are packed back to back. */
+int kyb_bn254_hash_g1(size_t n, const uint8_t *msgs, size_t msg_len, const uint8_t *dst, size_t dst_len, uint8_t *out,
+                      uint8_t *status);
+int kyb_bn254_hash_g1_dev(size_t n, const void *d_msgs, size_t msg_len, const uint8_t *dst, size_t dst_len, void *d_out,
+                          void *d_status, void *stream);
+
 /* ------------------------------------------------------- multi-scalar multiplication
  * out = sum_i scalars[i] * points[i]  (one point).  The reference has no MSM function: its
  * MSM-shaped call sites do N x (Mul + Add) sequentially -- share.PubPoly.Eval (share/poly.go:340-348),
@@ -342,6 +385,21 @@ int kyb_bn256_g2_poly_eval(size_t n, const uint32_t *idx, size_t t, const uint8_
 int kyb_bn256_g1_poly_eval_dev(size_t n, const void *d_idx, size_t t, const void *d_commits, void *d_out,
                                void *d_status, uint32_t flags, void *stream);
 int kyb_bn256_g2_poly_eval_dev(size_t n, const void *d_idx, size_t t, const void *d_commits, void *d_out,
+                               void *d_status, uint32_t flags, void *stream);
+/* pairing/bn254: the same eight entry points */
+int kyb_bn254_g1_msm(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t out[64], uint8_t *status, uint32_t flags);
+int kyb_bn254_g2_msm(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t out[128], uint8_t *status, uint32_t flags);
+int kyb_bn254_g1_msm_dev(size_t n, const void *d_scalars, const void *d_points, void *d_out, void *d_status,
+                         uint32_t flags, void *stream);
+int kyb_bn254_g2_msm_dev(size_t n, const void *d_scalars, const void *d_points, void *d_out, void *d_status,
+                         uint32_t flags, void *stream);
+int kyb_bn254_g1_poly_eval(size_t n, const uint32_t *idx, size_t t, const uint8_t *commits, uint8_t *out,
+                           uint8_t *status, uint32_t flags);
+int kyb_bn254_g2_poly_eval(size_t n, const uint32_t *idx, size_t t, const uint8_t *commits, uint8_t *out,
+                           uint8_t *status, uint32_t flags);
+int kyb_bn254_g1_poly_eval_dev(size_t n, const void *d_idx, size_t t, const void *d_commits, void *d_out,
+                               void *d_status, uint32_t flags, void *stream);
+int kyb_bn254_g2_poly_eval_dev(size_t n, const void *d_idx, size_t t, const void *d_commits, void *d_out,
                                void *d_status, uint32_t flags, void *stream);
 
 #ifdef __cplusplus

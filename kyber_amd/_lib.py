@@ -113,6 +113,34 @@ SIGNATURES = {
     "kyb_bn256_g2_poly_eval": [_sz, _vp, _sz, _vp, _vp, _vp, _u32],
     "kyb_bn256_g1_poly_eval_dev": [_sz, _vp, _sz, _vp, _vp, _vp, _u32, _vp],
     "kyb_bn256_g2_poly_eval_dev": [_sz, _vp, _sz, _vp, _vp, _vp, _u32, _vp],
+    "kyb_bn254_g1_msm": [_sz, _vp, _vp, _vp, _vp, _u32],
+    "kyb_bn254_g2_msm": [_sz, _vp, _vp, _vp, _vp, _u32],
+    "kyb_bn254_g1_msm_dev": [_sz, _vp, _vp, _vp, _vp, _u32, _vp],
+    "kyb_bn254_g2_msm_dev": [_sz, _vp, _vp, _vp, _vp, _u32, _vp],
+    "kyb_bn254_g1_mul": [_sz, _vp, _vp, _vp, _vp, _u32],
+    "kyb_bn254_g2_mul": [_sz, _vp, _vp, _vp, _vp, _u32],
+    "kyb_bn254_g1_mul_same_base": [_sz, _vp, _vp, _vp, _vp, _u32],
+    "kyb_bn254_g2_mul_same_base": [_sz, _vp, _vp, _vp, _vp, _u32],
+    "kyb_bn254_g1_mul_dev": [_sz, _vp, _vp, _sz, _vp, _vp, _u32, _vp],
+    "kyb_bn254_g2_mul_dev": [_sz, _vp, _vp, _sz, _vp, _vp, _u32, _vp],
+    "kyb_bn254_g1_add": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_bn254_g2_add": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_bn254_pair": [_sz, _vp, _vp, _vp, _vp, _u32],
+    "kyb_bn254_gt_mul": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_bn254_gt_mul_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
+    "kyb_bn254_pair_dev": [_sz, _vp, _vp, _vp, _vp, _u32, _vp],
+    "kyb_bn254_pair_check": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _u32],
+    "kyb_bn254_pair_check_dev": [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
+    "kyb_bn254_g1_unmarshal": [_sz, _vp, _vp, _vp, _u32],
+    "kyb_bn254_g1_unmarshal_dev": [_sz, _vp, _vp, _vp, _u32, _vp],
+    "kyb_bn254_g2_unmarshal": [_sz, _vp, _vp, _vp, _u32],
+    "kyb_bn254_g2_unmarshal_dev": [_sz, _vp, _vp, _vp, _u32, _vp],
+    "kyb_bn254_g1_poly_eval": [_sz, _vp, _sz, _vp, _vp, _vp, _u32],
+    "kyb_bn254_g2_poly_eval": [_sz, _vp, _sz, _vp, _vp, _vp, _u32],
+    "kyb_bn254_g1_poly_eval_dev": [_sz, _vp, _sz, _vp, _vp, _vp, _u32, _vp],
+    "kyb_bn254_g2_poly_eval_dev": [_sz, _vp, _sz, _vp, _vp, _vp, _u32, _vp],
+    "kyb_bn254_hash_g1": [_sz, _vp, _sz, _vp, _sz, _vp, _vp],
+    "kyb_bn254_hash_g1_dev": [_sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp],
 }
 _RESTYPES = {"kyb_last_error": C.c_char_p, "kyb_shard_range": None}
 

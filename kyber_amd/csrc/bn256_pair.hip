@@ -1,178 +1,10 @@
-// bn256 Suite.Pair / Suite.ValidatePairing (pairing/bn256/suite.go:97-107 -> optimalAte, optate.go:266-274) on the
-// cooperative tower machine (tower_vm.cuh; programs generated by gen_tower_vm.py: ate loop over the NAF of 6u + 2 with
-// homogeneous projective steps on the D-type twist, the two Frobenius steps, the final exponentiation's own addition
-// chain -- GT bytes equal the reference's), GT exponentiation one element per lane.
-//   1. bn256_*_prep_kernel, one lane per pairing: UnmarshalBinary of the operands (bn256.cuh g1_decode / g2_decode:
-//      coordinates reduced mod p, (0, 0) = infinity, on-curve check, no subgroup check -- point.go:206-238, 466-499)
-//   2. bn256_tvm_kernel<PAIR | CHECK>: 12 waves per 64 pairings, persistent workgroups.  CHECK is the reference's
-//      ValidatePairing literally: two whole pairings and a comparison.
+// pairing/bn256: Suite.Pair / ValidatePairing / pointGT.Mul entry points (bn_pair.inc over the bn256 device library
+// and its generated tower-machine programs).
 #include "bn256.cuh"
-#include "pairing_abi.cuh"
-#include "tower_vm.cuh"
 #include "tower_vm_bn256.inc"
-
-namespace kyb {
-namespace bnvm {
-
-constexpr int FP_WORDS = 8;
-constexpr uint8_t PST_INF = 0x80;  // status byte per (operand, pairing): bits 0-6 UnmarshalBinary status, bit 7 infinity
-
-struct Inv {  // the per-lane code's Kaliski inverse (radix 2^261); the program moves the result to the machine's radix
-    __device__ static void inv(uint32_t (&w)[FP_WORDS]) {
-        bn::fp x;
-#pragma unroll
-        for (int k = 0; k < FP_WORDS; k++) x.v[k] = w[k];
-        fp_inv(x, x);
-#pragma unroll
-        for (int k = 0; k < FP_WORDS; k++) w[k] = x.v[k];
-    }
-};
-
-constexpr int LDS_WORDS = 63 * Bn256Vm::N * tvm::LANES;
-static_assert(TVM_BN256_PAIR_NSLOTS == 63 && TVM_BN256_CHECK_NSLOTS == 63, "slot count");
-
-template <int CHECK>
-__global__ __launch_bounds__(tvm::THREADS) void bn256_tvm_kernel(tvm::Args a) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[LDS_WORDS];
-    __shared__ uint32_t misc[tvm::LANES];
-    __shared__ int32_t clds[16 * tvm::MAX_CONSTS];
-    a.prog = CHECK ? TVM_BN256_CHECK_PROG : TVM_BN256_PAIR_PROG;
-    a.sched = reinterpret_cast<const tvm::Sched*>(CHECK ? TVM_BN256_CHECK_SCHED : TVM_BN256_PAIR_SCHED);
-    a.nsched = CHECK ? TVM_BN256_CHECK_NSCHED : TVM_BN256_PAIR_NSCHED;
-    a.consts = reinterpret_cast<const int32_t*>(CHECK ? TVM_BN256_CHECK_CONSTS : TVM_BN256_PAIR_CONSTS);
-    constexpr uint32_t NC = CHECK ? TVM_BN256_CHECK_NCONSTS : TVM_BN256_PAIR_NCONSTS;
-    static_assert(NC <= tvm::MAX_CONSTS, "constant table exceeds its LDS copy");
-    for (uint32_t i = threadIdx.x; i < 16 * NC; i += tvm::THREADS) clds[i] = a.consts[i];
-    a.check = CHECK;
-    a.ngslots = CHECK ? TVM_BN256_CHECK_NGSLOTS : TVM_BN256_PAIR_NGSLOTS;
-    tvm::run<Bn256Vm, Inv>(a, lds, misc, clds);
-}
-
-__device__ __forceinline__ void put_fp(uint32_t* in, size_t n, int idx, size_t i, const bn::fp& x) {
-    uint32_t* d = in + ((size_t)idx * n + i) * FP_WORDS;
-#pragma unroll
-    for (int k = 0; k < FP_WORDS; k += 4) *reinterpret_cast<uint4*>(d + k) = make_uint4(x.v[k], x.v[k + 1], x.v[k + 2], x.v[k + 3]);
-}
-__device__ __forceinline__ void put_pair(uint32_t* in, size_t n, int first, size_t i, const bn::g1_aff& p, const bn::g2_aff& q) {
-    put_fp(in, n, first, i, p.x);
-    put_fp(in, n, first + 1, i, p.y);
-    put_fp(in, n, first + 2, i, q.x.c0);
-    put_fp(in, n, first + 3, i, q.x.c1);
-    put_fp(in, n, first + 4, i, q.y.c0);
-    put_fp(in, n, first + 5, i, q.y.c1);
-}
-__device__ __forceinline__ uint8_t pst_of(int st, bool inf) { return (uint8_t)((st & 0x7f) | ((inf && !st) ? PST_INF : 0)); }
-__global__ __launch_bounds__(64) void bn256_pair_prep_kernel(size_t n, const uint8_t* __restrict__ g1, const uint8_t* __restrict__ g2,
-                                                             uint32_t* __restrict__ in, uint8_t* __restrict__ pst) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    bn::g1_aff p;
-    bn::g2_aff q;
-    const int st = bn::g1_decode(p, g1 + 64 * i);
-    const int st2 = bn::g2_decode(q, g2 + 128 * i);
-    put_pair(in, n, 0, i, p, q);
-    pst[i] = pst_of(st, p.inf);
-    pst[n + i] = pst_of(st2, q.inf);
-}
-__global__ __launch_bounds__(64) void bn256_check_prep_kernel(size_t n, const uint8_t* __restrict__ p1, const uint8_t* __restrict__ p2,
-                                                              const uint8_t* __restrict__ i1, const uint8_t* __restrict__ i2,
-                                                              uint32_t* __restrict__ in, uint8_t* __restrict__ pst) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    bn::g1_aff a, c;
-    bn::g2_aff b, d;
-    const int s0 = bn::g1_decode(a, p1 + 64 * i), s1 = bn::g2_decode(b, p2 + 128 * i);
-    const int s2 = bn::g1_decode(c, i1 + 64 * i), s3 = bn::g2_decode(d, i2 + 128 * i);
-    put_pair(in, n, 0, i, a, b);
-    put_pair(in, n, 6, i, c, d);
-    pst[i] = pst_of(s0, a.inf);
-    pst[n + i] = pst_of(s1, b.inf);
-    pst[2 * n + i] = pst_of(s2, c.inf);
-    pst[3 * n + i] = pst_of(s3, d.inf);
-}
-
-struct Work {
-    uint32_t* in;
-    uint8_t* pst;
-    uint32_t* gspill;
-    unsigned grid;
-};
-inline size_t al256(size_t x) { return (x + 255) & ~size_t(255); }
-static int workspace(DeviceCtx* ctx, hipStream_t st, size_t n, int ninputs, Work* w) {
-    const size_t batches = (n + tvm::LANES - 1) / tvm::LANES;
-    const unsigned grid = (unsigned)(batches < (size_t)ctx->num_cu ? batches : (size_t)ctx->num_cu);
-    const size_t slot_bytes = (size_t)Bn256Vm::N * tvm::LANES * 4;
-    const size_t in_bytes = al256((size_t)ninputs * n * FP_WORDS * 4), fl_bytes = al256(4 * n);
-    const size_t sp_bytes = (size_t)grid * 5 * tvm::WAVES * slot_bytes;  // up to 5 global slots per workgroup
-    void* base;
-    int rc = ctx_workspace(ctx, WS_PAIR, st, in_bytes + fl_bytes + sp_bytes + 256, &base);
-    if (rc) return rc;
-    w->in = (uint32_t*)base;
-    w->pst = (uint8_t*)base + in_bytes;
-    w->gspill = (uint32_t*)((uint8_t*)base + in_bytes + fl_bytes);
-    w->grid = grid;
-    return KYB_OK;
-}
-static tvm::Args make_args(const Work& w, size_t n, uint8_t* out, uint32_t stride, uint32_t npst, uint8_t* status) {
-    tvm::Args a{};
-    a.in = w.in;
-    a.pst = w.pst;
-    a.npst = npst;
-    a.status = status;
-    a.out = out;
-    a.n = n;
-    a.out_stride = stride;
-    a.gspill = w.gspill;
-    return a;
-}
-
-}  // namespace bnvm
-}  // namespace kyb
-
-KYB_DEFINE_GT_ABI(bn256, bn, 384)
-
-extern "C" {
-int kyb_bn256_pair_dev(size_t n, const void* d_g1, const void* d_g2, void* d_gt, void* d_status, uint32_t flags, void* stream) {
-    using namespace kyb;
-    KYB_TRY(check_flags(flags, 2, false, "kyb_bn256_pair_dev"));
-    if (n && (!d_g1 || !d_g2 || !d_gt)) {
-        set_error("kyb_bn256_pair_dev: bad argument");
-        return KYB_E_ARG;
-    }
-    if (!n) return KYB_OK;
-    DeviceCtx* ctx;
-    KYB_TRY(get_ctx(&ctx));
-    std::lock_guard<std::recursive_mutex> enq_lock(ctx->enq_mu);
-    bnvm::Work w;
-    KYB_TRY(bnvm::workspace(ctx, (hipStream_t)stream, n, 6, &w));
-    hipLaunchKernelGGL(bnvm::bn256_pair_prep_kernel, dim3(grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n,
-                       (const uint8_t*)d_g1, (const uint8_t*)d_g2, w.in, w.pst);
-    hipLaunchKernelGGL(bnvm::bn256_tvm_kernel<0>, dim3(w.grid), dim3(tvm::THREADS), 0, (hipStream_t)stream,
-                       bnvm::make_args(w, n, (uint8_t*)d_gt, 384, 2, (uint8_t*)d_status));
-    KYB_HIP_CHECK(hipGetLastError());
-    return KYB_OK;
-}
-int kyb_bn256_pair_check_dev(size_t n, const void* d_p1, const void* d_p2, const void* d_inv1, const void* d_inv2, void* d_ok,
-                             void* d_status, uint32_t flags, void* stream) {
-    using namespace kyb;
-    KYB_TRY(check_flags(flags, 4, false, "kyb_bn256_pair_check_dev"));
-    if (n && (!d_p1 || !d_p2 || !d_inv1 || !d_inv2 || !d_ok)) {
-        set_error("kyb_bn256_pair_check_dev: bad argument");
-        return KYB_E_ARG;
-    }
-    if (!n) return KYB_OK;
-    DeviceCtx* ctx;
-    KYB_TRY(get_ctx(&ctx));
-    std::lock_guard<std::recursive_mutex> enq_lock(ctx->enq_mu);
-    bnvm::Work w;
-    KYB_TRY(bnvm::workspace(ctx, (hipStream_t)stream, n, 12, &w));
-    hipLaunchKernelGGL(bnvm::bn256_check_prep_kernel, dim3(grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n,
-                       (const uint8_t*)d_p1, (const uint8_t*)d_p2, (const uint8_t*)d_inv1, (const uint8_t*)d_inv2, w.in, w.pst);
-    hipLaunchKernelGGL(bnvm::bn256_tvm_kernel<1>, dim3(w.grid), dim3(tvm::THREADS), 0, (hipStream_t)stream,
-                       bnvm::make_args(w, n, (uint8_t*)d_ok, 1, 4, (uint8_t*)d_status));
-    KYB_HIP_CHECK(hipGetLastError());
-    return KYB_OK;
-}
-}
-
-KYB_DEFINE_PAIR_HOST(bn256, bn, 384)
+#define KYB_BN_PFX bn256
+#define KYB_BN_NS bn
+#define KYB_BN_VMNS bnvm
+#define KYB_BN_VM Bn256Vm
+#define KYB_BN_TVM(x) TVM_BN256_##x
+#include "bn_pair.inc"

@@ -173,3 +173,17 @@ def NewSchemeOnG1_bn256() -> SchemeOnG1:
     from ..pairing import bn256
 
     return SchemeOnG1(bn256, bn256_batch_hash_g1)
+
+
+def NewSchemeOnG1_bn254(dst: bytes | None = None) -> SchemeOnG1:
+    """bls.NewSchemeOnG1(bn254.NewSuite()) (pairing/bn254/bls_test.go:12-16): signatures on G1 hashed with the suite's
+    Keccak-256 / Shallue-van de Woestijne hash_to_curve, keys on G2."""
+    from ..pairing import bn254
+
+    d = bn254.DOMAIN_G1 if dst is None else dst
+
+    def hash_one_length(msgs):
+        h, st = bn254.batch_hash_g1(msgs, d)
+        return h, st
+
+    return SchemeOnG1(bn254, _grouped(hash_one_length, 64))

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Known answers of the CPU oracle (oracle/bls12381.py, oracle/bn256.py -- themselves pinned by the reference-held
+"""Known answers of the CPU oracles (oracle/bls12381.py, oracle/bn256.py, oracle/bn254.py -- themselves pinned by the reference-held
 vectors) on SHAKE-derived operands, so that the GPU tests can compare pairing outputs BYTE FOR
 BYTE inside config-size batches instead of checking the engine against itself.  The shape
 follows the reference's own pairing test (pairing/bn256/suite_test.go:231-259: e(aP, bQ) for random a, b).
 
-Writes tests/golden/{bls12381,bn256}_pair_kat.npz (numpy, uint8 arrays):
+Writes tests/golden/{bls12381,bn256,bn254}_pair_kat.npz (numpy, uint8 arrays):
   g1 (n, G1), g2 (n, G2)       operands  P_i = a_i G1, Q_i = b_i G2 in the suite's wire format; entries 0..2 hold the
                                point at infinity (G1, G2, both); bn256 entries 3..6 hold on-curve G2 points OUTSIDE the
                                order-n subgroup, which pairing/bn256 accepts (point.go:466-499)
@@ -25,6 +25,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle import bls12381 as OB  # noqa: E402
+from oracle import bn254 as ON4  # noqa: E402
 from oracle import bn256 as ON  # noqa: E402
 
 N = 384
@@ -100,17 +101,28 @@ def build(name, O, order, enc1, enc2, inf1, inf2, pair_bytes, check, mul1, mul2,
 
 
 def main():
+    which = set(sys.argv[1:]) or {"bls12381", "bn256", "bn254"}  # python make_golden_pair_kat.py [suite ...]
+
     def bls_check(p1, q1, p2, q2):
         return OB.pair_check(OB.g1_decompress(p1), OB.g2_decompress(q1), OB.g1_decompress(p2), OB.g2_decompress(q2))
 
-    build(b"bls12381", OB, OB.R, OB.g1_compress, OB.g2_compress, OB.g1_compress(None), OB.g2_compress(None),
-          OB.pair_bytes, bls_check, OB.g1_mul_bytes, OB.g2_mul_bytes, 48, 96, 576)
+    if "bls12381" in which:
+        build(b"bls12381", OB, OB.R, OB.g1_compress, OB.g2_compress, OB.g1_compress(None), OB.g2_compress(None),
+              OB.pair_bytes, bls_check, OB.g1_mul_bytes, OB.g2_mul_bytes, 48, 96, 576)
 
     def bn_check(p1, q1, p2, q2):
         return ON.validate_pairing(ON.g1_unmarshal(p1), ON.g2_unmarshal(q1), ON.g1_unmarshal(p2), ON.g2_unmarshal(q2))
 
-    build(b"bn256", ON, ON.ORDER, ON.g1_marshal, ON.g2_marshal, ON.g1_marshal(None), ON.g2_marshal(None),
-          ON.pair_bytes, bn_check, ON.g1_mul_bytes, ON.g2_mul_bytes, 64, 128, 384)
+    if "bn256" in which:
+        build(b"bn256", ON, ON.ORDER, ON.g1_marshal, ON.g2_marshal, ON.g1_marshal(None), ON.g2_marshal(None),
+              ON.pair_bytes, bn_check, ON.g1_mul_bytes, ON.g2_mul_bytes, 64, 128, 384)
+
+    def bn4_check(p1, q1, p2, q2):
+        return ON4.validate_pairing(ON4.g1_unmarshal(p1), ON4.g2_unmarshal(q1), ON4.g1_unmarshal(p2), ON4.g2_unmarshal(q2))
+
+    if "bn254" in which:  # every G2 operand is in the subgroup: pairing/bn254 rejects the others (twist.go:47-66)
+        build(b"bn254", ON4, ON4.ORDER, ON4.g1_marshal, ON4.g2_marshal, ON4.g1_marshal(None), ON4.g2_marshal(None),
+              ON4.pair_bytes, bn4_check, ON4.g1_mul_bytes, ON4.g2_mul_bytes, 64, 128, 384)
 
 
 if __name__ == "__main__":

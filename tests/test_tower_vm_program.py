@@ -100,3 +100,52 @@ def test_encoding_round_trip(pair_prog):
                 w0 = words[i + 1 + 2 * k]
                 assert (w0 >> 24) & 3 in (G.K_PROD, G.K_LIN, G.K_PROD_CONST)
                 assert (w0 & 63) < pair_prog.nslots
+
+
+# ---- the BN programs (bn256: xi = 3 + i, 28-bit limbs; bn254: xi = 9 + i, 27-bit limbs)
+@pytest.fixture(scope="module", params=["bn256", "bn254"])
+def bn_case(request):
+    import importlib
+
+    curve = {"bn256": G.BN256, "bn254": G.BN254}[request.param]
+    return importlib.import_module("oracle." + request.param), G.build_bn_pair(curve), G.build_bn_check(curve)
+
+
+def _bn_gt_bytes(res):
+    out = bytearray(384)
+    for off, (v, _) in res["gt"].items():
+        out[off:off + 32] = v.to_bytes(32, "big")
+    return bytes(out)
+
+
+def test_bn_pair_programs_equal_the_oracle_pairing(bn_case):
+    ON, pair, _ = bn_case
+    f = pair.f
+    rng = random.Random(12)
+    for k in range(3):
+        a, b = (1, 1) if k == 0 else (rng.randrange(1, ON.ORDER), rng.randrange(1, ON.ORDER))
+        p, q = ON.g1_mul(a, ON.G1_GEN), ON.g2_mul(b, ON.G2_GEN)
+        _, res = pair.simulate(_inputs(f, p, q))
+        assert _bn_gt_bytes(res) == ON.gt_marshal(ON.pair(p, q)), k
+    p, q = ON.g1_mul(0xC0FFEE, ON.G1_GEN), ON.g2_mul(0xBADC0DE, ON.G2_GEN)
+    _, res = pair.simulate_limbs(_inputs(f, p, q))            # limb for limb what the kernel does, overflow asserts on
+    assert _bn_gt_bytes(res) == ON.gt_marshal(ON.pair(p, q))
+    pair.simulate_limbs([f.p - 1] * 6)
+
+
+def test_bn_check_programs_and_bounds(bn_case):
+    ON, pair, check = bn_case
+    f = check.f
+    p1, q1 = ON.g1_mul(5, ON.G1_GEN), ON.g2_mul(7, ON.G2_GEN)
+
+    def run(p2, q2, flags=0):
+        ins = _inputs(f, p1, q1) + (_inputs(f, p2, q2) if p2 else [0] * 6)
+        return not check.simulate(ins, flags)[1]["not_one"]
+
+    assert run(ON.g1_mul(35, ON.G1_GEN), ON.G2_GEN)           # e(5P, 7Q) == e(35P, Q): two whole pairings compared
+    assert not run(ON.g1_mul(36, ON.G1_GEN), ON.G2_GEN)
+    assert not run(None, None, flags=2)                       # pair B at infinity pairs to one; e(5P, 7Q) != 1
+    for prog in (pair, check):
+        col, val = prog.check_bounds()
+        assert col < 63 and val < 1024
+    assert pair.f.W == (27 if ON.__name__.endswith("bn254") else 28)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput probe of a pairing suite's kernels (device-resident inputs, HIP-event timing).
-usage: pair_probe.py {bls12381|bn256} [n]"""
+usage: pair_probe.py {bls12381|bn256|bn254} [n]"""
 import hashlib, importlib, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -26,4 +26,7 @@ ms = timeit(lambda: m.g1_batch_mul(k, P)); res["g1_mul_per_s"] = n / ms * 1e3; r
 ms = timeit(lambda: m.g2_batch_mul(k, Q)); res["g2_mul_per_s"] = n / ms * 1e3; res["g2_mul_ms"] = ms
 ms = timeit(lambda: m.batch_pair(P, Q)); res["pair_per_s"] = n / ms * 1e3; res["pair_ms"] = ms
 ms = timeit(lambda: m.batch_validate_pairing(P, Q, P, Q)); res["pair_check_per_s"] = n / ms * 1e3; res["pair_check_ms"] = ms
+T = m.F_TRUSTED(0) | m.F_TRUSTED(1)
+ms = timeit(lambda: m.batch_pair(P, Q, T)); res["pair_validated_per_s"] = n / ms * 1e3; res["pair_validated_ms"] = ms
+ms = timeit(lambda: m.g2_batch_mul(k, Q, m.F_TRUSTED(0))); res["g2_mul_validated_per_s"] = n / ms * 1e3
 print(json.dumps(res))
