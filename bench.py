@@ -136,7 +136,8 @@ def _tvm_mads():
     import gen_tower_vm as G
 
     return {"bls12381": (G.build_bls12381_pair().mads(), G.build_bls12381_check().mads()),
-            "bn256": (G.build_bn256_pair().mads(), G.build_bn256_check().mads())}
+            "bn256": (G.build_bn256_pair().mads(), G.build_bn256_check().mads()),
+            "bn254": (G.build_bn254_pair().mads(), G.build_bn254_check().mads())}
 
 
 def _roof(units_per_s, mads_per_unit, alg_bytes_per_unit, prof, key):
@@ -156,12 +157,13 @@ def other_workloads(rank, world, dist):
     import torch
 
     from kyber_amd import dist as kd
-    from kyber_amd.pairing import bls12381 as bls, bn256 as bn
+    from kyber_amd.pairing import bls12381 as bls, bn254 as bn4, bn256 as bn
 
     out = {}
     prof = _prof()
     mads = _tvm_mads()
-    for name, m, npair in (("bls12381", bls, 1 << 16), ("bn256", bn, 1 << 18)):  # configs[3] / configs[4] sizes
+    # configs[3] / configs[4] sizes; bn254 (SURVEY section 8 f4's last item, no config of its own) at bn256's
+    for name, m, npair in (("bls12381", bls, 1 << 16), ("bn256", bn, 1 << 18), ("bn254", bn4, 1 << 18)):
         k = torch.from_numpy(be_scalars(b"kyberhip/v1/%s/k/%d" % (name.encode(), rank), npair)).cuda()
         h = torch.from_numpy(be_scalars(b"kyberhip/v1/%s/h/%d" % (name.encode(), rank), npair)).cuda()
         g1b = torch.from_numpy(np.frombuffer(m.G1_BASE, dtype=np.uint8).copy()).cuda()
@@ -203,8 +205,8 @@ def other_workloads(rank, world, dist):
             "pair_validated_inputs": _roof(npair / ms_pair_t * 1e3, mads[name][0], g1b_ + g2b_ + m.GT_LEN, prof, name + "_pair"),
             "pair_check": _roof(npair / ms_chk * 1e3, mads[name][1], 2 * (g1b_ + g2b_) + 1, prof, name + "_check")}
         if True:
-            # the whole sign/bls Verify pipeline on the device: Hash(msg) (bn256: SHA-256 + try-and-increment;
-            # BLS12-381: RFC 9380 hash_to_curve) then the pairing check (sign/bls/bls.go:82-96), 32-byte messages
+            # the whole sign/bls Verify pipeline on the device: Hash(msg) (bn256: SHA-256 + try-and-increment; bn254:
+            # Keccak-256 expand + Shallue-van de Woestijne; BLS12-381: RFC 9380 hash_to_curve) then the pairing check (sign/bls/bls.go:82-96), 32-byte messages
             msgs = torch.from_numpy(shake(b"kyberhip/v1/%s/msgs/%d" % (name.encode(), rank), npair * 32).reshape(npair, 32).copy()).cuda()
 
             def verify():

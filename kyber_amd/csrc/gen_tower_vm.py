@@ -1447,10 +1447,85 @@ def build_bn_check(curve):
     return P
 
 
+def build_bn_check_product(curve):
+    """ValidatePairing as ONE final exponentiation: ok = (f_{Q1}(P1) f_{Q2}(-P2))^e == 1, the two Miller loops sharing the
+    squarings of f.  Equivalent to the reference's two pairings + Equal whenever both G2 operands lie in the order-n
+    subgroup -- which pairing/bn254's UnmarshalBinary guarantees (twist.go:47-66); bn256, whose G2 is unchecked, keeps
+    build_bn_check.  (e(-P, Q) = e(P, Q)^-1: negating y_P negates the w^0 coefficient of every line, i.e. the Miller
+    value is conjugated up to sign, and conjugation inverts after the easy part.)  Inputs 0..5: P1, Q1; 6..11: P2 with y
+    ALREADY NEGATED by the operand kernel, Q2.  Flag bit 0 / 1: pair A / B has an operand at infinity and contributes 1."""
+    f = curve.field()
+    P = Prog(f, BN_NSLOTS, curve.xi0, n_inputs=12, n_gslots=4)
+    T = Tower(P)
+    p = f.p
+    xi = (curve.xi0, 1)
+    gam = {K: frob_gammas(p, xi, K) for K in (1, 2, 3)}
+    Ts = [((12, 13), (14, 15), (16, 17)), ((18, 19), (20, 21), (22, 23))]
+    tmp = list(range(24, 34))
+    L = list(range(34, 40))
+    Ps = [(40, 41), (42, 43)]
+    Qs = [[44, 45, 46, 47], [48, 49, 50, 51]]
+    QT = [52, 53, 54, 55]
+    QF = [56, 57, 58, 59]
+    for k in range(2):
+        bls_load_inputs(P, f, [Ps[k][0], Ps[k][1]] + Qs[k], 6 * k)
+    P.misc([dict(op=OP_CLOAD, dst=BN_A + i, arg=P.c_one if i == 0 else P.c_zero) for i in range(12)], "f=1")
+    for k in range(2):
+        (TX, TY, TZ), Q = Ts[k], Qs[k]
+        P.misc([dict(op=OP_DOT, dst=d, terms=[("l", Lin.slot(q))], scale=1, mask=0, raw=True) for d, q in
+                ((TX[0], Q[0]), (TX[1], Q[1]), (TY[0], Q[2]), (TY[1], Q[3]))]
+               + [dict(op=OP_CLOAD, dst=TZ[0], arg=P.c_one), dict(op=OP_CLOAD, dst=TZ[1], arg=P.c_zero)], "T=Q")
+    FF = T.reg(BN_A)
+
+    def step():
+        T.sqr12(BN_A, FF, "miller/sqr")
+        for k in range(2):
+            bn_dbl_step(P, T, *Ts[k], tmp, L, Ps[k][0], Ps[k][1], BN_A, k + 1)
+
+    def add(srcs, sign):
+        for k in range(2):
+            P.dot([Out(QT[i], [("l", Lin.slot(srcs[k][i]))], raw=True) for i in range(4)], "add/copyQ")
+            bn_add_step(P, T, *Ts[k], QT, sign, tmp, L, Ps[k][0], Ps[k][1], BN_A, k + 1)
+
+    digits = curve.digits
+    run = 0
+    for i in range(len(digits) - 1, 0, -1):
+        run += 1
+        d = digits[i - 1]
+        if d:
+            with P.repeat(run):
+                step()
+            run = 0
+            add(Qs, d)
+    if run:
+        with P.repeat(run):
+            step()
+    k1x, k1y = _f2_pow(xi, (p - 1) // 3, p), _f2_pow(xi, (p - 1) // 2, p)
+    k2x = _f2_pow(xi, (p * p - 1) // 3, p)
+    for which in (1, 2):  # pi(Q), then -pi^2(Q), for both pairs in turn (QF is recycled)
+        for k in range(2):
+            xQ, yQ = E2.slots(Qs[k][0], Qs[k][1]), E2.slots(Qs[k][2], Qs[k][3])
+            if which == 1:
+                o = outs2(QF[0], QF[1], Acc2().prod_const(xQ.conj(), P.mont(k1x[0]), P.mont(k1x[1])))
+                o += outs2(QF[2], QF[3], Acc2().prod_const(yQ.conj(), P.mont(k1y[0]), P.mont(k1y[1])))
+            else:
+                o = outs2(QF[0], QF[1], Acc2().prod_const(xQ, P.mont(k2x[0]), None))
+                o += outs2(QF[2], QF[3], Acc2().prod_const(yQ, (P.c_one, P.consts[P.c_one]), None))
+            P.dot(o, "frobQ%d" % which)
+            P.dot([Out(QT[i], [("l", Lin.slot(QF[i]))], raw=True) for i in range(4)], "add/copyQ")
+            bn_add_step(P, T, *Ts[k], QT, 1, tmp, L, Ps[k][0], Ps[k][1], BN_A, k + 1)
+    res = bn_final_exp(P, T, FF, gam, curve)
+    one = (P.c_plain_one, 1)
+    P.dot(sum((outs2(BN_A + 2 * j, BN_A + 2 * j + 1, Acc2().prod_const(res[j], one, None)) for j in range(6)), []), "to_plain")
+    P.misc([dict(op=OP_IS_ONE, dst=BN_A + 2 * j + c, arg=(1 if (j == 0 and c == 0) else 0) << 16) for j in range(6) for c in range(2)],
+           "is_one")
+    return P
+
+
 def build_bn256_pair(): return build_bn_pair(BN256)
 def build_bn256_check(): return build_bn_check(BN256)
 def build_bn254_pair(): return build_bn_pair(BN254)
-def build_bn254_check(): return build_bn_check(BN254)
+def build_bn254_check(): return build_bn_check_product(BN254)
 
 
 # ------------------------------------------------------------------------------------------------ emission

@@ -276,6 +276,29 @@ def g2_in_subgroup(p) -> bool:
     return g2_mul(ORDER, p) is None
 
 
+def g2_psi(q):
+    """psi = twist^-1 o Frobenius o twist on E'(Fp2) (the Q1 of miller, optate.go:180-186): acts as [p] on G2."""
+    if q is None:
+        return None
+    return (f2_mul(f2_conj(q[0]), f2_pow(XI, (P - 1) // 3)), f2_mul(f2_conj(q[1]), f2_pow(XI, (P - 1) // 2)))
+
+
+G2_COFACTOR_PRIMES = (10069, 5864401, 1875725156269, 197620364512881247228717050342013327560683201906968909)
+
+
+def g2_in_subgroup_fast(q) -> bool:
+    """The criterion the device library uses instead of the 254-bit ladder: [u+1]Q + psi([u]Q) + psi^2([u]Q) ==
+    psi^3([2u]Q).  Equivalent to g2_in_subgroup on every point of the twist: #E'(Fp2) = n (2p - n) with 2p - n the
+    product of the four distinct primes above (none dividing n), so the group is cyclic, psi acts on each prime
+    component as a root of X^2 - t X + p, and (u+1) + u X + u X^2 - 2u X^3 vanishes at that root only on the
+    n-component (tests/test_oracle_bn254.py, tests/test_constants.py)."""
+    xq = g2_mul(U, q)
+    b = g2_psi(xq)
+    lhs = g2_add(g2_add(g2_add(xq, q), b), g2_psi(b))
+    rhs = g2_psi(g2_psi(b))
+    return lhs == g2_add(rhs, rhs)
+
+
 def g2_unmarshal(buf: bytes):
     """pointG2.UnmarshalBinary (point.go:474-520): coordinates < p, all-zero = infinity, otherwise on the twist AND in
     the order-n subgroup (twist.go:47-66)."""

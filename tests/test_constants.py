@@ -112,3 +112,64 @@ def test_bn_params(name):
         assert (k1 + k2 * lam - k) % N.ORDER == 0 and abs(k1) < 1 << 130 and abs(k2) < 1 << 130
     if name == "bn254":
         assert [mont(arr["SVDW_C%d" % i][0]) for i in (1, 2, 3, 4)] == [N.SVDW_C1, N.SVDW_C2, N.SVDW_C3, N.SVDW_C4]
+
+
+def test_bn254_g2_subgroup_criterion_is_exact():
+    """kyber_amd/csrc/bn_suite.inc g2_in_subgroup decides [n]Q = infinity by (u+1) + u psi + u psi^2 - 2u psi^3 = 0.
+    Exactness on alt_bn128: #E'(Fp2) = n h, h = 2p - n = q1 q2 q3 q4 (distinct primes, none dividing n: the group is
+    cyclic); on the q-component psi is a root mu of X^2 - t X + p (mod q), and the polynomial is non-zero at BOTH roots
+    for every q -- so the relation holds exactly on G2."""
+    from oracle import bn254 as N
+
+    def is_prime(m):
+        d, s = m - 1, 0
+        while d % 2 == 0:
+            d, s = d // 2, s + 1
+        for a in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53):
+            if m == a:
+                return True
+            x = pow(a, d, m)
+            if x in (1, m - 1):
+                continue
+            for _ in range(s - 1):
+                x = x * x % m
+                if x == m - 1:
+                    break
+            else:
+                return False
+        return True
+
+    def sqrt_mod(a, q):  # Tonelli-Shanks
+        a %= q
+        assert pow(a, (q - 1) // 2, q) == 1
+        Q, S = q - 1, 0
+        while Q % 2 == 0:
+            Q, S = Q // 2, S + 1
+        z = 2
+        while pow(z, (q - 1) // 2, q) != q - 1:
+            z += 1
+        m, c, t, r = S, pow(z, Q, q), pow(a, Q, q), pow(a, (Q + 1) // 2, q)
+        while t != 1:
+            i, t2 = 0, t
+            while t2 != 1:
+                t2, i = t2 * t2 % q, i + 1
+            b = pow(c, 1 << (m - i - 1), q)
+            m, c = i, b * b % q
+            t, r = t * c % q, r * b % q
+        return r
+
+    u, p, n = N.U, N.P, N.ORDER
+    t = 6 * u * u + 1
+    assert p + 1 - t == n
+    h = 2 * p - n
+    prod = 1
+    for q in N.G2_COFACTOR_PRIMES:
+        assert is_prime(q) and n % q != 0
+        prod *= q
+    assert prod == h and len(set(N.G2_COFACTOR_PRIMES)) == 4
+    assert ((u + 1) + u * p + u * p * p - 2 * u * p**3) % n == 0          # the relation on G2, where psi = [p]
+    for q in N.G2_COFACTOR_PRIMES:
+        r = sqrt_mod(t * t - 4 * p, q)
+        for mu in ((t + r) * pow(2, -1, q) % q, (t - r) * pow(2, -1, q) % q):
+            assert (mu * mu - t * mu + p) % q == 0
+            assert ((u + 1) + u * mu + u * mu * mu - 2 * u * mu**3) % q != 0

@@ -52,9 +52,9 @@ def test_ed25519_config2_2p20_fixed_and_var_base():
     assert not st2.any() and (out == Ac[idx]).all()
 
 
-@pytest.mark.parametrize("name,n", [("bls12381", 1 << 16), ("bn256", 1 << 18)])
+@pytest.mark.parametrize("name,n", [("bls12381", 1 << 16), ("bn256", 1 << 18), ("bn254", 1 << 17)])
 def test_pairing_suites_at_config_sizes(name, n):
-    """configs[3] (BLS12-381, 2^16 pairs) and configs[4] (bn256, 2^18): G1 mul checksum by MSM, bilinearity
+    """configs[3] (BLS12-381, 2^16 pairs), configs[4] (bn256, 2^18) and bn254 (2^17): G1 mul checksum by MSM, bilinearity
     e(kP, Q) == e(P, kQ) over the whole batch, ValidatePairing truth table with forged entries."""
     import importlib
 
@@ -90,7 +90,7 @@ def test_pairing_suites_at_config_sizes(name, n):
     assert not st3.any().item() and torch.equal(ok.bool(), exp)
 
 
-@pytest.mark.parametrize("name,n", [("bls12381", 1 << 16), ("bn256", 1 << 18)])
+@pytest.mark.parametrize("name,n", [("bls12381", 1 << 16), ("bn256", 1 << 18), ("bn254", 1 << 17)])
 def test_pairing_known_answers_inside_config_size_batches(name, n, golden_dir):
     """The oracle's known answers (tests/golden/<suite>_pair_kat.npz, written by make_golden_pair_kat.py: 384 pairs with
     infinity rows and, for bn256, G2 points outside the order-n subgroup) scattered through a configs[3] / configs[4]
@@ -126,7 +126,7 @@ def test_pairing_known_answers_inside_config_size_batches(name, n, golden_dir):
     assert bad.size == 0, f"GT bytes differ from the oracle at KAT rows {bad[:8]}"
     # operands the caller vouches for take the unchecked path: same bytes
     gt2, st = m.batch_pair(P, Q, m.F_TRUSTED(0) | m.F_TRUSTED(1))
-    if name == "bls12381":  # (bn256's KAT holds off-subgroup G2 points: nothing to vouch for there, flags are a no-op)
+    if name != "bn256":  # (bn256's KAT holds off-subgroup G2 points: nothing to vouch for there, flags are a no-op)
         assert not st.any().item() and torch.equal(gt2, gt)
     # ValidatePairing(P_i, Q_i, P_j, Q_j) at lanes spread over the batch
     ci, ck = K["chk_idx"], K["chk_ok"]

@@ -72,6 +72,15 @@ def test_scalar_multiplication_and_strict_decoding():
             break
     off = O.g2_marshal((xx, yy))
     assert H.call("hh_bn4_g2_decode", off, 1)[0] == 2 and H.call("hh_bn4_g2_decode", off, 0)[0] == 0
+    # points the endomorphism criterion could confuse if it were not exact: prime-order components of the cofactor
+    h = 2 * O.P - O.ORDER
+    g = O.g2_mul(rng.randrange(1, O.ORDER), O.G2_GEN)
+    assert H.call("hh_bn4_g2_decode", O.g2_marshal(g), 1)[0] == 0
+    for q in O.G2_COFACTOR_PRIMES:
+        small = O.g2_mul(O.ORDER * h // q, (xx, yy))
+        if small is not None:
+            assert H.call("hh_bn4_g2_decode", O.g2_marshal(small), 1)[0] == 2, q
+            assert H.call("hh_bn4_g2_decode", O.g2_marshal(O.g2_add(g, small)), 1)[0] == 2, q
     assert H.call("hh_bn4_g2_mul", _be(3), off, 0, out_sizes=(128,)) == (2, bytes(128))
     assert H.call("hh_bn4_g2_mul", _be(3), off, 0x100, out_sizes=(128,)) == (0, O.g2_marshal(O.g2_mul(3, (xx, yy))))
 

@@ -93,3 +93,44 @@ def test_pairing_restatement_equals_textbook_and_is_bilinear():
     assert len(O.gt_marshal(e)) == 384
     assert O.validate_pairing(Pa, Qb, O.g1_mul(a * b % O.ORDER, O.G1_GEN), O.G2_GEN)
     assert not O.validate_pairing(Pa, Qb, O.G1_GEN, O.G2_GEN)
+
+
+def _random_twist_point(rng):
+    while True:
+        x = (rng.randrange(O.P), rng.randrange(O.P))
+        y = O.f2_sqrt(O.f2_add(O.f2_mul(O.f2_sqr(x), x), O.TWIST_B))
+        if y is not None:
+            return (x, y)
+
+
+def test_fast_subgroup_criterion_is_the_references_test():
+    """[Order]Q == infinity (twist.go:62-65) against the endomorphism criterion of the device library, on the cases that
+    could tell them apart: the group is cyclic of order n * q1 q2 q3 q4; points of every prime order, G2 points with a
+    small-order component added, random points."""
+    h = 2 * O.P - O.ORDER
+    prod = 1
+    for q in O.G2_COFACTOR_PRIMES:
+        prod *= q
+        assert O.ORDER % q != 0
+    assert prod == h
+    # psi satisfies X^2 - t X + p on the twist; on the prime-order components the criterion's polynomial is non-zero
+    t = 6 * O.U * O.U + 1
+    for q in O.G2_COFACTOR_PRIMES[:3]:
+        roots = [m for m in range(q) if (m * m - t * m + O.P) % q == 0] if q < 20000 else None
+        if roots is not None:
+            assert roots and all(((O.U + 1) + O.U * m + O.U * m * m - 2 * O.U * m**3) % q != 0 for m in roots)
+    rng = random.Random(21)
+    R = _random_twist_point(rng)
+    assert O.g2_mul(O.ORDER * h, R) is None                                            # the group order
+    assert not O.g2_in_subgroup(R) and not O.g2_in_subgroup_fast(R)
+    g = O.g2_mul(rng.randrange(1, O.ORDER), O.G2_GEN)
+    assert O.g2_in_subgroup(g) and O.g2_in_subgroup_fast(g) and O.g2_in_subgroup_fast(O.G2_GEN)
+    assert O.g2_psi(g) == O.g2_mul(O.P % O.ORDER, g)                                   # psi = [p] on G2
+    for q in O.G2_COFACTOR_PRIMES:
+        small = O.g2_mul(O.ORDER * h // q, R)                                          # a point of order q (or infinity)
+        if small is None:
+            continue
+        assert O.g2_mul(q, small) is None
+        assert not O.g2_in_subgroup(small) and not O.g2_in_subgroup_fast(small)
+        mixed = O.g2_add(g, small)                                                     # G2 point + small-order component
+        assert not O.g2_in_subgroup(mixed) and not O.g2_in_subgroup_fast(mixed)

@@ -107,8 +107,8 @@ def test_encoding_round_trip(pair_prog):
 def bn_case(request):
     import importlib
 
-    curve = {"bn256": G.BN256, "bn254": G.BN254}[request.param]
-    return importlib.import_module("oracle." + request.param), G.build_bn_pair(curve), G.build_bn_check(curve)
+    build = {"bn256": (G.build_bn256_pair, G.build_bn256_check), "bn254": (G.build_bn254_pair, G.build_bn254_check)}[request.param]
+    return importlib.import_module("oracle." + request.param), build[0](), build[1]()  # the programs the kernels run
 
 
 def _bn_gt_bytes(res):
@@ -138,11 +138,16 @@ def test_bn_check_programs_and_bounds(bn_case):
     f = check.f
     p1, q1 = ON.g1_mul(5, ON.G1_GEN), ON.g2_mul(7, ON.G2_GEN)
 
+    product = ON.__name__.endswith("bn254")  # bn254: e(p1, p2) e(-inv1, inv2) == 1 (its G2 operands are in the subgroup)
+
     def run(p2, q2, flags=0):
+        if p2 and product:
+            p2 = ON.g1_neg(p2)                                # the operand kernel's part
         ins = _inputs(f, p1, q1) + (_inputs(f, p2, q2) if p2 else [0] * 6)
         return not check.simulate(ins, flags)[1]["not_one"]
 
-    assert run(ON.g1_mul(35, ON.G1_GEN), ON.G2_GEN)           # e(5P, 7Q) == e(35P, Q): two whole pairings compared
+    assert run(ON.g1_mul(35, ON.G1_GEN), ON.G2_GEN)           # e(5P, 7Q) == e(35P, Q)
+    assert run(ON.g1_mul(7, ON.G1_GEN), ON.g2_mul(5, ON.G2_GEN))
     assert not run(ON.g1_mul(36, ON.G1_GEN), ON.G2_GEN)
     assert not run(None, None, flags=2)                       # pair B at infinity pairs to one; e(5P, 7Q) != 1
     for prog in (pair, check):

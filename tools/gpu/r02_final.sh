@@ -15,7 +15,7 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $O -o ed_trace -- $B > $O/ed_tra
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O -o ed_fetch -- $B > $O/ed_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O -o ed_write -- $B > $O/ed_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc $SQ -d $O -o ed_sq -- $B > $O/ed_sq.log 2>&1
-for s in "bls12381 65536" "bn256 262144"; do
+for s in "bls12381 65536" "bn256 262144" "bn254 262144"; do
 set -- $s; P="python tools/pair_probe.py $1 $2"
 timeout 300 $P 2>/dev/null | tail -1 | tee $O/probe_$1.json
 timeout 300 rocprofv3 --kernel-trace --stats -d $O -o $1_trace -- $P > $O/$1_trace.log 2>&1

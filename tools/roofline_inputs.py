@@ -60,7 +60,9 @@ for key, prefix, sub, units in (("ed25519_mul", "ed", "ed25519_mul_kernel<true>"
                                 ("bls12381_pair", "bls12381", "bls12381_tvm_kernel<0>", 1 << 16),
                                 ("bls12381_check", "bls12381", "bls12381_tvm_kernel<1>", 1 << 16),
                                 ("bn256_pair", "bn256", "bn256_tvm_kernel<0>", 1 << 18),
-                                ("bn256_check", "bn256", "bn256_tvm_kernel<1>", 1 << 18)):
+                                ("bn256_check", "bn256", "bn256_tvm_kernel<1>", 1 << 18),
+                                ("bn254_pair", "bn254", "bn254_tvm_kernel<0>", 1 << 18),
+                                ("bn254_check", "bn254", "bn254_tvm_kernel<1>", 1 << 18)):
     e = entry(prefix, sub, units)
     if e:
         res["kernels"][key] = e
