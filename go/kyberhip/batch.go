@@ -1,5 +1,5 @@
 // Batch helpers over kyber's own interfaces: they marshal []kyber.Scalar / []kyber.Point of ANY suite whose
-// encodings are the reference's (group/edwards25519, pairing/bls12381/*, pairing/bn256), run one engine call, and
+// encodings are the reference's (group/edwards25519, pairing/bls12381/*, pairing/bn256, pairing/bn254), run one engine call, and
 // unmarshal the results back into points of that same suite -- so every other method of the returned values is the
 // reference's own.  This is the smallest possible integration: the MSM-shaped loops of share/poly.go and
 // sign/bdn/bdn.go call these instead of n x (Mul + Add); see INTEGRATION.md for the patches.
@@ -26,6 +26,8 @@ const (
 	Bls12381G2
 	Bn256G1
 	Bn256G2
+	Bn254G1
+	Bn254G2
 )
 
 func marshalAll[T interface{ MarshalBinary() ([]byte, error) }](xs []T, size int) ([]byte, error) {
@@ -87,6 +89,10 @@ func BatchMul(k Kind, g kyber.Group, scalars []kyber.Scalar, points []kyber.Poin
 		out, st, err = Bn256G1Mul(sb, pb)
 	case Bn256G2:
 		out, st, err = Bn256G2Mul(sb, pb)
+	case Bn254G1:
+		out, st, err = Bn254G1Mul(sb, pb, Trusted(0)) // kyber.Points: unmarshalled (validated) before
+	case Bn254G2:
+		out, st, err = Bn254G2Mul(sb, pb, Trusted(0))
 	}
 	if err != nil {
 		return nil, err
@@ -132,6 +138,10 @@ func MSMBits(k Kind, g kyber.Group, scalars []kyber.Scalar, points []kyber.Point
 		out, st, err = Bn256G1MSM(sb, pb, fl)
 	case Bn256G2:
 		out, st, err = Bn256G2MSM(sb, pb, fl)
+	case Bn254G1:
+		out, st, err = Bn254G1MSM(sb, pb, fl|Trusted(0))
+	case Bn254G2:
+		out, st, err = Bn254G2MSM(sb, pb, fl|Trusted(0))
 	}
 	if err != nil {
 		return nil, err
@@ -169,6 +179,10 @@ func Commit(k Kind, g kyber.Group, coeffs []kyber.Scalar, base kyber.Point) ([]k
 		out, st, err = Bn256G1MulSameBase(sb, bb)
 	case Bn256G2:
 		out, st, err = Bn256G2MulSameBase(sb, bb)
+	case Bn254G1:
+		out, st, err = Bn254G1MulSameBase(sb, bb, Trusted(0))
+	case Bn254G2:
+		out, st, err = Bn254G2MulSameBase(sb, bb, Trusted(0))
 	}
 	if err != nil {
 		return nil, err
@@ -210,6 +224,10 @@ func BatchValidate(k Kind, encodings []byte) (status []byte, err error) {
 		_, status, err = Bn256G1Unmarshal(encodings)
 	case Bn256G2:
 		_, status, err = Bn256G2Unmarshal(encodings)
+	case Bn254G1:
+		_, status, err = Bn254G1Unmarshal(encodings, 0) // bytes from the wire: full validation
+	case Bn254G2:
+		_, status, err = Bn254G2Unmarshal(encodings, 0)
 	}
 	return status, err
 }

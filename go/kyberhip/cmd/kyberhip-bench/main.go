@@ -76,7 +76,8 @@ func main() {
 		out = os.Args[1]
 	}
 	results := map[string]map[string]map[string]any{"groups": {}}
-	for _, g := range []kyber.Group{suite.NewBlakeSHA256Ed25519HIP(), suite.NewGroupSuiteBLS12381(), suite.NewGroupSuiteBn256()} {
+	for _, g := range []kyber.Group{suite.NewBlakeSHA256Ed25519HIP(), suite.NewGroupSuiteBLS12381(), suite.NewGroupSuiteBn256(),
+		suite.NewGroupSuiteBn254()} {
 		fmt.Printf("Running benchmarks for group %s...\n", g.String())
 		results["groups"][g.String()] = map[string]any{
 			"group":       g.String(),

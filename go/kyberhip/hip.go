@@ -615,3 +615,165 @@ func Bn256HashG1(n int, msgs []byte, msgLen int) (out, status []byte, err error)
 	err = call(func() C.int { return C.kyb_bn256_hash_g1(C.size_t(n), ptr(msgs), C.size_t(msgLen), ptr(out), ptr(status)) })
 	return
 }
+
+// ---------------------------------------------------------------- bn254 (alt_bn128; formats as bn256)
+// pairing/bn254 rejects coordinates >= p and G2 points outside the subgroup; Trusted(i) on a G2 operand that was
+// unmarshalled before skips the subgroup re-check (flags argument of every call that decodes points).
+
+func Bn254G1Mul(scalars, points []byte, flags uint32) (out, status []byte, err error) {
+	n, err := count("scalars", scalars, 32)
+	if err = firstErr(err, need("points", points, n, 64)); err != nil {
+		return nil, nil, err
+	}
+	out, status = make([]byte, 64*n), make([]byte, n)
+	err = call(func() C.int { return C.kyb_bn254_g1_mul(C.size_t(n), ptr(scalars), ptr(points), ptr(out), ptr(status), C.uint32_t(flags)) })
+	return
+}
+
+func Bn254G2Mul(scalars, points []byte, flags uint32) (out, status []byte, err error) {
+	n, err := count("scalars", scalars, 32)
+	if err = firstErr(err, need("points", points, n, 128)); err != nil {
+		return nil, nil, err
+	}
+	out, status = make([]byte, 128*n), make([]byte, n)
+	err = call(func() C.int { return C.kyb_bn254_g2_mul(C.size_t(n), ptr(scalars), ptr(points), ptr(out), ptr(status), C.uint32_t(flags)) })
+	return
+}
+
+func Bn254G1MulSameBase(scalars, point []byte, flags uint32) (out, status []byte, err error) {
+	n, err := count("scalars", scalars, 32)
+	if err = firstErr(err, need("point", point, 1, 64)); err != nil {
+		return nil, nil, err
+	}
+	out, status = make([]byte, 64*n), make([]byte, n)
+	err = call(func() C.int {
+		return C.kyb_bn254_g1_mul_same_base(C.size_t(n), ptr(scalars), ptr(point), ptr(out), ptr(status), C.uint32_t(flags))
+	})
+	return
+}
+
+func Bn254G2MulSameBase(scalars, point []byte, flags uint32) (out, status []byte, err error) {
+	n, err := count("scalars", scalars, 32)
+	if err = firstErr(err, need("point", point, 1, 128)); err != nil {
+		return nil, nil, err
+	}
+	out, status = make([]byte, 128*n), make([]byte, n)
+	err = call(func() C.int {
+		return C.kyb_bn254_g2_mul_same_base(C.size_t(n), ptr(scalars), ptr(point), ptr(out), ptr(status), C.uint32_t(flags))
+	})
+	return
+}
+
+func Bn254G1MSM(scalars, points []byte, flags uint32) (out, status []byte, err error) {
+	n, err := count("scalars", scalars, 32)
+	if err = firstErr(err, need("points", points, n, 64)); err != nil {
+		return nil, nil, err
+	}
+	out, status = make([]byte, 64), make([]byte, n+1)
+	err = call(func() C.int {
+		return C.kyb_bn254_g1_msm(C.size_t(n), ptr(scalars), ptr(points), ptr(out), ptr(status), C.uint32_t(flags))
+	})
+	return out, status[:n], err
+}
+
+func Bn254G2MSM(scalars, points []byte, flags uint32) (out, status []byte, err error) {
+	n, err := count("scalars", scalars, 32)
+	if err = firstErr(err, need("points", points, n, 128)); err != nil {
+		return nil, nil, err
+	}
+	out, status = make([]byte, 128), make([]byte, n+1)
+	err = call(func() C.int {
+		return C.kyb_bn254_g2_msm(C.size_t(n), ptr(scalars), ptr(points), ptr(out), ptr(status), C.uint32_t(flags))
+	})
+	return out, status[:n], err
+}
+
+// Bn254G1Unmarshal / G2Unmarshal: batch UnmarshalBinary (coordinates < p, on the curve, G2 in the subgroup).
+func Bn254G1Unmarshal(points []byte, flags uint32) (out, status []byte, err error) {
+	n, err := count("points", points, 64)
+	if err != nil {
+		return nil, nil, err
+	}
+	out, status = make([]byte, 64*n), make([]byte, n)
+	err = call(func() C.int { return C.kyb_bn254_g1_unmarshal(C.size_t(n), ptr(points), ptr(out), ptr(status), C.uint32_t(flags)) })
+	return
+}
+
+func Bn254G2Unmarshal(points []byte, flags uint32) (out, status []byte, err error) {
+	n, err := count("points", points, 128)
+	if err != nil {
+		return nil, nil, err
+	}
+	out, status = make([]byte, 128*n), make([]byte, n)
+	err = call(func() C.int { return C.kyb_bn254_g2_unmarshal(C.size_t(n), ptr(points), ptr(out), ptr(status), C.uint32_t(flags)) })
+	return
+}
+
+func Bn254G1Add(a, b []byte) (out, status []byte, err error) {
+	n, err := count("a", a, 64)
+	if err = firstErr(err, need("b", b, n, 64)); err != nil {
+		return nil, nil, err
+	}
+	out, status = make([]byte, 64*n), make([]byte, n)
+	err = call(func() C.int { return C.kyb_bn254_g1_add(C.size_t(n), ptr(a), ptr(b), ptr(out), ptr(status)) })
+	return
+}
+
+func Bn254G2Add(a, b []byte) (out, status []byte, err error) {
+	n, err := count("a", a, 128)
+	if err = firstErr(err, need("b", b, n, 128)); err != nil {
+		return nil, nil, err
+	}
+	out, status = make([]byte, 128*n), make([]byte, n)
+	err = call(func() C.int { return C.kyb_bn254_g2_add(C.size_t(n), ptr(a), ptr(b), ptr(out), ptr(status)) })
+	return
+}
+
+func Bn254Pair(g1, g2 []byte, flags uint32) (gt, status []byte, err error) {
+	n, err := count("g1", g1, 64)
+	if err = firstErr(err, need("g2", g2, n, 128)); err != nil {
+		return nil, nil, err
+	}
+	gt, status = make([]byte, 384*n), make([]byte, n)
+	err = call(func() C.int { return C.kyb_bn254_pair(C.size_t(n), ptr(g1), ptr(g2), ptr(gt), ptr(status), C.uint32_t(flags)) })
+	return
+}
+
+func Bn254ValidatePairing(p1, p2, inv1, inv2 []byte, flags uint32) (ok, status []byte, err error) {
+	n, err := count("p1", p1, 64)
+	if err = firstErr(err, need("p2", p2, n, 128), need("inv1", inv1, n, 64), need("inv2", inv2, n, 128)); err != nil {
+		return nil, nil, err
+	}
+	ok, status = make([]byte, n), make([]byte, n)
+	err = call(func() C.int {
+		return C.kyb_bn254_pair_check(C.size_t(n), ptr(p1), ptr(p2), ptr(inv1), ptr(inv2), ptr(ok), ptr(status), C.uint32_t(flags))
+	})
+	return
+}
+
+// Bn254GTMul: out[i] = gt[i]^scalars[i]  (pointGT.Mul, pairing/bn254/point.go:606 -> gfP12.Exp); coefficients >= p are rejected.
+func Bn254GTMul(scalars, gt []byte) (out, status []byte, err error) {
+	n, err := count("scalars", scalars, 32)
+	if err = firstErr(err, need("gt", gt, n, 384)); err != nil {
+		return nil, nil, err
+	}
+	out, status = make([]byte, 384*n), make([]byte, n)
+	err = call(func() C.int { return C.kyb_bn254_gt_mul(C.size_t(n), ptr(scalars), ptr(gt), ptr(out), ptr(status)) })
+	return
+}
+
+// Bn254HashG1: pointG1.Hash (pairing/bn254/point.go:207-285) for n messages of msgLen bytes under the suite's domain
+// separation tag (suite.go:42-44, SetDomainG1).
+func Bn254HashG1(n int, msgs []byte, msgLen int, dst []byte) (out, status []byte, err error) {
+	if err = messages(msgs, msgLen, n); err != nil {
+		return nil, nil, err
+	}
+	if len(dst) > 255 {
+		return nil, nil, fmt.Errorf("kyberhip: domain separation tag of %d bytes (at most 255)", len(dst))
+	}
+	out, status = make([]byte, 64*n), make([]byte, n)
+	err = call(func() C.int {
+		return C.kyb_bn254_hash_g1(C.size_t(n), ptr(msgs), C.size_t(msgLen), ptr(dst), C.size_t(len(dst)), ptr(out), ptr(status))
+	})
+	return
+}

@@ -47,13 +47,13 @@ func (g *Group) flags() uint32 {
 
 // points that exist as kyber.Point values were validated when they were unmarshalled: no re-check on the device
 func (g *Group) trusted() uint32 {
-	if g.kind == hip.Bls12381G1 || g.kind == hip.Bls12381G2 {
+	if g.kind == hip.Bls12381G1 || g.kind == hip.Bls12381G2 || g.kind == hip.Bn254G1 || g.kind == hip.Bn254G2 {
 		return hip.Trusted(0)
 	}
 	return 0
 }
 
-func (g *Group) pointLen() int { return [...]int{32, 48, 96, 64, 128}[g.kind] }
+func (g *Group) pointLen() int { return [...]int{32, 48, 96, 64, 128, 64, 128}[g.kind] }
 
 // mul: n scalars x n points (encodings back to back)
 func (g *Group) mul(sb, pb []byte) (out, st []byte, err error) {
@@ -68,6 +68,10 @@ func (g *Group) mul(sb, pb []byte) (out, st []byte, err error) {
 		return hip.Bn256G1Mul(sb, pb)
 	case hip.Bn256G2:
 		return hip.Bn256G2Mul(sb, pb)
+	case hip.Bn254G1:
+		return hip.Bn254G1Mul(sb, pb, g.trusted())
+	case hip.Bn254G2:
+		return hip.Bn254G2Mul(sb, pb, g.trusted())
 	}
 	return nil, nil, fmt.Errorf("kyberhip: %s has no device multiplication", g.name)
 }
@@ -97,6 +101,10 @@ func (g *Group) mulSame(sb, bb []byte) (out, st []byte, err error) {
 		return hip.Bn256G1MulSameBase(sb, bb)
 	case hip.Bn256G2:
 		return hip.Bn256G2MulSameBase(sb, bb)
+	case hip.Bn254G1:
+		return hip.Bn254G1MulSameBase(sb, bb, g.trusted())
+	case hip.Bn254G2:
+		return hip.Bn254G2MulSameBase(sb, bb, g.trusted())
 	}
 	return nil, nil, fmt.Errorf("kyberhip: %s has no device multiplication", g.name)
 }
@@ -204,6 +212,10 @@ func (g *Group) MSM(scalars []kyber.Scalar, points []kyber.Point, bits uint) (ky
 		out, st, err = hip.Bn256G1MSM(sb, pb, fl)
 	case hip.Bn256G2:
 		out, st, err = hip.Bn256G2MSM(sb, pb, fl)
+	case hip.Bn254G1:
+		out, st, err = hip.Bn254G1MSM(sb, pb, fl)
+	case hip.Bn254G2:
+		out, st, err = hip.Bn254G2MSM(sb, pb, fl)
 	default:
 		err = fmt.Errorf("kyberhip: %s has no device MSM", g.name)
 	}
@@ -244,6 +256,10 @@ func (g *Group) Validate(encs [][]byte) ([]byte, error) {
 		_, st, err = hip.Bn256G1Unmarshal(buf)
 	case hip.Bn256G2:
 		_, st, err = hip.Bn256G2Unmarshal(buf)
+	case hip.Bn254G1:
+		_, st, err = hip.Bn254G1Unmarshal(buf, 0)
+	case hip.Bn254G2:
+		_, st, err = hip.Bn254G2Unmarshal(buf, 0)
 	default:
 		err = fmt.Errorf("kyberhip: %s has no device validation", g.name)
 	}

@@ -20,8 +20,16 @@ import (
 type PairingSuite struct {
 	inner      pairing.Suite
 	g1, g2, gt *Group
-	bls        bool // BLS12-381 (flags, fused verification) or bn256
+	curve      curveID // which engine entry points: BLS12-381 (flags, fused verification), bn256, bn254 (flags)
 }
+
+type curveID int
+
+const (
+	curveBLS12381 curveID = iota
+	curveBn256
+	curveBn254
+)
 
 var _ pairing.Suite = (*PairingSuite)(nil)
 
@@ -78,10 +86,13 @@ func (s *PairingSuite) BatchPair(p1, p2 []kyber.Point) ([]kyber.Point, error) {
 	}
 	var gt, st []byte
 	size := 384
-	if s.bls {
+	switch s.curve {
+	case curveBLS12381:
 		size = 576
 		gt, st, err = hip.Bls12381Pair(a, b, hip.Trusted(0)|hip.Trusted(1)) // kyber.Points: validated when unmarshalled
-	} else {
+	case curveBn254:
+		gt, st, err = hip.Bn254Pair(a, b, hip.Trusted(0)|hip.Trusted(1))
+	default:
 		gt, st, err = hip.Bn256Pair(a, b)
 	}
 	if err != nil {
@@ -123,9 +134,12 @@ func (s *PairingSuite) BatchValidatePairing(p1, p2, inv1, inv2 []kyber.Point) ([
 		return nil, err
 	}
 	var ok, st []byte
-	if s.bls {
+	switch s.curve {
+	case curveBLS12381:
 		ok, st, err = hip.Bls12381ValidatePairing(a, b, c, d, hip.TrustedAll)
-	} else {
+	case curveBn254:
+		ok, st, err = hip.Bn254ValidatePairing(a, b, c, d, hip.TrustedAll)
+	default:
 		ok, st, err = hip.Bn256ValidatePairing(a, b, c, d)
 	}
 	if err != nil {
@@ -146,7 +160,7 @@ func (s *PairingSuite) BatchValidatePairing(p1, p2, inv1, inv2 []kyber.Point) ([
 // per signature, all on the device.  Public keys are kyber.Points (validated); signatures are the raw bytes received.
 // A signature of the wrong length verifies false by itself.  BLS12-381 only.
 func (s *PairingSuite) BatchVerify(publics []kyber.Point, msgs [][]byte, sigs [][]byte, dst []byte) ([]bool, error) {
-	if !s.bls {
+	if s.curve != curveBLS12381 {
 		return nil, fmt.Errorf("kyberhip: fused verification exists for BLS12-381 only")
 	}
 	n := len(msgs)
@@ -193,7 +207,7 @@ func (s *PairingSuite) BatchGTMul(scalars []kyber.Scalar, gts []kyber.Point) ([]
 		return nil, errLen
 	}
 	size := 384
-	if s.bls {
+	if s.curve == curveBLS12381 {
 		size = 576
 	}
 	sb, err := scalarBytes(scalars)
@@ -205,9 +219,12 @@ func (s *PairingSuite) BatchGTMul(scalars []kyber.Scalar, gts []kyber.Point) ([]
 		return nil, err
 	}
 	var out, st []byte
-	if s.bls {
+	switch s.curve {
+	case curveBLS12381:
 		out, st, err = hip.Bls12381GTMul(sb, gb)
-	} else {
+	case curveBn254:
+		out, st, err = hip.Bn254GTMul(sb, gb)
+	default:
 		out, st, err = hip.Bn256GTMul(sb, gb)
 	}
 	if err != nil {

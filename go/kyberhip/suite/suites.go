@@ -12,6 +12,7 @@ import (
 	"go.dedis.ch/kyber/v4/group/edwards25519"
 	hip "go.dedis.ch/kyber/v4/hip"
 	"go.dedis.ch/kyber/v4/pairing/bls12381/kilic"
+	"go.dedis.ch/kyber/v4/pairing/bn254"
 	"go.dedis.ch/kyber/v4/pairing/bn256"
 )
 
@@ -40,7 +41,7 @@ func (s *SuiteEd25519) New(t reflect.Type) any                { return s.ref.New
 // hash-to-curve domains, Pair / ValidatePairing / Mul on the device.
 func NewSuiteBLS12381() *PairingSuite {
 	ref := kilic.NewBLS12381Suite()
-	return &PairingSuite{inner: ref, bls: true,
+	return &PairingSuite{inner: ref, curve: curveBLS12381,
 		g1: &Group{name: "bls12-381.G1.hip", inner: ref.G1(), kind: hip.Bls12381G1},
 		g2: &Group{name: "bls12-381.G2.hip", inner: ref.G2(), kind: hip.Bls12381G2},
 		gt: &Group{name: "bls12-381.GT.hip", inner: ref.GT(), kind: -1}}
@@ -49,10 +50,20 @@ func NewSuiteBLS12381() *PairingSuite {
 // NewSuiteBn256 is the pairing suite over pairing/bn256 (suite.go:43).
 func NewSuiteBn256() *PairingSuite {
 	ref := bn256.NewSuite()
-	return &PairingSuite{inner: ref, bls: false,
+	return &PairingSuite{inner: ref, curve: curveBn256,
 		g1: &Group{name: "bn256.G1.hip", inner: ref.G1(), kind: hip.Bn256G1},
 		g2: &Group{name: "bn256.G2.hip", inner: ref.G2(), kind: hip.Bn256G2},
 		gt: &Group{name: "bn256.GT.hip", inner: ref.GT(), kind: -1}}
+}
+
+// NewSuiteBn254 is the pairing suite over pairing/bn254 (Ethereum's alt_bn128; suite.go:52): the reference's points and
+// scalars, its Keccak / Shallue-van de Woestijne Hash, Pair / ValidatePairing / Mul on the device.
+func NewSuiteBn254() *PairingSuite {
+	ref := bn254.NewSuite()
+	return &PairingSuite{inner: ref, curve: curveBn254,
+		g1: &Group{name: "bn254.G1.hip", inner: ref.G1(), kind: hip.Bn254G1},
+		g2: &Group{name: "bn254.G2.hip", inner: ref.G2(), kind: hip.Bn254G2},
+		gt: &Group{name: "bn254.GT.hip", inner: ref.GT(), kind: -1}}
 }
 
 // GroupSuite adapts a pairing suite to the single-group suites.Suite the registry and the benchmark take, the way
@@ -66,6 +77,7 @@ var _ kyber.Group = (*GroupSuite)(nil)
 
 func NewGroupSuiteBLS12381() *GroupSuite { return &GroupSuite{NewSuiteBLS12381(), "bls12-381.hip.adapter"} }
 func NewGroupSuiteBn256() *GroupSuite    { return &GroupSuite{NewSuiteBn256(), "bn256.hip.adapter"} }
+func NewGroupSuiteBn254() *GroupSuite    { return &GroupSuite{NewSuiteBn254(), "bn254.hip.adapter"} }
 
 func (s *GroupSuite) Point() kyber.Point   { return s.G2().Point() }
 func (s *GroupSuite) PointLen() int        { return s.G2().PointLen() }
