@@ -1551,6 +1551,7 @@ def emit_field(f, struct_name):
         f"    static constexpr int N = {f.N}, NW = {f.NW}, W = {f.W};  // limbs, packed words, bits per limb",
         f"    static constexpr int32_t P[{f.N}] = {{{', '.join(str(d) for d in f.balanced(p))}}};  // balanced W-bit digits of p",
         f"    static constexpr uint32_t NINV = 0x{f.ninv:x}u;  // -p^-1 mod 2^W",
+        f"    static constexpr bool OPAQUE_P = {'true' if any(abs(d) > 1 and abs(d) & (abs(d) - 1) == 0 for d in f.balanced(p)) else 'false'};  // a digit of p is +-2^k (tower_vm.cuh mont_reduce)",
         f"    static constexpr uint32_t P1[{f.N + 1}] = {{{arr(digits(p))}}};  // p, 2p, 4p: unsigned W-bit digits",
         f"    static constexpr uint32_t P2[{f.N + 1}] = {{{arr(digits(2 * p))}}};",
         f"    static constexpr uint32_t P4[{f.N + 1}] = {{{arr(digits(4 * p))}}};",

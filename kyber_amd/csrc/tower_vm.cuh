@@ -152,11 +152,21 @@ __device__ __forceinline__ void normalise(int32_t (&r)[N], const int64_t* t) {
 template <class F>
 __device__ __forceinline__ void mont_reduce(int64_t (&t)[2 * F::N]) {
     constexpr int N = F::N, W = F::W;
+    // F::OPAQUE_P: the digits of p as opaque scalars.  Left as literals, a digit that happens to be +-2^k (BLS12-381
+    // has one) is strength-reduced into a 64-bit shift and a subtract-with-borrow pair -- five instructions where one
+    // multiply-add with an SGPR operand does (-1.5 % per pairing); a field without such a digit is better off with
+    // the literals (+1.1 % on the BN fields, same-box A/B)
+    int32_t pd[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        pd[j] = F::P[j];
+        if constexpr (F::OPAQUE_P) asm volatile("" : "+s"(pd[j]));
+    }
 #pragma unroll
     for (int i = 0; i < N; i++) {
         const int32_t m = sext<W>((uint32_t)t[i] * F::NINV);
 #pragma unroll
-        for (int j = 0; j < N; j++) t[i + j] += (int64_t)m * F::P[j];
+        for (int j = 0; j < N; j++) t[i + j] += (int64_t)m * pd[j];
         t[i + 1] += t[i] >> W;  // exact: the low W bits are zero
     }
 }
@@ -285,21 +295,28 @@ __device__ void run(const Args& a, uint32_t* lds, uint32_t* misc, const int32_t*
                             if (kind == K_LIN) {
 #pragma unroll
                                 for (int i = 0; i < N; i++) t[N + i] += (int64_t)x[i];
-                            } else if (kind == K_PROD) {
+                                continue;
+                            }
+                            // ONE multiply-add block for both kinds of product: the second operand is assembled first
+                            // (slots, or a constant's wave-uniform limbs), so the 2N column accumulators keep their
+                            // registers whatever path the operands took
+                            int32_t y[N];
+                            if (kind == K_PROD) {
                                 const int cy1 = (int8_t)((w1 >> 16) & 0xff), cy2 = (int8_t)(w1 >> 24);
-                                int32_t y[N];
                                 operand<F>(y, lds, (w0 >> 12) & 63u, cy1, (w0 >> 18) & 63u, cy2, lane);
-#pragma unroll
-                                for (int i = 0; i < N; i++)
-#pragma unroll
-                                    for (int j = 0; j < N; j++) t[i + j] += (int64_t)x[i] * y[j];
-                            } else {  // constant y: wave-uniform limbs
+                            } else {
                                 const int32_t* c = clds + 16 * ((w0 >> 12) & 0xfffu);
 #pragma unroll
-                                for (int i = 0; i < N; i++)
-#pragma unroll
-                                    for (int j = 0; j < N; j++) t[i + j] += (int64_t)x[i] * c[j];
+                                for (int j = 0; j < N; j++) y[j] = c[j];
                             }
+#pragma unroll
+                            for (int i = 0; i < N; i++) {
+                                asm volatile("" : "+v"(x[i]), "+v"(y[i]));  // operands are final here: one block below
+                            }
+#pragma unroll
+                            for (int i = 0; i < N; i++)
+#pragma unroll
+                                for (int j = 0; j < N; j++) t[i + j] += (int64_t)x[i] * y[j];
                         }
                         if (!((hdr >> 13) & 1u)) mont_reduce<F>(t);
                         normalise<N, F::W>(r, t + N);
