@@ -230,6 +230,10 @@ int kyb_shutdown(void) {
             if (c->stage[i]) hipFree(c->stage[i]);
         for (int i = 0; i < 3; i++)
             if (c->pipe[i]) hipStreamDestroy(c->pipe[i]);
+        for (int i = 0; i < 3; i++) {
+            if (c->pin_in[i]) hipHostFree(c->pin_in[i]);
+            if (c->pin_out[i]) hipHostFree(c->pin_out[i]);
+        }
         delete c;
     }
     kyb::g_ctx.clear();

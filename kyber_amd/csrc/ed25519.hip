@@ -520,10 +520,11 @@ int kyb_ed25519_mul_base(size_t n, const uint8_t* scalars, uint8_t* out, uint32_
 }
 
 // Host-buffer batches of at least 2 * PIPE_CHUNK elements are cut in chunks and software-pipelined over three
-// streams: while chunk i computes, chunk i+1 is copied in and chunk i-1 is copied out.  The copies are issued in
-// the order H2D(i+1), kernel(i+1), D2H(i), so even where the runtime makes a pageable-memory copy block the host
-// thread, the compute stream always has the next kernel queued.  (PCIe moves 97 bytes per variable-base element
-// in ~1/3 of the time the kernel needs for it: overlapped, the host path approaches the resident rate.)
+// streams and three page-locked staging slots: while chunk i computes, chunk i+1 is copied in and chunk i-1 is copied
+// out.  The caller's memory is pageable, and a copy straight from it is staged by the runtime at ~10 GB/s while it
+// blocks the issuing thread; instead the host thread memcpys a chunk into a pinned slot (and results out of one) and
+// the DMA engines move pinned <-> device asynchronously, so both the host's copies and the DMA hide behind the
+// kernels.  (97 bytes per variable-base element: a quarter of the kernel's time per chunk at memcpy speed.)
 constexpr size_t PIPE_CHUNK = size_t(1) << 18;
 constexpr size_t SAME_BASE_TABLE_MIN = 16384;  // below this the table (4 544 short multiplications) does not pay
 
@@ -583,49 +584,79 @@ static int mul_host(size_t n, const uint8_t* scalars, const uint8_t* points, siz
     }
     if ((rc = pipe_streams(ctx))) return rc;
     hipStream_t s_in = ctx->pipe[0], s_k = ctx->pipe[1], s_out = ctx->pipe[2];
+    const bool per_point = !fixed && stride;
+    const bool want_status = status && !fixed;
+    // page-locked slots: [scalars | points] in, [points | status] out, one chunk each, three of each
+    const size_t in_bytes = PIPE_CHUNK * (per_point ? 64 : 32), out_bytes = PIPE_CHUNK * 33;
+    if (ctx->pin_in_cap < in_bytes) {
+        for (int i = 0; i < 3; i++) {
+            if (ctx->pin_in[i]) hipHostFree(ctx->pin_in[i]);
+            ctx->pin_in[i] = nullptr;
+        }
+        ctx->pin_in_cap = 0;
+        for (int i = 0; i < 3; i++) KYB_HIP_CHECK(hipHostMalloc(&ctx->pin_in[i], PIPE_CHUNK * 64, hipHostMallocDefault));
+        ctx->pin_in_cap = PIPE_CHUNK * 64;
+    }
+    if (ctx->pin_out_cap < out_bytes) {
+        for (int i = 0; i < 3; i++) KYB_HIP_CHECK(hipHostMalloc(&ctx->pin_out[i], out_bytes, hipHostMallocDefault));
+        ctx->pin_out_cap = out_bytes;
+    }
     const size_t nchunks = (n + PIPE_CHUNK - 1) / PIPE_CHUNK;
-    std::vector<hipEvent_t> ev_in(nchunks), ev_k(nchunks);
+    std::vector<hipEvent_t> ev_in(nchunks), ev_k(nchunks), ev_out(nchunks);
     for (size_t i = 0; i < nchunks; i++) {
         KYB_HIP_CHECK(hipEventCreateWithFlags(&ev_in[i], hipEventDisableTiming));
         KYB_HIP_CHECK(hipEventCreateWithFlags(&ev_k[i], hipEventDisableTiming));
+        KYB_HIP_CHECK(hipEventCreateWithFlags(&ev_out[i], hipEventDisableTiming));
     }
-    auto h2d = [&](size_t i) -> int {
+    // chunk i: the host copies it into slot i % 3, the DMA engine moves it in (s_in), the kernel runs (s_k), the DMA
+    // engine moves the results into the slot's out half (s_out), the host copies them out.  Before slot i % 3 is
+    // refilled, chunk i - 3 has been drained (so its kernel has read the slot's inputs, too): the host's two memcpys
+    // per chunk run while the kernels of the two chunks in between execute.
+    auto enqueue = [&](size_t i) -> int {
         const size_t off = i * PIPE_CHUNK, cnt = std::min(PIPE_CHUNK, n - off);
-        KYB_HIP_CHECK(hipMemcpyAsync((uint8_t*)d_s.p + off * 32, scalars + off * 32, cnt * 32, hipMemcpyHostToDevice, s_in));
-        if (!fixed && stride)
-            KYB_HIP_CHECK(hipMemcpyAsync((uint8_t*)d_p.p + off * 32, points + off * 32, cnt * 32, hipMemcpyHostToDevice, s_in));
+        uint8_t* pin = (uint8_t*)ctx->pin_in[i % 3];
+        memcpy(pin, scalars + off * 32, cnt * 32);
+        KYB_HIP_CHECK(hipMemcpyAsync((uint8_t*)d_s.p + off * 32, pin, cnt * 32, hipMemcpyHostToDevice, s_in));
+        if (per_point) {
+            memcpy(pin + PIPE_CHUNK * 32, points + off * 32, cnt * 32);
+            KYB_HIP_CHECK(hipMemcpyAsync((uint8_t*)d_p.p + off * 32, pin + PIPE_CHUNK * 32, cnt * 32, hipMemcpyHostToDevice, s_in));
+        }
         KYB_HIP_CHECK(hipEventRecord(ev_in[i], s_in));
-        return KYB_OK;
-    };
-    auto kern = [&](size_t i) -> int {
-        const size_t off = i * PIPE_CHUNK, cnt = std::min(PIPE_CHUNK, n - off);
         KYB_HIP_CHECK(hipStreamWaitEvent(s_k, ev_in[i], 0));
         int r = launch(off, cnt, s_k);
         if (r) return r;
         KYB_HIP_CHECK(hipEventRecord(ev_k[i], s_k));
+        KYB_HIP_CHECK(hipStreamWaitEvent(s_out, ev_k[i], 0));
+        uint8_t* pout = (uint8_t*)ctx->pin_out[i % 3];
+        KYB_HIP_CHECK(hipMemcpyAsync(pout, (uint8_t*)d_o.p + off * 32, cnt * 32, hipMemcpyDeviceToHost, s_out));
+        if (want_status)
+            KYB_HIP_CHECK(hipMemcpyAsync(pout + PIPE_CHUNK * 32, (uint8_t*)d_st.p + off, cnt, hipMemcpyDeviceToHost, s_out));
+        KYB_HIP_CHECK(hipEventRecord(ev_out[i], s_out));
         return KYB_OK;
     };
-    auto d2h = [&](size_t i) -> int {
+    auto drain = [&](size_t i) -> int {
         const size_t off = i * PIPE_CHUNK, cnt = std::min(PIPE_CHUNK, n - off);
-        KYB_HIP_CHECK(hipStreamWaitEvent(s_out, ev_k[i], 0));
-        KYB_HIP_CHECK(hipMemcpyAsync(out + off * 32, (uint8_t*)d_o.p + off * 32, cnt * 32, hipMemcpyDeviceToHost, s_out));
-        if (status && !fixed)
-            KYB_HIP_CHECK(hipMemcpyAsync(status + off, (uint8_t*)d_st.p + off, cnt, hipMemcpyDeviceToHost, s_out));
+        KYB_HIP_CHECK(hipEventSynchronize(ev_out[i]));
+        const uint8_t* pout = (const uint8_t*)ctx->pin_out[i % 3];
+        memcpy(out + off * 32, pout, cnt * 32);
+        if (want_status) memcpy(status + off, pout + PIPE_CHUNK * 32, cnt);
         return KYB_OK;
     };
     if (!fixed && !stride) KYB_HIP_CHECK(hipMemcpyAsync(d_p.p, points, 32, hipMemcpyHostToDevice, s_in));
-    rc = h2d(0);
-    if (rc == KYB_OK) rc = kern(0);
-    for (size_t i = 1; i < nchunks && rc == KYB_OK; i++) {
-        rc = h2d(i);
-        if (rc == KYB_OK) rc = kern(i);
-        if (rc == KYB_OK) rc = d2h(i - 1);
+    size_t drained = 0;
+    for (size_t i = 0; i < nchunks && rc == KYB_OK; i++) {
+        if (i >= 3) {  // slot i % 3 still belongs to chunk i - 3
+            rc = drain(drained++);
+            if (rc) break;
+        }
+        rc = enqueue(i);
     }
-    if (rc == KYB_OK) rc = d2h(nchunks - 1);
+    while (rc == KYB_OK && drained < nchunks) rc = drain(drained++);
     hipError_t e1 = hipStreamSynchronize(s_out), e2 = hipStreamSynchronize(s_k), e3 = hipStreamSynchronize(s_in);
     for (size_t i = 0; i < nchunks; i++) {
         hipEventDestroy(ev_in[i]);
         hipEventDestroy(ev_k[i]);
+        hipEventDestroy(ev_out[i]);
     }
     if (rc == KYB_OK && (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)) {
         set_error("ed25519 host pipeline: stream synchronisation failed");
