@@ -54,11 +54,11 @@ struct DeviceCtx {
     std::mutex stage_mu;
     // streams of the chunk-pipelined host paths (H2D | compute | D2H), created on first use
     hipStream_t pipe[3] = {};
-    // page-locked staging of those paths: three chunk slots each way (grow-only).  A copy from pageable memory is staged
+    // page-locked staging of those paths: six chunk slots each way (allocated on first use).  A copy from pageable memory is staged
     // by the runtime at ~10 GB/s and blocks the issuing thread; through these slots the DMA is asynchronous and the
     // host's own memcpy into / out of them overlaps the kernels (ed25519.hip mul_host).
-    void* pin_in[3] = {};
-    void* pin_out[3] = {};
+    void* pin_in[6] = {};
+    void* pin_out[6] = {};
     size_t pin_in_cap = 0, pin_out_cap = 0;
 };
 

@@ -230,7 +230,7 @@ int kyb_shutdown(void) {
             if (c->stage[i]) hipFree(c->stage[i]);
         for (int i = 0; i < 3; i++)
             if (c->pipe[i]) hipStreamDestroy(c->pipe[i]);
-        for (int i = 0; i < 3; i++) {
+        for (int i = 0; i < 6; i++) {
             if (c->pin_in[i]) hipHostFree(c->pin_in[i]);
             if (c->pin_out[i]) hipHostFree(c->pin_out[i]);
         }

@@ -11,9 +11,12 @@
 #include "ge25519.cuh"
 #include "msm.cuh"
 #include "ed25519_h2c.cuh"
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 namespace kyb {
@@ -519,17 +522,56 @@ int kyb_ed25519_mul_base(size_t n, const uint8_t* scalars, uint8_t* out, uint32_
     return mul_host(n, scalars, nullptr, 0, out, nullptr, flags);
 }
 
-// Host-buffer batches of at least 2 * PIPE_CHUNK elements are cut in chunks and software-pipelined over three
-// streams and three page-locked staging slots: while chunk i computes, chunk i+1 is copied in and chunk i-1 is copied
-// out.  The caller's memory is pageable, and a copy straight from it is staged by the runtime at ~10 GB/s while it
-// blocks the issuing thread; instead the host thread memcpys a chunk into a pinned slot (and results out of one) and
-// the DMA engines move pinned <-> device asynchronously, so both the host's copies and the DMA hide behind the
-// kernels.  (97 bytes per variable-base element: a quarter of the kernel's time per chunk at memcpy speed.)
-constexpr size_t PIPE_CHUNK = size_t(1) << 18;
+// Host-buffer batches of at least two chunks (pipe_chunk) are cut in chunks and software-pipelined over three
+// page-locked staging slots: while chunk i computes, chunk i+1 is copied in and chunk i-1 is copied out.  The caller's
+// memory is pageable, and a copy straight from it is staged by the runtime at ~10 GB/s while it blocks the issuing
+// thread; instead host threads memcpy a chunk into a pinned slot (and results out of one) and the kernels work on the
+// slots in place, over PCIe.  (97 bytes per variable-base element: a quarter of the kernel's time at memcpy speed.)
+constexpr size_t PIPE_CHUNK_MAX = size_t(1) << 17;  // capacity of a staging slot, in elements
+constexpr int PIPE_SLOTS = 6, PIPE_STREAMS = 3;
+// Chunks of 2^17 elements alternate between two compute streams, so the tail of one chunk's kernel overlaps the head
+// of the next and the pipeline fills in the time one chunk takes to copy.  Same-box sweep at the C ABI, 2^20 elements,
+// fixed-base / variable-base ms (tools/gpu/r02_host5.sh): 1 stream x 2^18: 3.13 / 15.30; 1 x 2^17: 3.90 / 15.90;
+// 2 x 2^17: 2.78 / 13.93; 2 x 2^18: 2.79 / 14.60; 3 x 2^17: 2.61 / 14.29; 3 x 2^16: 3.24 / 17.11 (resident: 1.6 / 12.0).
+// KYB_PIPE_CHUNK / KYB_PIPE_STREAMS override the defaults for such sweeps.
+static size_t pipe_chunk(const DeviceCtx* ctx) {
+    if (const char* e = getenv("KYB_PIPE_CHUNK")) {  // tuning knob (elements, a multiple of 64)
+        const size_t v = (size_t)strtoull(e, nullptr, 10) & ~size_t(63);
+        if (v >= 4096) return std::min(PIPE_CHUNK_MAX, v);
+    }
+    (void)ctx;
+    return size_t(1) << 17;
+}
+static int pipe_nstreams() {
+    if (const char* e = getenv("KYB_PIPE_STREAMS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= PIPE_STREAMS) return v;
+    }
+    return 2;
+}
 constexpr size_t SAME_BASE_TABLE_MIN = 16384;  // below this the table (4 544 short multiplications) does not pay
 
+// memcpy between the caller's pageable buffers and the page-locked slots, cut over a few threads: one core moves
+// ~10 GB/s, and for the fixed-base path (64 bytes per 1.5 us of kernel time) that copy is the whole critical path
+static void par_memcpy(void* dst, const void* src, size_t bytes) {
+    constexpr size_t MIN_PART = size_t(1) << 20;
+    const int parts = (int)std::min<size_t>(4, bytes / MIN_PART);
+    if (parts <= 1) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t per = ((bytes / parts) + 63) & ~size_t(63);
+    std::thread th[3];
+    for (int t = 1; t < parts; t++) {
+        const size_t lo = per * t, hi = t == parts - 1 ? bytes : per * (t + 1);
+        th[t - 1] = std::thread([=] { memcpy((uint8_t*)dst + lo, (const uint8_t*)src + lo, hi - lo); });
+    }
+    memcpy(dst, src, per);
+    for (int t = 1; t < parts; t++) th[t - 1].join();
+}
+
 static int pipe_streams(DeviceCtx* ctx) {
-    for (int i = 0; i < 3; i++)
+    for (int i = 0; i < PIPE_STREAMS; i++)
         if (!ctx->pipe[i]) KYB_HIP_CHECK(hipStreamCreateWithFlags(&ctx->pipe[i], hipStreamNonBlocking));
     return KYB_OK;
 }
@@ -574,6 +616,7 @@ static int mul_host(size_t n, const uint8_t* scalars, const uint8_t* points, siz
         const uint8_t* p = (const uint8_t*)d_p.p + (stride ? off * 32 : 0);
         return launch_mul(cnt, s, p, stride, o, (uint8_t*)d_st.p + off, flags, st);
     };
+    const size_t PIPE_CHUNK = pipe_chunk(ctx);
     if (n < 2 * PIPE_CHUNK) {
         KYB_HIP_CHECK(hipMemcpy(d_s.p, scalars, n * 32, hipMemcpyHostToDevice));
         if (npts) KYB_HIP_CHECK(hipMemcpy(d_p.p, points, npts * 32, hipMemcpyHostToDevice));
@@ -583,82 +626,97 @@ static int mul_host(size_t n, const uint8_t* scalars, const uint8_t* points, siz
         return rc;
     }
     if ((rc = pipe_streams(ctx))) return rc;
-    hipStream_t s_in = ctx->pipe[0], s_k = ctx->pipe[1], s_out = ctx->pipe[2];
+    const int nstreams = pipe_nstreams();
     const bool per_point = !fixed && stride;
     const bool want_status = status && !fixed;
-    // page-locked slots: [scalars | points] in, [points | status] out, one chunk each, three of each
-    const size_t in_bytes = PIPE_CHUNK * (per_point ? 64 : 32), out_bytes = PIPE_CHUNK * 33;
+    // page-locked slots: [scalars | points] in, [points | status] out, one chunk each, PIPE_SLOTS of each
+    const size_t in_bytes = PIPE_CHUNK_MAX * 64, out_bytes = PIPE_CHUNK_MAX * 33;
     if (ctx->pin_in_cap < in_bytes) {
-        for (int i = 0; i < 3; i++) {
-            if (ctx->pin_in[i]) hipHostFree(ctx->pin_in[i]);
-            ctx->pin_in[i] = nullptr;
-        }
-        ctx->pin_in_cap = 0;
-        for (int i = 0; i < 3; i++) KYB_HIP_CHECK(hipHostMalloc(&ctx->pin_in[i], PIPE_CHUNK * 64, hipHostMallocDefault));
-        ctx->pin_in_cap = PIPE_CHUNK * 64;
+        for (int i = 0; i < PIPE_SLOTS; i++) KYB_HIP_CHECK(hipHostMalloc(&ctx->pin_in[i], PIPE_CHUNK_MAX * 64, hipHostMallocDefault));
+        ctx->pin_in_cap = PIPE_CHUNK_MAX * 64;
     }
     if (ctx->pin_out_cap < out_bytes) {
-        for (int i = 0; i < 3; i++) KYB_HIP_CHECK(hipHostMalloc(&ctx->pin_out[i], out_bytes, hipHostMallocDefault));
+        for (int i = 0; i < PIPE_SLOTS; i++) KYB_HIP_CHECK(hipHostMalloc(&ctx->pin_out[i], out_bytes, hipHostMallocDefault));
         ctx->pin_out_cap = out_bytes;
     }
     const size_t nchunks = (n + PIPE_CHUNK - 1) / PIPE_CHUNK;
-    std::vector<hipEvent_t> ev_in(nchunks), ev_k(nchunks), ev_out(nchunks);
-    for (size_t i = 0; i < nchunks; i++) {
-        KYB_HIP_CHECK(hipEventCreateWithFlags(&ev_in[i], hipEventDisableTiming));
-        KYB_HIP_CHECK(hipEventCreateWithFlags(&ev_k[i], hipEventDisableTiming));
-        KYB_HIP_CHECK(hipEventCreateWithFlags(&ev_out[i], hipEventDisableTiming));
-    }
-    // chunk i: the host copies it into slot i % 3, the DMA engine moves it in (s_in), the kernel runs (s_k), the DMA
-    // engine moves the results into the slot's out half (s_out), the host copies them out.  Before slot i % 3 is
-    // refilled, chunk i - 3 has been drained (so its kernel has read the slot's inputs, too): the host's two memcpys
-    // per chunk run while the kernels of the two chunks in between execute.
+    std::vector<hipEvent_t> ev_out(nchunks);
+    for (size_t i = 0; i < nchunks; i++) KYB_HIP_CHECK(hipEventCreateWithFlags(&ev_out[i], hipEventDisableTiming));
+    // chunk i: the host copies it into slot i % PIPE_SLOTS, the kernels run on it in place on stream i % PIPE_STREAMS, a
+    // second host thread copies the results out of the slot's out half.  Before a slot is refilled, the chunk that
+    // held it has been drained (so its kernel has read the slot's inputs, too): the host's memcpys run while the
+    // kernels of the chunks in between execute.
     auto enqueue = [&](size_t i) -> int {
         const size_t off = i * PIPE_CHUNK, cnt = std::min(PIPE_CHUNK, n - off);
-        uint8_t* pin = (uint8_t*)ctx->pin_in[i % 3];
-        memcpy(pin, scalars + off * 32, cnt * 32);
-        KYB_HIP_CHECK(hipMemcpyAsync((uint8_t*)d_s.p + off * 32, pin, cnt * 32, hipMemcpyHostToDevice, s_in));
-        if (per_point) {
-            memcpy(pin + PIPE_CHUNK * 32, points + off * 32, cnt * 32);
-            KYB_HIP_CHECK(hipMemcpyAsync((uint8_t*)d_p.p + off * 32, pin + PIPE_CHUNK * 32, cnt * 32, hipMemcpyHostToDevice, s_in));
+        uint8_t* pin = (uint8_t*)ctx->pin_in[i % PIPE_SLOTS];
+        uint8_t* pout = (uint8_t*)ctx->pin_out[i % PIPE_SLOTS];
+        hipStream_t s_k = ctx->pipe[i % nstreams];
+        par_memcpy(pin, scalars + off * 32, cnt * 32);
+        if (per_point) par_memcpy(pin + PIPE_CHUNK_MAX * 32, points + off * 32, cnt * 32);
+        // zero copy: the kernels read the chunk's scalars / points straight from the page-locked slot over PCIe (one
+        // coalesced 2 KB read per wave at the start of ~10 us of arithmetic) and write the encoded results straight
+        // into the slot's out half.  (Through hipMemcpyAsync the runtime ran most of these transfers as blit KERNELS,
+        // 6 ms of them per 2^20 elements competing with the ladder for the CUs.)
+        int r;
+        if (fixed) {
+            r = launch_mul_base(ctx, cnt, pin, pout, flags, s_k, tab);
+        } else {
+            const uint8_t* p = per_point ? pin + PIPE_CHUNK_MAX * 32 : (const uint8_t*)d_p.p;
+            r = launch_mul(cnt, pin, p, stride, pout, (uint8_t*)d_st.p + off, flags, s_k);
         }
-        KYB_HIP_CHECK(hipEventRecord(ev_in[i], s_in));
-        KYB_HIP_CHECK(hipStreamWaitEvent(s_k, ev_in[i], 0));
-        int r = launch(off, cnt, s_k);
         if (r) return r;
-        KYB_HIP_CHECK(hipEventRecord(ev_k[i], s_k));
-        KYB_HIP_CHECK(hipStreamWaitEvent(s_out, ev_k[i], 0));
-        uint8_t* pout = (uint8_t*)ctx->pin_out[i % 3];
-        KYB_HIP_CHECK(hipMemcpyAsync(pout, (uint8_t*)d_o.p + off * 32, cnt * 32, hipMemcpyDeviceToHost, s_out));
         if (want_status)
-            KYB_HIP_CHECK(hipMemcpyAsync(pout + PIPE_CHUNK * 32, (uint8_t*)d_st.p + off, cnt, hipMemcpyDeviceToHost, s_out));
-        KYB_HIP_CHECK(hipEventRecord(ev_out[i], s_out));
+            KYB_HIP_CHECK(hipMemcpyAsync(pout + PIPE_CHUNK_MAX * 32, (uint8_t*)d_st.p + off, cnt, hipMemcpyDeviceToHost, s_k));
+        KYB_HIP_CHECK(hipEventRecord(ev_out[i], s_k));
         return KYB_OK;
     };
     auto drain = [&](size_t i) -> int {
         const size_t off = i * PIPE_CHUNK, cnt = std::min(PIPE_CHUNK, n - off);
         KYB_HIP_CHECK(hipEventSynchronize(ev_out[i]));
-        const uint8_t* pout = (const uint8_t*)ctx->pin_out[i % 3];
-        memcpy(out + off * 32, pout, cnt * 32);
-        if (want_status) memcpy(status + off, pout + PIPE_CHUNK * 32, cnt);
+        const uint8_t* pout = (const uint8_t*)ctx->pin_out[i % PIPE_SLOTS];
+        par_memcpy(out + off * 32, pout, cnt * 32);
+        if (want_status) memcpy(status + off, pout + PIPE_CHUNK_MAX * 32, cnt);
         return KYB_OK;
     };
-    if (!fixed && !stride) KYB_HIP_CHECK(hipMemcpyAsync(d_p.p, points, 32, hipMemcpyHostToDevice, s_in));
-    size_t drained = 0;
-    for (size_t i = 0; i < nchunks && rc == KYB_OK; i++) {
-        if (i >= 3) {  // slot i % 3 still belongs to chunk i - 3
-            rc = drain(drained++);
-            if (rc) break;
+    if (!fixed && !stride) KYB_HIP_CHECK(hipMemcpy(d_p.p, points, 32, hipMemcpyHostToDevice));
+    // a second host thread copies results out (chunks in order) while this one copies inputs in: the host's memcpy
+    // bandwidth is what bounds the fixed-base path (64 bytes moved per 1.5 us of kernel)
+    std::atomic<size_t> enqueued{0}, drained{0};
+    std::atomic<int> drain_rc{KYB_OK};
+    std::atomic<bool> stop{false};
+    const int device = ctx->device;
+    std::thread drainer([&] {
+        hipSetDevice(device);
+        for (size_t i = 0; i < nchunks; i++) {
+            while (enqueued.load(std::memory_order_acquire) <= i) {
+                if (stop.load(std::memory_order_acquire)) return;
+                std::this_thread::yield();
+            }
+            const int r = drain(i);
+            if (r) {
+                drain_rc.store(r);
+                return;
+            }
+            drained.store(i + 1, std::memory_order_release);
         }
+    });
+    for (size_t i = 0; i < nchunks && rc == KYB_OK; i++) {
+        while (i >= (size_t)PIPE_SLOTS && drained.load(std::memory_order_acquire) + PIPE_SLOTS <= i && drain_rc.load() == KYB_OK)
+            std::this_thread::yield();  // the slot still belongs to chunk i - PIPE_SLOTS
+        if (drain_rc.load() != KYB_OK) break;
         rc = enqueue(i);
+        if (rc == KYB_OK) enqueued.store(i + 1, std::memory_order_release);
     }
-    while (rc == KYB_OK && drained < nchunks) rc = drain(drained++);
-    hipError_t e1 = hipStreamSynchronize(s_out), e2 = hipStreamSynchronize(s_k), e3 = hipStreamSynchronize(s_in);
-    for (size_t i = 0; i < nchunks; i++) {
-        hipEventDestroy(ev_in[i]);
-        hipEventDestroy(ev_k[i]);
-        hipEventDestroy(ev_out[i]);
+    if (rc != KYB_OK) stop.store(true, std::memory_order_release);
+    drainer.join();
+    if (rc == KYB_OK) rc = drain_rc.load();
+    hipError_t e2 = hipSuccess;
+    for (int i = 0; i < PIPE_STREAMS; i++) {
+        const hipError_t e = hipStreamSynchronize(ctx->pipe[i]);
+        if (e != hipSuccess) e2 = e;
     }
-    if (rc == KYB_OK && (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)) {
+    for (size_t i = 0; i < nchunks; i++) hipEventDestroy(ev_out[i]);
+    if (rc == KYB_OK && e2 != hipSuccess) {
         set_error("ed25519 host pipeline: stream synchronisation failed");
         rc = KYB_E_HIP;
     }
