@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <string>
@@ -57,10 +58,16 @@ struct DeviceCtx {
     // page-locked staging of those paths: six chunk slots each way (allocated on first use).  A copy from pageable memory is staged
     // by the runtime at ~10 GB/s and blocks the issuing thread; through these slots the DMA is asynchronous and the
     // host's own memcpy into / out of them overlaps the kernels (ed25519.hip mul_host).
-    void* pin_in[6] = {};
-    void* pin_out[6] = {};
-    size_t pin_in_cap = 0, pin_out_cap = 0;
+    static constexpr int NPIN = 6;
+    void* pin_in[NPIN] = {};   // PIN_SLOT_ELEMS * 64 bytes each
+    void* pin_out[NPIN] = {};  // PIN_SLOT_ELEMS * 33 bytes each
+    bool pinned = false;
 };
+constexpr size_t PIN_SLOT_ELEMS = size_t(1) << 17;
+constexpr size_t PIN_IN_BYTES = PIN_SLOT_ELEMS * 64, PIN_OUT_BYTES = PIN_SLOT_ELEMS * 33;
+int ctx_pin_slots(DeviceCtx* ctx);  // allocates the slots on first use (hipHostMalloc)
+// memcpy between pageable buffers and page-locked slots, cut over a few threads: one core moves ~10 GB/s
+void par_memcpy(void* dst, const void* src, size_t bytes);
 
 // Flag validation of the pairing-suite entry points: only the documented bits of include/kyber_hip.h for a call with
 // `npoint` point arguments (KYB_F_TRUSTED(i), i < npoint), uncompressed input, and -- where the call writes points --
@@ -138,15 +145,67 @@ struct StageBuf {
         p = c->stage[slot];
         return KYB_OK;
     }
+    // Large transfers bounce through two page-locked slots: the runtime stages a copy from / to pageable memory itself
+    // at ~10 GB/s and blocks; here a piece is memcpy'd by four host threads while the previous piece moves by DMA
+    // (a 2^20-point MSM uploads 84-168 MB -- at 10 GB/s that is longer than the MSM takes).
+    static constexpr size_t BOUNCE_MIN = size_t(4) << 20;
     int upload(const void* src, size_t bytes) {
         int rc = alloc(bytes);
         if (rc) return rc;
-        if (bytes) KYB_HIP_CHECK(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
-        return KYB_OK;
+        if (!bytes) return KYB_OK;
+        if (bytes < BOUNCE_MIN) {
+            KYB_HIP_CHECK(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+            return KYB_OK;
+        }
+        return bounce(const_cast<void*>(src), bytes, true);
     }
     int download(void* dst, size_t bytes) {
-        if (bytes) KYB_HIP_CHECK(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
-        return KYB_OK;
+        if (!bytes) return KYB_OK;
+        if (bytes < BOUNCE_MIN) {
+            KYB_HIP_CHECK(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
+            return KYB_OK;
+        }
+        return bounce(dst, bytes, false);
+    }
+    int bounce(void* host, size_t bytes, bool up) {
+        StageScope* sc = StageScope::current();
+        DeviceCtx* c = sc->ctx;
+        int rc = ctx_pin_slots(c);
+        if (rc) return rc;
+        hipEvent_t ev[2];
+        for (int k = 0; k < 2; k++) KYB_HIP_CHECK(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+        const size_t piece = PIN_IN_BYTES;
+        const size_t npiece = (bytes + piece - 1) / piece;
+        rc = KYB_OK;
+        for (size_t i = 0; i <= npiece && rc == KYB_OK; i++) {
+            // up:   host -> slot(i) by memcpy, then slot(i) -> device by DMA (async); a slot is reused two pieces later
+            // down: device -> slot(i) by DMA (async), slot(i - 1) -> host by memcpy meanwhile
+            if (up) {
+                if (i == npiece) break;
+                const size_t off = i * piece, len = std::min(piece, bytes - off);
+                if (i >= 2 && hipEventSynchronize(ev[i & 1]) != hipSuccess) rc = KYB_E_HIP;
+                par_memcpy(c->pin_in[i & 1], (const uint8_t*)host + off, len);
+                if (hipMemcpyAsync((uint8_t*)p + off, c->pin_in[i & 1], len, hipMemcpyHostToDevice, nullptr) != hipSuccess ||
+                    hipEventRecord(ev[i & 1], nullptr) != hipSuccess)
+                    rc = KYB_E_HIP;
+            } else {
+                if (i < npiece) {
+                    const size_t off = i * piece, len = std::min(piece, bytes - off);
+                    if (hipMemcpyAsync(c->pin_in[i & 1], (const uint8_t*)p + off, len, hipMemcpyDeviceToHost, nullptr) != hipSuccess ||
+                        hipEventRecord(ev[i & 1], nullptr) != hipSuccess)
+                        rc = KYB_E_HIP;
+                }
+                if (i >= 1 && rc == KYB_OK) {
+                    const size_t off = (i - 1) * piece, len = std::min(piece, bytes - off);
+                    if (hipEventSynchronize(ev[(i - 1) & 1]) != hipSuccess) rc = KYB_E_HIP;
+                    else par_memcpy((uint8_t*)host + off, c->pin_in[(i - 1) & 1], len);
+                }
+            }
+        }
+        if (hipStreamSynchronize(nullptr) != hipSuccess) rc = KYB_E_HIP;
+        for (int k = 0; k < 2; k++) hipEventDestroy(ev[k]);
+        if (rc == KYB_E_HIP) set_error("staging: page-locked bounce copy failed");
+        return rc;
     }
 };
 

@@ -1,6 +1,9 @@
 #include "context.h"
 #include "hd.h"
 
+#include <string.h>
+
+#include <algorithm>
 #include <map>
 #include <thread>
 #include <vector>
@@ -119,6 +122,34 @@ int md_run_impl(size_t n, int (*thunk)(void*, int, size_t, size_t), void* arg) {
     return KYB_OK;
 }
 
+}  // namespace kyb
+
+namespace kyb {
+int ctx_pin_slots(DeviceCtx* ctx) {
+    if (ctx->pinned) return KYB_OK;
+    for (int i = 0; i < DeviceCtx::NPIN; i++) {
+        if (!ctx->pin_in[i]) KYB_HIP_CHECK(hipHostMalloc(&ctx->pin_in[i], PIN_IN_BYTES, hipHostMallocDefault));
+        if (!ctx->pin_out[i]) KYB_HIP_CHECK(hipHostMalloc(&ctx->pin_out[i], PIN_OUT_BYTES, hipHostMallocDefault));
+    }
+    ctx->pinned = true;
+    return KYB_OK;
+}
+void par_memcpy(void* dst, const void* src, size_t bytes) {
+    constexpr size_t MIN_PART = size_t(1) << 20;
+    const int parts = (int)std::min<size_t>(4, bytes / MIN_PART);
+    if (parts <= 1) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t per = ((bytes / parts) + 63) & ~size_t(63);
+    std::thread th[3];
+    for (int t = 1; t < parts; t++) {
+        const size_t lo = per * t, hi = t == parts - 1 ? bytes : per * (t + 1);
+        th[t - 1] = std::thread([=] { memcpy((uint8_t*)dst + lo, (const uint8_t*)src + lo, hi - lo); });
+    }
+    memcpy(dst, src, per);
+    for (int t = 1; t < parts; t++) th[t - 1].join();
+}
 }  // namespace kyb
 
 extern "C" {

@@ -527,8 +527,8 @@ int kyb_ed25519_mul_base(size_t n, const uint8_t* scalars, uint8_t* out, uint32_
 // memory is pageable, and a copy straight from it is staged by the runtime at ~10 GB/s while it blocks the issuing
 // thread; instead host threads memcpy a chunk into a pinned slot (and results out of one) and the kernels work on the
 // slots in place, over PCIe.  (97 bytes per variable-base element: a quarter of the kernel's time at memcpy speed.)
-constexpr size_t PIPE_CHUNK_MAX = size_t(1) << 17;  // capacity of a staging slot, in elements
-constexpr int PIPE_SLOTS = 6, PIPE_STREAMS = 3;
+constexpr size_t PIPE_CHUNK_MAX = PIN_SLOT_ELEMS;  // capacity of a staging slot, in elements (context.h)
+constexpr int PIPE_SLOTS = DeviceCtx::NPIN, PIPE_STREAMS = 3;
 // Chunks of 2^17 elements alternate between two compute streams, so the tail of one chunk's kernel overlaps the head
 // of the next and the pipeline fills in the time one chunk takes to copy.  Same-box sweep at the C ABI, 2^20 elements,
 // fixed-base / variable-base ms (tools/gpu/r02_host5.sh): 1 stream x 2^18: 3.13 / 15.30; 1 x 2^17: 3.90 / 15.90;
@@ -550,25 +550,6 @@ static int pipe_nstreams() {
     return 2;
 }
 constexpr size_t SAME_BASE_TABLE_MIN = 16384;  // below this the table (4 544 short multiplications) does not pay
-
-// memcpy between the caller's pageable buffers and the page-locked slots, cut over a few threads: one core moves
-// ~10 GB/s, and for the fixed-base path (64 bytes per 1.5 us of kernel time) that copy is the whole critical path
-static void par_memcpy(void* dst, const void* src, size_t bytes) {
-    constexpr size_t MIN_PART = size_t(1) << 20;
-    const int parts = (int)std::min<size_t>(4, bytes / MIN_PART);
-    if (parts <= 1) {
-        memcpy(dst, src, bytes);
-        return;
-    }
-    const size_t per = ((bytes / parts) + 63) & ~size_t(63);
-    std::thread th[3];
-    for (int t = 1; t < parts; t++) {
-        const size_t lo = per * t, hi = t == parts - 1 ? bytes : per * (t + 1);
-        th[t - 1] = std::thread([=] { memcpy((uint8_t*)dst + lo, (const uint8_t*)src + lo, hi - lo); });
-    }
-    memcpy(dst, src, per);
-    for (int t = 1; t < parts; t++) th[t - 1].join();
-}
 
 static int pipe_streams(DeviceCtx* ctx) {
     for (int i = 0; i < PIPE_STREAMS; i++)
@@ -630,15 +611,7 @@ static int mul_host(size_t n, const uint8_t* scalars, const uint8_t* points, siz
     const bool per_point = !fixed && stride;
     const bool want_status = status && !fixed;
     // page-locked slots: [scalars | points] in, [points | status] out, one chunk each, PIPE_SLOTS of each
-    const size_t in_bytes = PIPE_CHUNK_MAX * 64, out_bytes = PIPE_CHUNK_MAX * 33;
-    if (ctx->pin_in_cap < in_bytes) {
-        for (int i = 0; i < PIPE_SLOTS; i++) KYB_HIP_CHECK(hipHostMalloc(&ctx->pin_in[i], PIPE_CHUNK_MAX * 64, hipHostMallocDefault));
-        ctx->pin_in_cap = PIPE_CHUNK_MAX * 64;
-    }
-    if (ctx->pin_out_cap < out_bytes) {
-        for (int i = 0; i < PIPE_SLOTS; i++) KYB_HIP_CHECK(hipHostMalloc(&ctx->pin_out[i], out_bytes, hipHostMallocDefault));
-        ctx->pin_out_cap = out_bytes;
-    }
+    if ((rc = ctx_pin_slots(ctx))) return rc;
     const size_t nchunks = (n + PIPE_CHUNK - 1) / PIPE_CHUNK;
     std::vector<hipEvent_t> ev_out(nchunks);
     for (size_t i = 0; i < nchunks; i++) KYB_HIP_CHECK(hipEventCreateWithFlags(&ev_out[i], hipEventDisableTiming));
