@@ -50,3 +50,15 @@ def test_tuned_kernels_keep_their_register_budget():
     # two waves per SIMD: <= 256
     assert find(msm, "13decode_kernel", "BlsG1Msm") <= 256
     assert find(msm, "17accumulate_kernel", "BlsG1Msm") <= 256
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-readelf")), reason="no llvm-readelf")
+def test_tower_machine_kernels_fit_three_waves_per_simd():
+    """The machine is one 12-wave workgroup per CU (it owns the CU's LDS): three waves per SIMD, i.e. at most 168
+    registers per lane.  The BLS12-381 interpreter sits right at that line (167): one register more and the workgroup
+    no longer launches with its 12 waves resident."""
+    for obj, name in (("bls12381_pair.o", "bls12381_tvm_kernel"), ("bn256_pair.o", "bn256_tvm_kernel"), ("bn254_pair.o", "bn254_tvm_kernel")):
+        regs = _kernel_regs(os.path.join(CSRC, obj))
+        tvm = {k: v for k, v in regs.items() if name in k}
+        assert len(tvm) == 2, (obj, list(regs))
+        assert all(v <= 168 for v in tvm.values()), tvm
