@@ -250,7 +250,8 @@ int kyb_bls12381_pair_check_dev(size_t n, const void *d_p1, const void *d_p2, co
  *   GT      : 384 bytes, 12 x 32, order x.x.x ... y.z.y (point.go:630-662)
  * UnmarshalBinary semantics kept: coordinates are reduced mod p (not rejected), (0,0) is
  * infinity, on-curve check only -- G2 inputs outside the order-n subgroup are accepted and
- * processed like the reference does.  status: KYB_ST_BAD_POINT, output zeroed. */
+ * processed like the reference does.  status: KYB_ST_BAD_POINT, output zeroed.
+ * flags: accepted and without effect, except on pair_check (below). */
 int kyb_bn256_g1_mul(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status, uint32_t flags);
 int kyb_bn256_g2_mul(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status, uint32_t flags);
 int kyb_bn256_g1_mul_same_base(size_t n, const uint8_t *scalars, const uint8_t point[64], uint8_t *out,
@@ -284,7 +285,10 @@ int kyb_bn256_hash_g1_dev(size_t n, const void *d_msgs, size_t msg_len, void *d_
  * like pointGT.UnmarshalBinary (point.go:664-716) coefficients are reduced mod p and nothing is rejected. */
 int kyb_bn256_gt_mul(size_t n, const uint8_t *scalars, const uint8_t *gt, uint8_t *out, uint8_t *status);
 int kyb_bn256_gt_mul_dev(size_t n, const void *d_scalars, const void *d_gt, void *d_out, void *d_status, void *stream);
-/* ok[i] = Pair(p1, p2).Equal(Pair(inv1, inv2)): Suite.ValidatePairing (suite.go:105-107). */
+/* ok[i] = Pair(p1, p2).Equal(Pair(inv1, inv2)): Suite.ValidatePairing (suite.go:105-107): two whole pairings and a
+ * comparison, like the reference.  With KYB_F_TRUSTED(1) | KYB_F_TRUSTED(3) -- the caller vouches that both G2
+ * operands lie in the order-n subgroup, which bn256's own UnmarshalBinary never checks -- the same predicate is
+ * evaluated as e(p1, p2) e(-inv1, inv2) == 1 with one final exponentiation (1.6x the rate). */
 int kyb_bn256_pair_check(size_t n, const uint8_t *p1, const uint8_t *p2, const uint8_t *inv1, const uint8_t *inv2,
                          uint8_t *ok, uint8_t *status, uint32_t flags);
 int kyb_bn256_pair_check_dev(size_t n, const void *d_p1, const void *d_p2, const void *d_inv1, const void *d_inv2,

@@ -7,4 +7,5 @@
 #define KYB_BN_VMNS bnvm
 #define KYB_BN_VM Bn256Vm
 #define KYB_BN_TVM(x) TVM_BN256_##x
+#define KYB_BN_HAS_CHECKP 1  // a product-form ValidatePairing program next to the literal one
 #include "bn_pair.inc"

@@ -51,7 +51,8 @@ def f2_muls(a, s): return (a[0] * s % P, a[1] * s % P)
 
 
 def f2_inv(a):
-    n = pow(a[0] * a[0] + a[1] * a[1], -1, P)
+    # gfP2.Invert (gfp2.go:146-161) over gfP.Invert = f^(p-2) (gfp.go): the inverse of zero is zero, not an error
+    n = pow(a[0] * a[0] + a[1] * a[1], P - 2, P)
     return (a[0] * n % P, -a[1] * n % P)
 
 

@@ -207,3 +207,34 @@ def test_batch_unmarshal(bn):
     for i in (0, 1, 2, 3, 5):
         assert bytes(out[i]) == batch[i]
     assert not out[4].any()
+
+
+def test_validate_pairing_product_form_under_trusted_g2(bn):
+    """KYB_F_TRUSTED on both G2 operands selects the product-form program (one final exponentiation): same booleans as
+    the reference's two pairings + Equal, on valid, forged and infinity rows."""
+    n = 1500
+    a, b = _scalars(b"bn/pf/a", n), _scalars(b"bn/pf/b", n)
+    ab = np.empty_like(a)
+    for i in range(n):
+        v = int.from_bytes(bytes(a[i]), "big") * int.from_bytes(bytes(b[i]), "big") % O.ORDER
+        ab[i] = np.frombuffer(_fp(v), dtype=np.uint8)
+    aP, _ = bn.g1_commit(a)
+    abP, _ = bn.g1_commit(ab)
+    bQ, _ = bn.g2_commit(b)
+    G2 = np.tile(np.frombuffer(bn.G2_BASE, dtype=np.uint8), (n, 1))
+    forged = np.array(abP, copy=True)
+    forged[::7] = aP[::7]
+    p1, inv1 = np.array(aP, copy=True), forged
+    p2, inv2 = np.array(bQ, copy=True), np.array(G2, copy=True)
+    p1[5] = 0          # e(inf, Q) == e(abP, G2) is false
+    p1[6] = 0
+    inv1[6] = 0        # 1 == 1
+    inv2[12] = 0       # e(aP, bQ) == e(., inf) = 1 is false
+    ok0, st0 = bn.batch_validate_pairing(p1, p2, inv1, inv2)
+    ok1, st1 = bn.batch_validate_pairing(p1, p2, inv1, inv2, bn.F_TRUSTED(1) | bn.F_TRUSTED(3))
+    ok2, st2 = bn.batch_validate_pairing(p1, p2, inv1, inv2, bn.F_TRUSTED_ALL)
+    assert not st0.any() and not st1.any() and not st2.any()
+    exp = np.ones(n, dtype=np.uint8)
+    exp[::7] = 0
+    exp[5], exp[6], exp[12] = 0, 1, 0
+    assert (np.asarray(ok0) == exp).all() and (np.asarray(ok1) == exp).all() and (np.asarray(ok2) == exp).all()

@@ -154,3 +154,41 @@ def test_bn_check_programs_and_bounds(bn_case):
         col, val = prog.check_bounds()
         assert col < 63 and val < 1024
     assert pair.f.W == (27 if ON.__name__.endswith("bn254") else 28)
+
+
+def test_bn256_product_form_check_and_degenerate_g2_points():
+    """bn256 keeps the reference's two pairings + Equal by default and takes the product form when the caller vouches
+    for both G2 operands; same truth table.  And Pair on the G2 inputs bn256 alone accepts -- twist points of small
+    order (the cofactor 2p - n has the factors 13 and 7369) and subgroup points with such a component -- equals the
+    reference's formulas (oracle), zero Miller values included."""
+    from oracle import bn256 as ON
+
+    check = G.build_bn256_check_product()
+    f = check.f
+    p1, q1 = ON.g1_mul(5, ON.G1_GEN), ON.g2_mul(7, ON.G2_GEN)
+
+    def run(p2, q2, flags=0):
+        ins = _inputs(f, p1, q1) + (_inputs(f, ON.g1_neg(p2), q2) if p2 else [0] * 6)
+        return not check.simulate(ins, flags)[1]["not_one"]
+
+    assert run(ON.g1_mul(35, ON.G1_GEN), ON.G2_GEN) and run(ON.g1_mul(7, ON.G1_GEN), ON.g2_mul(5, ON.G2_GEN))
+    assert not run(ON.g1_mul(36, ON.G1_GEN), ON.G2_GEN) and not run(None, None, flags=2)
+    col, val = check.check_bounds()
+    assert col < 63 and val < 1024
+    pair = G.build_bn256_pair()
+    h = 2 * ON.P - ON.ORDER
+    assert h % 13 == 0 and h % 7369 == 0
+    rng = random.Random(5)
+    while True:
+        x = (rng.randrange(ON.P), rng.randrange(ON.P))
+        y = ON.f2_sqrt(ON.f2_add(ON.f2_mul(ON.f2_sqr(x), x), ON.TWIST_B))
+        if y is not None:
+            break
+    p = ON.g1_mul(5, ON.G1_GEN)
+    for q in (13, 7369):
+        small = ON.g2_mul(ON.ORDER * h // q, (x, y))
+        if small is None:
+            continue
+        for Q in (small, ON.g2_add(ON.g2_mul(7, ON.G2_GEN), small)):
+            _, res = pair.simulate(_inputs(f, p, Q))
+            assert _bn_gt_bytes(res) == ON.gt_marshal(ON.pair(p, Q)), q
