@@ -251,7 +251,9 @@ int kyb_bls12381_pair_check_dev(size_t n, const void *d_p1, const void *d_p2, co
  * UnmarshalBinary semantics kept: coordinates are reduced mod p (not rejected), (0,0) is
  * infinity, on-curve check only -- G2 inputs outside the order-n subgroup are accepted and
  * processed like the reference does.  status: KYB_ST_BAD_POINT, output zeroed.
- * flags: accepted and without effect, except on pair_check (below). */
+ * flags: KYB_F_TRUSTED(i) on a G2 operand is the caller's word that the point lies in the order-n subgroup (which this
+ * suite's UnmarshalBinary never checks): g2_mul then walks a GLS decomposition and pair_check (below) the product form;
+ * a vouched-for point outside the subgroup gives a result the reference could not.  Otherwise flags have no effect. */
 int kyb_bn256_g1_mul(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status, uint32_t flags);
 int kyb_bn256_g2_mul(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status, uint32_t flags);
 int kyb_bn256_g1_mul_same_base(size_t n, const uint8_t *scalars, const uint8_t point[64], uint8_t *out,

@@ -100,6 +100,7 @@ int hh_bn_g1_unmarshal(const uint8_t* in, uint8_t* out) { return bn::g1_unmarsha
 int hh_bn_g2_unmarshal(const uint8_t* in, uint8_t* out) { return bn::g2_unmarshal_wire(out, in); }
 int hh_bn_g1_mul(const uint8_t* k, const uint8_t* pt, uint8_t* out) { return bn::g1_mul_wire(out, k, pt); }
 int hh_bn_g2_mul(const uint8_t* k, const uint8_t* pt, uint8_t* out) { return bn::g2_mul_wire(out, k, pt); }
+int hh_bn_g2_mul_f(const uint8_t* k, const uint8_t* pt, int flags, uint8_t* out) { return bn::g2_mul_wire(out, k, pt, (uint32_t)flags); }
 // Fp12 operations on GT-encoded operands (384 bytes): the shared tower code at bn256's parameters (two lazy levels)
 int hh_bn_fp12_op(int op, const uint8_t* a384, const uint8_t* b384, uint8_t* out384) {
     bn::fp12 a, b, r;

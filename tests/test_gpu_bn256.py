@@ -238,3 +238,18 @@ def test_validate_pairing_product_form_under_trusted_g2(bn):
     exp[::7] = 0
     exp[5], exp[6], exp[12] = 0, 1, 0
     assert (np.asarray(ok0) == exp).all() and (np.asarray(ok1) == exp).all() and (np.asarray(ok2) == exp).all()
+
+
+def test_g2_mul_gls_under_trusted_flag(bn):
+    """bn256 G2: plain ladder by default (unchecked inputs), GLS when the caller vouches for the subgroup: same bytes."""
+    n = 2000
+    k = _scalars(b"bn/gls/k", n)
+    k[0] = 0
+    k[1] = np.frombuffer(_fp(O.ORDER), dtype=np.uint8)
+    k[2] = 0xFF
+    Q, _ = bn.g2_commit(_scalars(b"bn/gls/q", n))
+    a, st = bn.g2_batch_mul(k, Q)
+    b, st2 = bn.g2_batch_mul(k, Q, bn.F_TRUSTED(0))
+    assert not st.any() and not st2.any() and (np.asarray(a) == np.asarray(b)).all()
+    for i in (0, 1, 2, 3, n - 1):
+        assert bytes(b[i]) == O.g2_mul_bytes(bytes(k[i]), bytes(Q[i]))

@@ -163,3 +163,15 @@ def test_unmarshal_wire():
         xx += 1
     buf = O.g2_marshal((X, y2))
     assert H.call("hh_bn_g2_unmarshal", buf, out_sizes=(128,)) == (0, buf)
+
+
+def test_g2_gls_multiplication_for_vouched_points():
+    """bn256's G2 is unchecked, so the default is the reference's plain ladder; with KYB_F_TRUSTED the caller vouches for
+    the subgroup and the 4-dimensional GLS walk runs: same multiples on subgroup points."""
+    rng = random.Random(77)
+    lam = 6 * O.U * O.U
+    q = O.g2_mul(rng.randrange(1, O.ORDER), O.G2_GEN)
+    for k in [0, 1, 16, O.ORDER - 1, O.ORDER, (1 << 256) - 1, lam, lam - 1, lam * lam % O.ORDER] + [rng.getrandbits(256) for _ in range(6)]:
+        kb = k.to_bytes(32, "big")
+        assert H.call("hh_bn_g2_mul_f", kb, O.g2_marshal(q), 0x100, out_sizes=(128,)) == (0, O.g2_marshal(O.g2_mul(k, q))), k
+        assert H.call("hh_bn_g2_mul_f", kb, O.g2_marshal(q), 0, out_sizes=(128,)) == (0, O.g2_marshal(O.g2_mul(k, q))), k
