@@ -18,6 +18,8 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 def _kernel_regs(obj):
     """{demangled-ish kernel name: total VGPR allocation (arch + acc)} of one fat object file."""
+    if not os.path.exists(obj):
+        pytest.skip(os.path.basename(obj) + " not built (python -c 'import __graft_entry__ as g; g.build()')")
     with tempfile.TemporaryDirectory() as tmp:
         local = os.path.join(tmp, os.path.basename(obj))
         shutil.copy(obj, local)
@@ -60,5 +62,5 @@ def test_tower_machine_kernels_fit_three_waves_per_simd():
     for obj, name in (("bls12381_pair.o", "bls12381_tvm_kernel"), ("bn256_pair.o", "bn256_tvm_kernel"), ("bn254_pair.o", "bn254_tvm_kernel")):
         regs = _kernel_regs(os.path.join(CSRC, obj))
         tvm = {k: v for k, v in regs.items() if name in k}
-        assert len(tvm) == 2, (obj, list(regs))
+        assert len(tvm) >= 2, (obj, list(regs))  # Pair, ValidatePairing (bn256: + its product form)
         assert all(v <= 168 for v in tvm.values()), tvm
