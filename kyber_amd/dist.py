@@ -130,3 +130,19 @@ def bn256_g2_msm(scalars_shard, points_shard, group=None, flags: int = 0):
 
     return msm_allgather(scalars_shard, points_shard, lambda s, p: m.g2_msm(s, p, flags), m.G2_LEN, False, group,
                          combine_add=lambda a, b: m.ENGINE.add(2, a, b))
+
+
+def bn254_g1_msm(scalars_shard, points_shard, group=None, flags: int = 0):
+    """flags: the shard's input flags (F_TRUSTED(0), kyber_amd.pairing._engine)."""
+    from .pairing import bn254 as m
+
+    return msm_allgather(scalars_shard, points_shard, lambda s, p: m.g1_msm(s, p, flags), m.G1_LEN, False, group,
+                         combine_add=lambda a, b: m.ENGINE.add(1, a, b))
+
+
+def bn254_g2_msm(scalars_shard, points_shard, group=None, flags: int = 0):
+    """flags: the shard's input flags (F_TRUSTED(0): the points were unmarshalled, i.e. subgroup-checked, before)."""
+    from .pairing import bn254 as m
+
+    return msm_allgather(scalars_shard, points_shard, lambda s, p: m.g2_msm(s, p, flags), m.G2_LEN, False, group,
+                         combine_add=lambda a, b: m.ENGINE.add(2, a, b))
