@@ -66,6 +66,8 @@ def test_scalar_multiplication_and_strict_decoding():
     assert H.call("hh_bn4_g1_decode", _be(O.P) + _be(O.P))[0] == 1
     assert H.call("hh_bn4_g1_decode", _be(5) + _be(5))[0] == 1
     assert H.call("hh_bn4_g1_mul", _be(7), bytes(64), out_sizes=(64,)) == (0, bytes(64))
+    assert H.call("hh_bn4_g2_mul", _be(7), bytes(128), 0, out_sizes=(128,)) == (0, bytes(128))          # GLS walk on infinity
+    assert H.call("hh_bn4_g2_mul", _be(O.ORDER), g2, 0x100, out_sizes=(128,)) == (0, bytes(128))
     assert H.call("hh_bn4_g1_mul", _be(7), _be(x + O.P) + _be(y), out_sizes=(64,)) == (1, bytes(64))
     assert H.call("hh_bn4_g2_decode", bytes(128), 1)[0] == 0
     assert H.call("hh_bn4_g2_decode", _be(O.P) + g2[32:], 1)[0] == 1
