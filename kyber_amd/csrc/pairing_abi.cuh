@@ -5,6 +5,8 @@
 // include/kyber_hip.h.  Pair / ValidatePairing are NOT per-lane code: each suite's *_pair.hip supplies the `_dev`
 // entry points on the cooperative tower machine (tower_vm.cuh) and KYB_DEFINE_PAIR_HOST adds the host-buffer ones.
 #pragma once
+#include <string.h>
+
 #include "context.h"
 
 namespace kyb {
@@ -125,6 +127,20 @@ static int PFX##_mul_host(bool g2, size_t n, const uint8_t* scalars, const uint8
     KYB_TRY(p.upload(points, (stride ? n : 1) * isz)); \
     KYB_TRY(o.alloc(n * psz)); \
     KYB_TRY(st.alloc(n)); \
+    if (!stride && n > 1 && !(flags & KYB_F_TRUSTED(0))) { \
+        /* one shared base (PriPoly.Commit): UnmarshalBinary's checks run ONCE, not in every lane -- on BLS12-381 the \
+           subgroup test is half of a lane's work -- and the lanes take the point as validated */ \
+        KYB_TRY(g2 ? kyb_##PFX##_g2_unmarshal_dev(1, p.p, o.p, st.p, flags & ~KYB_F_UNCOMPRESSED_OUT, nullptr) \
+                   : kyb_##PFX##_g1_unmarshal_dev(1, p.p, o.p, st.p, flags & ~KYB_F_UNCOMPRESSED_OUT, nullptr)); \
+        uint8_t st0 = 0; \
+        KYB_HIP_CHECK(hipMemcpy(&st0, st.p, 1, hipMemcpyDeviceToHost)); \
+        if (st0) { \
+            memset(out, 0, n * psz); \
+            if (status) memset(status, st0, n); \
+            return KYB_OK; \
+        } \
+        flags |= KYB_F_TRUSTED(0); \
+    } \
     KYB_TRY(g2 ? kyb_##PFX##_g2_mul_dev(n, s.p, p.p, stride, o.p, st.p, flags, nullptr) \
                : kyb_##PFX##_g1_mul_dev(n, s.p, p.p, stride, o.p, st.p, flags, nullptr)); \
     KYB_TRY(o.download(out, n * psz)); \
