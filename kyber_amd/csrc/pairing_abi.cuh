@@ -21,9 +21,17 @@ static inline unsigned grid_for(size_t n, int block) { return (unsigned)((n + bl
         if (rc_) return rc_; \
     } while (0)
 
+// Register budget of the G1 / G2 multiplication kernels in waves per SIMD (a suite's translation unit may set it before
+// including this file): one wave unless measured otherwise at the suite's configured batch size.
+#ifndef KYB_G1_MUL_WAVES
+#define KYB_G1_MUL_WAVES 1
+#endif
+#ifndef KYB_G2_MUL_WAVES
+#define KYB_G2_MUL_WAVES 1
+#endif
 #define KYB_DEFINE_MUL_ABI(PFX, NS, G1SZ, G2SZ) \
 namespace kyb { \
-__global__ __launch_bounds__(64) void PFX##_g1_mul_kernel(size_t n, const uint8_t* __restrict__ scalars, \
+__global__ __launch_bounds__(64, KYB_G1_MUL_WAVES) void PFX##_g1_mul_kernel(size_t n, const uint8_t* __restrict__ scalars, \
                                                         const uint8_t* __restrict__ pts, size_t pt_stride, \
                                                         uint8_t* __restrict__ out, uint8_t* __restrict__ status, \
                                                         uint32_t flags) { \
@@ -32,7 +40,7 @@ __global__ __launch_bounds__(64) void PFX##_g1_mul_kernel(size_t n, const uint8_
     const int st = NS::g1_mul_wire(out + NS::g1_out_size(flags) * idx, scalars + 32 * idx, pts + pt_stride * idx, flags); \
     if (status) status[idx] = (uint8_t)st; \
 } \
-__global__ __launch_bounds__(64) void PFX##_g2_mul_kernel(size_t n, const uint8_t* __restrict__ scalars, \
+__global__ __launch_bounds__(64, KYB_G2_MUL_WAVES) void PFX##_g2_mul_kernel(size_t n, const uint8_t* __restrict__ scalars, \
                                                         const uint8_t* __restrict__ pts, size_t pt_stride, \
                                                         uint8_t* __restrict__ out, uint8_t* __restrict__ status, \
                                                         uint32_t flags) { \
