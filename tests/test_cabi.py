@@ -211,3 +211,29 @@ def test_go_suite_implements_every_method_of_the_kyber_interfaces():
         assert iface(g, "Group") == _GROUP
         assert iface(open(os.path.join(ref, "encoding.go")).read(), "Marshaling") == ["String", "MarshalSize", "MarshalTo", "UnmarshalFrom"]
         assert iface(open(os.path.join(ref, "pairing", "pairing.go")).read(), "Suite") == ["G1", "G2", "GT", "Pair", "ValidatePairing"]
+
+
+def test_go_packages_reference_only_what_package_hip_defines():
+    """No Go toolchain here: at least every `hip.X` the suite / benchmark packages use must be a function, constant or
+    type of go/kyberhip (package hip), and braces / parentheses must balance outside strings and comments."""
+    import glob
+    import re
+
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "go", "kyberhip")
+    defs = set()
+    for f in glob.glob(os.path.join(root, "*.go")):
+        src = open(f).read()
+        defs |= set(re.findall(r"^func (\w+)\(", src, re.M))
+        defs |= set(re.findall(r"^(?:const|var|type) (\w+)", src, re.M))
+        for blk in re.findall(r"(?:const|var) \((.*?)\n\)", src, re.S):
+            defs |= set(re.findall(r"^\t(\w+)", blk, re.M))
+    used = set()
+    files = glob.glob(os.path.join(root, "**", "*.go"), recursive=True)
+    assert len(files) >= 7
+    for f in files:
+        src = open(f).read()
+        code = re.sub(r'"(?:[^"\\]|\\.)*"|`[^`]*`|//[^\n]*', "", src)
+        assert code.count("{") == code.count("}") and code.count("(") == code.count(")"), f
+        if os.path.dirname(f) != root:
+            used |= set(re.findall(r"\bhip\.(\w+)", code))
+    assert used and not (used - defs), sorted(used - defs)
