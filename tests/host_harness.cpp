@@ -116,6 +116,12 @@ int hh_bn_fp12_op(int op, const uint8_t* a384, const uint8_t* b384, uint8_t* out
 int hh_bn_gt_mul(const uint8_t* k, const uint8_t* gt, uint8_t* out) { return bn::gt_mul_wire(out, k, gt); }
 int hh_bls_gt_mul(const uint8_t* k, const uint8_t* gt, uint8_t* out) { return bls::gt_mul_wire(out, k, gt); }
 int hh_bn_hash_g1(const uint8_t* msg, int len, uint8_t* out) { return bn::hash_g1_wire(out, msg, (size_t)len); }
+void hh_bn4_fp_inv(const uint8_t* a32, uint8_t* out32) {
+    bn4::fp a, r;
+    bn4::fp_decode(a, a32);
+    fp_inv(r, a);
+    bn4::fp_encode(out32, r);
+}
 // bn254: the same library at alt_bn128's constants with the strict decoding rules, and its Keccak / SvdW hash
 int hh_bn4_g1_decode(const uint8_t* in) { bn4::g1_aff a; return bn4::g1_decode(a, in); }
 int hh_bn4_g2_decode(const uint8_t* in, int check) { bn4::g2_aff a; return bn4::g2_decode(a, in, check != 0); }

@@ -108,3 +108,27 @@ def test_gt_exponentiation_and_tower():
         for b in cases:
             assert H.call("hh_bn4_fp12_op", 0, ab, O.gt_marshal(b), out_sizes=(384,)) == (0, O.gt_marshal(O.f12_mul(a, b)))
         assert H.call("hh_bn4_fp12_op", 1, ab, ab, out_sizes=(384,)) == (0, O.gt_marshal(O.f12_sqr(a)))
+
+
+def test_field_inversion_by_division_steps():
+    """fp_inv (mont.cuh: Bernstein-Yang division steps, thirty per batch): zero, one, p - 1, powers of two, values whose
+    (f, g) walk is long or short, random values -- on the three fields, against pow(a, -1, p)."""
+    from oracle import bls12381 as OB, bn256 as ON
+
+    rng = random.Random(99)
+
+    def cases(p, nbytes):
+        vals = [0, 1, 2, 3, p - 1, p - 2, (p + 1) // 2, (p - 1) // 2, (1 << 30) - 1, 1 << 30, (1 << 60) + 1, (1 << 255) % p]
+        vals += [(1 << k) % p for k in range(0, 8 * nbytes, 29)] + [p - ((1 << k) % p) for k in range(1, 8 * nbytes, 31)]
+        vals += [rng.randrange(p) for _ in range(200)] + [rng.randrange(1 << 64) for _ in range(20)]
+        return vals
+
+    for a in cases(O.P, 32):
+        exp = pow(a, -1, O.P) if a % O.P else 0
+        assert H.call("hh_bn4_fp_inv", _be(a), out_sizes=(32,))[1] == _be(exp), a
+    for a in cases(ON.P, 32):
+        exp = pow(a, -1, ON.P) if a % ON.P else 0
+        assert H.call("hh_bn_fp_op", 4, _be(a), _be(0), out_sizes=(32,))[1] == _be(exp), a
+    for a in cases(OB.P, 48):
+        exp = pow(a, -1, OB.P) if a % OB.P else 0
+        assert H.call("hh_bls_fp_op", 4, a.to_bytes(48, "big"), bytes(48), out_sizes=(48,))[1] == exp.to_bytes(48, "big"), a
