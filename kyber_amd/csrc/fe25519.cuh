@@ -114,11 +114,10 @@ KYB_DEV void fe_cswap(fe& f, fe& g, bool b) {
 // column as exactly 2^24 on top of the carry -- one 64-bit add less per pair of columns.
 KYB_DEV constexpr int64_t fe_bias(int i) { return (i & 1) ? 0 : ((int64_t)1 << 25) + ((int64_t)1 << 50); }
 
-// The compiler reassociates bias + a0 b0 + a1 b1 + ... so that the constant is added last, as a separate 64-bit
-// add.  An empty asm after the first product pins (bias + a0 b0) as one value -- one v_mad_i64_i32 with the bias (a
-// scalar-register pair) as its addend -- and emits nothing itself, so it cannot change a result.  Used on the even
-// columns only, the ones that are handed a bias (window loop of ed25519_mul_kernel: 5 480 -> 5 357 instructions, 7
-// reloads of spilled loop invariants per window instead of 3).
+// The compiler reassociates bias + a0 b0 + a1 b1 + ... so that the constant (or a carry that arrives late) is added
+// last, as a separate 64-bit add, and splits a long column into two partial sums.  An empty asm after a product pins
+// the running sum as one value -- one v_mad_i64_i32 with the previous sum as its addend -- and emits nothing itself,
+// so it cannot change a result.  fe_chain_store below says what that is worth.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define KYB_PIN64(x) asm("" : "+v"(x))
 #else
@@ -163,6 +162,39 @@ KYB_DEV void fe_carry_store(fe& h, int64_t T[10]) {
     for (int i = 0; i < 10; i++) h.v[i] = r[i];
 }
 
+// The same chain with the columns computed INSIDE it: col(k, addend) returns addend + (the ten products of column k).
+// An odd column takes the carry out of the even column below it as that addend -- the first v_mad_i64_i32 of the
+// column adds it for nothing, where fe_carry_store spends a 64-bit add (an odd column has no bias of its own: it
+// arrives inside the carry, fe_bias above); even columns keep their bias as the addend and add the carry afterwards.
+// The callers pin the accumulator after EVERY product (KYB_PIN64): left alone, the compiler splits each column into
+// two partial sums to shorten the dependency chain and joins them with a 64-bit add, and moves the carry to the end
+// of the column as another one -- 17 v_lshl_add_u64 per multiplication where this form has 4.  Every 3-operand VALU
+// instruction costs what a multiply-add costs (4.6-5.2 cycles per wave64 instruction against 2.6-2.9 for a 2-operand
+// 32-bit one: tools/valu_rates.hip, profiles/r02_valu_rates.jsonl), so the 13 adds are worth 13 products; the serial
+// chain costs an s_nop between back-to-back dependent multiply-adds, which the other two waves of the SIMD fill.
+// Window loop of ed25519_mul_kernel 5 376 -> 5 146 VALU instructions (v_lshl_add_u64 404 -> 185, scratch 920 -> 572 B);
+// 2^20 variable-base scalar multiplications 11.85 -> 11.10 ms on the same box.  Same limbs as fe_carry_store.
+template <class ColF>
+KYB_DEV void fe_chain_store(fe& h, ColF col) {
+    int32_t r[10];
+    const int64_t T0 = col(0, fe_bias(0));
+    int64_t c = T0 >> 26;
+    const uint32_t b0 = KYB_LOW(T0, 26);
+#pragma unroll
+    for (int k = 1; k < 10; k++) {
+        const int w = (k & 1) ? 25 : 26;
+        const int64_t T = (k & 1) ? col(k, c) : col(k, fe_bias(k)) + c;
+        c = T >> w;
+        r[k] = (int32_t)KYB_LOW(T, w) - (1 << (w - 1));
+    }
+    const int64_t t0 = (int64_t)b0 + c * 19;
+    c = t0 >> 26;
+    r[0] = (int32_t)KYB_LOW(t0, 26) - (1 << 25);
+    r[1] += (int32_t)c;
+#pragma unroll
+    for (int i = 0; i < 10; i++) h.v[i] = r[i];
+}
+
 // h = f * g
 KYB_DEV void fe_mul(fe& h, const fe& f, const fe& g) {
     KYB_FE_NOTE(KYB_FE_MAG(f), KYB_FE_MAG(g), 1.0);
@@ -172,23 +204,19 @@ KYB_DEV void fe_mul(fe& h, const fe& f, const fe& g) {
         g19[i] = 19 * g.v[i];
         f2[i] = 2 * f.v[i];
     }
-    int64_t t[10];
-#pragma unroll
-    for (int k = 0; k < 10; k++) {
-        int64_t acc = fe_bias(k);
+    fe_chain_store(h, [&](int k, int64_t acc) {
 #pragma unroll
         for (int i = 0; i < 10; i++) {
             const int j = (k - i + 10) % 10;
-            const bool wrap = i > k;                    // i + j == k + 10
-            const bool both_odd = (i & 1) && (j & 1);   // 2^25.5 radix: odd*odd carries a factor 2
+            const bool wrap = i > k;
+            const bool both_odd = (i & 1) && (j & 1);
             const int32_t a = both_odd ? f2[i] : f.v[i];
             const int32_t b = wrap ? g19[j] : g.v[j];
             acc += (int64_t)a * (int64_t)b;
-            if (i == 0 && !(k & 1)) KYB_PIN64(acc);
+            KYB_PIN64(acc);
         }
-        t[k] = acc;
-    }
-    fe_carry_store(h, t);
+        return acc;
+    });
     KYB_FE_MAG_SET(h, 1.01);
 }
 
@@ -201,34 +229,23 @@ KYB_DEV void fe_sq_t(fe& h, const fe& f) {
     for (int i = 0; i < 10; i++) {
         f2[i] = 2 * f.v[i];
         f19[i] = 19 * f.v[i];
-        f38[i] = 38 * f.v[i];
+        f38[i] = 2 * f19[i];
     }
-    int64_t t[10];
-#pragma unroll
-    for (int k = 0; k < 10; k++) {
-        int64_t acc = DBL ? 0 : fe_bias(k);  // 2 acc + bias is one shift-add
+    fe_chain_store(h, [&](int k, int64_t addend) {
+        int64_t acc = DBL ? 0 : addend;
 #pragma unroll
         for (int i = 0; i < 10; i++) {
             const int j = (k - i + 10) % 10;
             if (i > j) continue;
             const bool wrap = (i + j) >= 10;
             const bool both_odd = (i & 1) && (j & 1);
-            // total coefficient = (i==j ? 1 : 2) * (both_odd ? 2 : 1) * (wrap ? 19 : 1)
-            // split as  a-side in {1,2}  x  b-side in {1,2,19,38}
-            int32_t a, b;
-            if (i == j) {
-                a = f.v[i];
-                b = wrap ? (both_odd ? f38[j] : f19[j]) : (both_odd ? f2[j] : f.v[j]);
-            } else {
-                a = f2[i];
-                b = wrap ? (both_odd ? f38[j] : f19[j]) : (both_odd ? f2[j] : f.v[j]);
-            }
+            const int32_t a = i == j ? f.v[i] : f2[i];
+            const int32_t b = wrap ? (both_odd ? f38[j] : f19[j]) : (both_odd ? f2[j] : f.v[j]);
             acc += (int64_t)a * (int64_t)b;
-            if (!DBL && i == 0 && !(k & 1)) KYB_PIN64(acc);
+            KYB_PIN64(acc);
         }
-        t[k] = DBL ? (acc + acc) + fe_bias(k) : acc;
-    }
-    fe_carry_store(h, t);
+        return DBL ? (acc + acc) + addend : acc;
+    });
     KYB_FE_MAG_SET(h, 1.01);
 }
 // h = (dbl ? 2 : 1) * f^2 with a per-lane choice (the cooperative doubling of the MSM tail squares X, Y, X + Y and
@@ -241,7 +258,7 @@ KYB_DEV void fe_sq_sel(fe& h, const fe& f, bool dbl) {
     for (int i = 0; i < 10; i++) {
         f2[i] = 2 * g.v[i];
         f19[i] = 19 * g.v[i];
-        f38[i] = 38 * g.v[i];
+        f38[i] = 2 * f19[i];
     }
     int64_t t[10];
 #pragma unroll
