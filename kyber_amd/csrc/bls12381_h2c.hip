@@ -111,14 +111,21 @@ int kyb_bls12381_verify_g1_dev(size_t n, const void* d_pks, const void* d_msgs, 
     KYB_TRY(get_ctx(&ctx));
     std::lock_guard<std::recursive_mutex> enq_lock(ctx->enq_mu);
     blsvm::Work w;
-    KYB_TRY(blsvm::workspace(ctx, (hipStream_t)stream, n, blsvm::CHECK_INPUTS, &w));
     // signatures on G1, keys on G2:  e(H(m), X) e(-sig, G2.Base()) == 1   (status precedence: key, then signature)
     const blsvm::Operand ops[4] = {{(const uint8_t*)d_msgs, blsvm::OPND_G1_HASH, (uint32_t)msg_len, 0, 0, 0},
                                    {(const uint8_t*)d_pks, blsvm::OPND_G2, (uint32_t)bls::g2_wire_size(flags), 2, 0, 0},
                                    {(const uint8_t*)d_sigs, blsvm::OPND_G1, (uint32_t)bls::g1_wire_size(flags), 6, 1, 1},
                                    {nullptr, blsvm::OPND_G2_GEN, 0, 8, 0, 0}};
+#ifdef KYB_BLS_VERIFY_GENERAL  // A/B: the general product check with the generator as an ordinary operand
+    KYB_TRY(blsvm::workspace(ctx, (hipStream_t)stream, n, blsvm::CHECK_INPUTS, &w));
     KYB_TRY(blsvm::launch_prep(w, n, ops, 4, flags, dst, dst_len, (hipStream_t)stream));
     return blsvm::launch_check(w, n, (uint8_t*)d_ok, (uint8_t*)d_status, (hipStream_t)stream);
+#else
+    // the generator's Miller lines are constants of the VERIFY program: three operands, two thirds of the line work
+    KYB_TRY(blsvm::workspace(ctx, (hipStream_t)stream, n, blsvm::VERIFY_INPUTS, &w));
+    KYB_TRY(blsvm::launch_prep(w, n, ops, 3, flags, dst, dst_len, (hipStream_t)stream));
+    return blsvm::launch_verify(w, n, (uint8_t*)d_ok, (uint8_t*)d_status, (hipStream_t)stream);
+#endif
 }
 int kyb_bls12381_verify_g1(size_t n, const uint8_t* pks, const uint8_t* msgs, size_t msg_len, const uint8_t* dst,
                            size_t dst_len, const uint8_t* sigs, uint8_t* ok, uint8_t* status, uint32_t flags) {

@@ -44,5 +44,9 @@ int workspace(DeviceCtx* ctx, hipStream_t st, size_t n, int ninputs, Work* w);
 int launch_pair(const Work& w, size_t n, uint8_t* d_gt, uint8_t* d_status, hipStream_t st);
 // Enqueue the CHECK program: one boolean per pairing.
 int launch_check(const Work& w, size_t n, uint8_t* d_ok, uint8_t* d_status, hipStream_t st);
+// Enqueue the VERIFY program: CHECK whose second G2 operand is the generator (its Miller lines are a table of
+// constants); operands 0, 1 = pair A (G1, G2), operand 2 = pair B's G1 point (negated), inputs 0-7.
+constexpr int VERIFY_INPUTS = 8;
+int launch_verify(const Work& w, size_t n, uint8_t* d_ok, uint8_t* d_status, hipStream_t st);
 }  // namespace blsvm
 }  // namespace kyb

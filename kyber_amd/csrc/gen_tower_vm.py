@@ -27,7 +27,7 @@ WAVES = 12
 W = 28  # default limb width; a field may choose a narrower one (VmField.W)
 REC_WORDS = 64
 OP_DOT, OP_IDLE, OP_GLOAD, OP_INV, OP_GT_STORE, OP_IS_ONE, OP_CLOAD, OP_SPILL, OP_FILL, OP_CMP_EQ = range(10)
-K_PROD, K_LIN, K_PROD_CONST = 0, 1, 2
+K_PROD, K_LIN, K_PROD_CONST, K_PROD_GCONST = 0, 1, 2, 3
 
 
 # ------------------------------------------------------------------------------------------------ field
@@ -166,6 +166,22 @@ class Acc2:
                 lst.append(("c", x, c))
         return self
 
+    def prod_gconst(self, a, g):
+        """+= a * G with G = (gre, gim) an Fp2 entry of the program's TABLE in global memory: each part is (base, stride),
+        the table index being base + stride * (repetition of the enclosing block) -- the constants of a loop body that
+        change from one pass to the next (the lines of a fixed point, Prog.gconsts)"""
+        gre, gim = g
+        for lst, x, c in ((self.re, a.re, gre), (self.re, -a.im, gim), (self.im, a.re, gim), (self.im, a.im, gre)):
+            if not x.is_zero():
+                lst.append(("g", x, c))
+        return self
+
+    def gconst_fp(self, g, b):
+        """+= G * b with b a base-field operand (Lin)"""
+        self.re.append(("g", b, g[0]))
+        self.im.append(("g", b, g[1]))
+        return self
+
     def lin(self, a):
         if not a.re.is_zero():
             self.re.append(("l", a.re))
@@ -191,6 +207,7 @@ class Prog:
         self.ins = []      # instruction = list of WAVES records (dict)
         self.names = []
         self.consts = []   # stored values (ints in [0, p))
+        self.gconsts = []  # the table of per-repetition constants (stored values), read from global memory
         self.sched = []    # (start, len, repeat)
         self._open = None
         self.c_zero = self.const(0)
@@ -208,6 +225,12 @@ class Prog:
         """constant holding the field element x (Montgomery form), as (index, stored) for Acc2.prod_const"""
         s = x % self.f.p * self.f.R % self.f.p
         return None if s == 0 else (self.const(s), s)
+
+    def gtable(self, elements):
+        """appends field elements (Montgomery form is applied here) to the table; returns the index of the first"""
+        base = len(self.gconsts)
+        self.gconsts += [x % self.f.p * self.f.R % self.f.p for x in elements]
+        return base
 
     # --- schedule
     class _Rep:
@@ -300,6 +323,8 @@ class Prog:
         for o in outs:
             assert 0 <= o.dst < self.nslots
             for t in o.terms:
+                if t[0] == "g":
+                    assert 0 <= t[2][0] < 4096 and 0 <= t[2][1] < 256
                 for lin in (t[1:3] if t[0] == "p" else t[1:2]):
                     assert 1 <= len(lin.d) <= 2, (name, lin)
                     assert all(0 <= s < self.nslots and -128 <= c <= 127 for s, c in lin.d.items()), (name, lin)
@@ -322,7 +347,7 @@ class Prog:
         G = {}
         res = {"gt": {}, "not_one": False}
         for start, ln, rep in self.sched:
-            for _ in range(rep):
+            for it in range(rep):
                 for ins in self.ins[start:start + ln]:
                     new = {}
                     for w, r in enumerate(ins):
@@ -336,6 +361,8 @@ class Prog:
                                     acc += x * y * (1 if r["raw"] else Rinv)
                                 elif t[0] == "c":
                                     acc += x * t[2][1] * Rinv
+                                elif t[0] == "g":
+                                    acc += x * self.gconsts[t[2][0] + it * t[2][1]] * Rinv
                                 else:
                                     acc += x
                             v = acc * r["scale"] % p
@@ -409,7 +436,7 @@ class Prog:
         G = {}
         res = {"gt": {}, "not_one": False}
         for start, ln, rep in self.sched:
-            for _ in range(rep):
+            for it in range(rep):
                 for ins in self.ins[start:start + ln]:
                     new = {}
                     for w, r in enumerate(ins):
@@ -422,7 +449,12 @@ class Prog:
                                     for i in range(N):
                                         t[N + i] += x[i]
                                 else:
-                                    y = operand(term[2]) if term[0] == "p" else f.balanced(term[2][1])
+                                    if term[0] == "p":
+                                        y = operand(term[2])
+                                    elif term[0] == "g":
+                                        y = f.balanced(self.gconsts[term[2][0] + it * term[2][1]])
+                                    else:
+                                        y = f.balanced(term[2][1])
                                     for i in range(N):
                                         for j in range(N):
                                             t[i + j] += x[i] * y[j]
@@ -586,6 +618,9 @@ class Prog:
                             ci = t[2][0]
                             cy1 = cy2 = 0
                             w0 = x1 | (x2 << 6) | ((ci & 0xfff) << 12) | (K_PROD_CONST << 24)
+                        elif t[0] == "g":  # table index = base (12 bits of w0) + stride (the cy1 byte) * repetition
+                            cy1, cy2 = t[2][1], 0
+                            w0 = x1 | (x2 << 6) | ((t[2][0] & 0xfff) << 12) | (K_PROD_GCONST << 24)
                         else:
                             cy1 = cy2 = 0
                             w0 = x1 | (x2 << 6) | (K_LIN << 24)
@@ -613,8 +648,10 @@ class Prog:
                     prog.extend(blobs[b])
             sched.append((placed[key], ln, rep))
         merged = []
-        for s in sched:  # consecutive repeats of one block
-            if merged and merged[-1][0] == s[0] and merged[-1][1] == s[1]:
+        has_g = [any(t[0] == "g" for r in ins if r["op"] == OP_DOT for t in r["terms"]) for ins in self.ins]
+        gblock = [any(has_g[start:start + ln]) for start, ln, rep in self.sched]
+        for k, s in enumerate(sched):  # consecutive repeats of one block (a table index restarts with its block)
+            if merged and merged[-1][0] == s[0] and merged[-1][1] == s[1] and not gblock[k]:
                 merged[-1] = (s[0], s[1], merged[-1][2] + s[2])
             else:
                 merged.append(s)
@@ -708,10 +745,11 @@ class Tower:
             acc = Acc2()
             for j, l in ls.items():
                 i = k - j
-                if i >= 0:
-                    acc.prod(a[i], l)
+                x = a[i] if i >= 0 else a[i + 6].mul_xi(self.xi0)
+                if isinstance(l, tuple):  # a coefficient held in the program's table: ((re base, stride), (im base, stride))
+                    acc.prod_gconst(x, l)
                 else:
-                    acc.prod(a[i + 6].mul_xi(self.xi0), l)
+                    acc.prod(x, l)
             outs += outs2(dst + 2 * k, dst + 2 * k + 1, acc, mask=mask)
         self.P.dot(outs, name)
 
@@ -938,6 +976,50 @@ def bls_add_step(P, T, TX, TY, TZ, Q, tmp, L, PX, PY, fset, mask):
     T.mul_sparse(fset, f, {0: E2.slots(L[0], L[1]), 2: E2.slots(L[2], L[3]), 3: E2.slots(L[4], L[5])}, mask=mask, name="add/line")
 
 
+# --- the Miller loop of a FIXED point Q (the G2 generator of bls.Verify): T's walk does not depend on the input, so
+# the three line coefficients of every step are constants.  Per step the table holds l0 (Fp2) and the factors of xP and
+# yP in l2, l3 (Fp2 each): six field elements, in the order the loop visits the steps (doubling, then the addition where
+# the parameter has a one).  The values follow bls_dbl_step / bls_add_step formula for formula (same scale factors), so
+# the fixed loop multiplies exactly the lines the general loop would.
+BLS_G2_GEN = ((0x024AA2B2F08F0A91260805272DC51051C6E47AD4FA403B02B4510B647AE3D1770BAC0326A805BBEFD48056C8C121BDB8,
+               0x13E02B6052719F607DACD3A088274F65596BD0D09920B61AB5DA61BBDC7F5049334CF11213945D57E5AC7D055D042B7E),
+              (0x0CE5D527727D6E118CC9CDC6DA2E351AADFD9BAA8CBDD3A76D429A695160D12C923AC9CC3BACA289E193548608B82801,
+               0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE))
+
+
+def bls_fixed_line_table(p, Q):
+    """[(l0, c2, c3)] per Miller step (Fp2 pairs of ints): line = l0 + (c2 xP) w^2 + (c3 yP) w^3"""
+    def mul(a, b): return _f2_mul(a, b, p)
+    def add(a, b): return ((a[0] + b[0]) % p, (a[1] + b[1]) % p)
+    def sub(a, b): return ((a[0] - b[0]) % p, (a[1] - b[1]) % p)
+    def sc(a, c): return (a[0] * c % p, a[1] * c % p)
+    xQ, yQ = Q
+    assert sub(mul(yQ, yQ), mul(mul(xQ, xQ), xQ)) == (4, 4), "Q is not on the twist y^2 = x^3 + 4 xi"
+    X, Y, Z = xQ, yQ, (1, 0)
+    out = []
+    for b in bin(BLS_X_ABS)[3:]:
+        XY, B, YZ, A3 = mul(X, Y), mul(Y, Y), mul(Y, Z), sc(mul(X, X), 3)
+        E = sc(mul(mul(Z, Z), (1, 1)), 12)  # 3 b' Z^2, b' = 4 xi
+        out.append((sub(B, E), sc(A3, -1), sc(YZ, 2)))
+        X, Y, Z = mul(sc(XY, 2), sub(B, sc(E, 3))), add(mul(B, B), mul(sc(E, 3), sub(sc(B, 2), E))), sc(mul(B, YZ), 8)
+        if b == "1":
+            TH, LA = sub(Y, mul(yQ, Z)), sub(X, mul(xQ, Z))
+            out.append((sub(mul(TH, xQ), mul(LA, yQ)), sc(TH, -1), LA))
+            C, D = mul(TH, TH), mul(LA, LA)
+            Ee, Ff, Gg = mul(LA, D), mul(Z, C), mul(X, D)
+            X, Y, Z = (mul(LA, sub(add(Ee, Ff), sc(Gg, 2))), sub(mul(TH, sub(sc(Gg, 3), add(Ee, Ff))), mul(Ee, Y)), mul(Z, Ee))
+    return out
+
+
+def bls_fixed_step(P, T, g, stride, L, PX, PY, fset, mask, name):
+    """f <- f * (the line whose coefficients are table entries g .. g + 5, advanced by `stride` per repetition)"""
+    G = lambda k: ((g + 2 * k, stride), (g + 2 * k + 1, stride))
+    o = outs2(L[2], L[3], Acc2().gconst_fp(G(1), Lin.slot(PX)))
+    o += outs2(L[4], L[5], Acc2().gconst_fp(G(2), Lin.slot(PY)))
+    P.dot(o, name + "/l")
+    T.mul_sparse(fset, Tower.reg(fset), {0: G(0), 2: E2.slots(L[2], L[3]), 3: E2.slots(L[4], L[5])}, mask=mask, name=name + "/line")
+
+
 def tower_easy_part(P, T, f, gamma2, F_, G_, H_, SPARE):
     """F <- f^((p^6 - 1)(p^2 + 1)) for the symbolic Fp12 value f held in register set F (possibly with signs): the
     inverse through the tower (one base-field inversion), conj(f) f^-1, then times its p^2-Frobenius.  Uses the
@@ -1156,6 +1238,69 @@ def build_bls12381_check():
             bls_add_step(P, T, TT[0], TT[1], TT[2], Qs, tmp[4:10], L, PP[0], PP[1], F_, mask)
 
     bls_sched_miller(P, step, add)
+    res = bls_final_exp(P, T, T.conj12(FF), gam)
+    one = (P.c_plain_one, 1)
+    P.dot(sum((outs2(F_ + 2 * j, F_ + 2 * j + 1, Acc2().prod_const(res[j], one, None)) for j in range(6)), []), "to_plain")
+    P.misc([dict(op=OP_IS_ONE, dst=F_ + 2 * j + c, arg=(1 if (j == 0 and c == 0) else 0) << 16) for j in range(6) for c in range(2)],
+           "is_one")
+    return P
+
+
+def build_bls12381_verify():
+    """CHECK with the second pair's G2 operand fixed to the generator (bls.Verify with signatures on G1, sign/bls
+    bls.go:83-96: e(H(m), pk) e(-sig, g2) == 1): inputs P1 (2), Q1 (4), P2 (2, negated by the decode kernel); the lines
+    of the second Miller loop come from the table, its point is never computed."""
+    f = bls12381_field()
+    P = Prog(f, NSLOTS, 1, n_inputs=8, n_gslots=4)
+    T = Tower(P)
+    xi = (1, 1)
+    gam = {K: frob_gammas(f.p, xi, K) for K in (1, 2, 3)}
+    T1 = [(12, 13), (14, 15), (16, 17)]
+    tmp = list(range(24, 34))
+    L = list(range(34, 40))
+    P1, P2 = (40, 41), (42, 43)
+    Qs = tmp[0:4]
+    bls_load_inputs(P, f, Qs, 2)
+    P.misc([dict(op=OP_SPILL, dst=Qs[i], arg=2) for i in range(4)], "park Q")
+    bls_load_inputs(P, f, [P1[0], P1[1]], 0)
+    bls_load_inputs(P, f, [P2[0], P2[1]], 6)
+    P.misc([dict(op=OP_CLOAD, dst=F_ + i, arg=P.c_one if i == 0 else P.c_zero) for i in range(12)], "f=1")
+    P.misc([dict(op=OP_FILL, dst=T1[0][0], arg=2), dict(op=OP_FILL, dst=T1[0][1], arg=2), dict(op=OP_FILL, dst=T1[1][0], arg=2),
+            dict(op=OP_FILL, dst=T1[1][1], arg=2), dict(op=OP_CLOAD, dst=T1[2][0], arg=P.c_one),
+            dict(op=OP_CLOAD, dst=T1[2][1], arg=P.c_zero)], "T=Q")
+    FF = T.reg(F_)
+    lines = bls_fixed_line_table(f.p, BLS_G2_GEN)
+    cur = [P.gtable([c for line in lines for z in line for c in z])]
+    assert cur[0] == 0
+
+    def step():
+        T.sqr12(F_, FF, "miller/sqr")
+        bls_dbl_step(P, T, T1[0], T1[1], T1[2], tmp, L, P1[0], P1[1], F_, 1)
+        bls_fixed_step(P, T, cur[0], 6, L, P2[0], P2[1], F_, 2, "fixdbl")
+
+    def add():
+        P.misc([dict(op=OP_FILL, dst=Qs[i], arg=2) for i in range(4)], "add/fillQ")
+        bls_add_step(P, T, T1[0], T1[1], T1[2], Qs, tmp[4:10], L, P1[0], P1[1], F_, 1)
+        bls_fixed_step(P, T, cur[0], 0, L, P2[0], P2[1], F_, 2, "fixadd")
+        cur[0] += 6
+
+    def sched(step, add):  # bls_sched_miller with the table cursor moved past every run of doublings
+        run = 0
+        for b in bin(BLS_X_ABS)[3:]:
+            run += 1
+            if b == "1":
+                with P.repeat(run):
+                    step()
+                cur[0] += 6 * run
+                run = 0
+                add()
+        if run:
+            with P.repeat(run):
+                step()
+            cur[0] += 6 * run
+
+    sched(step, add)
+    assert cur[0] == len(P.gconsts)
     res = bls_final_exp(P, T, T.conj12(FF), gam)
     one = (P.c_plain_one, 1)
     P.dot(sum((outs2(F_ + 2 * j, F_ + 2 * j + 1, Acc2().prod_const(res[j], one, None)) for j in range(6)), []), "to_plain")
@@ -1567,7 +1712,12 @@ def emit_prog(P, name):
     flat = []
     for s in sched:
         flat += [s[0], s[1], s[2], 0]
-    return "\n".join([
+    table = []
+    for c in P.gconsts:
+        table += [d & 0xffffffff for d in P.f.balanced(c)] + [0] * (16 - P.f.N)
+    gtab = [f"static __device__ const uint32_t TVM_{name}_GCONSTS[{len(table)}] = {_carr(table)};  // {len(P.gconsts)} per-repetition constants",
+            ""] if table else []
+    return "\n".join(gtab + [
         f"// program {name}: {len(prog) // (WAVES * REC_WORDS)} stored instructions, {sum(s[1] * s[2] for s in sched)} executed",
         f"static __device__ const uint32_t TVM_{name}_PROG[{len(prog)}] = {_carr(prog)};",
         f"static __device__ const uint32_t TVM_{name}_SCHED[{len(flat)}] = {_carr(flat)};",
@@ -1589,6 +1739,8 @@ def main():
                emit_field(pair.f, struct), emit_prog(pair, up + "_PAIR"), emit_prog(check, up + "_CHECK")]
         if suite == "bn256":  # the product form, for calls whose G2 operands the caller vouches for (bn_pair.inc)
             out.append(emit_prog(build_bn256_check_product(), up + "_CHECKP"))
+        if suite == "bls12381":  # CHECK with the second G2 operand fixed to the generator (bls.Verify on G1)
+            out.append(emit_prog(build_bls12381_verify(), up + "_VERIFY"))
         out += ["}  // namespace kyb", ""]
         open(os.path.join(HERE, "tower_vm_%s.inc" % suite), "w").write("\n".join(out))
         for n, P in (("pair", pair), ("check", check)):

@@ -44,7 +44,9 @@ enum Op : uint32_t { OP_DOT = 0, OP_IDLE = 1, OP_GLOAD = 2, OP_INV = 3, OP_GT_ST
 // term words
 //   w0: 0-5 x1 | 6-11 x2 | 12-17 y1 | 18-23 y2 | 24-25 kind (0 product, 1 linear: x only, 2 product with y = CONST[y1 + 64 y2])
 //   w1: int8 cx1 | cx2 | cy1 | cy2          operand = c1 S[s1] + c2 S[s2]  (c2 = 0: one slot)
-enum Kind : uint32_t { K_PROD = 0, K_LIN = 1, K_PROD_CONST = 2 };
+//   kind 3: product with y = TABLE[(bits 12-23 of w0) + (cy1 byte of w1) * r], r = the running repetition of the
+//   instruction's block: constants of a loop body that change from one pass to the next (the lines of a fixed point)
+enum Kind : uint32_t { K_PROD = 0, K_LIN = 1, K_PROD_CONST = 2, K_PROD_GCONST = 3 };
 
 struct Sched {
     uint32_t start, len, repeat, pad;
@@ -69,6 +71,7 @@ struct Args {
     uint32_t check;          // 1: the program ends in IS_ONE and `out` takes one boolean per pairing
     uint32_t* gspill;        // global scratch: [workgroup][global slot][wave][slot image]
     uint32_t ngslots;
+    const int32_t* gconsts;  // [index][16] the program's table of per-repetition constants (kind 3 terms), global memory
 };
 
 template <class F>
@@ -304,8 +307,12 @@ __device__ void run(const Args& a, uint32_t* lds, uint32_t* misc, const int32_t*
                             if (kind == K_PROD) {
                                 const int cy1 = (int8_t)((w1 >> 16) & 0xff), cy2 = (int8_t)(w1 >> 24);
                                 operand<F>(y, lds, (w0 >> 12) & 63u, cy1, (w0 >> 18) & 63u, cy2, lane);
-                            } else {
+                            } else if (kind == K_PROD_CONST) {
                                 const int32_t* c = clds + 16 * ((w0 >> 12) & 0xfffu);
+#pragma unroll
+                                for (int j = 0; j < N; j++) y[j] = c[j];
+                            } else {  // wave-uniform address: the limbs arrive through the scalar cache
+                                const int32_t* c = a.gconsts + 16 * (((w0 >> 12) & 0xfffu) + rep * ((w1 >> 16) & 0xffu));
 #pragma unroll
                                 for (int j = 0; j < N; j++) y[j] = c[j];
                             }

@@ -74,6 +74,80 @@ def test_check_program_truth_table(check_prog):
     assert not res["not_one"]
 
 
+@pytest.fixture(scope="module")
+def verify_prog():
+    return G.build_bls12381_verify()
+
+
+def test_fixed_point_line_table_is_the_generator_s_walk():
+    """the table's walk ends where the general loop's point ends: [|x|] Q (projective), and Q is the suite's generator"""
+    assert G.BLS_G2_GEN == O.G2_GEN
+    lines = G.bls_fixed_line_table(O.P, G.BLS_G2_GEN)
+    assert len(lines) == 63 + 5  # doublings + the ones of the parameter below its top bit
+
+
+def test_verify_program_equals_the_check_program_with_the_generator(check_prog, verify_prog):
+    """e(P1, Q1) e(P2, g2) == 1 decided by the fixed-point program as by the general one: bls.Verify's shape
+    (P1 = H(m), Q1 = pk = [s] g2, -P2 = sig = [s] H(m)), a wrong signature, a wrong key, pair B dead, both dead; and the
+    Miller values themselves agree (same lines, not merely the same verdict)"""
+    f = verify_prog.f
+    rng = random.Random(5)
+
+    def run(prog, p1, q1, p2, flags=0):
+        ins = (_inputs(f, p1, q1) if p1 else [0] * 6) + ([v * f.R1 % f.p for v in O.g1_neg(p2)[:2]] if p2 else [0, 0])
+        if prog is check_prog:
+            ins = ins + [v * f.R1 % f.p for v in (O.G2_GEN[0][0], O.G2_GEN[0][1], O.G2_GEN[1][0], O.G2_GEN[1][1])]
+        S, res = prog.simulate(ins, flags)
+        return not res["not_one"], S
+
+    for k in range(3):
+        s, h = rng.randrange(1, O.R), rng.randrange(1, O.R)
+        hm, pk = O.g1_mul(h, O.G1_GEN), O.g2_mul(s, O.G2_GEN)
+        sig = O.g1_mul(s, hm)
+        ok_v, Sv = run(verify_prog, hm, pk, sig)
+        ok_c, Sc = run(check_prog, hm, pk, sig)
+        assert ok_v and ok_c
+        bad = O.g1_mul(s + 1, hm)
+        assert not run(verify_prog, hm, pk, bad)[0]
+        assert not run(verify_prog, hm, O.g2_mul(s + 1, O.G2_GEN), sig)[0]
+    assert not run(verify_prog, hm, pk, None, flags=2)[0]      # signature at infinity: e(H, pk) == 1 is false
+    assert run(verify_prog, None, None, None, flags=3)[0]      # both pairs dead: 1 == 1
+    assert not run(verify_prog, None, None, sig, flags=1)[0]   # pair A dead: e(-sig, g2) == 1 only for sig = O
+
+
+def test_verify_program_in_device_arithmetic_and_bounds(verify_prog):
+    f = verify_prog.f
+    s, h = 0xC0FFEE, 0xBADC0DE
+    hm, pk = O.g1_mul(h, O.G1_GEN), O.g2_mul(s, O.G2_GEN)
+    sig = O.g1_mul(s, hm)
+    ins = _inputs(f, hm, pk) + [v * f.R1 % f.p for v in O.g1_neg(sig)[:2]]
+    _, res = verify_prog.simulate_limbs(ins)
+    assert not res["not_one"]
+    verify_prog.simulate_limbs([f.p - 1] * 8)  # garbage in: nothing may overflow
+    col, val = verify_prog.check_bounds()
+    assert col < 63 and val < 1024
+    words, sched = verify_prog.encode()
+    assert sum(ln * rep for _, ln, rep in sched) == verify_prog.stats()["executed"]
+    kinds = set()
+    for i in range(0, len(words), G.REC_WORDS):
+        hdr = words[i]
+        if (hdr >> 21) & 15 == G.OP_DOT:
+            for k in range((hdr >> 6) & 63):
+                w0, w1 = words[i + 1 + 2 * k], words[i + 2 + 2 * k]
+                kinds.add((w0 >> 24) & 3)
+                if (w0 >> 24) & 3 == G.K_PROD_GCONST:
+                    assert ((w0 >> 12) & 0xfff) + 62 * ((w1 >> 16) & 0xff) < len(verify_prog.gconsts) + 6 * 62
+    assert G.K_PROD_GCONST in kinds
+    # every run of doublings indexes inside the table: base + stride * (repeat - 1) + 5 < len
+    for start, ln, rep in verify_prog.sched:
+        for ins_ in verify_prog.ins[start:start + ln]:
+            for r in ins_:
+                if r["op"] == G.OP_DOT:
+                    for t in r["terms"]:
+                        if t[0] == "g":
+                            assert t[2][0] + t[2][1] * (rep - 1) < len(verify_prog.gconsts)
+
+
 def test_worst_case_bounds(pair_prog, check_prog):
     """for ANY residues: operand limbs < 2^31, accumulator columns < 2^63, |value| < 1024 p, canonicaliser inputs < 4p"""
     for prog in (pair_prog, check_prog):
