@@ -746,7 +746,9 @@ class Tower:
             for j, l in ls.items():
                 i = k - j
                 x = a[i] if i >= 0 else a[i + 6].mul_xi(self.xi0)
-                if isinstance(l, tuple):  # a coefficient held in the program's table: ((re base, stride), (im base, stride))
+                if l == 1:  # the coefficient one: a linear term
+                    acc.lin(x)
+                elif isinstance(l, tuple):  # a coefficient held in the program's table: ((re base, stride), (im base, stride))
                     acc.prod_gconst(x, l)
                 else:
                     acc.prod(x, l)
@@ -977,10 +979,10 @@ def bls_add_step(P, T, TX, TY, TZ, Q, tmp, L, PX, PY, fset, mask):
 
 
 # --- the Miller loop of a FIXED point Q (the G2 generator of bls.Verify): T's walk does not depend on the input, so
-# the three line coefficients of every step are constants.  Per step the table holds l0 (Fp2) and the factors of xP and
-# yP in l2, l3 (Fp2 each): six field elements, in the order the loop visits the steps (doubling, then the addition where
-# the parameter has a one).  The values follow bls_dbl_step / bls_add_step formula for formula (same scale factors), so
-# the fixed loop multiplies exactly the lines the general loop would.
+# the three line coefficients of every step are constants.  Per step the table holds the factors of xP and yP in l2, l3
+# divided by l0 (Fp2 each: four field elements), in the order the loop visits the steps (doubling, then the addition
+# where the parameter has a one).  The walk follows bls_dbl_step / bls_add_step formula for formula, so the fixed loop
+# multiplies the lines the general loop would, each scaled by an Fp2 constant (which the final exponentiation kills).
 BLS_G2_GEN = ((0x024AA2B2F08F0A91260805272DC51051C6E47AD4FA403B02B4510B647AE3D1770BAC0326A805BBEFD48056C8C121BDB8,
                0x13E02B6052719F607DACD3A088274F65596BD0D09920B61AB5DA61BBDC7F5049334CF11213945D57E5AC7D055D042B7E),
               (0x0CE5D527727D6E118CC9CDC6DA2E351AADFD9BAA8CBDD3A76D429A695160D12C923AC9CC3BACA289E193548608B82801,
@@ -988,11 +990,19 @@ BLS_G2_GEN = ((0x024AA2B2F08F0A91260805272DC51051C6E47AD4FA403B02B4510B647AE3D17
 
 
 def bls_fixed_line_table(p, Q):
-    """[(l0, c2, c3)] per Miller step (Fp2 pairs of ints): line = l0 + (c2 xP) w^2 + (c3 yP) w^3"""
+    """[(c2, c3)] per Miller step (Fp2 pairs of ints): line = 1 + (c2 xP) w^2 + (c3 yP) w^3 -- the general loop's line
+    l0 + (-3X^2 xP) w^2 + (2YZ yP) w^3 divided by l0 (an Fp2 factor dies in the final exponentiation), so that the
+    sparse multiplication has one coefficient that costs nothing"""
     def mul(a, b): return _f2_mul(a, b, p)
     def add(a, b): return ((a[0] + b[0]) % p, (a[1] + b[1]) % p)
     def sub(a, b): return ((a[0] - b[0]) % p, (a[1] - b[1]) % p)
     def sc(a, c): return (a[0] * c % p, a[1] * c % p)
+
+    def unit(l0, c2, c3):
+        n = pow(l0[0] * l0[0] + l0[1] * l0[1], -1, p)  # l0 = 0 would make Q a point of small order
+        inv = (l0[0] * n % p, -l0[1] * n % p)
+        return (mul(c2, inv), mul(c3, inv))
+
     xQ, yQ = Q
     assert sub(mul(yQ, yQ), mul(mul(xQ, xQ), xQ)) == (4, 4), "Q is not on the twist y^2 = x^3 + 4 xi"
     X, Y, Z = xQ, yQ, (1, 0)
@@ -1000,11 +1010,11 @@ def bls_fixed_line_table(p, Q):
     for b in bin(BLS_X_ABS)[3:]:
         XY, B, YZ, A3 = mul(X, Y), mul(Y, Y), mul(Y, Z), sc(mul(X, X), 3)
         E = sc(mul(mul(Z, Z), (1, 1)), 12)  # 3 b' Z^2, b' = 4 xi
-        out.append((sub(B, E), sc(A3, -1), sc(YZ, 2)))
+        out.append(unit(sub(B, E), sc(A3, -1), sc(YZ, 2)))
         X, Y, Z = mul(sc(XY, 2), sub(B, sc(E, 3))), add(mul(B, B), mul(sc(E, 3), sub(sc(B, 2), E))), sc(mul(B, YZ), 8)
         if b == "1":
             TH, LA = sub(Y, mul(yQ, Z)), sub(X, mul(xQ, Z))
-            out.append((sub(mul(TH, xQ), mul(LA, yQ)), sc(TH, -1), LA))
+            out.append(unit(sub(mul(TH, xQ), mul(LA, yQ)), sc(TH, -1), LA))
             C, D = mul(TH, TH), mul(LA, LA)
             Ee, Ff, Gg = mul(LA, D), mul(Z, C), mul(X, D)
             X, Y, Z = (mul(LA, sub(add(Ee, Ff), sc(Gg, 2))), sub(mul(TH, sub(sc(Gg, 3), add(Ee, Ff))), mul(Ee, Y)), mul(Z, Ee))
@@ -1012,12 +1022,12 @@ def bls_fixed_line_table(p, Q):
 
 
 def bls_fixed_step(P, T, g, stride, L, PX, PY, fset, mask, name):
-    """f <- f * (the line whose coefficients are table entries g .. g + 5, advanced by `stride` per repetition)"""
+    """f <- f * (1 + c2 xP w^2 + c3 yP w^3) with (c2, c3) = table entries g .. g + 3, advanced by `stride` per repetition"""
     G = lambda k: ((g + 2 * k, stride), (g + 2 * k + 1, stride))
-    o = outs2(L[2], L[3], Acc2().gconst_fp(G(1), Lin.slot(PX)))
-    o += outs2(L[4], L[5], Acc2().gconst_fp(G(2), Lin.slot(PY)))
+    o = outs2(L[2], L[3], Acc2().gconst_fp(G(0), Lin.slot(PX)))
+    o += outs2(L[4], L[5], Acc2().gconst_fp(G(1), Lin.slot(PY)))
     P.dot(o, name + "/l")
-    T.mul_sparse(fset, Tower.reg(fset), {0: G(0), 2: E2.slots(L[2], L[3]), 3: E2.slots(L[4], L[5])}, mask=mask, name=name + "/line")
+    T.mul_sparse(fset, Tower.reg(fset), {0: 1, 2: E2.slots(L[2], L[3]), 3: E2.slots(L[4], L[5])}, mask=mask, name=name + "/line")
 
 
 def tower_easy_part(P, T, f, gamma2, F_, G_, H_, SPARE):
@@ -1276,13 +1286,13 @@ def build_bls12381_verify():
     def step():
         T.sqr12(F_, FF, "miller/sqr")
         bls_dbl_step(P, T, T1[0], T1[1], T1[2], tmp, L, P1[0], P1[1], F_, 1)
-        bls_fixed_step(P, T, cur[0], 6, L, P2[0], P2[1], F_, 2, "fixdbl")
+        bls_fixed_step(P, T, cur[0], 4, L, P2[0], P2[1], F_, 2, "fixdbl")
 
     def add():
         P.misc([dict(op=OP_FILL, dst=Qs[i], arg=2) for i in range(4)], "add/fillQ")
         bls_add_step(P, T, T1[0], T1[1], T1[2], Qs, tmp[4:10], L, P1[0], P1[1], F_, 1)
         bls_fixed_step(P, T, cur[0], 0, L, P2[0], P2[1], F_, 2, "fixadd")
-        cur[0] += 6
+        cur[0] += 4
 
     def sched(step, add):  # bls_sched_miller with the table cursor moved past every run of doublings
         run = 0
@@ -1291,13 +1301,13 @@ def build_bls12381_verify():
             if b == "1":
                 with P.repeat(run):
                     step()
-                cur[0] += 6 * run
+                cur[0] += 4 * run
                 run = 0
                 add()
         if run:
             with P.repeat(run):
                 step()
-            cur[0] += 6 * run
+            cur[0] += 4 * run
 
     sched(step, add)
     assert cur[0] == len(P.gconsts)
