@@ -26,8 +26,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 WAVES = 12
 W = 28  # default limb width; a field may choose a narrower one (VmField.W)
 REC_WORDS = 64
-OP_DOT, OP_IDLE, OP_GLOAD, OP_INV, OP_GT_STORE, OP_IS_ONE, OP_CLOAD, OP_SPILL, OP_FILL, OP_CMP_EQ = range(10)
-K_PROD, K_LIN, K_PROD_CONST, K_PROD_GCONST = 0, 1, 2, 3
+OP_DOT, OP_IDLE, OP_GLOAD, OP_INV, OP_GT_STORE, OP_IS_ONE, OP_CLOAD, OP_SPILL, OP_FILL, OP_CMP_EQ, OP_GCLOAD = range(11)
+K_PROD, K_LIN, K_PROD_CONST = 0, 1, 2
+GC_ENTRIES = 4  # table entries one OP_GCLOAD record moves into the constant area (64 lanes x 1 word = 4 x 16 words)
 
 
 # ------------------------------------------------------------------------------------------------ field
@@ -166,20 +167,20 @@ class Acc2:
                 lst.append(("c", x, c))
         return self
 
-    def prod_gconst(self, a, g):
-        """+= a * G with G = (gre, gim) an Fp2 entry of the program's TABLE in global memory: each part is (base, stride),
-        the table index being base + stride * (repetition of the enclosing block) -- the constants of a loop body that
-        change from one pass to the next (the lines of a fixed point, Prog.gconsts)"""
-        gre, gim = g
-        for lst, x, c in ((self.re, a.re, gre), (self.re, -a.im, gim), (self.im, a.re, gim), (self.im, a.im, gre)):
+    def prod_dconst(self, a, g):
+        """+= a * G with G = (dre, dim) two DYNAMIC constants: entries of the constant area that an OP_GCLOAD record
+        refills from the program's table (Prog.gconsts) -- the constants of a loop body that change from one pass to
+        the next (the lines of a fixed point)"""
+        dre, dim = g
+        for lst, x, c in ((self.re, a.re, dre), (self.re, -a.im, dim), (self.im, a.re, dim), (self.im, a.im, dre)):
             if not x.is_zero():
-                lst.append(("g", x, c))
+                lst.append(("d", x, c))
         return self
 
-    def gconst_fp(self, g, b):
+    def dconst_fp(self, g, b):
         """+= G * b with b a base-field operand (Lin)"""
-        self.re.append(("g", b, g[0]))
-        self.im.append(("g", b, g[1]))
+        self.re.append(("d", b, g[0]))
+        self.im.append(("d", b, g[1]))
         return self
 
     def lin(self, a):
@@ -207,7 +208,8 @@ class Prog:
         self.ins = []      # instruction = list of WAVES records (dict)
         self.names = []
         self.consts = []   # stored values (ints in [0, p))
-        self.gconsts = []  # the table of per-repetition constants (stored values), read from global memory
+        self.gconsts = []  # the table of per-repetition constants (stored values), global memory
+        self.dyn_base = None  # first of the GC_ENTRIES constant-area entries that OP_GCLOAD refills (after the fixed ones)
         self.sched = []    # (start, len, repeat)
         self._open = None
         self.c_zero = self.const(0)
@@ -318,13 +320,14 @@ class Prog:
             s.update((r["dst"], r["arg"]))
         return s
 
-    def dot(self, outs, name=""):
+    def dot(self, outs, name="", extra=()):
+        """one instruction of DOT records (+ `extra` non-DOT records for the waves left over)"""
         recs = []
         for o in outs:
             assert 0 <= o.dst < self.nslots
             for t in o.terms:
-                if t[0] == "g":
-                    assert 0 <= t[2][0] < 4096 and 0 <= t[2][1] < 256
+                if t[0] == "d":
+                    assert 0 <= t[2] < GC_ENTRIES
                 for lin in (t[1:3] if t[0] == "p" else t[1:2]):
                     assert 1 <= len(lin.d) <= 2, (name, lin)
                     assert all(0 <= s < self.nslots and -128 <= c <= 127 for s, c in lin.d.items()), (name, lin)
@@ -332,7 +335,7 @@ class Prog:
                 assert all(t[0] == "l" for t in o.terms)
             assert len(o.terms) <= 31 and 1 <= o.scale <= 15
             recs.append(dict(op=OP_DOT, dst=o.dst, terms=o.terms, scale=o.scale, mask=o.mask, raw=o.raw))
-        self._emit(recs, name)
+        self._emit(recs + list(extra), name)
 
     def misc(self, recs, name=""):
         self._emit(recs, name)
@@ -345,11 +348,12 @@ class Prog:
         p, Rinv = f.p, pow(f.R, -1, f.p)
         S = [0] * self.nslots
         G = {}
+        CL = [None] * GC_ENTRIES  # the dynamic constants; refilled at the END of the instruction that holds the GCLOAD
         res = {"gt": {}, "not_one": False}
         for start, ln, rep in self.sched:
             for it in range(rep):
                 for ins in self.ins[start:start + ln]:
-                    new = {}
+                    new, newc = {}, None
                     for w, r in enumerate(ins):
                         op = r["op"]
                         if op == OP_DOT:
@@ -361,8 +365,8 @@ class Prog:
                                     acc += x * y * (1 if r["raw"] else Rinv)
                                 elif t[0] == "c":
                                     acc += x * t[2][1] * Rinv
-                                elif t[0] == "g":
-                                    acc += x * self.gconsts[t[2][0] + it * t[2][1]] * Rinv
+                                elif t[0] == "d":
+                                    acc += x * CL[t[2]] * Rinv
                                 else:
                                     acc += x
                             v = acc * r["scale"] % p
@@ -371,6 +375,9 @@ class Prog:
                             new[r["dst"]] = v
                         elif op == OP_GLOAD:
                             new[r["dst"]] = inputs[r["arg"]] % p
+                        elif op == OP_GCLOAD:
+                            base = r["arg"][0] + it * r["arg"][1]
+                            newc = self.gconsts[base:base + GC_ENTRIES]
                         elif op == OP_CLOAD:
                             new[r["dst"]] = self.consts[r["arg"]]
                         elif op == OP_INV:
@@ -390,6 +397,8 @@ class Prog:
                                 res["not_one"] = True
                     for k, v in new.items():
                         S[k] = v
+                    if newc is not None:
+                        CL = list(newc) + [None] * (GC_ENTRIES - len(newc))
         return S, res
 
     # --- the device's arithmetic, limb for limb
@@ -434,11 +443,12 @@ class Prog:
 
         S = [[0] * N for _ in range(self.nslots)]
         G = {}
+        CL = [None] * GC_ENTRIES
         res = {"gt": {}, "not_one": False}
         for start, ln, rep in self.sched:
             for it in range(rep):
                 for ins in self.ins[start:start + ln]:
-                    new = {}
+                    new, newc = {}, None
                     for w, r in enumerate(ins):
                         op = r["op"]
                         if op == OP_DOT:
@@ -451,8 +461,8 @@ class Prog:
                                 else:
                                     if term[0] == "p":
                                         y = operand(term[2])
-                                    elif term[0] == "g":
-                                        y = f.balanced(self.gconsts[term[2][0] + it * term[2][1]])
+                                    elif term[0] == "d":
+                                        y = f.balanced(CL[term[2]])
                                     else:
                                         y = f.balanced(term[2][1])
                                     for i in range(N):
@@ -475,6 +485,9 @@ class Prog:
                             new[r["dst"]] = v
                         elif op == OP_GLOAD:
                             new[r["dst"]] = from_words(inputs[r["arg"]] % p)
+                        elif op == OP_GCLOAD:
+                            base = r["arg"][0] + it * r["arg"][1]
+                            newc = self.gconsts[base:base + GC_ENTRIES]
                         elif op == OP_CLOAD:
                             new[r["dst"]] = f.balanced(self.consts[r["arg"]])
                         elif op == OP_INV:
@@ -494,6 +507,8 @@ class Prog:
                                 res["not_one"] = True
                     for k, v in new.items():
                         S[k] = v
+                    if newc is not None:
+                        CL = list(newc) + [None] * (GC_ENTRIES - len(newc))
         return S, res
 
     # --- worst-case bounds for any input
@@ -618,9 +633,9 @@ class Prog:
                             ci = t[2][0]
                             cy1 = cy2 = 0
                             w0 = x1 | (x2 << 6) | ((ci & 0xfff) << 12) | (K_PROD_CONST << 24)
-                        elif t[0] == "g":  # table index = base (12 bits of w0) + stride (the cy1 byte) * repetition
-                            cy1, cy2 = t[2][1], 0
-                            w0 = x1 | (x2 << 6) | ((t[2][0] & 0xfff) << 12) | (K_PROD_GCONST << 24)
+                        elif t[0] == "d":  # a dynamic constant is an entry of the constant area like any other
+                            cy1 = cy2 = 0
+                            w0 = x1 | (x2 << 6) | (((self.dyn_base + t[2]) & 0xfff) << 12) | (K_PROD_CONST << 24)
                         else:
                             cy1 = cy2 = 0
                             w0 = x1 | (x2 << 6) | (K_LIN << 24)
@@ -628,6 +643,9 @@ class Prog:
                         rec[2 + 2 * k] = cx1 | (cx2 << 8) | (cy1 << 16) | (cy2 << 24)
                 elif op == OP_IDLE:
                     pass
+                elif op == OP_GCLOAD:  # word 1: table index of the first entry | its advance per repetition << 16
+                    hdr |= self.dyn_base
+                    rec[1] = r["arg"][0] | (r["arg"][1] << 16)
                 else:
                     hdr |= r["dst"]
                     rec[1] = r["src"] if op == OP_INV else r["arg"]
@@ -648,7 +666,7 @@ class Prog:
                     prog.extend(blobs[b])
             sched.append((placed[key], ln, rep))
         merged = []
-        has_g = [any(t[0] == "g" for r in ins if r["op"] == OP_DOT for t in r["terms"]) for ins in self.ins]
+        has_g = [any(r["op"] == OP_GCLOAD for r in ins) for ins in self.ins]
         gblock = [any(has_g[start:start + ln]) for start, ln, rep in self.sched]
         for k, s in enumerate(sched):  # consecutive repeats of one block (a table index restarts with its block)
             if merged and merged[-1][0] == s[0] and merged[-1][1] == s[1] and not gblock[k]:
@@ -748,8 +766,8 @@ class Tower:
                 x = a[i] if i >= 0 else a[i + 6].mul_xi(self.xi0)
                 if l == 1:  # the coefficient one: a linear term
                     acc.lin(x)
-                elif isinstance(l, tuple):  # a coefficient held in the program's table: ((re base, stride), (im base, stride))
-                    acc.prod_gconst(x, l)
+                elif isinstance(l, tuple):  # a coefficient held in two dynamic constants (re, im)
+                    acc.prod_dconst(x, l)
                 else:
                     acc.prod(x, l)
             outs += outs2(dst + 2 * k, dst + 2 * k + 1, acc, mask=mask)
@@ -917,7 +935,7 @@ def bls_load_inputs(P, f, slots, first_input):
         P.dot([Out(s, [("c", Lin.slot(s), (k1, P.consts[k1]))]) for s in part], "to_vm_form")
 
 
-def bls_dbl_step(P, T, TX, TY, TZ, tmp, L, PX, PY, fset, mask):
+def bls_dbl_step(P, T, TX, TY, TZ, tmp, L, PX, PY, fset, mask, extra=()):
     """T <- 2T on the twist, f <- f * tangent(P): two product rounds + the sparse multiplication.
     tmp: 10 slots, L: 6 slots."""
     X, Y, Z = E2.slots(*TX), E2.slots(*TY), E2.slots(*TZ)
@@ -933,7 +951,7 @@ def bls_dbl_step(P, T, TX, TY, TZ, tmp, L, PX, PY, fset, mask):
     o += outs2(tmp[4], tmp[5], zz, scale=12)
     o += outs2(tmp[6], tmp[7], Acc2().prod(Y, Z))
     o += outs2(tmp[8], tmp[9], Acc2().sqr(X), scale=3)
-    P.dot(o, "dbl/a")
+    P.dot(o, "dbl/a", extra)  # ten records: two waves are free for a caller's bookkeeping records
     o = []
     o += outs2(TX[0], TX[1], Acc2().prod(XY.scale(2), B - E.scale(3)))                     # 4 X3 = 2 XY (B - 3E)
     o += outs2(TY[0], TY[1], Acc2().sqr(B).prod(E.scale(3), B.scale(2) - E))               # 4 Y3 = B^2 + 3E(2B - E)
@@ -946,7 +964,7 @@ def bls_dbl_step(P, T, TX, TY, TZ, tmp, L, PX, PY, fset, mask):
     T.mul_sparse(fset, f, {0: E2.slots(L[0], L[1]), 2: E2.slots(L[2], L[3]), 3: E2.slots(L[4], L[5])}, mask=mask, name="dbl/line")
 
 
-def bls_add_step(P, T, TX, TY, TZ, Q, tmp, L, PX, PY, fset, mask):
+def bls_add_step(P, T, TX, TY, TZ, Q, tmp, L, PX, PY, fset, mask, extra=()):
     """T <- T + Q (Q affine), f <- f * chord(P).  tmp: 6 slots besides Q's 4 (which are recycled), L: 6 slots."""
     X, Y, Z = E2.slots(*TX), E2.slots(*TY), E2.slots(*TZ)
     xQ, yQ = E2.slots(Q[0], Q[1]), E2.slots(Q[2], Q[3])
@@ -954,7 +972,7 @@ def bls_add_step(P, T, TX, TY, TZ, Q, tmp, L, PX, PY, fset, mask):
     o = []
     o += outs2(tmp[0], tmp[1], Acc2().lin(Y).prod(-yQ, Z))       # theta = Y - yQ Z
     o += outs2(tmp[2], tmp[3], Acc2().lin(X).prod(-xQ, Z))       # lambda = X - xQ Z
-    P.dot(o, "add/a")
+    P.dot(o, "add/a", extra)
     C, D = E2.slots(Q[0], Q[1]), E2.slots(Q[2], Q[3])             # recycle Q's slots (it is last read here)
     o = []
     o += outs2(L[0], L[1], Acc2().prod(TH, xQ).prod(-LA, yQ))     # l0 = theta xQ - lambda yQ
@@ -1021,11 +1039,16 @@ def bls_fixed_line_table(p, Q):
     return out
 
 
-def bls_fixed_step(P, T, g, stride, L, PX, PY, fset, mask, name):
-    """f <- f * (1 + c2 xP w^2 + c3 yP w^3) with (c2, c3) = table entries g .. g + 3, advanced by `stride` per repetition"""
-    G = lambda k: ((g + 2 * k, stride), (g + 2 * k + 1, stride))
-    o = outs2(L[2], L[3], Acc2().gconst_fp(G(0), Lin.slot(PX)))
-    o += outs2(L[4], L[5], Acc2().gconst_fp(G(1), Lin.slot(PY)))
+def bls_fixed_load(g, stride):
+    """the record that moves the step's (c2, c3) -- table entries g .. g + 3, advanced by `stride` per repetition of the
+    enclosing block -- into the dynamic constants; it goes into an EARLIER instruction of the same step"""
+    return dict(op=OP_GCLOAD, arg=(g, stride))
+
+
+def bls_fixed_step(P, T, L, PX, PY, fset, mask, name):
+    """f <- f * (1 + c2 xP w^2 + c3 yP w^3) with (c2, c3) the dynamic constants 0 .. 3"""
+    o = outs2(L[2], L[3], Acc2().dconst_fp((0, 1), Lin.slot(PX)))
+    o += outs2(L[4], L[5], Acc2().dconst_fp((2, 3), Lin.slot(PY)))
     P.dot(o, name + "/l")
     T.mul_sparse(fset, Tower.reg(fset), {0: 1, 2: E2.slots(L[2], L[3]), 3: E2.slots(L[4], L[5])}, mask=mask, name=name + "/line")
 
@@ -1285,13 +1308,13 @@ def build_bls12381_verify():
 
     def step():
         T.sqr12(F_, FF, "miller/sqr")
-        bls_dbl_step(P, T, T1[0], T1[1], T1[2], tmp, L, P1[0], P1[1], F_, 1)
-        bls_fixed_step(P, T, cur[0], 4, L, P2[0], P2[1], F_, 2, "fixdbl")
+        bls_dbl_step(P, T, T1[0], T1[1], T1[2], tmp, L, P1[0], P1[1], F_, 1, extra=[bls_fixed_load(cur[0], 4)])
+        bls_fixed_step(P, T, L, P2[0], P2[1], F_, 2, "fixdbl")
 
     def add():
         P.misc([dict(op=OP_FILL, dst=Qs[i], arg=2) for i in range(4)], "add/fillQ")
-        bls_add_step(P, T, T1[0], T1[1], T1[2], Qs, tmp[4:10], L, P1[0], P1[1], F_, 1)
-        bls_fixed_step(P, T, cur[0], 0, L, P2[0], P2[1], F_, 2, "fixadd")
+        bls_add_step(P, T, T1[0], T1[1], T1[2], Qs, tmp[4:10], L, P1[0], P1[1], F_, 1, extra=[bls_fixed_load(cur[0], 0)])
+        bls_fixed_step(P, T, L, P2[0], P2[1], F_, 2, "fixadd")
         cur[0] += 4
 
     def sched(step, add):  # bls_sched_miller with the table cursor moved past every run of doublings
@@ -1310,12 +1333,13 @@ def build_bls12381_verify():
             cur[0] += 4 * run
 
     sched(step, add)
-    assert cur[0] == len(P.gconsts)
+    assert cur[0] == len(P.gconsts) and len(lines[0]) * 2 == GC_ENTRIES
     res = bls_final_exp(P, T, T.conj12(FF), gam)
     one = (P.c_plain_one, 1)
     P.dot(sum((outs2(F_ + 2 * j, F_ + 2 * j + 1, Acc2().prod_const(res[j], one, None)) for j in range(6)), []), "to_plain")
     P.misc([dict(op=OP_IS_ONE, dst=F_ + 2 * j + c, arg=(1 if (j == 0 and c == 0) else 0) << 16) for j in range(6) for c in range(2)],
            "is_one")
+    P.dyn_base = len(P.consts)  # the dynamic constants follow the fixed ones in the constant area
     return P
 
 
@@ -1733,7 +1757,7 @@ def emit_prog(P, name):
         f"static __device__ const uint32_t TVM_{name}_SCHED[{len(flat)}] = {_carr(flat)};",
         f"static constexpr uint32_t TVM_{name}_NSCHED = {len(sched)};",
         f"static __device__ const uint32_t TVM_{name}_CONSTS[{len(consts)}] = {_carr(consts)};",
-        f"static constexpr uint32_t TVM_{name}_NCONSTS = {len(P.consts)};",
+        f"static constexpr uint32_t TVM_{name}_NCONSTS = {len(P.consts)}, TVM_{name}_NDYNCONSTS = {GC_ENTRIES if P.dyn_base is not None else 0};",
         f"static constexpr uint32_t TVM_{name}_NGSLOTS = {P.n_gslots}, TVM_{name}_NINPUTS = {P.n_inputs}, TVM_{name}_NSLOTS = {P.nslots};",
         f"static constexpr uint64_t TVM_{name}_MADS_PER_UNIT = {P.mads()}ull;  // integer MADs per pairing (check), all waves",
         ""])

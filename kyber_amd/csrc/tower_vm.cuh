@@ -36,17 +36,19 @@ constexpr int MAX_CONSTS = 32;
 //   0-5 out slot | 6-11 n terms | 12 barrier before the store (an input slot of some wave is overwritten) |
 //   13 raw: no products, no Montgomery reduction -- the linear terms are normalised as they are |
 //   14-18 post scale (0 = 1) | 19-20 store mask (0 none, 1 lanes live in pair A, 2 pair B) | 21-24 opcode
-enum Op : uint32_t { OP_DOT = 0, OP_IDLE = 1, OP_GLOAD = 2, OP_INV = 3, OP_GT_STORE = 4, OP_IS_ONE = 5, OP_CLOAD = 6, OP_SPILL = 7, OP_FILL = 8, OP_CMP_EQ = 9 };
+enum Op : uint32_t { OP_DOT = 0, OP_IDLE = 1, OP_GLOAD = 2, OP_INV = 3, OP_GT_STORE = 4, OP_IS_ONE = 5, OP_CLOAD = 6, OP_SPILL = 7, OP_FILL = 8, OP_CMP_EQ = 9, OP_GCLOAD = 10 };
 //   GLOAD: slot <- input[word 1] of this pairing (packed words of the per-lane field code, taken as an integer)
 //   CLOAD: slot <- constant[word 1];  INV: slot <- Inv(slot[word 1]);  SPILL / FILL: slot <-> global scratch (word 1, wave)
 //   GT_STORE: canonical big-endian bytes of the slot at byte offset (word 1 & 0xffff) of the pairing's output
 //   IS_ONE: record slot != (word 1 >> 16) in the workgroup's result flags;  CMP_EQ: record slot != slot[word 1]
+//   GCLOAD: constant area entries [out field .. + 3] <- TABLE[(word 1 & 0xffff) + (word 1 >> 16) * r .. + 3], r = the
+//   running repetition of the instruction's block: the constants of a loop body that change from one pass to the next
+//   (the lines of a fixed point).  Product terms then read them like any constant -- the multiply-add block has no
+//   third operand path (a term kind that read the table directly cost the OTHER programs 6 %: DESIGN.md 4a)
 // term words
 //   w0: 0-5 x1 | 6-11 x2 | 12-17 y1 | 18-23 y2 | 24-25 kind (0 product, 1 linear: x only, 2 product with y = CONST[y1 + 64 y2])
 //   w1: int8 cx1 | cx2 | cy1 | cy2          operand = c1 S[s1] + c2 S[s2]  (c2 = 0: one slot)
-//   kind 3: product with y = TABLE[(bits 12-23 of w0) + (cy1 byte of w1) * r], r = the running repetition of the
-//   instruction's block: constants of a loop body that change from one pass to the next (the lines of a fixed point)
-enum Kind : uint32_t { K_PROD = 0, K_LIN = 1, K_PROD_CONST = 2, K_PROD_GCONST = 3 };
+enum Kind : uint32_t { K_PROD = 0, K_LIN = 1, K_PROD_CONST = 2 };
 
 struct Sched {
     uint32_t start, len, repeat, pad;
@@ -71,7 +73,7 @@ struct Args {
     uint32_t check;          // 1: the program ends in IS_ONE and `out` takes one boolean per pairing
     uint32_t* gspill;        // global scratch: [workgroup][global slot][wave][slot image]
     uint32_t ngslots;
-    const int32_t* gconsts;  // [index][16] the program's table of per-repetition constants (kind 3 terms), global memory
+    const int32_t* gconsts;  // [index][16] the program's table of per-repetition constants (OP_GCLOAD), global memory
 };
 
 template <class F>
@@ -232,7 +234,7 @@ __device__ void words_to_limbs(int32_t (&r)[F::N], const uint32_t (&w)[F::NW]) {
 // The interpreter.  `Inv` supplies the base-field inversion on packed words (the per-lane field code's Kaliski inverse).
 // Workgroups are persistent: workgroup b takes the batches b, b + gridDim.x, ... of 64 pairings.
 template <class F, class Inv>
-__device__ void run(const Args& a, uint32_t* lds, uint32_t* misc, const int32_t* clds) {
+__device__ void run(const Args& a, uint32_t* lds, uint32_t* misc, int32_t* clds) {
     constexpr int N = F::N;
     constexpr int SW = Lds<F>::SLOT_WORDS;
     const int lane = threadIdx.x & (LANES - 1);
@@ -307,12 +309,8 @@ __device__ void run(const Args& a, uint32_t* lds, uint32_t* misc, const int32_t*
                             if (kind == K_PROD) {
                                 const int cy1 = (int8_t)((w1 >> 16) & 0xff), cy2 = (int8_t)(w1 >> 24);
                                 operand<F>(y, lds, (w0 >> 12) & 63u, cy1, (w0 >> 18) & 63u, cy2, lane);
-                            } else if (kind == K_PROD_CONST) {
+                            } else {
                                 const int32_t* c = clds + 16 * ((w0 >> 12) & 0xfffu);
-#pragma unroll
-                                for (int j = 0; j < N; j++) y[j] = c[j];
-                            } else {  // wave-uniform address: the limbs arrive through the scalar cache
-                                const int32_t* c = a.gconsts + 16 * (((w0 >> 12) & 0xfffu) + rep * ((w1 >> 16) & 0xffu));
 #pragma unroll
                                 for (int j = 0; j < N; j++) y[j] = c[j];
                             }
@@ -349,6 +347,8 @@ __device__ void run(const Args& a, uint32_t* lds, uint32_t* misc, const int32_t*
                         for (int k = 0; k < F::NW; k++) w[k] = src[k];
                         words_to_limbs<F>(r, w);
                         have = true;
+                    } else if (op == OP_GCLOAD) {  // 64 lanes x one word = four entries
+                        clds[16 * out_slot + lane] = a.gconsts[16 * ((arg & 0xffffu) + rep * (arg >> 16)) + lane];
                     } else if (op == OP_CLOAD) {
                         const int32_t* c = clds + 16 * arg;
 #pragma unroll

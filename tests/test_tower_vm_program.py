@@ -128,24 +128,22 @@ def test_verify_program_in_device_arithmetic_and_bounds(verify_prog):
     assert col < 63 and val < 1024
     words, sched = verify_prog.encode()
     assert sum(ln * rep for _, ln, rep in sched) == verify_prog.stats()["executed"]
-    kinds = set()
-    for i in range(0, len(words), G.REC_WORDS):
-        hdr = words[i]
-        if (hdr >> 21) & 15 == G.OP_DOT:
-            for k in range((hdr >> 6) & 63):
-                w0, w1 = words[i + 1 + 2 * k], words[i + 2 + 2 * k]
-                kinds.add((w0 >> 24) & 3)
-                if (w0 >> 24) & 3 == G.K_PROD_GCONST:
-                    assert ((w0 >> 12) & 0xfff) + 62 * ((w1 >> 16) & 0xff) < len(verify_prog.gconsts) + 6 * 62
-    assert G.K_PROD_GCONST in kinds
-    # every run of doublings indexes inside the table: base + stride * (repeat - 1) + 5 < len
+    # every table load stays inside the table for every repetition of its block, and is encoded as (base, stride)
+    loads = 0
     for start, ln, rep in verify_prog.sched:
         for ins_ in verify_prog.ins[start:start + ln]:
             for r in ins_:
-                if r["op"] == G.OP_DOT:
-                    for t in r["terms"]:
-                        if t[0] == "g":
-                            assert t[2][0] + t[2][1] * (rep - 1) < len(verify_prog.gconsts)
+                if r["op"] == G.OP_GCLOAD:
+                    loads += rep
+                    assert r["arg"][0] + r["arg"][1] * (rep - 1) + G.GC_ENTRIES <= len(verify_prog.gconsts)
+    assert loads == 68
+    n = 0
+    for i in range(0, len(words), G.REC_WORDS):
+        if (words[i] >> 21) & 15 == G.OP_GCLOAD:
+            n += 1
+            assert words[i] & 63 == verify_prog.dyn_base and (words[i + 1] & 0xffff) + G.GC_ENTRIES <= len(verify_prog.gconsts)
+    assert n >= 10  # one per run of doublings and per addition
+    assert verify_prog.dyn_base + G.GC_ENTRIES <= 32  # tvm::MAX_CONSTS
 
 
 def test_worst_case_bounds(pair_prog, check_prog):
@@ -168,7 +166,7 @@ def test_encoding_round_trip(pair_prog):
     for i in range(0, len(words), G.REC_WORDS):
         hdr = words[i]
         op, nterm = (hdr >> 21) & 15, (hdr >> 6) & 63
-        assert op <= G.OP_FILL and nterm <= 31
+        assert op <= G.OP_GCLOAD and nterm <= 31
         if op == G.OP_DOT:
             for k in range(nterm):
                 w0 = words[i + 1 + 2 * k]
