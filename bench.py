@@ -135,7 +135,7 @@ def _tvm_mads():
     sys.path.insert(0, os.path.join(ROOT, "kyber_amd", "csrc"))
     import gen_tower_vm as G
 
-    return {"bls12381": (G.build_bls12381_pair().mads(), G.build_bls12381_check().mads()),
+    return {"bls12381": (G.build_bls12381_pair().mads(), G.build_bls12381_check().mads(), G.build_bls12381_verify().mads()),
             "bn256": (G.build_bn256_pair().mads(), G.build_bn256_check().mads()),
             "bn254": (G.build_bn254_pair().mads(), G.build_bn254_check().mads())}
 
@@ -228,6 +228,8 @@ def other_workloads(rank, world, dist):
                 dist.all_reduce(tv, op=dist.ReduceOp.MAX)
             out[name]["bls_verify_pipeline_per_s"] = world * npair / float(tv[0].item()) * 1e3
             out[name]["bls_verify_pipeline_per_s_known_keys"] = world * npair / float(tv[1].item()) * 1e3
+            if name == "bls12381":  # the VERIFY program (generator lines from a table); hashing and unmarshalling are extra
+                out[name]["roofline"]["verify"] = _roof(npair / ms_v * 1e3, mads[name][2], g1b_ + g2b_ + 32 + 1, prof, name + "_check")
         if name == "bls12381":
             # node-wide MSM at 2^20 points: points sharded over the ranks, all-gather of the partial points
             n = 1 << 20
