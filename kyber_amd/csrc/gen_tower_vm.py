@@ -988,8 +988,10 @@ def bls_add_step(P, T, TX, TY, TZ, Q, tmp, L, PX, PY, fset, mask, extra=()):
     o += outs2(tmp[4], tmp[5], Acc2().prod(X, D))                 # G = X D
     P.dot(o, "add/c")
     o = []
-    o += outs2(TX[0], TX[1], Acc2().prod(LA, Ee).prod(LA, Ff).prod(LA.scale(-2), Gg))              # X3 = lambda (E + F - 2G)
-    o += outs2(TY[0], TY[1], Acc2().prod(TH.scale(3), Gg).prod(-TH, Ee).prod(-TH, Ff).prod(-Ee, Y))  # Y3 = theta (3G - E - F) - E Y
+    # E + F is one operand (two slots): five Fp2 products in X3, Y3 instead of seven -- Y3's record is the longest of
+    # the instruction, everything else waits for it
+    o += outs2(TX[0], TX[1], Acc2().prod(LA, Ee + Ff).prod(LA.scale(-2), Gg))                      # X3 = lambda (E + F - 2G)
+    o += outs2(TY[0], TY[1], Acc2().prod(TH.scale(3), Gg).prod(-TH, Ee + Ff).prod(-Ee, Y))          # Y3 = theta (3G - E - F) - E Y
     o += outs2(TZ[0], TZ[1], Acc2().prod(Z, Ee))                                                    # Z3 = Z E
     P.dot(o, "add/d")
     f = Tower.reg(fset)
@@ -1466,8 +1468,8 @@ def bn_add_step(P, T, TX, TY, TZ, Q, sign, tmp, L, PX, PY, fset, mask):
     o += outs2(tmp[4], tmp[5], Acc2().prod(X, D))
     P.dot(o, "add/c")
     o = []
-    o += outs2(TX[0], TX[1], Acc2().prod(LA, Ee).prod(LA, Ff).prod(LA.scale(-2), Gg))
-    o += outs2(TY[0], TY[1], Acc2().prod(TH.scale(3), Gg).prod(-TH, Ee).prod(-TH, Ff).prod(-Ee, Y))
+    o += outs2(TX[0], TX[1], Acc2().prod(LA, Ee + Ff).prod(LA.scale(-2), Gg))              # (E + F: one two-slot operand)
+    o += outs2(TY[0], TY[1], Acc2().prod(TH.scale(3), Gg).prod(-TH, Ee + Ff).prod(-Ee, Y))
     o += outs2(TZ[0], TZ[1], Acc2().prod(Z, Ee))
     P.dot(o, "add/d")
     f = Tower.reg(fset)
