@@ -245,6 +245,12 @@ def test_fused_verify_matches_hash_plus_pairing_check(bls):
     sig[7] = 0  # does not unmarshal (compression flag missing)
     X = X.copy()
     X[11] = 0xFF
+    # points at infinity (the ZCash encoding 0xC0 00 ..): a dead pair contributes 1 -- signature alone, key alone, both
+    inf1, inf2 = np.zeros(48, dtype=np.uint8), np.zeros(96, dtype=np.uint8)
+    inf1[0] = inf2[0] = 0xC0
+    sig[13] = inf1
+    X[17] = inf2
+    sig[19], X[19] = inf1, inf2
     ok_f, st_f = bls.batch_verify_g1(X, msgs, sig)
     G2 = np.tile(np.frombuffer(bls.G2_BASE, dtype=np.uint8), (n, 1))
     ok_r, st_r = bls.batch_validate_pairing(Hm, X, sig, G2)
@@ -252,8 +258,8 @@ def test_fused_verify_matches_hash_plus_pairing_check(bls):
     assert (ok_f == ok_r).all()
     exp = np.ones(n, dtype=bool)
     exp[::5] = False
-    exp[[7, 11]] = False
-    assert (ok_f.astype(bool) == exp).all()
+    exp[[7, 11, 13, 17]] = False  # e(H, pk) = 1 or e(sig, g2) = 1 alone is false; index 19 (both dead) is 1 = 1
+    assert (ok_f.astype(bool) == exp).all() and ok_f[19]
 
 
 def test_wrong_length_key_or_signature_fails_alone(bls):
