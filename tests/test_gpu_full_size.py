@@ -90,6 +90,39 @@ def test_pairing_suites_at_config_sizes(name, n):
     assert not st3.any().item() and torch.equal(ok.bool(), exp)
 
 
+def test_bls12381_fused_verification_at_config_size():
+    """configs[3] as sign/bls meets it: 2^16 (key, message, signature) triples through kyb_bls12381_verify_g1 (the VERIFY
+    program: the generator's Miller lines from a table) -- every valid triple accepted, every signature moved to the
+    neighbouring key rejected, and the same verdicts as the general product check on hash + signature + generator."""
+    import torch
+
+    from kyber_amd.pairing import bls12381 as m
+
+    n = 1 << 16
+    k = _shake(b"full/verify/k", n * 32).reshape(n, 32).copy()
+    k[:, 0] &= 0x3F
+    k = torch.from_numpy(k).cuda()
+    msgs = torch.from_numpy(_shake(b"full/verify/m", n * 32).reshape(n, 32).copy()).cuda()
+    g2b = torch.from_numpy(np.frombuffer(m.G2_BASE, dtype=np.uint8).copy()).cuda()
+    X, _ = m._mul(2, k, g2b, True)
+    Hm, st = m.batch_hash_g1(msgs)
+    assert not st.any().item()
+    sig, _ = m.g1_batch_mul(k, Hm)
+    ok, st = m.batch_verify_g1(X, msgs, sig)
+    assert not st.any().item() and ok.bool().all().item()
+    bad = sig.clone()
+    bad[1::2] = sig[0:-1:2]
+    okb, st = m.batch_verify_g1(X, msgs, bad)
+    exp = torch.ones(n, dtype=torch.bool, device="cuda")
+    exp[1::2] = False
+    assert not st.any().item() and torch.equal(okb.bool(), exp)
+    G2 = g2b.repeat(n, 1)
+    okr, st = m.batch_validate_pairing(Hm, X, bad, G2)
+    assert not st.any().item() and torch.equal(okr.bool(), exp)
+    okt, st = m.batch_verify_g1(X, msgs, bad, flags=m.F_TRUSTED(0))
+    assert not st.any().item() and torch.equal(okt.bool(), exp)
+
+
 @pytest.mark.parametrize("name,n", [("bls12381", 1 << 16), ("bn256", 1 << 18), ("bn254", 1 << 17)])
 def test_pairing_known_answers_inside_config_size_batches(name, n, golden_dir):
     """The oracle's known answers (tests/golden/<suite>_pair_kat.npz, written by make_golden_pair_kat.py: 384 pairs with
