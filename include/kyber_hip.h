@@ -344,7 +344,9 @@ int kyb_bn254_hash_g1_dev(size_t n, const void *d_msgs, size_t msg_len, const ui
  * MSM-shaped call sites do N x (Mul + Add) sequentially -- share.PubPoly.Eval (share/poly.go:340-348),
  * share.RecoverCommit (share/poly.go:449-476), bdn.AggregateSignatures / AggregatePublicKeys
  * (sign/bdn/bdn.go:126-181, mask.go:57-61).  Encodings are canonical, so the Pippenger result is
- * byte-identical to that sequential sum.  status[i] reports undecodable inputs; if any input is
+ * byte-identical to that sequential sum -- for every 32-byte scalar: an Ed25519 scalar that the
+ * reference's radix-16 recoding mangles (top digit above 8, see kyb_ed25519_mul) counts as the integer
+ * the reference's Mul multiplies by.  status[i] reports undecodable inputs; if any input is
  * rejected the output is all-zero bytes.  n == 0 yields the encoding of the identity.
  * The _dev variants work in a grow-only workspace per (device, stream).                            */
 int kyb_ed25519_msm(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t out[32], uint8_t *status);

@@ -100,6 +100,21 @@ struct Split<A, decltype((void)A::SPLIT)> {
     static constexpr int value = A::SPLIT, bits = A::SPLIT_BITS, cmax = 16;
 };
 
+// Effective<A>: an adapter may replace (k, P) by an equivalent pair before the digits are cut -- Ed25519 maps a scalar
+// the reference's radix-16 recoding would mangle (top digit above 8, dropped by the table select: ge.go:374-390,
+// 419-435) to the integer the reference actually multiplies by, negating the point when that integer is negative, so
+// that the sum equals N x Mul + N x Add for EVERY 32-byte scalar, not only the reduced ones its callers produce.
+template <class A, class = void>
+struct Effective {
+    template <class Aff>
+    __device__ static void apply(uint32_t (&)[8], Aff&, int) {}
+};
+template <class A>
+struct Effective<A, decltype((void)A::HAS_EFFECTIVE)> {
+    template <class Aff>
+    __device__ static void apply(uint32_t (&k)[8], Aff& a, int bits) { A::effective(k, a, bits); }
+};
+
 // Register budget of the decode kernel in waves per SIMD: it is bound by its histogram atomics and digit stores, so
 // co-resident waves pay (two for the Weierstrass adapters: 1.27 -> 0.98 ms; an adapter may ask for more).
 template <class A, class = void>
@@ -126,6 +141,7 @@ __global__ __launch_bounds__(64, DecodeWaves<A>::value) void decode_kernel(Plan 
     if constexpr (S == 1) {
         st = A::decode(a[0], points + A::wire_size(p.flags) * i, p.flags);
         A::scalar_words(k[0], scalars + 32 * i);
+        Effective<A>::apply(k[0], a[0], p.bits);
     } else {
         st = A::decode_split(a, k, points + A::wire_size(p.flags) * i, scalars + 32 * i, p.flags);
     }

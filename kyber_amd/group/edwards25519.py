@@ -121,8 +121,9 @@ def commit(scalars, base=None, vartime: bool = False):
 
 def msm(scalars, points, scalar_bits: int = 256):
     """(out, status): out = sum_i scalars[i] * points[i] as one 32-byte point -- what PubPoly.Eval /
-    RecoverCommit (share/poly.go:340-348, 449-476) compute with N x (Mul + Add).  Scalars are plain
-    256-bit little-endian integers (never reduced mod l).  If any status is non-zero the output is
+    RecoverCommit (share/poly.go:340-348, 449-476) compute with N x (Mul + Add).  Scalars are 256-bit
+    little-endian integers, never reduced mod l; one whose top radix-16 digit the reference's recoding drops (>= ~2^255)
+    counts as the integer the reference's Mul multiplies by, as in batch_mul.  If any status is non-zero the output is
     all-zero bytes.  scalar_bits < 256 (host buffers): every scalar is below 2^scalar_bits, higher bits are ignored
     (KYB_F_SCALAR_BITS: proportionally fewer windows)."""
     lib = load()

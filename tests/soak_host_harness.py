@@ -1,5 +1,5 @@
 """Randomised soak of the device headers compiled for the host (tests/host_harness.cpp) against the Python oracles:
-python tools/soak_host_harness.py [seed].  About 1 000 scalar multiplications over the five groups (edge scalars around
+python tests/soak_host_harness.py [seed] (it lives under tests/ because it uses the oracles).  About 1 000 scalar multiplications over the five groups (edge scalars around
 the group orders, every BLS12-381 flag combination), the Ed25519 window walk in both scalar semantics; prints the number of mismatches.  Not part of the test suite (the suite runs a fixed subset); run it after
 touching mont.cuh / tower.cuh / curve.cuh / fe25519.cuh / ge25519.cuh.  No GPU needed."""
 import os

@@ -1,0 +1,121 @@
+"""Randomised GPU soak against the oracles, seed after seed (opt-in: KYB_SOAK_SEEDS=<count>, default 1 seed so that the
+regular `-m gpu` run stays short): what the fixed-seed parity tests check, on fresh inputs every seed -- Ed25519 fixed /
+variable base (both scalar semantics) and MSM element for element against the C oracle with edge scalars mixed in; G1 / G2
+scalar multiplication, Pair bytes, ValidatePairing and the fused verification of the three pairing suites against the
+Python oracles on a few elements per seed (an oracle pairing takes about a second)."""
+import hashlib
+import importlib
+import os
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEEDS = list(range(int(os.environ.get("KYB_SOAK_SEEDS", "1"))))
+
+
+def _shake(label, n):
+    return np.frombuffer(hashlib.shake_256(label).digest(n), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_ed25519_soak(seed):
+    import torch
+
+    from kyber_amd.group import edwards25519 as ed
+    from oracle import ed25519 as O
+    from tests import _oracle_c as OC
+
+    n = 4096
+    rng = random.Random(1000 + seed)
+    s = _shake(b"soak/ed/s/%d" % seed, n * 32).reshape(n, 32).copy()
+    h = _shake(b"soak/ed/h/%d" % seed, n * 32).reshape(n, 32).copy()
+    h[:, 31] &= 0x0F
+    # edge scalars: 0, 1, l - 1, l, l + 1, 2^252, 2^255 - 1, 2^255, 2^256 - 1, and a few with long zero / one runs
+    edge = [0, 1, O.L - 1, O.L, O.L + 1, 1 << 252, (1 << 255) - 1, 1 << 255, (1 << 256) - 1,
+            ((1 << 256) - 1) ^ ((1 << 128) - 1), (1 << 128) - 1, 0x8888888888888888888888888888888888888888888888888888888888888888 >> 1]
+    for j, e in enumerate(edge):
+        s[rng.randrange(n) if j else 0] = np.frombuffer(e.to_bytes(32, "little"), dtype=np.uint8)
+    d_s, d_h = torch.from_numpy(s).cuda(), torch.from_numpy(h).cuda()
+    P = ed.batch_mul_base(d_h)
+    assert (OC.ed_mul_base(h) == P.cpu().numpy()).all()
+    Pb = ed.batch_mul_base(d_s)  # the edge scalars through the fixed-base kernel too
+    assert (OC.ed_mul_base(s) == Pb.cpu().numpy()).all()
+    for vt in (False, True):
+        A, st = ed.batch_mul(d_s, P, vartime=vt)
+        exp, est = OC.ed_mul(s, P.cpu().numpy(), vartime=vt)
+        assert (st.cpu().numpy() == est).all() and (A.cpu().numpy() == exp).all(), ("vartime", vt)
+    m, _ = ed.msm(d_s, P)
+    exp, rc = OC.ed_msm(s, P.cpu().numpy())
+    assert rc == 0 and bytes(m.cpu().numpy()) == bytes(exp)
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+@pytest.mark.parametrize("name", ["bls12381", "bn256", "bn254"])
+def test_pairing_suite_soak(name, seed):
+    m = importlib.import_module("kyber_amd.pairing." + name)
+    O = importlib.import_module("oracle." + name)
+    rng = random.Random(2000 + seed)
+    order = O.R if name == "bls12381" else O.ORDER
+    n = 3
+    ks = [rng.randrange(1, order) for _ in range(n)]
+    hs = [rng.randrange(1, order) for _ in range(n)]
+    g1, g2 = O.G1_GEN, O.G2_GEN
+    if name == "bls12381":
+        e1, e2 = O.g1_compress, O.g2_compress
+        gtb = lambda a: O.gt_to_bytes(a)
+    else:
+        e1, e2 = O.g1_marshal, O.g2_marshal
+        gtb = lambda a: O.gt_marshal(a)
+    Ps = [O.g1_mul(h, g1) for h in hs]
+    Qs = [O.g2_mul(k, g2) for k in ks]
+    P = np.stack([np.frombuffer(e1(p), dtype=np.uint8) for p in Ps])
+    Q = np.stack([np.frombuffer(e2(q), dtype=np.uint8) for q in Qs])
+    kb = np.stack([np.frombuffer(k.to_bytes(32, "big"), dtype=np.uint8) for k in ks])
+    # scalar multiplications
+    kP, st = m.g1_batch_mul(kb, P)
+    assert not np.asarray(st).any()
+    assert [bytes(r) for r in kP] == [e1(O.g1_mul(k, p)) for k, p in zip(ks, Ps)]
+    kQ, st = m.g2_batch_mul(kb, Q)
+    assert not np.asarray(st).any()
+    assert [bytes(r) for r in kQ] == [e2(O.g2_mul(k, q)) for k, q in zip(ks, Qs)]
+    # pairings, byte for byte
+    gt, st = m.batch_pair(P, Q)
+    assert not np.asarray(st).any()
+    assert [bytes(r) for r in gt] == [gtb(O.pair(p, q)) for p, q in zip(Ps, Qs)]
+    # e(kP, Q) == e(P, kQ); a forged entry fails
+    ok, st = m.batch_validate_pairing(kP, Q, P, kQ)
+    assert not np.asarray(st).any() and np.asarray(ok).astype(bool).all()
+    forged = np.array(kP).copy()
+    forged[1] = P[1]
+    ok, st = m.batch_validate_pairing(forged, Q, P, kQ)
+    assert list(np.asarray(ok).astype(bool)) == [True, False, True]
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_bls12381_fused_verification_soak(seed):
+    """sign/bls Verify on BLS12-381: hash to G1 by the oracle's RFC 9380 restatement, signature = [x] H(m) by the oracle;
+    the engine's fused verification accepts them and rejects a swapped pair"""
+    from kyber_amd.pairing import bls12381 as m
+    from oracle import bls12381 as O
+
+    rng = random.Random(3000 + seed)
+    n = 4
+    xs = [rng.randrange(1, O.R) for _ in range(n)]
+    msgs = np.stack([_shake(b"soak/fv/%d/%d" % (seed, i), 32) for i in range(n)])
+    Hm, st = m.batch_hash_g1(msgs)
+    assert not np.asarray(st).any()
+    hpts = [O.hash_to_g1(bytes(mm), m.DOMAIN_G1) for mm in msgs]
+    assert [bytes(r) for r in Hm] == [O.g1_compress(h) for h in hpts]
+    X = np.stack([np.frombuffer(O.g2_compress(O.g2_mul(x, O.G2_GEN)), dtype=np.uint8) for x in xs])
+    xb = np.stack([np.frombuffer(x.to_bytes(32, "big"), dtype=np.uint8) for x in xs])
+    sig, _ = m.g1_batch_mul(xb, Hm)
+    assert [bytes(r) for r in sig] == [O.g1_compress(O.g1_mul(x, h)) for x, h in zip(xs, hpts)]
+    ok, st = m.batch_verify_g1(X, msgs, sig)
+    assert not np.asarray(st).any() and np.asarray(ok).astype(bool).all()
+    swapped = np.array(sig).copy()
+    swapped[[0, 1]] = swapped[[1, 0]]
+    ok, st = m.batch_verify_g1(X, msgs, swapped)
+    assert list(np.asarray(ok).astype(bool)) == [False, False, True, True]
