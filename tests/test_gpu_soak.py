@@ -119,3 +119,72 @@ def test_bls12381_fused_verification_soak(seed):
     swapped[[0, 1]] = swapped[[1, 0]]
     ok, st = m.batch_verify_g1(X, msgs, swapped)
     assert list(np.asarray(ok).astype(bool)) == [False, False, True, True]
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+@pytest.mark.parametrize("name", ["bls12381", "bn256", "bn254"])
+def test_pairing_suite_msm_and_hash_soak(name, seed):
+    """G1 / G2 MSM with scalars on both sides of the group order (mod.Int encodings are plain integers: 0, 1, n - 1, n,
+    n + 1, 2^255, 2^256 - 1 mixed into random ones), short-scalar MSM, and hash-to-G1 of random messages, against the
+    oracle's sums"""
+    m = importlib.import_module("kyber_amd.pairing." + name)
+    O = importlib.import_module("oracle." + name)
+    rng = random.Random(4000 + seed)
+    order = O.R if name == "bls12381" else O.ORDER
+    e1, e2 = (O.g1_compress, O.g2_compress) if name == "bls12381" else (O.g1_marshal, O.g2_marshal)
+    n = 24
+    ks = [rng.getrandbits(256) for _ in range(n)]
+    for j, e in enumerate([0, 1, order - 1, order, order + 1, 1 << 255, (1 << 256) - 1, (1 << 128) - 1]):
+        ks[2 * j] = e
+    kb = np.stack([np.frombuffer(k.to_bytes(32, "big"), dtype=np.uint8) for k in ks])
+    Ps = [O.g1_mul(rng.randrange(1, order), O.G1_GEN) for _ in range(n)]
+    Qs = [O.g2_mul(rng.randrange(1, order), O.G2_GEN) for _ in range(8)]
+    P = np.stack([np.frombuffer(e1(p), dtype=np.uint8) for p in Ps])
+    Q = np.stack([np.frombuffer(e2(q), dtype=np.uint8) for q in Qs])
+    acc = None
+    for k, p in zip(ks, Ps):
+        acc = O.g1_add(acc, O.g1_mul(k % order, p))
+    out, st = m.g1_msm(kb, P)
+    assert not np.asarray(st).any() and bytes(out) == e1(acc)
+    acc = None
+    for k, q in zip(ks[:8], Qs):
+        acc = O.g2_add(acc, O.g2_mul(k % order, q))
+    out, st = m.g2_msm(kb[:8], Q)
+    assert not np.asarray(st).any() and bytes(out) == e2(acc)
+    # element-wise multiplication by the same edge scalars
+    kP, st = m.g1_batch_mul(kb, P)
+    assert not np.asarray(st).any()
+    assert [bytes(r) for r in kP] == [e1(O.g1_mul(k % order, p)) for k, p in zip(ks, Ps)]
+    # hash to G1 (sign/bls Hash): the suite's own map, random message bytes
+    msgs = np.stack([_shake(b"soak/hash/%s/%d/%d" % (name.encode(), seed, i), 32) for i in range(6)])
+    Hm, st = m.batch_hash_g1(msgs)
+    assert not np.asarray(st).any()
+    if name == "bls12381":
+        exp = [e1(O.hash_to_g1(bytes(x), m.DOMAIN_G1)) for x in msgs]
+    else:
+        exp = [e1(O.hash_to_g1(bytes(x))) for x in msgs]
+    assert [bytes(r) for r in Hm] == exp
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_ed25519_unmarshal_and_hash_soak(seed):
+    """random 32-byte strings through the batch UnmarshalBinary (about half decode) and random messages through Hash,
+    against the oracle"""
+    from kyber_amd.group import edwards25519 as ed
+    from oracle import ed25519 as O
+
+    n = 512
+    raw = _shake(b"soak/ed/unmarshal/%d" % seed, n * 32).reshape(n, 32).copy()
+    out, st = ed.batch_unmarshal(raw)
+    out, st = np.asarray(out), np.asarray(st)
+    for i in range(n):
+        pt = O.decode(bytes(raw[i]))
+        assert (st[i] == 0) == (pt is not None), i
+        if pt is not None:
+            assert bytes(out[i]) == O.encode(pt), i
+    assert 100 < int((st == 0).sum()) < 400
+    dst = b"soak-dst-%d" % seed
+    for ln in (1, 31, 64, 129):  # equal-length batches (the call's contract), lengths around the SHA-512 block
+        msgs = [bytes(_shake(b"soak/ed/hash/%d/%d/%d" % (seed, ln, i), ln)) for i in range(4)]
+        Hm = ed.batch_hash(msgs, dst)
+        assert [bytes(r) for r in np.asarray(Hm)] == [O.hash_to_curve(x, dst) for x in msgs], ln
