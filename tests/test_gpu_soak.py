@@ -41,6 +41,17 @@ def test_ed25519_soak(seed):
     d_s, d_h = torch.from_numpy(s).cuda(), torch.from_numpy(h).cuda()
     P = ed.batch_mul_base(d_h)
     assert (OC.ed_mul_base(h) == P.cpu().numpy()).all()
+    # points outside the prime-order subgroup: the small-order points themselves and prime-order points shifted by
+    # them, some sitting on the edge scalars' rows
+    import json
+
+    small = [bytes.fromhex(x) for x in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ed25519_misc.json")))["small_order"]]
+    Pn = P.cpu().numpy().copy()
+    for j, t in enumerate(small):
+        Pn[rng.randrange(n)] = np.frombuffer(t, dtype=np.uint8)
+        r = rng.randrange(n) if j else 0
+        Pn[r] = np.frombuffer(O.encode(O.add(O.decode(bytes(Pn[r])), O.decode(t))), dtype=np.uint8)
+    P = torch.from_numpy(Pn).cuda()
     Pb = ed.batch_mul_base(d_s)  # the edge scalars through the fixed-base kernel too
     assert (OC.ed_mul_base(s) == Pb.cpu().numpy()).all()
     for vt in (False, True):
