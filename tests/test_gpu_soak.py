@@ -239,3 +239,35 @@ def test_pairing_suite_unmarshal_mutation_soak(name, seed):
                 accepted += 1
                 assert bytes(out[i]) == enc[group](pt), (name, group, i)
         assert accepted >= cnt // 8
+
+
+@pytest.mark.parametrize("name", ["bls12381", "bn256", "bn254"])
+def test_pairing_batch_shapes(name):
+    """the tower machine works on 64 pairings per workgroup: batches of 0, 1, 2, 63, 64, 65 and 129 pairings give, row
+    for row, the bytes of the 129-row batch (partial workgroups, a workgroup with one live lane, grid-stride reuse)"""
+    m = importlib.import_module("kyber_amd.pairing." + name)
+    n = 129
+    raw = _shake(b"shapes/" + name.encode(), 2 * n * 32).reshape(2, n, 32).copy()
+    raw[:, :, 0] &= 0x3F
+    g1b = np.frombuffer(m.G1_BASE, dtype=np.uint8)
+    g2b = np.frombuffer(m.G2_BASE, dtype=np.uint8)
+    P, _ = m._mul(1, raw[0], g1b, True)
+    Q, _ = m._mul(2, raw[1], g2b, True)
+    P, Q = np.asarray(P), np.asarray(Q)
+    gt, st = m.batch_pair(P, Q)
+    gt = np.asarray(gt)
+    assert not np.asarray(st).any()
+    kP, _ = m.g1_batch_mul(raw[1], P)
+    kQ, _ = m.g2_batch_mul(raw[1], Q)
+    kP, kQ = np.array(kP), np.asarray(kQ)
+    kP[5] = P[5]  # one false row
+    ok, st = m.batch_validate_pairing(kP, Q, P, kQ)
+    ok = np.asarray(ok).astype(bool)
+    assert not ok[5] and ok.sum() == n - 1
+    for k in (0, 1, 2, 63, 64, 65):
+        g, s = m.batch_pair(P[:k], Q[:k])
+        assert np.asarray(g).shape == (k, gt.shape[1]) and (np.asarray(g) == gt[:k]).all(), k
+        g, s = m.batch_pair(P[n - k:], Q[n - k:])
+        assert (np.asarray(g) == gt[n - k:]).all(), k
+        o, s = m.batch_validate_pairing(kP[:k], Q[:k], P[:k], kQ[:k])
+        assert (np.asarray(o).astype(bool) == ok[:k]).all(), k
