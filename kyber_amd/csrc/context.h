@@ -48,7 +48,8 @@ struct DeviceCtx {
     };
     std::map<std::pair<int, hipStream_t>, StreamBuf> sws;
     // grow-only device staging buffers of the host-buffer entry points (no hipMalloc / hipFree per call);
-    // stage_mu serialises those calls per device -- they synchronise the device anyway
+    // stage_mu serialises those calls per device -- they synchronise the device anyway.  LOCK ORDER: stage_mu (StageScope)
+    // before enq_mu, never the other way round
     static constexpr int NSTAGE = 8;
     void* stage[NSTAGE] = {};
     size_t stage_cap[NSTAGE] = {};

@@ -720,9 +720,12 @@ int run_host_single(size_t n, const uint8_t* scalars, const uint8_t* points, uin
     DeviceCtx* ctx;
     int rc = get_ctx(&ctx);
     if (rc) return rc;
-    // the pipeline lives in the per-device workspace: host-buffer MSM calls on one device are serialised
-    std::lock_guard<std::recursive_mutex> ws_lock(ctx->enq_mu);
+    // the pipeline lives in the per-device workspace: host-buffer MSM calls on one device are serialised.  Lock order
+    // as in every other host-buffer call -- the staging pool first, the enqueue mutex second (taken the other way round
+    // here until the concurrency test of tests/test_gpu_soak.py ran this against a host-buffer multiplication on a
+    // second thread: each held what the other waited for)
     StageScope sc_(ctx);
+    std::lock_guard<std::recursive_mutex> ws_lock(ctx->enq_mu);
     StageBuf d_s, d_p, d_o, d_st;
     rc = d_s.upload(scalars, n * 32);
     if (rc == KYB_OK) rc = d_p.upload(points, n * A::wire_size(flags));
@@ -867,8 +870,8 @@ int poly_eval_host(size_t n, const uint32_t* idx, size_t t, const uint8_t* commi
     DeviceCtx* ctx;
     int rc = get_ctx(&ctx);
     if (rc) return rc;
+    StageScope sc_(ctx);  // staging pool first, enqueue mutex second (the order of every host-buffer call)
     std::lock_guard<std::recursive_mutex> ws_lock(ctx->enq_mu);
-    StageScope sc_(ctx);
     StageBuf d_i, d_c, d_o, d_st;
     rc = d_i.upload(idx, n * 4);
     if (rc == KYB_OK) rc = d_c.upload(commits, t * A::wire_size(flags));

@@ -271,3 +271,69 @@ def test_pairing_batch_shapes(name):
         assert (np.asarray(g) == gt[n - k:]).all(), k
         o, s = m.batch_validate_pairing(kP[:k], Q[:k], P[:k], kQ[:k])
         assert (np.asarray(o).astype(bool) == ok[:k]).all(), k
+
+
+def test_concurrent_host_threads_and_streams():
+    """four host threads hammer different entry points at once -- host-buffer calls (staging pool, page-locked slots,
+    per-device mutex) and device-tensor calls on their own streams (per-(kind, stream) workspaces) -- and every call
+    returns what the same call returned alone"""
+    import threading
+
+    import torch
+
+    from kyber_amd.group import edwards25519 as ed
+    from kyber_amd.pairing import bls12381 as bls, bn256 as bn
+
+    n = 20000
+    s = _shake(b"conc/s", n * 32).reshape(n, 32).copy()
+    h = _shake(b"conc/h", n * 32).reshape(n, 32).copy()
+    h[:, 31] &= 0x0F
+    P = np.asarray(ed.batch_mul_base(h))
+    ref_mul = np.asarray(ed.batch_mul(s, P)[0])
+    ref_msm = bytes(np.asarray(ed.msm(s[:5000], P[:5000])[0]))
+    m = 256
+    raw = _shake(b"conc/p", 4 * m * 32).reshape(4, m, 32).copy()
+    raw[:, :, 0] &= 0x3F
+    bP, _ = bls._mul(1, raw[0], np.frombuffer(bls.G1_BASE, dtype=np.uint8), True)
+    bQ, _ = bls._mul(2, raw[1], np.frombuffer(bls.G2_BASE, dtype=np.uint8), True)
+    nP, _ = bn._mul(1, raw[2], np.frombuffer(bn.G1_BASE, dtype=np.uint8), True)
+    nQ, _ = bn._mul(2, raw[3], np.frombuffer(bn.G2_BASE, dtype=np.uint8), True)
+    bP, bQ, nP, nQ = (np.asarray(x) for x in (bP, bQ, nP, nQ))
+    ref_bls = np.asarray(bls.batch_pair(bP, bQ)[0])
+    ref_bn = np.asarray(bn.batch_pair(nP, nQ)[0])
+    errors = []
+
+    def run(fn, check, reps):
+        try:
+            for _ in range(reps):
+                if not check(fn()):
+                    errors.append(fn.__name__ if hasattr(fn, "__name__") else "mismatch")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def dev_mul():
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            out, _ = ed.batch_mul(torch.from_numpy(s).cuda(), torch.from_numpy(P).cuda())
+            st.synchronize()
+            return out.cpu().numpy()
+
+    def dev_pair():
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            out, _ = bls.batch_pair(torch.from_numpy(bP).cuda(), torch.from_numpy(bQ).cuda())
+            st.synchronize()
+            return out.cpu().numpy()
+
+    jobs = [(lambda: np.asarray(ed.batch_mul(s, P)[0]), lambda r: (r == ref_mul).all(), 4),
+            (lambda: bytes(np.asarray(ed.msm(s[:5000], P[:5000])[0])), lambda r: r == ref_msm, 6),
+            (lambda: np.asarray(bls.batch_pair(bP, bQ)[0]), lambda r: (r == ref_bls).all(), 6),
+            (lambda: np.asarray(bn.batch_pair(nP, nQ)[0]), lambda r: (r == ref_bn).all(), 6),
+            (dev_mul, lambda r: (r == ref_mul).all(), 4),
+            (dev_pair, lambda r: (r == ref_bls).all(), 6)]
+    threads = [threading.Thread(target=run, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
