@@ -765,34 +765,12 @@ struct EdMsm {
     __device__ static void scalar_words(uint32_t (&k)[8], const uint8_t* wire) {
         load_words8(k, reinterpret_cast<const uint32_t*>(wire));
     }
-    // The integer geScalarMult multiplies by (msm.cuh Effective): with e[63] = (a + 0x0888..8) >> 252 the top digit of
-    // the reference's signed radix-16 recoding, a scalar with e[63] > 8 loses that digit -- a - e[63] 2^252, which is
-    // a mod 2^252 when the recoding carried nothing into the top digit and a mod 2^252 - 2^252 (negative: -P takes
-    // its magnitude) when it did.  Scalars cut short by KYB_F_SCALAR_BITS never reach the top digit.
+    // msm.cuh Effective: the integer geScalarMult multiplies by (ge25519.cuh ed_effective_scalar); a negative one
+    // takes -P.  Scalars cut short by KYB_F_SCALAR_BITS never reach the top digit.
     static constexpr bool HAS_EFFECTIVE = true;
     __device__ static void effective(uint32_t (&k)[8], Aff& p, int bits) {
         if (bits < 253) return;
-        uint32_t c = 0, t7 = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint64_t s = (uint64_t)k[j] + (j < 7 ? 0x88888888u : 0x08888888u) + c;
-            t7 = (uint32_t)s;
-            c = (uint32_t)(s >> 32);
-        }
-        const uint32_t e63 = (c << 4) | (t7 >> 28);
-        if (e63 <= 8) return;
-        const uint32_t carried = e63 - (k[7] >> 28);  // 0 or 1
-        k[7] &= 0x0fffffffu;
-        if (carried) {
-            uint32_t b = 0;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint64_t d = (uint64_t)(j == 7 ? 0x10000000u : 0u) - k[j] - b;
-                k[j] = (uint32_t)d;
-                b = (uint32_t)(d >> 63);
-            }
-            ge_precomp_cneg(p, true);
-        }
+        if (ed_effective_scalar(k)) ge_precomp_cneg(p, true);
     }
     __device__ static void identity(Acc& a) { ge_p3_0(a); }
     __device__ static void madd(Acc& acc, const Aff& p, bool neg) {

@@ -187,4 +187,32 @@ KYB_DEV void recode16(int8_t e[65], const uint32_t a[8], bool full256) {
     e[64] = (int8_t)c2;
 }
 
+// The integer the recoding above makes geScalarMult / geScalarMultBase multiply by, as a 256-bit magnitude and a sign
+// (for the callers that cut their own digits: the MSM).  With e[63] = (a + 0x0888..8) >> 252 the top digit of the
+// signed radix-16 recoding, a scalar with e[63] > 8 loses that digit: a - e[63] 2^252, which is a mod 2^252 when the
+// recoding carried nothing into the top digit and (a mod 2^252) - 2^252 -- negative -- when it did.  Returns true
+// when the result is negative (k then holds its magnitude).  Same function as oracle effective_scalar_consttime.
+KYB_DEV bool ed_effective_scalar(uint32_t (&k)[8]) {
+    uint32_t c = 0, t7 = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint64_t s = (uint64_t)k[j] + (j < 7 ? 0x88888888u : 0x08888888u) + c;
+        t7 = (uint32_t)s;
+        c = (uint32_t)(s >> 32);
+    }
+    const uint32_t e63 = (c << 4) | (t7 >> 28);
+    if (e63 <= 8) return false;
+    const uint32_t carried = e63 - (k[7] >> 28);  // 0 or 1
+    k[7] &= 0x0fffffffu;
+    if (!carried) return false;
+    uint32_t b = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint64_t d = (uint64_t)(j == 7 ? 0x10000000u : 0u) - k[j] - b;
+        k[j] = (uint32_t)d;
+        b = (uint32_t)(d >> 63);
+    }
+    return true;
+}
+
 }  // namespace kyb

@@ -187,6 +187,14 @@ void hh_ed_fe_op(int op, const uint8_t* f40, const uint8_t* g40, uint8_t* out40)
     }
     memcpy(out40, h.v, 40);
 }
+// ge25519.cuh ed_effective_scalar: k32 (little-endian) -> magnitude in out32, returns the sign (1 = negative)
+int hh_ed_effective_scalar(const uint8_t* k32, uint8_t* out32) {
+    uint32_t k[8];
+    memcpy(k, k32, 32);
+    const bool neg = ed_effective_scalar(k);
+    memcpy(out32, k, 32);
+    return neg ? 1 : 0;
+}
 // out = k * P with the kernels' own building blocks: decode, signed radix-16 recoding, 8-entry cached table,
 // 4 doublings + 1 addition per window (the walk of ed25519_mul_kernel, ge.go:443-502), encode.  vartime = the
 // all-256-bits semantics of ge_mult_vartime.go.  Returns 0, or 1 when P does not decode.

@@ -2,6 +2,7 @@
 the host, against the reference's RFC 9380 vectors (group/edwards25519/point_test.go:369-445) and the oracle."""
 import json
 import os
+import random
 
 from oracle import ed25519 as O
 from tests import _host_harness as H
@@ -102,3 +103,19 @@ def test_scalar_mul_walk_vs_oracle(golden_dir):
                     assert st == 1 and out == bytes(32)
                 else:
                     assert (st, out) == (0, exp), (vt, s.hex(), p.hex())
+
+
+def test_effective_scalar_equals_the_reference_recoding():
+    """ge25519.cuh ed_effective_scalar (what the MSM's digit cutter is given) == oracle effective_scalar_consttime (the
+    integer geScalarMult's radix-16 recoding multiplies by, ge.go:374-390, 419-435) on 20 000 random 256-bit scalars
+    and the boundaries of the top digit"""
+    rng = random.Random(77)
+    C8 = int("0" + "8" * 63, 16)
+    edge = [0, 1, (1 << 256) - 1, 1 << 255, (1 << 255) - 1, C8, C8 - 1, (1 << 256) - 1 - C8, 8 << 252, 9 << 252,
+            (9 << 252) - 1, (8 << 252) + C8, (1 << 252) - 1, (15 << 252) + (1 << 252) - 1, 15 << 252,
+            (7 << 252) + (1 << 252) - C8, (8 << 252) + (1 << 252) - C8, (8 << 252) + (1 << 252) - C8 - 1, O.L, O.L - 1]
+    for i in range(20000):
+        a = edge[i] if i < len(edge) else rng.getrandbits(256)
+        neg, mag = H.call("hh_ed_effective_scalar", a.to_bytes(32, "little"), out_sizes=(32,))
+        v = int.from_bytes(mag, "little")
+        assert (-v if neg else v) == O.effective_scalar_consttime(a.to_bytes(32, "little")), hex(a)
