@@ -229,7 +229,7 @@ def other_workloads(rank, world, dist):
             out[name]["bls_verify_pipeline_per_s"] = world * npair / float(tv[0].item()) * 1e3
             out[name]["bls_verify_pipeline_per_s_known_keys"] = world * npair / float(tv[1].item()) * 1e3
             if name == "bls12381":  # the VERIFY program (generator lines from a table); hashing and unmarshalling are extra
-                out[name]["roofline"]["verify"] = _roof(npair / ms_v * 1e3, mads[name][2], g1b_ + g2b_ + 32 + 1, prof, name + "_check")
+                out[name]["roofline"]["verify"] = _roof(npair / ms_v * 1e3, mads[name][2], g1b_ + g2b_ + 32 + 1, prof, name + "_verify")
         if name == "bls12381":
             # node-wide MSM at 2^20 points: points sharded over the ranks, all-gather of the partial points
             n = 1 << 20

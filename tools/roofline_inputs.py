@@ -59,6 +59,7 @@ res = {"_comment": "Inputs bench.py reads for its roofline objects; every number
 for key, prefix, sub, units in (("ed25519_mul", "ed", "ed25519_mul_kernel<true>", 1 << 20),
                                 ("bls12381_pair", "bls12381", "bls12381_tvm_kernel<0>", 1 << 16),
                                 ("bls12381_check", "bls12381", "bls12381_tvm_kernel<1>", 1 << 16),
+                                ("bls12381_verify", "verify", "bls12381_tvm_kernel<2>", 1 << 16),
                                 ("bn256_pair", "bn256", "bn256_tvm_kernel<0>", 1 << 18),
                                 ("bn256_check", "bn256", "bn256_tvm_kernel<1>", 1 << 18),
                                 ("bn254_pair", "bn254", "bn254_tvm_kernel<0>", 1 << 18),
