@@ -331,9 +331,11 @@ def test_concurrent_host_threads_and_streams():
             (lambda: np.asarray(bn.batch_pair(nP, nQ)[0]), lambda r: (r == ref_bn).all(), 6),
             (dev_mul, lambda r: (r == ref_mul).all(), 4),
             (dev_pair, lambda r: (r == ref_bls).all(), 6)]
-    threads = [threading.Thread(target=run, args=j) for j in jobs]
+    # daemon threads and a bounded join: a deadlock fails the test instead of hanging the run (and the interpreter's exit)
+    threads = [threading.Thread(target=run, args=j, daemon=True) for j in jobs]
     for t in threads:
         t.start()
     for t in threads:
-        t.join()
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "host threads are stuck: lock order?"
     assert not errors, errors
