@@ -506,8 +506,9 @@ def final_exp(f):
     five-exponentiation chain of final_exp_kilic_chain() below, which is NOT the canonical exponent (p^4-p^2+1)/r but
     three times it -- test_oracle_bls12381.py checks that the chain, restated from the published code, equals exactly
     this cube (gnark-crypto documents the same cofactor 3 for its FinalExponentiation).  ValidatePairing is unaffected
-    (gcd(3, r) = 1); Suite.Pair's GT value is the cube of the canonical reduced pairing.  GT bytes remain unpinned by
-    the reference's own tests; round 1 of this repo used the canonical exponent."""
+    (gcd(3, r) = 1); Suite.Pair's GT value is the cube of the canonical reduced pairing.  Pinned by the reference's IBE
+    vector (encrypt/ibe/ibe_test.go:202-245): the cube decrypts it, the canonical exponent does not
+    (tests/test_oracle_bls12381.py::test_ibe_vector_pins_gt_bytes); round 1 of this repo used the canonical exponent."""
     f = f12_mul(f12_conj(f), f12_inv(f))  # ^(p^6 - 1)
     f = f12_mul(f12_frob(f, 2), f)  # ^(p^2 + 1)
     return f12_pow(f, 3 * HARD_EXP)
@@ -557,7 +558,9 @@ def pair_check(p1, q1, p2, q2) -> bool:
 
 def gt_to_bytes(a) -> bytes:
     """576 bytes, big-endian Fp, reverse tower order (Fp12.c1 then c0; within Fp6 c2,c1,c0; within
-    Fp2 c1,c0) -- kilic's layout as recalled in SURVEY.md Appendix A (unverifiable offline)."""
+    Fp2 c1,c0) -- kilic's layout, PINNED together with the exponent of final_exp() by the
+    reference's IBE interop vector (encrypt/ibe/ibe_test.go:202-245, tests/golden/bls12381_ibe.json: decryption hashes
+    these 576 bytes; tests/test_oracle_bls12381.py::test_ibe_vector_pins_gt_bytes)."""
     out = b""
     for half in (1, 0):  # c1 (odd w-powers) first
         for m in (2, 1, 0):

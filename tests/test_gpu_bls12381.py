@@ -503,3 +503,36 @@ def test_batch_unmarshal_zcash_fixtures_flags_and_device_path(bls, golden_dir):
     assert st[0] == 0 and bytes(out[0]) == c
     out, st = bls.g1_batch_unmarshal(b"")
     assert out.shape == (0, 48) and st.shape == (0,)
+
+
+def test_ibe_vector_pins_pair_bytes_on_the_engine(bls, golden_dir):
+    """encrypt/ibe/ibe_test.go:202-245 through the engine: DecryptCCAonG1 (ibe.go:100-135) hashes the 576 bytes of
+    Suite.Pair(U, beacon) -- the one vector in the reference that fixes BLS12-381 GT BYTES.  The GPU's bytes must
+    decrypt to deadbeef x 4; the same vector placed in a 256-pair batch must give the same bytes in every slot; and
+    the CCA check r*P == U (ibe.go:123-131) is replayed with the engine's G1 multiplication on a ciphertext made by
+    the oracle (the vector's own U predates today's h3, see tests/test_oracle_bls12381.py)."""
+    from tests.test_oracle_bls12381 import _ibe_decrypt, _ibe_h3
+    v = json.load(open(os.path.join(golden_dir, "bls12381_ibe.json")))
+    U, beacon = bytes.fromhex(v["U_g1"]), bytes.fromhex(v["beacon_g2"])
+    V, W, want = bytes.fromhex(v["V"]), bytes.fromhex(v["W"]), bytes.fromhex(v["expected"])
+    for flags in (0, bls.F_TRUSTED(0) | bls.F_TRUSTED(1)):
+        gt, st = bls.batch_pair(U, beacon, flags)
+        assert st[0] == 0
+        assert _ibe_decrypt(bytes(gt[0]), V, W, v["tags"])[1] == want
+    gts, st = bls.batch_pair([U] * 256, [beacon] * 256)
+    assert not np.asarray(st).any() and all(bytes(g) == bytes(gt[0]) for g in gts)
+    assert bytes(gt[0]) == O.pair_bytes(U, beacon)
+    # a ciphertext of our own: encrypt on the oracle, decrypt with the engine's Pair and G1 Mul
+    s = 0x1CEB00DA % O.R
+    qid = O.hash_to_g2(b"passtherand", bls.DOMAIN_G2)
+    msg, sigma = b"kyberhip ibe msg", bytes(range(16))
+    r = _ibe_h3(sigma, msg, v["tags"])
+    Uc = O.g1_compress(O.g1_mul(r, O.G1_GEN))
+    gid_r = O.f12_pow(O.pair(O.g1_mul(s, O.G1_GEN), qid), r)
+    Vc = bytes(a ^ b for a, b in zip(sigma, hashlib.sha256(b"IBE-H2" + O.gt_to_bytes(gid_r)).digest()[:16]))
+    Wc = bytes(a ^ b for a, b in zip(msg, hashlib.sha256(b"IBE-H4" + sigma).digest()[:16]))
+    gt, st = bls.batch_pair(Uc, O.g2_compress(O.g2_mul(s, qid)))
+    sigma2, msg2 = _ibe_decrypt(bytes(gt[0]), Vc, Wc, v["tags"])
+    assert (sigma2, msg2) == (sigma, msg)
+    rp, st = bls.g1_batch_mul(_ibe_h3(sigma2, msg2, v["tags"]).to_bytes(32, "big"), bls.G1_BASE)
+    assert st[0] == 0 and bytes(rp[0]) == Uc

@@ -102,3 +102,73 @@ def test_final_exponent_is_the_kilic_chain():
     canon = O.f12_pow(easy, O.HARD_EXP)
     assert canon != e and O.f12_mul(O.f12_sqr(canon), canon) == e
     assert O.f12_pow(e, O.R) == O.F12_ONE and e != O.F12_ONE
+
+
+# --------------------------------------------------------------------------- GT bytes: the IBE interop vector
+def _ibe_decrypt(gt_bytes: bytes, v: bytes, w: bytes, tags):
+    """DecryptCCAonG1 steps 1-2 (encrypt/ibe/ibe.go:100-121) given the GT bytes of Pair(U, private):
+    sigma = V xor SHA-256("IBE-H2" || gt)[:len(W)]  (gtToHash ibe.go:297-313, suite hash = SHA-256),
+    msg = W xor SHA-256("IBE-H4" || sigma)[:len(W)]  (h4 ibe.go:283-295)."""
+    import hashlib
+    sigma = bytes(a ^ b for a, b in zip(hashlib.sha256(tags["H2"].encode() + gt_bytes).digest()[:len(w)], v))
+    msg = bytes(a ^ b for a, b in zip(hashlib.sha256(tags["H4"].encode() + sigma).digest()[:len(w)], w))
+    return sigma, msg
+
+
+def _ibe_h3(sigma: bytes, msg: bytes, tags) -> int:
+    """h3 (ibe.go:234-281): rejection-sample r from SHA-256(LE16(i) || SHA-256("IBE-H3" || sigma || msg)) with the
+    top bit masked (BLS12-381: one bit, big-endian scalars) until the value is below the group order."""
+    import hashlib
+    buf = hashlib.sha256(tags["H3"].encode() + sigma + msg).digest()
+    for i in range(1, 65535):
+        h = bytearray(hashlib.sha256(i.to_bytes(2, "little") + buf).digest())
+        h[0] >>= 1
+        r = int.from_bytes(h, "big")
+        if r < O.R:
+            return r
+    raise AssertionError("rejection sampling failure")
+
+
+def test_ibe_vector_pins_gt_bytes(golden_dir):
+    """encrypt/ibe/ibe_test.go:202-245: the ciphertext (U, V, W) under the drand beacon decrypts to deadbeef x 4 only if
+    Pair's 576 output bytes are the reference's -- exponent (the cube of the canonical reduced pairing: kilic's chain)
+    and coefficient order (gt_to_bytes) both.  The canonical exponent must NOT decrypt, and neither may a different
+    coefficient order; the CCA check rP == U (ibe.go:123-131) closes the loop through G1 scalar multiplication."""
+    v = json.load(open(os.path.join(golden_dir, "bls12381_ibe.json")))
+    U, beacon = bytes.fromhex(v["U_g1"]), bytes.fromhex(v["beacon_g2"])
+    V, W, want = bytes.fromhex(v["V"]), bytes.fromhex(v["W"]), bytes.fromhex(v["expected"])
+    p, q = O.g1_decompress(U), O.g2_decompress(beacon)
+    gt = O.pair_bytes(U, beacon)
+    sigma, msg = _ibe_decrypt(gt, V, W, v["tags"])
+    assert msg == want
+    # the canonical exponent (p^12 - 1)/r gives other bytes and does not decrypt
+    f = O.miller_loop(p, q)
+    easy = O.f12_mul(O.f12_frob(O.f12_mul(O.f12_conj(f), O.f12_inv(f)), 2), O.f12_mul(O.f12_conj(f), O.f12_inv(f)))
+    canonical = O.f12_pow(easy, O.HARD_EXP)
+    assert O.f12_pow(canonical, 3) == O.pair(p, q)
+    assert _ibe_decrypt(O.gt_to_bytes(canonical), V, W, v["tags"])[1] != want
+    # ... and so does the forward tower order
+    a = O.pair(p, q)
+    fwd = b"".join(c[0].to_bytes(48, "big") + c[1].to_bytes(48, "big") for half in (0, 1) for m in (0, 1, 2)
+                   for c in (a[2 * m + half],))
+    assert _ibe_decrypt(fwd, V, W, v["tags"])[1] != want
+
+
+def test_ibe_round_trip(golden_dir):
+    """EncryptCCAonG1 / DecryptCCAonG1 (ibe.go:51-135) end to end on the oracle: Gid = e(master, H(ID)), U = rP,
+    V = sigma xor H2(Gid^r), W = msg xor H4(sigma); decryption with s*H(ID) recovers msg and passes rP == U."""
+    import hashlib
+    tags = json.load(open(os.path.join(golden_dir, "bls12381_ibe.json")))["tags"]
+    s = 0x1CEB00DA % O.R
+    master = O.g1_mul(s, O.G1_GEN)
+    qid = O.hash_to_g2(b"passtherand", b"BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_NUL_")
+    msg, sigma = b"Hello World\n\0\0\0\0", bytes(range(16))
+    r = _ibe_h3(sigma, msg, tags)
+    U = O.g1_compress(O.g1_mul(r, O.G1_GEN))
+    gid_r = O.f12_pow(O.pair(master, qid), r)
+    V = bytes(a ^ b for a, b in zip(sigma, hashlib.sha256(b"IBE-H2" + O.gt_to_bytes(gid_r)).digest()[:16]))
+    W = bytes(a ^ b for a, b in zip(msg, hashlib.sha256(b"IBE-H4" + sigma).digest()[:16]))
+    private = O.g2_compress(O.g2_mul(s, qid))
+    sigma2, msg2 = _ibe_decrypt(O.pair_bytes(U, private), V, W, tags)
+    assert (sigma2, msg2) == (sigma, msg)
+    assert O.g1_compress(O.g1_mul(_ibe_h3(sigma2, msg2, tags), O.G1_GEN)) == U
