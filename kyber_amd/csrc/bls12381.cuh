@@ -274,6 +274,8 @@ KYB_HD int g2_decode_f(g2_aff& a, const uint8_t* in, uint32_t flags, int arg) {
 }
 KYB_HD size_t g1_wire_size(uint32_t flags) { return (flags & FLAG_UNCOMPRESSED) ? G1_WIRE_UNC : 48; }
 KYB_HD size_t g2_wire_size(uint32_t flags) { return (flags & FLAG_UNCOMPRESSED) ? G2_WIRE_UNC : 96; }
+// UnmarshalBinary proves r-torsion (kilic/g2.go: ZCash rules), so "decoded once" and "vouched for" are the same claim
+constexpr bool g2_decode_proves_subgroup() { return true; }
 
 // ------------------------------------------------------------------ encoding
 KYB_HD_NOINLINE void g1_encode(uint8_t* out, const g1_aff& a) {

@@ -9,6 +9,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <vector>
 #include <utility>
 
 #include "../../include/kyber_hip.h"
@@ -94,10 +95,12 @@ size_t md_threshold();
 void shard_range(size_t n, int rank, int world, size_t* lo, size_t* hi);
 // f(shard, lo, hi) -> status code, once per shard, on a thread whose current device is the shard's; returns the first
 // non-zero code (its error message becomes the caller's kyb_last_error()).
-int md_run_impl(size_t n, int (*thunk)(void*, int, size_t, size_t), void* arg);
+// `on`: the device list to run on (a snapshot from md_devices()); nullptr = snapshot now.
+std::vector<int> md_devices();
+int md_run_impl(size_t n, int (*thunk)(void*, int, size_t, size_t), void* arg, const std::vector<int>* on = nullptr);
 template <class F>
-int md_run(size_t n, F&& f) {
-    return md_run_impl(n, [](void* a, int s, size_t lo, size_t hi) -> int { return (*static_cast<F*>(a))(s, lo, hi); }, &f);
+int md_run(size_t n, F&& f, const std::vector<int>* on = nullptr) {
+    return md_run_impl(n, [](void* a, int s, size_t lo, size_t hi) -> int { return (*static_cast<F*>(a))(s, lo, hi); }, &f, on);
 }
 inline bool md_active(size_t n) { return md_count() > 1 && n >= md_threshold() && n >= (size_t)md_count(); }
 

@@ -88,12 +88,15 @@ void shard_range(size_t n, int rank, int world, size_t* lo, size_t* hi) {
     *lo = r * base + (r < rem ? r : rem);
     *hi = *lo + base + (r < rem ? 1 : 0);
 }
-int md_run_impl(size_t n, int (*thunk)(void*, int, size_t, size_t), void* arg) {
-    std::vector<int> devs;
-    {
-        std::lock_guard<std::mutex> lk(g_md_mu);
-        devs = g_md_devs;
-    }
+std::vector<int> md_devices() {
+    if (t_in_shard) return {};
+    std::lock_guard<std::mutex> lk(g_md_mu);
+    return g_md_devs;
+}
+int md_run_impl(size_t n, int (*thunk)(void*, int, size_t, size_t), void* arg, const std::vector<int>* on) {
+    // ONE snapshot of the device list per call: a concurrent kyb_set_devices() changes later calls, never the width
+    // of one in flight (callers that size buffers by the width pass the snapshot they sized them with)
+    const std::vector<int> devs = on ? *on : md_devices();
     const int w = (int)devs.size();
     std::vector<int> rcs(w, KYB_OK);
     std::vector<std::string> errs(w);

@@ -660,8 +660,13 @@ static int mul_host(size_t n, const uint8_t* scalars, const uint8_t* points, siz
     std::atomic<int> drain_rc{KYB_OK};
     std::atomic<bool> stop{false};
     const int device = ctx->device;
+    std::string drain_err;  // g_err is thread_local: the drainer's message is carried over to the caller after the join
     std::thread drainer([&] {
-        hipSetDevice(device);
+        if (hipSetDevice(device) != hipSuccess) {
+            drain_err = "ed25519 host pipeline: hipSetDevice failed on the drain thread";
+            drain_rc.store(KYB_E_HIP);
+            return;
+        }
         for (size_t i = 0; i < nchunks; i++) {
             while (enqueued.load(std::memory_order_acquire) <= i) {
                 if (stop.load(std::memory_order_acquire)) return;
@@ -669,6 +674,7 @@ static int mul_host(size_t n, const uint8_t* scalars, const uint8_t* points, siz
             }
             const int r = drain(i);
             if (r) {
+                drain_err = kyb_last_error();
                 drain_rc.store(r);
                 return;
             }
@@ -684,7 +690,7 @@ static int mul_host(size_t n, const uint8_t* scalars, const uint8_t* points, siz
     }
     if (rc != KYB_OK) stop.store(true, std::memory_order_release);
     drainer.join();
-    if (rc == KYB_OK) rc = drain_rc.load();
+    if (rc == KYB_OK && (rc = drain_rc.load()) != KYB_OK) set_error(drain_err);
     hipError_t e2 = hipSuccess;
     for (int i = 0; i < PIPE_STREAMS; i++) {
         const hipError_t e = hipStreamSynchronize(ctx->pipe[i]);

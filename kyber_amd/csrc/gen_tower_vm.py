@@ -1778,7 +1778,10 @@ def main():
         if suite == "bls12381":  # CHECK with the second G2 operand fixed to the generator (bls.Verify on G1)
             out.append(emit_prog(build_bls12381_verify(), up + "_VERIFY"))
         out += ["}  // namespace kyb", ""]
-        open(os.path.join(HERE, "tower_vm_%s.inc" % suite), "w").write("\n".join(out))
+        dst = os.path.join(HERE, "tower_vm_%s.inc" % suite)   # written whole, then renamed: a reader never sees half a file
+        with open(dst + ".tmp", "w") as f:
+            f.write("\n".join(out))
+        os.replace(dst + ".tmp", dst)
         for n, P in (("pair", pair), ("check", check)):
             print(suite, n, P.stats(), "bounds (log2 column, value/p):", P.check_bounds())
 

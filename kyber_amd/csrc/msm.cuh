@@ -254,6 +254,10 @@ static inline void launch_scan(const uint32_t* hist, uint32_t* offs, size_t m, u
 // ballot aggregation would save nothing on top of the LDS counters.)
 constexpr int HIST_T = 1024;
 constexpr int HIST_MAX_NB = 1 << 15;
+// 128 KB of static LDS: gfx950's 160 KB per CU, nothing smaller (the Makefile's ARCH is overridable; this says why not)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "msm.cuh: the LDS-staged counting sort needs gfx950's 160 KB of LDS per workgroup (HIST_MAX_NB counters = 128 KB)"
+#endif
 static __global__ __launch_bounds__(HIST_T) void hist_lds_kernel(Plan p, int tiles, const int32_t* __restrict__ digits,
                                                                  uint32_t* __restrict__ hist2) {
     __shared__ uint32_t h[HIST_MAX_NB];
@@ -751,7 +755,11 @@ int run_host(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* o
         return KYB_E_ARG;
     }
     if (int frc = check_flags(flags & ~KYB_F_SCALAR_BITS_MASK, 1, false, "msm")) return frc;
-    const int w = md_count();
+    // the width the partial buffer is sized with and the width the shards run at are the same snapshot (a concurrent
+    // kyb_set_devices() must not make shard s write past partial[w])
+    const std::vector<int> devs = md_devices();
+    const int w = (int)devs.size();
+    if (w < 2 || n < (size_t)w) return run_host_single<A>(n, scalars, points, out, status, flags);
     std::vector<uint8_t> partial((size_t)w * A::OUT), st_tmp;
     uint8_t* stp = status;
     if (!stp) {
@@ -762,7 +770,7 @@ int run_host(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* o
     int rc = md_run(n, [&](int s, size_t lo, size_t hi) {
         return run_host_single<A>(hi - lo, scalars + 32 * lo, points + wire * lo, partial.data() + (size_t)s * A::OUT, stp + lo,
                                   flags);
-    });
+    }, &devs);
     if (rc) return rc;
     bool bad = false;
     for (size_t i = 0; i < n; i++) bad |= stp[i] != 0;

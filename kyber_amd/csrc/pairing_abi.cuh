@@ -135,11 +135,13 @@ static int PFX##_mul_host(bool g2, size_t n, const uint8_t* scalars, const uint8
     KYB_TRY(p.upload(points, (stride ? n : 1) * isz)); \
     KYB_TRY(o.alloc(n * psz)); \
     KYB_TRY(st.alloc(n)); \
-    if (!stride && n >= (size_t(1) << 18) && !(flags & KYB_F_TRUSTED(0))) { \
+    if (!stride && n >= (size_t(1) << 18) && !(flags & KYB_F_TRUSTED(0)) && (!g2 || kyb::NS::g2_decode_proves_subgroup())) { \
         /* one shared base and MANY coefficients (PriPoly.Commit): UnmarshalBinary's checks run once, in one lane, and \
            the lanes take the point as validated.  A lone lane needs as long for them (~2 ms on BLS12-381 G1) as a full \
            chip of lanes does side by side, so this pays only once every SIMD has several waves to run one after the \
-           other (measured: 2^16 coefficients 6.0 ms per-lane against 6.9 ms this way; from 2^18 on it wins) */ \
+           other (measured: 2^16 coefficients 6.0 ms per-lane against 6.9 ms this way; from 2^18 on it wins).  Not for a G2 \
+           base of a suite whose UnmarshalBinary does not prove subgroup membership (bn256): there TRUSTED selects the GLS \
+           walk, which differs from the reference's double-and-add on off-subgroup points whatever n is */ \
         KYB_TRY(g2 ? kyb_##PFX##_g2_unmarshal_dev(1, p.p, o.p, st.p, flags & ~KYB_F_UNCOMPRESSED_OUT, nullptr) \
                    : kyb_##PFX##_g1_unmarshal_dev(1, p.p, o.p, st.p, flags & ~KYB_F_UNCOMPRESSED_OUT, nullptr)); \
         uint8_t st0 = 0; \

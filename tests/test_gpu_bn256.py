@@ -253,3 +253,33 @@ def test_g2_mul_gls_under_trusted_flag(bn):
     assert not st.any() and not st2.any() and (np.asarray(a) == np.asarray(b)).all()
     for i in (0, 1, 2, 3, n - 1):
         assert bytes(b[i]) == O.g2_mul_bytes(bytes(k[i]), bytes(Q[i]))
+
+
+def test_same_base_commit_with_an_off_subgroup_g2_base_at_2p18(bn):
+    """kyb_bn256_g2_mul_same_base with >= 2^18 coefficients validates the shared base once.  bn256's UnmarshalBinary
+    checks the curve equation only (point.go:466-499, twist.go:49-60), so "decoded" must not become "vouched for the
+    subgroup" (which selects the GLS walk): on a base with a cofactor component the result must still be the
+    reference's plain double-and-add, whatever n is and however the batch is sharded (round-2 advisor finding)."""
+    q = None
+    x0 = 1
+    while q is None:
+        x = (x0, 1)
+        y = O.f2_sqrt(O.f2_add(O.f2_mul(O.f2_mul(x, x), x), O.TWIST_B))
+        if y is not None:
+            q = (x, y)
+        x0 += 1
+    assert O.g2_mul(O.ORDER, q) is not None
+    base = O.g2_marshal(q)
+    n = (1 << 18) + 3
+    rng = random.Random(11)
+    ks = [rng.randrange(O.ORDER) for _ in range(6)]
+    k = np.zeros((n, 32), dtype=np.uint8)
+    k[:, 31] = 1
+    pos = [0, 1, n // 2, n - 2, n - 1, 77777]
+    for p, v in zip(pos, ks):
+        k[p] = np.frombuffer(v.to_bytes(32, "big"), dtype=np.uint8)
+    out, st = bn.g2_commit(k, base)              # host buffers: the entry point the shortcut lives in
+    assert not np.asarray(st).any()
+    for p, v in zip(pos, ks):
+        assert bytes(out[p]) == O.g2_marshal(O.g2_mul(v, q)), p
+    assert bytes(out[5]) == base

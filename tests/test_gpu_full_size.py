@@ -212,3 +212,69 @@ def test_ed25519_pipelined_host_path_matches_device_path():
     com_h = ed.commit(s, bytes(base_host[3]))
     com_d, _ = ed.batch_mul(torch.from_numpy(s).cuda(), torch.from_numpy(np.tile(base_host[3], (n, 1))).cuda())
     assert (com_h == com_d.cpu().numpy()).all()
+
+
+def _be_scalars_mod(label: bytes, n: int, order: int) -> np.ndarray:
+    """n canonical big-endian scalars, uniform mod order (48 random bytes each, reduced)."""
+    raw = hashlib.shake_256(label).digest(n * 48)
+    out = np.empty((n, 32), dtype=np.uint8)
+    for i in range(n):
+        out[i] = np.frombuffer((int.from_bytes(raw[48 * i:48 * i + 48], "big") % order).to_bytes(32, "big"), dtype=np.uint8)
+    return out
+
+
+@pytest.mark.parametrize("name,grp,n", [("bls12381", 1, 1 << 20), ("bls12381", 2, 1 << 18),
+                                        ("bn256", 1, 1 << 20), ("bn254", 1, 1 << 20), ("bn256", 2, 1 << 17)])
+def test_msm_at_config_size_against_an_independent_expectation(name, grp, n):
+    """configs[2] (BLS12-381 G1 Pippenger MSM, 2^20 points; share/poly.go:340-348, 449-476, sign/bdn/bdn.go:126-161 are
+    its N x (Mul + Add) shapes) and its siblings: with P_i = h_i G the sum must be (sum k_i h_i mod r) G, where the
+    expectation is big-integer arithmetic on the host and ONE fixed-base multiplication -- independent of the bucket
+    pipeline.  Edge scalars (0, 1, r-1, r, 2^256-1, a run of equal scalars that lands in one bucket) are planted at the
+    ends and in the middle; every calling convention (re-validated, vouched-for, uncompressed) must give the same
+    bytes; a point that fails UnmarshalBinary in the LAST tile must surface as its status with a zeroed output."""
+    import importlib
+
+    import torch
+
+    m = importlib.import_module("kyber_amd.pairing." + name)
+    r = m.ORDER
+    tag = ("full-msm/%s/%d" % (name, grp)).encode()
+    k, h = _be_scalars_mod(tag + b"/k", n, r), _be_scalars_mod(tag + b"/h", n, r)
+    edge = [0, 1, r - 1, r, (1 << 256) - 1, 2, 1 << 255, r + 1]
+    for j, e in enumerate(edge):
+        for base in (0, n // 2, n - len(edge)):
+            k[base + j] = np.frombuffer(e.to_bytes(32, "big"), dtype=np.uint8)
+    k[n // 3:n // 3 + 3000] = k[n // 3]            # one long bucket per window
+    commit, msm = (m.g1_commit, m.g1_msm) if grp == 1 else (m.g2_commit, m.g2_msm)
+    ln = m.G1_LEN if grp == 1 else m.G2_LEN
+    dk, dh = torch.from_numpy(k).cuda(), torch.from_numpy(h).cuda()
+    P, st = commit(dh)
+    assert not st.any().item()
+    tot = sum(int.from_bytes(bytes(a), "big") * int.from_bytes(bytes(b), "big") for a, b in zip(k, h)) % r
+    exp = bytes(commit(tot.to_bytes(32, "big"))[0][0])
+    out, st = msm(dk, P)
+    assert not st.any().item() and bytes(out.cpu().numpy()) == exp, "checked MSM"
+    out, st = msm(dk, P, m.F_TRUSTED(0))
+    assert not st.any().item() and bytes(out.cpu().numpy()) == exp, "MSM over vouched-for points"
+    if name == "bls12381":
+        Pu, st = m._mul(grp, dh, torch.from_numpy(np.frombuffer(m.G1_BASE if grp == 1 else m.G2_BASE, dtype=np.uint8).copy()).cuda(),
+                        True, m.F_UNCOMPRESSED_OUT)
+        assert not st.any().item()
+        for fl in (m.F_UNCOMPRESSED, m.F_UNCOMPRESSED | m.F_TRUSTED(0)):
+            out, st = msm(dk, Pu, fl)
+            assert not st.any().item() and bytes(out.cpu().numpy()) == exp, "uncompressed points, flags %x" % fl
+    # short coefficients (bdn's 128 bits): the planner drops the upper windows
+    k128 = k.copy()
+    k128[:, :16] = 0
+    tot128 = sum(int.from_bytes(bytes(a[16:]), "big") * int.from_bytes(bytes(b), "big") for a, b in zip(k128, h)) % r
+    out, st = msm(torch.from_numpy(k128).cuda(), P, m.F_SCALAR_BITS(128) | m.F_TRUSTED(0))
+    assert not st.any().item() and bytes(out.cpu().numpy()) == bytes(commit(tot128.to_bytes(32, "big"))[0][0])
+    # a bad point in the last tile
+    bad = P.clone()
+    bad[n - 5] = 0
+    bad[n - 5, ln - 1] = 5
+    if name == "bls12381":
+        bad[n - 5, 0] = 0x80    # compressed flag set, x = 5: not on the curve (G1) / handled per fixture rules
+    out, st = msm(dk, bad)
+    st = st.cpu().numpy()
+    assert st[n - 5] != 0 and not np.delete(st, n - 5).any() and not out.cpu().numpy().any()
