@@ -519,7 +519,7 @@ def test_ibe_vector_pins_pair_bytes_on_the_engine(bls, golden_dir):
         gt, st = bls.batch_pair(U, beacon, flags)
         assert st[0] == 0
         assert _ibe_decrypt(bytes(gt[0]), V, W, v["tags"])[1] == want
-    gts, st = bls.batch_pair([U] * 256, [beacon] * 256)
+    gts, st = bls.batch_pair(U * 256, beacon * 256)
     assert not np.asarray(st).any() and all(bytes(g) == bytes(gt[0]) for g in gts)
     assert bytes(gt[0]) == O.pair_bytes(U, beacon)
     # a ciphertext of our own: encrypt on the oracle, decrypt with the engine's Pair and G1 Mul
