@@ -10,6 +10,19 @@
 // (this translation unit: G1 / G2 scalar multiplication; pairing kernels are in bls12381_pair.hip, MSM in
 //  bls12381_msm.hip -- split only so that the three compile in parallel)
 #include "bls12381.cuh"
+#include "bls12381_lvm.cuh"
 #include "pairing_abi.cuh"
 
 KYB_DEFINE_MUL_ABI(bls12381, bls, 48, 96)
+
+// Debugging aid of the lane machine (tests/test_gpu_lane_vm.py): the multiplication of bls12381_lvm.cuh with the
+// interpreter's trace switched on -- lanes 0 and 1 of the first wave store the result of every record that writes a
+// slot, [record][lane][16] int32 -- so that a divergence from gen_lane_vm.py's simulator is found at the first record
+// that differs.  Device pointers; the batch must be large enough for the machine (KYB_LVM_MIN).
+extern "C" int kyb_debug_bls12381_lvm_trace(int g2, size_t n, const void* d_scalars, const void* d_points, size_t point_stride, void* d_out,
+                                            void* d_status, uint32_t flags, void* d_trace, void* stream) {
+    const uint8_t* only = nullptr;
+    KYB_TRY(kyb::bls::lvm_mul(g2 != 0, n, (const uint8_t*)d_scalars, (const uint8_t*)d_points, point_stride, (uint8_t*)d_out,
+                              (uint8_t*)d_status, flags, (hipStream_t)stream, &only, (int32_t*)d_trace));
+    return only ? KYB_OK : KYB_E_ARG;
+}

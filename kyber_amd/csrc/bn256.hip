@@ -10,6 +10,15 @@
 #include "bn256.cuh"
 #include "pairing_abi.cuh"
 
+namespace kyb {
+namespace bn {
+// (the lane machine of bls12381_lvm.cuh has no BN programs yet: every element goes to the per-lane kernels)
+inline int lvm_mul(bool, size_t, const uint8_t*, const uint8_t*, size_t, uint8_t*, uint8_t*, uint32_t, hipStream_t, const uint8_t** only) {
+    *only = nullptr;
+    return KYB_OK;
+}
+}  // namespace bn
+}  // namespace kyb
 KYB_DEFINE_MUL_ABI(bn256, bn, 64, 128)
 
 // ---- pointG1.Hash (pairing/bn256/point.go:261-313): the step before the pairing check in sign/bls Verify

@@ -37,7 +37,7 @@ sys.path.insert(0, HERE)
 from gen_tower_vm import VmField, bls12381_field, emit_field, _carr  # noqa: E402
 
 REC_WORDS = 64
-NSLOTS = 7
+NSLOTS = 6
 OP_DOT, OP_IN, OP_OUTW, OP_INV, OP_TSTORE, OP_SELDIGIT, OP_CTRSET, OP_CTRADD, OP_ZFLAG = range(9)
 (K_MUL, K_LIN, K_MULC, K_LINC, K_MULT, K_LINT, K2_MUL, K2_SQR, K2_MULT, K2_MULC, K2_NORM) = range(11)
 KIND_NAMES = ["mul", "lin", "mulc", "linc", "mult", "lint", "mul2", "sqr2", "mul2t", "mul2c", "norm2"]
@@ -463,8 +463,8 @@ class LProg:
 
 
 # ------------------------------------------------------------------------------------------------ curve programs
-# slots: the accumulator T = (X, Y, Z) and four temporaries
-SX, SY, SZ, SA, SB, SC, SD = range(7)
+# slots: the accumulator T = (X, Y, Z) and three temporaries (five slots live in LDS, the sixth in registers)
+SX, SY, SZ, SA, SB, SC = range(6)
 NENTRY = 9          # table entries: (2 i + 1) P for i = 0..7, entry 8 = 2 P
 E2P = 8
 
@@ -512,19 +512,21 @@ class Curve:
     def madd(self, cx, cy, entry=DYN, signed=True, name="madd"):
         """(X, Y, Z) <- (X, Y, Z) + (x2, y2), the second operand affine from the table (coordinates cx, cy of `entry`;
         y2 negated by the digit's sign).  madd-2004-hmv: H = U2 - X1, r = S2 - Y1, Z3 = Z1 H, X3 = r^2 - H^3 - 2 X1 H^2,
-        Y3 = r (X1 H^2 - X3) - Y1 H^3.  11 products, temporaries A, B, C, D.  H = 0 (equal or opposite operands)
+        Y3 = r (X1 H^2 - X3) - Y1 H^3.  11 products + one stored difference (H: with it the working set is six slots,
+        with H as an operand combination it would be seven), temporaries A, B, C.  H = 0 (equal or opposite operands)
         gives Z3 = 0, which every later step preserves."""
         P = self.P
         P.dot(SA, [self.sqr(L(SZ))], name=name + ".ZZ")                                     # A = Z^2
         P.dot(SB, [self.mult(L(SA), cx, False, entry)], name=name + ".U2")                  # B = U2 = x2 Z^2
         P.dot(SA, [self.mul(L(SA), L(SZ))], name=name + ".ZZZ")                             # A = Z^3
         P.dot(SC, [self.mult(L(SA), cy, signed, entry)], name=name + ".S2")                 # C = S2 = y2 Z^3
-        P.dot(SZ, [self.mul(L(SZ), L(SB, 1, SX, -1))], name=name + ".Z3")                   # Z3 = Z H
-        P.dot(SA, [self.sqr(L(SB, 1, SX, -1))], name=name + ".HH")                          # A = H^2
-        P.dot(SD, [self.mul(L(SA), L(SB, 1, SX, -1))], name=name + ".HHH")                  # D = H^3
-        P.dot(SB, [self.mul(L(SX), L(SA))], name=name + ".V")                               # B = V = X1 H^2
-        P.dot(SX, [self.sqr(L(SC, 1, SY, -1)), ("lin", L(SD, -1, SB, -2))], name=name + ".X3")
-        P.dot(SY, [self.mul(L(SC, 1, SY, -1), L(SB, 1, SX, -1)), self.mul(L(SY, -1), L(SD))], name=name + ".Y3")
+        P.dot(SB, [("lin", L(SB, 1, SX, -1))], raw=True, name=name + ".H")                  # B = H = U2 - X1
+        P.dot(SZ, [self.mul(L(SZ), L(SB))], name=name + ".Z3")                              # Z3 = Z H
+        P.dot(SA, [self.sqr(L(SB))], name=name + ".HH")                                     # A = H^2
+        P.dot(SB, [self.mul(L(SA), L(SB))], name=name + ".HHH")                             # B = H^3
+        P.dot(SA, [self.mul(L(SX), L(SA))], name=name + ".V")                               # A = V = X1 H^2
+        P.dot(SX, [self.sqr(L(SC, 1, SY, -1)), ("lin", L(SB, -1, SA, -2))], name=name + ".X3")
+        P.dot(SY, [self.mul(L(SC, 1, SY, -1), L(SA, 1, SX, -1)), self.mul(L(SY, -1), L(SB))], name=name + ".Y3")
 
     def load_affine(self, cx, cy, entry=DYN, signed=True, name="load"):
         P = self.P
@@ -588,12 +590,12 @@ def table_g1(P, C, beta_mont):
     store_affine(0, SX, SY, SA)
     # 2 P, made affine at once: every later addition is a mixed one
     C.dbl("dbl2p")
-    C.inverse(SA, SZ, SD, "inv2p")                               # A = 1 / Z
+    C.inverse(SA, SZ, SB, "inv2p")                               # A = 1 / Z
     P.dot(SB, [C.sqr(L(SA))], name="2p.zi2")
     P.dot(SC, [C.mul(L(SX), L(SB))], name="2p.x")
     P.dot(SB, [C.mul(L(SB), L(SA))], name="2p.zi3")
-    P.dot(SD, [C.mul(L(SY), L(SB))], name="2p.y")
-    store_affine(E2P, SC, SD, SA)
+    P.dot(SA, [C.mul(L(SY), L(SB))], name="2p.y")
+    store_affine(E2P, SC, SA, SB)
     # T = P, then T += 2P seven times: 3P .. 15P in Jacobian form, parked in the table (X -> x, Z -> beta x, Y -> y)
     C.load_affine(CX, CY, entry=0, signed=False, name="t=p")
     for e in range(1, 8):
@@ -607,13 +609,13 @@ def table_g1(P, C, beta_mont):
     for e in range(2, 8):
         P.dot(SC, [C.mult(L(SC), CBX, False, e)], name="c%d" % e)
         P.op(OP_TSTORE, out=SC, arg=(e << 8) | CS)
-    C.inverse(SD, SC, SA, "invtab")                              # D = 1 / (Z_1 .. Z_7)
+    C.inverse(SZ, SC, SA, "invtab")                              # Z = 1 / (Z_1 .. Z_7): the running inverse
     for e in range(7, 0, -1):
         if e > 1:
-            P.dot(SA, [C.mult(L(SD), CS, False, e - 1)], name="zi%d" % e)       # A = 1 / Z_e
-            P.dot(SD, [C.mult(L(SD), CBX, False, e)], name="run%d" % e)         # D = 1 / (Z_1 .. Z_{e-1})
+            P.dot(SA, [C.mult(L(SZ), CS, False, e - 1)], name="zi%d" % e)       # A = 1 / Z_e
+            P.dot(SZ, [C.mult(L(SZ), CBX, False, e)], name="run%d" % e)         # Z = 1 / (Z_1 .. Z_{e-1})
         else:
-            P.dot(SA, [("lin", L(SD))], raw=True, name="zi1")
+            P.dot(SA, [("lin", L(SZ))], raw=True, name="zi1")
         P.dot(SB, [C.sqr(L(SA))], name="zi2.%d" % e)
         P.dot(SX, [C.mult(L(SB), CX, False, e)], name="x%d" % e)
         P.dot(SB, [C.mul(L(SB), L(SA))], name="zi3.%d" % e)
@@ -659,12 +661,12 @@ def table_g2(P, C, psi):
     P.dot(SZ, [("linc", C.c_one, 1)], name="z.one")
     store_affine(0, SX, SY, SA, SB)
     C.dbl("dbl2p")
-    C.inverse(SA, SZ, SD, "inv2p")
+    C.inverse(SA, SZ, SB, "inv2p")
     P.dot(SB, [C.sqr(L(SA))], name="2p.zi2")
     P.dot(SC, [C.mul(L(SX), L(SB))], name="2p.x")
     P.dot(SB, [C.mul(L(SB), L(SA))], name="2p.zi3")
-    P.dot(SD, [C.mul(L(SY), L(SB))], name="2p.y")
-    store_affine(E2P, SC, SD, SA, SB)
+    P.dot(SA, [C.mul(L(SY), L(SB))], name="2p.y")
+    store_affine(E2P, SC, SA, SB, SX)
     C.load_affine(CX, CY, entry=0, signed=False, name="t=p")
     for e in range(1, 8):
         C.madd(CX, CY, entry=E2P, signed=False, name="odd%d" % e)
@@ -676,18 +678,18 @@ def table_g2(P, C, psi):
     for e in range(2, 8):
         P.dot(SC, [C.mult(L(SC), CZ, False, e)], name="c%d" % e)
         P.op(OP_TSTORE, out=SC, arg=(e << 8) | CS)
-    C.inverse(SD, SC, SA, "invtab")
+    C.inverse(SZ, SC, SA, "invtab")                              # Z: the running inverse
     for e in range(7, 0, -1):
         if e > 1:
-            P.dot(SA, [C.mult(L(SD), CS, False, e - 1)], name="zi%d" % e)
-            P.dot(SD, [C.mult(L(SD), CZ, False, e)], name="run%d" % e)
+            P.dot(SA, [C.mult(L(SZ), CS, False, e - 1)], name="zi%d" % e)
+            P.dot(SZ, [C.mult(L(SZ), CZ, False, e)], name="run%d" % e)
         else:
-            P.dot(SA, [("lin", L(SD))], raw=True, name="zi1")
+            P.dot(SA, [("lin", L(SZ))], raw=True, name="zi1")
         P.dot(SB, [C.sqr(L(SA))], name="zi2.%d" % e)
         P.dot(SX, [C.mult(L(SB), CX, False, e)], name="x%d" % e)
         P.dot(SB, [C.mul(L(SB), L(SA))], name="zi3.%d" % e)
         P.dot(SY, [C.mult(L(SB), CY, False, e)], name="y%d" % e)
-        # (D, the running inverse, must survive: the images are built in A, B, C)
+        # (Z, the running inverse, must survive: the images are built in A, B)
         store_affine(e, SX, SY, SA, SB)
     return [(0, 1), (2, 3), (4, 5), (6, 7)]
 
@@ -723,20 +725,26 @@ def ladder(P, C, variants, npos):
         C.madd(cx, cy, name="corr%d" % j)
     # affine result; Z = 0 <=> infinity or an exceptional addition on the way: flagged, the outputs are then void
     P.op(OP_ZFLAG, out=SZ, arg=0, name="zflag")
-    C.inverse(SA, SZ, SD, "invout")
+    C.inverse(SA, SZ, SB, "invout")
     P.dot(SB, [C.sqr(L(SA))], name="out.zi2")
     P.dot(SC, [C.mul(L(SX), L(SB))], name="out.x")
     P.dot(SB, [C.mul(L(SB), L(SA))], name="out.zi3")
-    P.dot(SD, [C.mul(L(SY), L(SB))], name="out.y")
+    P.dot(SA, [C.mul(L(SY), L(SB))], name="out.y")
     P.dot(SC, [("mulc", L(SC), C.c_plain)], name="out.x.plain")
-    P.dot(SD, [("mulc", L(SD), C.c_plain)], name="out.y.plain")
+    P.dot(SA, [("mulc", L(SA), C.c_plain)], name="out.y.plain")
     P.op(OP_OUTW, out=SC, arg=0)
-    P.op(OP_OUTW, out=SD, arg=1)
+    P.op(OP_OUTW, out=SA, arg=1)
 
 
 BLS_P = bls12381_field().p
 BLS_BETA = pow(2, (BLS_P - 1) // 3, BLS_P)
 G1_NPOS, G2_NPOS = 33, 17
+BLS_G1 = (0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB,
+          0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1)
+BLS_G2 = ((0x024AA2B2F08F0A91260805272DC51051C6E47AD4FA403B02B4510B647AE3D1770BAC0326A805BBEFD48056C8C121BDB8,
+           0x13E02B6052719F607DACD3A088274F65596BD0D09920B61AB5DA61BBDC7F5049334CF11213945D57E5AC7D055D042B7E),
+          (0x0CE5D527727D6E118CC9CDC6DA2E351AADFD9BAA8CBDD3A76D429A695160D12C923AC9CC3BACA289E193548608B82801,
+           0x0606C4A02EA734CC32ACD2B02BC28B99CB3E287E85A763AF267492AB572E99AB3F370D275CEC1DA1AAA9075FF05F79BE))
 
 
 def _f2_mul(a, b, p):
@@ -837,6 +845,13 @@ def main():
     out = ["// generated by gen_lane_vm.py -- do not edit", "#pragma once", "#include <stdint.h>", "namespace kyb {"]
     f = bls12381_field()
     out.append(emit_field(f, "Bls12381Lvm"))
+
+    def words(x):
+        return "{" + ", ".join("0x%xu" % ((x >> (32 * i)) & 0xffffffff) for i in range(12)) + "}"
+    # the generators, plain canonical words: what the prep kernel feeds the machine for elements it does not compute
+    out.append("static __device__ const uint32_t LVM_BLS12381_G1_GEN[2][12] = {%s, %s};" % (words(BLS_G1[0]), words(BLS_G1[1])))
+    out.append("static __device__ const uint32_t LVM_BLS12381_G2_GEN[4][12] = {%s};  // x.c0, x.c1, y.c0, y.c1"
+               % ", ".join(words(v) for v in (BLS_G2[0][0], BLS_G2[0][1], BLS_G2[1][0], BLS_G2[1][1])))
     for up, build in (("BLS12381_G1_MUL", build_bls12381_g1_mul), ("BLS12381_G2_MUL", build_bls12381_g2_mul)):
         P = build()
         out.append(P.emit(up))

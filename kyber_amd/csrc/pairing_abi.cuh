@@ -34,18 +34,20 @@ namespace kyb { \
 __global__ __launch_bounds__(64, KYB_G1_MUL_WAVES) void PFX##_g1_mul_kernel(size_t n, const uint8_t* __restrict__ scalars, \
                                                         const uint8_t* __restrict__ pts, size_t pt_stride, \
                                                         uint8_t* __restrict__ out, uint8_t* __restrict__ status, \
-                                                        uint32_t flags) { \
+                                                        uint32_t flags, const uint8_t* __restrict__ only) { \
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
     if (idx >= n) return; \
+    if (only && !only[idx]) return;  /* the lane machine did this element (bls12381_lvm.cuh step 4) */ \
     const int st = NS::g1_mul_wire(out + NS::g1_out_size(flags) * idx, scalars + 32 * idx, pts + pt_stride * idx, flags); \
     if (status) status[idx] = (uint8_t)st; \
 } \
 __global__ __launch_bounds__(64, KYB_G2_MUL_WAVES) void PFX##_g2_mul_kernel(size_t n, const uint8_t* __restrict__ scalars, \
                                                         const uint8_t* __restrict__ pts, size_t pt_stride, \
                                                         uint8_t* __restrict__ out, uint8_t* __restrict__ status, \
-                                                        uint32_t flags) { \
+                                                        uint32_t flags, const uint8_t* __restrict__ only) { \
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
     if (idx >= n) return; \
+    if (only && !only[idx]) return;  /* the lane machine did this element (bls12381_lvm.cuh step 4) */ \
     const int st = NS::g2_mul_wire(out + NS::g2_out_size(flags) * idx, scalars + 32 * idx, pts + pt_stride * idx, flags); \
     if (status) status[idx] = (uint8_t)st; \
 } \
@@ -91,9 +93,12 @@ int kyb_##PFX##_g1_mul_dev(size_t n, const void* d_scalars, const void* d_points
         return KYB_E_ARG; \
     } \
     if (!n) return KYB_OK; \
+    const uint8_t* only = nullptr; \
+    KYB_TRY(kyb::NS::lvm_mul(false, n, (const uint8_t*)d_scalars, (const uint8_t*)d_points, point_stride, (uint8_t*)d_out, \
+                             (uint8_t*)d_status, flags, (hipStream_t)stream, &only)); \
     hipLaunchKernelGGL(kyb::PFX##_g1_mul_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
                        (const uint8_t*)d_scalars, (const uint8_t*)d_points, point_stride, (uint8_t*)d_out, \
-                       (uint8_t*)d_status, flags); \
+                       (uint8_t*)d_status, flags, only); \
     KYB_HIP_CHECK(hipGetLastError()); \
     return KYB_OK; \
 } \
@@ -105,9 +110,12 @@ int kyb_##PFX##_g2_mul_dev(size_t n, const void* d_scalars, const void* d_points
         return KYB_E_ARG; \
     } \
     if (!n) return KYB_OK; \
+    const uint8_t* only = nullptr; \
+    KYB_TRY(kyb::NS::lvm_mul(true, n, (const uint8_t*)d_scalars, (const uint8_t*)d_points, point_stride, (uint8_t*)d_out, \
+                             (uint8_t*)d_status, flags, (hipStream_t)stream, &only)); \
     hipLaunchKernelGGL(kyb::PFX##_g2_mul_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
                        (const uint8_t*)d_scalars, (const uint8_t*)d_points, point_stride, (uint8_t*)d_out, \
-                       (uint8_t*)d_status, flags); \
+                       (uint8_t*)d_status, flags, only); \
     KYB_HIP_CHECK(hipGetLastError()); \
     return KYB_OK; \
 } \

@@ -1,0 +1,147 @@
+"""The lane machine (kyber_amd/csrc/lane_vm.cuh, bls12381_lvm.cuh) on the GPU: (1) the interpreter against the
+program simulator of gen_lane_vm.py, record by record, through the trace switch of kyb_debug_bls12381_lvm_trace;
+(2) G1Elt.Mul / G2Elt.Mul (kilic/g1.go:110-116, kilic/g2.go) through the public entry points at batch sizes that take the
+machine, byte for byte against the oracle: edge scalars, points at infinity, rejected points, results at infinity
+(the lanes the per-lane kernel redoes), every input / output form."""
+import ctypes as C
+import hashlib
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import bls12381 as O
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kyber_amd", "csrc"))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bls():
+    import torch
+
+    assert torch.cuda.is_available()
+    from kyber_amd.pairing import bls12381 as bls
+
+    return bls
+
+
+def _g1_unc(p):
+    return p[0].to_bytes(48, "big") + p[1].to_bytes(48, "big")
+
+
+def _g2_unc(q):
+    return q[0][1].to_bytes(48, "big") + q[0][0].to_bytes(48, "big") + q[1][1].to_bytes(48, "big") + q[1][0].to_bytes(48, "big")
+
+
+@pytest.mark.parametrize("g2", [False, True])
+def test_interpreter_follows_the_simulator_record_by_record(bls, g2):
+    import torch
+
+    import gen_lane_vm as G
+    from kyber_amd import _lib
+
+    lib = C.CDLL(_lib.LIB_PATH)
+    fn = lib.kyb_debug_bls12381_lvm_trace
+    fn.argtypes = [C.c_int, C.c_size_t] + [C.c_void_p] * 2 + [C.c_size_t] + [C.c_void_p] * 2 + [C.c_uint32, C.c_void_p, C.c_void_p]
+    P = G.build_bls12381_g2_mul() if g2 else G.build_bls12381_g1_mul()
+    rng = random.Random(9)
+    n = 1024
+    k0 = rng.randrange(O.R)
+    h0 = rng.randrange(1, O.R)
+    if g2:
+        pt = O.g2_mul(h0, O.G2_GEN)
+        wire, ln = _g2_unc(pt), 192
+        inputs = [[pt[0][0], pt[1][0]], [pt[0][1], pt[1][1]]]
+        digits = [G.bls_g2_digits(k0)] * 2
+    else:
+        pt = O.g1_mul(h0, O.G1_GEN)
+        wire, ln = _g1_unc(pt), 96
+        inputs = [[pt[0], pt[1]]]
+        digits = [G.bls_g1_digits(k0)]
+    trace = []
+    outs, flags, _ = P.simulate(inputs, digits, trace=trace)
+    pts = torch.from_numpy(np.frombuffer(wire * n, dtype=np.uint8).copy()).cuda()
+    ks = torch.from_numpy(np.frombuffer(k0.to_bytes(32, "big") * n, dtype=np.uint8).copy()).cuda()
+    out = torch.zeros(n * ln, dtype=torch.uint8, device="cuda")
+    st = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    tr = torch.zeros((len(trace) + 8, 2, 16), dtype=torch.int32, device="cuda")
+    fl = bls.F_UNCOMPRESSED | bls.F_TRUSTED(0) | bls.F_UNCOMPRESSED_OUT
+    rc = fn(int(g2), n, ks.data_ptr(), pts.data_ptr(), ln, out.data_ptr(), st.data_ptr(), fl, tr.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = tr.cpu().numpy()
+    N = P.f.N
+    for j, (idx, lanes) in enumerate(trace):
+        for lane, limbs in enumerate(lanes):
+            dev = [int(x) for x in got[j, lane, :N]]
+            assert dev == limbs, "record %d (%s, executed #%d), lane %d: device %s simulator %s" % (idx, P.names[idx], j, lane, dev[:3], limbs[:3])
+    exp = O.g2_mul(k0, pt) if g2 else O.g1_mul(k0, pt)
+    res = bytes(out.cpu().numpy()[:ln])
+    assert res == (_g2_unc(exp) if g2 else _g1_unc(exp))
+
+
+def _scalars(label, n):
+    raw = hashlib.shake_256(label).digest(n * 32)
+    a = np.frombuffer(raw, dtype=np.uint8).reshape(n, 32).copy()
+    return a
+
+
+@pytest.mark.parametrize("grp", [1, 2])
+def test_mul_through_the_machine_against_the_oracle(bls, grp):
+    """n = 3000 elements (above the machine's threshold, not a multiple of 64): random 256-bit scalars (most of them
+    above r), edge scalars, infinity and rejected points sprinkled in, every flag combination."""
+    n = 3000
+    rng = random.Random(grp)
+    k = _scalars(b"lvm/k%d" % grp, n)
+    edge = [0, 1, 2, 3, O.R - 1, O.R, O.R + 1, 2 * O.R, (1 << 256) - 1, 1 << 255, 0xD201000000010000, 0xD201000000010000 ** 2]
+    for j, e in enumerate(edge):
+        k[10 + j] = np.frombuffer(e.to_bytes(32, "big"), dtype=np.uint8)
+        k[n - 1 - j] = np.frombuffer(e.to_bytes(32, "big"), dtype=np.uint8)
+    hs = [rng.randrange(1, O.R) for _ in range(8)]
+    if grp == 1:
+        base = [O.g1_mul(h, O.G1_GEN) for h in hs]
+        comp, unc, mul, ln, dec = O.g1_compress, O.g1_serialize_unc, O.g1_mul, 48, bls.g1_batch_mul
+    else:
+        base = [O.g2_mul(h, O.G2_GEN) for h in hs]
+        comp, unc, mul, ln, dec = O.g2_compress, O.g2_serialize_unc, O.g2_mul, 96, bls.g2_batch_mul
+    which = [i % 8 for i in range(n)]
+    pts_c = [comp(base[w]) for w in which]
+    pts_u = [unc(base[w]) for w in which]
+    inf_rows, bad_rows = [5, 100, n - 30], [7, 101, n - 31]
+    for i in inf_rows:
+        pts_c[i], pts_u[i] = comp(None), unc(None)
+    for i in bad_rows:
+        pts_c[i] = bytes([0x80]) + bytes(ln - 2) + b"\x05" if grp == 1 else bytes([0x80]) + bytes(ln - 2) + b"\x07"
+        pts_u[i] = bytes(2 * ln - 1) + b"\x01"   # (0, 1): not on the curve
+    samples = sorted(set(list(range(0, 40)) + list(range(n - 40, n)) + [rng.randrange(n) for _ in range(24)] + inf_rows + bad_rows))
+    ki = [int.from_bytes(bytes(k[i]), "big") for i in range(n)]
+    for fin, fout in ((0, 0), (bls.F_UNCOMPRESSED, 0), (bls.F_UNCOMPRESSED | bls.F_TRUSTED(0), bls.F_UNCOMPRESSED_OUT), (bls.F_TRUSTED(0), 0)):
+        pts = pts_u if fin & bls.F_UNCOMPRESSED else pts_c
+        out, st = dec(k, b"".join(pts), fin | fout)
+        out, st = np.asarray(out), np.asarray(st)
+        enc = unc if fout else comp
+        for i in samples:
+            if i in bad_rows:
+                if fin & bls.F_TRUSTED(0) and fin & bls.F_UNCOMPRESSED:
+                    continue  # vouched-for garbage: no contract
+                if fin & bls.F_TRUSTED(0) and not (fin & bls.F_UNCOMPRESSED):
+                    # compressed, trusted: the square root still has to exist
+                    try:
+                        (O.g1_decompress if grp == 1 else O.g2_decompress)(pts[i], subgroup_check=False)
+                        continue
+                    except O.DecodeError:
+                        pass
+                assert st[i] != 0 and not out[i].any(), (fin, i)
+                continue
+            assert st[i] == 0, (fin, fout, i, st[i])
+            p = None if i in inf_rows else base[which[i]]
+            assert bytes(out[i]) == enc(mul(ki[i], p)), (fin, fout, i, hex(ki[i]))
+    # a shared base (PriPoly.Commit's shape)
+    out, st = (bls.g1_commit if grp == 1 else bls.g2_commit)(k, comp(base[3]))
+    out = np.asarray(out)
+    for i in samples[::3]:
+        assert bytes(out[i]) == comp(mul(ki[i], base[3])), i
