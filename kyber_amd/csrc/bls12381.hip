@@ -26,3 +26,8 @@ extern "C" int kyb_debug_bls12381_lvm_trace(int g2, size_t n, const void* d_scal
                               (uint8_t*)d_status, flags, (hipStream_t)stream, &only, (int32_t*)d_trace));
     return only ? KYB_OK : KYB_E_ARG;
 }
+// The machine's batch threshold for both groups (< 0: back to the built-in rule); tests and A/B runs.
+extern "C" int kyb_debug_bls12381_lvm_min(long long n) {
+    kyb::bls::lvm_min_override() = n;
+    return KYB_OK;
+}

@@ -233,12 +233,23 @@ __global__ __launch_bounds__(64) void bls12381_lvm_encode_kernel(size_t n, const
     }
 }
 
-inline size_t lvm_min_batch() {
-    static const size_t v = [] {
-        const char* e = getenv("KYB_LVM_MIN");  // A/B switch: a huge value sends everything to the per-lane kernels
-        return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1024;
+// Smallest batch the machine takes.  G2: a point is two lanes, so the machine has twice the waves of the per-lane
+// kernel at any size and wins from the first full wave per CU on (measured 1.4x at 2^16 and 2^18).  G1: with one wave per
+// SIMD (up to 64 lanes x 4 SIMDs x CUs elements) both formulations are bound by the latency of a lone wave and the
+// per-lane kernel is slightly ahead (3.77 against 3.97 ms per 2^16); from two waves per SIMD the machine's 202
+// registers let them overlap and it leads by 1.3x (profiles/r03_lvm_*).  KYB_LVM_MIN overrides both (A/B runs; a huge
+// value sends everything to the per-lane kernels).
+inline long long& lvm_min_override() {
+    static long long v = [] {
+        const char* e = getenv("KYB_LVM_MIN");
+        return e ? (long long)strtoull(e, nullptr, 10) : -1ll;
     }();
     return v;
+}
+inline size_t lvm_min_batch(bool g2, int num_cu) {
+    const long long env = lvm_min_override();
+    if (env >= 0) return (size_t)env;
+    return g2 ? (size_t)1024 : (size_t)num_cu * 4 * 64 + 1;
 }
 inline size_t lvm_al(size_t x) { return (x + 255) & ~size_t(255); }
 
@@ -247,10 +258,10 @@ inline size_t lvm_al(size_t x) { return (x + 255) & ~size_t(255); }
 inline int lvm_mul(bool g2, size_t n, const uint8_t* d_scalars, const uint8_t* d_points, size_t point_stride, uint8_t* d_out,
                    uint8_t* d_status, uint32_t flags, hipStream_t st, const uint8_t** only, int32_t* trace = nullptr) {
     *only = nullptr;
-    if (n < lvm_min_batch()) return KYB_OK;
     DeviceCtx* ctx;
     int rc = get_ctx(&ctx);
     if (rc) return rc;
+    if (n < lvm_min_batch(g2, ctx->num_cu)) return KYB_OK;
     std::lock_guard<std::recursive_mutex> lk(ctx->enq_mu);
     const size_t chunk = g2 ? (size_t(1) << 16) : (size_t(1) << 17);
     const size_t cn = n < chunk ? n : chunk, cl = g2 ? 2 * cn : cn;

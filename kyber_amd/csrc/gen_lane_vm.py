@@ -39,8 +39,8 @@ from gen_tower_vm import VmField, bls12381_field, emit_field, _carr  # noqa: E40
 REC_WORDS = 64
 NSLOTS = 6
 OP_DOT, OP_IN, OP_OUTW, OP_INV, OP_TSTORE, OP_SELDIGIT, OP_CTRSET, OP_CTRADD, OP_ZFLAG = range(9)
-(K_MUL, K_LIN, K_MULC, K_LINC, K_MULT, K_LINT, K2_MUL, K2_SQR, K2_MULT, K2_MULC, K2_NORM) = range(11)
-KIND_NAMES = ["mul", "lin", "mulc", "linc", "mult", "lint", "mul2", "sqr2", "mul2t", "mul2c", "norm2"]
+(K_MUL, K_LIN, K_MULC, K_LINC, K_MULT, K_LINT, K2_MUL, K2_SQR, K2_MULT, K2_MULC, K2_NORM, K_SQR) = range(12)
+KIND_NAMES = ["mul", "lin", "mulc", "linc", "mult", "lint", "mul2", "sqr2", "mul2t", "mul2c", "norm2", "sqr"]
 DYN = -1  # table entry chosen by the lane's current digit (OP_SELDIGIT) instead of a static index
 
 
@@ -128,6 +128,7 @@ class LProg:
         assert 0 <= out < NSLOTS and 1 <= len(terms) <= 30
         if raw:
             assert all(t[0] in ("lin", "linc", "lint") for t in terms)
+        assert all(t[0] != "sqr" for t in terms[1:]), "the symmetric square is the first term of its record"
         if not self.pair:
             assert not negodd and all(not t[0].endswith("2") and t[0] not in ("mul2t", "mul2c") for t in terms)
         self._emit(dict(op=OP_DOT, out=out, terms=list(terms), raw=raw, negodd=negodd), name)
@@ -155,6 +156,8 @@ class LProg:
             for t in r["terms"]:
                 k = t[0]
                 tot += {"mul": 1, "mulc": 1, "mult": 1, "mul2": 2, "mul2t": 2, "mul2c": 2, "norm2": 2, "sqr2": 1}.get(k, 0) * n2
+                if k == "sqr":
+                    tot += self.f.N * (self.f.N + 1) // 2
             if not r["raw"]:
                 tot += n2
         return tot
@@ -247,6 +250,10 @@ class LProg:
                                 t[N + i] += x[i]
                         elif k == "mul":
                             mac(t, operand(lane, term[1]), operand(lane, term[2]))
+                        elif k == "sqr":
+                            x = operand(lane, term[1])
+                            assert all(abs(2 * v) < 1 << 31 for v in x), "operand limb overflow"
+                            mac(t, x, x)
                         elif k == "mulc":
                             mac(t, operand(lane, term[1]), cl[term[2]])
                         elif k == "mult":
@@ -373,14 +380,14 @@ class LProg:
                         cx, vx = opb(term[1])
                         if k in ("mul", "mul2"):
                             cy, vy = opb(term[2])
-                        elif k in ("sqr2", "norm2"):
+                        elif k in ("sqr2", "norm2", "sqr"):
                             cy, vy = cx, vx
                         elif k in ("mult", "mul2t"):
                             cy, vy = 1.0, tabb(term[2], term[4])
                         else:
                             cy, vy = 1.0, 1.0
                         # limb products: N per column; the top limbs are bounded by the value bounds
-                        mult = {"mul": 1, "mulc": 1, "mult": 1, "mul2": 2, "mul2t": 2, "mul2c": 2, "norm2": 2, "sqr2": 4}[k]
+                        mult = {"mul": 1, "sqr": 1, "mulc": 1, "mult": 1, "mul2": 2, "mul2t": 2, "mul2c": 2, "norm2": 2, "sqr2": 4}[k]
                         lx = max(cx * half, vx * top_unit + cx)
                         ly = max(cy * half, vy * top_unit + cy)
                         col += mult * N * lx * ly
@@ -479,7 +486,7 @@ class Curve:
         return ("mul2", X, Y) if self.pair else ("mul", X, Y)
 
     def sqr(self, X):
-        return ("sqr2", X) if self.pair else ("mul", X, X)
+        return ("sqr2", X) if self.pair else ("sqr", X)
 
     def mult(self, X, coord, signed=False, entry=DYN):
         return ("mul2t", X, coord, signed, entry) if self.pair else ("mult", X, coord, signed, entry)
@@ -493,7 +500,7 @@ class Curve:
             P.dot(SB, [self.sqr(L(SY))], name=name + ".B")
             P.dot(SZ, [self.mul(L(SY, 2), L(SZ))], name=name + ".Z")
             P.dot(SC, [self.mul(L(SX), L(SB))], name=name + ".C")
-            P.dot(SX, [self.mul(L(SA, 3), L(SA, 3)), ("lin", L(SC, -8))], name=name + ".X")
+            P.dot(SX, [self.sqr(L(SA, 3)), ("lin", L(SC, -8))], name=name + ".X")
             P.dot(SY, [self.mul(L(SA, 3), L(SC, 4, SX, -1)), self.mul(L(SB, -8), L(SB))], name=name + ".Y")
         else:
             # squarings are one product per lane, multiplications two: dbl-2009-l (2M + 5S)
