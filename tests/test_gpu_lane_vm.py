@@ -24,9 +24,15 @@ def bls():
     import torch
 
     assert torch.cuda.is_available()
+    from kyber_amd import _lib
     from kyber_amd.pairing import bls12381 as bls
 
-    return bls
+    # every batch of these tests takes the machine (G1 batches below two waves per SIMD stay on the per-lane kernel by default)
+    lib = C.CDLL(_lib.LIB_PATH)
+    lib.kyb_debug_bls12381_lvm_min.argtypes = [C.c_longlong]
+    assert lib.kyb_debug_bls12381_lvm_min(1024) == 0
+    yield bls
+    lib.kyb_debug_bls12381_lvm_min(-1)
 
 
 def _g1_unc(p):
