@@ -187,6 +187,10 @@ int kyb_bls12381_g2_mul_dev(size_t n, const void *d_scalars, const void *d_point
 /* out[i] = a[i] + b[i]: G1Elt.Add / G2Elt.Add (kilic/g1.go:90-96, g2.go). */
 int kyb_bls12381_g1_add(size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out, uint8_t *status);
 int kyb_bls12381_g2_add(size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out, uint8_t *status);
+/* the same on device pointers, enqueued on `stream` (kilic/g1.go:90-96): what the node-wide MSM's combine of the gathered partial
+ * points uses, so that nothing of the exchange step touches the host */
+int kyb_bls12381_g1_add_dev(size_t n, const void *d_a, const void *d_b, void *d_out, void *d_status, void *stream);
+int kyb_bls12381_g2_add_dev(size_t n, const void *d_a, const void *d_b, void *d_out, void *d_status, void *stream);
 
 /* Batch UnmarshalBinary: status[i] = what G1Elt / G2Elt.UnmarshalBinary would decide (kilic/g1.go:127-131, g2.go:
  * ZCash flag rules, x < p, on the curve, in the r-torsion subgroup -- the 34 fixtures of
@@ -267,6 +271,10 @@ int kyb_bn256_g2_mul_dev(size_t n, const void *d_scalars, const void *d_points, 
 /* out[i] = a[i] + b[i]: pointG1.Add / pointG2.Add (pairing/bn256/point.go:130-140, 381-391 -> curve.go:69). */
 int kyb_bn256_g1_add(size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out, uint8_t *status);
 int kyb_bn256_g2_add(size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out, uint8_t *status);
+/* the same on device pointers, enqueued on `stream` (pairing/bn256/point.go:130-140): what the node-wide MSM's combine of the gathered partial
+ * points uses, so that nothing of the exchange step touches the host */
+int kyb_bn256_g1_add_dev(size_t n, const void *d_a, const void *d_b, void *d_out, void *d_status, void *stream);
+int kyb_bn256_g2_add_dev(size_t n, const void *d_a, const void *d_b, void *d_out, void *d_status, void *stream);
 /* Batch UnmarshalBinary: pointG1 / pointG2.UnmarshalBinary (pairing/bn256/point.go:206-238, 466-499): on the curve
  * (G2: on the twist, NO subgroup check, as the reference), 64 / 128 zero bytes = infinity; out[i] = MarshalBinary of
  * the accepted point (zero bytes when rejected).  flags are accepted and ignored. */
@@ -318,6 +326,10 @@ int kyb_bn254_g2_mul_dev(size_t n, const void *d_scalars, const void *d_points, 
                          void *d_status, uint32_t flags, void *stream);
 int kyb_bn254_g1_add(size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out, uint8_t *status);
 int kyb_bn254_g2_add(size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out, uint8_t *status);
+/* the same on device pointers, enqueued on `stream` (pairing/bn254/point.go:92-101): what the node-wide MSM's combine of the gathered partial
+ * points uses, so that nothing of the exchange step touches the host */
+int kyb_bn254_g1_add_dev(size_t n, const void *d_a, const void *d_b, void *d_out, void *d_status, void *stream);
+int kyb_bn254_g2_add_dev(size_t n, const void *d_a, const void *d_b, void *d_out, void *d_status, void *stream);
 int kyb_bn254_g1_unmarshal(size_t n, const uint8_t *points, uint8_t *out, uint8_t *status, uint32_t flags);
 int kyb_bn254_g2_unmarshal(size_t n, const uint8_t *points, uint8_t *out, uint8_t *status, uint32_t flags);
 int kyb_bn254_g1_unmarshal_dev(size_t n, const void *d_points, void *d_out, void *d_status, uint32_t flags, void *stream);

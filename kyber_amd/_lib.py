@@ -63,6 +63,8 @@ SIGNATURES = {
     "kyb_bls12381_g2_mul_dev": [_sz, _vp, _vp, _sz, _vp, _vp, _u32, _vp],
     "kyb_bls12381_g1_add": [_sz, _vp, _vp, _vp, _vp],
     "kyb_bls12381_g2_add": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_bls12381_g1_add_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
+    "kyb_bls12381_g2_add_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
     "kyb_bls12381_pair": [_sz, _vp, _vp, _vp, _vp, _u32],
     "kyb_bls12381_hash_g1": [_sz, _vp, _sz, _vp, _sz, _vp, _vp],
     "kyb_bls12381_hash_g2": [_sz, _vp, _sz, _vp, _sz, _vp, _vp],
@@ -85,6 +87,8 @@ SIGNATURES = {
     "kyb_bn256_g2_mul_dev": [_sz, _vp, _vp, _sz, _vp, _vp, _u32, _vp],
     "kyb_bn256_g1_add": [_sz, _vp, _vp, _vp, _vp],
     "kyb_bn256_g2_add": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_bn256_g1_add_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
+    "kyb_bn256_g2_add_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
     "kyb_bn256_pair": [_sz, _vp, _vp, _vp, _vp, _u32],
     "kyb_bn256_hash_g1": [_sz, _vp, _sz, _vp, _vp],
     "kyb_bn256_hash_g1_dev": [_sz, _vp, _sz, _vp, _vp, _vp],
@@ -125,6 +129,8 @@ SIGNATURES = {
     "kyb_bn254_g2_mul_dev": [_sz, _vp, _vp, _sz, _vp, _vp, _u32, _vp],
     "kyb_bn254_g1_add": [_sz, _vp, _vp, _vp, _vp],
     "kyb_bn254_g2_add": [_sz, _vp, _vp, _vp, _vp],
+    "kyb_bn254_g1_add_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
+    "kyb_bn254_g2_add_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
     "kyb_bn254_pair": [_sz, _vp, _vp, _vp, _vp, _u32],
     "kyb_bn254_gt_mul": [_sz, _vp, _vp, _vp, _vp],
     "kyb_bn254_gt_mul_dev": [_sz, _vp, _vp, _vp, _vp, _vp],

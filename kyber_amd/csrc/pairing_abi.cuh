@@ -264,6 +264,28 @@ static int PFX##_add_host(bool g2, size_t n, const uint8_t* a, const uint8_t* b,
     if (status) KYB_TRY(st.download(status, n)); \
     return KYB_OK; \
 } \
+int kyb_##PFX##_g1_add_dev(size_t n, const void* d_a, const void* d_b, void* d_out, void* d_status, void* stream) { \
+    if (n && (!d_a || !d_b || !d_out)) { \
+        kyb::set_error("kyb_" #PFX "_g1_add_dev: bad argument"); \
+        return KYB_E_ARG; \
+    } \
+    if (!n) return KYB_OK; \
+    hipLaunchKernelGGL(kyb::PFX##_g1_add_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, (const uint8_t*)d_a, \
+                       (const uint8_t*)d_b, (uint8_t*)d_out, (uint8_t*)d_status); \
+    KYB_HIP_CHECK(hipGetLastError()); \
+    return KYB_OK; \
+} \
+int kyb_##PFX##_g2_add_dev(size_t n, const void* d_a, const void* d_b, void* d_out, void* d_status, void* stream) { \
+    if (n && (!d_a || !d_b || !d_out)) { \
+        kyb::set_error("kyb_" #PFX "_g2_add_dev: bad argument"); \
+        return KYB_E_ARG; \
+    } \
+    if (!n) return KYB_OK; \
+    hipLaunchKernelGGL(kyb::PFX##_g2_add_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, (const uint8_t*)d_a, \
+                       (const uint8_t*)d_b, (uint8_t*)d_out, (uint8_t*)d_status); \
+    KYB_HIP_CHECK(hipGetLastError()); \
+    return KYB_OK; \
+} \
 int kyb_##PFX##_g1_add(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, uint8_t* status) { \
     return PFX##_add_host(false, n, a, b, out, status); \
 } \

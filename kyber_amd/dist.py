@@ -35,8 +35,23 @@ def _unit_scalars(world: int, little_endian: bool) -> np.ndarray:
     return s
 
 
-def _tree_sum(points: np.ndarray, add_fn: Callable):
-    """Sum the rows of `points` (encoded group elements) with log2(n) batched Point.Add calls.  Returns (enc, ok)."""
+def _tree_sum(points, add_fn: Callable, bad=None):
+    """Sum the rows of `points` (encoded group elements) with log2(n) batched Point.Add calls.  Returns (enc, ok).
+    CUDA tensors stay on the device: the adds are enqueued on the current stream and the "any input rejected" bit is
+    read once, at the end (one synchronisation for the whole combine instead of one per level and a host round trip
+    of the partial points)."""
+    if type(points).__module__.startswith("torch"):
+        import torch
+
+        pts = points.contiguous()
+        bad = torch.zeros((), dtype=torch.bool, device=pts.device) if bad is None else bad  # (a rank already saw a bad input)
+        while pts.shape[0] > 1:
+            m = pts.shape[0] // 2
+            out, st = add_fn(pts[0:2 * m:2].contiguous(), pts[1:2 * m:2].contiguous())
+            bad = bad | st.any()
+            out = out.view(m, -1)
+            pts = torch.cat([out, pts[2 * m:]], dim=0) if pts.shape[0] % 2 else out
+        return pts[0], not bool(bad.item())
     pts = np.ascontiguousarray(points)
     ok = True
     while pts.shape[0] > 1:
@@ -69,18 +84,26 @@ def msm_allgather(scalars_shard, points_shard, local_msm: Callable, point_len: i
     part, st = local_msm(scalars_shard, points_shard)
     is_t = type(part).__module__.startswith("torch")
     dev = part.device if is_t else torch.device("cpu")
-    bad_local = bool(st.any().item()) if is_t else bool(np.asarray(st).any())
-    # payload: encoded partial point + one "bad input seen" byte
+    on_gpu = is_t and dev.type == "cuda"
+    # payload: encoded partial point + one "bad input seen" byte.  On the GPU everything up to the final verdict is
+    # enqueued -- the status reduction, the all-gather (RCCL on the same stream), the combine -- and the host reads ONE
+    # boolean at the end.
     buf = torch.zeros(point_len + 1, dtype=torch.uint8, device=dev)
     buf[:point_len] = part.view(-1) if is_t else torch.from_numpy(np.frombuffer(bytes(part), dtype=np.uint8).copy())
-    buf[point_len] = 1 if bad_local else 0
+    if on_gpu:
+        buf[point_len] = st.any().to(torch.uint8)
+    else:
+        buf[point_len] = 1 if (bool(st.any().item()) if is_t else bool(np.asarray(st).any())) else 0
     gathered = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(gathered, buf, group=group)
     allp = torch.stack(gathered)
+    pts = allp[:, :point_len].contiguous()
+    if on_gpu and combine_add is not None:
+        enc, ok = _tree_sum(pts, combine_add, bad=allp[:, point_len].any())
+        return (enc if ok else torch.zeros(point_len, dtype=torch.uint8, device=dev)), ok
     if bool(allp[:, point_len].any().item()):
         zero = torch.zeros(point_len, dtype=torch.uint8, device=dev)
         return (zero if is_t else zero.numpy()), False
-    pts = allp[:, :point_len].contiguous()
     if combine_add is not None:
         enc, ok = _tree_sum(pts.cpu().numpy(), combine_add)
         return (torch.from_numpy(np.ascontiguousarray(enc)).to(dev) if is_t else enc), ok

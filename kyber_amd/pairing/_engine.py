@@ -131,8 +131,19 @@ class Engine:
         return self.mul(2, scalars, base, True, flags)
 
     def add(self, group: int, a, b):
-        """(out, status): out[i] = a[i] + b[i]  (N x Point.Add)."""
+        """(out, status): out[i] = a[i] + b[i]  (N x Point.Add).  CUDA tensors stay on the device (enqueue only)."""
         w = self.G1_LEN if group == 1 else self.G2_LEN
+        if _is_torch(a):
+            import torch
+
+            x, y = a.contiguous().view(-1, w), b.contiguous().view(-1, w)
+            if x.shape != y.shape:
+                raise ValueError("length mismatch")
+            out = torch.empty_like(x)
+            st = torch.empty(x.shape[0], dtype=torch.uint8, device=x.device)
+            fn, nm = self._fn(f"g{group}_add_dev")
+            check(fn(x.shape[0], x.data_ptr(), y.data_ptr(), out.data_ptr(), st.data_ptr(), _stream()), nm)
+            return out, st
         x, y = _host(a, w), _host(b, w)
         if x.shape != y.shape:
             raise ValueError("length mismatch")

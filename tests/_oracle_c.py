@@ -24,6 +24,10 @@ def lib():
         l.ora_ed25519_mul.restype = None
         l.ora_ed25519_msm.argtypes = [sz, vp, vp, vp]
         l.ora_ed25519_msm.restype = C.c_long
+        for name in ("ora_bn256_pair", "ora_bn256_g1_mul_sum", "ora_bn256_g1_mul", "ora_bls12381_g1_mul_sum"):
+            f = getattr(l, name)
+            f.argtypes = [sz, vp, vp, vp, vp, i]
+            f.restype = None
         _lib = l
     return _lib
 
@@ -51,3 +55,42 @@ def ed_msm(scalars, points):
     out = np.empty(32, dtype=np.uint8)
     rc = lib().ora_ed25519_msm(len(s), s.ctypes.data, p.ctypes.data, out.ctypes.data)
     return out, rc
+
+
+def bn256_pair(g1, g2, threads: int = 0):
+    """(gt, status): oracle/bn256_ref.c, the reference's optimalAte restated in C (64 + 128 bytes -> 384 bytes)."""
+    a = np.ascontiguousarray(np.frombuffer(g1, dtype=np.uint8) if isinstance(g1, (bytes, bytearray)) else g1, dtype=np.uint8).reshape(-1, 64)
+    b = np.ascontiguousarray(np.frombuffer(g2, dtype=np.uint8) if isinstance(g2, (bytes, bytearray)) else g2, dtype=np.uint8).reshape(-1, 128)
+    out = np.empty((len(a), 384), dtype=np.uint8)
+    st = np.empty(len(a), dtype=np.uint8)
+    lib().ora_bn256_pair(len(a), a.ctypes.data, b.ctypes.data, out.ctypes.data, st.ctypes.data, threads or (os.cpu_count() or 1))
+    return out, st
+
+
+def bn256_g1_mul(scalars, points, threads: int = 0):
+    s = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
+    p = np.ascontiguousarray(points, dtype=np.uint8).reshape(-1, 64)
+    out = np.empty((len(s), 64), dtype=np.uint8)
+    st = np.empty(len(s), dtype=np.uint8)
+    lib().ora_bn256_g1_mul(len(s), s.ctypes.data, p.ctypes.data, out.ctypes.data, st.ctypes.data, threads or (os.cpu_count() or 1))
+    return out, st
+
+
+def bn256_g1_mul_sum(scalars, points, threads: int = 0):
+    """sum_i k_i P_i the reference's way: N x (Mul + Add)"""
+    s = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
+    p = np.ascontiguousarray(points, dtype=np.uint8).reshape(-1, 64)
+    out = np.empty(64, dtype=np.uint8)
+    st = np.zeros(len(s), dtype=np.uint8)
+    lib().ora_bn256_g1_mul_sum(len(s), s.ctypes.data, p.ctypes.data, out.ctypes.data, st.ctypes.data, threads or (os.cpu_count() or 1))
+    return out, st
+
+
+def bls12381_g1_mul_sum(scalars, points_unc, threads: int = 0):
+    """sum_i k_i P_i, N x (Mul + Add) on BLS12-381 G1; ZCash uncompressed points in, uncompressed point out (96 bytes)"""
+    s = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
+    p = np.ascontiguousarray(points_unc, dtype=np.uint8).reshape(-1, 96)
+    out = np.empty(96, dtype=np.uint8)
+    st = np.zeros(len(s), dtype=np.uint8)
+    lib().ora_bls12381_g1_mul_sum(len(s), s.ctypes.data, p.ctypes.data, out.ctypes.data, st.ctypes.data, threads or (os.cpu_count() or 1))
+    return out, st

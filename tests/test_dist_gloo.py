@@ -128,3 +128,73 @@ def test_msm_allgather_world2_gloo():
         assert p.exitcode == 0
     for rank, res in results:
         assert all(res.values()), (rank, res)
+
+
+def _worker_wide(rank, world, port, q):
+    """world 4 / 8: uneven shards (n not a multiple of world, some ranks one point longer), a rejected point on a MIDDLE
+    rank, an empty shard (n < world), and the partial points combined by the add tree with an odd count at some level."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests import _oracle_c as OC
+
+        res = {}
+        for n in (world * 5 + 3, world + 1, world - 1):
+            rng = np.random.default_rng(100 + n)
+            s = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+            s[:, 31] &= 0x0F
+            h = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+            h[:, 31] &= 0x0F
+            P = OC.ed_mul_base(h, threads=1)
+            lo, hi = kd.shard_range(n, rank, world)
+            full, rc = OC.ed_msm(s, P)
+            out, ok = kd.msm_allgather(s[lo:hi], P[lo:hi], _oracle_ed_msm, 32, True)
+            res["ed_n%d" % n] = bool(ok) and rc == 0 and bytes(out) == bytes(full)
+            out, ok = kd.msm_allgather(s[lo:hi], P[lo:hi], _oracle_ed_msm, 32, True, combine_add=_oracle_ed_add)
+            res["ed_tree_n%d" % n] = bool(ok) and bytes(out) == bytes(full)
+        # a bad point inside the shard of a middle rank: every rank must report failure and hold zero bytes
+        n = world * 5 + 3
+        rng = np.random.default_rng(100 + n)
+        s = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+        s[:, 31] &= 0x0F
+        h = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+        h[:, 31] &= 0x0F
+        P = OC.ed_mul_base(h, threads=1)
+        mid_lo, mid_hi = kd.shard_range(n, world // 2, world)
+        P[mid_lo + 1] = np.frombuffer(bytes([2]) + bytes(31), dtype=np.uint8)
+        lo, hi = kd.shard_range(n, rank, world)
+        for name, kw in (("msm", {}), ("tree", {"combine_add": _oracle_ed_add})):
+            out, ok = kd.msm_allgather(s[lo:hi], P[lo:hi], _oracle_ed_msm, 32, True, **kw)
+            res["bad_mid_" + name] = (not ok) and not np.asarray(out).any()
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def _oracle_ed_add(a, b):
+    from oracle import ed25519 as O
+
+    a = np.asarray(a, dtype=np.uint8).reshape(-1, 32)
+    b = np.asarray(b, dtype=np.uint8).reshape(-1, 32)
+    out = np.stack([np.frombuffer(O.encode(O.add(O.decode(bytes(x)), O.decode(bytes(y)))), dtype=np.uint8) for x, y in zip(a, b)])
+    return out, np.zeros(len(a), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_msm_allgather_world4_and_8_gloo(world):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_wide, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in results) == list(range(world))
+    for rank, res in results:
+        assert all(res.values()), (rank, res)

@@ -126,3 +126,45 @@ def test_bls_verify_sharded(three_shards):
     exp = np.ones(n, dtype=bool)
     exp[::5] = False
     assert (np.asarray(got[0]).astype(bool) == exp).all()
+
+
+def test_eight_listed_devices_msm_and_batches():
+    """The shape of the 8-GPU node the driver scales to, on the one GPU there is: eight shards (eight host threads, eight
+    device contexts' worth of calls on device 0), uneven split (1003 = 3 x 126 + 5 x 125), a rejected point in the
+    shard of a middle device, the MSM's combine of eight partial points, and a batch big enough that the BLS12-381 G2
+    shards take the lane machine."""
+    from kyber_amd import devices
+    from kyber_amd.group import edwards25519 as ed
+    from kyber_amd.pairing import bls12381 as bls
+
+    devices.set_devices([0] * 8)
+    devices.set_shard_threshold(1)
+    try:
+        assert devices.get_devices() == [0] * 8
+        n = 1003
+        s = _shake(b"md8/s", n * 32).reshape(n, 32).copy()
+        h = _shake(b"md8/h", n * 32).reshape(n, 32).copy()
+        s[:, 31] &= 0x7F
+        h[:, 31] &= 0x0F
+        good = ed.batch_mul_base(h)
+        ref, got = _both(devices, lambda: ed.msm(s, good))
+        assert _same(ref, got) and np.asarray(got[0]).any()
+        bad = good.copy()
+        bad[126 * 3 + 125 + 7] = 0
+        bad[126 * 3 + 125 + 7, 0] = 2          # inside the fifth shard
+        ref, got = _both(devices, lambda: ed.msm(s, bad))
+        assert _same(ref, got) and not np.asarray(got[0]).any() and np.asarray(got[1]).sum() == 1
+        ref, got = _both(devices, lambda: ed.batch_mul(s, bad))
+        assert _same(ref, got) and np.nonzero(got[1])[0].tolist() == [126 * 3 + 125 + 7]
+        m = 8 * 1100 + 5                          # every shard above the lane machine's G2 threshold
+        k = _shake(b"md8/k", m * 32).reshape(m, 32).copy()
+        k[:, 0] &= 0x3F
+        Q = np.asarray(bls.g2_commit(k[:64])[0])
+        Qs = np.tile(Q, (m // 64 + 1, 1))[:m].copy()
+        ref, got = _both(devices, lambda: bls.g2_batch_mul(k, Qs))
+        assert _same(ref, got) and not np.asarray(got[1]).any()
+        ref, got = _both(devices, lambda: bls.g1_msm(k[:n], np.asarray(bls.g1_commit(k[:n])[0])))
+        assert _same(ref, got)
+    finally:
+        devices.set_devices([])
+        devices.set_shard_threshold(16384)
