@@ -70,11 +70,45 @@ def be_scalars(label: bytes, n: int) -> np.ndarray:
     return a
 
 
-def cpu_baseline(scalars: np.ndarray, points: np.ndarray):
-    """The oracle's C restatement (kind "port") on the host cores, bounded sample (~10-20 s)."""
+def cpu_info():
+    """cores this process may run on (the lease, not the machine: os.cpu_count() names every logical CPU of the host) and
+    the CPU model"""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    quota = None  # a cgroup CPU quota caps the lease below its affinity mask (cpu.max: "<quota> <period>" or "max")
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return cores, os.cpu_count() or cores, model, quota
+
+
+def _sha(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def cpu_baseline(scalars: np.ndarray, points: np.ndarray, gpu_fix: np.ndarray, gpu_var: np.ndarray):
+    """The oracle's C restatement (kind "port") on the host cores, on a bounded prefix of THE SAME batch the GPU
+    just processed (the whole 2^20 when the host manages it in ~10 s), and the comparison SURVEY.md section 8d asks for:
+    SHA-256 over the concatenated outputs, oracle against GPU."""
     from tests import _oracle_c as OC
 
-    cores = os.cpu_count() or 1
+    cores, logical, model, quota = cpu_info()
 
     def rate(n, threads):
         t0 = time.perf_counter()
@@ -83,25 +117,77 @@ def cpu_baseline(scalars: np.ndarray, points: np.ndarray):
         return 2 * n / (time.perf_counter() - t0)
 
     r1 = rate(2048, 1)
-    rall = rate(min(len(scalars), 2048 * min(cores, 64)), cores)
+    rall = rate(min(len(scalars), 2048 * min(cores, 64)), cores) if cores > 1 else r1
     threads = cores if rall > r1 else 1
     per_s = max(r1, rall)
-    n = int(min(len(scalars), max(4096, per_s * 5.0)))  # ~10 s of CPU work (two kernels x 5 s)
+    n = int(min(len(scalars), max(4096, per_s * 6.0)))  # ~12 s of CPU work (two kernels x 6 s)
     t0 = time.perf_counter()
-    OC.ed_mul(scalars[:n], points[:n], threads=threads)
-    OC.ed_mul_base(scalars[:n], threads=threads)
+    var, st = OC.ed_mul(scalars[:n], points[:n], threads=threads)
+    fix = OC.ed_mul_base(scalars[:n], threads=threads)
     dt = time.perf_counter() - t0
+    h_cpu, h_gpu = _sha(fix, var), _sha(gpu_fix[:n], gpu_var[:n])
     return {"value": 2 * n / dt, "unit": "scalar-muls/s", "cores": threads, "kind": "port",
-            "single_thread_value": r1,
-            "sample": f"{n} fixed-base + {n} variable-base Ed25519 scalar-muls of the same batch, "
+            "single_thread_value": r1, "affinity_cores": cores, "cgroup_cpu_quota_cores": quota,
+            "logical_cpus_of_the_host": logical, "cpu_model": model,
+            "outputs_match": bool(h_cpu == h_gpu and not st.any()), "outputs_compared": 2 * n, "outputs_sha256": h_cpu,
+            "sample": f"{n} fixed-base + {n} variable-base Ed25519 scalar-muls = the first {n} elements of the GPU's batch, "
                       f"oracle/ed25519_ref.c (radix-2^51 C restatement of ge.go:373/443, gcc -O3), "
-                      f"{threads} thread(s) of {cores} logical cores; the Go reference itself cannot run "
-                      f"here (no Go toolchain)"}
+                      f"{threads} thread(s) on {cores} core(s) this process may use ({logical} logical CPUs on the host, {model}); "
+                      f"the Go reference itself cannot run here (no Go toolchain)"}
 
 
-# No CPU figure is produced for the pairing side-workloads: the only pairing code that ran on the host was the
-# per-lane device headers (since removed with the per-lane pairing kernels), far slower than any CPU library, so a
-# GPU/CPU ratio from it meant nothing.  The reference's own published single-core rate is quoted instead.
+def cpu_baseline_pairing_and_msm(bn, bls):
+    """CPU figures for the composite metric's other two thirds, each on a bounded sample of the GPU's own inputs with the
+    outputs compared: Suite.Pair on bn256 (oracle/bn256_ref.c: optate.go restated in C -- the one pairing whose
+    arithmetic is in the reference tree) and the N x (Mul + Add) sum the reference runs where this engine runs an MSM
+    (oracle/bls12381_g1_ref.c on the MSM config's curve; oracle/bn256_ref.c for the in-tree curve)."""
+    import torch
+
+    from tests import _oracle_c as OC
+
+    cores, logical, model, quota = cpu_info()
+    out = {"affinity_cores": cores, "cgroup_cpu_quota_cores": quota, "cpu_model": model, "kind": "port"}
+    # ---- pairings (bn256)
+    n0 = 64
+    k = be_scalars(b"kyberhip/v1/cpu/pair/k", 4096)
+    h = be_scalars(b"kyberhip/v1/cpu/pair/h", 4096)
+    P = np.asarray(bn.g1_commit(h)[0])
+    Q = np.asarray(bn.g2_commit(k)[0])
+    t0 = time.perf_counter()
+    OC.bn256_pair(P[:n0], Q[:n0], threads=1)
+    r1 = n0 / (time.perf_counter() - t0)
+    n = int(min(4096, max(n0, r1 * cores * 8.0)))
+    t0 = time.perf_counter()
+    gt_c, st = OC.bn256_pair(P[:n], Q[:n], threads=cores)
+    dt = time.perf_counter() - t0
+    gt_g, st_g = bn.batch_pair(P[:n], Q[:n])
+    out["bn256_pairings"] = {"value": n / dt, "unit": "pairings/s", "cores": cores, "single_thread_value": r1,
+                             "outputs_match": bool(_sha(gt_c) == _sha(np.asarray(gt_g)) and not st.any() and not np.asarray(st_g).any()),
+                             "outputs_compared": n,
+                             "sample": f"{n} Suite.Pair calls, oracle/bn256_ref.c (pairing/bn256 optate.go:126-274 over "
+                                       f"gfp_generic.go:158 restated in C), GT bytes compared with the GPU's"}
+    # ---- N x (Mul + Add) where the engine runs an MSM
+    for name, m, fn, unc in (("bls12381_g1_mul_add", bls, OC.bls12381_g1_mul_sum, True), ("bn256_g1_mul_add", bn, OC.bn256_g1_mul_sum, False)):
+        pts = np.asarray(m._mul(1, h, m.G1_BASE, True, m.F_UNCOMPRESSED_OUT)[0]) if unc else P
+        t0 = time.perf_counter()
+        fn(k[:128], pts[:128], threads=1)
+        r1 = 128 / (time.perf_counter() - t0)
+        n = int(min(4096, max(128, r1 * cores * 6.0)))
+        t0 = time.perf_counter()
+        sum_c, st = fn(k[:n], pts[:n], threads=cores)
+        dt = time.perf_counter() - t0
+        sum_g, st_g = m.g1_msm(k[:n], pts[:n], (m.F_UNCOMPRESSED if unc else 0))
+        if unc:  # the GPU returns the compressed point: bring the oracle's sum into the same form through the engine
+            sum_c = np.asarray(m.g1_batch_unmarshal(sum_c.tobytes(), m.F_UNCOMPRESSED)[0])[0]
+        out[name] = {"value": n / dt, "unit": "points/s", "cores": cores, "single_thread_value": r1,
+                     "seconds_for_2p20_points_extrapolated": (1 << 20) / (n / dt),
+                     "outputs_match": bool(bytes(np.asarray(sum_c)) == bytes(np.asarray(sum_g)) and not st.any()),
+                     "outputs_compared": n,
+                     "sample": f"sum of {n} x (Point.Mul + Point.Add), {'oracle/bls12381_g1_ref.c' if unc else 'oracle/bn256_ref.c'} "
+                               f"(curve.go:69-203 double-and-add), against the GPU MSM of the same {n} points"}
+    return out
+
+
 REF_BLS_VERIFY_PER_S_SINGLE_CORE = 303  # BASELINE.md section 1 (sign/bls Verify, BLS12-381 circl backend, signatures on G1, one core)
 
 
@@ -140,16 +226,52 @@ def _tvm_mads():
             "bn254": (G.build_bn254_pair().mads(), G.build_bn254_check().mads())}
 
 
-def _roof(units_per_s, mads_per_unit, alg_bytes_per_unit, prof, key):
-    """roofline object of a side workload: integer-MAD issue is the binding resource, HBM figures alongside"""
+def _lvm_mads():
+    """integer MADs per scalar multiplication of the lane-machine programs (kyber_amd/csrc/gen_lane_vm.py, product
+    tooling): a G1 element is one lane, a G2 element two"""
+    sys.path.insert(0, os.path.join(ROOT, "kyber_amd", "csrc"))
+    import gen_lane_vm as G
+
+    g1, g2 = G.build_bls12381_g1_mul(), G.build_bls12381_g2_mul()
+    return {"g1": g1.mads(), "g2": 2 * g2.mads(), "g2_karatsuba": 2 * g2.mads(karatsuba=True)}
+
+
+# UnmarshalBinary on BLS12-381 as the per-lane code does it (bls12381.cuh; a field multiplication is 13 x 13 products +
+# 13 x 13 reduction multiply-adds = 338, a squaring 91 + 169 = 260): G1 = a 379-bit power for the square root (4-bit
+# windows: 379 S + 109 M) + the endomorphism test phi(P) = [-z^2]P (2 x (63 doublings of 2M + 5S + 5 additions of 11M + 5S));
+# G2 = two such powers for the Fp2 square root + psi(Q) = [z]Q (63 doublings + 5 additions over Fp2, Karatsuba: M2 = 3M, S2 = 2M)
+_M, _S = 338, 260
+MADS_G1_UNMARSHAL = (379 * _S + 109 * _M) + 2 * (63 * (2 * _M + 5 * _S) + 5 * (11 * _M + 5 * _S))
+MADS_G2_UNMARSHAL = 2 * (379 * _S + 109 * _M) + 12 * _M + (63 * (2 * 3 + 5 * 2) + 5 * (11 * 3 + 5 * 2)) * _M
+# Pippenger on BLS12-381 G1 at 2^20 points (msm.cuh): 2n half-scalars x 8 windows of 16 bits, one mixed addition
+# (7M + 4S) per (point, window), + the running-sum reduction of 8 x 2^15 buckets (2 full additions each, 11M + 5S)
+MADS_MSM_BLS_G1_2P20_PER_POINT = 2 * 8 * (7 * _M + 4 * _S) + (8 * (1 << 15) * 2 * (11 * _M + 5 * _S)) / (1 << 20)
+# the best known count for the BLS12-381 pairing on this limb arithmetic: the Karatsuba tower of round 1 (5.4e6 per
+# Pair, VERDICT r2) against the machine's schoolbook-with-lazy-reduction program; checks / verifies scaled alike
+BLS_PAIR_BEST_KNOWN = 5.4e6
+# pairing/bn256's own formulas cost 31 595 gfpMul per pairing (oracle/bn256_ref.c built with -DORA_COUNT): at one
+# reduction per multiplication that is 31 595 x 200 multiply-adds on 10 limbs -- MORE than the machine's program,
+# which reduces once per output coefficient
+BN256_PAIR_REFERENCE_FORMULA = 31595 * 200
+
+
+def _roof(units_per_s, mads_per_unit, alg_bytes_per_unit, prof, key, best_known=None):
+    """roofline object of a side workload: integer-MAD issue is the binding resource, HBM figures alongside.
+    best_known: multiply-adds of the cheapest formula known for the unit -- the fraction against it cannot be raised
+    by doing more work"""
     peak = prof.get("imad_peak_lane_ops_per_s")
     k = prof.get("kernels", {}).get(key, {})
-    return {"bound": "valu-imad", "mads_per_unit": mads_per_unit, "achieved": units_per_s * mads_per_unit, "peak": peak,
-            "unit": "lane-MAD/s", "frac": (units_per_s * mads_per_unit / peak) if peak else None,
-            "hbm": {"algorithmic_bytes_per_unit": alg_bytes_per_unit, "achieved_GBps": units_per_s * alg_bytes_per_unit / 1e9,
-                    "peak_GBps": HBM_PEAK_GBS, "frac": units_per_s * alg_bytes_per_unit / 1e9 / HBM_PEAK_GBS},
-            "traffic": k.get("hbm_bytes_per_launch"), "traffic_units_per_launch": k.get("units_per_launch"),
-            "valu_busy_profiled": k.get("valu_busy"), "profile": k.get("source")}
+    r = {"bound": "valu-imad", "mads_per_unit": mads_per_unit, "achieved": units_per_s * mads_per_unit, "peak": peak,
+         "unit": "lane-MAD/s", "frac": (units_per_s * mads_per_unit / peak) if peak else None,
+         "hbm": {"algorithmic_bytes_per_unit": alg_bytes_per_unit, "achieved_GBps": units_per_s * alg_bytes_per_unit / 1e9,
+                 "peak_GBps": HBM_PEAK_GBS, "frac": units_per_s * alg_bytes_per_unit / 1e9 / HBM_PEAK_GBS},
+         "traffic": k.get("hbm_bytes_per_launch"), "traffic_units_per_launch": k.get("units_per_launch"),
+         "valu_busy_profiled": k.get("valu_busy"), "profile": k.get("source")}
+    if best_known is not None:
+        m = min(best_known, mads_per_unit)
+        r["mads_best_known_formula"] = m
+        r["frac_of_best_known_formula"] = (units_per_s * m / peak) if peak else None
+    return r
 
 
 def other_workloads(rank, world, dist):
@@ -200,10 +322,19 @@ def other_workloads(rank, world, dist):
         # roofline of the pairing entry points: the MADs of the tower-machine program (operand unmarshalling and
         # its subgroup checks are extra work inside the measured time, so the fraction is a lower bound for the
         # machine itself; the validated-input figure is the machine alone plus a 5 % operand kernel)
+        bk = {"bls12381": BLS_PAIR_BEST_KNOWN, "bn256": min(BN256_PAIR_REFERENCE_FORMULA, mads[name][0])}.get(name)
+        bk_chk = None if bk is None else bk * mads[name][1] / mads[name][0]
         out[name]["roofline"] = {
-            "pair": _roof(npair / ms_pair * 1e3, mads[name][0], g1b_ + g2b_ + m.GT_LEN, prof, name + "_pair"),
-            "pair_validated_inputs": _roof(npair / ms_pair_t * 1e3, mads[name][0], g1b_ + g2b_ + m.GT_LEN, prof, name + "_pair"),
-            "pair_check": _roof(npair / ms_chk * 1e3, mads[name][1], 2 * (g1b_ + g2b_) + 1, prof, name + "_check")}
+            "pair": _roof(npair / ms_pair * 1e3, mads[name][0], g1b_ + g2b_ + m.GT_LEN, prof, name + "_pair", bk),
+            "pair_validated_inputs": _roof(npair / ms_pair_t * 1e3, mads[name][0], g1b_ + g2b_ + m.GT_LEN, prof, name + "_pair", bk),
+            "pair_check": _roof(npair / ms_chk * 1e3, mads[name][1], 2 * (g1b_ + g2b_) + 1, prof, name + "_check", bk_chk)}
+        if name == "bls12381":
+            # G1Elt.Mul / G2Elt.Mul with everything UnmarshalBinary checks (flags = 0): the per-lane unmarshal kernel +
+            # the lane machine's ladder; G2 also against the count with Karatsuba Fp2 products (3 instead of 4)
+            lm = _lvm_mads()
+            out[name]["roofline"]["g1_mul"] = _roof(npair / ms_g1 * 1e3, lm["g1"] + MADS_G1_UNMARSHAL, 32 + 2 * g1b_, prof, "bls12381_g1_mul")
+            out[name]["roofline"]["g2_mul"] = _roof(npair / ms_g2 * 1e3, lm["g2"] + MADS_G2_UNMARSHAL, 32 + 2 * g2b_, prof, "bls12381_g2_mul",
+                                                    lm["g2_karatsuba"] + MADS_G2_UNMARSHAL)
         if True:
             # the whole sign/bls Verify pipeline on the device: Hash(msg) (bn256: SHA-256 + try-and-increment; bn254:
             # Keccak-256 expand + Shallue-van de Woestijne; BLS12-381: RFC 9380 hash_to_curve) then the pairing check (sign/bls/bls.go:82-96), 32-byte messages
@@ -253,7 +384,13 @@ def other_workloads(rank, world, dist):
             else:
                 fn_t = lambda: m.g1_msm(ks, pts, tr)
                 fn_u = lambda: m.g1_msm(ks, pts_u, tr | m.F_UNCOMPRESSED)
-            same = bytes(fn()[0].cpu().numpy()) == bytes(fn_t()[0].cpu().numpy()) == bytes(fn_u()[0].cpu().numpy())
+            # the expectation is independent of the bucket pipeline: P_i = h_i G, so sum k_i P_i = (sum k_i h_i mod r) G
+            # (share/poly.go:340-348: the reference's N x (Mul + Add)), big-integer arithmetic on the host + ONE
+            # fixed-base multiplication; all three calling conventions must give exactly these bytes
+            k_all, h_all = be_scalars(b"kyberhip/v1/msm/k", n), be_scalars(b"kyberhip/v1/msm/h", n)
+            tot = sum(int.from_bytes(bytes(a), "big") * int.from_bytes(bytes(b), "big") for a, b in zip(k_all, h_all)) % m.ORDER
+            expect = bytes(np.asarray(m.g1_commit(tot.to_bytes(32, "big"))[0])[0])
+            same = all(bytes(f()[0].cpu().numpy()) == expect for f in (fn, fn_t, fn_u))
             ms_t, ms_u = timed(fn_t), timed(fn_u)
             t = torch.tensor([ms, ms_t, ms_u], dtype=torch.float64, device="cuda")
             if dist:
@@ -261,7 +398,8 @@ def other_workloads(rank, world, dist):
             out["bls12381_g1_msm_2p20"] = {"points": n, "seconds": float(t[0].item()) * 1e-3,
                                            "seconds_validated_points": float(t[1].item()) * 1e-3,
                                            "seconds_validated_uncompressed_points": float(t[2].item()) * 1e-3,
-                                           "three_variants_agree": same, "scaling": "strong",
+                                           "matches_sum_ki_hi_times_G": same, "scaling": "strong",
+                                           "roofline": _roof(n / float(t[2].item()) * 1e3, MADS_MSM_BLS_G1_2P20_PER_POINT, 32 + 96, prof, "bls12381_g1_msm"),
                                            "exchange": "all-gather of %d encoded partial points" % world if dist else "none"}
             del ks, hs, pts, pts_u
     # Ed25519 MSM at 2^20 points (PubPoly.Eval / RecoverCommit shape), sharded like the BLS one
@@ -302,6 +440,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dist = None
+    rccl_ranks_seen = None
     # KYB_BENCH_FORCE_DIST=1 exercises the RCCL path (init, barrier, all-gather) with a single rank
     if world > 1 or os.environ.get("KYB_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
@@ -315,6 +454,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             warm = torch.zeros(1, device="cuda")
             dist.all_reduce(warm)
+            # every rank of the job really is on the communicator: gather the rank ids over RCCL and count them
+            ids = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(dist.get_world_size())]
+            dist.all_gather(ids, torch.tensor([rank], dtype=torch.int64, device="cuda"))
+            rccl_ranks_seen = len({int(x.item()) for x in ids})
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -406,7 +549,7 @@ def main():
             "metric": "scalar-muls/s + pairings/s per node; MSM sec at 2^20 points",
             "value": total_ops / elapsed,
             "unit": "scalar-muls/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "rccl_ranks_seen": rccl_ranks_seen,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak",
             # BASELINE.md section 1 (docs/benchmark-app data.json:38-40, 14-16): one variable-base + one fixed-base
@@ -438,9 +581,13 @@ def main():
         if other is not None:
             res["other_workloads"] = other
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(s_h, d_pts.cpu().numpy())
-            res["cpu_baseline"]["pairings"] = {"reference_published_bls_verify_per_s_single_core": REF_BLS_VERIFY_PER_S_SINGLE_CORE,
-                                               "note": "BASELINE.md; no host pairing code is timed here"}
+            res["cpu_baseline"] = cpu_baseline(s_h, d_pts.cpu().numpy(), outs[0].cpu().numpy(), outs[1].cpu().numpy())
+            res["outputs_match"] = res["cpu_baseline"]["outputs_match"]
+            if not args.no_other:
+                from kyber_amd.pairing import bls12381 as bls_, bn256 as bn_
+
+                res["cpu_baseline"]["other_workloads"] = cpu_baseline_pairing_and_msm(bn_, bls_)
+                res["cpu_baseline"]["other_workloads"]["reference_published_bls_verify_per_s_single_core"] = REF_BLS_VERIFY_PER_S_SINGLE_CORE
         print(json.dumps(res))
     if dist:
         dist.destroy_process_group()

@@ -146,21 +146,24 @@ class LProg:
     def executed(self):
         return sum(ln * rep for _, ln, rep in self.sched)
 
-    def mads(self):
-        """integer multiply-adds per LANE (a G2 point is two lanes)"""
+    def mads(self, karatsuba=False):
+        """integer multiply-adds per LANE (a G2 point is two lanes).  karatsuba: what the same program would cost if an
+        Fp2 product took three base-field products per point instead of four (1.5 per lane) -- not expressible with one
+        coordinate half per lane, reported as the best known count"""
         n2 = self.f.N * self.f.N
+        m2 = 1.5 if karatsuba else 2
         tot = 0
         for _, r in self.walk():
             if r["op"] != OP_DOT:
                 continue
             for t in r["terms"]:
                 k = t[0]
-                tot += {"mul": 1, "mulc": 1, "mult": 1, "mul2": 2, "mul2t": 2, "mul2c": 2, "norm2": 2, "sqr2": 1}.get(k, 0) * n2
+                tot += {"mul": 1, "mulc": 1, "mult": 1, "mul2": m2, "mul2t": m2, "mul2c": m2, "norm2": 2, "sqr2": 1}.get(k, 0) * n2
                 if k == "sqr":
                     tot += self.f.N * (self.f.N + 1) // 2
             if not r["raw"]:
                 tot += n2
-        return tot
+        return int(tot)
 
     # ---- the device's arithmetic, limb for limb
     def simulate(self, inputs, digits, trace=None):

@@ -88,6 +88,8 @@ class Engine:
             import torch
 
             s = scalars.contiguous().view(-1, 32)
+            if not _is_torch(points):  # (a base point given as bytes next to device scalars: Commit's default base)
+                points = torch.from_numpy(_host(points, wi).copy()).to(s.device)
             p = points.contiguous().view(-1, wi)
             n = s.shape[0]
             if not same_base and p.shape[0] != n:

@@ -89,7 +89,14 @@ static void fp_neg(fp *r, const fp *a) {
     fp z = {{0, 0, 0, 0}};
     fp_sub(r, &z, a);
 }
+#ifdef ORA_COUNT  /* gcc -DORA_COUNT: count gfpMul calls (how the "best known formula" multiply-add figures of bench.py were obtained) */
+unsigned long long ora_fp_mul_count;
+#define ORA_TICK ora_fp_mul_count++
+#else
+#define ORA_TICK ((void)0)
+#endif
 static void fp_mul(fp *r, const fp *a, const fp *b) { /* gfpMul: a b R^-1 mod p */
+    ORA_TICK;
     u64 t[6] = {0, 0, 0, 0, 0, 0};
     for (int i = 0; i < 4; i++) {
         u128 c = 0;
