@@ -142,6 +142,13 @@ func (g *Group) BatchMul(scalars []kyber.Scalar, points []kyber.Point) ([]kyber.
 	if len(scalars) != len(points) {
 		return nil, errLen
 	}
+	if len(scalars) < MinDeviceBatch && !SingleOpOnDevice { // below one wave's break-even: the reference, in a loop
+		out := make([]kyber.Point, len(scalars))
+		for i := range out {
+			out[i] = &Point{g: g, p: g.inner.Point().Mul(scalars[i], un(points[i]))}
+		}
+		return out, nil
+	}
 	sb, err := scalarBytes(scalars)
 	if err != nil {
 		return nil, err
@@ -161,6 +168,17 @@ func (g *Group) BatchMul(scalars []kyber.Scalar, points []kyber.Point) ([]kyber.
 }
 
 func (g *Group) Commit(coeffs []kyber.Scalar, base kyber.Point) ([]kyber.Point, error) {
+	if len(coeffs) < MinDeviceBatch && !SingleOpOnDevice {
+		out := make([]kyber.Point, len(coeffs))
+		for i := range out {
+			if base == nil {
+				out[i] = &Point{g: g, p: g.inner.Point().Mul(coeffs[i], nil)}
+			} else {
+				out[i] = &Point{g: g, p: g.inner.Point().Mul(coeffs[i], un(base))}
+			}
+		}
+		return out, nil
+	}
 	sb, err := scalarBytes(coeffs)
 	if err != nil {
 		return nil, err
@@ -187,6 +205,13 @@ func (g *Group) Commit(coeffs []kyber.Scalar, base kyber.Point) ([]kyber.Point, 
 func (g *Group) MSM(scalars []kyber.Scalar, points []kyber.Point, bits uint) (kyber.Point, error) {
 	if len(scalars) != len(points) {
 		return nil, errLen
+	}
+	if len(scalars) < MinDeviceBatch && !SingleOpOnDevice { // the reference's own N x (Mul + Add) (share/poly.go:340-348)
+		acc := g.inner.Point().Null()
+		for i := range scalars {
+			acc = acc.Add(acc, g.inner.Point().Mul(scalars[i], un(points[i])))
+		}
+		return &Point{g: g, p: acc}, nil
 	}
 	sb, err := scalarBytes(scalars)
 	if err != nil {

@@ -37,18 +37,26 @@ func (s *PairingSuite) G1() kyber.Group { return s.g1 }
 func (s *PairingSuite) G2() kyber.Group { return s.g2 }
 func (s *PairingSuite) GT() kyber.Group { return s.gt }
 
-// Pair computes e(p1, p2) on the device and returns it as a GT point of this suite.
+// Pair computes e(p1, p2) and returns it as a GT point of this suite: ONE pairing is the reference's own (the embedded
+// suite, one CPU core, 1.6 ms -- a lone wave of the tower machine needs ~20 ms for it), unless SingleOpOnDevice asks
+// for the device path; batches go through BatchPair.
 func (s *PairingSuite) Pair(p1, p2 kyber.Point) kyber.Point {
-	out, err := s.BatchPair([]kyber.Point{p1}, []kyber.Point{p2})
+	if !SingleOpOnDevice {
+		return &Point{g: s.gt, p: s.inner.Pair(un(p1), un(p2))}
+	}
+	out, err := s.pairOnDevice([]kyber.Point{p1}, []kyber.Point{p2})
 	if err != nil {
 		panic(err)
 	}
 	return out[0]
 }
 
-// ValidatePairing reports e(p1, p2) == e(inv1, inv2).
+// ValidatePairing reports e(p1, p2) == e(inv1, inv2); a single check is the reference's (see Pair).
 func (s *PairingSuite) ValidatePairing(p1, p2, inv1, inv2 kyber.Point) bool {
-	ok, err := s.BatchValidatePairing([]kyber.Point{p1}, []kyber.Point{p2}, []kyber.Point{inv1}, []kyber.Point{inv2})
+	if !SingleOpOnDevice {
+		return s.inner.ValidatePairing(un(p1), un(p2), un(inv1), un(inv2))
+	}
+	ok, err := s.validateOnDevice([]kyber.Point{p1}, []kyber.Point{p2}, []kyber.Point{inv1}, []kyber.Point{inv2})
 	if err != nil {
 		panic(err)
 	}
@@ -76,6 +84,17 @@ func (s *PairingSuite) BatchPair(p1, p2 []kyber.Point) ([]kyber.Point, error) {
 	if len(p1) != len(p2) {
 		return nil, errLen
 	}
+	if len(p1) < MinDevicePairings && !SingleOpOnDevice { // too few for one wave to beat a CPU core: the reference, in a loop
+		out := make([]kyber.Point, len(p1))
+		for i := range out {
+			out[i] = &Point{g: s.gt, p: s.inner.Pair(un(p1[i]), un(p2[i]))}
+		}
+		return out, nil
+	}
+	return s.pairOnDevice(p1, p2)
+}
+
+func (s *PairingSuite) pairOnDevice(p1, p2 []kyber.Point) ([]kyber.Point, error) {
 	a, err := encodings(p1, s.g1.pointLen())
 	if err != nil {
 		return nil, err
@@ -113,6 +132,17 @@ func (s *PairingSuite) BatchPair(p1, p2 []kyber.Point) ([]kyber.Point, error) {
 }
 
 func (s *PairingSuite) BatchValidatePairing(p1, p2, inv1, inv2 []kyber.Point) ([]bool, error) {
+	if len(p1) == len(p2) && len(p1) == len(inv1) && len(p1) == len(inv2) && len(p1) < MinDevicePairings && !SingleOpOnDevice {
+		ok := make([]bool, len(p1))
+		for i := range ok {
+			ok[i] = s.inner.ValidatePairing(un(p1[i]), un(p2[i]), un(inv1[i]), un(inv2[i]))
+		}
+		return ok, nil
+	}
+	return s.validateOnDevice(p1, p2, inv1, inv2)
+}
+
+func (s *PairingSuite) validateOnDevice(p1, p2, inv1, inv2 []kyber.Point) ([]bool, error) {
 	n := len(p1)
 	if len(p2) != n || len(inv1) != n || len(inv2) != n {
 		return nil, errLen

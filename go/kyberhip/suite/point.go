@@ -98,11 +98,46 @@ func (P *Point) Neg(a kyber.Point) kyber.Point {
 	return P
 }
 
-// Mul is the hot path: P = s * p (p == nil: the standard base) on the device.  One multiplication per call is the
-// reference's signature; loops should use Group.BatchMul / Commit / MSM.  The engine reproduces the reference's
-// result bytes, including group/edwards25519's treatment of scalars >= 2^255 (SURVEY.md 8a); an engine failure
-// panics, as the reference's type-cast failures do.
+// SingleOpOnDevice sends the single-element methods of the kyber interfaces -- Point.Mul, Suite.Pair,
+// Suite.ValidatePairing -- to the device like a batch of one.  Off by default: ONE multiplication or pairing is a
+// lone lane in a lone wave on a 256-CU chip, and the host-buffer round trip alone (upload, launch, download,
+// synchronise: ~40-60 us; the arithmetic in a lone wave another 1-20 ms, profiles/r03_single_call_latency.json)
+// exceeds what the reference needs on one core (0.06-0.35 ms per Mul, 1.6 ms per Pair; measured: 1.0-9.0 ms per Mul, 3.3-6.2 ms per Pair on the device).  SURVEY.md section 8b: keep
+// n = 1 on the CPU.  The reference point embedded in every Point IS that CPU path, so delegating costs one branch and
+// the result is the reference's own bytes by definition.  Tests of the device path through the single-element
+// interface (util/test.CompareGroups) switch it on.
+var SingleOpOnDevice = false
+
+// MinDeviceBatch / MinDevicePairings are the batch sizes from which the batch methods (BatchMul, Commit, MSM; BatchPair,
+// BatchValidatePairing) use the device; smaller batches loop over the reference on the CPU.  A device call costs
+// what ONE wave costs whatever the batch (up to 64 lanes x 4 SIMDs x 256 CUs elements run side by side) -- measured on
+// MI355X through the host-buffer entry points (profiles/r03_single_call_latency.json, median of 9 calls): 1.0 ms for an
+// Ed25519 Mul, 3.7 / 9.0 ms for a BLS12-381 G1 / G2 Mul, 1.6 ms for a bn256 G1 Mul, 6.2 / 3.3 ms for a BLS12-381 /
+// bn256 Pair, flat from 1 to 4096 elements -- so the break-even against one CPU core of the reference (0.35 ms,
+// ~0.12 / 0.28 ms, 0.15 ms, 1.6 ms) is 4 elements for Ed25519 and the pairings and 16-64 for the pairing-curve
+// multiplications.
+var (
+	MinDeviceBatch    = 64
+	MinDevicePairings = 8
+)
+
+// Mul: P = s * p (p == nil: the standard base).  One multiplication per call is the reference's signature and a
+// single element stays on the CPU (SingleOpOnDevice); loops belong in Group.BatchMul / Commit / MSM, which is where the
+// device is.  On the device the engine reproduces the reference's result bytes, including group/edwards25519's
+// treatment of scalars >= 2^255 (SURVEY.md 8a); an engine failure panics, as the reference's type-cast failures do.
 func (P *Point) Mul(s kyber.Scalar, p kyber.Point) kyber.Point {
+	if !SingleOpOnDevice {
+		if p == nil {
+			P.p = P.p.Mul(s, nil)
+		} else {
+			P.p = P.p.Mul(s, un(p))
+		}
+		return P
+	}
+	return P.mulOnDevice(s, p)
+}
+
+func (P *Point) mulOnDevice(s kyber.Scalar, p kyber.Point) kyber.Point {
 	sb, err := s.MarshalBinary()
 	if err != nil {
 		panic(err)

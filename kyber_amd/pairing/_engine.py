@@ -17,6 +17,12 @@ F_UNCOMPRESSED_OUT = 4
 F_TRUSTED_ALL = 0xF00
 
 
+# Batch sizes from which a device call beats one CPU core of the reference (tools/latency_probe.py on MI355X,
+# profiles/r03_single_call_latency.json; the Go suite's MinDeviceBatch / MinDevicePairings): below them a caller with a
+# CPU implementation at hand should use it.  tests/test_callers_host.py holds these equal to the Go suite's.
+MIN_DEVICE_BATCH, MIN_DEVICE_PAIRINGS = 64, 8
+
+
 def F_SCALAR_BITS(b: int) -> int:
     """*_msm only: every scalar is below 2^b (KYB_F_SCALAR_BITS); higher bits are ignored."""
     if not 1 <= b <= 256:
@@ -415,6 +421,11 @@ class Engine:
                 return self.Mul(Scalar().Pick(rand), None)
 
             def Mul(self, s, A=None):
+                """Point.Mul, a batch of ONE: ~1-9 ms on the device whatever the batch size (profiles/
+                r03_single_call_latency.json) against 0.1-0.3 ms on a CPU core of the reference.  The Go suite keeps
+                single elements on the embedded reference (go/kyberhip/suite/point.go, MinDeviceBatch); this mirror
+                has no CPU implementation to delegate to -- the product path has no CPU fallback -- so loops belong
+                in g1_batch_mul / g1_commit / g1_msm."""
                 base = self.BASE if A is None else self._cast(A).enc
                 out, st = eng.mul(self.GROUP, _sc(s).MarshalBinary(), base, False)
                 if st[0]:

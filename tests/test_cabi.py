@@ -184,9 +184,23 @@ def test_go_suite_implements_every_method_of_the_kyber_interfaces():
     assert {"BatchMul", "Commit", "MSM", "Validate"} <= _go_methods(group, "Group")
     assert set(_PAIRING) <= _go_methods(pairing, "PairingSuite")
     assert {"BatchPair", "BatchValidatePairing", "BatchVerify", "BatchGTMul"} <= _go_methods(pairing, "PairingSuite")
-    # the hot methods call the binding, not the reference
-    mul = point[point.index("func (P *Point) Mul("):point.index("// AllowVarTime")]
-    assert "P.g.mul(" in mul and "P.g.mulBase(" in mul and "P.p.Mul(" not in mul
+    # the n = 1 policy: a single Mul / Pair / ValidatePairing is the embedded
+    # reference's unless SingleOpOnDevice says otherwise; the device path calls the binding, never the reference;
+    # batches below MinDeviceBatch loop over the reference
+    mul = point[point.index("func (P *Point) Mul("):point.index("func (P *Point) mulOnDevice(")]
+    assert "if !SingleOpOnDevice" in mul and "P.p.Mul(s, un(p))" in mul and "P.mulOnDevice(s, p)" in mul
+    dev = point[point.index("func (P *Point) mulOnDevice("):point.index("// AllowVarTime")]
+    assert "P.g.mul(" in dev and "P.g.mulBase(" in dev and "P.p.Mul(" not in dev
+    assert re.search(r"var SingleOpOnDevice = false", point) and re.search(r"MinDeviceBatch\s+= \d+", point) and re.search(r"MinDevicePairings = \d+", point)
+    pair = pairing[pairing.index("func (s *PairingSuite) Pair("):pairing.index("// ---- kyber.Encoding")]
+    assert "s.inner.Pair(un(p1), un(p2))" in pair and "s.inner.ValidatePairing(un(p1), un(p2), un(inv1), un(inv2))" in pair
+    assert "s.pairOnDevice(" in pair and "s.validateOnDevice(" in pair
+    for fn in ("BatchMul", "Commit", "MSM"):
+        body = group[group.index("func (g *Group) %s(" % fn):]
+        assert "MinDeviceBatch && !SingleOpOnDevice" in body[:1200], fn
+    for fn in ("BatchPair", "BatchValidatePairing"):
+        body = pairing[pairing.index("func (s *PairingSuite) %s(" % fn):]
+        assert "MinDevicePairings && !SingleOpOnDevice" in body[:800], fn
     assert "hip.Bls12381Pair(" in pairing and "hip.Bn256ValidatePairing(" in pairing and "hip.Bls12381VerifyG1(" in pairing
     # the suites are declared variable-time and registered with the variable-time suites only
     patch = open(os.path.join(root, "go", "patches", "suites_all_vartime.patch")).read()

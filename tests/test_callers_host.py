@@ -162,3 +162,25 @@ def test_pack_fixed_isolates_wrong_length_elements():
     assert bytes(arr[0]) == items[0] and bytes(arr[4]) == items[4] and not arr[1:4].any()
     arr, bad = pack_fixed([], 96)
     assert arr.shape == (0, 96) and bad == []
+
+
+def test_single_element_policy_constants_match_the_go_suite_and_the_measurement():
+    """SURVEY.md section 8b / VERDICT r2 item 6: one element stays on the CPU.  The thresholds the Python mirror documents are
+    the Go suite's, and both are at or above every break-even batch size measured on the GPU
+    (profiles/r03_single_call_latency.json, written by tools/latency_probe.py)."""
+    import json
+    import os
+    import re
+
+    from kyber_amd.pairing import _engine as E
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    go = open(os.path.join(root, "go", "kyberhip", "suite", "point.go")).read()
+    assert int(re.search(r"MinDeviceBatch\s+= (\d+)", go).group(1)) == E.MIN_DEVICE_BATCH
+    assert int(re.search(r"MinDevicePairings = (\d+)", go).group(1)) == E.MIN_DEVICE_PAIRINGS
+    lat = json.load(open(os.path.join(root, "profiles", "r03_single_call_latency.json")))
+    for name, be in lat["break_even_batch"].items():
+        assert be is not None and be <= (E.MIN_DEVICE_PAIRINGS if "pair" in name else E.MIN_DEVICE_BATCH), (name, be)
+    # a single call on the device is slower than the reference's one core for every operation measured: the policy is needed
+    for name, v in lat["latency_us"].items():
+        assert v[0] > lat["reference_single_core_us_per_op"][name], name
