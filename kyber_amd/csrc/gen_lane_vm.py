@@ -506,37 +506,36 @@ class Curve:
             P.dot(SX, [self.sqr(L(SA, 3)), ("lin", L(SC, -8))], name=name + ".X")
             P.dot(SY, [self.mul(L(SA, 3), L(SC, 4, SX, -1)), self.mul(L(SB, -8), L(SB))], name=name + ".Y")
         else:
-            # squarings are one product per lane, multiplications two: dbl-2009-l (2M + 5S)
+            # squarings are one product per lane, multiplications two: dbl-2009-l (2M + 5S) with D' = D / 2 carried, so
+            # that the difference (X + B)^2 - A - C rides on the squaring's reduction: seven records
             P.dot(SA, [self.sqr(L(SX))], name=name + ".A")                      # A = X^2
             P.dot(SB, [self.sqr(L(SY))], name=name + ".B")                      # B = Y^2
             P.dot(SZ, [self.mul(L(SY, 2), L(SZ))], name=name + ".Z")            # Z3 = 2 Y Z
-            P.dot(SY, [self.sqr(L(SX, 1, SB, 1))], name=name + ".t")            # t = (X + B)^2       (in Y)
             P.dot(SC, [self.sqr(L(SB))], name=name + ".C")                      # C = B^2
-            P.dot(SX, [("lin", L(SY, 2, SA, -2)), ("lin", L(SC, -2))], raw=True, name=name + ".D")  # D = 2 (t - A - C)  (in X)
-            # E = 3A as a stored value: (3 (a0 + a1)) (3 (a0 - a1)) on unnormalised limbs would put 504 x 2^54 in a column
-            P.dot(SA, [("lin", L(SA, 3))], raw=True, name=name + ".E")
-            P.dot(SB, [self.sqr(L(SA)), ("lin", L(SX, -2))], name=name + ".X3")          # X3 = E^2 - 2 D  (in B)
-            P.dot(SY, [self.mul(L(SA), L(SX, 1, SB, -1)), ("lin", L(SC, -8))], name=name + ".Y3")  # Y3 = E (D - X3) - 8 C
-            P.dot(SX, [("lin", L(SB))], raw=True, name=name + ".mv")
+            P.dot(SY, [self.sqr(L(SX, 1, SB, 1)), ("lin", L(SA, -1, SC, -1))], name=name + ".D")  # D' = (X + B)^2 - A - C  (in Y)
+            # X3 = (3A)^2 - 4 D' as a PRODUCT of 3A with itself: the one-product square (3 (a0 + a1)) (3 (a0 - a1)) on
+            # unnormalised limbs would put 504 x 2^54 in a column; storing 3A first costs a record more than the
+            # second pass does
+            P.dot(SX, [self.mul(L(SA, 3), L(SA, 3)), ("lin", L(SY, -4))], name=name + ".X3")
+            P.dot(SY, [self.mul(L(SA, 3), L(SY, 2, SX, -1)), ("lin", L(SC, -8))], name=name + ".Y3")  # Y3 = 3A (2 D' - X3) - 8 C
 
     def madd(self, cx, cy, entry=DYN, signed=True, name="madd"):
         """(X, Y, Z) <- (X, Y, Z) + (x2, y2), the second operand affine from the table (coordinates cx, cy of `entry`;
         y2 negated by the digit's sign).  madd-2004-hmv: H = U2 - X1, r = S2 - Y1, Z3 = Z1 H, X3 = r^2 - H^3 - 2 X1 H^2,
-        Y3 = r (X1 H^2 - X3) - Y1 H^3.  11 products + one stored difference (H: with it the working set is six slots,
-        with H as an operand combination it would be seven), temporaries A, B, C.  H = 0 (equal or opposite operands)
+        Y3 = r (X1 H^2 - X3) - Y1 H^3.  11 products in ten records (H and r are formed on the reductions of U2 and S2: as
+        stored values they keep the working set at six slots), temporaries A, B, C.  H = 0 (equal or opposite operands)
         gives Z3 = 0, which every later step preserves."""
         P = self.P
         P.dot(SA, [self.sqr(L(SZ))], name=name + ".ZZ")                                     # A = Z^2
-        P.dot(SB, [self.mult(L(SA), cx, False, entry)], name=name + ".U2")                  # B = U2 = x2 Z^2
+        P.dot(SB, [self.mult(L(SA), cx, False, entry), ("lin", L(SX, -1))], name=name + ".H")   # B = H = x2 Z^2 - X1
         P.dot(SA, [self.mul(L(SA), L(SZ))], name=name + ".ZZZ")                             # A = Z^3
-        P.dot(SC, [self.mult(L(SA), cy, signed, entry)], name=name + ".S2")                 # C = S2 = y2 Z^3
-        P.dot(SB, [("lin", L(SB, 1, SX, -1))], raw=True, name=name + ".H")                  # B = H = U2 - X1
+        P.dot(SC, [self.mult(L(SA), cy, signed, entry), ("lin", L(SY, -1))], name=name + ".r")  # C = r = y2 Z^3 - Y1
         P.dot(SZ, [self.mul(L(SZ), L(SB))], name=name + ".Z3")                              # Z3 = Z H
         P.dot(SA, [self.sqr(L(SB))], name=name + ".HH")                                     # A = H^2
         P.dot(SB, [self.mul(L(SA), L(SB))], name=name + ".HHH")                             # B = H^3
         P.dot(SA, [self.mul(L(SX), L(SA))], name=name + ".V")                               # A = V = X1 H^2
-        P.dot(SX, [self.sqr(L(SC, 1, SY, -1)), ("lin", L(SB, -1, SA, -2))], name=name + ".X3")
-        P.dot(SY, [self.mul(L(SC, 1, SY, -1), L(SA, 1, SX, -1)), self.mul(L(SY, -1), L(SB))], name=name + ".Y3")
+        P.dot(SX, [self.sqr(L(SC)), ("lin", L(SB, -1, SA, -2))], name=name + ".X3")
+        P.dot(SY, [self.mul(L(SC), L(SA, 1, SX, -1)), self.mul(L(SY, -1), L(SB))], name=name + ".Y3")
 
     def load_affine(self, cx, cy, entry=DYN, signed=True, name="load"):
         P = self.P
