@@ -31,3 +31,47 @@ extern "C" int kyb_debug_bls12381_lvm_min(long long n) {
     kyb::bls::lvm_min_override() = n;
     return KYB_OK;
 }
+// Runs an arbitrary lane-machine program (device pointers: records, schedule entries of four words, constants) on
+// `nlanes` lanes whose inputs, digits, table and outputs live in one scratch allocation made here: the micro-benchmark
+// of tools/lvm_microbench.py (cost of a record by kind).  Returns the kernel's time in microseconds through *usec.
+extern "C" int kyb_debug_bls12381_lvm_run(int pair, size_t nlanes, const void* d_prog, const void* d_sched, uint32_t nsched,
+                                          const void* d_consts, int reps, float* usec) {
+    using namespace kyb;
+    const uint32_t ncoord = pair ? LVM_BLS12381_G2_MUL_NCOORD : LVM_BLS12381_G1_MUL_NCOORD, nentry = LVM_BLS12381_G1_MUL_NENTRY;
+    const size_t b_io = 2 * nlanes * 48, b_dig = nlanes * 72, b_tab = nlanes * (size_t)nentry * ncoord * lvm::TAB_WORDS * 4;
+    uint8_t* base;
+    KYB_HIP_CHECK(hipMalloc(&base, 2 * b_io + b_dig + nlanes + b_tab + 1024));
+    KYB_HIP_CHECK(hipMemset(base, 1, 2 * b_io + b_dig + nlanes + b_tab + 1024));
+    lvm::Args a{};
+    a.prog = (const uint32_t*)d_prog;
+    a.sched = (const lvm::Sched*)d_sched;
+    a.nsched = nsched;
+    a.consts = (const int32_t*)d_consts;
+    a.in = (const uint32_t*)base;
+    a.out = (uint32_t*)(base + b_io);
+    a.digits = base + 2 * b_io;
+    a.dstride = 72;
+    a.zflag = base + 2 * b_io + b_dig;
+    a.table = (int32_t*)(base + ((2 * b_io + b_dig + nlanes + 255) & ~size_t(255)));
+    a.nentry = nentry;
+    a.ncoord = ncoord;
+    a.nlanes = nlanes;
+    hipEvent_t e0, e1;
+    KYB_HIP_CHECK(hipEventCreate(&e0));
+    KYB_HIP_CHECK(hipEventCreate(&e1));
+    const unsigned gw = (unsigned)((nlanes + 63) / 64);
+    for (int r = 0; r <= reps; r++) {
+        if (r == 1) KYB_HIP_CHECK(hipEventRecord(e0, nullptr));
+        if (pair) hipLaunchKernelGGL((kyb::bls::bls12381_lvm_mul_kernel<true, true>), dim3(gw), dim3(64), 0, nullptr, a);
+        else hipLaunchKernelGGL((kyb::bls::bls12381_lvm_mul_kernel<false, true>), dim3(gw), dim3(64), 0, nullptr, a);
+    }
+    KYB_HIP_CHECK(hipEventRecord(e1, nullptr));
+    KYB_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    KYB_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *usec = ms * 1e3f / (reps > 0 ? reps : 1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    KYB_HIP_CHECK(hipFree(base));
+    return KYB_OK;
+}

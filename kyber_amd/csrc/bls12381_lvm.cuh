@@ -49,13 +49,19 @@ struct LvmInv {
     }
 };
 
-template <bool PAIR>
+// EXT: the program comes with the arguments (tools/lvm_microbench.py).  A separate instantiation: the product kernels
+// assign their program from the __device__ arrays unconditionally, so that the compiler knows the address space
+// (global loads it may leave in flight; through generic pointers every record fetch became a flat load followed by
+// a full wait) and keeps the schedule walk in scalar registers.
+template <bool PAIR, bool EXT = false>
 __global__ __launch_bounds__(64, 2) void bls12381_lvm_mul_kernel(lvm::Args a) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[lvm::NL * Bls12381Lvm::N * lvm::LANES];
-    a.prog = PAIR ? LVM_BLS12381_G2_MUL_PROG : LVM_BLS12381_G1_MUL_PROG;
-    a.sched = reinterpret_cast<const lvm::Sched*>(PAIR ? LVM_BLS12381_G2_MUL_SCHED : LVM_BLS12381_G1_MUL_SCHED);
-    a.nsched = PAIR ? LVM_BLS12381_G2_MUL_NSCHED : LVM_BLS12381_G1_MUL_NSCHED;
-    a.consts = reinterpret_cast<const int32_t*>(PAIR ? LVM_BLS12381_G2_MUL_CONSTS : LVM_BLS12381_G1_MUL_CONSTS);
+    if (!EXT) {
+        a.prog = PAIR ? LVM_BLS12381_G2_MUL_PROG : LVM_BLS12381_G1_MUL_PROG;
+        a.sched = reinterpret_cast<const lvm::Sched*>(PAIR ? LVM_BLS12381_G2_MUL_SCHED : LVM_BLS12381_G1_MUL_SCHED);
+        a.nsched = PAIR ? LVM_BLS12381_G2_MUL_NSCHED : LVM_BLS12381_G1_MUL_NSCHED;
+        a.consts = reinterpret_cast<const int32_t*>(PAIR ? LVM_BLS12381_G2_MUL_CONSTS : LVM_BLS12381_G1_MUL_CONSTS);
+    }
     lvm::run<Bls12381Lvm, LvmInv, PAIR>(a, lds);
 }
 

@@ -185,6 +185,14 @@ __device__ void run(const Args& a, uint32_t* lds) {
     bool more = a.nsched > 0;
     uint32_t recw = a.prog[(size_t)ins * REC_WORDS + lane];
     while (more) {
+        // The current record is consumed FIRST (its header read: the wait for its load lands here, with nothing else in
+        // flight) and only then is the next record requested, so that request stays in flight behind the whole record.
+        // Written the other way round -- request, then header -- the compiler's wait for the header covered the request
+        // just issued as well (vmcnt(0) at the loop head): every record paid an L2 round trip, ~1000 cycles, which is
+        // what an empty record cost in tools/lvm_microbench.py.
+        const uint32_t hdr = __builtin_amdgcn_readlane(recw, 0);
+        const uint32_t arg = __builtin_amdgcn_readlane(recw, 1);
+        __builtin_amdgcn_sched_barrier(0);
         uint32_t e2 = e, rep2 = rep, ins2 = ins + 1;
         Sched sc2 = sc;
         if (ins2 == sc.start + sc.len) {
@@ -199,8 +207,7 @@ __device__ void run(const Args& a, uint32_t* lds) {
         }
         const bool more2 = e2 < a.nsched;
         const uint32_t rec_next = more2 ? a.prog[(size_t)ins2 * REC_WORDS + lane] : 0u;
-        const uint32_t hdr = __builtin_amdgcn_readlane(recw, 0);
-        const uint32_t arg = __builtin_amdgcn_readlane(recw, 1);
+        __builtin_amdgcn_sched_barrier(0);
         const uint32_t op = hdr & 15u, out_slot = (hdr >> 4) & 7u, nterm = (hdr >> 7) & 31u;
         int32_t r[N];
         bool have = false;
