@@ -63,7 +63,14 @@ for key, prefix, sub, units in (("ed25519_mul", "ed", "ed25519_mul_kernel<true>"
                                 ("bn256_pair", "bn256", "bn256_tvm_kernel<0>", 1 << 18),
                                 ("bn256_check", "bn256", "bn256_tvm_kernel<1>", 1 << 18),
                                 ("bn254_pair", "bn254", "bn254_tvm_kernel<0>", 1 << 18),
-                                ("bn254_check", "bn254", "bn254_tvm_kernel<1>", 1 << 18)):
+                                ("bn254_check", "bn254", "bn254_tvm_kernel<1>", 1 << 18),
+                                # round 3: the lane machine's ladders (a G2 element is two lanes), the per-lane kernels of the
+                                # same probe with KYB_LVM_MIN huge, the MSM's accumulate stage
+                                ("bls12381_g1_mul", "mul", "bls12381_lvm_mul_kernel<false", 1 << 16),
+                                ("bls12381_g2_mul", "mul", "bls12381_lvm_mul_kernel<true", 1 << 16),
+                                ("bls12381_g1_mul_perlane", "mulperlane", "bls12381_g1_mul_kernel", 1 << 16),
+                                ("bls12381_g2_mul_perlane", "mulperlane", "bls12381_g2_mul_kernel", 1 << 16),
+                                ("bls12381_g1_msm", "msm_bls", "accumulate_kernel", 1 << 20)):
     e = entry(prefix, sub, units)
     if e:
         res["kernels"][key] = e
