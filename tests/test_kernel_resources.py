@@ -64,3 +64,32 @@ def test_tower_machine_kernels_fit_three_waves_per_simd():
         tvm = {k: v for k, v in regs.items() if name in k}
         assert len(tvm) >= 2, (obj, list(regs))  # Pair, ValidatePairing (bn256: + its product form)
         assert all(v <= 168 for v in tvm.values()), tvm
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-readelf")), reason="no llvm-readelf")
+def test_lane_machine_kernels_fit_two_waves_per_simd_without_a_scratch_working_set():
+    """the lane machine's point is two waves per SIMD (65 536 G2 elements ARE two waves per SIMD: a
+    wave that does not fit waits for the whole first round) out of 17.9 KB of LDS per wave (eight waves per CU), with no
+    working set in scratch -- the per-lane kernels it replaces sat at 512 registers and 2-5 KB of scratch per lane."""
+    obj = os.path.join(CSRC, "bls12381.o")
+    regs = _kernel_regs(obj)
+    lvm = {k: v for k, v in regs.items() if "bls12381_lvm_mul_kernel" in k}
+    assert len(lvm) == 4, list(regs)                    # G1 / pair, product / micro-benchmark instantiations
+    assert all(v <= 256 for v in lvm.values()), lvm
+    with tempfile.TemporaryDirectory() as tmp:
+        local = os.path.join(tmp, "bls12381.o")
+        shutil.copy(obj, local)
+        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", local], cwd=tmp, check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", glob.glob(os.path.join(tmp, "*gfx950*"))[0]],
+                               check=True, capture_output=True, text=True).stdout
+    seen = 0
+    for blk in notes.split("- .agpr_count:")[1:]:
+        if "bls12381_lvm_mul_kernel" not in blk:
+            continue
+        seen += 1
+        lds = int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", blk).group(1))
+        scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
+        assert lds * 8 <= 160 * 1024, lds               # eight waves per CU
+        assert scratch <= 160, scratch                  # the out-of-line inversion's frame and a handful of spilled words
+    assert seen == 4
