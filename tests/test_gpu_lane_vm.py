@@ -151,3 +151,44 @@ def test_mul_through_the_machine_against_the_oracle(bls, grp):
     out = np.asarray(out)
     for i in samples[::3]:
         assert bytes(out[i]) == comp(mul(ki[i], base[3])), i
+
+
+@pytest.mark.parametrize("grp,n", [(1, (1 << 17) + 1000), (2, (1 << 16) + 777)])
+def test_batches_larger_than_one_chunk(bls, grp, n):
+    """The machine works through a large batch in chunks (2^17 G1 / 2^16 G2 elements: the window tables stay bounded):
+    elements either side of the chunk boundary, the ragged last chunk, a rejected and an infinite point in the second
+    chunk, status bytes of the whole batch -- against the oracle, and the identity sum_i k_i P == (sum k_i) P over ALL
+    outputs through the MSM (so that no element of either chunk can be wrong unnoticed)."""
+    import torch
+
+    chunk = (1 << 17) if grp == 1 else (1 << 16)
+    k = _scalars(b"lvm/chunk/%d" % grp, n)
+    k[:, 0] &= 0x3F
+    h = 0xC0FFEE
+    if grp == 1:
+        base, comp, mul, mul_fn, msm, commit = O.g1_mul(h, O.G1_GEN), O.g1_compress, O.g1_mul, bls.g1_batch_mul, bls.g1_msm, bls.g1_commit
+    else:
+        base, comp, mul, mul_fn, msm, commit = O.g2_mul(h, O.G2_GEN), O.g2_compress, O.g2_mul, bls.g2_batch_mul, bls.g2_msm, bls.g2_commit
+    enc = np.frombuffer(comp(base), dtype=np.uint8)
+    pts = np.tile(enc, (n, 1)).copy()
+    bad, inf = chunk + 5, chunk + 9
+    pts[bad] = 0
+    pts[bad, 0] = 0x80
+    pts[bad, -1] = 5 if grp == 1 else 7
+    pts[inf] = np.frombuffer(comp(None), dtype=np.uint8)
+    dk, dp = torch.from_numpy(k).cuda(), torch.from_numpy(pts).cuda()
+    out, st = mul_fn(dk, dp)
+    out_h, st_h = out.cpu().numpy(), st.cpu().numpy()
+    assert st_h[bad] != 0 and not np.delete(st_h, bad).any() and not out_h[bad].any()
+    assert bytes(out_h[inf]) == comp(None)
+    for i in (0, 1, chunk - 2, chunk - 1, chunk, chunk + 1, n - 2, n - 1):
+        assert bytes(out_h[i]) == comp(mul(int.from_bytes(bytes(k[i]), "big"), base)), i
+    # every output at once: sum of the outputs (unit-scalar MSM) == (sum of the scalars) * base
+    keep = np.ones(n, dtype=bool)
+    keep[[bad, inf]] = False
+    ones = torch.zeros((int(keep.sum()), 32), dtype=torch.uint8, device="cuda")
+    ones[:, 31] = 1
+    tot, st2 = msm(ones, out[torch.from_numpy(keep).cuda()], bls.F_TRUSTED(0))
+    ksum = sum(int.from_bytes(bytes(x), "big") for x in k[keep]) % O.R
+    exp, _ = commit((ksum * h % O.R).to_bytes(32, "big"))
+    assert not st2.any().item() and bytes(tot.cpu().numpy()) == bytes(np.asarray(exp)[0])
