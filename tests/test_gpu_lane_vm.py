@@ -192,3 +192,124 @@ def test_batches_larger_than_one_chunk(bls, grp, n):
     ksum = sum(int.from_bytes(bytes(x), "big") for x in k[keep]) % O.R
     exp, _ = commit((ksum * h % O.R).to_bytes(32, "big"))
     assert not st2.any().item() and bytes(tot.cpu().numpy()) == bytes(np.asarray(exp)[0])
+
+
+SEEDS = list(range(int(os.environ.get("KYB_SOAK_SEEDS", "2"))))
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_lane_machine_soak(bls, seed):
+    """Fresh inputs every seed (KYB_SOAK_SEEDS=n for more): random batch size above the threshold, group, calling
+    convention, base points, scalars with edge values at random places, infinite and rejected points at random rows;
+    two dozen rows element for element against the oracle and ALL rows through sum_i out_i == sum_i k_i P_i (an MSM over
+    the inputs against a unit-scalar MSM over the outputs)."""
+    import torch
+
+    rng = random.Random(1000 + seed)
+    grp = rng.choice((1, 2))
+    n = rng.randrange(1024, 6000)
+    fin = rng.choice((0, bls.F_TRUSTED(0), bls.F_UNCOMPRESSED, bls.F_UNCOMPRESSED | bls.F_TRUSTED(0)))
+    fout = rng.choice((0, bls.F_UNCOMPRESSED_OUT))
+    if grp == 1:
+        gen, comp, unc, mul, mul_fn, msm = O.G1_GEN, O.g1_compress, O.g1_serialize_unc, O.g1_mul, bls.g1_batch_mul, bls.g1_msm
+    else:
+        gen, comp, unc, mul, mul_fn, msm = O.G2_GEN, O.g2_compress, O.g2_serialize_unc, O.g2_mul, bls.g2_batch_mul, bls.g2_msm
+    bases = [mul(rng.randrange(1, O.R), gen) for _ in range(6)]
+    which = [rng.randrange(6) for _ in range(n)]
+    enc_in = unc if fin & bls.F_UNCOMPRESSED else comp
+    tab = [enc_in(b) for b in bases]
+    pts = [tab[w] for w in which]
+    k = np.frombuffer(rng.randbytes(32 * n), dtype=np.uint8).reshape(n, 32).copy()
+    for e in (0, 1, 2, O.R - 1, O.R, O.R + 1, (1 << 256) - 1, 0xD201000000010000, (0xD201000000010000 ** 2) - 1):
+        k[rng.randrange(n)] = np.frombuffer(e.to_bytes(32, "big"), dtype=np.uint8)
+    inf_rows = {rng.randrange(n) for _ in range(3)}
+    for i in inf_rows:
+        pts[i] = enc_in(None)
+    bad_rows = set()
+    if not (fin & bls.F_TRUSTED(0)):          # (vouched-for garbage has no contract)
+        bad_rows = {rng.randrange(n) for _ in range(3)} - inf_rows
+        for i in bad_rows:
+            b = bytearray(pts[i])
+            b[-1] ^= 1                          # y (or x) off by one: not on the curve / not the encoded point
+            if not (fin & bls.F_UNCOMPRESSED):
+                b = bytearray(len(b))
+                b[0] = 0x80
+                b[-1] = 5 if grp == 1 else 7
+            pts[i] = bytes(b)
+    dk = torch.from_numpy(k).cuda()
+    dp = torch.from_numpy(np.frombuffer(b"".join(pts), dtype=np.uint8).copy()).cuda()
+    out, st = mul_fn(dk, dp, fin | fout)
+    out_h, st_h = out.cpu().numpy(), st.cpu().numpy()
+    enc_out = unc if fout else comp
+    rows = set(rng.sample(range(n), 20)) | inf_rows | bad_rows | {0, n - 1}
+    really_bad = set()
+    for i in sorted(rows):
+        if i in bad_rows:
+            try:  # the mutation may by chance be another valid encoding
+                (O.g1_deserialize_unc if grp == 1 else O.g2_deserialize_unc)(pts[i]) if fin & bls.F_UNCOMPRESSED else \
+                    (O.g1_decompress if grp == 1 else O.g2_decompress)(pts[i])
+            except O.DecodeError:
+                really_bad.add(i)
+                assert st_h[i] != 0 and not out_h[i].any(), (seed, i)
+                continue
+        if i in bad_rows:
+            continue
+        assert st_h[i] == 0, (seed, i, st_h[i])
+        p = None if i in inf_rows else bases[which[i]]
+        assert bytes(out_h[i]) == enc_out(mul(int.from_bytes(bytes(k[i]), "big"), p)), (seed, grp, hex(fin), hex(fout), i)
+    keep = np.ones(n, dtype=bool)
+    keep[list(bad_rows | inf_rows)] = False
+    dkeep = torch.from_numpy(keep).cuda()
+    lhs, s1 = msm(dk[dkeep], dp.view(n, -1)[dkeep], fin | bls.F_TRUSTED(0))
+    ones = torch.zeros((int(keep.sum()), 32), dtype=torch.uint8, device="cuda")
+    ones[:, 31] = 1
+    rhs, s2 = msm(ones, out.view(n, -1)[dkeep], bls.F_TRUSTED(0) | (bls.F_UNCOMPRESSED if fout else 0))
+    assert not s1.any().item() and not s2.any().item() and bytes(lhs.cpu().numpy()) == bytes(rhs.cpu().numpy()), seed
+
+
+def test_lane_machine_from_several_threads_and_streams(bls):
+    """Two host threads through the host-buffer entry points and two device streams at once: every call has its own
+    (kind, stream) workspace -- tables, digits, redo mask -- and returns what it returned alone."""
+    import threading
+
+    import torch
+
+    n = 3000
+    k = _scalars(b"lvm/thr/k", n)
+    q = np.frombuffer(O.g2_compress(O.g2_mul(0xABCDEF, O.G2_GEN)) * n, dtype=np.uint8).reshape(n, 96).copy()
+    p = np.frombuffer(O.g1_compress(O.g1_mul(0xFEDCBA, O.G1_GEN)) * n, dtype=np.uint8).reshape(n, 48).copy()
+    ref2 = np.asarray(bls.g2_batch_mul(k, q)[0]).copy()
+    ref1 = np.asarray(bls.g1_batch_mul(k, p)[0]).copy()
+    errors = []
+
+    def host(fn, arr, ref):
+        try:
+            for _ in range(4):
+                if not (np.asarray(fn(k, arr)[0]) == ref).all():
+                    errors.append("host mismatch")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def dev(fn, arr, ref):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                dk, da = torch.from_numpy(k).cuda(), torch.from_numpy(arr).cuda()
+                for _ in range(4):
+                    out, _ = fn(dk, da)
+                    st.synchronize()
+                    if not (out.cpu().numpy() == ref).all():
+                        errors.append("device mismatch")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=host, args=(bls.g2_batch_mul, q, ref2), daemon=True),
+               threading.Thread(target=host, args=(bls.g1_batch_mul, p, ref1), daemon=True),
+               threading.Thread(target=dev, args=(bls.g2_batch_mul, q, ref2), daemon=True),
+               threading.Thread(target=dev, args=(bls.g1_batch_mul, p, ref1), daemon=True)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "threads are stuck"
+    assert not errors, errors
