@@ -168,3 +168,35 @@ def test_eight_listed_devices_msm_and_batches():
     finally:
         devices.set_devices([])
         devices.set_shard_threshold(16384)
+
+
+def test_device_side_combine_of_gathered_partials():
+    """kyber_amd/dist.py _tree_sum on CUDA tensors (what the node-wide MSM runs after the RCCL all-gather since round 3:
+    batched Point.Add on device tensors, one host read at the end) against the host path, for every suite and for
+    counts that make the tree odd at some level; a rejected partial must come back as failure."""
+    import torch
+
+    from kyber_amd import dist as kd
+    from kyber_amd.group import edwards25519 as ed
+    from kyber_amd.pairing import bls12381 as bls, bn256 as bn
+
+    k = _shake(b"tree/k", 8 * 32).reshape(8, 32).copy()
+    k[:, 0] &= 0x3F
+    for name, pts, add in (("bls g1", np.asarray(bls.g1_commit(k)[0]), lambda a, b: bls.ENGINE.add(1, a, b)),
+                           ("bls g2", np.asarray(bls.g2_commit(k)[0]), lambda a, b: bls.ENGINE.add(2, a, b)),
+                           ("bn256 g1", np.asarray(bn.g1_commit(k)[0]), lambda a, b: bn.ENGINE.add(1, a, b))):
+        for m in (1, 2, 3, 5, 8):
+            host, ok_h = kd._tree_sum(pts[:m].copy(), add)
+            dev, ok_d = kd._tree_sum(torch.from_numpy(pts[:m].copy()).cuda(), add)
+            assert ok_h and ok_d and bytes(dev.cpu().numpy()) == bytes(np.asarray(host)), (name, m)
+    s = k.copy()
+    s[:, 31] &= 0x0F
+    e = np.asarray(ed.batch_mul_base(s[:, ::-1].copy()))
+    for m in (1, 4, 7):
+        host, ok_h = kd._tree_sum(e[:m].copy(), ed.batch_add)
+        dev, ok_d = kd._tree_sum(torch.from_numpy(e[:m].copy()).cuda(), ed.batch_add)
+        assert ok_h and ok_d and bytes(dev.cpu().numpy()) == bytes(np.asarray(host)), m
+    bad = np.asarray(bls.g1_commit(k)[0]).copy()
+    bad[2] = 0xFF
+    _, ok = kd._tree_sum(torch.from_numpy(bad[:5]).cuda(), lambda a, b: bls.ENGINE.add(1, a, b))
+    assert not ok
