@@ -328,6 +328,17 @@ def other_workloads(rank, world, dist):
             "pair": _roof(npair / ms_pair * 1e3, mads[name][0], g1b_ + g2b_ + m.GT_LEN, prof, name + "_pair", bk),
             "pair_validated_inputs": _roof(npair / ms_pair_t * 1e3, mads[name][0], g1b_ + g2b_ + m.GT_LEN, prof, name + "_pair", bk),
             "pair_check": _roof(npair / ms_chk * 1e3, mads[name][1], 2 * (g1b_ + g2b_) + 1, prof, name + "_check", bk_chk)}
+        if name == "bls12381" and rank == 0:
+            # Which kind of box is this?  The per-lane kernels stream 100-300 KB loop bodies through the 64 KB
+            # instruction cache; the lane machine is a 27 KB interpreter.  On the boxes of rounds 1-3 the ratio below is
+            # ~0.40; on one box (profiles/r03_codesize_ab.json) it was ~0.85 and every per-lane figure of this line 2-3x
+            # lower, with the interpreter kernels and the Ed25519 headline unchanged.
+            ms_um = timed(lambda: m.ENGINE.batch_unmarshal(2, Q))
+            ms_lm = timed(lambda: m.g2_batch_mul(k, Q, m.F_TRUSTED(0)))
+            out[name]["code_fetch_probe"] = {
+                "g2_unmarshal_ms": ms_um, "g2_lane_machine_mul_validated_ms": ms_lm, "ratio": ms_um / ms_lm,
+                "expected_ratio": 0.40, "slow_instruction_fetch_box": bool(ms_um / ms_lm > 0.6),
+                "see": "profiles/r03_codesize_ab.json, DESIGN.md section 5 item 24"}
         if name == "bls12381":
             # G1Elt.Mul / G2Elt.Mul with everything UnmarshalBinary checks (flags = 0): the per-lane unmarshal kernel +
             # the lane machine's ladder; G2 also against the count with Karatsuba Fp2 products (3 instead of 4)

@@ -10,11 +10,30 @@
 
 namespace kyb {
 
+// Code size.  The instruction cache of a CU pair holds 64 KB; an inlined base-field multiplication is 4-5 KB of code
+// (BLS12-381), so a point addition over Fp2 with every multiplier inlined is a 200 KB straight line and a window step
+// of the ladder twice that: each wave then streams its instructions from L2 / HBM on every iteration (measured on
+// MI355X, profiles/r03_codesize_*: G2 subgroup check 6.7 -> 4.1 ms per 2^16, bn256 G2 ladder 2x).  The point formulas
+// therefore CALL the Fp2 multiplier and squarer (one 13 KB / 8 KB copy each, operands through the lane's scratch, which
+// stays in L1 / L2), and the Fp ones too for fields of KYB_OUTLINE_FP_MIN_WORDS words and up, so that a whole ladder
+// iteration fits the cache.
+#ifndef KYB_OUTLINE_FP_MIN_WORDS
+#define KYB_OUTLINE_FP_MIN_WORDS 99
+#endif
+template <class C> KYB_HD_NOINLINE void fp_mul_c(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) { fp_mul(r, a, b); }
+template <class C> KYB_HD_NOINLINE void fp_sqr_c(Fp<C>& r, const Fp<C>& a) { fp_sqr(r, a); }
+
 // ---- uniform names over Fp / Fp2 so the point formulas are written once
 template <class C> KYB_HD void f_add(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) { fp_add(r, a, b); }
 template <class C> KYB_HD void f_sub(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) { fp_sub(r, a, b); }
-template <class C> KYB_HD void f_mul(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) { fp_mul(r, a, b); }
-template <class C> KYB_HD void f_sqr(Fp<C>& r, const Fp<C>& a) { fp_sqr(r, a); }
+template <class C> KYB_HD void f_mul(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
+    if constexpr (C::NWORDS >= KYB_OUTLINE_FP_MIN_WORDS) fp_mul_c(r, a, b);
+    else fp_mul(r, a, b);
+}
+template <class C> KYB_HD void f_sqr(Fp<C>& r, const Fp<C>& a) {
+    if constexpr (C::NWORDS >= KYB_OUTLINE_FP_MIN_WORDS) fp_sqr_c(r, a);
+    else fp_sqr(r, a);
+}
 template <class C> KYB_HD void f_dbl(Fp<C>& r, const Fp<C>& a) { fp_dbl(r, a); }
 template <class C> KYB_HD void f_neg(Fp<C>& r, const Fp<C>& a) { fp_neg(r, a); }
 template <class C> KYB_HD void f_inv(Fp<C>& r, const Fp<C>& a) { fp_inv(r, a); }
@@ -25,8 +44,13 @@ template <class C> KYB_HD bool f_eq(const Fp<C>& a, const Fp<C>& b) { return fp_
 template <class C> KYB_HD void f_cmov(Fp<C>& r, const Fp<C>& a, bool c) { fp_cmov(r, a, c); }
 template <class T> KYB_HD void f_add(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) { fp2_add(r, a, b); }
 template <class T> KYB_HD void f_sub(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) { fp2_sub(r, a, b); }
+#ifdef KYB_OUTLINE_FP2
+template <class T> KYB_HD void f_mul(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) { fp2_mul_c(r, a, b); }
+template <class T> KYB_HD void f_sqr(Fp2<T>& r, const Fp2<T>& a) { fp2_sqr_c(r, a); }
+#else
 template <class T> KYB_HD void f_mul(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) { fp2_mul(r, a, b); }
 template <class T> KYB_HD void f_sqr(Fp2<T>& r, const Fp2<T>& a) { fp2_sqr(r, a); }
+#endif
 template <class T> KYB_HD void f_dbl(Fp2<T>& r, const Fp2<T>& a) { fp2_dbl(r, a); }
 template <class T> KYB_HD void f_neg(Fp2<T>& r, const Fp2<T>& a) { fp2_neg(r, a); }
 template <class T> KYB_HD void f_inv(Fp2<T>& r, const Fp2<T>& a) { fp2_inv(r, a); }

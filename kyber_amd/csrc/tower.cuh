@@ -103,6 +103,15 @@ KYB_HD_NOINLINE void fp2_inv(Fp2<T>& r, const Fp2<T>& a) {
 // decoding): keeps the number of inlined 338-MAD multiplier bodies -- and the compile time -- down.
 template <class T> KYB_HD_NOINLINE void fp2_mul_c(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) { fp2_mul(r, a, b); }
 template <class T> KYB_HD_NOINLINE void fp2_sqr_c(Fp2<T>& r, const Fp2<T>& a) { fp2_sqr(r, a); }
+// The Fp2 products inside Fp6 / Fp12 arithmetic: inlined (an Fp12 multiplication is then ~290 KB of straight-line
+// code for BLS12-381), or calls to the copies above with -DKYB_OUTLINE_TOWER (curve.cuh "code size").
+#ifdef KYB_OUTLINE_TOWER
+template <class T> KYB_HD void fp2_mulx(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) { fp2_mul_c(r, a, b); }
+template <class T> KYB_HD void fp2_sqrx(Fp2<T>& r, const Fp2<T>& a) { fp2_sqr_c(r, a); }
+#else
+template <class T> KYB_HD void fp2_mulx(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) { fp2_mul(r, a, b); }
+template <class T> KYB_HD void fp2_sqrx(Fp2<T>& r, const Fp2<T>& a) { fp2_sqr(r, a); }
+#endif
 
 // ----------------------------------------------------------------------- Fp6
 template <class T> KYB_HD void fp6_zero(Fp6<T>& r) { fp2_zero(r.c0); fp2_zero(r.c1); fp2_zero(r.c2); }
@@ -124,26 +133,26 @@ KYB_HD void fp6_mul_v(Fp6<T>& r, const Fp6<T>& a) {
 template <class T>
 KYB_HD void fp6_mul(Fp6<T>& r, const Fp6<T>& a, const Fp6<T>& b) {
     Fp2<T> v0, v1, v2, s, u, t0, t1, t2;
-    fp2_mul(v0, a.c0, b.c0);
-    fp2_mul(v1, a.c1, b.c1);
-    fp2_mul(v2, a.c2, b.c2);
+    fp2_mulx(v0, a.c0, b.c0);
+    fp2_mulx(v1, a.c1, b.c1);
+    fp2_mulx(v2, a.c2, b.c2);
     fp2_add_nr(s, a.c1, a.c2);
     fp2_add_nr(u, b.c1, b.c2);
-    fp2_mul(t0, s, u);
+    fp2_mulx(t0, s, u);
     fp2_sub(t0, t0, v1);
     fp2_sub(t0, t0, v2);
     fp2_mul_xi(t0, t0);
     fp2_add(t0, t0, v0);  // c0
     fp2_add_nr(s, a.c0, a.c1);
     fp2_add_nr(u, b.c0, b.c1);
-    fp2_mul(t1, s, u);
+    fp2_mulx(t1, s, u);
     fp2_sub(t1, t1, v0);
     fp2_sub(t1, t1, v1);
     fp2_mul_xi(s, v2);
     fp2_add(t1, t1, s);  // c1
     fp2_add_nr(s, a.c0, a.c2);
     fp2_add_nr(u, b.c0, b.c2);
-    fp2_mul(t2, s, u);
+    fp2_mulx(t2, s, u);
     fp2_sub(t2, t2, v0);
     fp2_sub(t2, t2, v2);
     fp2_add(t2, t2, v1);  // c2
@@ -155,15 +164,15 @@ template <class T>
 KYB_HD void fp6_sqr(Fp6<T>& r, const Fp6<T>& a) {
     // Chung-Hasan SQR2: 2 multiplications + 3 squarings in Fp2
     Fp2<T> s0, s1, s2, s3, s4, t;
-    fp2_sqr(s0, a.c0);
-    fp2_mul(t, a.c0, a.c1);
+    fp2_sqrx(s0, a.c0);
+    fp2_mulx(t, a.c0, a.c1);
     fp2_dbl(s1, t);
     fp2_sub(t, a.c0, a.c1);
     fp2_add(t, t, a.c2);
-    fp2_sqr(s2, t);
-    fp2_mul(t, a.c1, a.c2);
+    fp2_sqrx(s2, t);
+    fp2_mulx(t, a.c1, a.c2);
     fp2_dbl(s3, t);
-    fp2_sqr(s4, a.c2);
+    fp2_sqrx(s4, a.c2);
     // c0 = s0 + xi s3 ; c1 = s1 + xi s4 ; c2 = s1 + s2 + s3 - s0 - s4
     fp2_mul_xi(t, s3);
     fp2_add(r.c0, s0, t);
