@@ -223,7 +223,9 @@ def _tvm_mads():
 
     return {"bls12381": (G.build_bls12381_pair().mads(), G.build_bls12381_check().mads(), G.build_bls12381_verify().mads()),
             "bn256": (G.build_bn256_pair().mads(), G.build_bn256_check().mads()),
-            "bn254": (G.build_bn254_pair().mads(), G.build_bn254_check().mads())}
+            "bn254": (G.build_bn254_pair().mads(), G.build_bn254_check().mads()),
+            "gtmul": {"bls12381": G.build_bls12381_gtmul().mads(), "bn256": G.build_bn256_gtmul().mads(),
+                      "bn254": G.build_bn254_gtmul().mads()}}
 
 
 def _lvm_mads():
@@ -306,10 +308,19 @@ def other_workloads(rank, world, dist):
         ok_t, st_t = m.batch_validate_pairing(P, Q, sig, G2, trust)
         ms_chk_t = timed(lambda: m.batch_validate_pairing(P, Q, sig, G2, trust))
         ms_pair_t = timed(lambda: m.batch_pair(P, Q, m.F_TRUSTED(0) | m.F_TRUSTED(1)))
-        t = torch.tensor([ms_pair, ms_chk, ms_g1, ms_g2, ms_chk_t, ms_pair_t], dtype=torch.float64, device="cuda")
+        # GT exponentiation (pointGT.Mul / GTElt.Mul) of the pairing values just computed: e(P, Q)^k == e(kP, Q)
+        gt, _ = m.batch_pair(P, Q, m.F_TRUSTED(0) | m.F_TRUSTED(1))
+        gk, st_gt = m.gt_batch_mul(k, gt)
+        ms_gt = timed(lambda: m.gt_batch_mul(k, gt))
+        ns = 256
+        kP, _ = m.g1_batch_mul(k[:ns].contiguous(), P[:ns].contiguous())
+        e_kp, _ = m.batch_pair(kP, Q[:ns].contiguous())
+        gt_ok = bool((gk[:ns] == e_kp).all().item()) and not bool(st_gt.any().item())
+        del gt, gk
+        t = torch.tensor([ms_pair, ms_chk, ms_g1, ms_g2, ms_chk_t, ms_pair_t, ms_gt], dtype=torch.float64, device="cuda")
         if dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ms_pair, ms_chk, ms_g1, ms_g2, ms_chk_t, ms_pair_t = [float(x) for x in t]
+        ms_pair, ms_chk, ms_g1, ms_g2, ms_chk_t, ms_pair_t, ms_gt = [float(x) for x in t]
         good = bool(ok.all().item()) and bool(ok_t.all().item()) and not (
             st1.any().item() or st2.any().item() or st3.any().item() or st_t.any().item())
         out[name] = {"pairs_per_gpu": npair, "pairings_per_s": world * npair / ms_pair * 1e3,
@@ -317,7 +328,8 @@ def other_workloads(rank, world, dist):
                      "pairings_per_s_validated_inputs": world * npair / ms_pair_t * 1e3,
                      "pairing_checks_per_s_only_sig_unvalidated": world * npair / ms_chk_t * 1e3,
                      "g1_muls_per_s": world * npair / ms_g1 * 1e3, "g2_muls_per_s": world * npair / ms_g2 * 1e3,
-                     "all_checks_true": good, "timing": "median of 20 launches after 5 warm-ups, HIP events"}
+                     "gt_muls_per_s": world * npair / ms_gt * 1e3, "gt_mul_matches_pairing_of_multiple": gt_ok,
+                     "all_checks_true": good and gt_ok, "timing": "median of 20 launches after 5 warm-ups, HIP events"}
         g1b_, g2b_ = m.G1_LEN, m.G2_LEN
         # roofline of the pairing entry points: the MADs of the tower-machine program (operand unmarshalling and
         # its subgroup checks are extra work inside the measured time, so the fraction is a lower bound for the
@@ -327,7 +339,8 @@ def other_workloads(rank, world, dist):
         out[name]["roofline"] = {
             "pair": _roof(npair / ms_pair * 1e3, mads[name][0], g1b_ + g2b_ + m.GT_LEN, prof, name + "_pair", bk),
             "pair_validated_inputs": _roof(npair / ms_pair_t * 1e3, mads[name][0], g1b_ + g2b_ + m.GT_LEN, prof, name + "_pair", bk),
-            "pair_check": _roof(npair / ms_chk * 1e3, mads[name][1], 2 * (g1b_ + g2b_) + 1, prof, name + "_check", bk_chk)}
+            "pair_check": _roof(npair / ms_chk * 1e3, mads[name][1], 2 * (g1b_ + g2b_) + 1, prof, name + "_check", bk_chk),
+            "gt_mul": _roof(npair / ms_gt * 1e3, mads["gtmul"][name], 32 + 2 * m.GT_LEN, prof, name + "_gt_mul")}
         if name == "bls12381" and rank == 0:
             # Which kind of box is this?  The per-lane kernels stream 100-300 KB loop bodies through the 64 KB
             # instruction cache; the lane machine is a 27 KB interpreter.  On the boxes of rounds 1-3 the ratio below is

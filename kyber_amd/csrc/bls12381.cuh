@@ -358,8 +358,9 @@ KYB_HD_NOINLINE void gt_encode(uint8_t* out, const fp12& f) {
         }
     }
 }
-// GT.FromBytes of the kilic backend (kilic/gt.go:100-104): 576 bytes, every coefficient < p, and
-// membership of the order-r subgroup (f^r = 1).  Layout as gt_encode.
+// The range half of GT.FromBytes of the kilic backend (kilic/gt.go:100-104): 576 bytes, every coefficient < p; the
+// membership of the order-r subgroup is decided by the tower machine's GTMUL program (bls12381_pair.hip).  Layout as
+// gt_encode.
 KYB_HD_NOINLINE int gt_decode(fp12& f, const uint8_t* in) {
     bool ok = true;
 #pragma unroll
@@ -378,16 +379,6 @@ KYB_HD_NOINLINE int gt_decode(fp12& f, const uint8_t* in) {
         }
     }
     return ok ? ST_OK : ST_BAD_POINT;
-}
-KYB_HD_NOINLINE void gt_pow_u256(fp12& r, const fp12& a, const uint32_t (&k)[8]) {
-    fp12 acc;
-    fp12_one(acc);
-#pragma unroll 1
-    for (int i = 255; i >= 0; i--) {
-        fp12_sqr(acc, acc);
-        if ((k[i >> 5] >> (i & 31)) & 1) fp12_mul(acc, acc, a);
-    }
-    r = acc;
 }
 // 32-byte big-endian scalar (mod.Int wire format, group/mod/int.go:334-350) -> little-endian words
 KYB_HD void scalar_from_be(uint32_t (&k)[8], const uint8_t* in) { words_from_be<8>(k, in); }
@@ -634,24 +625,6 @@ KYB_HD int g2_add_wire(uint8_t* out, const uint8_t* pa, const uint8_t* pb) {
     jac_add(r, p, q);
     jac_to_aff(a, r);
     g2_encode(out, a);
-    return ST_OK;
-}
-// out = gt^k   (GTElt.Mul, kilic/gt.go:79-84 -> GT.Exp).  Rejected input: status + zero output.
-KYB_HD int gt_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* gt) {
-    fp12 f, t;
-    int st = gt_decode(f, gt);
-    if (st == ST_OK) {
-        gt_pow_u256(t, f, CC::R_WORDS);
-        if (!fp12_is_one(t)) st = ST_NOT_IN_SUBGROUP;
-    }
-    if (st != ST_OK) {
-        zero_bytes(out, 576);
-        return st;
-    }
-    uint32_t k[8];
-    scalar_from_be(k, scalar_be);
-    gt_pow_u256(f, f, k);
-    gt_encode(out, f);
     return ST_OK;
 }
 }  // namespace bls

@@ -191,13 +191,17 @@ class Acc2:
         return self
 
 
+MASK_EXPO = 3  # store mask 3: the lane keeps the old value unless bit (base - repetition * stride) of ITS exponent is set
+
+
 class Out:
-    def __init__(self, dst, terms, scale=1, mask=0, raw=False):
-        self.dst, self.terms, self.scale, self.mask, self.raw = dst, terms, scale, mask, raw
+    def __init__(self, dst, terms, scale=1, mask=0, raw=False, ebit=None):
+        self.dst, self.terms, self.scale, self.mask, self.raw, self.ebit = dst, terms, scale, mask, raw, ebit
+        assert (mask == MASK_EXPO) == (ebit is not None)
 
 
-def outs2(dst_re, dst_im, acc, scale=1, mask=0, raw=False):
-    return [Out(dst_re, acc.re, scale, mask, raw), Out(dst_im, acc.im, scale, mask, raw)]
+def outs2(dst_re, dst_im, acc, scale=1, mask=0, raw=False, ebit=None):
+    return [Out(dst_re, acc.re, scale, mask, raw, ebit), Out(dst_im, acc.im, scale, mask, raw, ebit)]
 
 
 # ------------------------------------------------------------------------------------------------ program
@@ -335,15 +339,29 @@ class Prog:
                 assert all(t[0] == "l" for t in o.terms)
             assert len(o.terms) <= 31 and 1 <= o.scale <= 15
             recs.append(dict(op=OP_DOT, dst=o.dst, terms=o.terms, scale=o.scale, mask=o.mask, raw=o.raw))
+            if o.ebit is not None:
+                assert 0 <= o.ebit[0] < 1 << 16 and 0 <= o.ebit[1] < 1 << 16
+                recs[-1]["ebit"] = o.ebit
         self._emit(recs + list(extra), name)
 
     def misc(self, recs, name=""):
         self._emit(recs, name)
 
     # --- value-level simulation on stored residues
-    def simulate(self, inputs, flags=0):
+    @staticmethod
+    def _kept(r, flags, expo, it):
+        """does the lane keep the old value of the output slot?  (store masks of tower_vm.cuh)"""
+        if not r["mask"]:
+            return False
+        if r["mask"] == MASK_EXPO:
+            bit = r["ebit"][0] - it * r["ebit"][1]
+            assert bit >= 0
+            return not (expo >> bit) & 1
+        return bool((flags >> (r["mask"] - 1)) & 1)
+
+    def simulate(self, inputs, flags=0, expo=0):
         """inputs: list of stored residues (what the decode kernel leaves: a R1 mod p).  Returns (state, results) with
-        results = {'gt': {offset: (value, is_c0)}, 'is_one': bool}."""
+        results = {'gt': {offset: (value, is_c0)}, 'is_one': bool}.  expo: the lane's exponent (GT exponentiation)."""
         f = self.f
         p, Rinv = f.p, pow(f.R, -1, f.p)
         S = [0] * self.nslots
@@ -370,7 +388,7 @@ class Prog:
                                 else:
                                     acc += x
                             v = acc * r["scale"] % p
-                            if r["mask"] and (flags >> (r["mask"] - 1)) & 1:
+                            if self._kept(r, flags, expo, it):
                                 v = S[r["dst"]]
                             new[r["dst"]] = v
                         elif op == OP_GLOAD:
@@ -402,7 +420,7 @@ class Prog:
         return S, res
 
     # --- the device's arithmetic, limb for limb
-    def simulate_limbs(self, inputs, flags=0):
+    def simulate_limbs(self, inputs, flags=0, expo=0):
         f = self.f
         N, p = f.N, f.p
         pl = f.balanced(p)
@@ -480,7 +498,7 @@ class Prog:
                             v = normalise(t[N:])
                             if r["scale"] > 1:  # the scale is applied to the normalised limbs, then normalised again
                                 v = normalise([c * r["scale"] for c in v])
-                            if r["mask"] and (flags >> (r["mask"] - 1)) & 1:
+                            if self._kept(r, flags, expo, it):
                                 v = list(S[r["dst"]])
                             new[r["dst"]] = v
                         elif op == OP_GLOAD:
@@ -641,6 +659,8 @@ class Prog:
                             w0 = x1 | (x2 << 6) | (K_LIN << 24)
                         rec[1 + 2 * k] = w0
                         rec[2 + 2 * k] = cx1 | (cx2 << 8) | (cy1 << 16) | (cy2 << 24)
+                    if r["mask"] == MASK_EXPO:  # last word (terms end at 62): exponent bit of repetition 0 | stride << 16
+                        rec[REC_WORDS - 1] = r["ebit"][0] | (r["ebit"][1] << 16)
                 elif op == OP_IDLE:
                     pass
                 elif op == OP_GCLOAD:  # word 1: table index of the first entry | its advance per repetition << 16
@@ -666,7 +686,7 @@ class Prog:
                     prog.extend(blobs[b])
             sched.append((placed[key], ln, rep))
         merged = []
-        has_g = [any(r["op"] == OP_GCLOAD for r in ins) for ins in self.ins]
+        has_g = [any(r["op"] == OP_GCLOAD or r.get("mask") == MASK_EXPO for r in ins) for ins in self.ins]
         gblock = [any(has_g[start:start + ln]) for start, ln, rep in self.sched]
         for k, s in enumerate(sched):  # consecutive repeats of one block (a table index restarts with its block)
             if merged and merged[-1][0] == s[0] and merged[-1][1] == s[1] and not gblock[k]:
@@ -717,7 +737,7 @@ class Tower:
         """coefficient a_i contributing to w^k: a_i when no wrap, xi a_i after w^6 = xi"""
         return a[i]
 
-    def mul12(self, dst, a, b, name="mul12"):
+    def mul12(self, dst, a, b, name="mul12", mask=0, ebit=None):
         outs = []
         for k in range(6):
             acc = Acc2()
@@ -727,7 +747,7 @@ class Tower:
                     acc.prod(a[i], b[j])
                 else:
                     acc.prod(a[i + 6].mul_xi(self.xi0), b[j])
-            outs += outs2(dst + 2 * k, dst + 2 * k + 1, acc)
+            outs += outs2(dst + 2 * k, dst + 2 * k + 1, acc, mask=mask, ebit=ebit)
         self.P.dot(outs, name)
 
     def sqr12(self, dst, a, name="sqr12"):
@@ -1235,6 +1255,71 @@ def build_bls12381_pair():
     return P
 
 
+GT_EXP_BITS = 256  # GT exponentiation walks all 256 bits of the 32-byte scalar, most significant first
+
+
+def _gt_store(P, base, layout):
+    """register set `base` (Montgomery form, bound < 2^8 p) -> plain residues -> canonical bytes of the GT encoding"""
+    T = Tower(P)
+    X = T.reg(base)
+    one = (P.c_plain_one, 1)
+    P.dot(sum((outs2(base + 2 * j, base + 2 * j + 1, Acc2().prod_const(X[j], one, None)) for j in range(6)), []), "to_plain")
+    P.misc([dict(op=OP_GT_STORE, dst=base + 2 * j + c, arg=layout(j, c) | ((1 if (j == 0 and c == 0) else 0) << 16))
+            for j in range(6) for c in range(2)], "gt_store")
+
+
+def build_bls12381_gtmul():
+    """GTElt.Mul (kilic/gt.go:79-84: GT.Exp after the element was unmarshalled and found in the order-r subgroup) on the
+    machine: inputs 0..11 = the twelve Fp coefficients (w-basis, re / im; decoded by the per-lane code: a R1 mod p), the
+    lane's exponent enters through store mask 3.
+      membership  f^r = 1, decided without an r-exponentiation: f conj(f) = 1 (f is non-zero and unitary), f^(p^4) f =
+                  f^(p^2) (f^(p^4 - p^2 + 1) = 1: the cyclotomic subgroup, where inversion is conjugation and the
+                  Granger-Scott squaring is valid) and conj(f)^p = f^|x| (f^(p - x) = 1, x < 0): the order of f divides
+                  gcd(Phi_12(p), p - x) = r (the gcd is checked below).  A failed comparison sets the lane's flag; the
+                  kernel stores zeros and status 2 for it.
+      power       square-and-multiply from bit 255, cyclotomic squarings in [refresh, linear, linear] blocks like
+                  cyclo_sqr_run, the multiplication by f masked by the exponent bit."""
+    from math import gcd
+    f = bls12381_field()
+    p = f.p
+    r_order = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    assert (p ** 4 - p ** 2 + 1) % r_order == 0 and gcd(p ** 4 - p ** 2 + 1, p + BLS_X_ABS) == r_order
+    P = Prog(f, NSLOTS, 1, n_inputs=12, n_gslots=0)
+    T = Tower(P)
+    gam = {K: frob_gammas(p, (1, 1), K) for K in (1, 2, 4)}
+    ONE, ZERO = SPARE, SPARE + 1
+    bls_load_inputs(P, f, list(range(F_, F_ + 12)), 0)
+    FF, GG, HH = T.reg(F_), T.reg(G_), T.reg(H_)
+    P.misc([dict(op=OP_CLOAD, dst=ONE, arg=P.c_one), dict(op=OP_CLOAD, dst=ZERO, arg=P.c_zero)], "member/consts")
+
+    def same(a_base, b_of, name):
+        P.misc([dict(op=OP_CMP_EQ, dst=a_base + i, arg=b_of(i)) for i in range(12)], name)
+
+    T.mul12(H_, T.conj12(FF), FF, "member/norm")
+    same(H_, lambda i: ONE if i == 0 else ZERO, "member/norm==1")
+    T.frob12(G_, FF, 2, gam[2], "member/frob2")
+    T.frob12(H_, FF, 4, gam[4], "member/frob4")
+    T.mul12(H_, HH, FF, "member/f^(p^4+1)")
+    same(H_, lambda i: G_ + i, "member/cyclotomic")
+    T.pow_cyclo(G_, FF, BLS_X_ABS, "member/pow")
+    mone = P.mont(1)
+    P.dot(sum((outs2(G_ + 2 * j, G_ + 2 * j + 1, Acc2().prod_const(GG[j], mone, None)) for j in range(6)), []), "member/refresh")
+    T.frob12(H_, T.conj12(FF), 1, gam[1], "member/frob1")
+    same(H_, lambda i: G_ + i, "member/f^p==f^x")
+    # ---- the power
+    P.misc([dict(op=OP_CLOAD, dst=G_ + i, arg=P.c_one if i == 0 else P.c_zero) for i in range(12)], "exp/acc=1")
+    q, rem = divmod(GT_EXP_BITS, 3)
+    with P.repeat(q):
+        for j in range(3):
+            T.cyclo_sqr(G_, GG, "exp/sqr", refresh=(j == 0))
+            T.mul12(G_, GG, FF, "exp/mul", mask=MASK_EXPO, ebit=(GT_EXP_BITS - 1 - j, 3))
+    for j in range(rem):
+        T.cyclo_sqr(G_, GG, "exp/sqr", refresh=(j == 0))
+        T.mul12(G_, GG, FF, "exp/mul", mask=MASK_EXPO, ebit=(rem - 1 - j, 0))
+    _gt_store(P, G_, gt_layout_bls)
+    return P
+
+
 def build_bls12381_check():
     """inputs: P1 (2), Q1 (4), P2 (2), Q2 (4) with P2 already negated by the caller's decode kernel:
     ok = (f_{Q1}(P1) f_{Q2}(P2))^e == 1.  Flag bit 0 / 1: pair A / B has an operand at infinity (contributes 1)."""
@@ -1703,7 +1788,26 @@ def build_bn_check_product(curve):
     return P
 
 
+def build_bn_gtmul(curve):
+    """pointGT.Mul / gfP12.Exp (pairing/bn256/point.go:613, gfp12.go:177-192): a^k for ANY element of Fp12 -- the
+    reference's UnmarshalBinary checks no membership, so the squarings are general ones.  Inputs 0..11 = the twelve
+    coefficients (w-basis, re / im), the lane's exponent through store mask 3; square-and-multiply from bit 255."""
+    f = curve.field()
+    P = Prog(f, BN_NSLOTS, curve.xi0, n_inputs=12, n_gslots=0)
+    T = Tower(P)
+    bls_load_inputs(P, f, list(range(BN_A, BN_A + 12)), 0)
+    AA, BB = T.reg(BN_A), T.reg(BN_B)
+    P.misc([dict(op=OP_CLOAD, dst=BN_B + i, arg=P.c_one if i == 0 else P.c_zero) for i in range(12)], "exp/acc=1")
+    with P.repeat(GT_EXP_BITS):
+        T.sqr12(BN_B, BB, "exp/sqr")
+        T.mul12(BN_B, BB, AA, "exp/mul", mask=MASK_EXPO, ebit=(GT_EXP_BITS - 1, 1))
+    _gt_store(P, BN_B, gt_layout_bn)
+    return P
+
+
 def build_bn256_pair(): return build_bn_pair(BN256)
+def build_bn256_gtmul(): return build_bn_gtmul(BN256)
+def build_bn254_gtmul(): return build_bn_gtmul(BN254)
 def build_bn256_check(): return build_bn_check(BN256)
 def build_bn254_pair(): return build_bn_pair(BN254)
 def build_bn254_check(): return build_bn_check_product(BN254)
@@ -1773,6 +1877,8 @@ def main():
         up = suite.upper()
         out = ["// generated by gen_tower_vm.py -- do not edit", "#pragma once", "#include <stdint.h>", "namespace kyb {",
                emit_field(pair.f, struct), emit_prog(pair, up + "_PAIR"), emit_prog(check, up + "_CHECK")]
+        gtmul = {"bls12381": build_bls12381_gtmul, "bn256": build_bn256_gtmul, "bn254": build_bn254_gtmul}[suite]()
+        out.append(emit_prog(gtmul, up + "_GTMUL"))  # GT exponentiation (store mask 3: the lane's exponent bits)
         if suite == "bn256":  # the product form, for calls whose G2 operands the caller vouches for (bn_pair.inc)
             out.append(emit_prog(build_bn256_check_product(), up + "_CHECKP"))
         if suite == "bls12381":  # CHECK with the second G2 operand fixed to the generator (bls.Verify on G1)
@@ -1782,7 +1888,7 @@ def main():
         with open(dst + ".tmp", "w") as f:
             f.write("\n".join(out))
         os.replace(dst + ".tmp", dst)
-        for n, P in (("pair", pair), ("check", check)):
+        for n, P in (("pair", pair), ("check", check), ("gtmul", gtmul)):
             print(suite, n, P.stats(), "bounds (log2 column, value/p):", P.check_bounds())
 
 

@@ -295,20 +295,11 @@ int kyb_##PFX##_g2_add(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* ou
 }
 
 // ---- pairing entry points:
-//   KYB_DEFINE_GT_ABI         GT exponentiation, one element per lane (kernel + _dev + host entry points)
+//   KYB_DEFINE_GT_ABI         GT exponentiation: the _dev + host entry points over the suite's <pfx>_gt_mul_enqueue
+//                             (tower machine, program GTMUL)
 //   KYB_DEFINE_PAIR_HOST      the host-buffer Pair / ValidatePairing entry points, which stage and call the suite's
 //                             own `_dev` ones (the tower machine)
 #define KYB_DEFINE_GT_ABI(PFX, NS, GTSZ) \
-namespace kyb { \
-__global__ __launch_bounds__(64) void PFX##_gt_mul_kernel(size_t n, const uint8_t* __restrict__ scalars, \
-                                                        const uint8_t* __restrict__ gts, uint8_t* __restrict__ out, \
-                                                        uint8_t* __restrict__ status) { \
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
-    if (idx >= n) return; \
-    const int st = NS::gt_mul_wire(out + GTSZ * idx, scalars + 32 * idx, gts + GTSZ * idx); \
-    if (status) status[idx] = (uint8_t)st; \
-} \
-} \
 extern "C" { \
 int kyb_##PFX##_gt_mul_dev(size_t n, const void* d_scalars, const void* d_gt, void* d_out, void* d_status, void* stream) { \
     if (n && (!d_scalars || !d_gt || !d_out)) { \
@@ -316,10 +307,9 @@ int kyb_##PFX##_gt_mul_dev(size_t n, const void* d_scalars, const void* d_gt, vo
         return KYB_E_ARG; \
     } \
     if (!n) return KYB_OK; \
-    hipLaunchKernelGGL(kyb::PFX##_gt_mul_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
-                       (const uint8_t*)d_scalars, (const uint8_t*)d_gt, (uint8_t*)d_out, (uint8_t*)d_status); \
-    KYB_HIP_CHECK(hipGetLastError()); \
-    return KYB_OK; \
+    /* the suite's GTMUL program on the tower machine (its *_pair translation unit defines the enqueue function) */ \
+    return kyb::PFX##_gt_mul_enqueue(n, (const uint8_t*)d_scalars, (const uint8_t*)d_gt, (uint8_t*)d_out, (uint8_t*)d_status, \
+                                     (hipStream_t)stream); \
 } \
 int kyb_##PFX##_gt_mul(size_t n, const uint8_t* scalars, const uint8_t* gt, uint8_t* out, uint8_t* status) { \
     if (n && (!scalars || !gt || !out)) { \

@@ -103,144 +103,10 @@ KYB_HD_NOINLINE void fp2_inv(Fp2<T>& r, const Fp2<T>& a) {
 // decoding): keeps the number of inlined 338-MAD multiplier bodies -- and the compile time -- down.
 template <class T> KYB_HD_NOINLINE void fp2_mul_c(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) { fp2_mul(r, a, b); }
 template <class T> KYB_HD_NOINLINE void fp2_sqr_c(Fp2<T>& r, const Fp2<T>& a) { fp2_sqr(r, a); }
-// The Fp2 products inside Fp6 / Fp12 arithmetic: inlined (an Fp12 multiplication is then ~290 KB of straight-line
-// code for BLS12-381), or calls to the copies above with -DKYB_OUTLINE_TOWER (curve.cuh "code size").
-#ifdef KYB_OUTLINE_TOWER
-template <class T> KYB_HD void fp2_mulx(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) { fp2_mul_c(r, a, b); }
-template <class T> KYB_HD void fp2_sqrx(Fp2<T>& r, const Fp2<T>& a) { fp2_sqr_c(r, a); }
-#else
-template <class T> KYB_HD void fp2_mulx(Fp2<T>& r, const Fp2<T>& a, const Fp2<T>& b) { fp2_mul(r, a, b); }
-template <class T> KYB_HD void fp2_sqrx(Fp2<T>& r, const Fp2<T>& a) { fp2_sqr(r, a); }
-#endif
-
-// ----------------------------------------------------------------------- Fp6
-template <class T> KYB_HD void fp6_zero(Fp6<T>& r) { fp2_zero(r.c0); fp2_zero(r.c1); fp2_zero(r.c2); }
-template <class T> KYB_HD void fp6_one(Fp6<T>& r) { fp2_one(r.c0); fp2_zero(r.c1); fp2_zero(r.c2); }
-template <class T> KYB_HD void fp6_add(Fp6<T>& r, const Fp6<T>& a, const Fp6<T>& b) { fp2_add(r.c0, a.c0, b.c0); fp2_add(r.c1, a.c1, b.c1); fp2_add(r.c2, a.c2, b.c2); }
-template <class T> KYB_HD void fp6_sub(Fp6<T>& r, const Fp6<T>& a, const Fp6<T>& b) { fp2_sub(r.c0, a.c0, b.c0); fp2_sub(r.c1, a.c1, b.c1); fp2_sub(r.c2, a.c2, b.c2); }
-template <class T> KYB_HD void fp6_neg(Fp6<T>& r, const Fp6<T>& a) { fp2_neg(r.c0, a.c0); fp2_neg(r.c1, a.c1); fp2_neg(r.c2, a.c2); }
-template <class T> KYB_HD bool fp6_eq(const Fp6<T>& a, const Fp6<T>& b) { return fp2_eq(a.c0, b.c0) & fp2_eq(a.c1, b.c1) & fp2_eq(a.c2, b.c2); }
-// r = a * v
-template <class T>
-KYB_HD void fp6_mul_v(Fp6<T>& r, const Fp6<T>& a) {
-    Fp2<T> t;
-    fp2_mul_xi(t, a.c2);
-    r.c2 = a.c1;
-    r.c1 = a.c0;
-    r.c0 = t;
-}
-// Karatsuba, 6 Fp2 multiplications
-template <class T>
-KYB_HD void fp6_mul(Fp6<T>& r, const Fp6<T>& a, const Fp6<T>& b) {
-    Fp2<T> v0, v1, v2, s, u, t0, t1, t2;
-    fp2_mulx(v0, a.c0, b.c0);
-    fp2_mulx(v1, a.c1, b.c1);
-    fp2_mulx(v2, a.c2, b.c2);
-    fp2_add_nr(s, a.c1, a.c2);
-    fp2_add_nr(u, b.c1, b.c2);
-    fp2_mulx(t0, s, u);
-    fp2_sub(t0, t0, v1);
-    fp2_sub(t0, t0, v2);
-    fp2_mul_xi(t0, t0);
-    fp2_add(t0, t0, v0);  // c0
-    fp2_add_nr(s, a.c0, a.c1);
-    fp2_add_nr(u, b.c0, b.c1);
-    fp2_mulx(t1, s, u);
-    fp2_sub(t1, t1, v0);
-    fp2_sub(t1, t1, v1);
-    fp2_mul_xi(s, v2);
-    fp2_add(t1, t1, s);  // c1
-    fp2_add_nr(s, a.c0, a.c2);
-    fp2_add_nr(u, b.c0, b.c2);
-    fp2_mulx(t2, s, u);
-    fp2_sub(t2, t2, v0);
-    fp2_sub(t2, t2, v2);
-    fp2_add(t2, t2, v1);  // c2
-    r.c0 = t0;
-    r.c1 = t1;
-    r.c2 = t2;
-}
-template <class T>
-KYB_HD void fp6_sqr(Fp6<T>& r, const Fp6<T>& a) {
-    // Chung-Hasan SQR2: 2 multiplications + 3 squarings in Fp2
-    Fp2<T> s0, s1, s2, s3, s4, t;
-    fp2_sqrx(s0, a.c0);
-    fp2_mulx(t, a.c0, a.c1);
-    fp2_dbl(s1, t);
-    fp2_sub(t, a.c0, a.c1);
-    fp2_add(t, t, a.c2);
-    fp2_sqrx(s2, t);
-    fp2_mulx(t, a.c1, a.c2);
-    fp2_dbl(s3, t);
-    fp2_sqrx(s4, a.c2);
-    // c0 = s0 + xi s3 ; c1 = s1 + xi s4 ; c2 = s1 + s2 + s3 - s0 - s4
-    fp2_mul_xi(t, s3);
-    fp2_add(r.c0, s0, t);
-    fp2_mul_xi(t, s4);
-    fp2_add(r.c1, s1, t);
-    fp2_add(t, s1, s2);
-    fp2_add(t, t, s3);
-    fp2_sub(t, t, s0);
-    fp2_sub(r.c2, t, s4);
-}
-
-// Fp6 sum feeding an Fp6 multiplication: lazy where the field has the headroom for a third level
-template <class T>
-KYB_HD void fp6_add_pre(Fp6<T>& r, const Fp6<T>& a, const Fp6<T>& b) {
-    if constexpr (T::LAZY12) {
-        fp2_add_nr(r.c0, a.c0, b.c0);
-        fp2_add_nr(r.c1, a.c1, b.c1);
-        fp2_add_nr(r.c2, a.c2, b.c2);
-    } else {
-        fp6_add(r, a, b);
-    }
-}
-template <class T> KYB_HD_NOINLINE void fp6_mul_c(Fp6<T>& r, const Fp6<T>& a, const Fp6<T>& b) { fp6_mul(r, a, b); }
-template <class T> KYB_HD_NOINLINE void fp6_sqr_c(Fp6<T>& r, const Fp6<T>& a) { fp6_sqr(r, a); }
-
-// ---------------------------------------------------------------------- Fp12
-// (what GT exponentiation needs; Pair / ValidatePairing run on the tower machine, tower_vm.cuh, which expands the
-//  tower into base-field bilinear forms in its generator and shares nothing with this file)
-template <class T> KYB_HD void fp12_one(Fp12<T>& r) { fp6_one(r.c0); fp6_zero(r.c1); }
-template <class T> KYB_HD bool fp12_eq(const Fp12<T>& a, const Fp12<T>& b) { return fp6_eq(a.c0, b.c0) & fp6_eq(a.c1, b.c1); }
-template <class T>
-KYB_HD bool fp12_is_one(const Fp12<T>& a) {
-    Fp12<T> o;
-    fp12_one(o);
-    return fp12_eq(a, o);
-}
-template <class T>
-KYB_HD_NOINLINE void fp12_mul(Fp12<T>& r, const Fp12<T>& a, const Fp12<T>& b) {
-    Fp6<T> v0, v1, s, u, t;
-    fp6_mul(v0, a.c0, b.c0);
-    fp6_mul(v1, a.c1, b.c1);
-    fp6_add_pre(s, a.c0, a.c1);
-    fp6_add_pre(u, b.c0, b.c1);
-    fp6_mul(t, s, u);
-    fp6_sub(t, t, v0);
-    fp6_sub(r.c1, t, v1);
-    fp6_mul_v(t, v1);
-    fp6_add(r.c0, v0, t);
-}
-template <class T>
-KYB_HD void fp12_sqr_inl(Fp12<T>& r, const Fp12<T>& a) {
-    // complex squaring: 2 Fp6 multiplications
-    Fp6<T> ab, s, u, t;
-    fp6_mul(ab, a.c0, a.c1);
-    fp6_add_pre(s, a.c0, a.c1);
-    fp6_mul_v(t, a.c1);
-    fp6_add_pre(u, a.c0, t);
-    fp6_mul(s, s, u);  // (a0 + a1)(a0 + v a1) = a0^2 + v a1^2 + (1 + v) a0 a1
-    fp6_sub(s, s, ab);
-    fp6_mul_v(t, ab);
-    fp6_sub(r.c0, s, t);
-    fp6_add(r.c1, ab, ab);
-}
-template <class T>
-KYB_HD_NOINLINE void fp12_sqr(Fp12<T>& r, const Fp12<T>& a) {
-    fp12_sqr_inl(r, a);
-}
-
+// ------------------------------------------------------------------ Fp6 / Fp12
+// Only the containers remain per lane (GT encodings are decoded into them and handed to the tower machine coefficient
+// by coefficient: *_pair.hip gt_unpack kernels); the arithmetic of the tower lives in the machine's generated programs
+// (gen_tower_vm.py), GT exponentiation included since round 3.
 template <class T>
 KYB_HD void fp2_load_const(Fp2<T>& r, const uint32_t (&c)[2][T::F::NWORDS]) {
 #pragma unroll

@@ -35,7 +35,8 @@ constexpr int MAX_CONSTS = 32;
 // header word
 //   0-5 out slot | 6-11 n terms | 12 barrier before the store (an input slot of some wave is overwritten) |
 //   13 raw: no products, no Montgomery reduction -- the linear terms are normalised as they are |
-//   14-18 post scale (0 = 1) | 19-20 store mask (0 none, 1 lanes live in pair A, 2 pair B) | 21-24 opcode
+//   14-18 post scale (0 = 1) | 19-20 store mask (0 none, 1 lanes live in pair A, 2 pair B, 3 lanes whose exponent has
+//   bit (last word & 0xffff) - repetition * (last word >> 16) set: run<.., EXPO = true> only) | 21-24 opcode
 enum Op : uint32_t { OP_DOT = 0, OP_IDLE = 1, OP_GLOAD = 2, OP_INV = 3, OP_GT_STORE = 4, OP_IS_ONE = 5, OP_CLOAD = 6, OP_SPILL = 7, OP_FILL = 8, OP_CMP_EQ = 9, OP_GCLOAD = 10 };
 //   GLOAD: slot <- input[word 1] of this pairing (packed words of the per-lane field code, taken as an integer)
 //   CLOAD: slot <- constant[word 1];  INV: slot <- Inv(slot[word 1]);  SPILL / FILL: slot <-> global scratch (word 1, wave)
@@ -74,6 +75,8 @@ struct Args {
     uint32_t* gspill;        // global scratch: [workgroup][global slot][wave][slot image]
     uint32_t ngslots;
     const int32_t* gconsts;  // [index][16] the program's table of per-repetition constants (OP_GCLOAD), global memory
+    const uint32_t* expo;    // [pairing][F::NW] programs with store mask 3 (GT exponentiation): the element's exponent, 8
+                             // little-endian words at the head of its row
 };
 
 template <class F>
@@ -233,7 +236,10 @@ __device__ void words_to_limbs(int32_t (&r)[F::N], const uint32_t (&w)[F::NW]) {
 
 // The interpreter.  `Inv` supplies the base-field inversion on packed words (the per-lane field code's Kaliski inverse).
 // Workgroups are persistent: workgroup b takes the batches b, b + gridDim.x, ... of 64 pairings.
-template <class F, class Inv>
+// EXPO: the GT exponentiation programs -- store mask 3 is decoded, a failed comparison (OP_CMP_EQ: the membership test)
+// rejects the element (zero output, status 2) instead of feeding a boolean.  A separate instantiation, so that the
+// pairing kernels' code is what it was.
+template <class F, class Inv, bool EXPO = false>
 __device__ void run(const Args& a, uint32_t* lds, uint32_t* misc, int32_t* clds) {
     constexpr int N = F::N;
     constexpr int SW = Lds<F>::SLOT_WORDS;
@@ -252,7 +258,7 @@ __device__ void run(const Args& a, uint32_t* lds, uint32_t* misc, int32_t* clds)
             if (b & 0x80u) fl |= k < 2 ? 1u : 2u;
         }
         if (first_st) fl |= 0x80u;
-        if (a.status && wave == 0 && valid) a.status[pairing] = (uint8_t)first_st;
+        if (!EXPO && a.status && wave == 0 && valid) a.status[pairing] = (uint8_t)first_st;
         if (wave == 0) misc[lane] = 0;
         __syncthreads();
         // The schedule is walked one instruction AHEAD: the record of the next instruction is requested before the
@@ -286,6 +292,14 @@ __device__ void run(const Args& a, uint32_t* lds, uint32_t* misc, int32_t* clds)
                     int32_t r[N];
                     bool have = false;
                     if (op == OP_DOT) {
+                        uint32_t ebit_word = 0, ebit = 0;  // (requested before the products, consumed after them)
+                        if constexpr (EXPO) {
+                            if (((hdr >> 19) & 3u) == 3u) {
+                                const uint32_t desc = __builtin_amdgcn_readlane(recw, REC_WORDS - 1);
+                                ebit = (desc & 0xffffu) - rep * (desc >> 16);
+                                ebit_word = a.expo[pidx * F::NW + (ebit >> 5)];
+                            }
+                        }
                         int64_t t[2 * N];
 #pragma unroll
                         for (int i = 0; i < 2 * N; i++) t[i] = 0;
@@ -335,7 +349,10 @@ __device__ void run(const Args& a, uint32_t* lds, uint32_t* misc, int32_t* clds)
                         if (mask) {  // lanes whose pair is dead keep the old value of the output slot
                             int32_t old[N];
                             Lds<F>::load(old, lds, out_slot, lane);
-                            const bool dead = (fl >> (mask - 1)) & 1u;
+                            bool dead = (fl >> (mask - 1)) & 1u;
+                            if constexpr (EXPO) {
+                                if (mask == 3u) dead = !((ebit_word >> (ebit & 31u)) & 1u);
+                            }
 #pragma unroll
                             for (int i = 0; i < N; i++) r[i] = dead ? old[i] : r[i];
                         }
@@ -382,7 +399,7 @@ __device__ void run(const Args& a, uint32_t* lds, uint32_t* misc, int32_t* clds)
                         canon_words<F>(w, v);
                         if (op == OP_GT_STORE) {
                             const bool one = (fl & 3u) != 0;  // an operand at infinity: e = 1
-                            const bool rejected = fl >> 7;
+                            const bool rejected = (fl >> 7) || (EXPO && misc[lane] != 0);
                             if (valid) {
                                 uint32_t* q = reinterpret_cast<uint32_t*>(a.out + pairing * a.out_stride + (arg & 0xffffu));
                                 const uint32_t is_c0 = arg >> 16;  // this coefficient is the 1 of the identity
@@ -429,6 +446,7 @@ __device__ void run(const Args& a, uint32_t* lds, uint32_t* misc, int32_t* clds)
             more = more2;
         }
         if (a.check && wave == 0 && valid) a.out[pairing * a.out_stride] = (misc[lane] == 0 && !(fl >> 7)) ? 1 : 0;
+        if (EXPO && a.status && wave == 0 && valid) a.status[pairing] = (uint8_t)(first_st ? first_st : (misc[lane] ? 2u : 0u));
         __syncthreads();
     }
 }

@@ -63,21 +63,6 @@ int hh_bls_g2_unmarshal(const uint8_t* in, int flags, uint8_t* out) { return bls
 int hh_bls_g1_decode_unc(const uint8_t* in, int validate) { bls::g1_aff a; return bls::g1_decode_unc(a, in, validate != 0); }
 int hh_bls_g2_decode_unc(const uint8_t* in, int validate) { bls::g2_aff a; return bls::g2_decode_unc(a, in, validate != 0); }
 
-// Fp12 operations on GT-encoded operands (576 bytes, coefficients < p): the tower arithmetic at chosen magnitudes
-// (all coefficients p - 1 drives the lazy Karatsuba sums to their 2p / 4p / 8p bounds)
-int hh_bls_fp12_op(int op, const uint8_t* a576, const uint8_t* b576, uint8_t* out576) {
-    bls::fp12 a, b, r;
-    int st = bls::gt_decode(a, a576);
-    if (st) return st;
-    st = bls::gt_decode(b, b576);
-    if (st) return st;
-    switch (op) {
-        case 0: fp12_mul(r, a, b); break;
-        default: fp12_sqr(r, a); break;
-    }
-    bls::gt_encode(out576, r);
-    return 0;
-}
 
 // ---- bn256
 void hh_bn_fp_op(int op, const uint8_t* a32, const uint8_t* b32, uint8_t* out32) {
@@ -101,20 +86,6 @@ int hh_bn_g2_unmarshal(const uint8_t* in, uint8_t* out) { return bn::g2_unmarsha
 int hh_bn_g1_mul(const uint8_t* k, const uint8_t* pt, uint8_t* out) { return bn::g1_mul_wire(out, k, pt); }
 int hh_bn_g2_mul(const uint8_t* k, const uint8_t* pt, uint8_t* out) { return bn::g2_mul_wire(out, k, pt); }
 int hh_bn_g2_mul_f(const uint8_t* k, const uint8_t* pt, int flags, uint8_t* out) { return bn::g2_mul_wire(out, k, pt, (uint32_t)flags); }
-// Fp12 operations on GT-encoded operands (384 bytes): the shared tower code at bn256's parameters (two lazy levels)
-int hh_bn_fp12_op(int op, const uint8_t* a384, const uint8_t* b384, uint8_t* out384) {
-    bn::fp12 a, b, r;
-    bn::gt_decode(a, a384);
-    bn::gt_decode(b, b384);
-    switch (op) {
-        case 0: fp12_mul(r, a, b); break;
-        default: fp12_sqr(r, a); break;
-    }
-    bn::gt_encode(out384, r);
-    return 0;
-}
-int hh_bn_gt_mul(const uint8_t* k, const uint8_t* gt, uint8_t* out) { return bn::gt_mul_wire(out, k, gt); }
-int hh_bls_gt_mul(const uint8_t* k, const uint8_t* gt, uint8_t* out) { return bls::gt_mul_wire(out, k, gt); }
 int hh_bn_hash_g1(const uint8_t* msg, int len, uint8_t* out) { return bn::hash_g1_wire(out, msg, (size_t)len); }
 void hh_bn4_fp_inv(const uint8_t* a32, uint8_t* out32) {
     bn4::fp a, r;
@@ -129,16 +100,6 @@ int hh_bn4_g1_mul(const uint8_t* k, const uint8_t* pt, uint8_t* out) { return bn
 int hh_bn4_g2_mul(const uint8_t* k, const uint8_t* pt, int flags, uint8_t* out) { return bn4::g2_mul_wire(out, k, pt, (uint32_t)flags); }
 int hh_bn4_g1_add(const uint8_t* a, const uint8_t* b, uint8_t* out) { return bn4::g1_add_wire(out, a, b); }
 int hh_bn4_g2_add(const uint8_t* a, const uint8_t* b, uint8_t* out) { return bn4::g2_add_wire(out, a, b); }
-int hh_bn4_gt_mul(const uint8_t* k, const uint8_t* gt, uint8_t* out) { return bn4::gt_mul_wire(out, k, gt); }
-int hh_bn4_fp12_op(int op, const uint8_t* a384, const uint8_t* b384, uint8_t* out384) {
-    bn4::fp12 a, b, r;
-    bn4::gt_decode(a, a384);
-    bn4::gt_decode(b, b384);
-    if (op == 0) fp12_mul(r, a, b);
-    else fp12_sqr(r, a);
-    bn4::gt_encode(out384, r);
-    return 0;
-}
 void hh_bn4_keccak256(const uint8_t* msg, int len, uint8_t* out32) {
     Keccak256 c;
     c.init();

@@ -94,22 +94,6 @@ def test_scalar_multiplication_and_strict_decoding():
     assert H.call("hh_bn4_g2_mul", _be(3), off, 0x100, out_sizes=(128,))[0] == 0
 
 
-def test_gt_exponentiation_and_tower():
-    g = O.pair(O.g1_mul(5, O.G1_GEN), O.g2_mul(7, O.G2_GEN))
-    gb = O.gt_marshal(g)
-    for k in (0, 1, 0xC0FFEE, O.ORDER - 1):
-        assert H.call("hh_bn4_gt_mul", _be(k), gb, out_sizes=(384,)) == (0, O.gt_marshal(O.f12_pow(g, k)))
-    assert H.call("hh_bn4_gt_mul", _be(3), _be(O.P) + gb[32:], out_sizes=(384,)) == (1, bytes(384))
-    top = (O.P - 1, O.P - 1)
-    rng = random.Random(43)
-    cases = [[top] * 6, [top if k % 2 else (0, 0) for k in range(6)], [(rng.randrange(O.P), rng.randrange(O.P)) for _ in range(6)]]
-    for a in cases:                                          # xi = 9 + i in the lazy Karatsuba sums of the shared tower code
-        ab = O.gt_marshal(a)
-        for b in cases:
-            assert H.call("hh_bn4_fp12_op", 0, ab, O.gt_marshal(b), out_sizes=(384,)) == (0, O.gt_marshal(O.f12_mul(a, b)))
-        assert H.call("hh_bn4_fp12_op", 1, ab, ab, out_sizes=(384,)) == (0, O.gt_marshal(O.f12_sqr(a)))
-
-
 def test_field_inversion_by_division_steps():
     """fp_inv (mont.cuh: Bernstein-Yang division steps, thirty per batch): zero, one, p - 1, powers of two, values whose
     (f, g) walk is long or short, random values -- on the three fields, against pow(a, -1, p)."""

@@ -67,19 +67,6 @@ def test_scalar_mul_vs_oracle():
 
 
 
-def test_gt_mul_vs_oracle():
-    rng = random.Random(8)
-    g1 = O.g1_marshal(O.g1_mul(rng.randrange(1, O.ORDER), O.G1_GEN))
-    g2 = O.g2_marshal(O.g2_mul(rng.randrange(1, O.ORDER), O.G2_GEN))
-    gt = O.pair_bytes(g1, g2)
-    for k in (0, 1, 2, O.ORDER - 1, O.ORDER, rng.randrange(O.ORDER)):
-        assert H.call("hh_bn_gt_mul", _fp(k), gt, out_sizes=(384,)) == (0, O.gt_mul_bytes(_fp(k), gt)), hex(k)
-    # an arbitrary Fp12 element (not in GT) is accepted and exponentiated with general squarings
-    junk = bytes(rng.randrange(256) for _ in range(384))
-    k = rng.randrange(1 << 64)
-    assert H.call("hh_bn_gt_mul", _fp(k), junk, out_sizes=(384,)) == (0, O.gt_mul_bytes(_fp(k), junk))
-
-
 def test_fp_sqr_dedicated_path():
     rng = random.Random(12)
     for a in [0, 1, O.P - 1, (1 << 256) - 1] + [rng.randrange(O.P) for _ in range(300)]:
@@ -119,24 +106,6 @@ def test_g1_glv_split_edge_scalars():
         assert H.call("hh_bn_g1_mul", kb, pb, out_sizes=(64,)) == (0, O.g1_marshal(O.g1_mul(k % n, P))), hex(k)
     inf = O.g1_marshal(None)
     assert H.call("hh_bn_g1_mul", (77).to_bytes(32, "big"), inf, out_sizes=(64,)) == (0, inf)
-
-
-def test_fp12_ops_at_extreme_magnitudes():
-    """The shared tower code at bn256's parameters (lazy Karatsuba sums at the Fp2 and Fp6 levels only, and -- the
-    modulus filling its 256 bits -- carried out exactly in the packed representation): operands whose coefficients are
-    all p - 1 or alternate 0 / p - 1, against the oracle."""
-    rng = random.Random(33)
-    top = (O.P - 1, O.P - 1)
-    cases = [[top] * 6,
-             [top if k % 2 else (0, 0) for k in range(6)],
-             [(O.P - 1, 0) if k % 2 else (0, O.P - 1) for k in range(6)],
-             [(rng.randrange(O.P), rng.randrange(O.P)) for _ in range(6)]]
-    for a in cases:
-        ab = O.gt_marshal(a)
-        for b in cases:
-            bb = O.gt_marshal(b)
-            assert H.call("hh_bn_fp12_op", 0, ab, bb, out_sizes=(384,)) == (0, O.gt_marshal(O.f12_mul(a, b)))
-        assert H.call("hh_bn_fp12_op", 1, ab, ab, out_sizes=(384,)) == (0, O.gt_marshal(O.f12_sqr(a)))
 
 
 def test_unmarshal_wire():
