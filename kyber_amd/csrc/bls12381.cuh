@@ -222,7 +222,7 @@ KYB_HD_NOINLINE int g1_decode_unc(g1_aff& a, const uint8_t* in, bool validate) {
     if (validate && !g1_in_subgroup(a)) return ST_NOT_IN_SUBGROUP;
     return ST_OK;
 }
-KYB_HD_NOINLINE int g2_decode_unc(g2_aff& a, const uint8_t* in, bool validate) {
+KYB_HD_NOINLINE int g2_decode_unc(g2_aff& a, const uint8_t* in, bool validate, bool subgroup = true) {
     uint32_t w[4][12];
     uint32_t any = 0;
 #pragma unroll
@@ -260,7 +260,7 @@ KYB_HD_NOINLINE int g2_decode_unc(g2_aff& a, const uint8_t* in, bool validate) {
     a.x = x;
     a.y = y;
     a.inf = false;
-    if (validate && !g2_in_subgroup(a)) return ST_NOT_IN_SUBGROUP;
+    if (validate && subgroup && !g2_in_subgroup(a)) return ST_NOT_IN_SUBGROUP;
     return ST_OK;
 }
 // Input decoding as selected by the call's flags for point argument `arg`.
@@ -271,6 +271,11 @@ KYB_HD int g1_decode_f(g1_aff& a, const uint8_t* in, uint32_t flags, int arg) {
 KYB_HD int g2_decode_f(g2_aff& a, const uint8_t* in, uint32_t flags, int arg) {
     const bool validate = !flag_trusted(flags, arg);
     return (flags & FLAG_UNCOMPRESSED) ? g2_decode_unc(a, in, validate) : g2_decode(a, in, validate);
+}
+// UnmarshalBinary of an unvouched-for G2 point minus its r-torsion test (flag rules, range, on the curve): for callers
+// that decide the membership themselves (the pairing programs: bls12381_prep.hip)
+KYB_HD int g2_decode_on_curve(g2_aff& a, const uint8_t* in, uint32_t flags) {
+    return (flags & FLAG_UNCOMPRESSED) ? g2_decode_unc(a, in, true, false) : g2_decode(a, in, false);
 }
 KYB_HD size_t g1_wire_size(uint32_t flags) { return (flags & FLAG_UNCOMPRESSED) ? G1_WIRE_UNC : 48; }
 KYB_HD size_t g2_wire_size(uint32_t flags) { return (flags & FLAG_UNCOMPRESSED) ? G2_WIRE_UNC : 96; }

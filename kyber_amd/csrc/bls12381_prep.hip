@@ -62,7 +62,10 @@ __global__ __launch_bounds__(64) void bls12381_operand_kernel(PrepArgs a) {
     } else {
         bls::g2_aff q;
         if (o.kind == OPND_G2) {
-            st = bls::g2_decode_f(q, o.src + (size_t)o.stride * i, a.flags, (int)o.arg);
+            // an unvouched-for operand: every rule of UnmarshalBinary here except the r-torsion test, which the machine
+            // reads off the end of its Miller loop (gen_tower_vm.py bls_g2_member_check) -- 63 doublings saved per point
+            st = flag_trusted(a.flags, (int)o.arg) ? bls::g2_decode_f(q, o.src + (size_t)o.stride * i, a.flags, (int)o.arg)
+                                                        : bls::g2_decode_on_curve(q, o.src + (size_t)o.stride * i, a.flags);
         } else if (o.kind == OPND_G2_HASH) {
             bls::g2_jac h;
             bls::hash_g2_point(h, o.src + (size_t)o.stride * i, o.stride, a.dst);
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(64) void bls12381_operand_kernel(PrepArgs a) {
     a.pst[(size_t)k * a.n + i] = (uint8_t)((st & 0x7f) | ((inf && st == bls::ST_OK) ? PST_INF : 0));
 }
 
-int launch_prep(const Work& w, size_t n, const Operand* ops, int nops, uint32_t flags, const uint8_t* dst, size_t dst_len,
+int launch_prep(Work& w, size_t n, const Operand* ops, int nops, uint32_t flags, const uint8_t* dst, size_t dst_len,
                 hipStream_t st) {
     if (nops < 1 || nops > MAX_OPERANDS || dst_len > 255 || (dst_len && !dst)) {
         set_error("pairing operands: bad argument");
@@ -90,7 +93,11 @@ int launch_prep(const Work& w, size_t n, const Operand* ops, int nops, uint32_t 
     }
     PrepArgs a;
     memset(&a, 0, sizeof a);
-    for (int k = 0; k < nops; k++) a.op[k] = ops[k];
+    w.g2_member = 0;
+    for (int k = 0; k < nops; k++) {
+        a.op[k] = ops[k];
+        if (ops[k].kind == OPND_G2 && !flag_trusted(flags, (int)ops[k].arg)) w.g2_member |= 1u << k;
+    }
     a.nops = nops;
     a.n = n;
     a.in = w.in;

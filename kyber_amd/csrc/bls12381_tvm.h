@@ -32,9 +32,11 @@ struct Work {
     uint8_t* pst;
     uint32_t* gspill;
     unsigned grid;
+    uint32_t g2_member;  // set by launch_prep: bit k = operand k is a G2 point decoded WITHOUT its r-torsion test, which
+                         // the machine's program decides at the end of the Miller loop (tvm::Args::g2_member)
 };
 // Enqueue the operand kernel: ops[0 .. nops) -> w.in / w.pst.  dst: the hash-to-curve tag of the hash kinds.
-int launch_prep(const Work& w, size_t n, const Operand* ops, int nops, uint32_t flags, const uint8_t* dst, size_t dst_len,
+int launch_prep(Work& w, size_t n, const Operand* ops, int nops, uint32_t flags, const uint8_t* dst, size_t dst_len,
                 hipStream_t st);
 // Takes the (WS_PAIR, stream) workspace for n pairings with `ninputs` operands each.  The caller holds ctx->enq_mu
 // from here until the machine is enqueued.

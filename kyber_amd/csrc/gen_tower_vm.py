@@ -26,7 +26,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 WAVES = 12
 W = 28  # default limb width; a field may choose a narrower one (VmField.W)
 REC_WORDS = 64
-OP_DOT, OP_IDLE, OP_GLOAD, OP_INV, OP_GT_STORE, OP_IS_ONE, OP_CLOAD, OP_SPILL, OP_FILL, OP_CMP_EQ, OP_GCLOAD = range(11)
+OP_DOT, OP_IDLE, OP_GLOAD, OP_INV, OP_GT_STORE, OP_IS_ONE, OP_CLOAD, OP_SPILL, OP_FILL, OP_CMP_EQ, OP_GCLOAD, OP_CMP_NZ2 = range(12)
+# the comparison records (IS_ONE, CMP_EQ, CMP_NZ2) raise a bit of the lane's result flags: FLAG_VERDICT feeds the boolean of
+# a check program / rejects a GT element; FLAG_G2_A / FLAG_G2_B say that the G2 operand of pair A / B is outside the
+# order-r subgroup (decided at the end of the Miller loop: bls_g2_member_check)
+FLAG_VERDICT, FLAG_G2_A, FLAG_G2_B = 1, 2, 4
 K_PROD, K_LIN, K_PROD_CONST = 0, 1, 2
 GC_ENTRIES = 4  # table entries one OP_GCLOAD record moves into the constant area (64 lanes x 1 word = 4 x 16 words)
 
@@ -263,11 +267,11 @@ class Prog:
         reads = [self._reads(r) for r in recs]
         prebar = False
         for w, r in enumerate(recs):
-            if "dst" in r and r["op"] not in (OP_GT_STORE, OP_IS_ONE, OP_SPILL, OP_CMP_EQ):
+            if "dst" in r and r["op"] not in (OP_GT_STORE, OP_IS_ONE, OP_SPILL, OP_CMP_EQ, OP_CMP_NZ2):
                 for v, rd in enumerate(reads):
                     if v != w and r["dst"] in rd:
                         prebar = True
-        dsts = [r["dst"] for r in recs if "dst" in r and r["op"] not in (OP_GT_STORE, OP_IS_ONE, OP_SPILL, OP_CMP_EQ)]
+        dsts = [r["dst"] for r in recs if "dst" in r and r["op"] not in (OP_GT_STORE, OP_IS_ONE, OP_SPILL, OP_CMP_EQ, OP_CMP_NZ2)]
         assert len(dsts) == len(set(dsts)), "two waves write one slot: " + name
         for r in recs:
             r["prebar"] = prebar
@@ -320,7 +324,7 @@ class Prog:
             s.add(r["src"])
         elif r["op"] in (OP_GT_STORE, OP_IS_ONE, OP_SPILL):
             s.add(r["dst"])
-        elif r["op"] == OP_CMP_EQ:
+        elif r["op"] in (OP_CMP_EQ, OP_CMP_NZ2):
             s.update((r["dst"], r["arg"]))
         return s
 
@@ -367,7 +371,12 @@ class Prog:
         S = [0] * self.nslots
         G = {}
         CL = [None] * GC_ENTRIES  # the dynamic constants; refilled at the END of the instruction that holds the GCLOAD
-        res = {"gt": {}, "not_one": False}
+        res = {"gt": {}, "not_one": False, "flags": 0}
+
+        def raise_flag(r):
+            res["flags"] |= r.get("flag", FLAG_VERDICT)
+            res["not_one"] = bool(res["flags"] & FLAG_VERDICT)
+
         for start, ln, rep in self.sched:
             for it in range(rep):
                 for ins in self.ins[start:start + ln]:
@@ -409,10 +418,13 @@ class Prog:
                             res["gt"][r["arg"] & 0xffff] = (S[r["dst"]], r["arg"] >> 16)
                         elif op == OP_IS_ONE:
                             if S[r["dst"]] != (1 if r["arg"] >> 16 else 0):
-                                res["not_one"] = True
+                                raise_flag(r)
                         elif op == OP_CMP_EQ:
                             if S[r["dst"]] != S[r["arg"]]:
-                                res["not_one"] = True
+                                raise_flag(r)
+                        elif op == OP_CMP_NZ2:
+                            if S[r["dst"]] == 0 and S[r["arg"]] == 0:
+                                raise_flag(r)
                     for k, v in new.items():
                         S[k] = v
                     if newc is not None:
@@ -462,7 +474,12 @@ class Prog:
         S = [[0] * N for _ in range(self.nslots)]
         G = {}
         CL = [None] * GC_ENTRIES
-        res = {"gt": {}, "not_one": False}
+        res = {"gt": {}, "not_one": False, "flags": 0}
+
+        def raise_flag(r):
+            res["flags"] |= r.get("flag", FLAG_VERDICT)
+            res["not_one"] = bool(res["flags"] & FLAG_VERDICT)
+
         for start, ln, rep in self.sched:
             for it in range(rep):
                 for ins in self.ins[start:start + ln]:
@@ -519,10 +536,13 @@ class Prog:
                             res["gt"][r["arg"] & 0xffff] = (canon(S[r["dst"]]), r["arg"] >> 16)
                         elif op == OP_IS_ONE:
                             if canon(S[r["dst"]]) != (1 if r["arg"] >> 16 else 0):
-                                res["not_one"] = True
+                                raise_flag(r)
                         elif op == OP_CMP_EQ:
                             if canon(S[r["dst"]]) != canon(S[r["arg"]]):
-                                res["not_one"] = True
+                                raise_flag(r)
+                        elif op == OP_CMP_NZ2:
+                            if canon(S[r["dst"]]) == 0 and canon(S[r["arg"]]) == 0:
+                                raise_flag(r)
                     for k, v in new.items():
                         S[k] = v
                     if newc is not None:
@@ -619,8 +639,8 @@ class Prog:
                             new[r["dst"]] = GB[(r["arg"], w)]
                         elif op in (OP_GT_STORE, OP_IS_ONE):
                             assert B[r["dst"]] < 4, "canonicaliser input bound"
-                        elif op == OP_CMP_EQ:
-                            assert B[r["dst"]] < 4 and B[r["arg"]] < 4, "canonicaliser input bound"
+                        elif op in (OP_CMP_EQ, OP_CMP_NZ2):
+                            assert B[r["dst"]] < 4 and B[r["arg"]] < 4, ("canonicaliser input bound", self.names[start + ii])
                     for k, v in new.items():
                         B[k] = v
         return math.log2(worst_col), worst_val
@@ -669,6 +689,8 @@ class Prog:
                 else:
                     hdr |= r["dst"]
                     rec[1] = r["src"] if op == OP_INV else r["arg"]
+                    if op in (OP_IS_ONE, OP_CMP_EQ, OP_CMP_NZ2):
+                        rec[2] = r.get("flag", FLAG_VERDICT)  # the result-flag bits a failed comparison raises
                 rec[0] = hdr
                 words.extend(rec)
             key = tuple(words)
@@ -938,6 +960,39 @@ def _f2_pow(a, e, p):
 
 def frob_gammas(p, xi, K):
     return [_f2_pow(xi, j * (p ** K - 1) // 6, p) for j in range(6)]
+
+
+def bls_psi(p):
+    """psi(x, y) = (cx conj(x), cy conj(y)) on the M-type twist: cx = xi^-((p-1)/3), cy = xi^-((p-1)/2)"""
+    def inv(a):
+        n = pow(a[0] * a[0] + a[1] * a[1], -1, p)
+        return (a[0] * n % p, -a[1] * n % p)
+    return inv(_f2_pow((1, 1), (p - 1) // 3, p)), inv(_f2_pow((1, 1), (p - 1) // 2, p))
+
+
+def bls_g2_member_check(P, TX, TY, TZ, Q, tmp, flag, name="member"):
+    """UnmarshalBinary's r-torsion test of a G2 operand (kilic/g2.go FromCompressed -> InCorrectSubgroup), decided where
+    it is free: the Miller loop leaves T = [|x|] Q, and Q has order r exactly when psi(Q) = [x] Q = -T (Scott, eprint
+    2021/1130 -- the criterion of the per-lane decode, bls12381.cuh g2_in_subgroup).  With T = (X : Y : Z):
+    psi_x Z = X, psi_y Z = -Y, Z != 0.  The loop's formulas send every exceptional step (T = +-Q, T = infinity: only
+    possible when the order of Q divides a partial parameter +- 1, never for order r) to Z = 0 for good, so such points
+    are caught by the last condition.  Q: the four slots holding (xQ, yQ); tmp: ten free slots; a failed condition
+    raises `flag` in the lane's result flags."""
+    X, Y, Z = E2.slots(*TX), E2.slots(*TY), E2.slots(*TZ)
+    xQ, yQ = E2.slots(Q[0], Q[1]), E2.slots(Q[2], Q[3])
+    cx, cy = bls_psi(P.f.p)
+    zero = tmp[8]
+    o = outs2(tmp[0], tmp[1], Acc2().prod_const(xQ.conj(), P.mont(cx[0]), P.mont(cx[1])))        # psi_x
+    o += outs2(tmp[2], tmp[3], Acc2().prod_const(yQ.conj(), P.mont(cy[0]), P.mont(cy[1])))       # psi_y
+    P.dot(o, name + "/psi", extra=[dict(op=OP_CLOAD, dst=zero, arg=P.c_zero)])
+    px, py = E2.slots(tmp[0], tmp[1]), E2.slots(tmp[2], tmp[3])
+    mone = P.mont(1)
+    o = outs2(tmp[4], tmp[5], Acc2().prod(px, Z).prod_const(-X, mone, None))                      # psi_x Z - X
+    o += outs2(tmp[6], tmp[7], Acc2().prod(py, Z).prod_const(Y, mone, None))                      # psi_y Z + Y
+    o += outs2(tmp[0], tmp[1], Acc2().prod_const(Z, mone, None))                                  # Z, bound refreshed
+    P.dot(o, name + "/diff")
+    P.misc([dict(op=OP_CMP_EQ, dst=tmp[4 + i], arg=zero, flag=flag) for i in range(4)]
+           + [dict(op=OP_CMP_NZ2, dst=tmp[0], arg=tmp[1], flag=flag)], name + "/verdict")
 
 
 # slot map shared by the BLS12-381 programs
@@ -1246,6 +1301,7 @@ def build_bls12381_pair():
         bls_add_step(P, T, TX, TY, TZ, QT, tmp, L, PX, PY, F_, 0)
 
     bls_sched_miller(P, step, add)
+    bls_g2_member_check(P, TX, TY, TZ, Q, tmp, FLAG_G2_A)
     res = bls_final_exp(P, T, T.conj12(FF), gam)
     # plain residues, then canonical bytes
     one = (P.c_plain_one, 1)
@@ -1358,6 +1414,9 @@ def build_bls12381_check():
             bls_add_step(P, T, TT[0], TT[1], TT[2], Qs, tmp[4:10], L, PP[0], PP[1], F_, mask)
 
     bls_sched_miller(P, step, add)
+    for TT, g, flag in ((T1, 2, FLAG_G2_A), (T2, 3, FLAG_G2_B)):
+        P.misc([dict(op=OP_FILL, dst=Qs[i], arg=g) for i in range(4)], "member/fillQ")
+        bls_g2_member_check(P, TT[0], TT[1], TT[2], Qs, tmp[4:10] + L[0:4], flag)
     res = bls_final_exp(P, T, T.conj12(FF), gam)
     one = (P.c_plain_one, 1)
     P.dot(sum((outs2(F_ + 2 * j, F_ + 2 * j + 1, Acc2().prod_const(res[j], one, None)) for j in range(6)), []), "to_plain")
@@ -1421,6 +1480,8 @@ def build_bls12381_verify():
 
     sched(step, add)
     assert cur[0] == len(P.gconsts) and len(lines[0]) * 2 == GC_ENTRIES
+    P.misc([dict(op=OP_FILL, dst=Qs[i], arg=2) for i in range(4)], "member/fillQ")
+    bls_g2_member_check(P, T1[0], T1[1], T1[2], Qs, tmp[4:10] + L[0:4], FLAG_G2_A)
     res = bls_final_exp(P, T, T.conj12(FF), gam)
     one = (P.c_plain_one, 1)
     P.dot(sum((outs2(F_ + 2 * j, F_ + 2 * j + 1, Acc2().prod_const(res[j], one, None)) for j in range(6)), []), "to_plain")

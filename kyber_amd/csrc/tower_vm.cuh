@@ -37,11 +37,13 @@ constexpr int MAX_CONSTS = 32;
 //   13 raw: no products, no Montgomery reduction -- the linear terms are normalised as they are |
 //   14-18 post scale (0 = 1) | 19-20 store mask (0 none, 1 lanes live in pair A, 2 pair B, 3 lanes whose exponent has
 //   bit (last word & 0xffff) - repetition * (last word >> 16) set: run<.., EXPO = true> only) | 21-24 opcode
-enum Op : uint32_t { OP_DOT = 0, OP_IDLE = 1, OP_GLOAD = 2, OP_INV = 3, OP_GT_STORE = 4, OP_IS_ONE = 5, OP_CLOAD = 6, OP_SPILL = 7, OP_FILL = 8, OP_CMP_EQ = 9, OP_GCLOAD = 10 };
+enum Op : uint32_t { OP_DOT = 0, OP_IDLE = 1, OP_GLOAD = 2, OP_INV = 3, OP_GT_STORE = 4, OP_IS_ONE = 5, OP_CLOAD = 6, OP_SPILL = 7, OP_FILL = 8, OP_CMP_EQ = 9, OP_GCLOAD = 10, OP_CMP_NZ2 = 11 };
 //   GLOAD: slot <- input[word 1] of this pairing (packed words of the per-lane field code, taken as an integer)
 //   CLOAD: slot <- constant[word 1];  INV: slot <- Inv(slot[word 1]);  SPILL / FILL: slot <-> global scratch (word 1, wave)
 //   GT_STORE: canonical big-endian bytes of the slot at byte offset (word 1 & 0xffff) of the pairing's output
-//   IS_ONE: record slot != (word 1 >> 16) in the workgroup's result flags;  CMP_EQ: record slot != slot[word 1]
+//   IS_ONE: slot != (word 1 >> 16), CMP_EQ: slot != slot[word 1], CMP_NZ2: slot == 0 and slot[word 1] == 0  raise the bits
+//   of word 2 in the lane's result flags: bit 0 the verdict (a check program's boolean, a GT element's rejection), bit 1 /
+//   bit 2 the G2 operand of pair A / B is outside the order-r subgroup (honoured for the operands Args::g2_member names)
 //   GCLOAD: constant area entries [out field .. + 3] <- TABLE[(word 1 & 0xffff) + (word 1 >> 16) * r .. + 3], r = the
 //   running repetition of the instruction's block: the constants of a loop body that change from one pass to the next
 //   (the lines of a fixed point).  Product terms then read them like any constant -- the multiply-add block has no
@@ -77,6 +79,9 @@ struct Args {
     const int32_t* gconsts;  // [index][16] the program's table of per-repetition constants (OP_GCLOAD), global memory
     const uint32_t* expo;    // [pairing][F::NW] programs with store mask 3 (GT exponentiation): the element's exponent, 8
                              // little-endian words at the head of its row
+    uint32_t g2_member;      // bit k: operand k is a G2 point that was decoded without its r-torsion test; the program's
+                             // verdict on it (result-flag bit 1 for operands 0-1, bit 2 for operands 2-3) stands in:
+                             // status 2 and a rejected pairing, exactly as if the operand kernel had reported it
 };
 
 template <class F>
@@ -251,14 +256,16 @@ __device__ void run(const Args& a, uint32_t* lds, uint32_t* misc, int32_t* clds)
         const bool valid = pairing < a.n;
         const size_t pidx = valid ? pairing : a.n - 1;  // out-of-range lanes recompute the last pairing, store nothing
         // lane flags: bit 0 pair A dead (an operand at infinity), bit 1 pair B dead, bit 7 an operand was rejected
-        uint32_t fl = 0, first_st = 0;
+        // mchk: the result-flag bits that reject this lane (an operand named by g2_member that decoded fine and is not
+        // the point at infinity: its membership verdict is the program's)
+        uint32_t fl = 0, first_st = 0, mchk = 0;
         for (uint32_t k = 0; k < a.npst; k++) {
             const uint32_t b = a.pst[(size_t)k * a.n + pidx];
             if ((b & 0x7fu) && !first_st) first_st = b & 0x7fu;
             if (b & 0x80u) fl |= k < 2 ? 1u : 2u;
+            if (!b && ((a.g2_member >> k) & 1u)) mchk |= k < 2 ? 2u : 4u;
         }
         if (first_st) fl |= 0x80u;
-        if (!EXPO && a.status && wave == 0 && valid) a.status[pairing] = (uint8_t)first_st;
         if (wave == 0) misc[lane] = 0;
         __syncthreads();
         // The schedule is walked one instruction AHEAD: the record of the next instruction is requested before the
@@ -399,7 +406,7 @@ __device__ void run(const Args& a, uint32_t* lds, uint32_t* misc, int32_t* clds)
                         canon_words<F>(w, v);
                         if (op == OP_GT_STORE) {
                             const bool one = (fl & 3u) != 0;  // an operand at infinity: e = 1
-                            const bool rejected = (fl >> 7) || (EXPO && misc[lane] != 0);
+                            const bool rejected = (fl >> 7) || (misc[lane] & (mchk | (EXPO ? 1u : 0u)));
                             if (valid) {
                                 uint32_t* q = reinterpret_cast<uint32_t*>(a.out + pairing * a.out_stride + (arg & 0xffffu));
                                 const uint32_t is_c0 = arg >> 16;  // this coefficient is the 1 of the identity
@@ -415,20 +422,23 @@ __device__ void run(const Args& a, uint32_t* lds, uint32_t* misc, int32_t* clds)
                             uint32_t diff = 0;
 #pragma unroll
                             for (int k = 0; k < F::NW; k++) diff |= w[k] ^ (((arg >> 16) && k == 0) ? 1u : 0u);
-                            if (diff) atomicOr(&misc[lane], 1u);
+                            if (diff) atomicOr(&misc[lane], __builtin_amdgcn_readlane(recw, 2));
                         }
                     }
-                    else if (op == OP_CMP_EQ) {
+                    else if (op == OP_CMP_EQ || op == OP_CMP_NZ2) {
                         int32_t v[N];
                         uint32_t wa[F::NW], wb[F::NW];
                         Lds<F>::load(v, lds, out_slot, lane);
                         canon_words<F>(wa, v);
                         Lds<F>::load(v, lds, arg & 63u, lane);
                         canon_words<F>(wb, v);
-                        uint32_t diff = 0;
+                        uint32_t diff = 0, any = 0;
 #pragma unroll
-                        for (int k = 0; k < F::NW; k++) diff |= wa[k] ^ wb[k];
-                        if (diff) atomicOr(&misc[lane], 1u);
+                        for (int k = 0; k < F::NW; k++) {
+                            diff |= wa[k] ^ wb[k];
+                            any |= wa[k] | wb[k];
+                        }
+                        if (op == OP_CMP_EQ ? diff != 0 : any == 0) atomicOr(&misc[lane], __builtin_amdgcn_readlane(recw, 2));
                     }
                     // (Timing experiment, round 2: with every barrier compiled out -- wrong results, same instruction
                     // stream -- the BLS12-381 kernel runs 1 % faster and the bn256 one 7 %: the barriers and the waiting
@@ -445,8 +455,22 @@ __device__ void run(const Args& a, uint32_t* lds, uint32_t* misc, int32_t* clds)
             recw = rec_next;
             more = more2;
         }
-        if (a.check && wave == 0 && valid) a.out[pairing * a.out_stride] = (misc[lane] == 0 && !(fl >> 7)) ? 1 : 0;
-        if (EXPO && a.status && wave == 0 && valid) a.status[pairing] = (uint8_t)(first_st ? first_st : (misc[lane] ? 2u : 0u));
+        if (wave == 0 && valid) {
+            const uint32_t mf = misc[lane];
+            if (a.check) a.out[pairing * a.out_stride] = (!(mf & (1u | mchk)) && !(fl >> 7)) ? 1 : 0;
+            if (a.status) {
+                // the first operand, in argument order, that UnmarshalBinary would have refused: a decode status of the
+                // operand kernel, or status 2 where the program found a G2 operand outside the subgroup
+                uint32_t stv = 0;
+                for (uint32_t k = 0; k < a.npst && !stv; k++) {
+                    const uint32_t b = a.pst[(size_t)k * a.n + pidx];
+                    stv = b & 0x7fu;
+                    if (!b && ((a.g2_member >> k) & 1u) && (mf & (k < 2 ? 2u : 4u))) stv = 2u;
+                }
+                if (EXPO && !stv && (mf & 1u)) stv = 2u;
+                a.status[pairing] = (uint8_t)stv;
+            }
+        }
         __syncthreads();
     }
 }

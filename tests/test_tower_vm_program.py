@@ -166,7 +166,7 @@ def test_encoding_round_trip(pair_prog):
     for i in range(0, len(words), G.REC_WORDS):
         hdr = words[i]
         op, nterm = (hdr >> 21) & 15, (hdr >> 6) & 63
-        assert op <= G.OP_GCLOAD and nterm <= 31
+        assert op <= G.OP_CMP_NZ2 and nterm <= 31
         if op == G.OP_DOT:
             for k in range(nterm):
                 w0 = words[i + 1 + 2 * k]
@@ -264,3 +264,70 @@ def test_bn256_product_form_check_and_degenerate_g2_points():
         for Q in (small, ON.g2_add(ON.g2_mul(7, ON.G2_GEN), small)):
             _, res = pair.simulate(_inputs(f, p, Q))
             assert _bn_gt_bytes(res) == ON.gt_marshal(ON.pair(p, Q)), q
+
+
+# ---------------------------------------------------------------- G2 membership decided at the end of the Miller loop
+def _twist_points():
+    """members and non-members of G2 on the twist: a member; a random twist point (order r h' with h' huge); points of
+    every small prime order dividing the cofactor (the Miller loop's point passes through +-Q / infinity on these:
+    the exceptional steps must end in Z = 0); a member plus a point of small order"""
+    rng = random.Random(31)
+    member = O.g2_mul(rng.randrange(1, O.R), O.G2_GEN)
+    while True:
+        x = (rng.randrange(O.P), rng.randrange(O.P))
+        y = O.f2_sqrt(O.f2_add(O.f2_mul(O.f2_sqr(x), x), (4, 4)))
+        if y is not None:
+            big = (x, y)
+            break
+    cof = O.g2_mul(O.R, big)                      # in the cofactor group: order divides H2
+    small, h = [], O.H2
+    for q in (13, 23, 2713, 11953, 262069):
+        assert h % q == 0
+        e = h
+        while e % q == 0:
+            e //= q
+        pt = O.g2_mul(e, cof)                      # order a power of q
+        while pt is not None and O.g2_mul(q, pt) is not None:
+            pt = O.g2_mul(q, pt)
+        if pt is not None:
+            small.append((q, pt))
+    assert len(small) >= 3
+    return member, big, small
+
+
+def _q_inputs(f, q):
+    return [v * f.R1 % f.p for v in (q[0][0], q[0][1], q[1][0], q[1][1])]
+
+
+def test_g2_membership_at_the_end_of_the_miller_loop(pair_prog, check_prog, verify_prog):
+    f = pair_prog.f
+    member, big, small = _twist_points()
+    p = O.g1_mul(7, O.G1_GEN)
+    pin = [v * f.R1 % f.p for v in p]
+    cases = [(member, True), (big, False), (O.g2_add(member, small[0][1]), False)] + [(pt, False) for _, pt in small]
+    for q, ok in cases:
+        assert O.g2_in_subgroup(q) == ok
+        _, res = pair_prog.simulate(pin + _q_inputs(f, q))
+        assert bool(res["flags"] & G.FLAG_G2_A) == (not ok), (q, ok)
+        if ok:
+            assert res["flags"] == 0 and _gt_bytes(res) == O.gt_to_bytes(O.pair(p, q))
+    # the membership of Q does not depend on P: a lane whose G1 operand is at infinity (pair dead, garbage P) still decides it
+    _, res = pair_prog.simulate([0, 0] + _q_inputs(f, big), flags=1)
+    assert res["flags"] & G.FLAG_G2_A
+    _, res = pair_prog.simulate([0, 0] + _q_inputs(f, member), flags=1)
+    assert not res["flags"] & G.FLAG_G2_A
+    # CHECK: each pair raises its own bit; VERIFY: pair A only (pair B's G2 point is the generator's table)
+    neg = [v * f.R1 % f.p for v in O.g1_neg(p)]
+    for qa, qb, want in ((member, member, 0), (big, member, G.FLAG_G2_A), (member, small[0][1], G.FLAG_G2_B),
+                         (small[1][1], big, G.FLAG_G2_A | G.FLAG_G2_B)):
+        _, res = check_prog.simulate(pin + _q_inputs(f, qa) + neg + _q_inputs(f, qb))
+        assert res["flags"] & (G.FLAG_G2_A | G.FLAG_G2_B) == want
+    _, res = check_prog.simulate(pin + _q_inputs(f, member) + neg + _q_inputs(f, member))
+    assert res["flags"] == 0                        # e(P, Q) e(-P, Q) == 1 and both members
+    for qa, want in ((member, 0), (big, G.FLAG_G2_A), (small[2][1], G.FLAG_G2_A)):
+        _, res = verify_prog.simulate(pin + _q_inputs(f, qa) + neg)
+        assert res["flags"] & (G.FLAG_G2_A | G.FLAG_G2_B) == want
+    # device arithmetic on a non-member and on a small-order point (zeros everywhere): nothing overflows, same verdict
+    for q in (big, small[0][1]):
+        _, res = pair_prog.simulate_limbs(pin + _q_inputs(f, q))
+        assert res["flags"] & G.FLAG_G2_A
