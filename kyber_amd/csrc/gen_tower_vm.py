@@ -970,29 +970,35 @@ def bls_psi(p):
     return inv(_f2_pow((1, 1), (p - 1) // 3, p)), inv(_f2_pow((1, 1), (p - 1) // 2, p))
 
 
+def g2_member_check(P, TX, TY, TZ, Q, tmp, flag, cx, cy, minus_t, name="member"):
+    """Raise `flag` unless (cx conj(xQ), cy conj(yQ)) equals -T (minus_t) or T, T = (X : Y : Z) homogeneous, and Z != 0:
+    an endomorphism image of the G2 operand Q held against the point the Miller loop has just finished with.  Q: the
+    four slots of (xQ, yQ); tmp: ten free slots."""
+    X, Y, Z = E2.slots(*TX), E2.slots(*TY), E2.slots(*TZ)
+    xQ, yQ = E2.slots(Q[0], Q[1]), E2.slots(Q[2], Q[3])
+    zero = tmp[8]
+    o = outs2(tmp[0], tmp[1], Acc2().prod_const(xQ.conj(), P.mont(cx[0]), P.mont(cx[1])))
+    o += outs2(tmp[2], tmp[3], Acc2().prod_const(yQ.conj(), P.mont(cy[0]), P.mont(cy[1])))
+    P.dot(o, name + "/image", extra=[dict(op=OP_CLOAD, dst=zero, arg=P.c_zero)])
+    px, py = E2.slots(tmp[0], tmp[1]), E2.slots(tmp[2], tmp[3])
+    mone = P.mont(1)
+    o = outs2(tmp[4], tmp[5], Acc2().prod(px, Z).prod_const(-X, mone, None))                      # image_x Z - X
+    o += outs2(tmp[6], tmp[7], Acc2().prod(py, Z).prod_const(Y if minus_t else -Y, mone, None))   # image_y Z +- Y
+    o += outs2(tmp[0], tmp[1], Acc2().prod_const(Z, mone, None))                                  # Z, bound refreshed
+    P.dot(o, name + "/diff")
+    P.misc([dict(op=OP_CMP_EQ, dst=tmp[4 + i], arg=zero, flag=flag) for i in range(4)]
+           + [dict(op=OP_CMP_NZ2, dst=tmp[0], arg=tmp[1], flag=flag)], name + "/verdict")
+
+
 def bls_g2_member_check(P, TX, TY, TZ, Q, tmp, flag, name="member"):
     """UnmarshalBinary's r-torsion test of a G2 operand (kilic/g2.go FromCompressed -> InCorrectSubgroup), decided where
     it is free: the Miller loop leaves T = [|x|] Q, and Q has order r exactly when psi(Q) = [x] Q = -T (Scott, eprint
     2021/1130 -- the criterion of the per-lane decode, bls12381.cuh g2_in_subgroup).  With T = (X : Y : Z):
     psi_x Z = X, psi_y Z = -Y, Z != 0.  The loop's formulas send every exceptional step (T = +-Q, T = infinity: only
     possible when the order of Q divides a partial parameter +- 1, never for order r) to Z = 0 for good, so such points
-    are caught by the last condition.  Q: the four slots holding (xQ, yQ); tmp: ten free slots; a failed condition
-    raises `flag` in the lane's result flags."""
-    X, Y, Z = E2.slots(*TX), E2.slots(*TY), E2.slots(*TZ)
-    xQ, yQ = E2.slots(Q[0], Q[1]), E2.slots(Q[2], Q[3])
+    are caught by the last condition.  A failed condition raises `flag` in the lane's result flags."""
     cx, cy = bls_psi(P.f.p)
-    zero = tmp[8]
-    o = outs2(tmp[0], tmp[1], Acc2().prod_const(xQ.conj(), P.mont(cx[0]), P.mont(cx[1])))        # psi_x
-    o += outs2(tmp[2], tmp[3], Acc2().prod_const(yQ.conj(), P.mont(cy[0]), P.mont(cy[1])))       # psi_y
-    P.dot(o, name + "/psi", extra=[dict(op=OP_CLOAD, dst=zero, arg=P.c_zero)])
-    px, py = E2.slots(tmp[0], tmp[1]), E2.slots(tmp[2], tmp[3])
-    mone = P.mont(1)
-    o = outs2(tmp[4], tmp[5], Acc2().prod(px, Z).prod_const(-X, mone, None))                      # psi_x Z - X
-    o += outs2(tmp[6], tmp[7], Acc2().prod(py, Z).prod_const(Y, mone, None))                      # psi_y Z + Y
-    o += outs2(tmp[0], tmp[1], Acc2().prod_const(Z, mone, None))                                  # Z, bound refreshed
-    P.dot(o, name + "/diff")
-    P.misc([dict(op=OP_CMP_EQ, dst=tmp[4 + i], arg=zero, flag=flag) for i in range(4)]
-           + [dict(op=OP_CMP_NZ2, dst=tmp[0], arg=tmp[1], flag=flag)], name + "/verdict")
+    g2_member_check(P, TX, TY, TZ, Q, tmp, flag, cx, cy, True, name)
 
 
 # slot map shared by the BLS12-381 programs
@@ -1498,8 +1504,9 @@ def build_bls12381_verify():
 # (optate.go:215-264) -- the GT bytes must equal the reference's, so the exponent is exactly the chain's; the line
 # functions and the digit form are free (any Fp2 multiple of a line dies in the final exponentiation).
 class BnCurve:
-    def __init__(self, name, u, xi0, digits, w=W):
+    def __init__(self, name, u, xi0, digits, w=W, strict_g2=False):
         self.name, self.u, self.xi0, self.digits, self.w = name, u, xi0, digits, w
+        self.strict_g2 = strict_g2  # the package's UnmarshalBinary rejects G2 points outside the order-n subgroup
         self.p = 36 * u ** 4 + 36 * u ** 3 + 24 * u ** 2 + 6 * u + 1
         assert sum(d << i for i, d in enumerate(digits)) == 6 * u + 2
 
@@ -1517,7 +1524,7 @@ BN254 = BnCurve("bn254", 4965661367192848881, 9,   # pairing/bn254/constants.go:
                  0, 1, 1, 0, -1, 0, 0, 1, 0, -1, 0, 0, 0, 0, 1, 1,
                  1, 0, 0, -1, 0, 0, 1, 0, 0, 0, 0, 0, -1, 0, 0, 1,
                  1, 0, 0, -1, 0, 0, 0, 1, 1, 0, -1, 0, 0, 1, 0, 1, 1],
-                w=27)  # xi0 = 9 puts sums of 10-fold coefficients into the unreduced columns: 27-bit limbs keep them below 2^63
+                w=27, strict_g2=True)  # xi0 = 9 puts sums of 10-fold coefficients into the unreduced columns: 27-bit limbs keep them below 2^63
 BN_NSLOTS = 63
 BN_A, BN_B, BN_C, BN_D, BN_E = 0, 12, 24, 36, 48   # five Fp12 register sets; slots 60..62 spare
 
@@ -1622,7 +1629,20 @@ def bn_add_step(P, T, TX, TY, TZ, Q, sign, tmp, L, PX, PY, fset, mask):
     T.mul_sparse(fset, f, {0: E2.slots(L[0], L[1]), 1: E2.slots(L[2], L[3]), 3: E2.slots(L[4], L[5])}, mask=mask, name="add/line")
 
 
-def bn_miller(P, T, f, first_input, mask, curve=None):
+def bn_g2_member_check(P, curve, TX, TY, TZ, Q, tmp, flag, name="member"):
+    """pairing/bn254's UnmarshalBinary rejects G2 points outside the order-n subgroup (twist.go:47-66).  The ate loop ends
+    at T = [6u+2] Q + pi(Q) - pi^2(Q), and (6u+2) + pi - pi^2 + pi^3 = 0 on G2 (the optimal ate relation): Q is a member
+    exactly when T = -pi^3(Q) = (conj(x) k1x k2x, conj(y) k1y) -- exact on alt_bn128 because the polynomial is non-zero at
+    both eigenvalues of pi modulo each of the four primes of the cofactor (tests/test_constants.py), the twist group
+    being cyclic.  Exceptional steps end in Z = 0 as on BLS12-381 (bls_g2_member_check)."""
+    p = P.f.p
+    xi = (curve.xi0, 1)
+    k1x, k1y = _f2_pow(xi, (p - 1) // 3, p), _f2_pow(xi, (p - 1) // 2, p)
+    k2x = _f2_pow(xi, (p * p - 1) // 3, p)
+    g2_member_check(P, TX, TY, TZ, Q, tmp, flag, _f2_mul(k1x, k2x, p), k1y, False, name)
+
+
+def bn_miller(P, T, f, first_input, mask, curve=None, member_flag=None):
     """F (set A) <- miller(Q, P) of optate.go:126-213 up to factors that the final exponentiation removes.
     Inputs first_input .. +5: P.x, P.y, Q.x.re, Q.x.im, Q.y.re, Q.y.im."""
     curve = curve or BN256
@@ -1677,6 +1697,8 @@ def bn_miller(P, T, f, first_input, mask, curve=None):
     o += outs2(Q1[2], Q1[3], Acc2().prod_const(yQ, (P.c_one, P.consts[P.c_one]), None))
     P.dot(o, "frobQ2")
     add(Q1, 1)
+    if member_flag:
+        bn_g2_member_check(P, curve, TX, TY, TZ, Q, tmp, member_flag)
     return FF
 
 
@@ -1741,7 +1763,7 @@ def build_bn_pair(curve):
     P = Prog(f, BN_NSLOTS, curve.xi0, n_inputs=6, n_gslots=4)
     T = Tower(P)
     gam = {K: frob_gammas(f.p, (curve.xi0, 1), K) for K in (1, 2, 3)}
-    FF = bn_miller(P, T, f, 0, 0, curve)
+    FF = bn_miller(P, T, f, 0, 0, curve, FLAG_G2_A if curve.strict_g2 else None)
     res = bn_final_exp(P, T, FF, gam, curve)
     one = (P.c_plain_one, 1)
     P.dot(sum((outs2(BN_A + 2 * j, BN_A + 2 * j + 1, Acc2().prod_const(res[j], one, None)) for j in range(6)), []), "to_plain")
@@ -1774,7 +1796,7 @@ def build_bn_check(curve):
     return P
 
 
-def build_bn_check_product(curve):
+def build_bn_check_product(curve, member=True):
     """ValidatePairing as ONE final exponentiation: ok = (f_{Q1}(P1) f_{Q2}(-P2))^e == 1, the two Miller loops sharing the
     squarings of f.  Equivalent to the reference's two pairings + Equal whenever both G2 operands lie in the order-n
     subgroup -- which pairing/bn254's UnmarshalBinary guarantees (twist.go:47-66); bn256, whose G2 is unchecked, keeps
@@ -1841,6 +1863,9 @@ def build_bn_check_product(curve):
             P.dot(o, "frobQ%d" % which)
             P.dot([Out(QT[i], [("l", Lin.slot(QF[i]))], raw=True) for i in range(4)], "add/copyQ")
             bn_add_step(P, T, *Ts[k], QT, 1, tmp, L, Ps[k][0], Ps[k][1], BN_A, k + 1)
+    if curve.strict_g2 and member:
+        for k in range(2):
+            bn_g2_member_check(P, curve, *Ts[k], Qs[k], tmp, FLAG_G2_B if k else FLAG_G2_A)
     res = bn_final_exp(P, T, FF, gam, curve)
     one = (P.c_plain_one, 1)
     P.dot(sum((outs2(BN_A + 2 * j, BN_A + 2 * j + 1, Acc2().prod_const(res[j], one, None)) for j in range(6)), []), "to_plain")

@@ -123,3 +123,62 @@ def test_validate_pairing_and_verify_status_precedence():
     keys = [c2(X), c2(big), c2(small[2]), c2(O.g2_add(X, small[0])), c2(X), c2(None)]
     v, st = bls.batch_verify_g1(b"".join(keys), msgs, sigs)
     assert list(st) == [0, 2, 2, 2, 0, 0] and list(v) == [1, 0, 0, 0, 1, 0]
+
+
+def test_bn254_pair_and_validate_with_machine_decided_membership():
+    """pairing/bn254's UnmarshalBinary rejects G2 points outside the order-n subgroup (twist.go:47-66); for the pairing
+    entry points that verdict now comes from the end of the ate loop.  bn256, whose reference has no such rule, still
+    pairs whatever is on the twist."""
+    from kyber_amd.pairing import bn254 as bn4
+    from kyber_amd.pairing import bn256 as bn6
+    from oracle import bn254 as O
+    from oracle import bn256 as O6
+
+    rng = random.Random(41)
+    member = O.g2_mul(rng.randrange(1, O.ORDER), O.G2_GEN)
+    while True:
+        xx = (rng.randrange(O.P), rng.randrange(O.P))
+        yy = O.f2_sqrt(O.f2_add(O.f2_mul(O.f2_sqr(xx), xx), O.TWIST_B))
+        if yy is not None:
+            break
+    big = (xx, yy)
+    h = 2 * O.P - O.ORDER
+    small = [s for s in (O.g2_mul(O.ORDER * h // q, big) for q in O.G2_COFACTOR_PRIMES) if s is not None]
+    g2s = [(member, 0), (big, 2), (O.g2_add(member, small[0]), 2), (None, 0)] + [(s, 2) for s in small]
+    p = O.g1_mul(11, O.G1_GEN)
+    good1 = O.g1_marshal(p)
+    bad1 = (O.P).to_bytes(32, "big") + good1[32:]                              # coordinate >= p: status 1
+    g1s = [(good1, 0, p), (bad1, 1, None), (O.g1_marshal(None), 0, None)]
+    A, B, want_st, want = [], [], [], []
+    for e1, st1, pv in g1s:
+        for q, st2 in g2s:
+            A.append(e1); B.append(O.g2_marshal(q)); want_st.append(st1 or st2)
+            want.append(bytes(384) if (st1 or st2) else (O.gt_marshal(O.F12_ONE) if (pv is None or q is None) else O.gt_marshal(O.pair(pv, q))))
+    reps = 3
+    gt, st = bn4.batch_pair(b"".join(A) * reps, b"".join(B) * reps)
+    assert list(st) == want_st * reps
+    for r in range(len(A) * reps):
+        assert bytes(gt[r]) == want[r % len(A)], r
+    _, st_t = bn4.batch_pair(b"".join(A), b"".join(B), bn4.F_TRUSTED(1))
+    assert list(st_t) == [s1 for (_, s1, _) in g1s for _ in g2s]
+    # ValidatePairing: precedence in argument order
+    k = 77
+    kp, q = O.g1_mul(11 * k, O.G1_GEN), O.g2_mul(k, O.G2_GEN)
+    m1, m2 = O.g1_marshal, O.g2_marshal
+    rows = [(m1(p), m2(q), m1(kp), m2(O.G2_GEN), 1, 0), (m1(p), m2(q), m1(p), m2(O.G2_GEN), 0, 0),
+            (m1(p), m2(big), m1(kp), m2(O.G2_GEN), 0, 2), (m1(p), m2(q), m1(kp), m2(small[1]), 0, 2),
+            (m1(p), m2(big), bad1, m2(O.G2_GEN), 0, 2), (bad1, m2(big), m1(kp), m2(O.G2_GEN), 0, 1),
+            (m1(p), m2(q), bad1, m2(big), 0, 1), (m1(None), m2(big), m1(None), m2(O.G2_GEN), 0, 2),
+            (m1(None), m2(q), m1(None), m2(O.G2_GEN), 1, 0)]
+    cols = [b"".join(r[i] for r in rows) * 8 for i in range(4)]               # 72 lanes
+    ok, st = bn4.batch_validate_pairing(*cols)
+    assert list(st) == [r[5] for r in rows] * 8 and list(ok) == [r[4] for r in rows] * 8
+    # bn256: a point of the twist outside the subgroup is an ordinary operand (point.go:466-499 checks the curve only)
+    while True:
+        xx = (rng.randrange(O6.P), rng.randrange(O6.P))
+        yy = O6.f2_sqrt(O6.f2_add(O6.f2_mul(O6.f2_sqr(xx), xx), O6.TWIST_B))
+        if yy is not None:
+            break
+    p6 = O6.g1_mul(5, O6.G1_GEN)
+    gt6, st6 = bn6.batch_pair(O6.g1_marshal(p6), O6.g2_marshal((xx, yy)))
+    assert st6[0] == 0 and bytes(gt6[0]) == O6.gt_marshal(O6.pair(p6, (xx, yy)))

@@ -331,3 +331,42 @@ def test_g2_membership_at_the_end_of_the_miller_loop(pair_prog, check_prog, veri
     for q in (big, small[0][1]):
         _, res = pair_prog.simulate_limbs(pin + _q_inputs(f, q))
         assert res["flags"] & G.FLAG_G2_A
+
+
+def test_bn254_g2_membership_at_the_end_of_the_ate_loop():
+    """pairing/bn254 rejects G2 points outside the order-n subgroup (twist.go:47-66); the programs decide it on the ate
+    loop's final point: T = [6u+2]Q + pi(Q) - pi^2(Q) = -pi^3(Q) exactly for members.  Members, a random twist point,
+    points of each prime order of the cofactor (exceptional steps), a member plus such a point; bn256's programs carry no
+    such test (its reference has none)."""
+    from oracle import bn254 as O4
+
+    pair, check = G.build_bn254_pair(), G.build_bn254_check()
+    f = pair.f
+    rng = random.Random(41)
+    member = O4.g2_mul(rng.randrange(1, O4.ORDER), O4.G2_GEN)
+    while True:
+        xx = (rng.randrange(O4.P), rng.randrange(O4.P))
+        yy = O4.f2_sqrt(O4.f2_add(O4.f2_mul(O4.f2_sqr(xx), xx), O4.TWIST_B))
+        if yy is not None:
+            break
+    big = (xx, yy)
+    h = 2 * O4.P - O4.ORDER
+    small = [s for s in (O4.g2_mul(O4.ORDER * h // q, big) for q in O4.G2_COFACTOR_PRIMES) if s is not None]
+    assert len(small) >= 3
+    p = O4.g1_mul(7, O4.G1_GEN)
+    cases = [(member, True), (big, False), (O4.g2_add(member, small[0]), False)] + [(s, False) for s in small]
+    for q, ok in cases:
+        _, res = pair.simulate(_inputs(f, p, q))
+        assert bool(res["flags"] & G.FLAG_G2_A) == (not ok), ok
+        if ok:
+            assert res["flags"] == 0 and _bn_gt_bytes(res) == O4.gt_marshal(O4.pair(p, q))
+    _, res = pair.simulate_limbs(_inputs(f, p, small[0]))
+    assert res["flags"] & G.FLAG_G2_A
+    neg = O4.g1_neg(p)
+    for qa, qb, want in ((member, member, 0), (big, member, G.FLAG_G2_A), (member, small[1], G.FLAG_G2_B), (small[0], big, G.FLAG_G2_A | G.FLAG_G2_B)):
+        _, res = check.simulate(_inputs(f, p, qa) + _inputs(f, neg, qb))
+        assert res["flags"] & (G.FLAG_G2_A | G.FLAG_G2_B) == want
+    _, res = check.simulate(_inputs(f, p, member) + _inputs(f, neg, member))
+    assert res["flags"] == 0
+    for prog in (G.build_bn256_pair(), G.build_bn256_check(), G.build_bn256_check_product()):
+        assert not any(r.get("flag", 1) != 1 for ins in prog.ins for r in ins)
