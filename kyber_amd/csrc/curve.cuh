@@ -257,6 +257,71 @@ KYB_HD_NOINLINE void jac_madd(Jac<F>& r, const Jac<F>& p, const F& x2, const F& 
     jac_madd_inl(r, p, x2, y2, q_inf);
 }
 
+// Extended Jacobian ("XYZZ") accumulator for RUNS of mixed additions (the MSM's bucket pieces): x = X / ZZ,
+// y = Y / ZZZ with ZZ^3 = ZZZ^2, infinity <=> ZZ = 0.  A mixed addition is 8M + 2S and seven subtractions
+// (madd-2008-s) against 7M + 4S and fifteen for madd-2007-bl; the rare cases are BRANCHES instead of selects (the
+// accumulator is at infinity only before its first point or after a cancellation, equal x only for repeated or
+// opposite points), so the common path carries no conditional moves at all.  Leaving the form costs 2M.
+template <class F>
+struct Xyzz {
+    F X, Y, ZZ, ZZZ;
+};
+template <class F> KYB_HD void xyzz_set_inf(Xyzz<F>& r) { f_one(r.X); f_one(r.Y); f_zero(r.ZZ); f_zero(r.ZZZ); }
+template <class F> KYB_HD bool xyzz_is_inf(const Xyzz<F>& p) { return f_is_zero(p.ZZ); }
+// (X ZZ : Y ZZZ : ZZ) is the same point in Jacobian coordinates (Z = ZZ: Z^2 = ZZ^2, Z^3 = ZZZ^2).
+template <class F>
+KYB_HD void xyzz_to_jac(Jac<F>& r, const Xyzz<F>& p) {
+    f_mul(r.X, p.X, p.ZZ);
+    f_mul(r.Y, p.Y, p.ZZZ);
+    r.Z = p.ZZ;
+}
+// r += (x2, y2), a finite affine point (the caller skips points at infinity).
+template <class F>
+KYB_HD void xyzz_madd(Xyzz<F>& r, const F& x2, const F& y2) {
+    if (xyzz_is_inf(r)) {  // first point of a run, or the run cancelled so far
+        r.X = x2;
+        r.Y = y2;
+        f_one(r.ZZ);
+        f_one(r.ZZZ);
+        return;
+    }
+    F U2, S2, P, R, PP, PPP, Q, t;
+    f_mul(U2, x2, r.ZZ);
+    f_mul(S2, y2, r.ZZZ);
+    f_sub(P, U2, r.X);
+    f_sub(R, S2, r.Y);
+    if (f_is_zero(P)) {  // same x: the point itself (double it) or its inverse (cancel)
+        if (f_is_zero(R)) {
+            Jac<F> j;
+            j.X = x2;
+            j.Y = y2;
+            f_one(j.Z);
+            jac_dbl(j, j);
+            r.X = j.X;
+            r.Y = j.Y;
+            f_sqr(r.ZZ, j.Z);
+            f_mul(r.ZZZ, r.ZZ, j.Z);
+        } else {
+            xyzz_set_inf(r);
+        }
+        return;
+    }
+    f_sqr(PP, P);
+    f_mul(PPP, P, PP);
+    f_mul(Q, r.X, PP);
+    f_sqr(t, R);
+    f_sub(t, t, PPP);
+    f_sub(t, t, Q);
+    f_sub(t, t, Q);  // X3 = R^2 - PPP - 2 Q
+    f_sub(Q, Q, t);
+    f_mul(Q, R, Q);
+    f_mul(S2, r.Y, PPP);
+    r.X = t;
+    f_sub(r.Y, Q, S2);  // Y3 = R (Q - X3) - Y1 PPP
+    f_mul(r.ZZ, r.ZZ, PP);
+    f_mul(r.ZZZ, r.ZZZ, PPP);
+}
+
 // Signed radix-16 digits of a 256-bit scalar given as eight little-endian words:
 // e[0..63] in [-8, 8), e[64] in {0, 1}.
 KYB_HD void recode16_u256(int8_t (&e)[65], const uint32_t (&k)[8]) {

@@ -368,6 +368,23 @@ static __global__ __launch_bounds__(256) void piece_order_kernel(size_t nbk, siz
     if (valid) order[base[bin] + rank] = (uint32_t)t;
 }
 
+// PieceOps<A>: the accumulator of a bucket piece -- a run of mixed additions -- may have a form of its own
+// (A::Piece with piece_identity / piece_madd / piece_finish: XYZZ on the Weierstrass curves); Acc otherwise.
+template <class A, class = void>
+struct PieceOps {
+    using type = typename A::Acc;
+    __device__ static void identity(type& a) { A::identity(a); }
+    __device__ static void madd(type& a, const typename A::Aff& p, bool neg) { A::madd(a, p, neg); }
+    __device__ static void finish(typename A::Acc& r, const type& a) { r = a; }
+};
+template <class A>
+struct PieceOps<A, decltype((void)sizeof(typename A::Piece))> {
+    using type = typename A::Piece;
+    __device__ static void identity(type& a) { A::piece_identity(a); }
+    __device__ static void madd(type& a, const typename A::Aff& p, bool neg) { A::piece_madd(a, p, neg); }
+    __device__ static void finish(typename A::Acc& r, const type& a) { A::piece_finish(r, a); }
+};
+
 // One lane per bucket piece: sums up to SUB points (mixed additions).  Lanes take the pieces in order of decreasing
 // length, so the lanes of a wave run the same number of additions (bucket sizes are Poisson-spread: in bucket order a
 // wave would wait for its longest piece, ~40 % above the mean at 32 points per bucket).
@@ -384,15 +401,17 @@ __global__ __launch_bounds__(64, 2) void accumulate_kernel(size_t nbk, size_t ma
     if (i >= max_pieces || i >= suboffs[nbk]) return;
     const uint32_t t = order[i];
     const uint32_t lo = plo[t], hi = lo + plen[t];
-    typename A::Acc acc;
-    A::identity(acc);
+    typename PieceOps<A>::type acc;
+    PieceOps<A>::identity(acc);
 #pragma unroll 1
     for (uint32_t q = lo; q < hi; q++) {
         const uint32_t e = sorted[q];
         const typename A::Aff pt = aff[e & 0x7fffffffu];
-        A::madd(acc, pt, (e >> 31) != 0);
+        PieceOps<A>::madd(acc, pt, (e >> 31) != 0);
     }
-    pieces[t] = acc;
+    typename A::Acc res;
+    PieceOps<A>::finish(res, acc);
+    pieces[t] = res;
 }
 
 // bucket b = sum of its pieces (one piece for all but skewed buckets; long ones are left to bucket_long_kernel)

@@ -13,6 +13,31 @@
 
 using namespace kyb;
 
+
+// The MSM's bucket-piece accumulator (curve.cuh Xyzz, msm_ws.cuh piece_madd): sum of +-points through xyzz_madd, left
+// through xyzz_to_jac -- held against the oracle's plain sum, exceptional cases included (tests/test_host_harness_*).
+template <class F, class AffT, class Dec, class Enc>
+static int xyzz_sum(int n, const uint8_t* pts, int wire, const uint8_t* signs, uint8_t* out, Dec dec, Enc enc) {
+    Xyzz<F> acc;
+    xyzz_set_inf(acc);
+    int bad = 0;
+    for (int i = 0; i < n; i++) {
+        AffT a;
+        if (dec(a, pts + (size_t)wire * i)) { bad++; continue; }
+        if (a.inf) continue;
+        F y = a.y, ny;
+        f_neg(ny, a.y);
+        f_cmov(y, ny, signs[i] != 0);
+        xyzz_madd(acc, a.x, y);
+    }
+    Jac<F> j;
+    xyzz_to_jac(j, acc);
+    AffT r;
+    jac_to_aff(r, j);
+    enc(out, r);
+    return bad;
+}
+
 extern "C" {
 
 // canonical big-endian in/out through the Montgomery domain
@@ -50,6 +75,27 @@ int hh_bls_g2_recode(const uint8_t* in, uint8_t* out) {
 }
 int hh_bls_g1_mul(const uint8_t* k, const uint8_t* pt, uint8_t* out) { return bls::g1_mul_wire(out, k, pt); }
 int hh_bls_g2_mul(const uint8_t* k, const uint8_t* pt, uint8_t* out) { return bls::g2_mul_wire(out, k, pt); }
+
+int hh_bls_g1_xyzz_sum(int n, const uint8_t* pts, const uint8_t* signs, uint8_t* out) {
+    return xyzz_sum<bls::fp, bls::g1_aff>(n, pts, 48, signs, out,
+        [](bls::g1_aff& a, const uint8_t* in) { return bls::g1_decode(a, in, false); },
+        [](uint8_t* o, const bls::g1_aff& a) { bls::g1_encode(o, a); });
+}
+int hh_bls_g2_xyzz_sum(int n, const uint8_t* pts, const uint8_t* signs, uint8_t* out) {
+    return xyzz_sum<bls::fp2, bls::g2_aff>(n, pts, 96, signs, out,
+        [](bls::g2_aff& a, const uint8_t* in) { return bls::g2_decode(a, in, false); },
+        [](uint8_t* o, const bls::g2_aff& a) { bls::g2_encode(o, a); });
+}
+int hh_bn_g1_xyzz_sum(int n, const uint8_t* pts, const uint8_t* signs, uint8_t* out) {
+    return xyzz_sum<bn::fp, bn::g1_aff>(n, pts, 64, signs, out,
+        [](bn::g1_aff& a, const uint8_t* in) { return bn::g1_decode(a, in); },
+        [](uint8_t* o, const bn::g1_aff& a) { bn::g1_encode(o, a); });
+}
+int hh_bn_g2_xyzz_sum(int n, const uint8_t* pts, const uint8_t* signs, uint8_t* out) {
+    return xyzz_sum<bn::fp2, bn::g2_aff>(n, pts, 128, signs, out,
+        [](bn::g2_aff& a, const uint8_t* in) { return bn::g2_decode(a, in); },
+        [](uint8_t* o, const bn::g2_aff& a) { bn::g2_encode(o, a); });
+}
 
 // flag-aware variants (KYB_F_UNCOMPRESSED / _OUT / TRUSTED): ints come before the output buffers
 int hh_bls_g1_mul_f(const uint8_t* k, const uint8_t* pt, int flags, uint8_t* out) {

@@ -256,3 +256,31 @@ def test_unmarshal_wire_on_the_zcash_fixtures_and_flags(golden_dir):
     assert H.call("hh_bls_g2_unmarshal", O.g2_compress(c2), 0, out_sizes=(96,)) == (2, bytes(96))
     assert H.call("hh_bls_g1_unmarshal", O.g1_compress(c1), F_TRUSTED(0), out_sizes=(48,)) == (0, O.g1_compress(c1))
     assert H.call("hh_bls_g1_unmarshal", O.g1_compress(None), UO, out_sizes=(96,)) == (0, O.g1_serialize_unc(None))
+
+
+def _xyzz_cases(rng, gen, mul, neg):
+    """Runs of +-points for the MSM's XYZZ piece accumulator, the rare branches included."""
+    pts = [mul(rng.randrange(1, O.R), gen) for _ in range(6)]
+    P, Q = pts[0], pts[1]
+    yield [(p, rng.random() < 0.5) for p in pts]                      # plain run
+    yield [(P, False)]                                                # one point
+    yield []                                                          # empty run -> infinity
+    yield [(P, False), (P, False), (Q, True)]                         # second addition is a doubling
+    yield [(P, False), (P, True)]                                     # cancels to infinity
+    yield [(P, False), (P, True), (Q, False), (Q, False), (Q, False)]  # infinity, restart, doubling, 2Q + Q
+    yield [(None, False), (P, True), (None, True), (neg(P), True), (Q, False)]  # inputs at infinity are skipped
+
+
+def test_xyzz_piece_accumulator_vs_oracle():
+    rng = random.Random(41)
+    for grp in (1, 2):
+        gen, mul, add, neg, comp, size, fn = (
+            (O.G1_GEN, O.g1_mul, O.g1_add, O.g1_neg, O.g1_compress, 48, "hh_bls_g1_xyzz_sum") if grp == 1 else
+            (O.G2_GEN, O.g2_mul, O.g2_add, O.g2_neg, O.g2_compress, 96, "hh_bls_g2_xyzz_sum"))
+        for run in _xyzz_cases(rng, gen, mul, neg):
+            exp = None
+            for p, s in run:
+                exp = add(exp, neg(p) if s else p)
+            wire = b"".join(comp(p) for p, _ in run) or b"\x00"
+            signs = bytes(int(s) for _, s in run) or b"\x00"
+            assert H.call(fn, len(run), wire, signs, out_sizes=(size,)) == (0, comp(exp)), (grp, run)

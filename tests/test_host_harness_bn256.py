@@ -144,3 +144,31 @@ def test_g2_gls_multiplication_for_vouched_points():
         kb = k.to_bytes(32, "big")
         assert H.call("hh_bn_g2_mul_f", kb, O.g2_marshal(q), 0x100, out_sizes=(128,)) == (0, O.g2_marshal(O.g2_mul(k, q))), k
         assert H.call("hh_bn_g2_mul_f", kb, O.g2_marshal(q), 0, out_sizes=(128,)) == (0, O.g2_marshal(O.g2_mul(k, q))), k
+
+
+def test_xyzz_piece_accumulator_vs_oracle():
+    """The MSM's bucket-piece accumulator (curve.cuh Xyzz): plain runs, doubling, cancellation, restart, infinity inputs."""
+    import random
+    rng = random.Random(43)
+    for grp in (1, 2):
+        gen, mul, add, neg, mar, size, fn = (
+            (O.G1_GEN, O.g1_mul, O.g1_add, O.g1_neg, O.g1_marshal, 64, "hh_bn_g1_xyzz_sum") if grp == 1 else
+            (O.G2_GEN, O.g2_mul, O.g2_add, O.g2_neg, O.g2_marshal, 128, "hh_bn_g2_xyzz_sum"))
+        pts = [mul(rng.randrange(1, O.ORDER), gen) for _ in range(5)]
+        P, Q = pts[0], pts[1]
+        runs = [
+            [(p, rng.random() < 0.5) for p in pts],
+            [(P, False)],
+            [],
+            [(P, False), (P, False), (Q, True)],
+            [(P, False), (P, True)],
+            [(P, False), (P, True), (Q, False), (Q, False), (Q, False)],
+            [(None, False), (P, True), (None, True), (neg(P), True), (Q, False)],
+        ]
+        for run in runs:
+            exp = None
+            for p, s in run:
+                exp = add(exp, neg(p) if s else p)
+            wire = b"".join(mar(p) for p, _ in run) or b"\x00"
+            signs = bytes(int(s) for _, s in run) or b"\x00"
+            assert H.call(fn, len(run), wire, signs, out_sizes=(size,)) == (0, mar(exp)), (grp, run)
