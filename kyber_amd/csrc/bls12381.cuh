@@ -395,29 +395,90 @@ KYB_HD void scalar_from_be(uint32_t (&k)[8], const uint8_t* in) { words_from_be<
 // quotients are plain non-negative integers obtained by long division, so there is no lattice rounding to get wrong,
 // and scalars >= r need no special case (k P = sum a_i |z|^i P holds over the integers).
 //
-// Bitwise restoring division of the 256-bit k by a DW-word divisor whose top bit is set: ~25 instructions per bit,
-// <1 % of a scalar multiplication.
+// floor(k / d) and k mod d for the two divisors of the endomorphism splits -- DW = 4: d = z^2 (G1, GLV), DW = 2:
+// d = |z| (G2, GLS) -- by the divisor's reciprocal m = floor(2^(256 + 32 DW) / d) = 2^256 + MR (Barrett): with
+// k < 2^256 the estimate floor(k m / 2^(256 + 32 DW)) is the quotient or one below it, so one conditional correction
+// is exact (two are executed).  ~250 instructions; the bitwise restoring division this replaces took ~25 per bit --
+// 6 400 per scalar, more than a point addition of the MSM whose decode kernel splits 2^20 scalars.
 template <int DW>
-KYB_HD void divmod_u256(uint32_t (&q)[8], uint32_t (&rem)[DW], const uint32_t (&k)[8], const uint32_t (&d)[DW]) {
+struct ZDiv;
+template <>
+struct ZDiv<4> {  // z^2 = 0xac45a4010001a402 00000001 00000000
+    static constexpr uint32_t D[4] = {0x00000000u, 0x00000001u, 0x0001a402u, 0xac45a401u};
+    static constexpr uint32_t MR[8] = {0x818be409u, 0xa1a872d6u, 0x27adc027u, 0x034eb4b9u, 0xf6cfee2eu, 0x63f6e522u, 0xe01faaddu, 0x7c6becf1u};
+};
+template <>
+struct ZDiv<2> {  // |z| = 0xd201000000010000
+    static constexpr uint32_t D[2] = {0x00010000u, 0xd2010000u};
+    static constexpr uint32_t MR[8] = {0x2942e444u, 0xf77cf78au, 0x8573b29cu, 0x92078a5eu, 0x3e76ec28u, 0x33cfcc0du, 0x56cd56b5u, 0x381204cau};
+};
+template <int DW>
+KYB_HD void divmod_z(uint32_t (&q)[8], uint32_t (&rem)[DW], const uint32_t (&k)[8]) {
+    uint32_t d[DW], mr[8];
+#pragma unroll
+    for (int i = 0; i < DW; i++) d[i] = ZDiv<DW>::D[i];
+#pragma unroll
+    for (int i = 0; i < 8; i++) mr[i] = ZDiv<DW>::MR[i];
+    uint32_t acc[17];  // k * m = k * MR + k * 2^256
+#pragma unroll
+    for (int i = 0; i < 17; i++) acc[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint32_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint64_t t = (uint64_t)k[i] * mr[j] + acc[i + j] + carry;  // < 2^64
+            acc[i + j] = (uint32_t)t;
+            carry = (uint32_t)(t >> 32);
+        }
+        acc[i + 8] = carry;
+    }
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[8 + i] = adc32(acc[8 + i], k[i], c);
+    acc[16] = c;
+    constexpr int QW = 9 - DW;  // words of the quotient: k / d < 2^(257 - 32 DW)
+    uint32_t qh[QW];
+#pragma unroll
+    for (int i = 0; i < QW; i++) qh[i] = acc[8 + DW + i];
+    // r = k - qh * d, known to lie in [0, 2 d): DW + 1 words suffice
+    uint32_t pr[DW + 1];
+#pragma unroll
+    for (int i = 0; i <= DW; i++) pr[i] = 0;
+#pragma unroll
+    for (int i = 0; i <= DW && i < QW; i++) {
+        uint32_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < DW && i + j <= DW; j++) {
+            const uint64_t t = (uint64_t)qh[i] * d[j] + pr[i + j] + carry;
+            pr[i + j] = (uint32_t)t;
+            carry = (uint32_t)(t >> 32);
+        }
+        if (i + DW <= DW) pr[i + DW] += carry;  // only i = 0 reaches the top word this way
+    }
     uint32_t r[DW + 1];
+    uint32_t b = 0;
 #pragma unroll
-    for (int i = 0; i <= DW; i++) r[i] = 0;
+    for (int i = 0; i <= DW; i++) r[i] = sbb32(k[i], pr[i], b);
 #pragma unroll
-    for (int i = 0; i < 8; i++) q[i] = 0;
-#pragma unroll 1
-    for (int bit = 255; bit >= 0; bit--) {
-#pragma unroll
-        for (int i = DW; i > 0; i--) r[i] = (r[i] << 1) | (r[i - 1] >> 31);
-        r[0] = (r[0] << 1) | ((k[bit >> 5] >> (bit & 31)) & 1u);
+    for (int it = 0; it < 2; it++) {
         uint32_t t[DW + 1];
-        uint32_t b = 0;
+        b = 0;
 #pragma unroll
         for (int i = 0; i <= DW; i++) t[i] = sbb32(r[i], i < DW ? d[i] : 0u, b);
         const uint32_t ge = b - 1u;  // all ones when r >= d
 #pragma unroll
         for (int i = 0; i <= DW; i++) r[i] = sel32(ge, t[i], r[i]);
-        q[bit >> 5] |= (ge & 1u) << (bit & 31);
+        c = ge & 1u;
+#pragma unroll
+        for (int i = 0; i < QW; i++) {
+            const uint32_t v = qh[i] + c;
+            c = v < c ? 1u : 0u;
+            qh[i] = v;
+        }
     }
+#pragma unroll
+    for (int i = 0; i < 8; i++) q[i] = i < QW ? qh[i] : 0u;
 #pragma unroll
     for (int i = 0; i < DW; i++) rem[i] = r[i];
 }
@@ -445,12 +506,8 @@ KYB_HD_NOINLINE void g1_glv_step(g1_jac& acc, const g1_jac (&tab)[8], int d0, in
 }
 // r = k * P for P in G1: k = k1 z^2 + k0, z^2 P = -phi(P) = (beta x, -y); 34 windows of (4 doublings + 2 additions).
 KYB_HD_NOINLINE void g1_mul_glv(g1_jac& r, const g1_jac& p, const uint32_t (&k)[8]) {
-    constexpr uint32_t Z2[4] = {0x00000000u, 0x00000001u, 0x0001a402u, 0xac45a401u};  // z^2 (CC::X_ABS squared)
     uint32_t q[8], rem[4];
-    uint32_t d[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) d[i] = Z2[i];
-    divmod_u256<4>(q, rem, k, d);
+    divmod_z<4>(q, rem, k);
     int8_t e0[65], e1[65];
     glv_digits(e0, rem, 4);
     glv_digits(e1, q, 5);  // k < 2^256 and z^2 > 2^127: the quotient has at most 129 bits
@@ -471,11 +528,10 @@ KYB_HD_NOINLINE void g1_mul_glv(g1_jac& r, const g1_jac& p, const uint32_t (&k)[
 // k Q = a0 Q - a1 psi(Q) + a2 psi^2(Q) - a3 psi^3(Q); 18 windows of (4 doublings + 4 additions).
 // psi(X, Y, Z) = (cx conj X, cy conj Y, conj Z) on Jacobian coordinates; psi^2 scales X, Y by the norms of cx, cy.
 KYB_HD_NOINLINE void g2_mul_gls(g2_jac& r, const g2_jac& p, const uint32_t (&k)[8]) {
-    uint32_t d[2] = {(uint32_t)CC::X_ABS, (uint32_t)(CC::X_ABS >> 32)};
     uint32_t q1[8], q2[8], q3[8], a0[2], a1[2], a2[2];
-    divmod_u256<2>(q1, a0, k, d);
-    divmod_u256<2>(q2, a1, q1, d);
-    divmod_u256<2>(q3, a2, q2, d);  // q3 = a3 < 2^66
+    divmod_z<2>(q1, a0, k);
+    divmod_z<2>(q2, a1, q1);
+    divmod_z<2>(q3, a2, q2);  // q3 = a3 < 2^66
     int8_t e[4][65];
     glv_digits(e[0], a0, 2);
     glv_digits(e[1], a1, 2);

@@ -150,11 +150,10 @@ __global__ __launch_bounds__(64) void bls12381_lvm_prep_kernel(size_t n, const u
     uint32_t k[8];
     scalar_from_be(k, scalars + 32 * i);
     if constexpr (G2) {
-        uint32_t d[2] = {(uint32_t)CC::X_ABS, (uint32_t)(CC::X_ABS >> 32)};
         uint32_t q1[8], q2[8], q3[8], a0[2], a1[2], a2[2];
-        divmod_u256<2>(q1, a0, k, d);
-        divmod_u256<2>(q2, a1, q1, d);
-        divmod_u256<2>(q3, a2, q2, d);  // q3 = a3 < 2^66
+        divmod_z<2>(q1, a0, k);
+        divmod_z<2>(q2, a1, q1);
+        divmod_z<2>(q3, a2, q2);  // q3 = a3 < 2^66
         uint8_t b[LVM_G2_DSTRIDE];
         const uint32_t s0[3] = {a0[0], a0[1], 0}, s1[3] = {a1[0], a1[1], 0}, s2[3] = {a2[0], a2[1], 0}, s3[3] = {q3[0], q3[1], q3[2]};
         lvm_digits<3>(b, s0, LVM_G2_NPOS, false);
@@ -169,11 +168,8 @@ __global__ __launch_bounds__(64) void bls12381_lvm_prep_kernel(size_t n, const u
             o1[j] = v;
         }
     } else {
-        constexpr uint32_t Z2[4] = {0x00000000u, 0x00000001u, 0x0001a402u, 0xac45a401u};  // z^2
-        uint32_t d[4], q[8], rem[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) d[j] = Z2[j];
-        divmod_u256<4>(q, rem, k, d);  // q < 2^129
+        uint32_t q[8], rem[4];
+        divmod_z<4>(q, rem, k);  // by z^2: q < 2^129
         uint8_t b[LVM_G1_DSTRIDE];
         const uint32_t s0[5] = {rem[0], rem[1], rem[2], rem[3], 0}, s1[5] = {q[0], q[1], q[2], q[3], q[4]};
         lvm_digits<5>(b, s0, LVM_G1_NPOS, false);

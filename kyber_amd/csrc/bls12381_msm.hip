@@ -60,9 +60,8 @@ struct BlsG1Msm : msm::Weierstrass<bls::fp, BlsG1Codec> {
         const int st = Base::decode(a[0], pt, flags);
         uint32_t kk[8], q8[8], rem[4];
         Base::scalar_words(kk, scalar);
-        uint32_t d[4] = {0x00000000u, 0x00000001u, 0x0001a402u, 0xac45a401u};  // z^2
-        bls::divmod_u256<4>(q8, rem, kk, d);
-        const uint32_t Z2[5] = {d[0], d[1], d[2], d[3], 0u};
+        bls::divmod_z<4>(q8, rem, kk);
+        const uint32_t Z2[5] = {bls::ZDiv<4>::D[0], bls::ZDiv<4>::D[1], bls::ZDiv<4>::D[2], bls::ZDiv<4>::D[3], 0u};  // z^2
         const uint32_t HALF[5] = {0x80000000u, 0x00000000u, 0x8000d201u, 0x5622d200u, 0u};  // z^2 / 2
         const uint32_t ONE[5] = {1u, 0u, 0u, 0u, 0u};
         uint32_t q[5] = {q8[0], q8[1], q8[2], q8[3], q8[4]};  // q < 2^129

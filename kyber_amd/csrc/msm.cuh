@@ -64,26 +64,33 @@ inline Plan make_plan(size_t n, int scalar_bits = 256, int cmax = 16) {
     return p;
 }
 
-// signed digit w of k (c-bit windows, digits in [-2^(c-1), 2^(c-1)]), computed independently per window:
-// digit = raw_w + carry_in(w) - (carry_out << c), carry_in(w) = 1 iff the lower part, recoded, overflowed.
-// Sequential recoding is cheap (<= 129 steps), so each lane recodes its whole scalar once.
-template <int MAXWIN>
-__device__ __forceinline__ void recode(int32_t (&dig)[MAXWIN], const uint32_t (&k)[8], int c, int nwin, int bits = 256) {
+// signed digit w of k (c-bit windows, digits in [-2^(c-1), 2^(c-1)]): digit = raw_w + carry_in(w) - (carry_out << c),
+// carry_in(w) = 1 iff the lower part, recoded, overflowed.  Sequential recoding is cheap (<= 129 steps), so each lane
+// recodes its whole scalar once, handing every digit to `emit(w, d)` as it is produced.
+template <class Emit>
+__device__ __forceinline__ void recode_each(const uint32_t (&k)[8], int c, int nwin, int bits, Emit emit) {
     int carry = 0;
     const int half = 1 << (c - 1);
+#pragma unroll 1
     for (int w = 0; w < nwin; w++) {
         const int bit = w * c;
         uint32_t raw = 0;
         if (bit < bits) {
             const int idx = bit >> 5, sh = bit & 31;
-            raw = k[idx] >> sh;
-            if (sh + c > 32 && idx + 1 < 8) raw |= k[idx + 1] << (32 - sh);
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {  // k[idx], k[idx + 1] by selects: a dynamic index would put k in scratch
+                lo = j == idx ? k[j] : lo;
+                hi = j == idx + 1 ? k[j] : hi;
+            }
+            raw = lo >> sh;
+            if (sh + c > 32) raw |= hi << ((32 - sh) & 31);
             raw &= (1u << (bits - bit < c ? bits - bit : c)) - 1;  // the window, clipped at the last bit that counts
         }
         int d = (int)raw + carry;
         carry = d > half ? 1 : 0;
         d -= carry << c;
-        dig[w] = d;
+        emit(w, d);
     }
 }
 
@@ -151,12 +158,9 @@ __global__ __launch_bounds__(64, DecodeWaves<A>::value) void decode_kernel(Plan 
     for (int h = 0; h < S; h++) {
         const size_t e = (size_t)h * n_in + i;
         aff[e] = a[h];
-        int32_t dig[129];
-        recode<129>(dig, k[h], p.c, p.nwin, p.bits);
-        for (int w = 0; w < p.nwin; w++) {
-            const int d = st ? 0 : dig[w];
-            digits[(size_t)w * p.n + e] = d;  // histogrammed per (window, tile) out of LDS: hist_lds_kernel
-        }
+        // the digits go straight to memory as the recoding produces them (a digit array indexed by the window would
+        // live in scratch: 516 B per lane and half); histogrammed per (window, tile) out of LDS: hist_lds_kernel
+        recode_each(k[h], p.c, p.nwin, p.bits, [&](int w, int d) { digits[(size_t)w * p.n + e] = st ? 0 : d; });
     }
 }
 

@@ -97,6 +97,23 @@ int hh_bn_g2_xyzz_sum(int n, const uint8_t* pts, const uint8_t* signs, uint8_t* 
         [](uint8_t* o, const bn::g2_aff& a) { bn::g2_encode(o, a); });
 }
 
+// the endomorphism splits' division by z^2 (dw = 4) or |z| (dw = 2): little-endian words in and out
+void hh_bls_divmod_z(int dw, const uint8_t* k32, uint8_t* q32, uint8_t* rem16) {
+    uint32_t k[8], q[8];
+    memcpy(k, k32, 32);
+    memset(rem16, 0, 16);
+    if (dw == 4) {
+        uint32_t r[4];
+        bls::divmod_z<4>(q, r, k);
+        memcpy(rem16, r, 16);
+    } else {
+        uint32_t r[2];
+        bls::divmod_z<2>(q, r, k);
+        memcpy(rem16, r, 8);
+    }
+    memcpy(q32, q, 32);
+}
+
 // flag-aware variants (KYB_F_UNCOMPRESSED / _OUT / TRUSTED): ints come before the output buffers
 int hh_bls_g1_mul_f(const uint8_t* k, const uint8_t* pt, int flags, uint8_t* out) {
     return bls::g1_mul_wire(out, k, pt, (uint32_t)flags);

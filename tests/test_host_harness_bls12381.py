@@ -284,3 +284,24 @@ def test_xyzz_piece_accumulator_vs_oracle():
             wire = b"".join(comp(p) for p, _ in run) or b"\x00"
             signs = bytes(int(s) for _, s in run) or b"\x00"
             assert H.call(fn, len(run), wire, signs, out_sizes=(size,)) == (0, comp(exp)), (grp, run)
+
+
+def test_endomorphism_split_division_by_reciprocal():
+    """divmod_z (bls12381.cuh): floor(k / d), k mod d for d = z^2 and |z| through the reciprocal 2^256 + MR -- the
+    constants are recomputed here, and the quotient estimate's one-off cases (k just below a multiple of d) are hit."""
+    import re
+    z = 0xD201000000010000
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kyber_amd", "csrc", "bls12381.cuh")).read()
+    for dw, d in ((4, z * z), (2, z)):
+        blk = src[src.index("struct ZDiv<%d>" % dw):]
+        words = lambda name: [int(x, 16) for x in re.findall(r"0x[0-9a-f]+", blk[blk.index(name):blk.index(";", blk.index(name))])]
+        assert sum(w << (32 * i) for i, w in enumerate(words("D["))) == d
+        assert (1 << 256) + sum(w << (32 * i) for i, w in enumerate(words("MR["))) == (1 << (256 + 32 * dw)) // d
+        rng = random.Random(100 + dw)
+        ks = [0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, (1 << 256) - 1, (1 << 255), ((1 << 256) // d) * d - 1, ((1 << 256) // d) * d]
+        ks += [rng.randrange(1 << 256) for _ in range(300)]
+        ks += [min((1 << 256) - 1, rng.randrange(1, (1 << 256) // d) * d + e) for _ in range(150) for e in (-1, 0)]
+        ks += [rng.randrange(1 << b) for b in (1, 31, 32, 33, 64, 127, 128, 129, 192) for _ in range(6)]
+        for k in ks:
+            _, q, rem = H.call("hh_bls_divmod_z", dw, k.to_bytes(32, "little"), out_sizes=(32, 16))
+            assert int.from_bytes(q, "little") == k // d and int.from_bytes(rem, "little") == k % d, (dw, hex(k))
