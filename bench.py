@@ -245,9 +245,10 @@ def _lvm_mads():
 _M, _S = 338, 260
 MADS_G1_UNMARSHAL = (379 * _S + 109 * _M) + 2 * (63 * (2 * _M + 5 * _S) + 5 * (11 * _M + 5 * _S))
 MADS_G2_UNMARSHAL = 2 * (379 * _S + 109 * _M) + 12 * _M + (63 * (2 * 3 + 5 * 2) + 5 * (11 * 3 + 5 * 2)) * _M
-# Pippenger on BLS12-381 G1 at 2^20 points (msm.cuh): 2n half-scalars x 8 windows of 16 bits, one mixed addition
-# (7M + 4S) per (point, window), + the running-sum reduction of 8 x 2^15 buckets (2 full additions each, 11M + 5S)
-MADS_MSM_BLS_G1_2P20_PER_POINT = 2 * 8 * (7 * _M + 4 * _S) + (8 * (1 << 15) * 2 * (11 * _M + 5 * _S)) / (1 << 20)
+# Pippenger on BLS12-381 G1 at 2^20 points (msm.cuh): 2n half-scalars x 8 windows of 16 bits, one mixed addition per
+# (point, window) -- XYZZ form since round 3, 8M + 2S (3 224 multiply-adds; madd-2007-bl, 7M + 4S = 3 406, until then:
+# the numerator FELL with the change) -- + the running-sum reduction of 8 x 2^15 buckets (2 full additions each, 11M + 5S)
+MADS_MSM_BLS_G1_2P20_PER_POINT = 2 * 8 * (8 * _M + 2 * _S) + (8 * (1 << 15) * 2 * (11 * _M + 5 * _S)) / (1 << 20)
 # the best known count for the BLS12-381 pairing on this limb arithmetic: the Karatsuba tower of round 1 (5.4e6 per
 # Pair) against the machine's schoolbook-with-lazy-reduction program; checks / verifies scaled alike
 BLS_PAIR_BEST_KNOWN = 5.4e6

@@ -24,6 +24,7 @@
 //   identity(Acc&), madd(Acc&, const Aff&, bool neg), add(Acc&, const Acc&, const Acc&),
 //   dbl(Acc&, const Acc&), encode(uint8_t*, const Acc&).
 #pragma once
+#include <stdlib.h>
 #include <vector>
 #include "context.h"
 
@@ -301,13 +302,26 @@ static __global__ __launch_bounds__(256) void bucket_offs_kernel(size_t nbk, int
     if (b <= nbk) offs[b] = offs2[b * (size_t)tiles];  // b == nbk: the total (offs2 has one entry past the end)
 }
 
-constexpr int SUB = 64;  // points per accumulate lane: a bucket longer than this is split (skewed digits)
+constexpr int MAXSUB = 256;
+// Points per accumulate lane: a longer bucket is cut into pieces that are joined afterwards (one full addition per
+// extra piece, bucket_kernel).  Twice the mean bucket length, so that only skewed digits split a bucket -- with a fixed
+// 64 every second bucket of the 2^20-point BLS12-381 G1 MSM (mean 64) had a second, tiny piece: 6.10 -> 5.94 ms --
+// between 64 and MAXSUB.  KYB_MSM_SUB overrides (experiments: profiles/r03_msm_knobs.json).
+inline uint32_t piece_len(size_t ne, int nb) {
+    static const int forced = [] {
+        const char* e = getenv("KYB_MSM_SUB");
+        return e ? atoi(e) : 0;
+    }();
+    size_t v = forced > 0 ? (size_t)forced : 2 * (ne / (size_t)nb + 1);
+    v = (v + 31) / 32 * 32;
+    return (uint32_t)(v < 64 ? 64 : (v > MAXSUB ? MAXSUB : v));
+}
 
 constexpr uint32_t LONG_PIECES = 4;  // a bucket of more pieces is joined by a workgroup (tree), not by one lane
 
 // nsub[b] = number of SUB-sized pieces of bucket b; buckets of more than LONG_PIECES pieces (skewed digits: a short top
 // window, equal or small scalars) are appended to longlist (counter in nlong[0]).
-static __global__ __launch_bounds__(256) void subcount_kernel(size_t nbk, const uint32_t* __restrict__ offs,
+static __global__ __launch_bounds__(256) void subcount_kernel(size_t nbk, uint32_t SUB, const uint32_t* __restrict__ offs,
                                                               uint32_t* __restrict__ nsub,
                                                               uint32_t* __restrict__ nlong,
                                                               uint32_t* __restrict__ longlist) {
@@ -320,12 +334,12 @@ static __global__ __launch_bounds__(256) void subcount_kernel(size_t nbk, const 
 
 // Piece t -> (first index into `sorted`, length), plus a histogram of the lengths.  The piece -> bucket map is a
 // binary search in the scanned piece counts.
-static __global__ __launch_bounds__(256) void piece_kernel(size_t nbk, size_t max_pieces, const uint32_t* __restrict__ offs,
+static __global__ __launch_bounds__(256) void piece_kernel(size_t nbk, size_t max_pieces, uint32_t SUB, const uint32_t* __restrict__ offs,
                                                            const uint32_t* __restrict__ suboffs,
                                                            uint32_t* __restrict__ plo, uint32_t* __restrict__ plen,
                                                            uint32_t* __restrict__ lenhist) {
-    __shared__ uint32_t h[SUB + 1];
-    for (int i = threadIdx.x; i <= SUB; i += 256) h[i] = 0;
+    __shared__ uint32_t h[MAXSUB + 1];
+    for (uint32_t i = threadIdx.x; i <= SUB; i += 256) h[i] = 0;
     __syncthreads();
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < max_pieces && t < suboffs[nbk]) {
@@ -344,19 +358,19 @@ static __global__ __launch_bounds__(256) void piece_kernel(size_t nbk, size_t ma
         atomicAdd(&h[SUB - len], 1u);  // bin 0 = longest
     }
     __syncthreads();
-    for (int i = threadIdx.x; i <= SUB; i += 256)
+    for (uint32_t i = threadIdx.x; i <= SUB; i += 256)
         if (h[i]) atomicAdd(&lenhist[i], h[i]);
 }
 // order[] = the pieces sorted by decreasing length (counting sort; ranks within a workgroup come from LDS atomics, one
 // global atomic per length per workgroup reserves the range).
-static __global__ __launch_bounds__(256) void piece_order_kernel(size_t nbk, size_t max_pieces,
+static __global__ __launch_bounds__(256) void piece_order_kernel(size_t nbk, size_t max_pieces, uint32_t SUB,
                                                                  const uint32_t* __restrict__ suboffs,
                                                                  const uint32_t* __restrict__ plen,
                                                                  const uint32_t* __restrict__ lenoffs,
                                                                  uint32_t* __restrict__ lencursor,
                                                                  uint32_t* __restrict__ order) {
-    __shared__ uint32_t h[SUB + 1], base[SUB + 1];
-    for (int i = threadIdx.x; i <= SUB; i += 256) h[i] = 0;
+    __shared__ uint32_t h[MAXSUB + 1], base[MAXSUB + 1];
+    for (uint32_t i = threadIdx.x; i <= SUB; i += 256) h[i] = 0;
     __syncthreads();
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = t < max_pieces && t < suboffs[nbk];
@@ -366,7 +380,7 @@ static __global__ __launch_bounds__(256) void piece_order_kernel(size_t nbk, siz
         rank = atomicAdd(&h[bin], 1u);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i <= SUB; i += 256)
+    for (uint32_t i = threadIdx.x; i <= SUB; i += 256)
         if (h[i]) base[i] = lenoffs[i] + atomicAdd(&lencursor[i], h[i]);
     __syncthreads();
     if (valid) order[base[bin] + rank] = (uint32_t)t;
@@ -638,8 +652,9 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     const size_t m2 = nbk * (size_t)tiles;
     const size_t o_hist = take(sizeof(uint32_t) * m2);
     const size_t o_cursor = take(sizeof(uint32_t) * (m2 + 1));  // offs2: the scanned hist2
-    const size_t o_lenhist = take(sizeof(uint32_t) * (SUB + 2));
-    const size_t o_lencursor = take(sizeof(uint32_t) * (SUB + 2));
+    const uint32_t SUB = piece_len(ne ? ne : 1, p.nb);
+    const size_t o_lenhist = take(sizeof(uint32_t) * (MAXSUB + 2));
+    const size_t o_lencursor = take(sizeof(uint32_t) * (MAXSUB + 2));
     const size_t o_nlong = take(256);
     const size_t o_bad = take(256);
     const size_t zero_end = off;  // lenhist, lencursor, nlong, bad are zeroed together
@@ -699,14 +714,14 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
                        (const uint32_t*)offs2, sorted);
     hipLaunchKernelGGL(bucket_offs_kernel, dim3((unsigned)((nbk + 256) / 256)), dim3(256), 0, st, nbk, tiles,
                        (const uint32_t*)offs2, offs);
-    hipLaunchKernelGGL(subcount_kernel, dim3((unsigned)((nbk + 255) / 256)), dim3(256), 0, st, nbk, offs, nsub, nlong,
+    hipLaunchKernelGGL(subcount_kernel, dim3((unsigned)((nbk + 255) / 256)), dim3(256), 0, st, nbk, SUB, offs, nsub, nlong,
                        longlist);
     launch_scan(nsub, suboffs, nbk, tile, st);
     const unsigned pgrid = (unsigned)((max_pieces + 255) / 256);
-    hipLaunchKernelGGL(piece_kernel, dim3(pgrid), dim3(256), 0, st, nbk, max_pieces, (const uint32_t*)offs,
+    hipLaunchKernelGGL(piece_kernel, dim3(pgrid), dim3(256), 0, st, nbk, max_pieces, SUB, (const uint32_t*)offs,
                        (const uint32_t*)suboffs, plo, plen, lenhist);
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_T), 0, st, lenhist, (size_t)(SUB + 1));
-    hipLaunchKernelGGL(piece_order_kernel, dim3(pgrid), dim3(256), 0, st, nbk, max_pieces, (const uint32_t*)suboffs,
+    hipLaunchKernelGGL(piece_order_kernel, dim3(pgrid), dim3(256), 0, st, nbk, max_pieces, SUB, (const uint32_t*)suboffs,
                        (const uint32_t*)plen, (const uint32_t*)lenhist, lencursor, order);
     hipLaunchKernelGGL(accumulate_kernel<A>, dim3((unsigned)((max_pieces + 63) / 64)), dim3(64), 0, st, nbk, max_pieces, aff,
                        (const uint32_t*)suboffs, (const uint32_t*)order, (const uint32_t*)plo, (const uint32_t*)plen,
