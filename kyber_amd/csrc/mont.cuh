@@ -241,17 +241,17 @@ KYB_HD void fp_finish(Fp<C>& r, uint32_t (&s)[C::N]) {
     }
 }
 
-// r = a * b * R^-1 mod p
+// s = a * b * R^-1 (mod p) on unpacked operands: normalised limbs out (below 2^W each), VALUE BELOW 2p -- not reduced
+// further.  Operands are limbs below 2^W of values with a b < R p (see the lazily reduced sums above: anything
+// below 2p qualifies), so the output of one call is a valid operand of the next: chains of multiplications and
+// squarings (fp_pow_words) stay in this form and skip the pack / conditional subtraction / unpack between links.
 template <class C>
-KYB_HD void fp_mul(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
+KYB_HD void fp_mul_limbs(uint32_t (&s)[C::N], const uint32_t (&al)[C::N], const uint32_t (&bl)[C::N]) {
     constexpr int N = C::N, W = C::W;
     constexpr uint32_t MASK = (1u << W) - 1;
     // products of two W-bit limbs that fit a 64-bit column together with a carry-in
     constexpr int MAXP = (W >= 32) ? 0 : (int)((~0ull) / ((uint64_t)MASK * MASK)) - 1;
     static_assert(MAXP >= 4, "limb width too large for lazy column accumulation");
-    uint32_t al[N], bl[N];
-    fp_unpack<C>(al, a.v);
-    fp_unpack<C>(bl, b.v);
     uint64_t t[N];
 #pragma unroll
     for (int j = 0; j < N; j++) t[j] = 0;
@@ -279,13 +279,20 @@ KYB_HD void fp_mul(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
         t[N - 1] = 0;
         t[0] += carry;
     }
-    uint32_t s[N];
 #pragma unroll
     for (int j = 0; j < N - 1; j++) {
         t[j + 1] += t[j] >> W;
         s[j] = (uint32_t)t[j] & MASK;
     }
     s[N - 1] = (uint32_t)t[N - 1];
+}
+// r = a * b * R^-1 mod p
+template <class C>
+KYB_HD void fp_mul(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
+    uint32_t al[C::N], bl[C::N], s[C::N];
+    fp_unpack<C>(al, a.v);
+    fp_unpack<C>(bl, b.v);
+    fp_mul_limbs<C>(s, al, bl);
     fp_finish<C>(r, s);
 }
 // r = a^2 * R^-1 mod p.  Same interleaved product/reduction walk as fp_mul, but row i only adds
@@ -293,13 +300,11 @@ KYB_HD void fp_mul(Fp<C>& r, const Fp<C>& a, const Fp<C>& b) {
 // (BLS12-381: 260 vs 338).  `cnt` tracks, per window slot, how many 2^(2W)-sized products the
 // column may hold (a doubled product counts twice); all of it folds at compile time after unrolling.
 template <class C>
-KYB_HD void fp_sqr(Fp<C>& r, const Fp<C>& a) {
+KYB_HD void fp_sqr_limbs(uint32_t (&s)[C::N], const uint32_t (&al)[C::N]) {  // limbs in / out as fp_mul_limbs
     constexpr int N = C::N, W = C::W;
     constexpr uint32_t MASK = (1u << W) - 1;
     constexpr int MAXP = (W >= 32) ? 0 : (int)((~0ull) / ((uint64_t)MASK * MASK)) - 1;
     static_assert(MAXP >= 6, "limb width too large for lazy column accumulation");
-    uint32_t al[N];
-    fp_unpack<C>(al, a.v);
     uint64_t t[N];
     int cnt[N];
 #pragma unroll
@@ -343,13 +348,18 @@ KYB_HD void fp_sqr(Fp<C>& r, const Fp<C>& a) {
         t[0] += carry;
         cnt[0] += 1;
     }
-    uint32_t s[N];
 #pragma unroll
     for (int j = 0; j < N - 1; j++) {
         t[j + 1] += t[j] >> W;
         s[j] = (uint32_t)t[j] & MASK;
     }
     s[N - 1] = (uint32_t)t[N - 1];
+}
+template <class C>
+KYB_HD void fp_sqr(Fp<C>& r, const Fp<C>& a) {
+    uint32_t al[C::N], s[C::N];
+    fp_unpack<C>(al, a.v);
+    fp_sqr_limbs<C>(s, al);
     fp_finish<C>(r, s);
 }
 
@@ -364,28 +374,46 @@ KYB_HD void fp_mul3(Fp<C>& r, const Fp<C>& a) {
 // r = a^e for a public exponent held as NW little-endian 32-bit words.  Fixed 4-bit windows: nbits squarings +
 // nbits/4 + 14 multiplications (the square roots' exponents have about half their bits set: ~nbits/2 with plain
 // square-and-multiply).  The exponent is the same in every lane, so the table index and the branches are uniform.
+// The whole chain runs on unpacked limbs (fp_mul_limbs / fp_sqr_limbs: values below 2p, table entries included):
+// one unpack at the start, one pack + conditional subtraction at the end instead of one of each per link -- 80 of a
+// squaring's 512 instructions, 106 of a multiplication's 539 (BLS12-381).
 template <class C>
 KYB_HD_NOINLINE void fp_pow_words(Fp<C>& r, const Fp<C>& a, const uint32_t* e, int nbits) {
-    Fp<C> tab[15];  // a^1 .. a^15
-    tab[0] = a;
+    constexpr int N = C::N;
+    struct L {
+        uint32_t l[N];
+    };
+    L tab[15];  // a^1 .. a^15
+    fp_unpack<C>(tab[0].l, a.v);
 #pragma unroll 1
-    for (int j = 1; j < 15; j++) fp_mul(tab[j], tab[j - 1], a);
-    Fp<C> acc;
-    fp_one(acc);
+    for (int j = 1; j < 15; j++) fp_mul_limbs<C>(tab[j].l, tab[j - 1].l, tab[0].l);
+    L acc;
+    bool one = true;  // the accumulator is still 1 (uniform: the exponent is public)
     const int top = (nbits + 3) / 4 - 1;
 #pragma unroll 1
     for (int w = top; w >= 0; w--) {
-        if (w != top) {
-            fp_sqr(acc, acc);
-            fp_sqr(acc, acc);
-            fp_sqr(acc, acc);
-            fp_sqr(acc, acc);
+        if (!one) {
+            fp_sqr_limbs<C>(acc.l, acc.l);
+            fp_sqr_limbs<C>(acc.l, acc.l);
+            fp_sqr_limbs<C>(acc.l, acc.l);
+            fp_sqr_limbs<C>(acc.l, acc.l);
         }
         const int bit = 4 * w;
         const uint32_t nib = (e[bit >> 5] >> (bit & 31)) & 15u;  // windows are nibble-aligned: never straddle a word
-        if (nib) fp_mul(acc, acc, tab[nib - 1]);
+        if (nib) {
+            if (one) {
+                acc = tab[nib - 1];
+                one = false;
+            } else {
+                fp_mul_limbs<C>(acc.l, acc.l, tab[nib - 1].l);
+            }
+        }
     }
-    r = acc;
+    if (one) {
+        fp_one(r);
+        return;
+    }
+    fp_finish<C>(r, acc.l);
 }
 template <class C>
 KYB_HD void fp_inv_fermat(Fp<C>& r, const Fp<C>& a) {  // a^(p-2); inv(0) = 0.  (fp_inv below is ~4x cheaper.)
