@@ -496,11 +496,11 @@ KYB_HD_NOINLINE void g1_glv_step(g1_jac& acc, const g1_jac (&tab)[8], int d0, in
         for (int i = 0; i < 4; i++) jac_dbl_inl(x, x);
     }
     jac_select8(t, tab, d0);
-    jac_add_inl(s, x, t);
+    jac_madd_inl(s, x, t.X, t.Y, jac_is_inf(t));  // the table is affine (jac_table8_to_affine)
     jac_cmov(x, s, d0 != 0);
     jac_select8(t, tab, -d1);  // -y
     fp_mul(t.X, t.X, beta);
-    jac_add_inl(s, x, t);
+    jac_madd_inl(s, x, t.X, t.Y, jac_is_inf(t));
     jac_cmov(x, s, d1 != 0);
     acc = x;
 }
@@ -516,6 +516,7 @@ KYB_HD_NOINLINE void g1_mul_glv(g1_jac& r, const g1_jac& p, const uint32_t (&k)[
     jac_dbl(tab[1], p);
 #pragma unroll 1
     for (int j = 2; j < 8; j++) jac_add(tab[j], tab[j - 1], p);
+    jac_table8_to_affine(tab);
     fp beta;
     fp_const(beta, CC::BETA);
     g1_jac acc;
@@ -526,7 +527,7 @@ KYB_HD_NOINLINE void g1_mul_glv(g1_jac& r, const g1_jac& p, const uint32_t (&k)[
 }
 // r = k * Q for Q in G2: k = a0 + a1 |z| + a2 |z|^2 + a3 |z|^3 and |z| Q = -psi(Q), so
 // k Q = a0 Q - a1 psi(Q) + a2 psi^2(Q) - a3 psi^3(Q); 18 windows of (4 doublings + 4 additions).
-// psi(X, Y, Z) = (cx conj X, cy conj Y, conj Z) on Jacobian coordinates; psi^2 scales X, Y by the norms of cx, cy.
+// psi(x, y) = (cx conj x, cy conj y) on the affine table entries; psi^2 scales x, y by the norms of cx, cy.
 KYB_HD_NOINLINE void g2_mul_gls(g2_jac& r, const g2_jac& p, const uint32_t (&k)[8]) {
     uint32_t q1[8], q2[8], q3[8], a0[2], a1[2], a2[2];
     divmod_z<2>(q1, a0, k);
@@ -542,6 +543,7 @@ KYB_HD_NOINLINE void g2_mul_gls(g2_jac& r, const g2_jac& p, const uint32_t (&k)[
     jac_dbl(tab[1], p);
 #pragma unroll 1
     for (int j = 2; j < 8; j++) jac_add(tab[j], tab[j - 1], p);
+    jac_table8_to_affine(tab);  // psi^j acts on the affine entry; the 72 table additions are mixed additions
     fp2 cx, cy, cx3, cy3, t2;
     fp nx, ny, u;
     fp2_load_const<TC>(cx, CC::PSI_CX);
@@ -561,7 +563,7 @@ KYB_HD_NOINLINE void g2_mul_gls(g2_jac& r, const g2_jac& p, const uint32_t (&k)[
         if (i != 17) jac_dbl_n(acc, acc, 4);
         // a0 Q
         jac_select8(t, tab, e[0][i]);
-        jac_add(s, acc, t);
+        jac_madd(s, acc, t.X, t.Y, jac_is_inf(t));
         jac_cmov(acc, s, e[0][i] != 0);
         // -a1 psi(Q)
         jac_select8(t, tab, -e[1][i]);
@@ -569,14 +571,13 @@ KYB_HD_NOINLINE void g2_mul_gls(g2_jac& r, const g2_jac& p, const uint32_t (&k)[
         fp2_mul_c(t.X, t2, cx);
         fp2_conj(t2, t.Y);
         fp2_mul_c(t.Y, t2, cy);
-        fp2_conj(t.Z, t.Z);
-        jac_add(s, acc, t);
+        jac_madd(s, acc, t.X, t.Y, jac_is_inf(t));
         jac_cmov(acc, s, e[1][i] != 0);
         // a2 psi^2(Q)
         jac_select8(t, tab, e[2][i]);
         fp2_mul_fp(t.X, t.X, nx);
         fp2_mul_fp(t.Y, t.Y, ny);
-        jac_add(s, acc, t);
+        jac_madd(s, acc, t.X, t.Y, jac_is_inf(t));
         jac_cmov(acc, s, e[2][i] != 0);
         // -a3 psi^3(Q)
         jac_select8(t, tab, -e[3][i]);
@@ -584,8 +585,7 @@ KYB_HD_NOINLINE void g2_mul_gls(g2_jac& r, const g2_jac& p, const uint32_t (&k)[
         fp2_mul_c(t.X, t2, cx3);
         fp2_conj(t2, t.Y);
         fp2_mul_c(t.Y, t2, cy3);
-        fp2_conj(t.Z, t.Z);
-        jac_add(s, acc, t);
+        jac_madd(s, acc, t.X, t.Y, jac_is_inf(t));
         jac_cmov(acc, s, e[3][i] != 0);
     }
     r = acc;

@@ -188,22 +188,6 @@ KYB_HD void jac_select8(Jac<F>& t, const Jac<F> (&tab)[8], int d) {
     f_neg(ny, t.Y);
     f_cmov(t.Y, ny, d < 0);
 }
-// One window of a fixed-window scalar multiplication in ONE out-of-line call: acc = 16 acc (when dbl) + d P.
-// The accumulator stays in registers through the four doublings, the addition and the select that keeps or drops
-// it; as separate calls it crossed the call boundary (scratch) after each of them.
-template <class F>
-KYB_HD_NOINLINE void jac_window_step(Jac<F>& acc, const Jac<F> (&tab)[8], int d, bool dbl) {
-    Jac<F> x = acc, t, s;
-    if (dbl) {  // uniform across the grid
-#pragma unroll 1
-        for (int i = 0; i < 4; i++) jac_dbl_inl(x, x);
-    }
-    jac_select8(t, tab, d);
-    jac_add_inl(s, x, t);
-    jac_cmov(x, s, d != 0);
-    acc = x;
-}
-
 // Mixed addition r = p + (x2, y2) with the second operand affine (madd-2007-bl, 7M + 4S), exceptional
 // cases handled: p at infinity, q at infinity (q_inf), p = q (doubling), p = -q (infinity).
 template <class F>
@@ -255,6 +239,57 @@ KYB_HD void jac_madd_inl(Jac<F>& r, const Jac<F>& p, const F& x2, const F& y2, b
 template <class F>
 KYB_HD_NOINLINE void jac_madd(Jac<F>& r, const Jac<F>& p, const F& x2, const F& y2, bool q_inf) {
     jac_madd_inl(r, p, x2, y2, q_inf);
+}
+
+// The eight-entry window table tab[j] = (j + 1) P of the fixed-window ladders, brought to AFFINE form in place (Z = 1;
+// an entry at infinity keeps Z = 0) with ONE shared inversion (Montgomery's trick: 21 multiplications + the
+// inversion + 4 per entry): every table addition of the ladder is then a mixed addition, 7M + 4S instead of
+// 11M + 5S -- 64 to 72 additions per scalar multiplication against ~95 multiplication-equivalents for the conversion.
+// (Inlined into the ladder that owns the table: as an out-of-line function writing the caller's private array through
+// the reference, the gfx950 build faulted with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION -- every ladder, both
+// fields, ROCm 7.2; the same body inlined, or the same call with the body compiled out, runs.)
+template <class F>
+KYB_HD void jac_table8_to_affine(Jac<F> (&tab)[8]) {
+    F c[8], one, inv, zi, zi2;
+    f_one(one);
+    uint32_t infm = 0;
+#pragma unroll 1
+    for (int j = 0; j < 8; j++) {
+        const bool z0 = f_is_zero(tab[j].Z);
+        infm |= (z0 ? 1u : 0u) << j;
+        f_cmov(tab[j].Z, one, z0);  // a placeholder keeps the running product invertible
+        if (j == 0) c[0] = tab[0].Z;
+        else f_mul(c[j], c[j - 1], tab[j].Z);
+    }
+    f_inv(inv, c[7]);
+#pragma unroll 1
+    for (int j = 7; j >= 0; j--) {
+        if (j > 0) {
+            f_mul(zi, inv, c[j - 1]);      // 1 / Z_j
+            f_mul(inv, inv, tab[j].Z);     // 1 / (Z_0 ... Z_{j-1})
+        } else {
+            zi = inv;
+        }
+        f_sqr(zi2, zi);
+        f_mul(tab[j].X, tab[j].X, zi2);
+        f_mul(zi2, zi2, zi);
+        f_mul(tab[j].Y, tab[j].Y, zi2);
+        tab[j].Z = one;
+        if ((infm >> j) & 1u) f_zero(tab[j].Z);
+    }
+}
+// One window against an affine table (jac_table8_to_affine): acc = 16 acc (when dbl) + d P, in one out-of-line call.
+template <class F>
+KYB_HD_NOINLINE void jac_window_step_aff(Jac<F>& acc, const Jac<F> (&tab)[8], int d, bool dbl) {
+    Jac<F> x = acc, t, s;
+    if (dbl) {  // uniform across the grid
+#pragma unroll 1
+        for (int i = 0; i < 4; i++) jac_dbl_inl(x, x);
+    }
+    jac_select8(t, tab, d);
+    jac_madd_inl(s, x, t.X, t.Y, jac_is_inf(t));
+    jac_cmov(x, s, d != 0);
+    acc = x;
 }
 
 // Extended Jacobian ("XYZZ") accumulator for RUNS of mixed additions (the MSM's bucket pieces): x = X / ZZ,
@@ -345,12 +380,13 @@ KYB_HD_NOINLINE void jac_mul_u256(Jac<F>& r, const Jac<F>& p, const uint32_t (&k
     jac_dbl(tab[1], p);
 #pragma unroll 1
     for (int j = 2; j < 8; j++) jac_add(tab[j], tab[j - 1], p);
+    jac_table8_to_affine(tab);
     int8_t e[65];
     recode16_u256(e, k);
     Jac<F> acc;
     jac_set_inf(acc);
 #pragma unroll 1
-    for (int i = 64; i >= 0; i--) jac_window_step(acc, tab, e[i], i != 64);
+    for (int i = 64; i >= 0; i--) jac_window_step_aff(acc, tab, e[i], i != 64);
     r = acc;
 }
 // Short public multiplier (e.g. the curve parameter |x|), MSB-first double-and-add; uniform.
