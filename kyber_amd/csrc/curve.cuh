@@ -129,7 +129,9 @@ KYB_HD_NOINLINE void jac_dbl_n(Jac<F>& r, const Jac<F>& p, int n) {
 }
 
 // add-2007-bl with the exceptional cases handled (either operand infinity, P = Q, P = -Q).
-template <class F>
+// (CALL_DBL = false inlines the doubling of the P = Q case too: a kernel without any out-of-line callee keeps its own
+// register budget -- the cooperative tail kernels of the MSM)
+template <class F, bool CALL_DBL = true>
 KYB_HD void jac_add_inl(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
     const bool pinf = jac_is_inf(p), qinf = jac_is_inf(q);
     F Z1Z1, Z2Z2, U1, U2, S1, S2, H, I, J, rr, V, t;
@@ -145,7 +147,8 @@ KYB_HD void jac_add_inl(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
     f_sub(rr, S2, S1);
     if (!pinf && !qinf && f_is_zero(H)) {  // same x: doubling or cancellation (rare; divergence is fine)
         if (f_is_zero(rr)) {
-            jac_dbl(r, p);
+            if constexpr (CALL_DBL) jac_dbl(r, p);
+            else jac_dbl_inl(r, p);
         } else {
             jac_set_inf(r);
         }

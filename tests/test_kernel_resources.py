@@ -52,6 +52,9 @@ def test_tuned_kernels_keep_their_register_budget():
     # two waves per SIMD: <= 256
     assert find(msm, "13decode_kernel", "BlsG1Msm") <= 256
     assert find(msm, "17accumulate_kernel", "BlsG1Msm") <= 256
+    # the cooperative tail (four lanes per point): twice the lanes of the one-lane kernels, so two waves per SIMD
+    assert find(msm, "18reduce_coop_kernel", "BlsG1Msm") <= 256
+    assert find(msm, "21tree_fold_coop_kernel", "BlsG1Msm") <= 256
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-readelf")), reason="no llvm-readelf")
