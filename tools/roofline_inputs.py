@@ -3,7 +3,8 @@
 tools/rocpd_summary.py turns the rocpd databases into text): VALU-busy and HBM traffic per launch of the dominant
 kernels, the numbers bench.py quotes next to its live timings.
 
-usage: tools/roofline_inputs.py profiles r02_final
+usage: tools/roofline_inputs.py profiles r02_final [prefix=tag ...]   (e.g. msm_bls=r03_close2: that prefix's files
+come from another evidence run -- kernels re-profiled after the main run)
 
 Reading the counters (profiles/README.md): SQ_* are quad-cycles summed over all waves, GRBM_GUI_ACTIVE is cycles summed
 over the 8 XCDs, FETCH_SIZE / WRITE_SIZE are KiB (FETCH_SIZE may under-count wide coalesced reads 2x on gfx950,
@@ -14,6 +15,7 @@ import re
 import sys
 
 d, tag = sys.argv[1], sys.argv[2]
+tag_of = dict(a.split("=", 1) for a in sys.argv[3:])
 
 
 def counters(path):
@@ -35,6 +37,7 @@ def kernel(cs, sub):
 
 
 def entry(prefix, sub, units):
+    tag = tag_of.get(prefix, sys.argv[2])
     sq = kernel(counters(os.path.join(d, f"{tag}_{prefix}_sq.txt")), sub)
     fe = kernel(counters(os.path.join(d, f"{tag}_{prefix}_fetch.txt")), sub)
     wr = kernel(counters(os.path.join(d, f"{tag}_{prefix}_write.txt")), sub)
