@@ -550,7 +550,7 @@ __global__ __launch_bounds__(64) void tree_fold_kernel(int nwin, int nin, const 
 // ---- The tail on cooperating lanes (adapters with COOP_SLOTS: the Weierstrass curves, msm_ws.cuh) ------------------
 // Four lanes per point, coordinates and temporaries in LDS slots, a barrier between the product levels of a formula:
 // an addition of the running sums is 5 multiplications deep instead of 16, a doubling 3 instead of 7.  The two
-// kernels below replace reduce_kernel / tree_fold_kernel for those adapters (0.82 -> 0.69 ms and 0.41 -> 0.24 ms at
+// kernels below replace reduce_kernel / tree_fold_kernel for those adapters (0.82 -> 0.55 ms and 0.41 -> 0.16 ms at
 // 2^20 points; the final kernel keeps its three-lane register formulation, which is faster than slots for a lone
 // chain of doublings).
 template <class A, class = void>
@@ -581,30 +581,47 @@ __global__ __launch_bounds__(64, 2) void reduce_coop_kernel(Plan p, const typena
     const typename A::Acc* bw = buckets + w * p.nb;
     A::slot_load(S, RUN, bw + lo + p.chunk - 1, r);
     A::slot_load(S, TOT, bw + lo + p.chunk - 1, r);
-    __syncthreads();
-#pragma unroll 1
-    for (int b = lo + p.chunk - 2; b >= lo; b--) {
-        A::slot_load(S, BK, bw + b, r);
-        __syncthreads();
-        A::coop_add(S, fl, r, RUN, BK, T, true);
-        A::coop_add(S, fl, r, TOT, RUN, T, true);
-    }
-    // tot = sum (b - lo + 1) B_b ; add lo * run, lo = ch * chunk: double-and-add over the bits of ch (the additions a
-    // group does not want are computed and dropped; bit positions no group of the workgroup wants are skipped), then
-    // log2(chunk) doublings
     A::slot_identity(S, M, r);
     __syncthreads();
-    int chbits = 0;
+    // One loop over the chunk's whole schedule, so that the addition and the doubling are inlined once each:
+    //   steps [0, 2 (chunk - 1)):  run += B_b ; tot += run            (b from the chunk's top bucket down)
+    //   then per bit of ch, from the top: m = 2 m ; m += run if the bit is set   (lo * run, lo = ch * chunk: the
+    //     additions a group does not want are computed and dropped; bit positions no group of the workgroup wants
+    //     are skipped), log2(chunk) more doublings, and tot += m.
+    int chbits = 0, tz = 0;
     while ((1 << chbits) < p.nchunks) chbits++;
+    while ((1 << tz) < p.chunk) tz++;
+    const int nsum = 2 * (p.chunk - 1), nmul = 2 * chbits + tz, nsteps = nsum + nmul + 1;
 #pragma unroll 1
-    for (int bit = chbits - 1; bit >= 0; bit--) {
-        A::coop_dbl_slots(S, r, M, T, true);
-        const bool want = ((ch >> bit) & 1) != 0;
-        if (__syncthreads_or(want ? 1 : 0)) A::coop_add(S, fl, r, M, RUN, T, want);
+    for (int s = 0; s < nsteps; s++) {
+        bool is_dbl = false, commit = true, skip = false;
+        int P = TOT, Q = M;
+        if (s < nsum) {
+            if ((s & 1) == 0) {
+                A::slot_load(S, BK, bw + (lo + p.chunk - 2 - (s >> 1)), r);
+                __syncthreads();
+                P = RUN;
+                Q = BK;
+            } else {
+                P = TOT;
+                Q = RUN;
+            }
+        } else if (s < nsum + 2 * chbits) {
+            const int k = s - nsum, bit = chbits - 1 - (k >> 1);
+            if ((k & 1) == 0) {
+                is_dbl = true;
+            } else {
+                commit = ((ch >> bit) & 1) != 0;
+                skip = !__syncthreads_or(commit ? 1 : 0);
+                P = M;
+                Q = RUN;
+            }
+        } else if (s < nsum + nmul) {
+            is_dbl = true;
+        }
+        if (is_dbl) A::coop_dbl_slots(S, r, M, T, true);
+        else if (!skip) A::coop_add(S, fl, r, P, Q, T, commit);
     }
-#pragma unroll 1
-    for (int k = 1; k < p.chunk; k <<= 1) A::coop_dbl_slots(S, r, M, T, true);
-    A::coop_add(S, fl, r, TOT, M, T, true);
     if (live) A::slot_store(partial + t, S, TOT, r);
 }
 
@@ -843,6 +860,8 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
             }
             // (the final kernel stays the three-lane register version: its slot-based counterpart measured 0.91 ms
             // against 0.78 for the 112 doublings of the 2^20-point G1 MSM)
+            // (the final kernel stays the three-lane register version: a slot-based one measured 5.48 against 5.39 ms
+            // for the whole 2^20-point MSM -- a lone chain of doublings gains nothing from slots)
             const unsigned final_t = (unsigned)((p.nwin * Coop<A>::value + 63) / 64 * 64);
             hipLaunchKernelGGL(final_kernel<A>, dim3(1), dim3(final_t), 0, st, pr, cur, winsum, bad, (uint8_t*)d_out);
             KYB_HIP_CHECK(hipGetLastError());

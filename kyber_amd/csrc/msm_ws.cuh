@@ -8,6 +8,13 @@
 namespace kyb {
 namespace msm {
 
+// the one-lane addition behind the cooperative routine's rare case (equal x), out of line under a name of its own: only
+// kernels with the cooperative tail's two-wave budget reach it, so it is compiled for that budget
+template <class F>
+KYB_HD_NOINLINE void jac_add_rare(Jac<F>& r, const Jac<F>& p, const Jac<F>& q) {
+    jac_add_inl<F, false>(r, p, q);
+}
+
 template <class T>
 struct IsFp2 {
     static constexpr bool value = false;
@@ -110,9 +117,7 @@ struct Weierstrass {
     // workgroup barrier separates the levels.  A Jacobian addition is 5 product levels deep (17 products) instead of
     // 16 multiplications, a doubling 3 instead of 7.  All lanes of the block run the same levels; what a group keeps is
     // decided at the commit (`commit`: predicated steps of a double-and-add, dead groups of a fold).
-    // (G1 only: the Fp2 instantiation of the reduce kernel hung on the GPU -- not understood, not shipped; the G2 MSMs
-    // keep the one-lane tail)
-    static constexpr int COOP_SLOTS = IsFp2<F>::value ? 0 : 1, COOP_TEMPS = 10;
+    static constexpr int COOP_SLOTS = 1, COOP_TEMPS = 10;
     struct alignas(16) Slot {
         F f;
     };
@@ -134,7 +139,9 @@ struct Weierstrass {
     // P += Q (slots P..P+2, Q..Q+2 = X, Y, Z; temporaries T..T+9; fl = two flag words of the group).  add-2007-bl with
     // Z3 = 2 Z1 Z2 H as a product; infinity operands and equal x are settled at the commit (the latter by lane 0 running
     // the one-lane routine on the untouched operands).  Six barriers.
-    __device__ static void coop_add(Slot* S, uint32_t* fl, int r, int P, int Q, int T, bool commit) {
+    // (Both routines are force-inlined into ONE call site per kernel: as out-of-line functions they took the slots
+    // through a generic pointer and every LDS access became a flat_load / flat_store.)
+    __device__ __forceinline__ static void coop_add(Slot* S, uint32_t* fl, int r, int P, int Q, int T, bool commit) {
         F a, b, m, d, d2;
         a = S[sel4(r, P + 2, Q + 2, P + 1, Q + 1)].f;
         b = S[sel4(r, P + 2, Q + 2, Q + 2, P + 2)].f;
@@ -203,7 +210,7 @@ struct Weierstrass {
                     Acc p, q;
                     p.X = S[P].f; p.Y = S[P + 1].f; p.Z = S[P + 2].f;
                     q.X = S[Q].f; q.Y = S[Q + 1].f; q.Z = S[Q + 2].f;
-                    jac_add_inl<F, false>(p, p, q);
+                    jac_add_rare(p, p, q);
                     S[P].f = p.X; S[P + 1].f = p.Y; S[P + 2].f = p.Z;
                 }
             } else {
@@ -220,7 +227,7 @@ struct Weierstrass {
         __syncthreads();
     }
     // P = 2 P (dbl-2009-l, three barriers; infinity and Y = 0 give Z = 0 by the formulas)
-    __device__ static void coop_dbl_slots(Slot* S, int r, int P, int T, bool commit) {
+    __device__ __forceinline__ static void coop_dbl_slots(Slot* S, int r, int P, int T, bool commit) {
         F a, b, x, t1, t2, m;
         a = S[sel4(r, P, P + 1, P + 1, P + 1)].f;
         b = S[sel4(r, P, P + 1, P + 2, P + 2)].f;
