@@ -2,7 +2,7 @@
 # Closing check of round 3's second session: all GPU tests, smoke, the default bench line, and fresh trace + PMC passes
 # of what changed since r03_final (the MSM pipeline, the per-lane ladders).  Every step under its own timeout.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-O=gpurun_out/r03_close2; mkdir -p $O; export TMPDIR=/tmp
+O=gpurun_out/${CLOSE_TAG:-r03_close2}; mkdir -p $O; export TMPDIR=/tmp
 timeout 300 python -m pytest tests -m gpu -q --timeout 60 > $O/pytest_gpu.log 2>&1; echo "rc=$?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
 timeout 120 python -c "
 import sys, os; sys.path.insert(0, os.getcwd())
