@@ -11,12 +11,14 @@
 //                 recodes scalar i into signed c-bit digits and histograms them per (window, |digit|)
 //   2 scan      : exclusive prefix sum of the histogram -> start offset of every bucket
 //   3 scatter   : counting sort of point indices (sign in bit 31) by (window, bucket)
-//   4 accumulate: one lane per bucket piece (<= 64 points; long buckets from skewed digits are split)
-//                 adds its points with mixed additions, then one lane per bucket joins the pieces
-//   5 reduce    : per window, chunks of buckets -> sum_b b * B_b by running sums, one lane per chunk
-//   6 fold+final: chunk partials are folded 32 at a time, then one lane per window sums what is left and
-//                 shifts by 2^(c w); lane 0 adds the windows
-//                 and encodes.  If any input failed to decode the output is all-zero bytes.
+//   4 accumulate: one lane per bucket piece (at most twice the mean bucket length; long buckets from skewed digits are
+//                 split) adds its points with mixed additions -- in XYZZ form on the Weierstrass curves -- then one
+//                 lane per bucket joins the pieces
+//   5 reduce    : per window, chunks of buckets -> sum_b b * B_b by running sums; Weierstrass curves: FOUR lanes per
+//                 chunk cooperating through LDS slots (reduce_coop_kernel), others: one lane per chunk
+//   6 fold+final: chunk partials are folded 32 / 64 at a time as trees, then the window sums are shifted by 2^(c w)
+//                 (3 - 4 lanes per point share the products of a doubling), added and encoded.  If any input failed to
+//                 decode the output is all-zero bytes.
 // Sorting instead of atomics on ~150-byte points: the only atomics are 32-bit counters.
 //
 // Adapter A: typename Aff (decoded input), Acc (accumulator); WIRE (input bytes), OUT (output bytes);
