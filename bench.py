@@ -249,6 +249,9 @@ MADS_G2_UNMARSHAL = 2 * (379 * _S + 109 * _M) + 12 * _M + (63 * (2 * 3 + 5 * 2) 
 # (point, window) -- XYZZ form since round 3, 8M + 2S (3 224 multiply-adds; madd-2007-bl, 7M + 4S = 3 406, until then:
 # the numerator FELL with the change) -- + the running-sum reduction of 8 x 2^15 buckets (2 full additions each, 11M + 5S)
 MADS_MSM_BLS_G1_2P20_PER_POINT = 2 * 8 * (8 * _M + 2 * _S) + (8 * (1 << 15) * 2 * (11 * _M + 5 * _S)) / (1 << 20)
+# share.PriPoly.Commit through the fixed-base table (fixed_base.cuh): 33 XYZZ additions (8M + 2S), leaving the form
+# (2M), to affine (1S + 3M; the division-step inversion is ~25 batches of ~130 multiply-adds)
+MADS_G1_COMMIT = 33 * (8 * _M + 2 * _S) + 5 * _M + _S + 25 * 130
 # the best known count for the BLS12-381 pairing on this limb arithmetic: the Karatsuba tower of round 1 (5.4e6 per
 # Pair) against the machine's schoolbook-with-lazy-reduction program; checks / verifies scaled alike
 BLS_PAIR_BEST_KNOWN = 5.4e6
@@ -426,6 +429,22 @@ def other_workloads(rank, world, dist):
                                            "matches_sum_ki_hi_times_G": same, "scaling": "strong",
                                            "roofline": _roof(n / float(t[2].item()) * 1e3, MADS_MSM_BLS_G1_2P20_PER_POINT, 32 + 96, prof, "bls12381_g1_msm"),
                                            "exchange": "all-gather of %d encoded partial points" % world if dist else "none"}
+            # share.PriPoly.Commit (share/poly.go:143-149): the same n coefficients times ONE base -- an arbitrary
+            # point of the group, unmarshalled by the call like any base -- through the fixed-base table
+            # (kyber_amd/csrc/fixed_base.cuh: 33 table additions per coefficient, no doublings); checked against the
+            # variable-base kernels on a sample; weak scaling like every independent batch
+            cb = torch.from_numpy(np.asarray(m.g1_commit((0x1234567).to_bytes(32, "big"))[0])[0].copy()).cuda()
+            fn_c = lambda: m.g1_commit(ks, cb)
+            ms_c = timed(fn_c)
+            nchk = min(4096, int(ks.shape[0]))
+            ok_c = bool(torch.equal(fn_c()[0][:nchk], m.g1_batch_mul(ks[:nchk], cb.repeat(nchk, 1))[0]))
+            tc = torch.tensor([ms_c], dtype=torch.float64, device="cuda")
+            if dist:
+                dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+            out["bls12381_g1_commit_2p20"] = {"coefficients": n, "seconds": float(tc[0].item()) * 1e-3,
+                                              "commits_per_s": n / float(tc[0].item()) * 1e3,
+                                              "matches_variable_base_kernels": ok_c, "scaling": "strong",
+                                              "roofline": _roof(n / float(tc[0].item()) * 1e3, MADS_G1_COMMIT, 32 + 48, prof, "bls12381_g1_commit")}
             del ks, hs, pts, pts_u
     # Ed25519 MSM at 2^20 points (PubPoly.Eval / RecoverCommit shape), sharded like the BLS one
     from kyber_amd.group import edwards25519 as ed

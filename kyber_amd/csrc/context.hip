@@ -47,7 +47,8 @@ int get_ctx(DeviceCtx** out) {
     return KYB_OK;
 }
 
-int ctx_workspace(DeviceCtx* ctx, int kind, hipStream_t stream, size_t bytes, void** out) {
+int ctx_workspace(DeviceCtx* ctx, int kind, hipStream_t stream, size_t bytes, void** out, bool* grew) {
+    if (grew) *grew = false;
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceCtx::StreamBuf& b = ctx->sws[std::make_pair(kind, stream)];
     if (bytes > b.cap) {
@@ -63,6 +64,7 @@ int ctx_workspace(DeviceCtx* ctx, int kind, hipStream_t stream, size_t bytes, vo
             return KYB_E_ALLOC;
         }
         b.cap = want;
+        if (grew) *grew = true;
     }
     *out = b.p;
     return KYB_OK;

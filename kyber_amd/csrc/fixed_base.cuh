@@ -1,0 +1,235 @@
+// Fixed-base scalar multiplication for the same-base batches of the pairing suites: out_i = k_i * P for ONE point P and
+// many scalars -- share.PriPoly.Commit (share/poly.go:143-149: every coefficient times the same base), key generation
+// (x * G2.Base()), `Point.Mul(s, nil)`.  The reference runs its variable-base ladder n times; with the base shared, a
+// table of its multiples turns a multiplication into 33 table additions and NO doublings:
+//
+//   k = sum_w d_w 256^w, signed digits d_w in [-128, 128] (w = 0..32, the last one the recoding's carry), and
+//   T[w][j] = (j + 1) 256^w P in affine form (128 entries per window), so  k P = sum_w sign(d_w) T[w][|d_w| - 1]:
+//   33 mixed additions in XYZZ form (curve.cuh, 8M + 2S each) + one inversion, about a fifth of the GLV ladder's field
+//   multiplications and an eighth of the plain ladder's (bn256 G2).  No endomorphism is involved, so the result is the
+//   integer multiple for EVERY decodable base (bn256's G2 points outside the order-n subgroup included) and every
+//   256-bit scalar, like the reference's double-and-add.
+//
+// The table costs a chain of 256 dependent doublings (one lane: ~2.5 ms on G1, three times that on G2) + 33 x 128
+// independent small multiples: it pays for itself from ~2^17 scalars, or at any batch size once it exists -- the
+// workspace keeps the last base's table per (suite, group, stream), and the chain kernel recognises the base on the
+// device (no host round trip).  Table: 33 x 128 x (2 field elements) = 405 KB (BLS12-381 G1) .. 811 KB (G2): L2-resident.
+#pragma once
+#include "curve.cuh"
+#if defined(__HIPCC__)
+#include "context.h"
+#endif
+
+namespace kyb {
+namespace fb {
+
+constexpr int NWIN = 33, NENT = 128, WIRE_MAX = 192;
+constexpr uint64_t MAGIC = 0x6b79626662763031ull;  // "kybfbv01"
+
+// head of the workspace: which base the table below belongs to
+struct Header {
+    uint64_t magic;
+    uint32_t key_flags;   // the decode-relevant flag bits the base was decoded under
+    uint32_t key_len;     // bytes of its wire form
+    uint32_t status;      // UnmarshalBinary's verdict on it (ST_OK = 0)
+    uint32_t inf;         // it is the point at infinity
+    uint32_t fresh;       // set by the chain kernel of THIS call: the table has to be rebuilt
+    uint32_t pad;
+    uint8_t key[WIRE_MAX];
+};
+
+template <class F>
+struct Entry {  // affine multiple; (0, 0) -- not a point of y^2 = x^3 + b, b != 0 -- stands for infinity
+    F x, y;
+};
+
+// signed radix-256 digits of a 256-bit integer (eight little-endian words): d[0..32] in [-128, 128]
+KYB_HD void digits256(int (&d)[NWIN], const uint32_t (&k)[8]) {
+    int carry = 0;
+#pragma unroll
+    for (int w = 0; w < 32; w++) {
+        int v = (int)((k[w >> 2] >> ((w & 3) * 8)) & 0xffu) + carry;
+        carry = v > 128 ? 1 : 0;
+        d[w] = v - (carry << 8);
+    }
+    d[32] = carry;
+}
+
+// q[w] = 256^w P  (Jacobian): the one serial part of the table
+template <class F>
+KYB_HD void chain(Jac<F> (&q)[NWIN], const Aff<F>& base) {
+    jac_from_aff(q[0], base);
+#pragma unroll 1
+    for (int w = 1; w < NWIN; w++) {
+        Jac<F> t = q[w - 1];
+#pragma unroll 1
+        for (int i = 0; i < 8; i++) jac_dbl_inl(t, t);
+        q[w] = t;
+    }
+}
+
+// e = (j + 1) Q in affine form, j in [0, 128)
+template <class F>
+KYB_HD void entry(Entry<F>& e, const Jac<F>& q, int j) {
+    const int m = j + 1;  // 1 .. 128
+    Jac<F> acc;
+    jac_set_inf(acc);
+#pragma unroll 1
+    for (int bit = 7; bit >= 0; bit--) {
+        jac_dbl_inl(acc, acc);
+        if ((m >> bit) & 1) jac_add_inl<F, false>(acc, acc, q);
+    }
+    Aff<F> a;
+    jac_to_aff(a, acc);
+    e.x = a.x;
+    e.y = a.y;
+    if (a.inf) {
+        f_zero(e.x);
+        f_zero(e.y);
+    }
+}
+
+// r = k * P from P's table (tab[w * NENT + j]); r comes back in Jacobian form
+template <class F>
+KYB_HD void mul(Jac<F>& r, const uint32_t (&k)[8], const Entry<F>* __restrict__ tab) {
+    Xyzz<F> acc;
+    xyzz_set_inf(acc);
+    int carry = 0;
+#pragma unroll 1
+    for (int w = 0; w < NWIN; w++) {
+        // the digits of digits256, produced as the walk needs them
+        const int v = (w < 32 ? (int)((k[w >> 2] >> ((w & 3) * 8)) & 0xffu) : 0) + carry;
+        carry = v > 128 ? 1 : 0;
+        const int dw = v - (carry << 8);
+        if (dw == 0) continue;
+        const int a = dw < 0 ? -dw : dw;
+        const Entry<F> e = tab[w * NENT + (a - 1)];
+        if (f_is_zero(e.x) & f_is_zero(e.y)) continue;  // that multiple of the base is the point at infinity
+        F y = e.y, ny;
+        f_neg(ny, e.y);
+        f_cmov(y, ny, dw < 0);
+        xyzz_madd(acc, e.x, y);
+    }
+    xyzz_to_jac(r, acc);
+}
+
+
+#if defined(__HIPCC__)
+// ---- kernels and the enqueue routine, over a per-(suite, group) traits type T:
+//   F; decode(Aff<F>&, wire, flags) -> status; encode(out, Aff<F>, flags); wire_size(flags); out_size(flags);
+//   scalar(k[8], wire32); KIND (workspace kind); KEY_FLAGS (the flag bits decode() looks at)
+constexpr size_t HDR_BYTES = 512;
+template <class T>
+constexpr size_t chain_bytes() { return ((sizeof(Jac<typename T::F>) * NWIN + 255) / 256) * 256; }
+template <class T>
+constexpr size_t ws_bytes() { return HDR_BYTES + chain_bytes<T>() + sizeof(Entry<typename T::F>) * NWIN * NENT; }
+
+// One lane: is the table already this base's?  Otherwise decode the base and walk the doubling chain.
+template <class T>
+__global__ __launch_bounds__(64) void chain_kernel(uint8_t* __restrict__ ws, const uint8_t* __restrict__ base, uint32_t flags) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    using F = typename T::F;
+    Header* h = reinterpret_cast<Header*>(ws);
+    const uint32_t kf = flags & T::KEY_FLAGS, len = (uint32_t)T::wire_size(flags);
+    bool same = h->magic == MAGIC && h->key_flags == kf && h->key_len == len;
+    for (uint32_t i = 0; i < len && same; i++) same = h->key[i] == base[i];
+    if (same) {
+        h->fresh = 0;
+        return;
+    }
+    h->magic = 0;
+    Aff<F> a;
+    const int st = T::decode(a, base, flags);
+    h->status = (uint32_t)st;
+    h->inf = (st == 0 && a.inf) ? 1u : 0u;
+    h->key_flags = kf;
+    h->key_len = len;
+    for (uint32_t i = 0; i < len; i++) h->key[i] = base[i];
+    h->fresh = 1;
+    if (st == 0 && !a.inf) {
+        Jac<F>* q = reinterpret_cast<Jac<F>*>(ws + HDR_BYTES);
+        Jac<F> t;
+        jac_from_aff(t, a);
+        q[0] = t;
+#pragma unroll 1
+        for (int w = 1; w < NWIN; w++) {
+#pragma unroll 1
+            for (int i = 0; i < 8; i++) jac_dbl_inl(t, t);
+            q[w] = t;
+        }
+    }
+    __threadfence();
+    h->magic = MAGIC;
+}
+// One lane per table entry
+template <class T>
+__global__ __launch_bounds__(64) void table_kernel(uint8_t* __restrict__ ws) {
+    using F = typename T::F;
+    const Header* h = reinterpret_cast<const Header*>(ws);
+    if (!h->fresh || h->status || h->inf) return;
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= NWIN * NENT) return;
+    const int w = t / NENT, j = t - w * NENT;
+    const Jac<F> q = reinterpret_cast<const Jac<F>*>(ws + HDR_BYTES)[w];
+    Entry<F> e;
+    entry(e, q, j);
+    reinterpret_cast<Entry<F>*>(ws + HDR_BYTES + chain_bytes<T>())[t] = e;
+}
+// One lane per scalar
+template <class T>
+__global__ __launch_bounds__(64, 2) void mul_kernel(size_t n, const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ ws,
+                                                    uint8_t* __restrict__ out, uint8_t* __restrict__ status, uint32_t flags) {
+    using F = typename T::F;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const Header* h = reinterpret_cast<const Header*>(ws);
+    const size_t osz = T::out_size(flags);
+    uint8_t* o = out + osz * idx;
+    const uint32_t st = h->status;
+    if (st) {  // the reference's UnmarshalBinary fails once, for every coefficient
+        uint32_t* q = reinterpret_cast<uint32_t*>(o);
+        for (size_t i = 0; i < osz / 4; i++) q[i] = 0;
+        if (status) status[idx] = (uint8_t)st;
+        return;
+    }
+    Aff<F> a;
+    if (h->inf) {
+        f_zero(a.x);
+        f_zero(a.y);
+        a.inf = true;
+    } else {
+        uint32_t k[8];
+        T::scalar(k, scalars + 32 * idx);
+        Jac<F> r;
+        mul(r, k, reinterpret_cast<const Entry<F>*>(ws + HDR_BYTES + chain_bytes<T>()));
+        jac_to_aff(a, r);
+    }
+    T::encode(o, a, flags);
+    if (status) status[idx] = 0;
+}
+
+// Enqueue chain (if the base changed) + table + multiplication on `st`
+template <class T>
+int run(size_t n, const void* d_scalars, const void* d_base, void* d_out, void* d_status, uint32_t flags, hipStream_t st) {
+    DeviceCtx* ctx;
+    if (int rc = get_ctx(&ctx)) return rc;
+    std::lock_guard<std::recursive_mutex> enq_lock(ctx->enq_mu);
+    void* ws;
+    bool grew = false;
+    if (int rc = ctx_workspace(ctx, T::KIND, st, ws_bytes<T>(), &ws, &grew)) return rc;
+    if (grew) KYB_HIP_CHECK(hipMemsetAsync(ws, 0, HDR_BYTES, st));
+    hipLaunchKernelGGL(chain_kernel<T>, dim3(1), dim3(64), 0, st, (uint8_t*)ws, (const uint8_t*)d_base, flags);
+    hipLaunchKernelGGL(table_kernel<T>, dim3((NWIN * NENT + 63) / 64), dim3(64), 0, st, (uint8_t*)ws);
+    hipLaunchKernelGGL(mul_kernel<T>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, (const uint8_t*)d_scalars,
+                       (const uint8_t*)ws, (uint8_t*)d_out, (uint8_t*)d_status, flags);
+    if (hipGetLastError() != hipSuccess) {
+        hipMemsetAsync(ws, 0, HDR_BYTES, st);  // never trust a half-built table
+        set_error("fixed-base multiplication: launch failed");
+        return KYB_E_HIP;
+    }
+    return KYB_OK;
+}
+#endif  // __HIPCC__
+
+}  // namespace fb
+}  // namespace kyb

@@ -7,10 +7,43 @@
 #pragma once
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <string>
+
 #include "context.h"
+#include "fixed_base.cuh"
 
 namespace kyb {
 static inline unsigned grid_for(size_t n, int block) { return (unsigned)((n + block - 1) / block); }
+
+// ---- same-base batches: when does the fixed-base table (fixed_base.cuh) take over?
+constexpr int fb_suite_id(const char* pfx) { return (pfx[0] == 'b' && pfx[1] == 'l') ? 0 : (pfx[4] == '6' ? 1 : 2); }
+// from this many scalars a table is worth building for an unknown base (KYB_FB_MIN overrides both; 0 disables the path)
+static inline size_t fb_min_batch(bool g2) {
+    static const long forced = [] {
+        const char* e = getenv("KYB_FB_MIN");
+        return e ? atol(e) : -1L;
+    }();
+    if (forced == 0) return ~size_t(0);
+    if (forced > 0) return (size_t)forced;
+    (void)g2;
+    return size_t(1) << 17;  // measured break-even, table build included: ~1e5 (G1) / ~0.5e5-0.9e5 (G2) scalars
+}
+constexpr size_t FB_MIN_KNOWN = 64;  // ... and from this many when the table is (about to be) there anyway
+// What the HOST-buffer entry points know about the table on (device, kind, null stream): the wire bytes of the base
+// it was last built for.  A hint only -- the chain kernel decides on the device.
+static inline bool fb_host_known(int kind, const std::string& key, bool remember) {
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, std::string> last;
+    int dev = 0;
+    hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    std::string& k = last[std::make_pair(dev, kind)];
+    const bool hit = k == key;
+    if (remember) k = key;
+    return hit;
+}
 
 // Host entry points stage through the per-device pool of context.h (StageScope / StageBuf).
 }  // namespace kyb
@@ -31,6 +64,38 @@ static inline unsigned grid_for(size_t n, int block) { return (unsigned)((n + bl
 #endif
 #define KYB_DEFINE_MUL_ABI(PFX, NS, G1SZ, G2SZ) \
 namespace kyb { \
+struct PFX##_FbG1 { \
+    using F = NS::fp; \
+    static constexpr int KIND = WS_FB + 2 * fb_suite_id(#PFX); \
+    static constexpr uint32_t KEY_FLAGS = KYB_F_UNCOMPRESSED | KYB_F_TRUSTED(0); \
+    __host__ __device__ static int decode(Aff<F>& a, const uint8_t* in, uint32_t flags) { return NS::g1_decode_f(a, in, flags, 0); } \
+    __host__ __device__ static void encode(uint8_t* out, const Aff<F>& a, uint32_t flags) { NS::g1_encode_f(out, a, flags); } \
+    __host__ __device__ static size_t wire_size(uint32_t flags) { return NS::g1_wire_size(flags); } \
+    __host__ __device__ static size_t out_size(uint32_t flags) { return NS::g1_out_size(flags); } \
+    __host__ __device__ static void scalar(uint32_t (&k)[8], const uint8_t* in) { NS::scalar_from_be(k, in); } \
+    static void generator(Aff<F>& a) { NS::fp_const(a.x, NS::CC::G1X); NS::fp_const(a.y, NS::CC::G1Y); a.inf = false; } \
+}; \
+struct PFX##_FbG2 { \
+    using F = NS::fp2; \
+    static constexpr int KIND = WS_FB + 2 * fb_suite_id(#PFX) + 1; \
+    static constexpr uint32_t KEY_FLAGS = KYB_F_UNCOMPRESSED | KYB_F_TRUSTED(0); \
+    __host__ __device__ static int decode(Aff<F>& a, const uint8_t* in, uint32_t flags) { return NS::g2_decode_f(a, in, flags, 0); } \
+    __host__ __device__ static void encode(uint8_t* out, const Aff<F>& a, uint32_t flags) { NS::g2_encode_f(out, a, flags); } \
+    __host__ __device__ static size_t wire_size(uint32_t flags) { return NS::g2_wire_size(flags); } \
+    __host__ __device__ static size_t out_size(uint32_t flags) { return NS::g2_out_size(flags); } \
+    __host__ __device__ static void scalar(uint32_t (&k)[8], const uint8_t* in) { NS::scalar_from_be(k, in); } \
+    static void generator(Aff<F>& a) { fp2_load_const<NS::TC>(a.x, NS::CC::G2X); fp2_load_const<NS::TC>(a.y, NS::CC::G2Y); a.inf = false; } \
+}; \
+/* the suite generator's wire form under `flags` (host side): a same-base batch over it is worth a table at any size */ \
+template <class T> \
+static std::string PFX##_fb_generator_key(uint32_t flags) { \
+    Aff<typename T::F> g; \
+    T::generator(g); \
+    uint8_t buf[fb::WIRE_MAX]; \
+    /* the INPUT form the flags select: compressed unless KYB_F_UNCOMPRESSED */ \
+    T::encode(buf, g, (flags & KYB_F_UNCOMPRESSED) ? KYB_F_UNCOMPRESSED_OUT : 0u); \
+    return std::string((const char*)buf, T::wire_size(flags)); \
+} \
 __global__ __launch_bounds__(64, KYB_G1_MUL_WAVES) void PFX##_g1_mul_kernel(size_t n, const uint8_t* __restrict__ scalars, \
                                                         const uint8_t* __restrict__ pts, size_t pt_stride, \
                                                         uint8_t* __restrict__ out, uint8_t* __restrict__ status, \
@@ -93,6 +158,8 @@ int kyb_##PFX##_g1_mul_dev(size_t n, const void* d_scalars, const void* d_points
         return KYB_E_ARG; \
     } \
     if (!n) return KYB_OK; \
+    if (point_stride == 0 && n >= kyb::fb_min_batch(false)) /* one base, many scalars: fixed_base.cuh */ \
+        return kyb::fb::run<kyb::PFX##_FbG1>(n, d_scalars, d_points, d_out, d_status, flags, (hipStream_t)stream); \
     const uint8_t* only = nullptr; \
     KYB_TRY(kyb::NS::lvm_mul(false, n, (const uint8_t*)d_scalars, (const uint8_t*)d_points, point_stride, (uint8_t*)d_out, \
                              (uint8_t*)d_status, flags, (hipStream_t)stream, &only)); \
@@ -110,6 +177,8 @@ int kyb_##PFX##_g2_mul_dev(size_t n, const void* d_scalars, const void* d_points
         return KYB_E_ARG; \
     } \
     if (!n) return KYB_OK; \
+    if (point_stride == 0 && n >= kyb::fb_min_batch(true)) \
+        return kyb::fb::run<kyb::PFX##_FbG2>(n, d_scalars, d_points, d_out, d_status, flags, (hipStream_t)stream); \
     const uint8_t* only = nullptr; \
     KYB_TRY(kyb::NS::lvm_mul(true, n, (const uint8_t*)d_scalars, (const uint8_t*)d_points, point_stride, (uint8_t*)d_out, \
                              (uint8_t*)d_status, flags, (hipStream_t)stream, &only)); \
@@ -143,6 +212,31 @@ static int PFX##_mul_host(bool g2, size_t n, const uint8_t* scalars, const uint8
     KYB_TRY(p.upload(points, (stride ? n : 1) * isz)); \
     KYB_TRY(o.alloc(n * psz)); \
     KYB_TRY(st.alloc(n)); \
+    if (!stride && kyb::fb_min_batch(g2) != ~size_t(0)) { \
+        /* same base: the fixed-base table takes the batch when it is large, or from FB_MIN_KNOWN scalars when the \
+           table is there already (the base of the previous such call on this device) or is the suite's generator */ \
+        const int kind = g2 ? kyb::PFX##_FbG2::KIND : kyb::PFX##_FbG1::KIND; \
+        std::string key((const char*)points, isz); \
+        key.push_back((char)(flags & 0xff)); \
+        key.push_back((char)((flags >> 8) & 0xff)); \
+        bool use = n >= kyb::fb_min_batch(g2); \
+        if (!use && n >= kyb::FB_MIN_KNOWN) { \
+            use = kyb::fb_host_known(kind, key, false); \
+            if (!use) { \
+                std::string gk = g2 ? kyb::PFX##_fb_generator_key<kyb::PFX##_FbG2>(flags) \
+                                    : kyb::PFX##_fb_generator_key<kyb::PFX##_FbG1>(flags); \
+                use = gk.size() == isz && memcmp(gk.data(), points, isz) == 0; \
+            } \
+        } \
+        if (use) { \
+            kyb::fb_host_known(kind, key, true); \
+            KYB_TRY(g2 ? (kyb::fb::run<kyb::PFX##_FbG2>(n, s.p, p.p, o.p, st.p, flags, nullptr)) \
+                       : (kyb::fb::run<kyb::PFX##_FbG1>(n, s.p, p.p, o.p, st.p, flags, nullptr))); \
+            KYB_TRY(o.download(out, n * psz)); \
+            if (status) KYB_TRY(st.download(status, n)); \
+            return KYB_OK; \
+        } \
+    } \
     if (!stride && n >= (size_t(1) << 18) && !(flags & KYB_F_TRUSTED(0)) && (!g2 || kyb::NS::g2_decode_proves_subgroup())) { \
         /* one shared base and MANY coefficients (PriPoly.Commit): UnmarshalBinary's checks run once, in one lane, and \
            the lanes take the point as validated.  A lone lane needs as long for them (~2 ms on BLS12-381 G1) as a full \

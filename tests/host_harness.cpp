@@ -10,6 +10,8 @@
 #include "../kyber_amd/csrc/bn254.cuh"
 #include "../kyber_amd/csrc/bn256.cuh"
 #include "../kyber_amd/csrc/ed25519_h2c.cuh"
+#include "../kyber_amd/csrc/fixed_base.cuh"
+#include <vector>
 
 using namespace kyb;
 
@@ -36,6 +38,37 @@ static int xyzz_sum(int n, const uint8_t* pts, int wire, const uint8_t* signs, u
     jac_to_aff(r, j);
     enc(out, r);
     return bad;
+}
+
+// Fixed-base multiplication (fixed_base.cuh): table of the base built on the host, nk scalars multiplied through it.
+template <class F, class AffT, class Dec, class Enc>
+static int fb_mul_host(const uint8_t* base, int nk, const uint8_t* scalars_be, uint8_t* out, int osz, Dec dec, Enc enc) {
+    AffT b;
+    const int st = dec(b, base);
+    if (st) return st;
+    std::vector<fb::Entry<F>> tab((size_t)fb::NWIN * fb::NENT);
+    if (!b.inf) {
+        Jac<F> q[fb::NWIN];
+        fb::chain(q, b);
+        for (int w = 0; w < fb::NWIN; w++)
+            for (int j = 0; j < fb::NENT; j++) fb::entry(tab[(size_t)w * fb::NENT + j], q[w], j);
+    }
+    for (int i = 0; i < nk; i++) {
+        uint32_t k[8];
+        words_from_be<8>(k, scalars_be + 32 * i);
+        AffT a;
+        if (b.inf) {
+            f_zero(a.x);
+            f_zero(a.y);
+            a.inf = true;
+        } else {
+            Jac<F> r;
+            fb::mul(r, k, tab.data());
+            jac_to_aff(a, r);
+        }
+        enc(out + (size_t)osz * i, a);
+    }
+    return 0;
 }
 
 extern "C" {
@@ -112,6 +145,27 @@ void hh_bls_divmod_z(int dw, const uint8_t* k32, uint8_t* q32, uint8_t* rem16) {
         memcpy(rem16, r, 8);
     }
     memcpy(q32, q, 32);
+}
+
+int hh_bls_g1_fb_mul(const uint8_t* base, int nk, const uint8_t* ks, uint8_t* out) {
+    return fb_mul_host<bls::fp, bls::g1_aff>(base, nk, ks, out, 48,
+        [](bls::g1_aff& a, const uint8_t* in) { return bls::g1_decode(a, in, true); },
+        [](uint8_t* o, const bls::g1_aff& a) { bls::g1_encode(o, a); });
+}
+int hh_bls_g2_fb_mul(const uint8_t* base, int nk, const uint8_t* ks, uint8_t* out) {
+    return fb_mul_host<bls::fp2, bls::g2_aff>(base, nk, ks, out, 96,
+        [](bls::g2_aff& a, const uint8_t* in) { return bls::g2_decode(a, in, true); },
+        [](uint8_t* o, const bls::g2_aff& a) { bls::g2_encode(o, a); });
+}
+int hh_bn_g1_fb_mul(const uint8_t* base, int nk, const uint8_t* ks, uint8_t* out) {
+    return fb_mul_host<bn::fp, bn::g1_aff>(base, nk, ks, out, 64,
+        [](bn::g1_aff& a, const uint8_t* in) { return bn::g1_decode(a, in); },
+        [](uint8_t* o, const bn::g1_aff& a) { bn::g1_encode(o, a); });
+}
+int hh_bn_g2_fb_mul(const uint8_t* base, int nk, const uint8_t* ks, uint8_t* out) {
+    return fb_mul_host<bn::fp2, bn::g2_aff>(base, nk, ks, out, 128,
+        [](bn::g2_aff& a, const uint8_t* in) { return bn::g2_decode(a, in, true); },
+        [](uint8_t* o, const bn::g2_aff& a) { bn::g2_encode(o, a); });
 }
 
 // flag-aware variants (KYB_F_UNCOMPRESSED / _OUT / TRUSTED): ints come before the output buffers

@@ -305,3 +305,27 @@ def test_endomorphism_split_division_by_reciprocal():
         for k in ks:
             _, q, rem = H.call("hh_bls_divmod_z", dw, k.to_bytes(32, "little"), out_sizes=(32, 16))
             assert int.from_bytes(q, "little") == k // d and int.from_bytes(rem, "little") == k % d, (dw, hex(k))
+
+
+def _fb_scalars(rng, order):
+    ks = [0, 1, 2, 127, 128, 129, 255, 256, 257, order - 1, order, order + 1, (1 << 256) - 1, 1 << 255,
+          int.from_bytes(b"\x80" * 32, "big"), int.from_bytes(b"\x81" * 32, "big"), int.from_bytes(b"\x7f" * 32, "big")]
+    return ks + [rng.randrange(1 << 256) for _ in range(12)] + [rng.randrange(order) for _ in range(8)]
+
+
+def test_fixed_base_table_multiplication_vs_oracle():
+    """fixed_base.cuh: k P from the table of P's multiples (33 signed radix-256 digits, XYZZ additions) on G1 and G2 --
+    digit boundaries (127 / 128 / 129 bytes: the recoding's carries), scalars at and above the order, the infinity base."""
+    rng = random.Random(77)
+    ks = _fb_scalars(rng, O.R)
+    kb = b"".join(k.to_bytes(32, "big") for k in ks)
+    for grp in (1, 2):
+        gen, mul, comp, size, fn = ((O.G1_GEN, O.g1_mul, O.g1_compress, 48, "hh_bls_g1_fb_mul") if grp == 1 else
+                                    (O.G2_GEN, O.g2_mul, O.g2_compress, 96, "hh_bls_g2_fb_mul"))
+        P = mul(rng.randrange(1, O.R), gen)
+        st, out = H.call(fn, comp(P), len(ks), kb, out_sizes=(size * len(ks),))
+        assert st == 0
+        for i, k in enumerate(ks):
+            assert out[size * i:size * i + size] == comp(mul(k % O.R, P)), (grp, hex(k))
+        st, out = H.call(fn, comp(None), 3, kb[:96], out_sizes=(size * 3,))
+        assert st == 0 and out == comp(None) * 3

@@ -172,3 +172,36 @@ def test_xyzz_piece_accumulator_vs_oracle():
             wire = b"".join(mar(p) for p, _ in run) or b"\x00"
             signs = bytes(int(s) for _, s in run) or b"\x00"
             assert H.call(fn, len(run), wire, signs, out_sizes=(size,)) == (0, mar(exp)), (grp, run)
+
+
+def test_fixed_base_table_multiplication_vs_oracle():
+    """fixed_base.cuh on bn256: G1, and G2 with a base OUTSIDE the order-n subgroup (the reference accepts it and its
+    double-and-add multiplies by the plain integer): a twist point of order 13 n makes table entries hit infinity."""
+    import random
+    rng = random.Random(78)
+    n = O.ORDER
+    ks = [0, 1, 2, 13, 26, 127, 128, 129, 255, 256, 257, n - 1, n, n + 1, (1 << 256) - 1, 1 << 255, 13 * n, 13 * n - 1,
+          int.from_bytes(b"\x80" * 32, "big"), int.from_bytes(b"\x81" * 32, "big")] + [rng.randrange(1 << 256) for _ in range(12)]
+    ks = [k % (1 << 256) for k in ks]
+    kb = b"".join(k.to_bytes(32, "big") for k in ks)
+    P = O.g1_mul(rng.randrange(1, n), O.G1_GEN)
+    st, out = H.call("hh_bn_g1_fb_mul", O.g1_marshal(P), len(ks), kb, out_sizes=(64 * len(ks),))
+    assert st == 0
+    for i, k in enumerate(ks):
+        assert out[64 * i:64 * i + 64] == O.g1_marshal(O.g1_mul(k, P)), hex(k)
+    # a twist point with a component of order 13: cofactor 2p - n = 13 * 7369 * ...
+    cof = 2 * O.P - n
+    while True:
+        x = (rng.randrange(O.P), rng.randrange(O.P))
+        y = O.f2_sqrt(O.f2_add(O.f2_mul(O.f2_sqr(x), x), O.TWIST_B)) if hasattr(O, "f2_sqrt") else None
+        if y is None:
+            continue
+        T = (x, y)
+        T13 = O.g2_mul(cof // 13 * n, T)  # order 1 or 13
+        if T13 is not None:
+            break
+    for Q in (O.g2_mul(rng.randrange(1, n), O.G2_GEN), T13, O.g2_add(T13, O.g2_mul(5, O.G2_GEN))):
+        st, out = H.call("hh_bn_g2_fb_mul", O.g2_marshal(Q), len(ks), kb, out_sizes=(128 * len(ks),))
+        assert st == 0
+        for i, k in enumerate(ks):
+            assert out[128 * i:128 * i + 128] == O.g2_marshal(O.g2_mul(k, Q)), hex(k)
