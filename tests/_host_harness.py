@@ -29,7 +29,7 @@ def lib():
         fresh = os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read().strip() == digest
         if not fresh:
             os.makedirs(os.path.dirname(OUT), exist_ok=True)
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", OUT, SRC])
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-shared", "-fPIC", "-o", OUT, SRC])
             with open(stamp, "w") as f:
                 f.write(digest)
         _lib = C.CDLL(OUT)
@@ -46,7 +46,7 @@ def lib_audit():
     if _lib_audit is None:
         out = OUT.replace("libhostharness.so", "libhostharness_audit.so")
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-DKYB_FE_AUDIT", "-shared", "-fPIC", "-o", out, SRC])
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-DKYB_FE_AUDIT", "-shared", "-fPIC", "-o", out, SRC])
         _lib_audit = C.CDLL(out)
     return _lib_audit
 

@@ -11,6 +11,9 @@
 #include "../kyber_amd/csrc/bn256.cuh"
 #include "../kyber_amd/csrc/ed25519_h2c.cuh"
 #include "../kyber_amd/csrc/fixed_base.cuh"
+#include "../kyber_amd/csrc/coop_slots.cuh"
+#include <pthread.h>
+#include <thread>
 #include <vector>
 
 using namespace kyb;
@@ -67,6 +70,60 @@ static int fb_mul_host(const uint8_t* base, int nk, const uint8_t* scalars_be, u
             jac_to_aff(a, r);
         }
         enc(out + (size_t)osz * i, a);
+    }
+    return 0;
+}
+
+// ---- The MSM's cooperative slot arithmetic (coop_slots.cuh) with four threads as the four lanes of a group and a
+// pthread barrier as the workgroup barrier.
+static pthread_barrier_t g_coop_barrier;
+namespace kyb {
+void coop_host_sync() { pthread_barrier_wait(&g_coop_barrier); }
+}
+// ops: a string of steps over three points in slots -- P (0..2) = first input, Q (3..5) = second input:
+//   'a' P += Q ; 'n' P += Q computed and NOT committed ; 'd' P = 2 P ; 'x' P = 2 P not committed ; 's' swap roles (Q += P)
+template <class F, class AffT, class Dec, class Enc>
+static int coop_run(const char* ops, const uint8_t* pa, const uint8_t* pb, int wire, uint8_t* out, Dec dec, Enc enc) {
+    AffT a, b;
+    if (dec(a, pa) || dec(b, pb)) return 1;
+    constexpr int P = 0, Q = 3, T = 6, NS = T + coop::TEMPS;
+    static coop::Slot<F> S[NS];
+    static uint32_t fl[2];
+    Jac<F> ja, jb;
+    jac_from_aff(ja, a);
+    jac_from_aff(jb, b);
+    // scale the inputs to general Jacobian form so that Z != 1 paths are exercised: (X l^2, Y l^3, Z l)
+    F l, l2, l3;
+    f_one(l);
+    f_add(l, l, l);
+    f_add(l2, l, l);  // l = 2, l2 = 4 (Montgomery form of small integers via additions of one)
+    f_add(l3, l2, l2);
+    f_mul(ja.X, ja.X, l2);
+    f_mul(ja.Y, ja.Y, l3);
+    f_mul(ja.Z, ja.Z, l);
+    S[P].f = ja.X; S[P + 1].f = ja.Y; S[P + 2].f = ja.Z;
+    S[Q].f = jb.X; S[Q + 1].f = jb.Y; S[Q + 2].f = jb.Z;
+    pthread_barrier_init(&g_coop_barrier, nullptr, 4);
+    std::thread th[4];
+    for (int r = 0; r < 4; r++)
+        th[r] = std::thread([=]() {
+            for (const char* o = ops; *o; o++) {
+                if (*o == 'a') coop::add<F>(S, fl, r, P, Q, T, true);
+                else if (*o == 'n') coop::add<F>(S, fl, r, P, Q, T, false);
+                else if (*o == 's') coop::add<F>(S, fl, r, Q, P, T, true);
+                else if (*o == 'd') coop::dbl<F>(S, r, P, T, true);
+                else if (*o == 'x') coop::dbl<F>(S, r, P, T, false);
+            }
+        });
+    for (int r = 0; r < 4; r++) th[r].join();
+    pthread_barrier_destroy(&g_coop_barrier);
+    for (int which = 0; which < 2; which++) {
+        Jac<F> j;
+        const int base = which ? Q : P;
+        j.X = S[base].f; j.Y = S[base + 1].f; j.Z = S[base + 2].f;
+        AffT r;
+        jac_to_aff(r, j);
+        enc(out + (size_t)wire * which, r);
     }
     return 0;
 }
@@ -166,6 +223,22 @@ int hh_bn_g2_fb_mul(const uint8_t* base, int nk, const uint8_t* ks, uint8_t* out
     return fb_mul_host<bn::fp2, bn::g2_aff>(base, nk, ks, out, 128,
         [](bn::g2_aff& a, const uint8_t* in) { return bn::g2_decode(a, in, true); },
         [](uint8_t* o, const bn::g2_aff& a) { bn::g2_encode(o, a); });
+}
+
+int hh_bls_g1_coop(const uint8_t* ops, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    return coop_run<bls::fp, bls::g1_aff>((const char*)ops, a, b, 48, out,
+        [](bls::g1_aff& p, const uint8_t* in) { return bls::g1_decode(p, in, false); },
+        [](uint8_t* o, const bls::g1_aff& p) { bls::g1_encode(o, p); });
+}
+int hh_bls_g2_coop(const uint8_t* ops, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    return coop_run<bls::fp2, bls::g2_aff>((const char*)ops, a, b, 96, out,
+        [](bls::g2_aff& p, const uint8_t* in) { return bls::g2_decode(p, in, false); },
+        [](uint8_t* o, const bls::g2_aff& p) { bls::g2_encode(o, p); });
+}
+int hh_bn_g1_coop(const uint8_t* ops, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    return coop_run<bn::fp, bn::g1_aff>((const char*)ops, a, b, 64, out,
+        [](bn::g1_aff& p, const uint8_t* in) { return bn::g1_decode(p, in); },
+        [](uint8_t* o, const bn::g1_aff& p) { bn::g1_encode(o, p); });
 }
 
 // flag-aware variants (KYB_F_UNCOMPRESSED / _OUT / TRUSTED): ints come before the output buffers

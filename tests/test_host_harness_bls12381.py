@@ -329,3 +329,29 @@ def test_fixed_base_table_multiplication_vs_oracle():
             assert out[size * i:size * i + size] == comp(mul(k % O.R, P)), (grp, hex(k))
         st, out = H.call(fn, comp(None), 3, kb[:96], out_sizes=(size * 3,))
         assert st == 0 and out == comp(None) * 3
+
+
+def test_cooperative_slot_arithmetic_with_threads_as_lanes():
+    """coop_slots.cuh -- the MSM's reduce / fold additions on four lanes per point through LDS slots -- run on the CPU
+    with four threads as the lanes and a pthread barrier as the workgroup barrier: the slot schedule of the addition
+    (5 product levels) and the doubling (3) against the oracle, for general operands, P = Q (the one-lane fallback),
+    P = -Q, either operand at infinity, uncommitted steps, and chains of steps, on G1 and on G2 (Fp2)."""
+    rng = random.Random(91)
+    for grp in (1, 2):
+        gen, mul, add, neg, comp, size, fn = (
+            (O.G1_GEN, O.g1_mul, O.g1_add, O.g1_neg, O.g1_compress, 48, "hh_bls_g1_coop") if grp == 1 else
+            (O.G2_GEN, O.g2_mul, O.g2_add, O.g2_neg, O.g2_compress, 96, "hh_bls_g2_coop"))
+        A, B = mul(rng.randrange(1, O.R), gen), mul(rng.randrange(1, O.R), gen)
+        dbl = lambda p: add(p, p)
+        cases = [
+            ("a", A, B, add(A, B), B), ("n", A, B, A, B), ("d", A, B, dbl(A), B), ("x", A, B, A, B),
+            ("a", A, A, dbl(A), A), ("a", A, neg(A), None, neg(A)), ("a", None, B, B, B), ("a", A, None, A, None),
+            ("a", None, None, None, None), ("d", None, B, None, B),
+            ("aa", A, B, add(add(A, B), B), B), ("ada", A, B, add(dbl(add(A, B)), B), B),
+            ("as", A, B, add(A, B), add(B, add(A, B))), ("ddda", A, B, add(mul(8, A), B), B),
+            ("adnxa", A, B, add(dbl(add(A, B)), B), B),
+        ]
+        for ops, p, q, ep, eq in cases:
+            st, out = H.call(fn, ops.encode() + b"\0", comp(p), comp(q), out_sizes=(2 * size,))
+            assert st == 0
+            assert out[:size] == comp(ep) and out[size:] == comp(eq), (grp, ops)
