@@ -73,7 +73,9 @@ for key, prefix, sub, units in (("ed25519_mul", "ed", "ed25519_mul_kernel<true>"
                                 ("bls12381_g2_mul", "mul", "bls12381_lvm_mul_kernel<true", 1 << 16),
                                 ("bls12381_g1_mul_perlane", "mulperlane", "bls12381_g1_mul_kernel", 1 << 16),
                                 ("bls12381_g2_mul_perlane", "mulperlane", "bls12381_g2_mul_kernel", 1 << 16),
-                                ("bls12381_g1_msm", "msm_bls", "accumulate_kernel", 1 << 20)):
+                                ("bls12381_g1_msm", "msm_bls", "accumulate_kernel", 1 << 20),
+                                # same-base batches through the fixed-base table (fixed_base.cuh)
+                                ("bls12381_g1_commit", "fb", "mul_kernel<kyb::bls12381_FbG1>", 1 << 20)):
     e = entry(prefix, sub, units)
     if e:
         res["kernels"][key] = e
