@@ -249,9 +249,9 @@ MADS_G2_UNMARSHAL = 2 * (379 * _S + 109 * _M) + 12 * _M + (63 * (2 * 3 + 5 * 2) 
 # (point, window) -- XYZZ form since round 3, 8M + 2S (3 224 multiply-adds; madd-2007-bl, 7M + 4S = 3 406, until then:
 # the numerator FELL with the change) -- + the running-sum reduction of 8 x 2^15 buckets (2 full additions each, 11M + 5S)
 MADS_MSM_BLS_G1_2P20_PER_POINT = 2 * 8 * (8 * _M + 2 * _S) + (8 * (1 << 15) * 2 * (11 * _M + 5 * _S)) / (1 << 20)
-# share.PriPoly.Commit through the fixed-base table (fixed_base.cuh): 33 XYZZ additions (8M + 2S), leaving the form
+# share.PriPoly.Commit through the fixed-base table (fixed_base.cuh): 26 XYZZ additions (8M + 2S), leaving the form
 # (2M), to affine (1S + 3M; the division-step inversion is ~25 batches of ~130 multiply-adds)
-MADS_G1_COMMIT = 33 * (8 * _M + 2 * _S) + 5 * _M + _S + 25 * 130
+MADS_G1_COMMIT = 26 * (8 * _M + 2 * _S) + 5 * _M + _S + 25 * 130
 # the best known count for the BLS12-381 pairing on this limb arithmetic: the Karatsuba tower of round 1 (5.4e6 per
 # Pair) against the machine's schoolbook-with-lazy-reduction program; checks / verifies scaled alike
 BLS_PAIR_BEST_KNOWN = 5.4e6

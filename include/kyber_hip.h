@@ -174,7 +174,7 @@ int kyb_bls12381_g1_mul(size_t n, const uint8_t *scalars, const uint8_t *points,
 int kyb_bls12381_g2_mul(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status, uint32_t flags);
 /* out[i] = scalars[i] * point: the loop of share.PriPoly.Commit (share/poly.go:143-149).  Batches of 2^17 scalars and
  * more -- and, through the host-buffer calls, batches of 64 and more over the suite's generator or over the base of
- * the previous call -- run through a table of the base's multiples (33 table additions per scalar, no doublings; same
+ * the previous call -- run through a table of the base's multiples (26 table additions per scalar, no doublings; same
  * bytes and statuses as the per-element calls; the same holds for the bn256 / bn254 entry points and for the `_dev`
  * calls with point_stride = 0). */
 int kyb_bls12381_g1_mul_same_base(size_t n, const uint8_t *scalars, const uint8_t point[48], uint8_t *out,

@@ -1,19 +1,21 @@
 // Fixed-base scalar multiplication for the same-base batches of the pairing suites: out_i = k_i * P for ONE point P and
 // many scalars -- share.PriPoly.Commit (share/poly.go:143-149: every coefficient times the same base), key generation
 // (x * G2.Base()), `Point.Mul(s, nil)`.  The reference runs its variable-base ladder n times; with the base shared, a
-// table of its multiples turns a multiplication into 33 table additions and NO doublings:
+// table of its multiples turns a multiplication into 26 table additions and NO doublings:
 //
-//   k = sum_w d_w 256^w, signed digits d_w in [-128, 128] (w = 0..32, the last one the recoding's carry), and
-//   T[w][j] = (j + 1) 256^w P in affine form (128 entries per window), so  k P = sum_w sign(d_w) T[w][|d_w| - 1]:
-//   33 mixed additions in XYZZ form (curve.cuh, 8M + 2S each) + one inversion, about a fifth of the GLV ladder's field
-//   multiplications and an eighth of the plain ladder's (bn256 G2).  No endomorphism is involved, so the result is the
+//   k = sum_w d_w 1024^w, signed digits d_w in [-511, 512] (w = 0..25, the last one holding the top bits + carry), and
+//   T[w][j] = (j + 1) 1024^w P in affine form (512 entries per window), so  k P = sum_w sign(d_w) T[w][|d_w| - 1]:
+//   26 mixed additions in XYZZ form (curve.cuh, 8M + 2S each) + one inversion, about a sixth of the GLV ladder's field
+//   multiplications and a tenth of the plain ladder's (bn256 G2).  (Radix 256 -- 33 additions, a quarter of the table
+//   -- was the first version: 6.6 ms per 2^20 BLS12-381 G1 scalars against this one's figure in DESIGN.md.)  No endomorphism is involved, so the result is the
 //   integer multiple for EVERY decodable base (bn256's G2 points outside the order-n subgroup included) and every
 //   256-bit scalar, like the reference's double-and-add.
 //
-// The table costs a chain of 256 dependent doublings (one lane: ~2.5 ms on G1, three times that on G2) + 33 x 128
+// The table costs a chain of 250 dependent doublings (one lane: ~2.5 ms on G1, three times that on G2) + 26 x 512
 // independent small multiples: it pays for itself from ~2^17 scalars, or at any batch size once it exists -- the
 // workspace keeps the last base's table per (suite, group, stream), and the chain kernel recognises the base on the
-// device (no host round trip).  Table: 33 x 128 x (2 field elements) = 405 KB (BLS12-381 G1) .. 811 KB (G2): L2-resident.
+// device (no host round trip).  Table: 26 x 512 x (2 field elements) = 1.3 MB (BLS12-381 G1) .. 2.6 MB (G2): inside the
+// 4 MB of L2 each XCD has.
 #pragma once
 #include "curve.cuh"
 #if defined(__HIPCC__)
@@ -23,8 +25,9 @@
 namespace kyb {
 namespace fb {
 
-constexpr int NWIN = 33, NENT = 128, WIRE_MAX = 192;
-constexpr uint64_t MAGIC = 0x6b79626662763031ull;  // "kybfbv01"
+constexpr int WBITS = 10, NWIN = (256 + WBITS) / WBITS, NENT = 1 << (WBITS - 1), WIRE_MAX = 192;
+static_assert(NWIN * WBITS >= 257, "the last window must hold the recoding's carry");
+constexpr uint64_t MAGIC = 0x6b79626662763032ull;  // "kybfbv02"
 
 // head of the workspace: which base the table below belongs to
 struct Header {
@@ -43,19 +46,26 @@ struct Entry {  // affine multiple; (0, 0) -- not a point of y^2 = x^3 + b, b !=
     F x, y;
 };
 
-// signed radix-256 digits of a 256-bit integer (eight little-endian words): d[0..32] in [-128, 128]
-KYB_HD void digits256(int (&d)[NWIN], const uint32_t (&k)[8]) {
+// window w of k: bits [WBITS w, WBITS w + WBITS) of the 256-bit integer (zero beyond bit 255)
+KYB_HD int window_bits(const uint32_t (&k)[8], int w) {
+    const int bit = w * WBITS, idx = bit >> 5, sh = bit & 31;
+    if (idx >= 8) return 0;
+    uint32_t v = k[idx] >> sh;
+    if (sh + WBITS > 32 && idx + 1 < 8) v |= k[idx + 1] << (32 - sh);
+    return (int)(v & ((1u << WBITS) - 1));
+}
+// signed radix-2^WBITS digits: d[w] in [-(NENT - 1), NENT]
+KYB_HD void digits(int (&d)[NWIN], const uint32_t (&k)[8]) {
     int carry = 0;
 #pragma unroll
-    for (int w = 0; w < 32; w++) {
-        int v = (int)((k[w >> 2] >> ((w & 3) * 8)) & 0xffu) + carry;
-        carry = v > 128 ? 1 : 0;
-        d[w] = v - (carry << 8);
+    for (int w = 0; w < NWIN; w++) {
+        const int v = window_bits(k, w) + carry;
+        carry = v > NENT ? 1 : 0;
+        d[w] = v - (carry << WBITS);
     }
-    d[32] = carry;
 }
 
-// q[w] = 256^w P  (Jacobian): the one serial part of the table
+// q[w] = 2^(WBITS w) P  (Jacobian): the one serial part of the table
 template <class F>
 KYB_HD void chain(Jac<F> (&q)[NWIN], const Aff<F>& base) {
     jac_from_aff(q[0], base);
@@ -63,19 +73,19 @@ KYB_HD void chain(Jac<F> (&q)[NWIN], const Aff<F>& base) {
     for (int w = 1; w < NWIN; w++) {
         Jac<F> t = q[w - 1];
 #pragma unroll 1
-        for (int i = 0; i < 8; i++) jac_dbl_inl(t, t);
+        for (int i = 0; i < WBITS; i++) jac_dbl_inl(t, t);
         q[w] = t;
     }
 }
 
-// e = (j + 1) Q in affine form, j in [0, 128)
+// e = (j + 1) Q in affine form, j in [0, NENT)
 template <class F>
 KYB_HD void entry(Entry<F>& e, const Jac<F>& q, int j) {
-    const int m = j + 1;  // 1 .. 128
+    const int m = j + 1;  // 1 .. NENT
     Jac<F> acc;
     jac_set_inf(acc);
 #pragma unroll 1
-    for (int bit = 7; bit >= 0; bit--) {
+    for (int bit = WBITS - 1; bit >= 0; bit--) {
         jac_dbl_inl(acc, acc);
         if ((m >> bit) & 1) jac_add_inl<F, false>(acc, acc, q);
     }
@@ -97,10 +107,10 @@ KYB_HD void mul(Jac<F>& r, const uint32_t (&k)[8], const Entry<F>* __restrict__ 
     int carry = 0;
 #pragma unroll 1
     for (int w = 0; w < NWIN; w++) {
-        // the digits of digits256, produced as the walk needs them
-        const int v = (w < 32 ? (int)((k[w >> 2] >> ((w & 3) * 8)) & 0xffu) : 0) + carry;
-        carry = v > 128 ? 1 : 0;
-        const int dw = v - (carry << 8);
+        // the digits of digits(), produced as the walk needs them
+        const int v = window_bits(k, w) + carry;
+        carry = v > NENT ? 1 : 0;
+        const int dw = v - (carry << WBITS);
         if (dw == 0) continue;
         const int a = dw < 0 ? -dw : dw;
         const Entry<F> e = tab[w * NENT + (a - 1)];
@@ -154,7 +164,7 @@ __global__ __launch_bounds__(64) void chain_kernel(uint8_t* __restrict__ ws, con
 #pragma unroll 1
         for (int w = 1; w < NWIN; w++) {
 #pragma unroll 1
-            for (int i = 0; i < 8; i++) jac_dbl_inl(t, t);
+            for (int i = 0; i < WBITS; i++) jac_dbl_inl(t, t);
             q[w] = t;
         }
     }

@@ -308,7 +308,7 @@ def test_endomorphism_split_division_by_reciprocal():
 
 
 def _fb_scalars(rng, order):
-    ks = [0, 1, 2, 127, 128, 129, 255, 256, 257, order - 1, order, order + 1, (1 << 256) - 1, 1 << 255,
+    ks = [0, 1, 2, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, (1 << 250) + 512, (512 << 10) + 513, order - 1, order, order + 1, (1 << 256) - 1, 1 << 255,
           int.from_bytes(b"\x80" * 32, "big"), int.from_bytes(b"\x81" * 32, "big"), int.from_bytes(b"\x7f" * 32, "big")]
     return ks + [rng.randrange(1 << 256) for _ in range(12)] + [rng.randrange(order) for _ in range(8)]
 

@@ -180,7 +180,7 @@ def test_fixed_base_table_multiplication_vs_oracle():
     import random
     rng = random.Random(78)
     n = O.ORDER
-    ks = [0, 1, 2, 13, 26, 127, 128, 129, 255, 256, 257, n - 1, n, n + 1, (1 << 256) - 1, 1 << 255, 13 * n, 13 * n - 1,
+    ks = [0, 1, 2, 13, 26, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, (1 << 250) + 512, (512 << 10) + 513, n - 1, n, n + 1, (1 << 256) - 1, 1 << 255, 13 * n, 13 * n - 1,
           int.from_bytes(b"\x80" * 32, "big"), int.from_bytes(b"\x81" * 32, "big")] + [rng.randrange(1 << 256) for _ in range(12)]
     ks = [k % (1 << 256) for k in ks]
     kb = b"".join(k.to_bytes(32, "big") for k in ks)
