@@ -153,7 +153,9 @@ func MSMBits(k Kind, g kyber.Group, scalars []kyber.Scalar, points []kyber.Point
 	return p, p.UnmarshalBinary(out)
 }
 
-// Commit returns coeffs[i] * base: the loop of share.PriPoly.Commit (share/poly.go:143-149); base == nil is the
+// Commit returns coeffs[i] * base: the loop of share.PriPoly.Commit (share/poly.go:143-149) in one call -- on the pairing
+// suites through a fixed-base table of the base's multiples (26 table additions per coefficient instead of a ladder:
+// built per call from 2^17 coefficients, kept on the device for the generator and for a repeated base from 64); base == nil is the
 // group's standard base, as poly.go:144 passes nil through.
 func Commit(k Kind, g kyber.Group, coeffs []kyber.Scalar, base kyber.Point) ([]kyber.Point, error) {
 	sb, err := marshalAll(coeffs, 32)
