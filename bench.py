@@ -166,6 +166,32 @@ def cpu_baseline_pairing_and_msm(bn, bls):
                              "outputs_compared": n,
                              "sample": f"{n} Suite.Pair calls, oracle/bn256_ref.c (pairing/bn256 optate.go:126-274 over "
                                        f"gfp_generic.go:158 restated in C), GT bytes compared with the GPU's"}
+    # ---- pairings (BLS12-381, the batched-pairing config's own curve): oracle/bls12381_pair_ref.c, a C port of the
+    # published algorithm the reference's external backends implement (kind "port"), GT bytes compared with the GPU's.
+    # Guarded: nothing in this leg may cost the run its line.
+    try:
+        Pb = np.asarray(bls.g1_commit(h)[0])
+        Qb = np.asarray(bls.g2_commit(k)[0])
+        Pu = np.asarray(bls.g1_batch_unmarshal(Pb, bls.F_UNCOMPRESSED_OUT)[0])
+        Qu = np.asarray(bls.g2_batch_unmarshal(Qb, bls.F_UNCOMPRESSED_OUT)[0])
+        n0 = 32
+        t0 = time.perf_counter()
+        OC.bls12381_pair(Pu[:n0], Qu[:n0], threads=1)
+        r1 = n0 / (time.perf_counter() - t0)
+        n = int(min(4096, max(n0, r1 * cores * 8.0)))
+        t0 = time.perf_counter()
+        gt_c, st = OC.bls12381_pair(Pu[:n], Qu[:n], threads=cores)
+        dt = time.perf_counter() - t0
+        gt_g, st_g = bls.batch_pair(Pb[:n], Qb[:n])
+        out["bls12381_pairings"] = {"value": n / dt, "unit": "pairings/s", "cores": cores, "single_thread_value": r1,
+                                    "outputs_match": bool(_sha(gt_c) == _sha(np.asarray(gt_g)) and not st.any() and not np.asarray(st_g).any()),
+                                    "outputs_compared": n,
+                                    "sample": f"{n} Suite.Pair calls, oracle/bls12381_pair_ref.c (optimal ate pairing, projective "
+                                              f"Miller loop, Granger-Scott squarings in the five-exponentiation hard part: a port "
+                                              f"of the published algorithm, the reference's backends being external modules), "
+                                              f"576-byte GT encodings compared with the GPU's"}
+    except Exception as e:  # noqa: BLE001 -- a reported baseline must never take the benchmark line down
+        out["bls12381_pairings"] = {"error": repr(e)[:300]}
     # ---- N x (Mul + Add) where the engine runs an MSM
     for name, m, fn, unc in (("bls12381_g1_mul_add", bls, OC.bls12381_g1_mul_sum, True), ("bn256_g1_mul_add", bn, OC.bn256_g1_mul_sum, False)):
         pts = np.asarray(m._mul(1, h, m.G1_BASE, True, m.F_UNCOMPRESSED_OUT)[0]) if unc else P

@@ -24,7 +24,7 @@ def lib():
         l.ora_ed25519_mul.restype = None
         l.ora_ed25519_msm.argtypes = [sz, vp, vp, vp]
         l.ora_ed25519_msm.restype = C.c_long
-        for name in ("ora_bn256_pair", "ora_bn256_g1_mul_sum", "ora_bn256_g1_mul", "ora_bls12381_g1_mul_sum"):
+        for name in ("ora_bn256_pair", "ora_bn256_g1_mul_sum", "ora_bn256_g1_mul", "ora_bls12381_g1_mul_sum", "ora_bls12381_pair"):
             f = getattr(l, name)
             f.argtypes = [sz, vp, vp, vp, vp, i]
             f.restype = None
@@ -93,4 +93,15 @@ def bls12381_g1_mul_sum(scalars, points_unc, threads: int = 0):
     out = np.empty(96, dtype=np.uint8)
     st = np.zeros(len(s), dtype=np.uint8)
     lib().ora_bls12381_g1_mul_sum(len(s), s.ctypes.data, p.ctypes.data, out.ctypes.data, st.ctypes.data, threads or (os.cpu_count() or 1))
+    return out, st
+
+
+def bls12381_pair(g1_unc, g2_unc, threads: int = 0):
+    """(gt, status): oracle/bls12381_pair_ref.c, n x Suite.Pair on BLS12-381; ZCash uncompressed points in (96 / 192
+    bytes), kilic's 576-byte GT encoding out"""
+    a = np.ascontiguousarray(np.frombuffer(g1_unc, dtype=np.uint8) if isinstance(g1_unc, (bytes, bytearray)) else g1_unc, dtype=np.uint8).reshape(-1, 96)
+    b = np.ascontiguousarray(np.frombuffer(g2_unc, dtype=np.uint8) if isinstance(g2_unc, (bytes, bytearray)) else g2_unc, dtype=np.uint8).reshape(-1, 192)
+    out = np.empty((len(a), 576), dtype=np.uint8)
+    st = np.empty(len(a), dtype=np.uint8)
+    lib().ora_bls12381_pair(len(a), a.ctypes.data, b.ctypes.data, out.ctypes.data, st.ctypes.data, threads or (os.cpu_count() or 1))
     return out, st

@@ -1,0 +1,49 @@
+"""oracle/bls12381_pair_ref.c -- the C port of the BLS12-381 pairing that bench.py times as the CPU baseline of the
+batched-pairing config -- held byte for byte against oracle/bls12381.py, whose GT bytes are pinned by the reference's
+IBE interop vector (tests/test_oracle_bls12381.py): random pairs, multiples of one pair (bilinearity through the bytes),
+points at infinity, and several threads."""
+import random
+
+import numpy as np
+
+from oracle import bls12381 as O
+from tests import _oracle_c as OC
+
+
+def _pairs(rng, n):
+    out = []
+    for _ in range(n):
+        out.append((O.g1_mul(rng.randrange(1, O.R), O.G1_GEN), O.g2_mul(rng.randrange(1, O.R), O.G2_GEN)))
+    return out
+
+
+def test_gt_bytes_match_the_python_oracle():
+    rng = random.Random(21)
+    pairs = _pairs(rng, 4) + [(None, O.G2_GEN), (O.G1_GEN, None), (None, None), (O.G1_GEN, O.G2_GEN)]
+    g1 = b"".join(O.g1_serialize_unc(p) for p, _ in pairs)
+    g2 = b"".join(O.g2_serialize_unc(q) for _, q in pairs)
+    for threads in (1, 3):
+        gt, st = OC.bls12381_pair(g1, g2, threads=threads)
+        assert not st.any()
+        for i, (p, q) in enumerate(pairs):
+            assert bytes(gt[i]) == O.gt_to_bytes(O.pair(p, q)), (threads, i)
+
+
+def test_bilinearity_through_the_bytes():
+    rng = random.Random(22)
+    a, b = rng.randrange(1, O.R), rng.randrange(1, O.R)
+    P, Q = O.g1_mul(rng.randrange(1, O.R), O.G1_GEN), O.g2_mul(rng.randrange(1, O.R), O.G2_GEN)
+    g1 = O.g1_serialize_unc(O.g1_mul(a, P)) + O.g1_serialize_unc(P) + O.g1_serialize_unc(O.g1_mul(a * b % O.R, P))
+    g2 = O.g2_serialize_unc(O.g2_mul(b, Q)) + O.g2_serialize_unc(O.g2_mul(a * b % O.R, Q)) + O.g2_serialize_unc(Q)
+    gt, st = OC.bls12381_pair(g1, g2, threads=1)
+    assert not st.any() and bytes(gt[0]) == bytes(gt[1]) == bytes(gt[2])
+    one, _ = OC.bls12381_pair(O.g1_serialize_unc(None), O.g2_serialize_unc(Q), threads=1)
+    assert bytes(gt[0]) != bytes(one[0])
+
+
+def test_rejects_out_of_range_coordinates():
+    bad = bytearray(O.g1_serialize_unc(O.G1_GEN))
+    bad[0:48] = (O.P + 1).to_bytes(48, "big")
+    bad[0] &= 0x1F
+    gt, st = OC.bls12381_pair(bytes(bad), O.g2_serialize_unc(O.G2_GEN), threads=1)
+    assert st[0] == 1 and not gt.any()
