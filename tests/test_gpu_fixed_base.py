@@ -65,7 +65,6 @@ def test_arbitrary_base_at_table_sizes_reuse_and_rebuild(name, grp, n):
     s[:, 31] ^= torch.arange(n, device="cuda", dtype=torch.int64).to(torch.uint8)  # not all rows equal
     commit = m.g1_commit if grp == 1 else m.g2_commit
     batch = m.g1_batch_mul if grp == 1 else m.g2_batch_mul
-    gbase = np.frombuffer(m.G1_BASE if grp == 1 else m.G2_BASE, dtype=np.uint8)
     hs = np.frombuffer(b"".join(rng.randrange(1, m.ORDER).to_bytes(32, "big") for _ in range(2)), dtype=np.uint8).reshape(2, 32)
     bases, st = commit(hs, flags=0)  # two arbitrary points of the group (few scalars: the ladder)
     assert not np.asarray(st).any()
@@ -76,7 +75,6 @@ def test_arbitrary_base_at_table_sizes_reuse_and_rebuild(name, grp, n):
         torch.cuda.synchronize()
         assert not st.any().item() and not st2.any().item()
         assert torch.equal(out, ref), (name, grp, which)
-    del gbase
 
 
 @pytest.mark.parametrize("name", SUITES)
