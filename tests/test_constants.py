@@ -173,3 +173,64 @@ def test_bn254_g2_subgroup_criterion_is_exact():
         for mu in ((t + r) * pow(2, -1, q) % q, (t - r) * pow(2, -1, q) % q):
             assert (mu * mu - t * mu + p) % q == 0
             assert ((u + 1) + u * mu + u * mu * mu - 2 * u * mu**3) % q != 0
+
+
+def test_bn256_twist_cofactor_and_the_criterion_that_would_gate_gls():
+    """DESIGN.md section 9 item 4 (not built): bn256's UnmarshalBinary accepts G2 points outside the order-n subgroup, so
+    its default G2 ladder is the plain one.  The facts a membership-gated GLS walk would rest on, checked here so that the
+    claim in the design notes is not hearsay: the twist's cofactor is 13 * 7369 * (a 239-bit prime), coprime to n (the
+    group is cyclic), and bn254's criterion (u+1) + u psi + u psi^2 - 2u psi^3 = 0 is exact on this curve too -- the
+    polynomial vanishes at psi = [p] on G2 and is non-zero at both eigenvalues of psi modulo every cofactor prime."""
+    from oracle import bn256 as N
+
+    def is_prime(m):
+        d, s = m - 1, 0
+        while d % 2 == 0:
+            d, s = d // 2, s + 1
+        for a in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53):
+            if m == a:
+                return True
+            x = pow(a, d, m)
+            if x in (1, m - 1):
+                continue
+            for _ in range(s - 1):
+                x = x * x % m
+                if x == m - 1:
+                    break
+            else:
+                return False
+        return True
+
+    def roots(t, p, q):  # roots of X^2 - t X + p modulo the prime q (the discriminant is a residue for all three)
+        disc = (t * t - 4 * p) % q
+        assert pow(disc, (q - 1) // 2, q) == 1
+        # Tonelli-Shanks
+        Q, S = q - 1, 0
+        while Q % 2 == 0:
+            Q, S = Q // 2, S + 1
+        z = 2
+        while pow(z, (q - 1) // 2, q) != q - 1:
+            z += 1
+        m, c, tt, r = S, pow(z, Q, q), pow(disc, Q, q), pow(disc, (Q + 1) // 2, q)
+        while tt != 1:
+            i, t2 = 0, tt
+            while t2 != 1:
+                t2, i = t2 * t2 % q, i + 1
+            b = pow(c, 1 << (m - i - 1), q)
+            m, c = i, b * b % q
+            tt, r = tt * c % q, r * b % q
+        inv2 = pow(2, -1, q)
+        return ((t + r) * inv2 % q, (t - r) * inv2 % q)
+
+    u, p, n = N.U, N.P, N.ORDER
+    t = 6 * u * u + 1
+    assert p + 1 - t == n
+    h = 2 * p - n
+    q3 = h // (13 * 7369)
+    primes = (13, 7369, q3)
+    assert 13 * 7369 * q3 == h and q3.bit_length() == 239 and all(is_prime(q) and n % q != 0 for q in primes)
+    assert ((u + 1) + u * p + u * p * p - 2 * u * p**3) % n == 0
+    for q in primes:
+        for mu in roots(t, p, q):
+            assert (mu * mu - t * mu + p) % q == 0
+            assert ((u + 1) + u * mu + u * mu * mu - 2 * u * mu**3) % q != 0
