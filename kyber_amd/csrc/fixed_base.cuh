@@ -17,6 +17,7 @@
 // device (no host round trip).  Table: 26 x 512 x (2 field elements) = 1.3 MB (BLS12-381 G1) .. 2.6 MB (G2): inside the
 // 4 MB of L2 each XCD has.
 #pragma once
+#include "coop_slots.cuh"
 #include "curve.cuh"
 #if defined(__HIPCC__)
 #include "context.h"
@@ -171,6 +172,65 @@ __global__ __launch_bounds__(64) void chain_kernel(uint8_t* __restrict__ ws, con
     __threadfence();
     h->magic = MAGIC;
 }
+// The same on FOUR cooperating lanes (coop_slots.cuh: a doubling is three product levels deep instead of seven
+// multiplications) -- NOT the default: written at the end of round 3 without GPU time left to measure it, selected by
+// KYB_FB_CHAIN=coop for the A/B run that decides (the slot arithmetic itself runs in the MSM's reduce kernel and, on the
+// CPU, with threads as lanes).  One workgroup of four lanes; lane 0 does what chain_kernel's lane does before and after
+// the doublings.
+template <class T>
+__global__ __launch_bounds__(64, 2) void chain_coop_kernel(uint8_t* __restrict__ ws, const uint8_t* __restrict__ base, uint32_t flags) {
+    using F = typename T::F;
+    constexpr int P = 0, TMP = 3;
+    __shared__ coop::Slot<F> S[TMP + coop::TEMPS];
+    __shared__ int go;
+    const int r = (int)threadIdx.x & 3;
+    Header* h = reinterpret_cast<Header*>(ws);
+    Jac<F>* q = reinterpret_cast<Jac<F>*>(ws + HDR_BYTES);
+    if (threadIdx.x == 0) {
+        const uint32_t kf = flags & T::KEY_FLAGS, len = (uint32_t)T::wire_size(flags);
+        bool same = h->magic == MAGIC && h->key_flags == kf && h->key_len == len;
+        for (uint32_t i = 0; i < len && same; i++) same = h->key[i] == base[i];
+        go = 0;
+        if (same) {
+            h->fresh = 0;
+        } else {
+            h->magic = 0;
+            Aff<F> a;
+            const int st = T::decode(a, base, flags);
+            h->status = (uint32_t)st;
+            h->inf = (st == 0 && a.inf) ? 1u : 0u;
+            h->key_flags = kf;
+            h->key_len = len;
+            for (uint32_t i = 0; i < len; i++) h->key[i] = base[i];
+            h->fresh = 1;
+            if (st == 0 && !a.inf) {
+                Jac<F> t;
+                jac_from_aff(t, a);
+                q[0] = t;
+                S[P].f = t.X;
+                S[P + 1].f = t.Y;
+                S[P + 2].f = t.Z;
+                go = 1;
+            } else {
+                __threadfence();
+                h->magic = MAGIC;
+            }
+        }
+    }
+    __syncthreads();
+    if (!go) return;  // uniform: the table is current, or there is nothing to build
+#pragma unroll 1
+    for (int w = 1; w < NWIN; w++) {
+#pragma unroll 1
+        for (int i = 0; i < WBITS; i++) coop::dbl<F>(S, r, P, TMP, true);
+        if (r < 3) reinterpret_cast<F*>(q + w)[r] = S[P + r].f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        h->magic = MAGIC;
+    }
+}
 // One lane per table entry
 template <class T>
 __global__ __launch_bounds__(64) void table_kernel(uint8_t* __restrict__ ws) {
@@ -228,7 +288,12 @@ int run(size_t n, const void* d_scalars, const void* d_base, void* d_out, void* 
     bool grew = false;
     if (int rc = ctx_workspace(ctx, T::KIND, st, ws_bytes<T>(), &ws, &grew)) return rc;
     if (grew) KYB_HIP_CHECK(hipMemsetAsync(ws, 0, HDR_BYTES, st));
-    hipLaunchKernelGGL(chain_kernel<T>, dim3(1), dim3(64), 0, st, (uint8_t*)ws, (const uint8_t*)d_base, flags);
+    static const bool coop_chain = [] {
+        const char* e = getenv("KYB_FB_CHAIN");
+        return e && e[0] == 'c';
+    }();
+    if (coop_chain) hipLaunchKernelGGL(chain_coop_kernel<T>, dim3(1), dim3(4), 0, st, (uint8_t*)ws, (const uint8_t*)d_base, flags);
+    else hipLaunchKernelGGL(chain_kernel<T>, dim3(1), dim3(64), 0, st, (uint8_t*)ws, (const uint8_t*)d_base, flags);
     hipLaunchKernelGGL(table_kernel<T>, dim3((NWIN * NENT + 63) / 64), dim3(64), 0, st, (uint8_t*)ws);
     hipLaunchKernelGGL(mul_kernel<T>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, (const uint8_t*)d_scalars,
                        (const uint8_t*)ws, (uint8_t*)d_out, (uint8_t*)d_status, flags);

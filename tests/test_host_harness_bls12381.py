@@ -350,6 +350,7 @@ def test_cooperative_slot_arithmetic_with_threads_as_lanes():
             ("aa", A, B, add(add(A, B), B), B), ("ada", A, B, add(dbl(add(A, B)), B), B),
             ("as", A, B, add(A, B), add(B, add(A, B))), ("ddda", A, B, add(mul(8, A), B), B),
             ("adnxa", A, B, add(dbl(add(A, B)), B), B),
+            ("d" * 10, A, B, mul(1024, A), B),  # one window of the fixed-base table's doubling chain (chain_coop_kernel)
         ]
         for ops, p, q, ep, eq in cases:
             st, out = H.call(fn, ops.encode() + b"\0", comp(p), comp(q), out_sizes=(2 * size,))
