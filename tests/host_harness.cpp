@@ -241,6 +241,32 @@ int hh_bn_g1_coop(const uint8_t* ops, const uint8_t* a, const uint8_t* b, uint8_
         [](uint8_t* o, const bn::g1_aff& p) { bn::g1_encode(o, p); });
 }
 
+// jac_table8_to_affine (curve.cuh): the ladders' window table (j + 1) P, j < 8, with the entries named in `inf_mask`
+// replaced by the point at infinity, normalised by the shared inversion; out = 8 encodings
+int hh_bls_g1_table8(const uint8_t* pt, int inf_mask, uint8_t* out) {
+    bls::g1_aff a;
+    if (bls::g1_decode(a, pt, false)) return 1;
+    bls::g1_jac p, tab[8];
+    jac_from_aff(p, a);
+    tab[0] = p;
+    jac_dbl(tab[1], p);
+    for (int j = 2; j < 8; j++) jac_add(tab[j], tab[j - 1], p);
+    for (int j = 0; j < 8; j++)
+        if ((inf_mask >> j) & 1) jac_set_inf(tab[j]);
+    jac_table8_to_affine(tab);
+    for (int j = 0; j < 8; j++) {
+        bls::g1_aff e;
+        e.x = tab[j].X;
+        e.y = tab[j].Y;
+        e.inf = jac_is_inf(tab[j]);
+        bls::fp one;
+        fp_one(one);
+        if (!e.inf && !fp_eq(tab[j].Z, one)) return 2;  // finite entries must come back with Z = 1
+        bls::g1_encode(out + 48 * j, e);
+    }
+    return 0;
+}
+
 // flag-aware variants (KYB_F_UNCOMPRESSED / _OUT / TRUSTED): ints come before the output buffers
 int hh_bls_g1_mul_f(const uint8_t* k, const uint8_t* pt, int flags, uint8_t* out) {
     return bls::g1_mul_wire(out, k, pt, (uint32_t)flags);

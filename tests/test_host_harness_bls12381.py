@@ -356,3 +356,16 @@ def test_cooperative_slot_arithmetic_with_threads_as_lanes():
             st, out = H.call(fn, ops.encode() + b"\0", comp(p), comp(q), out_sizes=(2 * size,))
             assert st == 0
             assert out[:size] == comp(ep) and out[size:] == comp(eq), (grp, ops)
+
+
+def test_window_table_normalisation_with_entries_at_infinity():
+    """jac_table8_to_affine: the ladders' table brought to affine form by ONE shared inversion; entries at infinity (a base
+    of small order, or the base itself at infinity) must not poison the shared product and must come back as infinity."""
+    rng = random.Random(95)
+    P = O.g1_mul(rng.randrange(1, O.R), O.G1_GEN)
+    for mask in (0, 0b00000100, 0b10000001, 0b01111110, 0xFF):
+        st, out = H.call("hh_bls_g1_table8", O.g1_compress(P), mask, out_sizes=(48 * 8,))
+        assert st == 0
+        for j in range(8):
+            exp = None if (mask >> j) & 1 else O.g1_mul(j + 1, P)
+            assert out[48 * j:48 * j + 48] == O.g1_compress(exp), (mask, j)
