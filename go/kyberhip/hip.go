@@ -210,6 +210,31 @@ func Ed25519PolyEval(idx []uint32, commits []byte) (out, status []byte, err erro
 	return out, status[:t], err
 }
 
+// ScalarPolyEval: out[i] = sum_j coeffs[j] * (idx[i] + 1)^j mod the group order -- share.PriPoly.Eval
+// (share/poly.go:85-93) for many indices in one launch, i.e. PriPoly.Shares (share/poly.go:96-102).  coeffs and out are
+// 32-byte scalars in the suite's own encoding (Ed25519 little-endian, mod.Int big-endian).
+func ScalarPolyEval(suite string, idx []uint32, coeffs []byte) (out []byte, err error) {
+	t, err := count("coeffs", coeffs, 32)
+	if err != nil {
+		return nil, err
+	}
+	n := len(idx)
+	out = make([]byte, 32*n)
+	err = call(func() C.int {
+		switch suite {
+		case "ed25519":
+			return C.kyb_ed25519_scalar_poly_eval(C.size_t(n), idxPtr(idx), C.size_t(t), ptr(coeffs), ptr(out))
+		case "bls12381":
+			return C.kyb_bls12381_scalar_poly_eval(C.size_t(n), idxPtr(idx), C.size_t(t), ptr(coeffs), ptr(out))
+		case "bn256":
+			return C.kyb_bn256_scalar_poly_eval(C.size_t(n), idxPtr(idx), C.size_t(t), ptr(coeffs), ptr(out))
+		default:
+			return C.kyb_bn254_scalar_poly_eval(C.size_t(n), idxPtr(idx), C.size_t(t), ptr(coeffs), ptr(out))
+		}
+	})
+	return out, err
+}
+
 // messages: n equal-length messages packed back to back (msgLen may be 0: then n must be given by the caller)
 func messages(msgs []byte, msgLen, n int) error {
 	if msgLen < 0 || len(msgs) != n*msgLen {

@@ -410,6 +410,21 @@ int kyb_bn256_g1_poly_eval_dev(size_t n, const void *d_idx, size_t t, const void
                                void *d_status, uint32_t flags, void *stream);
 int kyb_bn256_g2_poly_eval_dev(size_t n, const void *d_idx, size_t t, const void *d_commits, void *d_out,
                                void *d_status, uint32_t flags, void *stream);
+/* --------------------------------------------------------- batched private-polynomial evaluation (scalar field)
+ * out[i] = sum_j coeffs[j] * (idx[i] + 1)^j mod q  (n scalars of 32 bytes, q = the group order).  share.PriPoly.Eval
+ * (share/poly.go:85-93: xi = 1 + i, Horner from the top coefficient with t x (Mul + Add) of group/mod.Int) for many
+ * indices in one launch -- the loop of PriPoly.Shares (share/poly.go:96-102), which every dealer of share/vss and
+ * share/dkg runs once per participant.  coeffs: t scalars in the suite's scalar encoding (Ed25519: 32 bytes
+ * little-endian, group/edwards25519/scalar.go; pairing suites: mod.Int's 32 bytes big-endian, group/mod/int.go);
+ * any 32-byte string is taken modulo q; outputs are canonical.  t == 0 yields zeros.                              */
+int kyb_ed25519_scalar_poly_eval(size_t n, const uint32_t *idx, size_t t, const uint8_t *coeffs, uint8_t *out);
+int kyb_ed25519_scalar_poly_eval_dev(size_t n, const void *d_idx, size_t t, const void *d_coeffs, void *d_out, void *stream);
+int kyb_bls12381_scalar_poly_eval(size_t n, const uint32_t *idx, size_t t, const uint8_t *coeffs, uint8_t *out);
+int kyb_bls12381_scalar_poly_eval_dev(size_t n, const void *d_idx, size_t t, const void *d_coeffs, void *d_out, void *stream);
+int kyb_bn256_scalar_poly_eval(size_t n, const uint32_t *idx, size_t t, const uint8_t *coeffs, uint8_t *out);
+int kyb_bn256_scalar_poly_eval_dev(size_t n, const void *d_idx, size_t t, const void *d_coeffs, void *d_out, void *stream);
+int kyb_bn254_scalar_poly_eval(size_t n, const uint32_t *idx, size_t t, const uint8_t *coeffs, uint8_t *out);
+int kyb_bn254_scalar_poly_eval_dev(size_t n, const void *d_idx, size_t t, const void *d_coeffs, void *d_out, void *stream);
 /* pairing/bn254: the same eight entry points */
 int kyb_bn254_g1_msm(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t out[64], uint8_t *status, uint32_t flags);
 int kyb_bn254_g2_msm(size_t n, const uint8_t *scalars, const uint8_t *points, uint8_t out[128], uint8_t *status, uint32_t flags);

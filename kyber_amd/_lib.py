@@ -141,6 +141,14 @@ SIGNATURES = {
     "kyb_bn254_g1_unmarshal_dev": [_sz, _vp, _vp, _vp, _u32, _vp],
     "kyb_bn254_g2_unmarshal": [_sz, _vp, _vp, _vp, _u32],
     "kyb_bn254_g2_unmarshal_dev": [_sz, _vp, _vp, _vp, _u32, _vp],
+    "kyb_ed25519_scalar_poly_eval": [_sz, _vp, _sz, _vp, _vp],
+    "kyb_ed25519_scalar_poly_eval_dev": [_sz, _vp, _sz, _vp, _vp, _vp],
+    "kyb_bls12381_scalar_poly_eval": [_sz, _vp, _sz, _vp, _vp],
+    "kyb_bls12381_scalar_poly_eval_dev": [_sz, _vp, _sz, _vp, _vp, _vp],
+    "kyb_bn256_scalar_poly_eval": [_sz, _vp, _sz, _vp, _vp],
+    "kyb_bn256_scalar_poly_eval_dev": [_sz, _vp, _sz, _vp, _vp, _vp],
+    "kyb_bn254_scalar_poly_eval": [_sz, _vp, _sz, _vp, _vp],
+    "kyb_bn254_scalar_poly_eval_dev": [_sz, _vp, _sz, _vp, _vp, _vp],
     "kyb_bn254_g1_poly_eval": [_sz, _vp, _sz, _vp, _vp, _vp, _u32],
     "kyb_bn254_g2_poly_eval": [_sz, _vp, _sz, _vp, _vp, _vp, _u32],
     "kyb_bn254_g1_poly_eval_dev": [_sz, _vp, _sz, _vp, _vp, _vp, _u32, _vp],

@@ -161,6 +161,11 @@ int kyb_##PFX##_g1_mul_dev(size_t n, const void* d_scalars, const void* d_points
     if (point_stride == 0 && n >= kyb::fb_min_batch(false)) /* one base, many scalars: fixed_base.cuh */ \
         return kyb::fb::run<kyb::PFX##_FbG1>(n, d_scalars, d_points, d_out, d_status, flags, (hipStream_t)stream); \
     const uint8_t* only = nullptr; \
+    /* the machine's steps and the per-lane redo launch are ONE unit on the stream: `only` points into the (WS_LVM, \
+       stream) workspace, which another thread's call on the same stream may rewrite or grow (enq_mu is recursive) */ \
+    kyb::DeviceCtx* ctx_; \
+    KYB_TRY(kyb::get_ctx(&ctx_)); \
+    std::lock_guard<std::recursive_mutex> enq_(ctx_->enq_mu); \
     KYB_TRY(kyb::NS::lvm_mul(false, n, (const uint8_t*)d_scalars, (const uint8_t*)d_points, point_stride, (uint8_t*)d_out, \
                              (uint8_t*)d_status, flags, (hipStream_t)stream, &only)); \
     hipLaunchKernelGGL(kyb::PFX##_g1_mul_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
@@ -180,6 +185,9 @@ int kyb_##PFX##_g2_mul_dev(size_t n, const void* d_scalars, const void* d_points
     if (point_stride == 0 && n >= kyb::fb_min_batch(true)) \
         return kyb::fb::run<kyb::PFX##_FbG2>(n, d_scalars, d_points, d_out, d_status, flags, (hipStream_t)stream); \
     const uint8_t* only = nullptr; \
+    kyb::DeviceCtx* ctx_; \
+    KYB_TRY(kyb::get_ctx(&ctx_)); \
+    std::lock_guard<std::recursive_mutex> enq_(ctx_->enq_mu); \
     KYB_TRY(kyb::NS::lvm_mul(true, n, (const uint8_t*)d_scalars, (const uint8_t*)d_points, point_stride, (uint8_t*)d_out, \
                              (uint8_t*)d_status, flags, (hipStream_t)stream, &only)); \
     hipLaunchKernelGGL(kyb::PFX##_g2_mul_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \

@@ -169,6 +169,19 @@ def poly_eval(commits, indices):
     return out, st[:t]
 
 
+def scalar_poly_eval(coeffs, indices):
+    """out[i] = sum_j coeffs[j] * (indices[i] + 1)^j mod l, 32-byte little-endian scalars -- share.PriPoly.Eval
+    (share/poly.go:85-93) for many indices in one launch: PriPoly.Shares (poly.go:96-102)."""
+    lib = load()
+    c = _as_host(coeffs, 32)
+    idx = np.ascontiguousarray(np.asarray(indices, dtype=np.uint32))
+    n, t = idx.shape[0], c.shape[0]
+    out = np.empty((n, 32), dtype=np.uint8)
+    check(lib.kyb_ed25519_scalar_poly_eval(n, idx.ctypes.data, t, c.ctypes.data, out.ctypes.data),
+          "kyb_ed25519_scalar_poly_eval")
+    return out
+
+
 def batch_unmarshal(points):
     """(out, status): N x (*point).UnmarshalBinary (point.go:65-70 -> ge.go:110-150): status[i] != 0 where the reference
     returns an error; out[i] = MarshalBinary of the accepted point (canonical y, point.go:54-58)."""

@@ -141,10 +141,12 @@ class Engine:
     def add(self, group: int, a, b):
         """(out, status): out[i] = a[i] + b[i]  (N x Point.Add).  CUDA tensors stay on the device (enqueue only)."""
         w = self.G1_LEN if group == 1 else self.G2_LEN
-        if _is_torch(a):
+        if _is_torch(a) and a.is_cuda:
             import torch
 
-            x, y = a.contiguous().view(-1, w), b.contiguous().view(-1, w)
+            if not _is_torch(b):
+                b = torch.from_numpy(_host(b, w).copy())
+            x, y = a.contiguous().view(-1, w), b.to(a.device).contiguous().view(-1, w)
             if x.shape != y.shape:
                 raise ValueError("length mismatch")
             out = torch.empty_like(x)
@@ -233,6 +235,17 @@ class Engine:
         fn, nm = self._fn(f"g{group}_poly_eval")
         check(fn(n, idx.ctypes.data, t, c.ctypes.data, out.ctypes.data, st.ctypes.data, flags), nm)
         return out, st[:t]
+
+    def scalar_poly_eval(self, coeffs, indices):
+        """out[i] = sum_j coeffs[j] * (indices[i] + 1)^j mod the group order, 32-byte big-endian scalars (mod.Int) --
+        share.PriPoly.Eval (share/poly.go:85-93) for many indices in one launch: PriPoly.Shares (poly.go:96-102)."""
+        c = _host(coeffs, 32)
+        idx = np.ascontiguousarray(np.asarray(indices, dtype=np.uint32))
+        n, t = idx.shape[0], c.shape[0]
+        out = np.empty((n, 32), dtype=np.uint8)
+        fn, nm = self._fn("scalar_poly_eval")
+        check(fn(n, idx.ctypes.data, t, c.ctypes.data, out.ctypes.data), nm)
+        return out
 
     def g1_msm(self, scalars, points, flags: int = 0):
         return self.msm(1, scalars, points, flags)

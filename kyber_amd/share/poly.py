@@ -8,7 +8,8 @@
   RecoverPubPoly   share/poly.go:480-508   t x basis.Commit(y_j) + Adds: t^2 x (Mul + Add)
                                            -> t MSMs over the same t shares (coefficient k = sum_j L_j[k] * y_j)
   PubPoly.Add      share/poly.go:365-380   t x Add                      -> ONE batch add
-  PriPoly.Shares / Add / Mul / Equal, RecoverSecret, RecoverPriPoly (poly.go:96-283): scalar-field only, host.
+  PriPoly.Shares   share/poly.go:96-102    n x Eval = n x t scalar (Mul + Add) -> ONE scalar-field Horner launch
+  PriPoly.Add / Mul / Equal, RecoverSecret, RecoverPriPoly (poly.go:106-283): scalar-field only, host.
 
 ``group`` is any engine-backed kyber.Group mirror (``edwards25519.NewSuite()``, ``bls12381.NewSuite().G1()``,
 ``bn256.NewSuite().G2()`` ...).  Scalar arithmetic stays on the host (as group/mod does in the reference); every
@@ -33,6 +34,12 @@ def _ops(group):
         if isinstance(pt, m.G2Elt):
             return (lambda s, b: m.ENGINE.mul(2, s, m.G2_BASE if b is None else b, True)[0]), m.g2_msm, m.G2_LEN
     raise TypeError("not an engine-backed group")
+
+
+def _engine_backed(group) -> bool:
+    """the group's scalars are one of the engine's mirrors (and not a host-only stand-in of the CPU tests)"""
+    mod = type(group.Scalar()).__module__
+    return mod.startswith("kyber_amd.group.edwards25519") or mod.startswith("kyber_amd.pairing")
 
 
 def _add_op(group):
@@ -86,7 +93,34 @@ class PriPoly:
             v.Add(v, c)
         return PriShare(i, v)
 
+    # from this many indices one engine launch replaces the host loop (the single-operation policy of INTEGRATION.md 1a:
+    # a device call costs one launch's latency whatever the batch)
+    DEVICE_MIN = 64
+
+    def EvalMany(self, indices) -> list:
+        """[Eval(i) for i in indices] in ONE launch (kyb_<suite>_scalar_poly_eval: a lane per index runs the Horner
+        loop of poly.go:85-93 over Montgomery residues modulo the group order)."""
+        indices = list(indices)
+        sc = self.g.Scalar()
+        cb = b"".join(c.MarshalBinary() for c in self.coeffs)
+        if type(sc).__module__.endswith("edwards25519"):
+            from ..group import edwards25519 as ed
+
+            out = ed.scalar_poly_eval(cb, indices)
+        else:
+            from ..pairing import bls12381, bn254, bn256
+
+            for m in (bls12381, bn256, bn254):
+                if isinstance(sc, m.Scalar):
+                    out = m.ENGINE.scalar_poly_eval(cb, indices)
+                    break
+            else:
+                raise TypeError("not an engine-backed group")
+        return [PriShare(i, self.g.Scalar().UnmarshalBinary(bytes(row))) for i, row in zip(indices, out)]
+
     def Shares(self, n: int) -> list:  # poly.go:96-102
+        if n >= self.DEVICE_MIN and _engine_backed(self.g):
+            return self.EvalMany(range(n))
         return [self.Eval(i) for i in range(n)]
 
     def Coefficients(self) -> list:  # poly.go:176-178

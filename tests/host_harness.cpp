@@ -12,6 +12,7 @@
 #include "../kyber_amd/csrc/ed25519_h2c.cuh"
 #include "../kyber_amd/csrc/fixed_base.cuh"
 #include "../kyber_amd/csrc/coop_slots.cuh"
+#include "../kyber_amd/csrc/scalar_field.cuh"
 #include <pthread.h>
 #include <thread>
 #include <vector>
@@ -476,5 +477,22 @@ void hh_ed_hash(const uint8_t* msg, int len, const uint8_t* dst, int dlen, uint8
     memcpy(d.b, dst, (size_t)dlen);
     d.len = (uint32_t)dlen;
     ed_hash_wire(out, msg, (size_t)len, d);
+}
+// ---- scalar-field Horner (scalar_field.cuh): suite 0 = Ed25519 (little-endian), 1 = BLS12-381, 2 = bn256, 3 = bn254
+int hh_scalar_poly_eval(int suite, int n, const uint8_t* idx4, int t, const uint8_t* coeffs, uint8_t* out) {
+    using namespace kyb::sf;
+    const Mod m = suite == 0 ? make_mod(Q_ED25519, false) : suite == 1 ? make_mod(Q_BLS12381, true) : suite == 2 ? make_mod(Q_BN256, true) : make_mod(Q_BN254, true);
+    std::vector<uint32_t> cm((size_t)8 * (t ? t : 1));
+    for (int j = 0; j < t; j++) {
+        uint32_t r[8];
+        to_mont(r, coeffs + 32 * j, m);
+        for (int i = 0; i < 8; i++) cm[8 * (size_t)j + i] = r[i];
+    }
+    for (int i = 0; i < n; i++) {
+        uint32_t ix;
+        memcpy(&ix, idx4 + 4 * i, 4);
+        horner(out + 32 * i, ix, (size_t)t, cm.data(), m);
+    }
+    return 0;
 }
 }
