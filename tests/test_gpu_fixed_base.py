@@ -75,6 +75,19 @@ def test_arbitrary_base_at_table_sizes_reuse_and_rebuild(name, grp, n):
         torch.cuda.synchronize()
         assert not st.any().item() and not st2.any().item()
         assert torch.equal(out, ref), (name, grp, which)
+        if which == 1:
+            # ... and DIRECTLY against the oracle (not only against the engine's own ladder): 64+ lanes -- first, last,
+            # strided -- of the table walk over an arbitrary base at table size
+            h = int.from_bytes(bytes(hs[1]), "big")
+            omul, gen = (O.g1_mul, O.G1_GEN) if grp == 1 else (O.g2_mul, O.G2_GEN)
+            enc = (getattr(O, "g1_compress", None) or O.g1_marshal) if grp == 1 else (getattr(O, "g2_compress", None) or O.g2_marshal)
+            base_pt = omul(h, gen)
+            lanes = [0, 1, 2, n - 1, n - 2] + list(range(1777, n - 2, n // 60))
+            assert len(lanes) >= 64
+            got, sc = out[lanes].cpu().numpy(), s[lanes].cpu().numpy()
+            for j, i in enumerate(lanes):
+                k = int.from_bytes(bytes(sc[j]), "big")
+                assert bytes(got[j]) == enc(omul(k % m.ORDER, base_pt)), (name, grp, i)
 
 
 @pytest.mark.parametrize("name", SUITES)

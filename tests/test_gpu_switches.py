@@ -1,0 +1,28 @@
+"""Every environment switch the shipped library reads selects a code path that must give the reference's bytes: one
+subprocess per value (the switches are function-local statics, read once), tests/_switch_probe.py holds each workload
+against the oracles.  VERDICT r3 item 2: "test what ships"."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASES = [
+    ("fb", {"KYB_FB_CHAIN": "lane"}), ("fb", {"KYB_FB_CHAIN": "coop"}),
+    ("fb", {"KYB_FB_MIN": "0"}), ("fb", {"KYB_FB_MIN": "1000"}),
+    ("msm", {"KYB_MSM_TAIL": "coop"}), ("msm", {"KYB_MSM_TAIL": "lane"}), ("msm", {"KYB_MSM_SUB": "64"}),
+    ("msm", {"KYB_MSM_GROUPS": "1"}), ("msm", {"KYB_MSM_GROUPS": "2"}),
+    ("lvm", {"KYB_LVM_MIN": "0"}), ("lvm", {"KYB_LVM_MIN": "1000000000"}),
+]
+
+
+@pytest.mark.parametrize("what,env", CASES, ids=[f"{w}-{'-'.join(f'{k}={v}' for k, v in e.items())}" for w, e in CASES])
+def test_switch(what, env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_switch_probe.py"), what], env=e, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and f"switch-probe ok {what}" in r.stdout, r.stdout[-3000:]

@@ -14,8 +14,40 @@ import os
 import re
 import sys
 
-d, tag = sys.argv[1], sys.argv[2]
-tag_of = dict(a.split("=", 1) for a in sys.argv[3:])
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import source_digest  # noqa: E402
+
+ALLOW_STALE = "--allow-stale" in sys.argv
+argv = [a for a in sys.argv if a != "--allow-stale"]
+d, tag = argv[1], argv[2]
+tag_of = dict(a.split("=", 1) for a in argv[3:])
+NOW = source_digest.digests()
+C = "kyber_amd/csrc/"
+# the sources a kernel is compiled from (beyond hd.h / context.h / include/kyber_hip.h, which every kernel shares and
+# whose edits are interface-level): a profile is stale once any of them differs from what the profiled binary was built from
+COMMON_PAIRING = [C + "mont.cuh", C + "curve.cuh", C + "tower.cuh"]
+SOURCES = {
+    "ed": [C + "ed25519.hip", C + "fe25519.cuh", C + "ge25519.cuh"],
+    "bls12381": [C + "bls12381_pair.hip", C + "tower_vm.cuh", C + "gen_tower_vm.py", C + "bls12381_tvm.h", C + "bls12381_prep.hip", C + "bls12381.cuh"] + COMMON_PAIRING,
+    "verify": [C + "bls12381_pair.hip", C + "tower_vm.cuh", C + "gen_tower_vm.py", C + "bls12381_tvm.h", C + "bls12381_prep.hip", C + "bls12381.cuh", C + "bls12381_h2c.cuh"] + COMMON_PAIRING,
+    "gtmul": [C + "bls12381_pair.hip", C + "tower_vm.cuh", C + "gen_tower_vm.py", C + "bls12381_tvm.h"],
+    "bn256": [C + "bn256_pair.hip", C + "bn_pair.inc", C + "tower_vm.cuh", C + "gen_tower_vm.py", C + "bn256.cuh", C + "bn_suite.inc"] + COMMON_PAIRING,
+    "bn254": [C + "bn254_pair.hip", C + "bn_pair.inc", C + "tower_vm.cuh", C + "gen_tower_vm.py", C + "bn254.cuh", C + "bn_suite.inc"] + COMMON_PAIRING,
+    "mul": [C + "bls12381.hip", C + "bls12381_lvm.cuh", C + "lane_vm.cuh", C + "gen_lane_vm.py", C + "bls12381.cuh", C + "pairing_abi.cuh"] + COMMON_PAIRING,
+    "mulperlane": [C + "bls12381.hip", C + "bls12381.cuh", C + "pairing_abi.cuh"] + COMMON_PAIRING,
+    "msm_bls": [C + "bls12381_msm.hip", C + "msm.cuh", C + "msm_ws.cuh", C + "coop_slots.cuh", C + "bls12381.cuh"] + COMMON_PAIRING,
+    "fb": [C + "fixed_base.cuh", C + "pairing_abi.cuh", C + "bls12381.hip", C + "bls12381.cuh", C + "coop_slots.cuh"] + COMMON_PAIRING,
+}
+
+
+def stale(prefix, tag):
+    """names of the kernel's sources that changed since the profile `tag` was taken (None: the profile carries no
+    source digests at all -- rounds 1-3)"""
+    meta = os.path.join(d, f"{tag}_{prefix}_meta.json")
+    if not os.path.exists(meta):
+        return None
+    then = json.load(open(meta))["sources"]
+    return [f for f in SOURCES[prefix] if then.get(f) != NOW.get(f)]
 
 
 def counters(path):
@@ -37,17 +69,24 @@ def kernel(cs, sub):
 
 
 def entry(prefix, sub, units):
-    tag = tag_of.get(prefix, sys.argv[2])
+    tag = tag_of.get(prefix, argv[2])
     sq = kernel(counters(os.path.join(d, f"{tag}_{prefix}_sq.txt")), sub)
     fe = kernel(counters(os.path.join(d, f"{tag}_{prefix}_fetch.txt")), sub)
     wr = kernel(counters(os.path.join(d, f"{tag}_{prefix}_write.txt")), sub)
     if not sq:
         return None
+    changed = stale(prefix, tag)
+    if changed is None or changed:
+        why = "no source digests recorded with it" if changed is None else "changed since: " + ", ".join(changed)
+        if not ALLOW_STALE:
+            print(f"REFUSED {prefix} ({sub}): profile {tag} is of another binary ({why})", file=sys.stderr)
+            return None
     e = {"units_per_launch": units,
          "valu_busy": 4 * sq["SQ_ACTIVE_INST_VALU"] / (1024 * sq["GRBM_GUI_ACTIVE"] / 8),
          "valu_insts_per_unit": sq["SQ_INSTS_VALU"] * 64 / units,
          "wait_share_of_wave_cycles": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
-         "source": f"profiles/{tag}_{prefix}_{{sq,fetch,write}}.txt ({sub})"}
+         "source": f"profiles/{tag}_{prefix}_{{sq,fetch,write}}.txt ({sub})",
+         "sources_unchanged_since_profile": changed == []}
     if fe and wr:
         e["hbm_bytes_per_launch"] = (fe["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024
         e["fetch_bytes"], e["write_bytes"] = fe["FETCH_SIZE"] * 1024, wr["WRITE_SIZE"] * 1024
