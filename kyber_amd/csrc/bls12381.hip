@@ -11,6 +11,7 @@
 //  bls12381_msm.hip -- split only so that the three compile in parallel)
 #include "bls12381.cuh"
 #include "bls12381_lvm.cuh"
+#include "bls12381_fb.cuh"
 #include "pairing_abi.cuh"
 
 KYB_DEFINE_MUL_ABI(bls12381, bls, 48, 96)

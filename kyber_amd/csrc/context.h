@@ -57,6 +57,10 @@ struct DeviceCtx {
     std::mutex stage_mu;
     // streams of the chunk-pipelined host paths (H2D | compute | D2H), created on first use
     hipStream_t pipe[3] = {};
+    // fixed_base.cuh: per (workspace kind, stream), the wire bytes + flag bytes of the base whose table the last call
+    // through the HOST-buffer entry points enqueued there -- a hint (the chain kernel decides on the device) that lets
+    // small same-base batches take the table path.  Guarded by mu; gone with the context at kyb_shutdown.
+    std::map<std::pair<int, hipStream_t>, std::string> fb_hint;
     // page-locked staging of those paths: six chunk slots each way (allocated on first use).  A copy from pageable memory is staged
     // by the runtime at ~10 GB/s and blocks the issuing thread; through these slots the DMA is asynchronous and the
     // host's own memcpy into / out of them overlaps the kernels (ed25519.hip mul_host).
@@ -110,6 +114,19 @@ enum { WS_MSM = 0, WS_ED = 1, WS_PAIR = 2, WS_LVM = 3, WS_SCALAR = 4, WS_FB = 16
 // Grow (never shrink) the (kind, stream) workspace; caller holds no lock.
 // `grew` (optional): set when the buffer was (re)allocated by this call -- its contents are undefined
 int ctx_workspace(DeviceCtx* ctx, int kind, hipStream_t stream, size_t bytes, void** out, bool* grew = nullptr);
+
+// fixed-base table hints (DeviceCtx::fb_hint): set after a successful enqueue, cleared (key == nullptr) by any call that
+// may replace the table without the host knowing its base
+inline void fb_hint_set(DeviceCtx* ctx, int kind, hipStream_t stream, const std::string* key) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (key) ctx->fb_hint[std::make_pair(kind, stream)] = *key;
+    else ctx->fb_hint.erase(std::make_pair(kind, stream));
+}
+inline bool fb_hint_is(DeviceCtx* ctx, int kind, hipStream_t stream, const std::string& key) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->fb_hint.find(std::make_pair(kind, stream));
+    return it != ctx->fb_hint.end() && it->second == key;
+}
 
 // A host-buffer call: holds the device's staging pool for its duration and hands out slots in order.
 struct StageScope {

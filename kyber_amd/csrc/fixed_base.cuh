@@ -1,21 +1,36 @@
 // Fixed-base scalar multiplication for the same-base batches of the pairing suites: out_i = k_i * P for ONE point P and
 // many scalars -- share.PriPoly.Commit (share/poly.go:143-149: every coefficient times the same base), key generation
 // (x * G2.Base()), `Point.Mul(s, nil)`.  The reference runs its variable-base ladder n times; with the base shared, a
-// table of its multiples turns a multiplication into 26 table additions and NO doublings:
+// table of its multiples turns a multiplication into ~26 table additions and NO doublings:
 //
-//   k = sum_w d_w 1024^w, signed digits d_w in [-511, 512] (w = 0..25, the last one holding the top bits + carry), and
-//   T[w][j] = (j + 1) 1024^w P in affine form (512 entries per window), so  k P = sum_w sign(d_w) T[w][|d_w| - 1]:
-//   26 mixed additions in XYZZ form (curve.cuh, 8M + 2S each) + one inversion, about a sixth of the GLV ladder's field
-//   multiplications and a tenth of the plain ladder's (bn256 G2).  (Radix 256 -- 33 additions, a quarter of the table
-//   -- was the first version: 6.6 ms per 2^20 BLS12-381 G1 scalars against this one's figure in DESIGN.md.)  No endomorphism is involved, so the result is the
-//   integer multiple for EVERY decodable base (bn256's G2 points outside the order-n subgroup included) and every
-//   256-bit scalar, like the reference's double-and-add.
+//   a sub-scalar s = sum_w d_w 1024^w with signed digits d_w in [-511, 512], and T[w][e] = (e + 1) 1024^w P in affine
+//   form (512 entries per window), so  s P = sum_w sign(d_w) T[w][|d_w| - 1]:  mixed additions in XYZZ form (curve.cuh,
+//   8M + 2S each) + one inversion, about a sixth of the GLV ladder's field multiplications and a tenth of the plain
+//   ladder's (bn256 G2).
 //
-// The table costs a chain of 250 dependent doublings (one lane: ~2.5 ms on G1, three times that on G2) + 26 x 512
-// independent small multiples: it pays for itself from ~2^17 scalars, or at any batch size once it exists -- the
-// workspace keeps the last base's table per (suite, group, stream), and the chain kernel recognises the base on the
-// device (no host round trip).  Table: 26 x 512 x (2 field elements) = 1.3 MB (BLS12-381 G1) .. 2.6 MB (G2): inside the
-// 4 MB of L2 each XCD has.
+// How many windows, and of what, is the group's POLICY (round 4):
+//   * plain (bn256 / bn254, both groups): ONE sub-scalar -- k itself, 26 windows; no endomorphism is involved, so the
+//     result is the integer multiple for EVERY decodable base (bn256's G2 points outside the order-n subgroup included)
+//     and every 256-bit scalar, like the reference's double-and-add;
+//   * BLS12-381 G1: k = q z^2 + rem (plain long division), two sub-scalars of 13 windows over the entry's two IMAGES
+//     (x, y) and z^2 P = (beta x, -y) -- 26 additions as before, but the table's doubling chain, the one serial part of
+//     a table build, is 120 doublings instead of 250;
+//   * BLS12-381 G2: k = a0 + a1 |z| + a2 |z|^2 + a3 |z|^3, four sub-scalars of 7 windows over the images
+//     |z|^j Q = (-1)^j psi^j(Q): 28 additions, a chain of 60 doublings instead of 250.
+//   The splits are integer identities, the images hold on the order-r subgroup -- which is what UnmarshalBinary
+//   guarantees for BLS12-381 (and KYB_F_TRUSTED vouches for).
+//
+// Membership of the base, where it is a rule of UnmarshalBinary and the caller has not vouched for the point, is not
+// tested in the lone lane that decodes the base (a 128-bit ladder there cost as much as half the doubling chain): the
+// finished table's plain image answers it -- Scott's criterion z^2 P = -phi(P) (G1: 13 additions), |z| Q = -psi(Q) (G2:
+// 7), [n] Q = infinity (bn254 G2: 26) -- in one lane between the table and the batch (0.1 - 0.3 ms, and only when the
+// table is new); a base that fails gets status 2 for every coefficient, as the reference's UnmarshalBinary would fail
+// once, for all of them.
+//
+// The table costs the chain (four cooperating lanes, coop_slots.cuh) + NW x 512 independent small multiples: it pays
+// for itself from ~2^17 scalars, or at any batch size once it exists -- the workspace keeps the last base's table per
+// (suite, group, stream), and the chain kernel recognises the base on the device (no host round trip).  Table: 1.3 MB
+// (BLS12-381 G1) .. 2.8 MB (G2): inside the 4 MB of L2 each XCD has.
 #pragma once
 #include "coop_slots.cuh"
 #include "curve.cuh"
@@ -26,52 +41,59 @@
 namespace kyb {
 namespace fb {
 
-constexpr int WBITS = 10, NWIN = (256 + WBITS) / WBITS, NENT = 1 << (WBITS - 1), WIRE_MAX = 192;
-static_assert(NWIN * WBITS >= 257, "the last window must hold the recoding's carry");
-constexpr uint64_t MAGIC = 0x6b79626662763032ull;  // "kybfbv02"
+constexpr int WBITS = 10, NENT = 1 << (WBITS - 1), WIRE_MAX = 192;
+constexpr uint64_t MAGIC = 0x6b79626662763033ull;  // "kybfbv03"
 
 // head of the workspace: which base the table below belongs to
 struct Header {
     uint64_t magic;
     uint32_t key_flags;   // the decode-relevant flag bits the base was decoded under
     uint32_t key_len;     // bytes of its wire form
-    uint32_t status;      // UnmarshalBinary's verdict on it (ST_OK = 0)
+    uint32_t status;      // UnmarshalBinary's verdict on it (ST_OK = 0); the membership verdict arrives late (below)
     uint32_t inf;         // it is the point at infinity
     uint32_t fresh;       // set by the chain kernel of THIS call: the table has to be rebuilt
-    uint32_t pad;
+    uint32_t member_pending;  // the base's subgroup membership is still to be read off the finished table
     uint8_t key[WIRE_MAX];
 };
 
-template <class F>
-struct Entry {  // affine multiple; (0, 0) -- not a point of y^2 = x^3 + b, b != 0 -- stands for infinity
-    F x, y;
+// affine multiple under the policy's NI images; (0, 0) -- not a point of y^2 = x^3 + b, b != 0 -- stands for infinity
+// (only a plain table of a base outside the prime-order subgroup can hold one)
+template <class F, int NI>
+struct Entry {
+    F x[NI], y[NI];
 };
 
-// window w of k: bits [WBITS w, WBITS w + WBITS) of the 256-bit integer (zero beyond bit 255)
-KYB_HD int window_bits(const uint32_t (&k)[8], int w) {
-    const int bit = w * WBITS, idx = bit >> 5, sh = bit & 31;
-    if (idx >= 8) return 0;
-    uint32_t v = k[idx] >> sh;
-    if (sh + WBITS > 32 && idx + 1 < 8) v |= k[idx + 1] << (32 - sh);
-    return (int)(v & ((1u << WBITS) - 1));
-}
-// signed radix-2^WBITS digits: d[w] in [-(NENT - 1), NENT]
-KYB_HD void digits(int (&d)[NWIN], const uint32_t (&k)[8]) {
-    int carry = 0;
+// The plain policy: one sub-scalar, the 256-bit integer itself
+template <class F>
+struct Plain {
+    static constexpr int NI = 1, NW = (256 + WBITS) / WBITS;
+    static_assert(NW * WBITS >= 257, "the last window must hold the recoding's carry");
+    KYB_HD static void split(uint32_t (&sub)[1][8], const uint32_t (&k)[8]) {
 #pragma unroll
-    for (int w = 0; w < NWIN; w++) {
-        const int v = window_bits(k, w) + carry;
-        carry = v > NENT ? 1 : 0;
-        d[w] = v - (carry << WBITS);
+        for (int i = 0; i < 8; i++) sub[0][i] = k[i];
     }
+    KYB_HD static void images(Entry<F, 1>& e, const F& x, const F& y) {
+        e.x[0] = x;
+        e.y[0] = y;
+    }
+};
+
+// the next signed radix-2^WBITS digit of s, in [-(NENT - 1), NENT]; s is shifted down by one window
+KYB_HD int next_digit(uint32_t (&s)[8], int& carry) {
+    const int v = (int)(s[0] & ((1u << WBITS) - 1)) + carry;
+#pragma unroll
+    for (int i = 0; i < 7; i++) s[i] = (s[i] >> WBITS) | (s[i + 1] << (32 - WBITS));
+    s[7] >>= WBITS;
+    carry = v > NENT ? 1 : 0;
+    return v - (carry << WBITS);
 }
 
-// q[w] = 2^(WBITS w) P  (Jacobian): the one serial part of the table
-template <class F>
-KYB_HD void chain(Jac<F> (&q)[NWIN], const Aff<F>& base) {
+// q[w] = 2^(WBITS w) P  (Jacobian): the one serial part of the table (one lane; the kernel below runs it on four)
+template <int NW, class F>
+KYB_HD void chain(Jac<F> (&q)[NW], const Aff<F>& base) {
     jac_from_aff(q[0], base);
 #pragma unroll 1
-    for (int w = 1; w < NWIN; w++) {
+    for (int w = 1; w < NW; w++) {
         Jac<F> t = q[w - 1];
 #pragma unroll 1
         for (int i = 0; i < WBITS; i++) jac_dbl_inl(t, t);
@@ -79,9 +101,9 @@ KYB_HD void chain(Jac<F> (&q)[NWIN], const Aff<F>& base) {
     }
 }
 
-// e = (j + 1) Q in affine form, j in [0, NENT)
+// a = (j + 1) Q in affine form, j in [0, NENT)
 template <class F>
-KYB_HD void entry(Entry<F>& e, const Jac<F>& q, int j) {
+KYB_HD void entry(Aff<F>& a, const Jac<F>& q, int j) {
     const int m = j + 1;  // 1 .. NENT
     Jac<F> acc;
     jac_set_inf(acc);
@@ -90,95 +112,92 @@ KYB_HD void entry(Entry<F>& e, const Jac<F>& q, int j) {
         jac_dbl_inl(acc, acc);
         if ((m >> bit) & 1) jac_add_inl<F, false>(acc, acc, q);
     }
-    Aff<F> a;
     jac_to_aff(a, acc);
-    e.x = a.x;
-    e.y = a.y;
+}
+template <class P, class F>
+KYB_HD void entry_images(Entry<F, P::NI>& e, const Jac<F>& q, int j) {
+    Aff<F> a;
+    entry(a, q, j);
     if (a.inf) {
-        f_zero(e.x);
-        f_zero(e.y);
+#pragma unroll
+        for (int i = 0; i < P::NI; i++) {
+            f_zero(e.x[i]);
+            f_zero(e.y[i]);
+        }
+    } else {
+        P::images(e, a.x, a.y);
     }
 }
 
-// r = k * P from P's table (tab[w * NENT + j]); r comes back in Jacobian form
-template <class F>
-KYB_HD void mul(Jac<F>& r, const uint32_t (&k)[8], const Entry<F>* __restrict__ tab) {
-    Xyzz<F> acc;
-    xyzz_set_inf(acc);
+// acc += s * (image j of the table's base), windows 0 .. nw - 1 of s (consumed)
+template <int NI, class F>
+KYB_HD void walk(Xyzz<F>& acc, uint32_t (&s)[8], int j, int nw, const Entry<F, NI>* __restrict__ tab) {
     int carry = 0;
 #pragma unroll 1
-    for (int w = 0; w < NWIN; w++) {
-        // the digits of digits(), produced as the walk needs them
-        const int v = window_bits(k, w) + carry;
-        carry = v > NENT ? 1 : 0;
-        const int dw = v - (carry << WBITS);
+    for (int w = 0; w < nw; w++) {
+        const int dw = next_digit(s, carry);
         if (dw == 0) continue;
         const int a = dw < 0 ? -dw : dw;
-        const Entry<F> e = tab[w * NENT + (a - 1)];
-        if (f_is_zero(e.x) & f_is_zero(e.y)) continue;  // that multiple of the base is the point at infinity
-        F y = e.y, ny;
-        f_neg(ny, e.y);
+        const F* e = reinterpret_cast<const F*>(tab + (w * NENT + (a - 1)));  // x[0 .. NI), y[0 .. NI)
+        const F x = e[j];
+        F y = e[NI + j], ny;
+        if (f_is_zero(x) & f_is_zero(y)) continue;  // that multiple of the base is the point at infinity
+        f_neg(ny, y);
         f_cmov(y, ny, dw < 0);
-        xyzz_madd(acc, e.x, y);
+        xyzz_madd(acc, x, y);
     }
+}
+// r = k * P from P's table under policy P_; r comes back in Jacobian form
+template <class P_, class F>
+KYB_HD void mul(Jac<F>& r, const uint32_t (&k)[8], const Entry<F, P_::NI>* __restrict__ tab) {
+    uint32_t sub[P_::NI][8];
+    P_::split(sub, k);
+    Xyzz<F> acc;
+    xyzz_set_inf(acc);
+#pragma unroll 1
+    for (int j = 0; j < P_::NI; j++) {
+        uint32_t s[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) s[i] = sub[j][i];
+        walk<P_::NI>(acc, s, j, P_::NW, tab);
+    }
+    xyzz_to_jac(r, acc);
+}
+// r = s * P for an integer s below 2^(WBITS nw - 1), from the PLAIN image alone: the integer multiple for any point of
+// the curve -- what the membership criteria are evaluated with
+template <int NI, class F>
+KYB_HD void mul_plain(Jac<F>& r, const uint32_t (&k)[8], int nw, const Entry<F, NI>* __restrict__ tab) {
+    uint32_t s[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) s[i] = k[i];
+    Xyzz<F> acc;
+    xyzz_set_inf(acc);
+    walk<NI>(acc, s, 0, nw, tab);
     xyzz_to_jac(r, acc);
 }
 
 
 #if defined(__HIPCC__)
 // ---- kernels and the enqueue routine, over a per-(suite, group) traits type T:
-//   F; decode(Aff<F>&, wire, flags) -> status; encode(out, Aff<F>, flags); wire_size(flags); out_size(flags);
-//   scalar(k[8], wire32); KIND (workspace kind); KEY_FLAGS (the flag bits decode() looks at)
+//   F; P (the policy: NI, NW, split, images); decode_on_curve(Aff<F>&, wire, flags) -> status (every rule of
+//   UnmarshalBinary except subgroup membership); needs_member(flags); member(Aff<F> base, table) -> bool;
+//   encode(out, Aff<F>, flags); wire_size(flags); out_size(flags); scalar(k[8], wire32); KIND (workspace kind);
+//   KEY_FLAGS (the flag bits decoding looks at)
 constexpr size_t HDR_BYTES = 512;
 template <class T>
-constexpr size_t chain_bytes() { return ((sizeof(Jac<typename T::F>) * NWIN + 255) / 256) * 256; }
+constexpr size_t chain_bytes() { return ((sizeof(Jac<typename T::F>) * T::P::NW + sizeof(Aff<typename T::F>) + 255) / 256) * 256; }
 template <class T>
-constexpr size_t ws_bytes() { return HDR_BYTES + chain_bytes<T>() + sizeof(Entry<typename T::F>) * NWIN * NENT; }
-
-// One lane: is the table already this base's?  Otherwise decode the base and walk the doubling chain.
+constexpr size_t ws_bytes() { return HDR_BYTES + chain_bytes<T>() + sizeof(Entry<typename T::F, T::P::NI>) * T::P::NW * NENT; }
 template <class T>
-__global__ __launch_bounds__(64) void chain_kernel(uint8_t* __restrict__ ws, const uint8_t* __restrict__ base, uint32_t flags) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    using F = typename T::F;
-    Header* h = reinterpret_cast<Header*>(ws);
-    const uint32_t kf = flags & T::KEY_FLAGS, len = (uint32_t)T::wire_size(flags);
-    bool same = h->magic == MAGIC && h->key_flags == kf && h->key_len == len;
-    for (uint32_t i = 0; i < len && same; i++) same = h->key[i] == base[i];
-    if (same) {
-        h->fresh = 0;
-        return;
-    }
-    h->magic = 0;
-    Aff<F> a;
-    const int st = T::decode(a, base, flags);
-    h->status = (uint32_t)st;
-    h->inf = (st == 0 && a.inf) ? 1u : 0u;
-    h->key_flags = kf;
-    h->key_len = len;
-    for (uint32_t i = 0; i < len; i++) h->key[i] = base[i];
-    h->fresh = 1;
-    if (st == 0 && !a.inf) {
-        Jac<F>* q = reinterpret_cast<Jac<F>*>(ws + HDR_BYTES);
-        Jac<F> t;
-        jac_from_aff(t, a);
-        q[0] = t;
-#pragma unroll 1
-        for (int w = 1; w < NWIN; w++) {
-#pragma unroll 1
-            for (int i = 0; i < WBITS; i++) jac_dbl_inl(t, t);
-            q[w] = t;
-        }
-    }
-    __threadfence();
-    h->magic = MAGIC;
+__device__ __forceinline__ Aff<typename T::F>* base_slot(uint8_t* ws) {  // the decoded base, kept for the membership test
+    return reinterpret_cast<Aff<typename T::F>*>(ws + HDR_BYTES + sizeof(Jac<typename T::F>) * T::P::NW);
 }
-// The same on FOUR cooperating lanes (coop_slots.cuh: a doubling is three product levels deep instead of seven
-// multiplications) -- NOT the default: written at the end of round 3 without GPU time left to measure it, selected by
-// KYB_FB_CHAIN=coop for the A/B run that decides (the slot arithmetic itself runs in the MSM's reduce kernel and, on the
-// CPU, with threads as lanes).  One workgroup of four lanes; lane 0 does what chain_kernel's lane does before and after
-// the doublings.
+
+// Is the table already this base's?  Otherwise lane 0 decodes the base and FOUR cooperating lanes walk the doubling
+// chain (coop_slots.cuh: a doubling is three product levels deep instead of seven multiplications).  One workgroup of
+// four lanes.
 template <class T>
-__global__ __launch_bounds__(64, 2) void chain_coop_kernel(uint8_t* __restrict__ ws, const uint8_t* __restrict__ base, uint32_t flags) {
+__global__ __launch_bounds__(64, 2) void chain_kernel(uint8_t* __restrict__ ws, const uint8_t* __restrict__ base, uint32_t flags) {
     using F = typename T::F;
     constexpr int P = 0, TMP = 3;
     __shared__ coop::Slot<F> S[TMP + coop::TEMPS];
@@ -193,20 +212,24 @@ __global__ __launch_bounds__(64, 2) void chain_coop_kernel(uint8_t* __restrict__
         go = 0;
         if (same) {
             h->fresh = 0;
+            h->member_pending = 0;
         } else {
             h->magic = 0;
             Aff<F> a;
-            const int st = T::decode(a, base, flags);
+            const int st = T::decode_on_curve(a, base, flags);
+            const bool build = st == 0 && !a.inf;
             h->status = (uint32_t)st;
             h->inf = (st == 0 && a.inf) ? 1u : 0u;
             h->key_flags = kf;
             h->key_len = len;
             for (uint32_t i = 0; i < len; i++) h->key[i] = base[i];
             h->fresh = 1;
-            if (st == 0 && !a.inf) {
+            h->member_pending = (build && T::needs_member(flags)) ? 1u : 0u;
+            if (build) {
                 Jac<F> t;
                 jac_from_aff(t, a);
                 q[0] = t;
+                *base_slot<T>(ws) = a;
                 S[P].f = t.X;
                 S[P + 1].f = t.Y;
                 S[P + 2].f = t.Z;
@@ -220,7 +243,7 @@ __global__ __launch_bounds__(64, 2) void chain_coop_kernel(uint8_t* __restrict__
     __syncthreads();
     if (!go) return;  // uniform: the table is current, or there is nothing to build
 #pragma unroll 1
-    for (int w = 1; w < NWIN; w++) {
+    for (int w = 1; w < T::P::NW; w++) {
 #pragma unroll 1
         for (int i = 0; i < WBITS; i++) coop::dbl<F>(S, r, P, TMP, true);
         if (r < 3) reinterpret_cast<F*>(q + w)[r] = S[P + r].f;
@@ -238,21 +261,34 @@ __global__ __launch_bounds__(64) void table_kernel(uint8_t* __restrict__ ws) {
     const Header* h = reinterpret_cast<const Header*>(ws);
     if (!h->fresh || h->status || h->inf) return;
     const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (t >= NWIN * NENT) return;
+    if (t >= T::P::NW * NENT) return;
     const int w = t / NENT, j = t - w * NENT;
     const Jac<F> q = reinterpret_cast<const Jac<F>*>(ws + HDR_BYTES)[w];
-    Entry<F> e;
-    entry(e, q, j);
-    reinterpret_cast<Entry<F>*>(ws + HDR_BYTES + chain_bytes<T>())[t] = e;
+    Entry<F, T::P::NI> e;
+    entry_images<typename T::P>(e, q, j);
+    reinterpret_cast<Entry<F, T::P::NI>*>(ws + HDR_BYTES + chain_bytes<T>())[t] = e;
+}
+// One lane, between the table and the batch: a fresh base's subgroup membership, read off the table's plain image (a
+// kernel of its own so that the multiplication kernel's register allocation is the walk's alone)
+template <class T>
+__global__ __launch_bounds__(64, T::MUL_WAVES) void member_kernel(uint8_t* __restrict__ ws) {
+    using F = typename T::F;
+    Header* h = reinterpret_cast<Header*>(ws);
+    if (threadIdx.x != 0 || blockIdx.x != 0 || !h->member_pending) return;
+    const auto* tab = reinterpret_cast<const Entry<F, T::P::NI>*>(ws + HDR_BYTES + chain_bytes<T>());
+    const Aff<F> a = *base_slot<T>(ws);
+    if (!T::member(a, tab)) h->status = 2u;  // ST_NOT_IN_SUBGROUP: every coefficient fails alike
+    h->member_pending = 0;
 }
 // One lane per scalar
 template <class T>
-__global__ __launch_bounds__(64, 2) void mul_kernel(size_t n, const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ ws,
+__global__ __launch_bounds__(64, T::MUL_WAVES) void mul_kernel(size_t n, const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ ws,
                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ status, uint32_t flags) {
     using F = typename T::F;
+    const Header* h = reinterpret_cast<const Header*>(ws);
+    const auto* tab = reinterpret_cast<const Entry<F, T::P::NI>*>(ws + HDR_BYTES + chain_bytes<T>());
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    const Header* h = reinterpret_cast<const Header*>(ws);
     const size_t osz = T::out_size(flags);
     uint8_t* o = out + osz * idx;
     const uint32_t st = h->status;
@@ -271,37 +307,39 @@ __global__ __launch_bounds__(64, 2) void mul_kernel(size_t n, const uint8_t* __r
         uint32_t k[8];
         T::scalar(k, scalars + 32 * idx);
         Jac<F> r;
-        mul(r, k, reinterpret_cast<const Entry<F>*>(ws + HDR_BYTES + chain_bytes<T>()));
+        mul<typename T::P>(r, k, tab);
         jac_to_aff(a, r);
     }
     T::encode(o, a, flags);
     if (status) status[idx] = 0;
 }
 
-// Enqueue chain (if the base changed) + table + multiplication on `st`
+// Enqueue chain (if the base changed) + table + multiplication on `st`.  `key`: the base's wire bytes + flag bytes when
+// the caller has them on the host (the host-buffer entry points) -- remembered per (kind, stream) as a HINT that the
+// table of that base is (about to be) there, which lets small batches take this path (pairing_abi.cuh); a call without
+// it (device pointers) forgets the hint, since it may replace the table.
 template <class T>
-int run(size_t n, const void* d_scalars, const void* d_base, void* d_out, void* d_status, uint32_t flags, hipStream_t st) {
+int run(size_t n, const void* d_scalars, const void* d_base, void* d_out, void* d_status, uint32_t flags, hipStream_t st,
+        const std::string* key = nullptr) {
     DeviceCtx* ctx;
     if (int rc = get_ctx(&ctx)) return rc;
     std::lock_guard<std::recursive_mutex> enq_lock(ctx->enq_mu);
     void* ws;
     bool grew = false;
+    fb_hint_set(ctx, T::KIND, st, nullptr);
     if (int rc = ctx_workspace(ctx, T::KIND, st, ws_bytes<T>(), &ws, &grew)) return rc;
     if (grew) KYB_HIP_CHECK(hipMemsetAsync(ws, 0, HDR_BYTES, st));
-    static const bool coop_chain = [] {
-        const char* e = getenv("KYB_FB_CHAIN");
-        return e && e[0] == 'c';
-    }();
-    if (coop_chain) hipLaunchKernelGGL(chain_coop_kernel<T>, dim3(1), dim3(4), 0, st, (uint8_t*)ws, (const uint8_t*)d_base, flags);
-    else hipLaunchKernelGGL(chain_kernel<T>, dim3(1), dim3(64), 0, st, (uint8_t*)ws, (const uint8_t*)d_base, flags);
-    hipLaunchKernelGGL(table_kernel<T>, dim3((NWIN * NENT + 63) / 64), dim3(64), 0, st, (uint8_t*)ws);
-    hipLaunchKernelGGL(mul_kernel<T>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, (const uint8_t*)d_scalars,
-                       (const uint8_t*)ws, (uint8_t*)d_out, (uint8_t*)d_status, flags);
+    hipLaunchKernelGGL(chain_kernel<T>, dim3(1), dim3(4), 0, st, (uint8_t*)ws, (const uint8_t*)d_base, flags);
+    hipLaunchKernelGGL(table_kernel<T>, dim3((T::P::NW * NENT + 63) / 64), dim3(64), 0, st, (uint8_t*)ws);
+    if (T::needs_member(flags)) hipLaunchKernelGGL(member_kernel<T>, dim3(1), dim3(64), 0, st, (uint8_t*)ws);
+    hipLaunchKernelGGL(mul_kernel<T>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, (const uint8_t*)d_scalars, (const uint8_t*)ws,
+                       (uint8_t*)d_out, (uint8_t*)d_status, flags);
     if (hipGetLastError() != hipSuccess) {
         hipMemsetAsync(ws, 0, HDR_BYTES, st);  // never trust a half-built table
         set_error("fixed-base multiplication: launch failed");
         return KYB_E_HIP;
     }
+    fb_hint_set(ctx, T::KIND, st, key);
     return KYB_OK;
 }
 #endif  // __HIPCC__

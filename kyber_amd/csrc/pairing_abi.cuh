@@ -31,20 +31,6 @@ static inline size_t fb_min_batch(bool g2) {
     return size_t(1) << 17;  // measured break-even, table build included: ~1e5 (G1) / ~0.5e5-0.9e5 (G2) scalars
 }
 constexpr size_t FB_MIN_KNOWN = 64;  // ... and from this many when the table is (about to be) there anyway
-// What the HOST-buffer entry points know about the table on (device, kind, null stream): the wire bytes of the base
-// it was last built for.  A hint only -- the chain kernel decides on the device.
-static inline bool fb_host_known(int kind, const std::string& key, bool remember) {
-    static std::mutex mu;
-    static std::map<std::pair<int, int>, std::string> last;
-    int dev = 0;
-    hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lk(mu);
-    std::string& k = last[std::make_pair(dev, kind)];
-    const bool hit = k == key;
-    if (remember) k = key;
-    return hit;
-}
-
 // Host entry points stage through the per-device pool of context.h (StageScope / StageBuf).
 }  // namespace kyb
 
@@ -62,13 +48,23 @@ static inline bool fb_host_known(int kind, const std::string& key, bool remember
 #ifndef KYB_G2_MUL_WAVES
 #define KYB_G2_MUL_WAVES 1
 #endif
+#ifndef KYB_FB_G1_WAVES
+#define KYB_FB_G1_WAVES 2
+#endif
+#ifndef KYB_FB_G2_WAVES
+#define KYB_FB_G2_WAVES 2
+#endif
 #define KYB_DEFINE_MUL_ABI(PFX, NS, G1SZ, G2SZ) \
 namespace kyb { \
 struct PFX##_FbG1 { \
     using F = NS::fp; \
+    using P = NS::fb_g1_policy; \
+    static constexpr int MUL_WAVES = KYB_FB_G1_WAVES; /* register budget of fb::mul_kernel in waves per SIMD */ \
     static constexpr int KIND = WS_FB + 2 * fb_suite_id(#PFX); \
     static constexpr uint32_t KEY_FLAGS = KYB_F_UNCOMPRESSED | KYB_F_TRUSTED(0); \
-    __host__ __device__ static int decode(Aff<F>& a, const uint8_t* in, uint32_t flags) { return NS::g1_decode_f(a, in, flags, 0); } \
+    __host__ __device__ static int decode_on_curve(Aff<F>& a, const uint8_t* in, uint32_t flags) { return P::decode_on_curve(a, in, flags); } \
+    __host__ __device__ static bool needs_member(uint32_t flags) { return P::needs_member(flags); } \
+    __device__ static bool member(const Aff<F>& a, const fb::Entry<F, P::NI>* tab) { return P::member(a, tab); } \
     __host__ __device__ static void encode(uint8_t* out, const Aff<F>& a, uint32_t flags) { NS::g1_encode_f(out, a, flags); } \
     __host__ __device__ static size_t wire_size(uint32_t flags) { return NS::g1_wire_size(flags); } \
     __host__ __device__ static size_t out_size(uint32_t flags) { return NS::g1_out_size(flags); } \
@@ -77,9 +73,13 @@ struct PFX##_FbG1 { \
 }; \
 struct PFX##_FbG2 { \
     using F = NS::fp2; \
+    using P = NS::fb_g2_policy; \
+    static constexpr int MUL_WAVES = KYB_FB_G2_WAVES; \
     static constexpr int KIND = WS_FB + 2 * fb_suite_id(#PFX) + 1; \
     static constexpr uint32_t KEY_FLAGS = KYB_F_UNCOMPRESSED | KYB_F_TRUSTED(0); \
-    __host__ __device__ static int decode(Aff<F>& a, const uint8_t* in, uint32_t flags) { return NS::g2_decode_f(a, in, flags, 0); } \
+    __host__ __device__ static int decode_on_curve(Aff<F>& a, const uint8_t* in, uint32_t flags) { return P::decode_on_curve(a, in, flags); } \
+    __host__ __device__ static bool needs_member(uint32_t flags) { return P::needs_member(flags); } \
+    __device__ static bool member(const Aff<F>& a, const fb::Entry<F, P::NI>* tab) { return P::member(a, tab); } \
     __host__ __device__ static void encode(uint8_t* out, const Aff<F>& a, uint32_t flags) { NS::g2_encode_f(out, a, flags); } \
     __host__ __device__ static size_t wire_size(uint32_t flags) { return NS::g2_wire_size(flags); } \
     __host__ __device__ static size_t out_size(uint32_t flags) { return NS::g2_out_size(flags); } \
@@ -229,7 +229,7 @@ static int PFX##_mul_host(bool g2, size_t n, const uint8_t* scalars, const uint8
         key.push_back((char)((flags >> 8) & 0xff)); \
         bool use = n >= kyb::fb_min_batch(g2); \
         if (!use && n >= kyb::FB_MIN_KNOWN) { \
-            use = kyb::fb_host_known(kind, key, false); \
+            use = kyb::fb_hint_is(ctx, kind, nullptr, key); \
             if (!use) { \
                 std::string gk = g2 ? kyb::PFX##_fb_generator_key<kyb::PFX##_FbG2>(flags) \
                                     : kyb::PFX##_fb_generator_key<kyb::PFX##_FbG1>(flags); \
@@ -237,9 +237,8 @@ static int PFX##_mul_host(bool g2, size_t n, const uint8_t* scalars, const uint8
             } \
         } \
         if (use) { \
-            kyb::fb_host_known(kind, key, true); \
-            KYB_TRY(g2 ? (kyb::fb::run<kyb::PFX##_FbG2>(n, s.p, p.p, o.p, st.p, flags, nullptr)) \
-                       : (kyb::fb::run<kyb::PFX##_FbG1>(n, s.p, p.p, o.p, st.p, flags, nullptr))); \
+            KYB_TRY(g2 ? (kyb::fb::run<kyb::PFX##_FbG2>(n, s.p, p.p, o.p, st.p, flags, nullptr, &key)) \
+                       : (kyb::fb::run<kyb::PFX##_FbG1>(n, s.p, p.p, o.p, st.p, flags, nullptr, &key))); \
             KYB_TRY(o.download(out, n * psz)); \
             if (status) KYB_TRY(st.download(status, n)); \
             return KYB_OK; \

@@ -1,7 +1,7 @@
 """One compact oracle-checked workload per environment switch of libkyberhip.so (the switches are read once per
 process, so tests/test_gpu_switches.py runs this file in a subprocess per value).  Prints "switch-probe ok <what>".
 
-  fb   : same-base batches (fixed_base.cuh) -- KYB_FB_CHAIN, KYB_FB_MIN
+  fb   : same-base batches (fixed_base.cuh) -- KYB_FB_MIN
   msm  : Pippenger pipeline tail (msm.cuh)  -- KYB_MSM_TAIL, KYB_MSM_SUB
   lvm  : G1 / G2 Mul dispatch (bls12381_lvm.cuh) -- KYB_LVM_MIN
 """
@@ -31,7 +31,7 @@ def fb():
             h = rng.randrange(1, m.ORDER)
             base_pt = (O.g1_mul if grp == 1 else O.g2_mul)(h, O.G1_GEN if grp == 1 else O.G2_GEN)
             base = (enc1 if grp == 1 else enc2)(base_pt)
-            edge = [0, 1, 511, 512, 513, 1023, 1024, m.ORDER - 1, m.ORDER, (1 << 256) - 1, (512 << 250) | 512]
+            edge = [0, 1, 511, 512, 513, 1023, 1024, m.ORDER - 1, m.ORDER, (1 << 256) - 1, (511 << 246) | 512]
             where = list(range(len(edge))) + [n - 1] + list(range(4099, n - 1, n // 56))  # first, last, strided: >= 64 lanes
             ks = edge + [rng.randrange(1 << 256) for _ in range(len(where) - len(edge))]
             assert len(where) >= 64

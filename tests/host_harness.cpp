@@ -11,6 +11,7 @@
 #include "../kyber_amd/csrc/bn256.cuh"
 #include "../kyber_amd/csrc/ed25519_h2c.cuh"
 #include "../kyber_amd/csrc/fixed_base.cuh"
+#include "../kyber_amd/csrc/bls12381_fb.cuh"
 #include "../kyber_amd/csrc/coop_slots.cuh"
 #include "../kyber_amd/csrc/scalar_field.cuh"
 #include <pthread.h>
@@ -44,19 +45,23 @@ static int xyzz_sum(int n, const uint8_t* pts, int wire, const uint8_t* signs, u
     return bad;
 }
 
-// Fixed-base multiplication (fixed_base.cuh): table of the base built on the host, nk scalars multiplied through it.
-template <class F, class AffT, class Dec, class Enc>
-static int fb_mul_host(const uint8_t* base, int nk, const uint8_t* scalars_be, uint8_t* out, int osz, Dec dec, Enc enc) {
+// Fixed-base multiplication (fixed_base.cuh): table of the base built on the host under the group's policy P (sub-scalars
+// over endomorphism images), nk scalars multiplied through it.  member_out (optional) receives the policy's membership
+// verdict read off the finished table.
+template <class P, class F, class AffT, class Enc>
+static int fb_mul_host(const uint8_t* base, uint32_t flags, int nk, const uint8_t* scalars_be, uint8_t* out, int osz, Enc enc,
+                       int* member_out = nullptr) {
     AffT b;
-    const int st = dec(b, base);
+    const int st = P::decode_on_curve(b, base, flags);
     if (st) return st;
-    std::vector<fb::Entry<F>> tab((size_t)fb::NWIN * fb::NENT);
+    std::vector<fb::Entry<F, P::NI>> tab((size_t)P::NW * fb::NENT);
     if (!b.inf) {
-        Jac<F> q[fb::NWIN];
-        fb::chain(q, b);
-        for (int w = 0; w < fb::NWIN; w++)
-            for (int j = 0; j < fb::NENT; j++) fb::entry(tab[(size_t)w * fb::NENT + j], q[w], j);
+        Jac<F> q[P::NW];
+        fb::chain<P::NW>(q, b);
+        for (int w = 0; w < P::NW; w++)
+            for (int j = 0; j < fb::NENT; j++) fb::entry_images<P>(tab[(size_t)w * fb::NENT + j], q[w], j);
     }
+    if (member_out) *member_out = b.inf ? 1 : (P::member(b, tab.data()) ? 1 : 0);
     for (int i = 0; i < nk; i++) {
         uint32_t k[8];
         words_from_be<8>(k, scalars_be + 32 * i);
@@ -67,7 +72,7 @@ static int fb_mul_host(const uint8_t* base, int nk, const uint8_t* scalars_be, u
             a.inf = true;
         } else {
             Jac<F> r;
-            fb::mul(r, k, tab.data());
+            fb::mul<P>(r, k, tab.data());
             jac_to_aff(a, r);
         }
         enc(out + (size_t)osz * i, a);
@@ -206,24 +211,29 @@ void hh_bls_divmod_z(int dw, const uint8_t* k32, uint8_t* q32, uint8_t* rem16) {
 }
 
 int hh_bls_g1_fb_mul(const uint8_t* base, int nk, const uint8_t* ks, uint8_t* out) {
-    return fb_mul_host<bls::fp, bls::g1_aff>(base, nk, ks, out, 48,
-        [](bls::g1_aff& a, const uint8_t* in) { return bls::g1_decode(a, in, true); },
-        [](uint8_t* o, const bls::g1_aff& a) { bls::g1_encode(o, a); });
+    return fb_mul_host<bls::fb_g1_policy, bls::fp, bls::g1_aff>(base, 0, nk, ks, out, 48, [](uint8_t* o, const bls::g1_aff& a) { bls::g1_encode(o, a); });
 }
 int hh_bls_g2_fb_mul(const uint8_t* base, int nk, const uint8_t* ks, uint8_t* out) {
-    return fb_mul_host<bls::fp2, bls::g2_aff>(base, nk, ks, out, 96,
-        [](bls::g2_aff& a, const uint8_t* in) { return bls::g2_decode(a, in, true); },
-        [](uint8_t* o, const bls::g2_aff& a) { bls::g2_encode(o, a); });
+    return fb_mul_host<bls::fb_g2_policy, bls::fp2, bls::g2_aff>(base, 0, nk, ks, out, 96, [](uint8_t* o, const bls::g2_aff& a) { bls::g2_encode(o, a); });
 }
 int hh_bn_g1_fb_mul(const uint8_t* base, int nk, const uint8_t* ks, uint8_t* out) {
-    return fb_mul_host<bn::fp, bn::g1_aff>(base, nk, ks, out, 64,
-        [](bn::g1_aff& a, const uint8_t* in) { return bn::g1_decode(a, in); },
-        [](uint8_t* o, const bn::g1_aff& a) { bn::g1_encode(o, a); });
+    return fb_mul_host<bn::fb_g1_policy, bn::fp, bn::g1_aff>(base, 0, nk, ks, out, 64, [](uint8_t* o, const bn::g1_aff& a) { bn::g1_encode(o, a); });
 }
 int hh_bn_g2_fb_mul(const uint8_t* base, int nk, const uint8_t* ks, uint8_t* out) {
-    return fb_mul_host<bn::fp2, bn::g2_aff>(base, nk, ks, out, 128,
-        [](bn::g2_aff& a, const uint8_t* in) { return bn::g2_decode(a, in, true); },
-        [](uint8_t* o, const bn::g2_aff& a) { bn::g2_encode(o, a); });
+    return fb_mul_host<bn::fb_g2_policy, bn::fp2, bn::g2_aff>(base, 0, nk, ks, out, 128, [](uint8_t* o, const bn::g2_aff& a) { bn::g2_encode(o, a); });
+}
+// the membership verdict the finished table gives for a base that is on the curve (status of the other rules returned):
+// group 1 / 2 of BLS12-381 (flags: FLAG_UNCOMPRESSED for the 96 / 192-byte form), group 2 of bn254
+int hh_bls_fb_member(int grp, const uint8_t* base, int flags, int* member) {
+    uint8_t sink[96];
+    const uint8_t one[32] = {0};
+    if (grp == 1) return fb_mul_host<bls::fb_g1_policy, bls::fp, bls::g1_aff>(base, (uint32_t)flags, 1, one, sink, 48, [](uint8_t* o, const bls::g1_aff& a) { bls::g1_encode(o, a); }, member);
+    return fb_mul_host<bls::fb_g2_policy, bls::fp2, bls::g2_aff>(base, (uint32_t)flags, 1, one, sink, 96, [](uint8_t* o, const bls::g2_aff& a) { bls::g2_encode(o, a); }, member);
+}
+int hh_bn4_g2_fb_member(const uint8_t* base, int* member) {
+    uint8_t sink[128];
+    const uint8_t one[32] = {0};
+    return fb_mul_host<bn4::fb_g2_policy, bn4::fp2, bn4::g2_aff>(base, 0, 1, one, sink, 128, [](uint8_t* o, const bn4::g2_aff& a) { bn4::g2_encode(o, a); }, member);
 }
 
 int hh_bls_g1_coop(const uint8_t* ops, const uint8_t* a, const uint8_t* b, uint8_t* out) {

@@ -11,15 +11,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CASES = [
-    ("fb", {"KYB_FB_CHAIN": "lane"}), ("fb", {"KYB_FB_CHAIN": "coop"}),
-    ("fb", {"KYB_FB_MIN": "0"}), ("fb", {"KYB_FB_MIN": "1000"}),
+    ("fb", {}), ("fb", {"KYB_FB_MIN": "0"}), ("fb", {"KYB_FB_MIN": "1000"}),
     ("msm", {"KYB_MSM_TAIL": "coop"}), ("msm", {"KYB_MSM_TAIL": "lane"}), ("msm", {"KYB_MSM_SUB": "64"}),
-    ("msm", {"KYB_MSM_GROUPS": "1"}), ("msm", {"KYB_MSM_GROUPS": "2"}),
     ("lvm", {"KYB_LVM_MIN": "0"}), ("lvm", {"KYB_LVM_MIN": "1000000000"}),
 ]
 
 
-@pytest.mark.parametrize("what,env", CASES, ids=[f"{w}-{'-'.join(f'{k}={v}' for k, v in e.items())}" for w, e in CASES])
+@pytest.mark.parametrize("what,env", CASES, ids=[f"{w}-{'-'.join(f'{k}={v}' for k, v in e.items()) or 'default'}" for w, e in CASES])
 def test_switch(what, env):
     e = dict(os.environ)
     e.update(env)

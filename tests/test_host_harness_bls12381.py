@@ -314,10 +314,15 @@ def _fb_scalars(rng, order):
 
 
 def test_fixed_base_table_multiplication_vs_oracle():
-    """fixed_base.cuh: k P from the table of P's multiples (33 signed radix-256 digits, XYZZ additions) on G1 and G2 --
-    digit boundaries (127 / 128 / 129 bytes: the recoding's carries), scalars at and above the order, the infinity base."""
+    """fixed_base.cuh: k P from the table of P's multiples under the group's policy -- G1: k = q z^2 + rem over the images
+    (x, y), (beta x, -y), 2 x 13 signed radix-1024 digits; G2: four base-|z| digits over the psi images, 4 x 7 -- XYZZ
+    additions; digit boundaries (511 / 512 / 513: the recoding's carries), scalars at and above the order, multiples of
+    z^2 and |z| and their neighbours (a sub-scalar of zero), the infinity base."""
     rng = random.Random(77)
+    z = O.X_ABS
     ks = _fb_scalars(rng, O.R)
+    ks += [z, z - 1, z + 1, z * z, z * z - 1, z * z + 1, z**3, z**3 - 1, z**4 - 1, (1 << 256) - (1 << 256) % (z * z), ((1 << 256) // z**3) * z**3,
+           512 * z * z + 512, (255 << 120) * z * z + (1 << 127), 3 * z**3 + 2 * z**2 + z]
     kb = b"".join(k.to_bytes(32, "big") for k in ks)
     for grp in (1, 2):
         gen, mul, comp, size, fn = ((O.G1_GEN, O.g1_mul, O.g1_compress, 48, "hh_bls_g1_fb_mul") if grp == 1 else
@@ -329,6 +334,36 @@ def test_fixed_base_table_multiplication_vs_oracle():
             assert out[size * i:size * i + size] == comp(mul(k % O.R, P)), (grp, hex(k))
         st, out = H.call(fn, comp(None), 3, kb[:96], out_sizes=(size * 3,))
         assert st == 0 and out == comp(None) * 3
+
+
+def test_fixed_base_table_answers_subgroup_membership():
+    """fixed_base.cuh round 4: the base's r-torsion rule is read off the finished table (Scott's criteria over the plain
+    image: z^2 P = -phi(P), |z| Q = -psi(Q)) instead of being laddered in the decoding lane -- members, random cofactor
+    points, a member plus a small-order point, the point at infinity, compressed and uncompressed forms."""
+    import ctypes
+
+    rng = random.Random(78)
+
+    def verdict(grp, wire, flags=0):
+        lib = H.lib()
+        m = ctypes.c_int(-1)
+        st = lib.hh_bls_fb_member(grp, ctypes.c_char_p(wire), flags, ctypes.byref(m))
+        return st, m.value
+
+    c1, c2 = _cofactor_points()
+    for grp, gen, mul, add, comp, unc, off, cof in ((1, O.G1_GEN, O.g1_mul, O.g1_add, O.g1_compress, O.g1_serialize_unc, c1, O.H1),
+                                                    (2, O.G2_GEN, O.g2_mul, O.g2_add, O.g2_compress, O.g2_serialize_unc, c2, O.H_EFF_G2)):
+        P = mul(rng.randrange(1, O.R), gen)
+        assert verdict(grp, comp(P)) == (0, 1)
+        assert verdict(grp, unc(P), 2) == (0, 1)
+        assert verdict(grp, comp(None)) == (0, 1)                       # infinity: nothing to build, a member
+        assert verdict(grp, comp(off)) == (0, 0)                        # on the curve, outside the subgroup
+        assert verdict(grp, unc(off), 2) == (0, 0)
+        small = mul(O.R, off)                                           # the cofactor component alone
+        assert small is not None and verdict(grp, comp(small)) == (0, 0)
+        assert verdict(grp, comp(add(P, small))) == (0, 0)              # a member plus a cofactor component
+        bad = bytearray(comp(P)); bad[0] &= 0x7F                        # compression bit clear: the other rules still apply
+        assert verdict(grp, bytes(bad))[0] == 1
 
 
 def test_cooperative_slot_arithmetic_with_threads_as_lanes():
@@ -350,7 +385,7 @@ def test_cooperative_slot_arithmetic_with_threads_as_lanes():
             ("aa", A, B, add(add(A, B), B), B), ("ada", A, B, add(dbl(add(A, B)), B), B),
             ("as", A, B, add(A, B), add(B, add(A, B))), ("ddda", A, B, add(mul(8, A), B), B),
             ("adnxa", A, B, add(dbl(add(A, B)), B), B),
-            ("d" * 10, A, B, mul(1024, A), B),  # one window of the fixed-base table's doubling chain (chain_coop_kernel)
+            ("d" * 10, A, B, mul(1024, A), B),  # one window of the fixed-base table's doubling chain (fb::chain_kernel)
         ]
         for ops, p, q, ep, eq in cases:
             st, out = H.call(fn, ops.encode() + b"\0", comp(p), comp(q), out_sizes=(2 * size,))

@@ -94,6 +94,31 @@ def test_scalar_multiplication_and_strict_decoding():
     assert H.call("hh_bn4_g2_mul", _be(3), off, 0x100, out_sizes=(128,))[0] == 0
 
 
+def test_fixed_base_table_answers_bn254_g2_membership():
+    """fixed_base.cuh round 4: bn254's G2 rule [Order] Q = infinity (twist.go:62-65) read off the finished plain table."""
+    import ctypes
+
+    rng = random.Random(8)
+    lib = H.lib()
+
+    def verdict(wire):
+        m = ctypes.c_int(-1)
+        return lib.hh_bn4_g2_fb_member(ctypes.c_char_p(wire), ctypes.byref(m)), m.value
+
+    g = O.g2_mul(rng.randrange(1, O.ORDER), O.G2_GEN)
+    assert verdict(O.g2_marshal(g)) == (0, 1)
+    while True:
+        xx = (rng.randrange(O.P), rng.randrange(O.P))
+        yy = O.f2_sqrt(O.f2_add(O.f2_mul(O.f2_sqr(xx), xx), O.TWIST_B))
+        if yy is not None:
+            break
+    assert verdict(O.g2_marshal((xx, yy))) == (0, 0)
+    h = 2 * O.P - O.ORDER
+    small = O.g2_mul(O.ORDER * h // O.G2_COFACTOR_PRIMES[0], (xx, yy))
+    if small is not None:
+        assert verdict(O.g2_marshal(small)) == (0, 0) and verdict(O.g2_marshal(O.g2_add(g, small))) == (0, 0)
+
+
 def test_field_inversion_by_division_steps():
     """fp_inv (mont.cuh: Bernstein-Yang division steps, thirty per batch): zero, one, p - 1, powers of two, values whose
     (f, g) walk is long or short, random values -- on the three fields, against pow(a, -1, p)."""
