@@ -461,6 +461,20 @@ func Bls12381HashG2(n int, msgs []byte, msgLen int, dst []byte) (out, status []b
 	return
 }
 
+// Bls12381VerifyG1SameKey: n x sign/bls Verify under ONE public key (a drand chain; sign/tbls/tbls.go:100-107): both
+// Miller loops from line tables, the key's built once per key on the device.  Trusted(0) = the key.
+func Bls12381VerifyG1SameKey(pubkey, msgs []byte, msgLen int, dst, sigs []byte, flags uint32) (ok, status []byte, err error) {
+	n, err := count("sigs", sigs, g1in(flags))
+	if err = firstErr(err, need("pubkey", pubkey, 1, g2in(flags)), messages(msgs, msgLen, n)); err != nil {
+		return nil, nil, err
+	}
+	ok, status = make([]byte, n), make([]byte, n)
+	err = call(func() C.int {
+		return C.kyb_bls12381_verify_g1_same_key(C.size_t(n), ptr(pubkey), ptr(msgs), C.size_t(msgLen), ptr(dst), C.size_t(len(dst)), ptr(sigs), ptr(ok), ptr(status), C.uint32_t(flags))
+	})
+	return
+}
+
 // Bls12381VerifyG1: n x sign/bls Verify (signatures on G1, keys on G2), hash + checks + product of two Miller loops
 // + final exponentiation on the device; Trusted(0) = keys.
 func Bls12381VerifyG1(pubkeys, msgs []byte, msgLen int, dst, sigs []byte, flags uint32) (ok, status []byte, err error) {

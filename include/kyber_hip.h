@@ -231,6 +231,19 @@ int kyb_bls12381_verify_g1(size_t n, const uint8_t *pubkeys, const uint8_t *msgs
 int kyb_bls12381_verify_g1_dev(size_t n, const void *d_pubkeys, const void *d_msgs, size_t msg_len,
                                const uint8_t *dst, size_t dst_len, const void *d_sigs, void *d_ok, void *d_status,
                                uint32_t flags, void *stream);
+/* ok[i] = bls.Verify(pubkey, msgs[i], sigs[i]) for ONE public key (96 B, or 192 B with KYB_F_UNCOMPRESSED; a HOST
+ * pointer in the first variant, a device pointer in `_dev`): sign/bls/bls.go:82-96 called in a loop with the same X --
+ * a drand chain's beacons, the partial signatures of one tbls participant (sign/tbls/tbls.go:100-107).  With both G2
+ * operands the same for every element, both Miller loops read their lines from tables (the generator's is a constant of
+ * the program; the key's is built on the device the first time a key is seen and reused while the key stays the same --
+ * compared on the device, per stream).  The key is checked as UnmarshalBinary would (KYB_F_TRUSTED(0) vouches for it);
+ * a key that fails gives every element its status and ok = 0; status precedence per element: key, then signature. */
+int kyb_bls12381_verify_g1_same_key(size_t n, const uint8_t *pubkey, const uint8_t *msgs, size_t msg_len,
+                                    const uint8_t *dst, size_t dst_len, const uint8_t *sigs, uint8_t *ok,
+                                    uint8_t *status, uint32_t flags);
+int kyb_bls12381_verify_g1_same_key_dev(size_t n, const void *d_pubkey, const void *d_msgs, size_t msg_len,
+                                        const uint8_t *dst, size_t dst_len, const void *d_sigs, void *d_ok,
+                                        void *d_status, uint32_t flags, void *stream);
 /* The same for the scheme with signatures on G2 and keys on G1 (NewSchemeOnG2, sign/bls/bls.go:48-58:
  * ValidatePairing(G1.Base(), sig, X, H(msg)) with H = hash_to_curve on G2): pubkeys 48 B, sigs 96 B. */
 int kyb_bls12381_verify_g2(size_t n, const uint8_t *pubkeys, const uint8_t *msgs, size_t msg_len, const uint8_t *dst,

@@ -40,8 +40,18 @@ extern "C" int kyb_debug_bls12381_lvm_run(int pair, size_t nlanes, const void* d
     using namespace kyb;
     const uint32_t ncoord = pair ? LVM_BLS12381_G2_MUL_NCOORD : LVM_BLS12381_G1_MUL_NCOORD, nentry = LVM_BLS12381_G1_MUL_NENTRY;
     const size_t b_io = 2 * nlanes * 48, b_dig = nlanes * 72, b_tab = nlanes * (size_t)nentry * ncoord * lvm::TAB_WORDS * 4;
-    uint8_t* base;
-    KYB_HIP_CHECK(hipMalloc(&base, 2 * b_io + b_dig + nlanes + b_tab + 1024));
+    // (every early return releases what was acquired before it)
+    struct Res {
+        uint8_t* base = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Res() {
+            if (e0) hipEventDestroy(e0);
+            if (e1) hipEventDestroy(e1);
+            if (base) hipFree(base);
+        }
+    } res;
+    KYB_HIP_CHECK(hipMalloc(&res.base, 2 * b_io + b_dig + nlanes + b_tab + 1024));
+    uint8_t* base = res.base;
     KYB_HIP_CHECK(hipMemset(base, 1, 2 * b_io + b_dig + nlanes + b_tab + 1024));
     lvm::Args a{};
     a.prog = (const uint32_t*)d_prog;
@@ -57,22 +67,18 @@ extern "C" int kyb_debug_bls12381_lvm_run(int pair, size_t nlanes, const void* d
     a.nentry = nentry;
     a.ncoord = ncoord;
     a.nlanes = nlanes;
-    hipEvent_t e0, e1;
-    KYB_HIP_CHECK(hipEventCreate(&e0));
-    KYB_HIP_CHECK(hipEventCreate(&e1));
+    KYB_HIP_CHECK(hipEventCreate(&res.e0));
+    KYB_HIP_CHECK(hipEventCreate(&res.e1));
     const unsigned gw = (unsigned)((nlanes + 63) / 64);
     for (int r = 0; r <= reps; r++) {
-        if (r == 1) KYB_HIP_CHECK(hipEventRecord(e0, nullptr));
+        if (r == 1) KYB_HIP_CHECK(hipEventRecord(res.e0, nullptr));
         if (pair) hipLaunchKernelGGL((kyb::bls::bls12381_lvm_mul_kernel<true, true>), dim3(gw), dim3(64), 0, nullptr, a);
         else hipLaunchKernelGGL((kyb::bls::bls12381_lvm_mul_kernel<false, true>), dim3(gw), dim3(64), 0, nullptr, a);
     }
-    KYB_HIP_CHECK(hipEventRecord(e1, nullptr));
-    KYB_HIP_CHECK(hipEventSynchronize(e1));
+    KYB_HIP_CHECK(hipEventRecord(res.e1, nullptr));
+    KYB_HIP_CHECK(hipEventSynchronize(res.e1));
     float ms = 0;
-    KYB_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    KYB_HIP_CHECK(hipEventElapsedTime(&ms, res.e0, res.e1));
     *usec = ms * 1e3f / (reps > 0 ? reps : 1);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    KYB_HIP_CHECK(hipFree(base));
     return KYB_OK;
 }

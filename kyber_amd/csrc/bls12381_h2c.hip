@@ -154,6 +154,60 @@ int kyb_bls12381_verify_g1(size_t n, const uint8_t* pks, const uint8_t* msgs, si
     if (status) KYB_TRY(st.download(status, n));
     return KYB_OK;
 }
+// sign/bls Verify (bls.go:82-96) for n (message, signature) pairs under ONE public key -- a drand chain, the partial
+// signatures of one tbls participant (sign/tbls/tbls.go:100-107): both Miller loops from line tables (program VERIFYK)
+int kyb_bls12381_verify_g1_same_key_dev(size_t n, const void* d_pk, const void* d_msgs, size_t msg_len, const uint8_t* dst,
+                                        size_t dst_len, const void* d_sigs, void* d_ok, void* d_status, uint32_t flags, void* stream) {
+    if (!d_pk || (n && ((!d_msgs && msg_len) || !d_sigs || !d_ok))) {
+        set_error("kyb_bls12381_verify_g1_same_key_dev: bad argument");
+        return KYB_E_ARG;
+    }
+    KYB_TRY(check_flags(flags, 2, false, "kyb_bls12381_verify_g1_same_key_dev"));
+    bls::DstArg d;
+    KYB_TRY(make_dst(d, dst, dst_len));
+    if (!n) return KYB_OK;
+    DeviceCtx* ctx;
+    KYB_TRY(get_ctx(&ctx));
+    std::lock_guard<std::recursive_mutex> enq_lock(ctx->enq_mu);
+    const int32_t* table;
+    const uint8_t* kst;
+    KYB_TRY(blsvm::prepare_key(ctx, (hipStream_t)stream, (const uint8_t*)d_pk, flags, &table, &kst));
+    blsvm::Work w;
+    KYB_TRY(blsvm::workspace(ctx, (hipStream_t)stream, n, blsvm::VERIFYK_INPUTS, &w));
+    // e(H(m), X) e(-sig, G2.Base()) == 1   (status precedence: key, then signature)
+    const blsvm::Operand ops[3] = {{(const uint8_t*)d_msgs, blsvm::OPND_G1_HASH, (uint32_t)msg_len, 0, 0, 0},
+                                   {kst, blsvm::OPND_STATUS, 0, 0, 0, 0},
+                                   {(const uint8_t*)d_sigs, blsvm::OPND_G1, (uint32_t)bls::g1_wire_size(flags), 2, 1, 1}};
+    KYB_TRY(blsvm::launch_prep(w, n, ops, 3, flags, dst, dst_len, (hipStream_t)stream));
+    return blsvm::launch_verify_same_key(w, n, table, (uint8_t*)d_ok, (uint8_t*)d_status, (hipStream_t)stream);
+}
+int kyb_bls12381_verify_g1_same_key(size_t n, const uint8_t* pk, const uint8_t* msgs, size_t msg_len, const uint8_t* dst,
+                                    size_t dst_len, const uint8_t* sigs, uint8_t* ok, uint8_t* status, uint32_t flags) {
+    if (!pk || (n && ((!msgs && msg_len) || !sigs || !ok))) {
+        set_error("kyb_bls12381_verify_g1_same_key: bad argument");
+        return KYB_E_ARG;
+    }
+    KYB_TRY(check_flags(flags, 2, false, "kyb_bls12381_verify_g1_same_key"));
+    if (!n) return KYB_OK;
+    if (md_active(n))
+        return md_run(n, [&](int, size_t lo, size_t hi) {
+            return kyb_bls12381_verify_g1_same_key(hi - lo, pk, msgs + msg_len * lo, msg_len, dst, dst_len,
+                                                   sigs + bls::g1_wire_size(flags) * lo, ok + lo, status ? status + lo : nullptr, flags);
+        });
+    DeviceCtx* ctx;
+    KYB_TRY(get_ctx(&ctx));
+    kyb::StageScope sc_(ctx);
+    StageBuf p, m, s, o, st;
+    KYB_TRY(p.upload(pk, bls::g2_wire_size(flags)));
+    KYB_TRY(m.upload(msgs, n * msg_len));
+    KYB_TRY(s.upload(sigs, n * bls::g1_wire_size(flags)));
+    KYB_TRY(o.alloc(n));
+    KYB_TRY(st.alloc(n));
+    KYB_TRY(kyb_bls12381_verify_g1_same_key_dev(n, p.p, m.p, msg_len, dst, dst_len, s.p, o.p, st.p, flags, nullptr));
+    KYB_TRY(o.download(ok, n));
+    if (status) KYB_TRY(st.download(status, n));
+    return KYB_OK;
+}
 int kyb_bls12381_verify_g2_dev(size_t n, const void* d_pks, const void* d_msgs, size_t msg_len, const uint8_t* dst,
                                size_t dst_len, const void* d_sigs, void* d_ok, void* d_status, uint32_t flags, void* stream) {
     if (n && (!d_pks || (!d_msgs && msg_len) || !d_sigs || !d_ok)) {

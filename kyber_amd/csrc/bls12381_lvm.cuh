@@ -18,6 +18,8 @@
 #pragma once
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "bls12381.cuh"
 #include "context.h"
 #include "lane_vm.cuh"
@@ -241,15 +243,15 @@ __global__ __launch_bounds__(64) void bls12381_lvm_encode_kernel(size_t n, const
 // per-lane kernel is slightly ahead (3.77 against 3.97 ms per 2^16); from two waves per SIMD the machine's 202
 // registers let them overlap and it leads by 1.3x (profiles/r03_lvm_*).  KYB_LVM_MIN overrides both (A/B runs; a huge
 // value sends everything to the per-lane kernels).
-inline long long& lvm_min_override() {
-    static long long v = [] {
+inline std::atomic<long long>& lvm_min_override() {  // atomic: the debug setter may race with calls on other threads
+    static std::atomic<long long> v{[] {
         const char* e = getenv("KYB_LVM_MIN");
         return e ? (long long)strtoull(e, nullptr, 10) : -1ll;
-    }();
+    }()};
     return v;
 }
 inline size_t lvm_min_batch(bool g2, int num_cu) {
-    const long long env = lvm_min_override();
+    const long long env = lvm_min_override().load(std::memory_order_relaxed);
     if (env >= 0) return (size_t)env;
     return g2 ? (size_t)1024 : (size_t)num_cu * 4 * 64 + 1;
 }

@@ -40,6 +40,10 @@ __global__ __launch_bounds__(64) void bls12381_operand_kernel(PrepArgs a) {
     const size_t i = (blockIdx.x - (size_t)k * nblk) * 64 + threadIdx.x;
     if (i >= a.n) return;
     const Operand& o = a.op[k];
+    if (o.kind == OPND_STATUS) {  // an operand shared by every pairing: only its verdict
+        a.pst[(size_t)k * a.n + i] = o.src[0];
+        return;
+    }
     int st = bls::ST_OK;
     bool inf = false;
     if (o.kind == OPND_G1 || o.kind == OPND_G1_HASH || o.kind == OPND_G1_GEN) {

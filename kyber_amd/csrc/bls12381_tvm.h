@@ -12,7 +12,9 @@ constexpr int CHECK_INPUTS = 12;      // pair A, then pair B with P_B already ne
 // One point argument of a batch call, prepared by its own lanes (bls12381_prep.hip): n lanes per operand, so that the
 // G1 and G2 decompressions, subgroup checks and hashes of one pairing run side by side instead of one after the other
 // in a single lane (65 536 pairings are only one wave per SIMD; four operands are four).
-enum OperandKind : uint32_t { OPND_G1 = 0, OPND_G2 = 1, OPND_G1_HASH = 2, OPND_G2_HASH = 3, OPND_G1_GEN = 4, OPND_G2_GEN = 5 };
+// OPND_STATUS: an operand every lane shares (the one public key of a same-key verification): no coordinates, its status
+// byte -- src[0], on the device -- is copied to every pairing
+enum OperandKind : uint32_t { OPND_G1 = 0, OPND_G2 = 1, OPND_G1_HASH = 2, OPND_G2_HASH = 3, OPND_G1_GEN = 4, OPND_G2_GEN = 5, OPND_STATUS = 6 };
 struct Operand {
     const uint8_t* src;  // wire encodings (messages for the hash kinds; unused for the generators)
     uint32_t kind;
@@ -50,5 +52,14 @@ int launch_check(const Work& w, size_t n, uint8_t* d_ok, uint8_t* d_status, hipS
 // constants); operands 0, 1 = pair A (G1, G2), operand 2 = pair B's G1 point (negated), inputs 0-7.
 constexpr int VERIFY_INPUTS = 8;
 int launch_verify(const Work& w, size_t n, uint8_t* d_ok, uint8_t* d_status, hipStream_t st);
+// Same-key verification (sign/bls/bls.go:82-96 for many messages under ONE public key): program VERIFYK takes the lines
+// of BOTH Miller loops from a table [generator | key].  prepare_key enqueues the kernel that decodes the key (d_key: its
+// wire form on the device) with UnmarshalBinary's rules and, unless the (WS_VKEY, stream) workspace already holds this
+// key's table, walks it through the loop once (bls12381_keylines.cuh); *table / *kst: the table and the key's status
+// byte (PST_INF convention), valid for kernels enqueued after it on `st`.
+constexpr int VERIFYK_INPUTS = 4;  // H(m) (2), -sig (2)
+int prepare_key(DeviceCtx* ctx, hipStream_t st, const uint8_t* d_key, uint32_t flags, const int32_t** table, const uint8_t** kst);
+// operands 0 (H(m)), 1 (the key: OPND_STATUS), 2 (the signature, negated; inputs 2-3)
+int launch_verify_same_key(const Work& w, size_t n, const int32_t* table, uint8_t* d_ok, uint8_t* d_status, hipStream_t st);
 }  // namespace blsvm
 }  // namespace kyb

@@ -229,7 +229,7 @@ KYB_DEV void fe_sq_t(fe& h, const fe& f) {
     for (int i = 0; i < 10; i++) {
         f2[i] = 2 * f.v[i];
         f19[i] = 19 * f.v[i];
-        f38[i] = 2 * f19[i];
+        f38[i] = (int32_t)(2u * (uint32_t)f19[i]);  // used for odd i only; an even limb's 38 f may wrap (unsigned: defined)
     }
     fe_chain_store(h, [&](int k, int64_t addend) {
         int64_t acc = DBL ? 0 : addend;
@@ -258,7 +258,7 @@ KYB_DEV void fe_sq_sel(fe& h, const fe& f, bool dbl) {
     for (int i = 0; i < 10; i++) {
         f2[i] = 2 * g.v[i];
         f19[i] = 19 * g.v[i];
-        f38[i] = 2 * f19[i];
+        f38[i] = (int32_t)(2u * (uint32_t)f19[i]);  // used for odd i only; an even limb's 38 f may wrap (unsigned: defined)
     }
     int64_t t[10];
 #pragma unroll

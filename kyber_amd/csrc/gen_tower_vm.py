@@ -217,7 +217,8 @@ class Prog:
         self.names = []
         self.consts = []   # stored values (ints in [0, p))
         self.gconsts = []  # the table of per-repetition constants (stored values), global memory
-        self.dyn_base = None  # first of the GC_ENTRIES constant-area entries that OP_GCLOAD refills (after the fixed ones)
+        self.dyn_base = None  # first of the constant-area entries that OP_GCLOAD refills (after the fixed ones)
+        self.ndyn = GC_ENTRIES  # how many there are: one GCLOAD record refills GC_ENTRIES of them, from its "dst" on
         self.sched = []    # (start, len, repeat)
         self._open = None
         self.c_zero = self.const(0)
@@ -335,7 +336,7 @@ class Prog:
             assert 0 <= o.dst < self.nslots
             for t in o.terms:
                 if t[0] == "d":
-                    assert 0 <= t[2] < GC_ENTRIES
+                    assert 0 <= t[2] < self.ndyn
                 for lin in (t[1:3] if t[0] == "p" else t[1:2]):
                     assert 1 <= len(lin.d) <= 2, (name, lin)
                     assert all(0 <= s < self.nslots and -128 <= c <= 127 for s, c in lin.d.items()), (name, lin)
@@ -370,7 +371,7 @@ class Prog:
         p, Rinv = f.p, pow(f.R, -1, f.p)
         S = [0] * self.nslots
         G = {}
-        CL = [None] * GC_ENTRIES  # the dynamic constants; refilled at the END of the instruction that holds the GCLOAD
+        CL = [None] * self.ndyn  # the dynamic constants; refilled at the END of the instruction that holds the GCLOAD
         res = {"gt": {}, "not_one": False, "flags": 0}
 
         def raise_flag(r):
@@ -380,7 +381,7 @@ class Prog:
         for start, ln, rep in self.sched:
             for it in range(rep):
                 for ins in self.ins[start:start + ln]:
-                    new, newc = {}, None
+                    new, newc = {}, {}
                     for w, r in enumerate(ins):
                         op = r["op"]
                         if op == OP_DOT:
@@ -404,7 +405,7 @@ class Prog:
                             new[r["dst"]] = inputs[r["arg"]] % p
                         elif op == OP_GCLOAD:
                             base = r["arg"][0] + it * r["arg"][1]
-                            newc = self.gconsts[base:base + GC_ENTRIES]
+                            newc[r.get("dst", 0)] = self.gconsts[base:base + GC_ENTRIES]
                         elif op == OP_CLOAD:
                             new[r["dst"]] = self.consts[r["arg"]]
                         elif op == OP_INV:
@@ -427,8 +428,9 @@ class Prog:
                                 raise_flag(r)
                     for k, v in new.items():
                         S[k] = v
-                    if newc is not None:
-                        CL = list(newc) + [None] * (GC_ENTRIES - len(newc))
+                    for d0, ent in newc.items():
+                        assert len(ent) == GC_ENTRIES and d0 + GC_ENTRIES <= self.ndyn
+                        CL[d0:d0 + GC_ENTRIES] = ent
         return S, res
 
     # --- the device's arithmetic, limb for limb
@@ -473,7 +475,7 @@ class Prog:
 
         S = [[0] * N for _ in range(self.nslots)]
         G = {}
-        CL = [None] * GC_ENTRIES
+        CL = [None] * self.ndyn
         res = {"gt": {}, "not_one": False, "flags": 0}
 
         def raise_flag(r):
@@ -483,7 +485,7 @@ class Prog:
         for start, ln, rep in self.sched:
             for it in range(rep):
                 for ins in self.ins[start:start + ln]:
-                    new, newc = {}, None
+                    new, newc = {}, {}
                     for w, r in enumerate(ins):
                         op = r["op"]
                         if op == OP_DOT:
@@ -522,7 +524,7 @@ class Prog:
                             new[r["dst"]] = from_words(inputs[r["arg"]] % p)
                         elif op == OP_GCLOAD:
                             base = r["arg"][0] + it * r["arg"][1]
-                            newc = self.gconsts[base:base + GC_ENTRIES]
+                            newc[r.get("dst", 0)] = self.gconsts[base:base + GC_ENTRIES]
                         elif op == OP_CLOAD:
                             new[r["dst"]] = f.balanced(self.consts[r["arg"]])
                         elif op == OP_INV:
@@ -545,8 +547,9 @@ class Prog:
                                 raise_flag(r)
                     for k, v in new.items():
                         S[k] = v
-                    if newc is not None:
-                        CL = list(newc) + [None] * (GC_ENTRIES - len(newc))
+                    for d0, ent in newc.items():
+                        assert len(ent) == GC_ENTRIES and d0 + GC_ENTRIES <= self.ndyn
+                        CL[d0:d0 + GC_ENTRIES] = ent
         return S, res
 
     # --- worst-case bounds for any input
@@ -684,7 +687,8 @@ class Prog:
                 elif op == OP_IDLE:
                     pass
                 elif op == OP_GCLOAD:  # word 1: table index of the first entry | its advance per repetition << 16
-                    hdr |= self.dyn_base
+                    hdr |= self.dyn_base + r.get("dst", 0)
+                    assert r["arg"][0] < 1 << 16 and r["arg"][1] < 1 << 16
                     rec[1] = r["arg"][0] | (r["arg"][1] << 16)
                 else:
                     hdr |= r["dst"]
@@ -1122,17 +1126,21 @@ def bls_fixed_line_table(p, Q):
     return out
 
 
-def bls_fixed_load(g, stride):
+def bls_fixed_load(g, stride, dst=0):
     """the record that moves the step's (c2, c3) -- table entries g .. g + 3, advanced by `stride` per repetition of the
-    enclosing block -- into the dynamic constants; it goes into an EARLIER instruction of the same step"""
-    return dict(op=OP_GCLOAD, arg=(g, stride))
+    enclosing block -- into the dynamic constants dst .. dst + 3; it goes into an EARLIER instruction of the same step"""
+    return dict(op=OP_GCLOAD, arg=(g, stride), dst=dst)
+
+
+def bls_fixed_lines(L, PX, PY, d0=0):
+    """outputs (c2 xP, c3 yP) -> L[2..5] with (c2, c3) the dynamic constants d0 .. d0 + 3"""
+    return (outs2(L[2], L[3], Acc2().dconst_fp((d0, d0 + 1), Lin.slot(PX)))
+            + outs2(L[4], L[5], Acc2().dconst_fp((d0 + 2, d0 + 3), Lin.slot(PY))))
 
 
 def bls_fixed_step(P, T, L, PX, PY, fset, mask, name):
     """f <- f * (1 + c2 xP w^2 + c3 yP w^3) with (c2, c3) the dynamic constants 0 .. 3"""
-    o = outs2(L[2], L[3], Acc2().dconst_fp((0, 1), Lin.slot(PX)))
-    o += outs2(L[4], L[5], Acc2().dconst_fp((2, 3), Lin.slot(PY)))
-    P.dot(o, name + "/l")
+    P.dot(bls_fixed_lines(L, PX, PY), name + "/l")
     T.mul_sparse(fset, Tower.reg(fset), {0: 1, 2: E2.slots(L[2], L[3]), 3: E2.slots(L[4], L[5])}, mask=mask, name=name + "/line")
 
 
@@ -1488,6 +1496,73 @@ def build_bls12381_verify():
     assert cur[0] == len(P.gconsts) and len(lines[0]) * 2 == GC_ENTRIES
     P.misc([dict(op=OP_FILL, dst=Qs[i], arg=2) for i in range(4)], "member/fillQ")
     bls_g2_member_check(P, T1[0], T1[1], T1[2], Qs, tmp[4:10] + L[0:4], FLAG_G2_A)
+    res = bls_final_exp(P, T, T.conj12(FF), gam)
+    one = (P.c_plain_one, 1)
+    P.dot(sum((outs2(F_ + 2 * j, F_ + 2 * j + 1, Acc2().prod_const(res[j], one, None)) for j in range(6)), []), "to_plain")
+    P.misc([dict(op=OP_IS_ONE, dst=F_ + 2 * j + c, arg=(1 if (j == 0 and c == 0) else 0) << 16) for j in range(6) for c in range(2)],
+           "is_one")
+    P.dyn_base = len(P.consts)  # the dynamic constants follow the fixed ones in the constant area
+    return P
+
+
+def build_bls12381_verify_same_key(key=None):
+    """bls.Verify for MANY messages under ONE public key (sign/bls/bls.go:82-96 called in a loop with the same X: a
+    drand chain, sign/tbls/tbls.go:100-107): e(H(m), X) e(-sig, g2) == 1 where BOTH G2 operands are the same for every
+    lane -- so both Miller loops take their lines from tables: the generator's (constants of the program, as in VERIFY)
+    and the key's (computed once per key by bls12381_key_lines_kernel with bls_fixed_line_table's formulas; the launch
+    hands the machine one table [generator | key]).  No point is walked at all: a step is f^2 and two sparse
+    multiplications.  inputs: P1 = H(m) (2), P2 = -sig (2).  `key`: the G2 point whose lines fill the key half of the
+    EMITTED table (any valid point: the device overwrites that half; the simulators use it)."""
+    f = bls12381_field()
+    P = Prog(f, NSLOTS, 1, n_inputs=4, n_gslots=4)
+    P.ndyn = 2 * GC_ENTRIES
+    T = Tower(P)
+    xi = (1, 1)
+    gam = {K: frob_gammas(f.p, xi, K) for K in (1, 2, 3)}
+    LK = list(range(24, 30))   # the key's line (pair A)
+    LG = list(range(34, 40))   # the generator's line (pair B)
+    P1, P2 = (40, 41), (42, 43)
+    bls_load_inputs(P, f, [P1[0], P1[1]], 0)
+    bls_load_inputs(P, f, [P2[0], P2[1]], 2)
+    P.misc([dict(op=OP_CLOAD, dst=F_ + i, arg=P.c_one if i == 0 else P.c_zero) for i in range(12)], "f=1")
+    FF = T.reg(F_)
+    gen_lines = bls_fixed_line_table(f.p, BLS_G2_GEN)
+    key_lines = bls_fixed_line_table(f.p, key if key is not None else BLS_G2_GEN)
+    g0 = P.gtable([c for line in gen_lines for z in line for c in z])
+    k0 = P.gtable([c for line in key_lines for z in line for c in z])
+    assert g0 == 0 and k0 == 4 * len(gen_lines)
+    P.key_table_base = k0
+    cur = [0]
+
+    def step(stride):
+        # the two loads ride in an instruction of their own (two waves; the constants change at its END)
+        P.misc([bls_fixed_load(k0 + cur[0], stride, 0), bls_fixed_load(g0 + cur[0], stride, GC_ENTRIES)], "samekey/load")
+        P.dot(bls_fixed_lines(LK, P1[0], P1[1], 0) + bls_fixed_lines(LG, P2[0], P2[1], GC_ENTRIES), "samekey/l")
+
+    def lines(name):
+        T.mul_sparse(F_, FF, {0: 1, 2: E2.slots(LK[2], LK[3]), 3: E2.slots(LK[4], LK[5])}, mask=1, name=name + "/key")
+        T.mul_sparse(F_, FF, {0: 1, 2: E2.slots(LG[2], LG[3]), 3: E2.slots(LG[4], LG[5])}, mask=2, name=name + "/gen")
+
+    run = 0
+    for b in bin(BLS_X_ABS)[3:]:
+        run += 1
+        if b == "1":
+            with P.repeat(run):
+                step(4)
+                T.sqr12(F_, FF, "miller/sqr")
+                lines("fixdbl")
+            cur[0] += 4 * run
+            run = 0
+            step(0)
+            lines("fixadd")
+            cur[0] += 4
+    if run:
+        with P.repeat(run):
+            step(4)
+            T.sqr12(F_, FF, "miller/sqr")
+            lines("fixdbl")
+        cur[0] += 4 * run
+    assert cur[0] == 4 * len(gen_lines) and len(P.gconsts) == 8 * len(gen_lines)
     res = bls_final_exp(P, T, T.conj12(FF), gam)
     one = (P.c_plain_one, 1)
     P.dot(sum((outs2(F_ + 2 * j, F_ + 2 * j + 1, Acc2().prod_const(res[j], one, None)) for j in range(6)), []), "to_plain")
@@ -1949,7 +2024,7 @@ def emit_prog(P, name):
         f"static __device__ const uint32_t TVM_{name}_SCHED[{len(flat)}] = {_carr(flat)};",
         f"static constexpr uint32_t TVM_{name}_NSCHED = {len(sched)};",
         f"static __device__ const uint32_t TVM_{name}_CONSTS[{len(consts)}] = {_carr(consts)};",
-        f"static constexpr uint32_t TVM_{name}_NCONSTS = {len(P.consts)}, TVM_{name}_NDYNCONSTS = {GC_ENTRIES if P.dyn_base is not None else 0};",
+        f"static constexpr uint32_t TVM_{name}_NCONSTS = {len(P.consts)}, TVM_{name}_NDYNCONSTS = {P.ndyn if P.dyn_base is not None else 0};",
         f"static constexpr uint32_t TVM_{name}_NGSLOTS = {P.n_gslots}, TVM_{name}_NINPUTS = {P.n_inputs}, TVM_{name}_NSLOTS = {P.nslots};",
         f"static constexpr uint64_t TVM_{name}_MADS_PER_UNIT = {P.mads()}ull;  // integer MADs per pairing (check), all waves",
         ""])
@@ -1969,6 +2044,9 @@ def main():
             out.append(emit_prog(build_bn256_check_product(), up + "_CHECKP"))
         if suite == "bls12381":  # CHECK with the second G2 operand fixed to the generator (bls.Verify on G1)
             out.append(emit_prog(build_bls12381_verify(), up + "_VERIFY"))
+            vk = build_bls12381_verify_same_key()  # both G2 operands fixed: the key's lines come from a per-key table
+            out.append(emit_prog(vk, up + "_VERIFYK"))
+            out.append(f"static constexpr uint32_t TVM_{up}_VERIFYK_KEY_TABLE_BASE = {vk.key_table_base};  // entries; the key's half starts here")
         out += ["}  // namespace kyb", ""]
         dst = os.path.join(HERE, "tower_vm_%s.inc" % suite)   # written whole, then renamed: a reader never sees half a file
         with open(dst + ".tmp", "w") as f:

@@ -108,6 +108,62 @@ def batch_verify_g2(pubkeys, msgs, sigs, dst: bytes = DOMAIN_G2, flags: int = 0)
     return _batch_verify(2, pubkeys, msgs, sigs, dst, flags)
 
 
+def batch_verify_g1_same_key(pubkey, msgs, sigs, dst: bytes = DOMAIN_G1, flags: int = 0):
+    """(ok, status): N x bls.Verify under ONE public key (sign/bls/bls.go:82-96 in a loop with the same X: a drand
+    chain, sign/tbls/tbls.go:100-107) -- both Miller loops from line tables (kyb_bls12381_verify_g1_same_key).
+    pubkey: 96 bytes (192 with F_UNCOMPRESSED) or a CUDA tensor of that size when msgs / sigs are CUDA tensors."""
+    import ctypes
+
+    import numpy as np
+
+    from .._lib import check, load
+    from ._engine import F_UNCOMPRESSED, _host, _is_torch, _stream, pack_fixed
+
+    wk, wsig = (192, 96) if flags & F_UNCOMPRESSED else (96, 48)
+    lib = load()
+    dbuf = ctypes.create_string_buffer(bytes(dst), len(dst)) if dst else None
+    dptr = ctypes.cast(dbuf, ctypes.c_void_p) if dst else None
+    if _is_torch(msgs):
+        import torch
+
+        m, s = msgs.contiguous(), sigs.contiguous().view(-1, wsig)
+        k = pubkey if _is_torch(pubkey) else torch.from_numpy(np.frombuffer(bytes(pubkey), dtype=np.uint8).copy())
+        k = k.to(m.device).contiguous().view(-1)
+        n, ln = m.shape[0], m.shape[1]
+        if k.numel() != wk or s.shape[0] != n:
+            raise ValueError(f"batch_verify_same_key: key of {k.numel()} bytes, {n} messages, {s.shape[0]} signatures")
+        ok = torch.empty(n, dtype=torch.uint8, device=m.device)
+        st = torch.empty(n, dtype=torch.uint8, device=m.device)
+        check(lib.kyb_bls12381_verify_g1_same_key_dev(n, k.data_ptr(), m.data_ptr(), ln, dptr, len(dst), s.data_ptr(), ok.data_ptr(),
+                                                      st.data_ptr(), flags, _stream()), "kyb_bls12381_verify_g1_same_key_dev")
+        return ok, st
+    if isinstance(msgs, (list, tuple)):
+        ln = len(msgs[0]) if msgs else 0
+        if any(len(x) != ln for x in msgs):
+            raise ValueError("batch_verify_same_key: messages must have equal length")
+        mb = np.frombuffer(b"".join(msgs), dtype=np.uint8)
+        n = len(msgs)
+    else:
+        a = np.ascontiguousarray(msgs, dtype=np.uint8)
+        n, ln = a.shape[0], a.shape[1]
+        mb = a.reshape(-1)
+    mb = np.ascontiguousarray(mb) if mb.size else np.zeros(1, dtype=np.uint8)
+    s, bad_s = pack_fixed(sigs, wsig) if isinstance(sigs, (list, tuple)) else (_host(sigs, wsig), [])
+    kb = bytes(pubkey)
+    if s.shape[0] != n:
+        raise ValueError(f"batch_verify_same_key: {n} messages, {s.shape[0]} signatures")
+    ok = np.empty(n, dtype=np.uint8)
+    st = np.empty(n, dtype=np.uint8)
+    if len(kb) != wk:  # a key of the wrong length fails every element, as UnmarshalBinary would fail the one key
+        ok[:], st[:] = 0, 1
+        return ok, st
+    check(lib.kyb_bls12381_verify_g1_same_key(n, kb, mb.ctypes.data, ln, dptr, len(dst), s.ctypes.data, ok.ctypes.data,
+                                              st.ctypes.data, flags), "kyb_bls12381_verify_g1_same_key")
+    for i in bad_s:
+        ok[i], st[i] = 0, 1  # KYB_ST_BAD_POINT
+    return ok, st
+
+
 def _batch_verify(sig_group: int, pubkeys, msgs, sigs, dst: bytes, flags: int):
     """(ok, status): N x bls.Verify (sign/bls/bls.go:82-96; signatures on G1, keys on G2) fused in ONE kernel:
     hash_to_curve, both unmarshal checks, two Miller loops sharing their squarings and one final exponentiation

@@ -12,6 +12,7 @@
 #include "../kyber_amd/csrc/ed25519_h2c.cuh"
 #include "../kyber_amd/csrc/fixed_base.cuh"
 #include "../kyber_amd/csrc/bls12381_fb.cuh"
+#include "../kyber_amd/csrc/bls12381_keylines.cuh"
 #include "../kyber_amd/csrc/coop_slots.cuh"
 #include "../kyber_amd/csrc/scalar_field.cuh"
 #include <pthread.h>
@@ -503,6 +504,17 @@ int hh_scalar_poly_eval(int suite, int n, const uint8_t* idx4, int t, const uint
         memcpy(&ix, idx4 + 4 * i, 4);
         horner(out + 32 * i, ix, (size_t)t, cm.data(), m);
     }
+    return 0;
+}
+// ---- the Miller lines of a fixed G2 point (bls12381_keylines.cuh): 68 x 4 x 48 bytes, each the little-endian integer
+// c 2^392 mod p the tower machine's same-key verification program takes as a constant
+int hh_bls_g2_key_lines(const uint8_t* q96, uint8_t* out) {
+    bls::g2_aff q;
+    const int st = bls::g2_decode(q, q96, true);
+    if (st || q.inf) return st ? st : 64;
+    static uint32_t lines[bls::KEYLINE_STEPS][4][12];
+    if (!bls::g2_key_lines(lines, q)) return 65;
+    memcpy(out, lines, sizeof lines);
     return 0;
 }
 }

@@ -170,6 +170,60 @@ def test_eight_listed_devices_msm_and_batches():
         devices.set_shard_threshold(16384)
 
 
+def test_eight_listed_devices_pair_check_verify_and_commit():
+    """the eight-shard shape for ValidatePairing, the fused bls.Verify and share.PriPoly.Commit (a
+    fixed-base table per device context; here eight shards race for the one context's table) -- uneven split, a forged
+    signature / a rejected point in several shards, generator and arbitrary bases, byte for byte against one device."""
+    from kyber_amd import devices
+    from kyber_amd.pairing import bls12381 as bls, bn256
+
+    devices.set_devices([0] * 8)
+    devices.set_shard_threshold(1)
+    try:
+        n = 8 * 70 + 3
+        k = _shake(b"md8p/k", n * 32).reshape(n, 32).copy()
+        a = _shake(b"md8p/a", n * 32).reshape(n, 32).copy()
+        k[:, 0] &= 0x3F
+        a[:, 0] &= 0x3F
+        for m in (bls, bn256):
+            # Commit: the generator (table known from 64 scalars per shard) and an arbitrary base, twice (table reused)
+            ref, got = _both(devices, lambda: m.g1_commit(a))
+            assert _same(ref, got) and not np.asarray(got[1]).any()
+            base = bytes(np.asarray(got[0])[5])
+            for _ in range(2):
+                ref, got = _both(devices, lambda: m.g1_commit(k, base))
+                assert _same(ref, got) and not np.asarray(got[1]).any()
+            ref, got = _both(devices, lambda: m.g2_commit(k))
+            assert _same(ref, got)
+            P = np.asarray(m.g1_commit(a)[0])
+            Q = np.asarray(got[0])
+            kP = np.asarray(m.g1_batch_mul(k, P)[0])
+            G2 = np.tile(np.frombuffer(m.G2_BASE, dtype=np.uint8), (n, 1))
+            forged = kP.copy()
+            forged[::9] = P[::9]
+            forged[[71, 300, n - 1]] = 0xFF          # undecodable: status, not just false
+            ref, got = _both(devices, lambda: m.batch_validate_pairing(P, Q, forged, G2))
+            assert _same(ref, got)
+            exp = np.ones(n, dtype=bool)
+            exp[::9] = False
+            exp[[71, 300, n - 1]] = False
+            assert (np.asarray(got[0]).astype(bool) == exp).all()
+            assert sorted(np.nonzero(np.asarray(got[1]))[0].tolist()) == [71, 300, n - 1]
+        msgs = _shake(b"md8p/m", n * 32).reshape(n, 32).copy()
+        X = np.asarray(bls.g2_commit(k)[0])
+        Hm = np.asarray(bls.batch_hash_g1(msgs)[0])
+        sig = np.asarray(bls.g1_batch_mul(k, Hm)[0]).copy()
+        sig[::11] = Hm[::11]
+        ref, got = _both(devices, lambda: bls.batch_verify_g1(X, msgs, sig))
+        assert _same(ref, got)
+        exp = np.ones(n, dtype=bool)
+        exp[::11] = False
+        assert (np.asarray(got[0]).astype(bool) == exp).all()
+    finally:
+        devices.set_devices([])
+        devices.set_shard_threshold(16384)
+
+
 def test_device_side_combine_of_gathered_partials():
     """kyber_amd/dist.py _tree_sum on CUDA tensors (what the node-wide MSM runs after the RCCL all-gather since round 3:
     batched Point.Add on device tensors, one host read at the end) against the host path, for every suite and for

@@ -1,0 +1,126 @@
+"""kyb_bls12381_verify_g1_same_key: sign/bls Verify (sign/bls/bls.go:82-96) for many (message, signature) pairs under ONE
+public key -- a drand chain, one tbls participant's partial signatures (sign/tbls/tbls.go:100-107) -- on program
+VERIFYK of the tower machine (both Miller loops from line tables; the key's table built on the device by one lane,
+bls12381_keylines.cuh).  Held against the general fused verification, the oracle and the reference's drand fixture."""
+import hashlib
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import bls12381 as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bls():
+    import torch
+
+    assert torch.cuda.is_available()
+    from kyber_amd.pairing import bls12381
+
+    return bls12381
+
+
+def _scalars(label, n):
+    a = np.frombuffer(hashlib.shake_256(label).digest(n * 32), dtype=np.uint8).reshape(n, 32).copy()
+    a[:, 0] &= 0x3F
+    return a
+
+
+def test_drand_fixture_and_oracle_signatures(bls, golden_dir):
+    """the reference's drand signature (kilic/suite_test.go:17-72: signature on G1 under the G2 domain tag) and three
+    oracle-made signatures under one key verify; each fails under another key or for another message"""
+    D = json.load(open(os.path.join(golden_dir, "bls12381_drand.json")))
+    f = D["sig_on_g1"]
+    msg = hashlib.sha256(struct.pack(">Q", f["round"])).digest()
+    pk, sig = bytes.fromhex(f["pk_g2"]), bytes.fromhex(f["sig_g1"])
+    dst = D["dst_g2"].encode()
+    ok, st = bls.batch_verify_g1_same_key(pk, [msg, msg[::-1]], [sig, sig], dst)
+    assert list(ok) == [1, 0] and not st.any()
+    assert list(bls.batch_verify_g1_same_key(pk, [msg], [sig])[0]) == [0]          # default domain: must fail
+    x = 0x5A17C0DE % O.R
+    X = O.g2_compress(O.g2_mul(x, O.G2_GEN))
+    msgs = [b"beacon-%02d-padding-to-32-bytes!!" % i for i in range(3)]
+    sigs = [O.g1_compress(O.g1_mul(x, O.hash_to_g1(m, bls.DOMAIN_G1))) for m in msgs]
+    ok, st = bls.batch_verify_g1_same_key(X, msgs, sigs)
+    assert list(ok) == [1, 1, 1] and not st.any()
+    ok, _ = bls.batch_verify_g1_same_key(O.g2_compress(O.g2_mul(x + 1, O.G2_GEN)), msgs, sigs)
+    assert not ok.any()
+    ok, _ = bls.batch_verify_g1_same_key(X, msgs, sigs[1:] + sigs[:1])
+    assert not ok.any()
+
+
+def test_same_key_equals_the_general_verification_at_2p16(bls):
+    """2^16 triples under one key, device-resident: forged and undecodable signatures and signatures at infinity
+    scattered through the batch; byte for byte the verdicts and statuses of kyb_bls12381_verify_g1 with the key repeated;
+    then another key (table rebuilt), the first again (rebuilt again), uncompressed + vouched-for forms."""
+    import torch
+
+    n = 1 << 16
+    msgs = torch.from_numpy(np.frombuffer(hashlib.shake_256(b"sk/m").digest(n * 32), dtype=np.uint8).reshape(n, 32).copy()).cuda()
+    Hm, st = bls.batch_hash_g1(msgs)
+    assert not st.any().item()
+    inf1 = torch.zeros(48, dtype=torch.uint8, device="cuda")
+    inf1[0] = 0xC0
+    for which, x in enumerate((0x1F2E3D4C5B6A79 % O.R, (O.R - 5), 0x1F2E3D4C5B6A79 % O.R)):
+        xb = torch.from_numpy(np.frombuffer(x.to_bytes(32, "big"), dtype=np.uint8).copy()).cuda()
+        X = bls.g2_commit(xb.view(1, 32))[0][0].contiguous()
+        sig, _ = bls.g1_batch_mul(xb.repeat(n, 1), Hm)
+        sig = sig.clone()
+        sig[::7] = Hm[::7]          # forged: a valid point, the wrong one
+        sig[5] = 0                  # does not unmarshal
+        sig[n - 1] = 0xFF
+        sig[11] = inf1              # e(H, X) = 1 alone is false
+        ok, st = bls.batch_verify_g1_same_key(X, msgs, sig)
+        ok_r, st_r = bls.batch_verify_g1(X.repeat(n, 1), msgs, sig)
+        torch.cuda.synchronize()
+        assert torch.equal(ok, ok_r) and torch.equal(st, st_r), which
+        exp = torch.ones(n, dtype=torch.bool, device="cuda")
+        exp[::7] = False
+        exp[[5, 11, n - 1]] = False
+        assert torch.equal(ok.bool(), exp) and st[5].item() != 0 and st[n - 1].item() != 0
+    # the same key uncompressed and vouched for (no checks on it): same verdicts
+    Xu = bls.g2_batch_unmarshal(X.view(1, 96), bls.F_UNCOMPRESSED_OUT)[0][0].contiguous()
+    sigu, stu = bls.g1_batch_unmarshal(sig, bls.F_UNCOMPRESSED_OUT)
+    good = (stu == 0)
+    ok_u, st_u = bls.batch_verify_g1_same_key(Xu, msgs, sigu, flags=bls.F_UNCOMPRESSED | bls.F_TRUSTED(0))
+    torch.cuda.synchronize()
+    assert torch.equal(ok_u[good], ok[good])
+
+
+def test_rejected_and_infinite_keys(bls):
+    """a key UnmarshalBinary rejects fails every element with its status; a key outside the subgroup is status 2 (unless
+    vouched for); the key at infinity leaves e(-sig, g2) == 1, true only for the signature at infinity"""
+    n = 200
+    msgs = [hashlib.sha256(b"rk%d" % i).digest() for i in range(n)]
+    x = 77
+    sigs = [O.g1_compress(O.g1_mul(x, O.hash_to_g1(m, bls.DOMAIN_G1))) for m in msgs[:3]] * (n // 3 + 1)
+    sigs = sigs[:n]
+    bad = bytes(96)                                   # compression bit clear
+    ok, st = bls.batch_verify_g1_same_key(bad, msgs, sigs)
+    assert not ok.any() and (st == 1).all()
+    xx = 1
+    while True:                                       # a twist point outside G2
+        c = (xx, 1)
+        y = O.f2_sqrt(O.f2_add(O.f2_mul(O.f2_sqr(c), c), (4, 4)))
+        if y is not None and not O.g2_in_subgroup((c, y)):
+            off = O.g2_compress((c, y))
+            break
+        xx += 1
+    ok, st = bls.batch_verify_g1_same_key(off, msgs, sigs)
+    assert not ok.any() and (st == 2).all()
+    inf2 = b"\xc0" + bytes(95)
+    sigs2 = list(sigs)
+    sigs2[4] = b"\xc0" + bytes(47)
+    ok, st = bls.batch_verify_g1_same_key(inf2, msgs, sigs2)
+    assert not st.any() and list(np.nonzero(ok)[0]) == [4]
+    assert not bls.batch_verify_g1_same_key(bytes(95), msgs, sigs)[0].any()   # a key of the wrong length
+    # ... and a valid key afterwards gets a fresh table
+    X = O.g2_compress(O.g2_mul(x, O.G2_GEN))
+    sg = [O.g1_compress(O.g1_mul(x, O.hash_to_g1(m, bls.DOMAIN_G1))) for m in msgs[:4]]
+    ok, st = bls.batch_verify_g1_same_key(X, msgs[:4], sg)
+    assert ok.all() and not st.any()

@@ -404,3 +404,23 @@ def test_window_table_normalisation_with_entries_at_infinity():
         for j in range(8):
             exp = None if (mask >> j) & 1 else O.g1_mul(j + 1, P)
             assert out[48 * j:48 * j + 48] == O.g1_compress(exp), (mask, j)
+
+
+def test_key_line_table_matches_the_generator_side_walk():
+    """bls12381_keylines.cuh (the per-key table of the same-key verification program, computed on the device by one lane)
+    against gen_tower_vm.py bls_fixed_line_table (which makes the generator's table at build time): every one of the
+    68 x 4 entries, as the integer c 2^392 mod p, for the generator and for random keys."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kyber_amd", "csrc"))
+    import gen_tower_vm as G
+
+    rng = random.Random(31)
+    for k in range(3):
+        Q = O.G2_GEN if k == 0 else O.g2_mul(rng.randrange(1, O.R), O.G2_GEN)
+        st, out = H.call("hh_bls_g2_key_lines", O.g2_compress(Q), out_sizes=(68 * 4 * 48,))
+        assert st == 0
+        want = [c for line in G.bls_fixed_line_table(O.P, Q) for z in line for c in z]
+        got = [int.from_bytes(out[48 * i:48 * i + 48], "little") for i in range(68 * 4)]
+        assert got == [c * (1 << 392) % O.P for c in want], k

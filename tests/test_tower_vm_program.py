@@ -370,3 +370,61 @@ def test_bn254_g2_membership_at_the_end_of_the_ate_loop():
     assert res["flags"] == 0
     for prog in (G.build_bn256_pair(), G.build_bn256_check(), G.build_bn256_check_product()):
         assert not any(r.get("flag", 1) != 1 for ins in prog.ins for r in ins)
+
+
+# ---- VERIFYK: both G2 operands fixed (one public key for every lane), both Miller loops from line tables
+def _samekey_inputs(f, hm, sig):
+    vals = (list(hm[:2]) if hm else [0, 0]) + (list(O.g1_neg(sig)[:2]) if sig else [0, 0])
+    return [v * f.R1 % f.p for v in vals]
+
+
+def test_same_key_verify_program_equals_the_verify_program(verify_prog):
+    """e(H(m), X) e(-sig, g2) == 1 with X's lines from a table: the verdicts AND the Miller-loop value's verdict agree with
+    VERIFY (whose first loop walks X) for a valid signature, a wrong signature, a signature under another key, either
+    pair dead -- for several keys (a program is built per key here; on the device the table half is data)."""
+    rng = random.Random(17)
+    for k in range(2):
+        s = rng.randrange(1, O.R)
+        pk = O.g2_mul(s, O.G2_GEN)
+        prog = G.build_bls12381_verify_same_key(pk)
+        f = prog.f
+        assert len(prog.gconsts) == 2 * 68 * 4 and prog.key_table_base == 68 * 4 and prog.ndyn == 8
+        for j in range(2):
+            hm = O.g1_mul(rng.randrange(1, O.R), O.G1_GEN)
+            sig = O.g1_mul(s, hm)
+            assert not prog.simulate(_samekey_inputs(f, hm, sig))[1]["not_one"]
+            assert prog.simulate(_samekey_inputs(f, hm, O.g1_mul(s + 1, hm)))[1]["not_one"]
+            assert prog.simulate(_samekey_inputs(f, O.g1_mul(3, hm), sig))[1]["not_one"]
+        # the same triple through VERIFY (the key as an operand): same verdicts
+        ins_v = _inputs(f, hm, pk) + [v * f.R1 % f.p for v in O.g1_neg(sig)[:2]]
+        assert not verify_prog.simulate(ins_v)[1]["not_one"]
+        assert prog.simulate(_samekey_inputs(f, hm, None), flags=2)[1]["not_one"]       # signature at infinity
+        assert not prog.simulate(_samekey_inputs(f, None, None), flags=3)[1]["not_one"]  # both pairs dead: 1 == 1
+        assert prog.simulate(_samekey_inputs(f, None, sig), flags=1)[1]["not_one"]       # pair A dead (key at infinity)
+
+
+def test_same_key_verify_program_in_device_arithmetic_and_bounds():
+    prog = G.build_bls12381_verify_same_key(O.g2_mul(0xC0FFEE, O.G2_GEN))
+    f = prog.f
+    hm = O.g1_mul(0xBADC0DE, O.G1_GEN)
+    sig = O.g1_mul(0xC0FFEE, hm)
+    _, res = prog.simulate_limbs(_samekey_inputs(f, hm, sig))
+    assert not res["not_one"]
+    _, res = prog.simulate_limbs(_samekey_inputs(f, hm, O.g1_mul(2, sig)))
+    assert res["not_one"]
+    prog.simulate_limbs([f.p - 1] * 4)  # garbage in: nothing may overflow
+    col, val = prog.check_bounds()
+    assert col < 63 and val < 1024
+    words, sched = prog.encode()
+    assert sum(ln * rep for _, ln, rep in sched) == prog.stats()["executed"]
+    loads = {0: 0, G.GC_ENTRIES: 0}
+    for start, ln, rep in prog.sched:
+        for ins_ in prog.ins[start:start + ln]:
+            for r in ins_:
+                if r["op"] == G.OP_GCLOAD:
+                    loads[r["dst"]] += rep
+                    assert r["arg"][0] + r["arg"][1] * (rep - 1) + G.GC_ENTRIES <= len(prog.gconsts)
+                    assert (r["arg"][0] >= prog.key_table_base) == (r["dst"] == 0)  # the key's lines feed constants 0 .. 3
+    assert loads == {0: 68, G.GC_ENTRIES: 68}
+    # cheaper than VERIFY, which walks the key's point: the reason the entry point exists
+    assert prog.mads() < 0.9 * G.build_bls12381_verify().mads()

@@ -51,6 +51,24 @@ res = {"n": n, "all_valid_accepted": bool(ok.all().item()) and not bool(st.any()
        "wrong_signatures_rejected": int((~okb.bool()).sum().item()), "wrong_signatures": n // 2,
        "verify_ms": t(lambda: m.batch_verify_g1(Q, msgs, sig)),
        "verify_known_keys_ms": t(lambda: m.batch_verify_g1(Q, msgs, sig, flags=m.F_TRUSTED(0)))}
+# one public key for every message (a drand chain): program VERIFYK, both Miller loops from line tables
+x1 = k[:1].contiguous()
+X1 = m.g2_commit(x1)[0][0].contiguous()
+sig1, _ = m.g1_batch_mul(x1.repeat(n, 1), Hm)
+ok1, st1 = m.batch_verify_g1_same_key(X1, msgs, sig1)
+okg, _ = m.batch_verify_g1(X1.repeat(n, 1), msgs, sig1)
+X2 = m.g2_commit(k[1:2].contiguous())[0][0].contiguous()
+alt = [X1, X2]
+i = [0]
+def alternating():  # every call changes the key: every call pays the key's table
+    i[0] ^= 1
+    return m.batch_verify_g1_same_key(alt[i[0]], msgs, sig1)
+res["same_key_all_valid_accepted"] = bool(ok1.all().item()) and not bool(st1.any().item()) and bool(okg.all().item())
+res["same_key_ms"] = t(lambda: m.batch_verify_g1_same_key(X1, msgs, sig1))
+res["same_key_known_key_ms"] = t(lambda: m.batch_verify_g1_same_key(X1, msgs, sig1, flags=m.F_TRUSTED(0)))
+res["same_key_general_program_ms"] = t(lambda: m.batch_verify_g1(X1.repeat(n, 1), msgs, sig1))
+res["same_key_alternating_keys_ms"] = t(alternating)
+res["same_key_per_s"] = n / res["same_key_ms"] * 1e3
 res["verify_per_s"] = n / res["verify_ms"] * 1e3
 res["verify_known_keys_per_s"] = n / res["verify_known_keys_ms"] * 1e3
 print(json.dumps(res))
