@@ -270,6 +270,7 @@ def _tvm_mads():
     return {"bls12381": (G.build_bls12381_pair().mads(), G.build_bls12381_check().mads(), G.build_bls12381_verify().mads()),
             "bn256": (G.build_bn256_pair().mads(), G.build_bn256_check().mads()),
             "bn254": (G.build_bn254_pair().mads(), G.build_bn254_check().mads()),
+            "verifyk": G.build_bls12381_verify_same_key().mads(),
             "gtmul": {"bls12381": G.build_bls12381_gtmul().mads(), "bn256": G.build_bn256_gtmul().mads(),
                       "bn254": G.build_bn254_gtmul().mads()}}
 
@@ -436,6 +437,21 @@ def other_workloads(rank, world, dist):
             out[name]["bls_verify_pipeline_per_s_known_keys"] = world * npair / float(tv[1].item()) * 1e3
             if name == "bls12381":  # the VERIFY program (generator lines from a table); hashing and unmarshalling are extra
                 out[name]["roofline"]["verify"] = _roof(npair / ms_v * 1e3, mads[name][2], g1b_ + g2b_ + 32 + 1, prof, name + "_verify")
+                # ONE signer for the whole batch (a drand chain; sign/bls/bls.go:82-96 in a loop with the same X): program
+                # VERIFYK, both Miller loops from line tables -- valid signatures of the first key over the same messages
+                Hm, _ = m.batch_hash_g1(msgs)
+                x1 = k[:1].contiguous()
+                X1 = m.g2_commit(x1)[0][0].contiguous()
+                sig1, _ = m.g1_batch_mul(x1.repeat(npair, 1), Hm)
+                ok1, st1 = m.batch_verify_g1_same_key(X1, msgs, sig1)
+                ms_v1 = timed(lambda: m.batch_verify_g1_same_key(X1, msgs, sig1))
+                t1 = torch.tensor([ms_v1], dtype=torch.float64, device="cuda")
+                if dist:
+                    dist.all_reduce(t1, op=dist.ReduceOp.MAX)
+                out[name]["bls_verify_same_key_per_s"] = world * npair / float(t1[0].item()) * 1e3
+                out[name]["bls_verify_same_key_all_true"] = bool(ok1.all().item()) and not bool(st1.any().item())
+                out[name]["roofline"]["verify_same_key"] = _roof(npair / ms_v1 * 1e3, mads["verifyk"], g1b_ + 32 + 1, prof, name + "_verifyk")
+                del Hm, sig1
         if name == "bls12381":
             # node-wide MSM at 2^20 points: points sharded over the ranks, all-gather of the partial points
             n = 1 << 20
@@ -694,6 +710,7 @@ def main():
             res["bn256_pairings_per_s"] = other.get("bn256", {}).get("pairings_per_s")
             res["bls12381_g1_commit_2p20_s"] = other.get("bls12381_g1_commit_2p20", {}).get("seconds")
             res["commit_matches_oracle_sample"] = cb.get("bls12381_g1_commit_oracle_sample", {}).get("outputs_match")
+            res["bls12381_verifies_per_s_same_key"] = b.get("bls_verify_same_key_per_s")
             res["bls12381_verifies_per_s"] = b.get("bls_verify_pipeline_per_s")
             res["bls12381_pair_checks_per_s"] = b.get("pairing_checks_per_s")
             res["bls12381_pairings_per_s_validated_inputs"] = b.get("pairings_per_s_validated_inputs")

@@ -96,11 +96,24 @@ class _Bls12381SchemeOnG1(SchemeOnG1):
         for i, m in enumerate(msgs):
             by_len.setdefault(len(m), []).append(i)
         flags = self.m.F_TRUSTED(0) if keys_validated else 0
+        # one signer for the whole batch (a drand chain; the loop of bls.go:82-96 with the same X): both Miller loops
+        # from line tables (kyb_bls12381_verify_g1_same_key), from the batch size at which the key's table pays
+        one_key = len(publics) >= self.SAME_KEY_MIN and all(bytes(p) == bytes(publics[0]) for p in publics)
         for _, idx in by_len.items():
-            ok, st = self.m.batch_verify_g1([publics[i] for i in idx], [bytes(msgs[i]) for i in idx],
-                                            [sigs[i] for i in idx], self.dst, flags)
+            if one_key:
+                ok, st = self.m.batch_verify_g1_same_key(bytes(publics[0]), [bytes(msgs[i]) for i in idx],
+                                                         [sigs[i] for i in idx], self.dst, flags)
+            else:
+                ok, st = self.m.batch_verify_g1([publics[i] for i in idx], [bytes(msgs[i]) for i in idx],
+                                                [sigs[i] for i in idx], self.dst, flags)
             out[idx] = (np.asarray(ok) == 1) & (np.asarray(st) == 0)
         return out
+
+    SAME_KEY_MIN = 256
+
+    def batch_verify_same_key(self, public: bytes, msgs, sigs, key_validated: bool = False):
+        """Verify for many messages of ONE signer (public: its key): what a drand client does with a chain of beacons."""
+        return self.batch_verify([public] * len(msgs), msgs, sigs, key_validated)
 
 
 def NewSchemeOnG1_bls12381(dst: bytes | None = None) -> SchemeOnG1:

@@ -124,3 +124,23 @@ def test_rejected_and_infinite_keys(bls):
     sg = [O.g1_compress(O.g1_mul(x, O.hash_to_g1(m, bls.DOMAIN_G1))) for m in msgs[:4]]
     ok, st = bls.batch_verify_g1_same_key(X, msgs[:4], sg)
     assert ok.all() and not st.any()
+
+
+def test_sign_bls_mirror_routes_one_signer_batches_to_the_same_key_program(bls):
+    """kyber_amd/sign/bls.py: a batch whose keys are all the same (>= SAME_KEY_MIN) goes through VERIFYK; same answers as
+    the per-key path, messages of two lengths, a forged signature"""
+    from kyber_amd.sign import bls as sbls
+
+    sch = sbls.NewSchemeOnG1_bls12381()
+    x = (0x77AA55 << 40 | 0x1234) % bls.ORDER
+    xb = x.to_bytes(32, "big")
+    pub = bytes(bls.g2_commit(xb)[0][0])
+    n = sch.SAME_KEY_MIN + 9
+    msgs = [(b"round-%05d" % i) + (b"!" if i % 3 == 0 else b"") for i in range(n)]
+    Hs = sch.batch_hash(msgs)
+    sigs = [bytes(r) for r in np.asarray(bls.g1_batch_mul(np.tile(np.frombuffer(xb, dtype=np.uint8), (n, 1)), Hs)[0])]
+    sigs[17] = sigs[18]
+    ok = sch.batch_verify_same_key(pub, msgs, sigs)
+    assert list(np.nonzero(~ok)[0]) == [17]
+    ok2 = sch.batch_verify([pub] * (sch.SAME_KEY_MIN - 1), msgs[:sch.SAME_KEY_MIN - 1], sigs[:sch.SAME_KEY_MIN - 1])  # the per-key path
+    assert list(np.nonzero(~ok2)[0]) == [17]
