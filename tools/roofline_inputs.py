@@ -29,14 +29,16 @@ COMMON_PAIRING = [C + "mont.cuh", C + "curve.cuh", C + "tower.cuh"]
 SOURCES = {
     "ed": [C + "ed25519.hip", C + "fe25519.cuh", C + "ge25519.cuh"],
     "bls12381": [C + "bls12381_pair.hip", C + "tower_vm.cuh", C + "gen_tower_vm.py", C + "bls12381_tvm.h", C + "bls12381_prep.hip", C + "bls12381.cuh"] + COMMON_PAIRING,
-    "verify": [C + "bls12381_pair.hip", C + "tower_vm.cuh", C + "gen_tower_vm.py", C + "bls12381_tvm.h", C + "bls12381_prep.hip", C + "bls12381.cuh", C + "bls12381_h2c.cuh"] + COMMON_PAIRING,
-    "gtmul": [C + "bls12381_pair.hip", C + "tower_vm.cuh", C + "gen_tower_vm.py", C + "bls12381_tvm.h"],
+    "verify": [C + "bls12381_pair.hip", C + "tower_vm.cuh", C + "gen_tower_vm.py", C + "bls12381_tvm.h", C + "bls12381_prep.hip", C + "bls12381.cuh", C + "bls12381_h2c.cuh",
+               C + "bls12381_keylines.cuh"] + COMMON_PAIRING,
+    "gtmul": [C + "bls12381_pair.hip", C + "bn256_pair.hip", C + "bn254_pair.hip", C + "bn_pair.inc", C + "tower_vm.cuh", C + "gen_tower_vm.py",
+              C + "bls12381_tvm.h"],
     "bn256": [C + "bn256_pair.hip", C + "bn_pair.inc", C + "tower_vm.cuh", C + "gen_tower_vm.py", C + "bn256.cuh", C + "bn_suite.inc"] + COMMON_PAIRING,
     "bn254": [C + "bn254_pair.hip", C + "bn_pair.inc", C + "tower_vm.cuh", C + "gen_tower_vm.py", C + "bn254.cuh", C + "bn_suite.inc"] + COMMON_PAIRING,
     "mul": [C + "bls12381.hip", C + "bls12381_lvm.cuh", C + "lane_vm.cuh", C + "gen_lane_vm.py", C + "bls12381.cuh", C + "pairing_abi.cuh"] + COMMON_PAIRING,
     "mulperlane": [C + "bls12381.hip", C + "bls12381.cuh", C + "pairing_abi.cuh"] + COMMON_PAIRING,
     "msm_bls": [C + "bls12381_msm.hip", C + "msm.cuh", C + "msm_ws.cuh", C + "coop_slots.cuh", C + "bls12381.cuh"] + COMMON_PAIRING,
-    "fb": [C + "fixed_base.cuh", C + "pairing_abi.cuh", C + "bls12381.hip", C + "bls12381.cuh", C + "coop_slots.cuh"] + COMMON_PAIRING,
+    "fb": [C + "fixed_base.cuh", C + "bls12381_fb.cuh", C + "pairing_abi.cuh", C + "bls12381.hip", C + "bls12381.cuh", C + "coop_slots.cuh"] + COMMON_PAIRING,
 }
 
 
@@ -81,8 +83,11 @@ def entry(prefix, sub, units):
         if not ALLOW_STALE:
             print(f"REFUSED {prefix} ({sub}): profile {tag} is of another binary ({why})", file=sys.stderr)
             return None
+    busy = 4 * sq["SQ_ACTIVE_INST_VALU"] / (1024 * sq["GRBM_GUI_ACTIVE"] / 8)
     e = {"units_per_launch": units,
-         "valu_busy": 4 * sq["SQ_ACTIVE_INST_VALU"] / (1024 * sq["GRBM_GUI_ACTIVE"] / 8),
+         # GRBM_GUI_ACTIVE is summed over the 8 XCDs, whose busy intervals differ by a percent: a saturated kernel can read
+         # 1.00x; the raw ratio is kept beside the clamped figure
+         "valu_busy": min(1.0, busy), "valu_busy_raw": busy,
          "valu_insts_per_unit": sq["SQ_INSTS_VALU"] * 64 / units,
          "wait_share_of_wave_cycles": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
          "source": f"profiles/{tag}_{prefix}_{{sq,fetch,write}}.txt ({sub})",
@@ -108,8 +113,13 @@ for key, prefix, sub, units in (("ed25519_mul", "ed", "ed25519_mul_kernel<true>"
                                 ("bn254_check", "bn254", "bn254_tvm_kernel<1>", 1 << 18),
                                 # round 3: the lane machine's ladders (a G2 element is two lanes), the per-lane kernels of the
                                 # same probe with KYB_LVM_MIN huge, the MSM's accumulate stage
-                                ("bls12381_g1_mul", "mul", "bls12381_lvm_mul_kernel<false", 1 << 16),
+                                # (2^16 G1 elements are one wave per SIMD: the dispatch rule keeps them on the per-lane kernel)
+                                ("bls12381_g1_mul", "mul", "kyb::bls12381_g1_mul_kernel", 1 << 16),
                                 ("bls12381_g2_mul", "mul", "bls12381_lvm_mul_kernel<true", 1 << 16),
+                                ("bls12381_verifyk", "verify", "bls12381_tvm_kernel<3>", 1 << 16),
+                                ("bls12381_gt_mul", "gtmul", "bls12381_gtmul_kernel", 1 << 16),
+                                ("bn256_gt_mul", "gtmul", "bn256_gtmul_kernel", 1 << 16),
+                                ("bn254_gt_mul", "gtmul", "bn254_gtmul_kernel", 1 << 16),
                                 ("bls12381_g1_mul_perlane", "mulperlane", "bls12381_g1_mul_kernel", 1 << 16),
                                 ("bls12381_g2_mul_perlane", "mulperlane", "bls12381_g2_mul_kernel", 1 << 16),
                                 ("bls12381_g1_msm", "msm_bls", "accumulate_kernel", 1 << 20),
