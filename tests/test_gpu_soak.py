@@ -339,3 +339,64 @@ def test_concurrent_host_threads_and_streams():
         t.join(timeout=120)
     assert not any(t.is_alive() for t in threads), "host threads are stuck: lock order?"
     assert not errors, errors
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+@pytest.mark.parametrize("name", ["bls12381", "bn256", "bn254"])
+def test_fixed_base_policies_soak(name, seed):
+    """Round 4: same-base batches through the fixed-base table under the group's policy (BLS12-381: sub-scalars over
+    endomorphism images) -- a fresh random base per seed on both groups, scalars built to stress the splits (multiples of
+    z^2 / |z| and their neighbours, zero sub-scalars, digit carries, values at and above the order), sampled lanes against
+    the oracle's own multiplication; a base outside the subgroup is rejected where UnmarshalBinary rejects it."""
+    import torch
+
+    m = importlib.import_module("kyber_amd.pairing." + name)
+    O = importlib.import_module("oracle." + name)
+    rng = random.Random(7000 + seed)
+    n = 1 << 17
+    z = getattr(O, "X_ABS", 0x44E992B44A6909F1)
+    edge = [0, 1, z, z - 1, z * z, z * z + 1, z * z - 1, z**3, z**3 - 1, 512 * z * z + 512, 3 * z**3 + 2 * z * z + z, (1 << 256) - 1,
+            m.ORDER, m.ORDER - 1, m.ORDER + 1, ((1 << 256) // (z * z)) * z * z, 1023 << 120, (511 << 246) | 512]
+    for grp in (1, 2):
+        omul, gen = (O.g1_mul, O.G1_GEN) if grp == 1 else (O.g2_mul, O.G2_GEN)
+        enc = (getattr(O, "g1_compress", None) or O.g1_marshal) if grp == 1 else (getattr(O, "g2_compress", None) or O.g2_marshal)
+        bp = omul(rng.randrange(1, m.ORDER), gen)
+        base = torch.from_numpy(np.frombuffer(enc(bp), dtype=np.uint8).copy()).cuda()
+        ks = edge + [rng.randrange(1 << 256) for _ in range(24)]
+        s = torch.from_numpy(_shake(b"soak/fb/%s/%d/%d" % (name.encode(), grp, seed), n * 32).reshape(n, 32).copy()).cuda()
+        where = [rng.randrange(n) for _ in ks]
+        where[0], where[1] = 0, n - 1
+        for w, k in zip(where, ks):
+            s[w] = torch.from_numpy(np.frombuffer(k.to_bytes(32, "big"), dtype=np.uint8).copy()).cuda()
+        out, st = (m.g1_commit if grp == 1 else m.g2_commit)(s, base)
+        torch.cuda.synchronize()
+        assert not st.any().item()
+        got, sc = out[where].cpu().numpy(), s[where].cpu().numpy()
+        for j in range(len(ks)):
+            k = int.from_bytes(bytes(sc[j]), "big")  # (a later edge scalar may have overwritten an earlier one's lane)
+            assert bytes(got[j]) == enc(omul(k % m.ORDER, bp)), (name, grp, hex(k))
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_same_key_verification_soak(seed):
+    """Round 4: program VERIFYK on a fresh key, fresh messages and oracle-made signatures per seed, forged ones mixed in;
+    the general fused verification must agree element for element."""
+    from kyber_amd.pairing import bls12381 as bls
+    from oracle import bls12381 as O
+
+    rng = random.Random(8000 + seed)
+    x = rng.randrange(1, O.R)
+    X = O.g2_compress(O.g2_mul(x, O.G2_GEN))
+    n = 40
+    msgs = [bytes(rng.randrange(256) for _ in range(32)) for _ in range(n)]
+    sigs = []
+    for i, mm in enumerate(msgs):
+        good = i % 3 != 1
+        if i < 6:  # a handful straight from the oracle (hash-to-curve + multiplication), the rest through the engine
+            sigs.append(O.g1_compress(O.g1_mul(x if good else x + 1, O.hash_to_g1(mm, bls.DOMAIN_G1))))
+        else:
+            h = bls.batch_hash_g1([mm])[0]
+            sigs.append(bytes(np.asarray(bls.g1_batch_mul(((x if good else x + 1) % O.R).to_bytes(32, "big"), h)[0])[0]))
+    ok, st = bls.batch_verify_g1_same_key(X, msgs, sigs)
+    ok_g, st_g = bls.batch_verify_g1([X] * n, msgs, sigs)
+    assert not np.asarray(st).any() and list(ok) == list(ok_g) == [1 if i % 3 != 1 else 0 for i in range(n)]
