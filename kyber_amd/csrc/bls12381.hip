@@ -24,7 +24,7 @@ extern "C" int kyb_debug_bls12381_lvm_trace(int g2, size_t n, const void* d_scal
                                             void* d_status, uint32_t flags, void* d_trace, void* stream) {
     const uint8_t* only = nullptr;
     KYB_TRY(kyb::bls::lvm_mul(g2 != 0, n, (const uint8_t*)d_scalars, (const uint8_t*)d_points, point_stride, (uint8_t*)d_out,
-                              (uint8_t*)d_status, flags, (hipStream_t)stream, &only, (int32_t*)d_trace));
+                              (uint8_t*)d_status, flags, (hipStream_t)stream, &only, nullptr, (int32_t*)d_trace));
     return only ? KYB_OK : KYB_E_ARG;
 }
 // The machine's batch threshold for both groups (< 0: back to the built-in rule); tests and A/B runs.

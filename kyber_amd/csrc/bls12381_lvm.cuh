@@ -21,6 +21,7 @@
 #include <atomic>
 
 #include "bls12381.cuh"
+#include "bls12381_g1coop.cuh"
 #include "context.h"
 #include "lane_vm.cuh"
 #include "lane_vm_bls12381.inc"
@@ -259,12 +260,33 @@ inline size_t lvm_al(size_t x) { return (x + 255) & ~size_t(255); }
 
 // Enqueues steps 0-3 for elements [0, n).  *only receives the device mask of the elements the per-lane kernel still has
 // to compute (null: the batch is too small for the machine, compute everything there).
+// *handled: the whole batch was done here (nothing left for the per-lane kernel): G1 batches of at most g1_coop_max()
+// elements take the kernel on four cooperating lanes per point (bls12381_g1coop.cuh) -- the chip is mostly empty at such
+// sizes and a call costs the latency of one ladder: 24 product levels per window instead of ~50 dependent
+// multiplications.  KYB_G1_COOP_MAX overrides the threshold (0 = never).
+inline size_t g1_coop_max(int num_cu) {
+    static const long long env = [] {
+        const char* e = getenv("KYB_G1_COOP_MAX");
+        return e ? (long long)strtoull(e, nullptr, 10) : -1ll;
+    }();
+    if (env >= 0) return (size_t)env;
+    return (size_t)num_cu * g1coop::GROUPS * 4;  // four workgroups of 16 points per CU: one wave per SIMD
+}
 inline int lvm_mul(bool g2, size_t n, const uint8_t* d_scalars, const uint8_t* d_points, size_t point_stride, uint8_t* d_out,
-                   uint8_t* d_status, uint32_t flags, hipStream_t st, const uint8_t** only, int32_t* trace = nullptr) {
+                   uint8_t* d_status, uint32_t flags, hipStream_t st, const uint8_t** only, bool* handled = nullptr,
+                   int32_t* trace = nullptr) {
     *only = nullptr;
+    if (handled) *handled = false;
     DeviceCtx* ctx;
     int rc = get_ctx(&ctx);
     if (rc) return rc;
+    if (!g2 && handled && !trace && point_stride && n <= g1_coop_max(ctx->num_cu)) {
+        hipLaunchKernelGGL(g1coop::bls12381_g1_mul_coop_kernel, dim3((unsigned)((n + g1coop::GROUPS - 1) / g1coop::GROUPS)), dim3(64), 0, st, n,
+                           d_scalars, d_points, point_stride, d_out, d_status, flags);
+        KYB_HIP_CHECK(hipGetLastError());
+        *handled = true;
+        return KYB_OK;
+    }
     if (n < lvm_min_batch(g2, ctx->num_cu)) return KYB_OK;
     std::lock_guard<std::recursive_mutex> lk(ctx->enq_mu);
     const size_t chunk = g2 ? (size_t(1) << 16) : (size_t(1) << 17);

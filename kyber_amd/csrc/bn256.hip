@@ -13,8 +13,9 @@
 namespace kyb {
 namespace bn {
 // (the lane machine of bls12381_lvm.cuh has no BN programs yet: every element goes to the per-lane kernels)
-inline int lvm_mul(bool, size_t, const uint8_t*, const uint8_t*, size_t, uint8_t*, uint8_t*, uint32_t, hipStream_t, const uint8_t** only) {
+inline int lvm_mul(bool, size_t, const uint8_t*, const uint8_t*, size_t, uint8_t*, uint8_t*, uint32_t, hipStream_t, const uint8_t** only, bool* handled) {
     *only = nullptr;
+    *handled = false;
     return KYB_OK;
 }
 }  // namespace bn

@@ -166,8 +166,10 @@ int kyb_##PFX##_g1_mul_dev(size_t n, const void* d_scalars, const void* d_points
     kyb::DeviceCtx* ctx_; \
     KYB_TRY(kyb::get_ctx(&ctx_)); \
     std::lock_guard<std::recursive_mutex> enq_(ctx_->enq_mu); \
+    bool handled_ = false; /* the suite's hook did the whole batch (BLS12-381 G1: the small-batch kernel on cooperating lanes) */ \
     KYB_TRY(kyb::NS::lvm_mul(false, n, (const uint8_t*)d_scalars, (const uint8_t*)d_points, point_stride, (uint8_t*)d_out, \
-                             (uint8_t*)d_status, flags, (hipStream_t)stream, &only)); \
+                             (uint8_t*)d_status, flags, (hipStream_t)stream, &only, &handled_)); \
+    if (handled_) return KYB_OK; \
     hipLaunchKernelGGL(kyb::PFX##_g1_mul_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
                        (const uint8_t*)d_scalars, (const uint8_t*)d_points, point_stride, (uint8_t*)d_out, \
                        (uint8_t*)d_status, flags, only); \
@@ -188,8 +190,10 @@ int kyb_##PFX##_g2_mul_dev(size_t n, const void* d_scalars, const void* d_points
     kyb::DeviceCtx* ctx_; \
     KYB_TRY(kyb::get_ctx(&ctx_)); \
     std::lock_guard<std::recursive_mutex> enq_(ctx_->enq_mu); \
+    bool handled_ = false; /* the suite's hook did the whole batch (BLS12-381 G1: the small-batch kernel on cooperating lanes) */ \
     KYB_TRY(kyb::NS::lvm_mul(true, n, (const uint8_t*)d_scalars, (const uint8_t*)d_points, point_stride, (uint8_t*)d_out, \
-                             (uint8_t*)d_status, flags, (hipStream_t)stream, &only)); \
+                             (uint8_t*)d_status, flags, (hipStream_t)stream, &only, &handled_)); \
+    if (handled_) return KYB_OK; \
     hipLaunchKernelGGL(kyb::PFX##_g2_mul_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
                        (const uint8_t*)d_scalars, (const uint8_t*)d_points, point_stride, (uint8_t*)d_out, \
                        (uint8_t*)d_status, flags, only); \

@@ -3,7 +3,7 @@ process, so tests/test_gpu_switches.py runs this file in a subprocess per value)
 
   fb   : same-base batches (fixed_base.cuh) -- KYB_FB_MIN
   msm  : Pippenger pipeline tail (msm.cuh)  -- KYB_MSM_TAIL, KYB_MSM_SUB
-  lvm  : G1 / G2 Mul dispatch (bls12381_lvm.cuh) -- KYB_LVM_MIN
+  lvm  : G1 / G2 Mul dispatch (bls12381_lvm.cuh) -- KYB_LVM_MIN, KYB_G1_COOP_MAX (the small-batch kernel on cooperating lanes)
 """
 import os
 import random

@@ -13,6 +13,7 @@
 #include "../kyber_amd/csrc/fixed_base.cuh"
 #include "../kyber_amd/csrc/bls12381_fb.cuh"
 #include "../kyber_amd/csrc/bls12381_keylines.cuh"
+#include "../kyber_amd/csrc/bls12381_g1coop.cuh"
 #include "../kyber_amd/csrc/coop_slots.cuh"
 #include "../kyber_amd/csrc/scalar_field.cuh"
 #include <pthread.h>
@@ -515,6 +516,59 @@ int hh_bls_g2_key_lines(const uint8_t* q96, uint8_t* out) {
     static uint32_t lines[bls::KEYLINE_STEPS][4][12];
     if (!bls::g2_key_lines(lines, q)) return 65;
     memcpy(out, lines, sizeof lines);
+    return 0;
+}
+// ---- G1Elt.Mul on four cooperating lanes (bls12381_g1coop.cuh) with four THREADS as the lanes of one group: the whole
+// ladder -- table, 34 windows, the z^2 half from the beta x slots -- against the per-lane routine's answer
+int hh_bls_g1_mul_coop(const uint8_t* k32, const uint8_t* pt, int flags, uint8_t* out) {
+    using namespace kyb::bls;
+    g1_aff a;
+    const int st = g1_decode_f(a, pt, (uint32_t)flags, 0);
+    if (st) return st;
+    if (a.inf) {
+        g1_encode_f(out, a, (uint32_t)flags);
+        return 0;
+    }
+    uint32_t k[8];
+    scalar_from_be(k, k32);
+    static int8_t e0[g1coop::NDIG], e1[g1coop::NDIG];
+    g1coop::digits(e0, e1, k);
+    static g1coop::Slot S[g1coop::NS];
+    static uint32_t fl[2];
+    S[g1coop::TAB].f = a.x;
+    S[g1coop::TAB + 1].f = a.y;
+    fp_one(S[g1coop::TAB + 2].f);
+    pthread_barrier_init(&g_coop_barrier, nullptr, 4);
+    std::thread th[4];
+    for (int r = 0; r < 4; r++) th[r] = std::thread([=]() { g1coop::ladder(S, fl, r, e0, e1); });
+    for (int r = 0; r < 4; r++) th[r].join();
+    pthread_barrier_destroy(&g_coop_barrier);
+    g1_jac p;
+    p.X = S[g1coop::ACC].f;
+    p.Y = S[g1coop::ACC + 1].f;
+    p.Z = S[g1coop::ACC + 2].f;
+    jac_to_aff(a, p);
+    g1_encode_f(out, a, (uint32_t)flags);
+    return 0;
+}
+// the subgroup rule on four cooperating lanes (g1coop::member), threads as lanes; *verdict = 1 for a member
+int hh_bls_g1_member_coop(const uint8_t* pt, int* verdict) {
+    using namespace kyb::bls;
+    g1_aff a;
+    const int st = g1_decode(a, pt, false);
+    if (st || a.inf) return st ? st : 64;
+    static g1coop::Slot S[g1coop::NS];
+    static uint32_t fl[2];
+    static int res[4];
+    S[g1coop::TAB].f = a.x;
+    S[g1coop::TAB + 1].f = a.y;
+    fp_one(S[g1coop::TAB + 2].f);
+    pthread_barrier_init(&g_coop_barrier, nullptr, 4);
+    std::thread th[4];
+    for (int r = 0; r < 4; r++) th[r] = std::thread([=]() { res[r] = g1coop::member(S, fl, r) ? 1 : 0; });
+    for (int r = 0; r < 4; r++) th[r].join();
+    pthread_barrier_destroy(&g_coop_barrier);
+    *verdict = res[0];
     return 0;
 }
 }

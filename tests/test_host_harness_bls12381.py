@@ -424,3 +424,47 @@ def test_key_line_table_matches_the_generator_side_walk():
         want = [c for line in G.bls_fixed_line_table(O.P, Q) for z in line for c in z]
         got = [int.from_bytes(out[48 * i:48 * i + 48], "little") for i in range(68 * 4)]
         assert got == [c * (1 << 392) % O.P for c in want], k
+
+
+def test_g1_mul_on_four_cooperating_lanes_vs_oracle():
+    """bls12381_g1coop.cuh -- the small-batch G1Elt.Mul: table of (j + 1) P and the GLV ladder on four lanes through LDS
+    slots -- run on the CPU with four threads as the lanes: edge scalars (0, 1, the order and its neighbours, 2^256 - 1,
+    multiples of z^2 so that a half is zero, digits of -8), scalars that make the accumulator meet a table entry
+    (the addition's P = Q case), random ones; compressed and uncompressed forms."""
+    rng = random.Random(41)
+    z2 = O.X_ABS**2
+    P = O.g1_mul(rng.randrange(1, O.R), O.G1_GEN)
+    ks = [0, 1, 2, 7, 8, 9, 15, 16, 17, O.R - 1, O.R, O.R + 1, (1 << 256) - 1, z2, z2 - 1, z2 + 1, 5 * z2, 8 * z2 + 8, 0x88888888 * z2 + 0x8888,
+          (1 << 255), int.from_bytes(b"\x88" * 32, "big"), int.from_bytes(b"\x77" * 32, "big")]
+    ks += [rng.randrange(1 << 256) for _ in range(10)] + [rng.randrange(O.R) for _ in range(4)]
+    for k in ks:
+        st, out = H.call("hh_bls_g1_mul_coop", k.to_bytes(32, "big"), O.g1_compress(P), 0, out_sizes=(48,))
+        assert st == 0 and out == O.g1_compress(O.g1_mul(k % O.R, P)), hex(k)
+    k = ks[-1]
+    st, out = H.call("hh_bls_g1_mul_coop", k.to_bytes(32, "big"), O.g1_serialize_unc(P), 2 | 4 | 0x100, out_sizes=(96,))
+    assert st == 0 and out == O.g1_serialize_unc(O.g1_mul(k % O.R, P))
+    st, out = H.call("hh_bls_g1_mul_coop", (5).to_bytes(32, "big"), O.g1_compress(None), 0, out_sizes=(48,))
+    assert st == 0 and out == O.g1_compress(None)
+    assert H.call("hh_bls_g1_mul_coop", (5).to_bytes(32, "big"), bytes(48), 0, out_sizes=(48,))[0] == 1
+
+
+def test_g1_subgroup_rule_on_four_cooperating_lanes():
+    """g1coop::member (the small-batch kernel's r-torsion test: two cooperative multiplications by |z|, Scott's criterion)
+    with threads as lanes: members, cofactor points found by trial, a member plus a cofactor component."""
+    import ctypes
+
+    lib = H.lib()
+
+    def verdict(pt):
+        v = ctypes.c_int(-1)
+        st = lib.hh_bls_g1_member_coop(ctypes.c_char_p(O.g1_compress(pt)), ctypes.byref(v))
+        return st, v.value
+
+    rng = random.Random(43)
+    c1, _ = _cofactor_points()
+    P = O.g1_mul(rng.randrange(1, O.R), O.G1_GEN)
+    assert verdict(P) == (0, 1) and verdict(O.G1_GEN) == (0, 1)
+    assert verdict(c1) == (0, 0)
+    small = O.g1_mul(O.R, c1)
+    assert verdict(small) == (0, 0) and verdict(O.g1_add(P, small)) == (0, 0)
+    assert verdict(O.g1_mul(O.H1, c1)) == (0, 1)  # clearing the cofactor lands in G1
