@@ -225,3 +225,225 @@ __global__ __launch_bounds__(64) void bls12381_g1_mul_coop_kernel(size_t n, cons
 }  // namespace g1coop
 }  // namespace bls
 }  // namespace kyb
+
+// ---------------------------------------------------------------------------------------------------------------- G2
+// The same for G2Elt.Mul (kilic/g2.go): a point is four lanes over Fp2 slots, the GLS ladder of g2_mul_gls -- k = a0 + a1 |z|
+// + a2 |z|^2 + a3 |z|^3, |z|^j Q = (-1)^j psi^j(Q), 18 windows of 4 doublings + 4 additions -- with psi^j applied to the
+// (Jacobian) table entry while it is staged: psi(X : Y : Z) = (cx conj X : cy conj Y : conj Z), one product level in which
+// lanes 0 and 1 multiply by the constants (kept once per workgroup in six shared slots).  Small batches only, like G1:
+// below ~2^13 elements a call costs the latency of the ladder (4.6 - 6.0 ms validated, 7.4 - 8.7 ms with the checks).
+namespace kyb {
+namespace bls {
+namespace g2coop {
+
+constexpr int NDIG = 18, NH = 4;
+constexpr int ACC = 0, Q = 3, TMP = 6, TAB = TMP + coop::TEMPS, NS = TAB + 24;
+using Slot = coop::Slot<fp2>;
+// shared constants: [0] cx, [1] cy, [2] (nx, 0), [3] (ny, 0), [4] cx nx, [5] cy ny   (psi, psi^2, psi^3 scalings)
+constexpr int NCONST = 6;
+
+KYB_HD void constants(Slot* C) {
+    fp2 cx, cy, t;
+    fp nx, ny, u;
+    fp2_load_const<TC>(cx, CC::PSI_CX);
+    fp2_load_const<TC>(cy, CC::PSI_CY);
+    fp_sqr(nx, cx.c0);
+    fp_sqr(u, cx.c1);
+    fp_add(nx, nx, u);
+    fp_sqr(ny, cy.c0);
+    fp_sqr(u, cy.c1);
+    fp_add(ny, ny, u);
+    C[0].f = cx;
+    C[1].f = cy;
+    t.c0 = nx;
+    fp_zero(t.c1);
+    C[2].f = t;
+    t.c0 = ny;
+    C[3].f = t;
+    fp2_mul_fp(t, cx, nx);
+    C[4].f = t;
+    fp2_mul_fp(t, cy, ny);
+    C[5].f = t;
+}
+KYB_HD void digits(int8_t (&e)[NH][NDIG], const uint32_t (&k)[8]) {
+    uint32_t q1[8], q2[8], q3[8], a0[2], a1[2], a2[2];
+    divmod_z<2>(q1, a0, k);
+    divmod_z<2>(q2, a1, q1);
+    divmod_z<2>(q3, a2, q2);
+    int8_t d[65];
+    const uint32_t* src[NH] = {a0, a1, a2, q3};
+#pragma unroll 1
+    for (int h = 0; h < NH; h++) {
+        glv_digits(d, src[h], h == 3 ? 3 : 2);
+#pragma unroll 1
+        for (int i = 0; i < NDIG; i++) e[h][i] = d[i];
+    }
+}
+// stage image h (|z|^h Q up to the sign the caller folds into `neg`) of the Jacobian point in slots B .. B + 2 into Q
+KYB_COOP_FN void stage(Slot* S, const Slot* C, int r, int B, int h, bool neg) {
+    if (r < 3) {
+        fp2 v = S[B + r].f;
+        if (h & 1) fp2_conj(v, v);
+        if (h && r < 2) fp2_mul_c(v, v, C[(h == 1 ? 0 : (h == 2 ? 2 : 4)) + r].f);
+        if (r == 1) {
+            fp2 nv;
+            fp2_neg(nv, v);
+            fp2_cmov(v, nv, neg);
+        }
+        S[Q + r].f = v;
+    }
+    KYB_COOP_SYNC();
+}
+// S[ACC ..] <- k Q for the affine point in S[TAB], S[TAB + 1] (S[TAB + 2] = 1); e: the group's digits e[h * NDIG + i]
+KYB_COOP_FN void ladder(Slot* S, const Slot* C, uint32_t* fl, int r, const int8_t* e) {
+    if (r < 3) S[ACC + r].f = S[TAB + r].f;
+    KYB_COOP_SYNC();
+    coop::dbl<fp2>(S, r, ACC, TMP, true);
+    if (r < 3) {
+        S[TAB + 3 + r].f = S[ACC + r].f;
+        S[Q + r].f = S[TAB + r].f;
+    }
+    KYB_COOP_SYNC();
+#pragma unroll 1
+    for (int j = 2; j < 8; j++) {
+        coop::add<fp2>(S, fl, r, ACC, Q, TMP, true);
+        if (r < 3) S[TAB + 3 * j + r].f = S[ACC + r].f;
+        KYB_COOP_SYNC();
+    }
+    if (r < 3) {
+        fp2 v;
+        fp2_one(v);
+        if (r == 2) fp2_zero(v);
+        S[ACC + r].f = v;
+    }
+    KYB_COOP_SYNC();
+#pragma unroll 1
+    for (int i = NDIG - 1; i >= 0; i--) {
+        if (i != NDIG - 1) {
+#pragma unroll 1
+            for (int d = 0; d < 4; d++) coop::dbl<fp2>(S, r, ACC, TMP, true);
+        }
+#pragma unroll 1
+        for (int h = 0; h < NH; h++) {
+            const int d = e[h * NDIG + i];
+            const int a = d < 0 ? -d : d, j = a ? a - 1 : 0;
+            stage(S, C, r, TAB + 3 * j, h, (h & 1) ? d > 0 : d < 0);  // |z|^h Q = (-1)^h psi^h(Q)
+            coop::add<fp2>(S, fl, r, ACC, Q, TMP, d != 0);
+        }
+    }
+}
+// [|z|] B on the four lanes (B: slots of a Jacobian point), as g1coop::mul_z
+KYB_COOP_FN void mul_z(Slot* S, uint32_t* fl, int r, int B) {
+    if (r < 3) {
+        const fp2 v = S[B + r].f;
+        S[ACC + r].f = v;
+        S[Q + r].f = v;
+    }
+    KYB_COOP_SYNC();
+#pragma unroll 1
+    for (int bit = 62; bit >= 0; bit--) {
+        coop::dbl<fp2>(S, r, ACC, TMP, true);
+        if ((CC::X_ABS >> bit) & 1ull) coop::add<fp2>(S, fl, r, ACC, Q, TMP, true);
+    }
+}
+// the r-torsion rule (g2_in_subgroup): |z| Q = -psi(Q) for the affine point in S[TAB ..]; lane 0's verdict
+KYB_COOP_FN bool member(Slot* S, const Slot* C, uint32_t* fl, int r) {
+    mul_z(S, fl, r, TAB);
+    bool ok = true;
+    if (r == 0) {
+        fp2 px, py, zz, zzz, l, rr;
+        const fp2 X = S[ACC].f, Y = S[ACC + 1].f, Z = S[ACC + 2].f;
+        fp2_conj(px, S[TAB].f);
+        fp2_mul_c(px, px, C[0].f);
+        fp2_conj(py, S[TAB + 1].f);
+        fp2_mul_c(py, py, C[1].f);
+        fp2_neg(py, py);
+        fp2_sqr_c(zz, Z);
+        fp2_mul_c(zzz, zz, Z);
+        fp2_mul_c(l, px, zz);
+        fp2_mul_c(rr, py, zzz);
+        ok = fp2_eq(l, X) & fp2_eq(rr, Y) & !fp2_is_zero(Z);
+    }
+    KYB_COOP_SYNC();
+    return ok;
+}
+
+#if defined(__HIPCC__)
+constexpr int GROUPS = 16;
+__global__ __launch_bounds__(64) void bls12381_g2_mul_coop_kernel(size_t n, const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ pts,
+                                                                  size_t pt_stride, uint8_t* __restrict__ out, uint8_t* __restrict__ status,
+                                                                  uint32_t flags) {
+    __shared__ Slot slots[GROUPS * NS];
+    __shared__ Slot consts[NCONST];
+    __shared__ uint32_t flg[GROUPS * 2];
+    __shared__ int8_t dig[GROUPS][NH * NDIG];
+    __shared__ int verdict[GROUPS];
+    const int gi = (int)threadIdx.x >> 2, r = (int)threadIdx.x & 3;
+    const size_t idx = (size_t)blockIdx.x * GROUPS + gi;
+    const bool live = idx < n;
+    const size_t ic = live ? idx : n - 1;
+    Slot* S = slots + gi * NS;
+    const bool check = !flag_trusted(flags, 0);
+    if (threadIdx.x == 1) constants(consts);  // (a lane that does no decoding)
+    if (r == 0) {
+        g2_aff a;
+        const uint8_t* in = pts + pt_stride * ic;
+        const int st = (flags & FLAG_UNCOMPRESSED) ? g2_decode_unc(a, in, check, false) : g2_decode(a, in, false);
+        verdict[gi] = st | ((st == ST_OK && a.inf) ? 0x100 : 0);
+        if (st != ST_OK || a.inf) {
+            fp2_load_const<TC>(a.x, CC::G2X);
+            fp2_load_const<TC>(a.y, CC::G2Y);
+        }
+        uint32_t k[8];
+        scalar_from_be(k, scalars + 32 * ic);
+        int8_t e[NH][NDIG];
+        digits(e, k);
+#pragma unroll 1
+        for (int h = 0; h < NH; h++)
+#pragma unroll 1
+            for (int i = 0; i < NDIG; i++) dig[gi][h * NDIG + i] = e[h][i];
+        S[TAB].f = a.x;
+        S[TAB + 1].f = a.y;
+        fp2 one;
+        fp2_one(one);
+        S[TAB + 2].f = one;
+    }
+    __syncthreads();
+    if (check) {
+        const bool in_g2 = member(S, consts, flg + gi * 2, r);
+        if (r == 0 && verdict[gi] == 0 && !in_g2) {
+            verdict[gi] = ST_NOT_IN_SUBGROUP;
+            fp2_load_const<TC>(S[TAB].f, CC::G2X);
+            fp2_load_const<TC>(S[TAB + 1].f, CC::G2Y);
+        }
+        __syncthreads();
+    }
+    ladder(S, consts, flg + gi * 2, r, dig[gi]);
+    if (r == 0 && live) {
+        uint8_t* o = out + g2_out_size(flags) * idx;
+        const int v = verdict[gi];
+        if (v & 0xff) {
+            zero_bytes(o, (int)g2_out_size(flags));
+        } else {
+            g2_aff a;
+            if (v & 0x100) {
+                fp2_zero(a.x);
+                fp2_zero(a.y);
+                a.inf = true;
+            } else {
+                g2_jac p;
+                p.X = S[ACC].f;
+                p.Y = S[ACC + 1].f;
+                p.Z = S[ACC + 2].f;
+                jac_to_aff(a, p);
+            }
+            g2_encode_f(o, a, flags);
+        }
+        if (status) status[idx] = (uint8_t)(v & 0xff);
+    }
+}
+#endif
+
+}  // namespace g2coop
+}  // namespace bls
+}  // namespace kyb

@@ -272,6 +272,14 @@ inline size_t g1_coop_max(int num_cu) {
     if (env >= 0) return (size_t)env;
     return (size_t)num_cu * g1coop::GROUPS * 4;  // four workgroups of 16 points per CU: one wave per SIMD
 }
+inline size_t g2_coop_max(int num_cu) {  // the same for G2 (g2coop): 61 KB of slots per workgroup, two per CU
+    static const long long env = [] {
+        const char* e = getenv("KYB_G2_COOP_MAX");
+        return e ? (long long)strtoull(e, nullptr, 10) : -1ll;
+    }();
+    if (env >= 0) return (size_t)env;
+    return (size_t)num_cu * g2coop::GROUPS * 2;
+}
 inline int lvm_mul(bool g2, size_t n, const uint8_t* d_scalars, const uint8_t* d_points, size_t point_stride, uint8_t* d_out,
                    uint8_t* d_status, uint32_t flags, hipStream_t st, const uint8_t** only, bool* handled = nullptr,
                    int32_t* trace = nullptr) {
@@ -282,6 +290,13 @@ inline int lvm_mul(bool g2, size_t n, const uint8_t* d_scalars, const uint8_t* d
     if (rc) return rc;
     if (!g2 && handled && !trace && point_stride && n <= g1_coop_max(ctx->num_cu)) {
         hipLaunchKernelGGL(g1coop::bls12381_g1_mul_coop_kernel, dim3((unsigned)((n + g1coop::GROUPS - 1) / g1coop::GROUPS)), dim3(64), 0, st, n,
+                           d_scalars, d_points, point_stride, d_out, d_status, flags);
+        KYB_HIP_CHECK(hipGetLastError());
+        *handled = true;
+        return KYB_OK;
+    }
+    if (g2 && handled && !trace && point_stride && n <= g2_coop_max(ctx->num_cu)) {
+        hipLaunchKernelGGL(g2coop::bls12381_g2_mul_coop_kernel, dim3((unsigned)((n + g2coop::GROUPS - 1) / g2coop::GROUPS)), dim3(64), 0, st, n,
                            d_scalars, d_points, point_stride, d_out, d_status, flags);
         KYB_HIP_CHECK(hipGetLastError());
         *handled = true;

@@ -571,4 +571,48 @@ int hh_bls_g1_member_coop(const uint8_t* pt, int* verdict) {
     *verdict = res[0];
     return 0;
 }
+// G2Elt.Mul on four cooperating lanes (g2coop), threads as lanes; member != null: only the subgroup rule's verdict
+int hh_bls_g2_mul_coop(const uint8_t* k32, const uint8_t* pt, int flags, uint8_t* out, int* member) {
+    using namespace kyb::bls;
+    g2_aff a;
+    const int st = member ? g2_decode(a, pt, false) : g2_decode_f(a, pt, (uint32_t)flags, 0);
+    if (st) return st;
+    if (a.inf) {
+        if (member) return 64;
+        g2_encode_f(out, a, (uint32_t)flags);
+        return 0;
+    }
+    uint32_t k[8];
+    scalar_from_be(k, k32);
+    static int8_t e[g2coop::NH][g2coop::NDIG];
+    g2coop::digits(e, k);
+    static g2coop::Slot S[g2coop::NS], C[g2coop::NCONST];
+    static uint32_t fl[2];
+    static int res[4];
+    g2coop::constants(C);
+    S[g2coop::TAB].f = a.x;
+    S[g2coop::TAB + 1].f = a.y;
+    fp2_one(S[g2coop::TAB + 2].f);
+    pthread_barrier_init(&g_coop_barrier, nullptr, 4);
+    std::thread th[4];
+    const bool only_member = member != nullptr;
+    for (int r = 0; r < 4; r++)
+        th[r] = std::thread([=]() {
+            if (only_member) res[r] = g2coop::member(S, C, fl, r) ? 1 : 0;
+            else g2coop::ladder(S, C, fl, r, &e[0][0]);
+        });
+    for (int r = 0; r < 4; r++) th[r].join();
+    pthread_barrier_destroy(&g_coop_barrier);
+    if (member) {
+        *member = res[0];
+        return 0;
+    }
+    g2_jac p;
+    p.X = S[g2coop::ACC].f;
+    p.Y = S[g2coop::ACC + 1].f;
+    p.Z = S[g2coop::ACC + 2].f;
+    jac_to_aff(a, p);
+    g2_encode_f(out, a, (uint32_t)flags);
+    return 0;
+}
 }

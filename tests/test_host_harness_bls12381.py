@@ -468,3 +468,35 @@ def test_g1_subgroup_rule_on_four_cooperating_lanes():
     small = O.g1_mul(O.R, c1)
     assert verdict(small) == (0, 0) and verdict(O.g1_add(P, small)) == (0, 0)
     assert verdict(O.g1_mul(O.H1, c1)) == (0, 1)  # clearing the cofactor lands in G1
+
+
+def test_g2_mul_and_subgroup_rule_on_four_cooperating_lanes():
+    """g2coop (the small-batch G2Elt.Mul): the GLS ladder with psi^j applied while a table entry is staged, and the
+    subgroup rule |z| Q = -psi(Q), four threads as the lanes, against the oracle: edge scalars, multiples of |z|^j (zero
+    sub-scalars), digits of -8, random scalars; members and cofactor points."""
+    import ctypes
+
+    lib = H.lib()
+    rng = random.Random(47)
+    z = O.X_ABS
+    Qp = O.g2_mul(rng.randrange(1, O.R), O.G2_GEN)
+    ks = [0, 1, 8, 9, 16, O.R - 1, O.R, O.R + 1, (1 << 256) - 1, z, z - 1, z + 1, z * z, z**3, z**3 - 1, 8 * z**3 + 8 * z * z + 8 * z + 8,
+          int.from_bytes(b"\x88" * 32, "big")] + [rng.randrange(1 << 256) for _ in range(6)]
+    for k in ks:
+        out = ctypes.create_string_buffer(96)
+        st = lib.hh_bls_g2_mul_coop(ctypes.c_char_p(k.to_bytes(32, "big")), ctypes.c_char_p(O.g2_compress(Qp)), 0, out, None)
+        assert st == 0 and out.raw == O.g2_compress(O.g2_mul(k % O.R, Qp)), hex(k)
+    out = ctypes.create_string_buffer(96)
+    assert lib.hh_bls_g2_mul_coop(ctypes.c_char_p((7).to_bytes(32, "big")), ctypes.c_char_p(O.g2_compress(None)), 0, out, None) == 0
+    assert out.raw == O.g2_compress(None)
+
+    def verdict(pt):
+        v = ctypes.c_int(-1)
+        st = lib.hh_bls_g2_mul_coop(ctypes.c_char_p(bytes(32)), ctypes.c_char_p(O.g2_compress(pt)), 0, None, ctypes.byref(v))
+        return st, v.value
+
+    _, c2 = _cofactor_points()
+    assert verdict(Qp) == (0, 1) and verdict(O.G2_GEN) == (0, 1)
+    assert verdict(c2) == (0, 0)
+    small = O.g2_mul(O.R, c2)
+    assert verdict(small) == (0, 0) and verdict(O.g2_add(Qp, small)) == (0, 0)
