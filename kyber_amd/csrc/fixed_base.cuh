@@ -188,6 +188,7 @@ template <class T>
 constexpr size_t chain_bytes() { return ((sizeof(Jac<typename T::F>) * T::P::NW + sizeof(Aff<typename T::F>) + 255) / 256) * 256; }
 template <class T>
 constexpr size_t ws_bytes() { return HDR_BYTES + chain_bytes<T>() + sizeof(Entry<typename T::F, T::P::NI>) * T::P::NW * NENT; }
+constexpr size_t PARK_MIN = size_t(1) << 14;  // batches from which the results are parked for the shared inversion
 template <class T>
 __device__ __forceinline__ Aff<typename T::F>* base_slot(uint8_t* ws) {  // the decoded base, kept for the membership test
     return reinterpret_cast<Aff<typename T::F>*>(ws + HDR_BYTES + sizeof(Jac<typename T::F>) * T::P::NW);
@@ -280,10 +281,13 @@ __global__ __launch_bounds__(64, T::MUL_WAVES) void member_kernel(uint8_t* __res
     if (!T::member(a, tab)) h->status = 2u;  // ST_NOT_IN_SUBGROUP: every coefficient fails alike
     h->member_pending = 0;
 }
-// One lane per scalar
+// One lane per scalar.  `park` (large batches): the Jacobian results go there and encode_kernel turns them into wire
+// bytes eight at a time with ONE inversion (Montgomery's trick) -- the division-step inversion is ~22 k instructions,
+// an eighth of the walk's 26 additions, per element otherwise.
 template <class T>
 __global__ __launch_bounds__(64, T::MUL_WAVES) void mul_kernel(size_t n, const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ ws,
-                                                    uint8_t* __restrict__ out, uint8_t* __restrict__ status, uint32_t flags) {
+                                                    uint8_t* __restrict__ out, uint8_t* __restrict__ status, uint32_t flags,
+                                                    Jac<typename T::F>* __restrict__ park) {
     using F = typename T::F;
     const Header* h = reinterpret_cast<const Header*>(ws);
     const auto* tab = reinterpret_cast<const Entry<F, T::P::NI>*>(ws + HDR_BYTES + chain_bytes<T>());
@@ -308,10 +312,65 @@ __global__ __launch_bounds__(64, T::MUL_WAVES) void mul_kernel(size_t n, const u
         T::scalar(k, scalars + 32 * idx);
         Jac<F> r;
         mul<typename T::P>(r, k, tab);
+        if (park) {
+            park[idx] = r;
+            return;
+        }
         jac_to_aff(a, r);
     }
     T::encode(o, a, flags);
     if (status) status[idx] = 0;
+}
+// The parked results of mul_kernel -> wire bytes: a lane takes EB consecutive elements, multiplies their Z's up, inverts
+// the product once and walks back (3 multiplications per element instead of an inversion each).  An element at infinity
+// (Z = 0) enters the product as one.
+template <class F>
+constexpr int encode_batch() { return sizeof(F) > 64 ? 4 : 8; }
+template <class T>
+__global__ __launch_bounds__(64) void encode_kernel(size_t n, const uint8_t* __restrict__ ws, const Jac<typename T::F>* __restrict__ park,
+                                                    uint8_t* __restrict__ out, uint8_t* __restrict__ status, uint32_t flags) {
+    using F = typename T::F;
+    constexpr int EB = encode_batch<F>();
+    const Header* h = reinterpret_cast<const Header*>(ws);
+    if (h->status || h->inf) return;  // mul_kernel wrote those outputs itself
+    const size_t lo = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * EB;
+    if (lo >= n) return;
+    const int m = (int)(n - lo < (size_t)EB ? n - lo : (size_t)EB);
+    F pre[EB];  // pre[j] = Z_0 .. Z_j (infinite elements skipped)
+    F run;
+    f_one(run);
+#pragma unroll
+    for (int j = 0; j < EB; j++) {
+        if (j < m) {
+            const F z = park[lo + j].Z;
+            if (!f_is_zero(z)) f_mul(run, run, z);
+        }
+        pre[j] = run;
+    }
+    F inv;
+    f_inv(inv, run);
+    const size_t osz = T::out_size(flags);
+#pragma unroll
+    for (int j = EB - 1; j >= 0; j--) {
+        if (j >= m) continue;
+        const Jac<F> r = park[lo + j];
+        Aff<F> a;
+        a.inf = f_is_zero(r.Z);
+        if (a.inf) {
+            f_zero(a.x);
+            f_zero(a.y);
+        } else {
+            F zi = inv, zi2;
+            if (j > 0) f_mul(zi, inv, pre[j - 1]);  // 1 / Z_j
+            f_mul(inv, inv, r.Z);                    // 1 / (Z_0 .. Z_{j-1})
+            f_sqr(zi2, zi);
+            f_mul(a.x, r.X, zi2);
+            f_mul(zi2, zi2, zi);
+            f_mul(a.y, r.Y, zi2);
+        }
+        T::encode(out + osz * (lo + j), a, flags);
+        if (status) status[lo + j] = 0;
+    }
 }
 
 // Enqueue chain (if the base changed) + table + multiplication on `st`.  `key`: the base's wire bytes + flag bytes when
@@ -327,13 +386,22 @@ int run(size_t n, const void* d_scalars, const void* d_base, void* d_out, void* 
     void* ws;
     bool grew = false;
     fb_hint_set(ctx, T::KIND, st, nullptr);
-    if (int rc = ctx_workspace(ctx, T::KIND, st, ws_bytes<T>(), &ws, &grew)) return rc;
+    const bool parked = n >= PARK_MIN;
+    const size_t tab_bytes = (ws_bytes<T>() + 255) & ~size_t(255);
+    if (int rc = ctx_workspace(ctx, T::KIND, st, tab_bytes + (parked ? n * sizeof(Jac<typename T::F>) : 0), &ws, &grew)) return rc;
     if (grew) KYB_HIP_CHECK(hipMemsetAsync(ws, 0, HDR_BYTES, st));
+    auto* park = parked ? reinterpret_cast<Jac<typename T::F>*>((uint8_t*)ws + tab_bytes) : nullptr;
     hipLaunchKernelGGL(chain_kernel<T>, dim3(1), dim3(4), 0, st, (uint8_t*)ws, (const uint8_t*)d_base, flags);
     hipLaunchKernelGGL(table_kernel<T>, dim3((T::P::NW * NENT + 63) / 64), dim3(64), 0, st, (uint8_t*)ws);
     if (T::needs_member(flags)) hipLaunchKernelGGL(member_kernel<T>, dim3(1), dim3(64), 0, st, (uint8_t*)ws);
     hipLaunchKernelGGL(mul_kernel<T>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, (const uint8_t*)d_scalars, (const uint8_t*)ws,
-                       (uint8_t*)d_out, (uint8_t*)d_status, flags);
+                       (uint8_t*)d_out, (uint8_t*)d_status, flags, park);
+    if (parked) {
+        constexpr int EB = encode_batch<typename T::F>();
+        const size_t lanes = (n + EB - 1) / EB;
+        hipLaunchKernelGGL(encode_kernel<T>, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, n, (const uint8_t*)ws,
+                           (const Jac<typename T::F>*)park, (uint8_t*)d_out, (uint8_t*)d_status, flags);
+    }
     if (hipGetLastError() != hipSuccess) {
         hipMemsetAsync(ws, 0, HDR_BYTES, st);  // never trust a half-built table
         set_error("fixed-base multiplication: launch failed");
