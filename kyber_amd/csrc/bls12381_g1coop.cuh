@@ -220,6 +220,46 @@ __global__ __launch_bounds__(64) void bls12381_g1_mul_coop_kernel(size_t n, cons
         if (status) status[idx] = (uint8_t)(v & 0xff);
     }
 }
+// G1Elt.UnmarshalBinary for small batches: lane 0 applies the flag / range / curve rules and the square root, the group's
+// four lanes the subgroup rule (member()), lane 0 re-encodes -- bls12381_g1_unmarshal_kernel's answer at the latency of
+// 438 product levels instead of ~1 040 dependent multiplications.
+__global__ __launch_bounds__(64) void bls12381_g1_unmarshal_coop_kernel(size_t n, const uint8_t* __restrict__ pts, uint8_t* __restrict__ out,
+                                                                        uint8_t* __restrict__ status, uint32_t flags) {
+    constexpr int MS = TAB + 6;  // ACC, Q, temporaries and two points
+    __shared__ Slot slots[GROUPS * MS];
+    __shared__ uint32_t flg[GROUPS * 2];
+    const int gi = (int)threadIdx.x >> 2, r = (int)threadIdx.x & 3;
+    const size_t idx = (size_t)blockIdx.x * GROUPS + gi;
+    const bool live = idx < n;
+    const size_t ic = live ? idx : n - 1;
+    Slot* S = slots + gi * MS;
+    const bool check = !flag_trusted(flags, 0);
+    g1_aff a;  // lane 0's
+    int st = ST_OK;
+    if (r == 0) {
+        const uint8_t* in = pts + g1_wire_size(flags) * ic;
+        st = (flags & FLAG_UNCOMPRESSED) ? g1_decode_unc(a, in, check, false) : g1_decode(a, in, false);
+        const bool walk = st == ST_OK && !a.inf;
+        if (walk) {
+            S[TAB].f = a.x;
+            S[TAB + 1].f = a.y;
+        } else {
+            fp_const(S[TAB].f, CC::G1X);
+            fp_const(S[TAB + 1].f, CC::G1Y);
+        }
+        fp_one(S[TAB + 2].f);
+    }
+    __syncthreads();
+    bool in_g1 = true;
+    if (check) in_g1 = member(S, flg + gi * 2, r);
+    if (r == 0 && live) {
+        if (st == ST_OK && !a.inf && !in_g1) st = ST_NOT_IN_SUBGROUP;
+        uint8_t* o = out + g1_out_size(flags) * idx;
+        if (st != ST_OK) zero_bytes(o, (int)g1_out_size(flags));
+        else g1_encode_f(o, a, flags);
+        if (status) status[idx] = (uint8_t)st;
+    }
+}
 #endif
 
 }  // namespace g1coop
@@ -440,6 +480,44 @@ __global__ __launch_bounds__(64) void bls12381_g2_mul_coop_kernel(size_t n, cons
             g2_encode_f(o, a, flags);
         }
         if (status) status[idx] = (uint8_t)(v & 0xff);
+    }
+}
+__global__ __launch_bounds__(64) void bls12381_g2_unmarshal_coop_kernel(size_t n, const uint8_t* __restrict__ pts, uint8_t* __restrict__ out,
+                                                                        uint8_t* __restrict__ status, uint32_t flags) {
+    constexpr int MS = TAB + 3;
+    __shared__ Slot slots[GROUPS * MS];
+    __shared__ Slot consts[NCONST];
+    __shared__ uint32_t flg[GROUPS * 2];
+    const int gi = (int)threadIdx.x >> 2, r = (int)threadIdx.x & 3;
+    const size_t idx = (size_t)blockIdx.x * GROUPS + gi;
+    const bool live = idx < n;
+    const size_t ic = live ? idx : n - 1;
+    Slot* S = slots + gi * MS;
+    const bool check = !flag_trusted(flags, 0);
+    if (threadIdx.x == 1) constants(consts);
+    g2_aff a;
+    int st = ST_OK;
+    if (r == 0) {
+        const uint8_t* in = pts + g2_wire_size(flags) * ic;
+        st = (flags & FLAG_UNCOMPRESSED) ? g2_decode_unc(a, in, check, false) : g2_decode(a, in, false);
+        if (st == ST_OK && !a.inf) {
+            S[TAB].f = a.x;
+            S[TAB + 1].f = a.y;
+        } else {
+            fp2_load_const<TC>(S[TAB].f, CC::G2X);
+            fp2_load_const<TC>(S[TAB + 1].f, CC::G2Y);
+        }
+        fp2_one(S[TAB + 2].f);
+    }
+    __syncthreads();
+    bool in_g2 = true;
+    if (check) in_g2 = member(S, consts, flg + gi * 2, r);
+    if (r == 0 && live) {
+        if (st == ST_OK && !a.inf && !in_g2) st = ST_NOT_IN_SUBGROUP;
+        uint8_t* o = out + g2_out_size(flags) * idx;
+        if (st != ST_OK) zero_bytes(o, (int)g2_out_size(flags));
+        else g2_encode_f(o, a, flags);
+        if (status) status[idx] = (uint8_t)st;
     }
 }
 #endif

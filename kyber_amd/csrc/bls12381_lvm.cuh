@@ -280,6 +280,21 @@ inline size_t g2_coop_max(int num_cu) {  // the same for G2 (g2coop): 61 KB of s
     if (env >= 0) return (size_t)env;
     return (size_t)num_cu * g2coop::GROUPS * 2;
 }
+// UnmarshalBinary of a small batch on cooperating lanes (the subgroup rule is what a lone lane spends its time on)
+inline int unmarshal_small(bool g2, size_t n, const uint8_t* d_points, uint8_t* d_out, uint8_t* d_status, uint32_t flags, hipStream_t st,
+                           bool* handled) {
+    *handled = false;
+    DeviceCtx* ctx;
+    int rc = get_ctx(&ctx);
+    if (rc) return rc;
+    if (n > (g2 ? g2_coop_max(ctx->num_cu) : g1_coop_max(ctx->num_cu))) return KYB_OK;
+    const unsigned grid = (unsigned)((n + 15) / 16);
+    if (g2) hipLaunchKernelGGL(g2coop::bls12381_g2_unmarshal_coop_kernel, dim3(grid), dim3(64), 0, st, n, d_points, d_out, d_status, flags);
+    else hipLaunchKernelGGL(g1coop::bls12381_g1_unmarshal_coop_kernel, dim3(grid), dim3(64), 0, st, n, d_points, d_out, d_status, flags);
+    KYB_HIP_CHECK(hipGetLastError());
+    *handled = true;
+    return KYB_OK;
+}
 inline int lvm_mul(bool g2, size_t n, const uint8_t* d_scalars, const uint8_t* d_points, size_t point_stride, uint8_t* d_out,
                    uint8_t* d_status, uint32_t flags, hipStream_t st, const uint8_t** only, bool* handled = nullptr,
                    int32_t* trace = nullptr) {

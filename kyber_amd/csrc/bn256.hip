@@ -18,6 +18,10 @@ inline int lvm_mul(bool, size_t, const uint8_t*, const uint8_t*, size_t, uint8_t
     *handled = false;
     return KYB_OK;
 }
+inline int unmarshal_small(bool, size_t, const uint8_t*, uint8_t*, uint8_t*, uint32_t, hipStream_t, bool* handled) {
+    *handled = false;
+    return KYB_OK;
+}
 }  // namespace bn
 }  // namespace kyb
 KYB_DEFINE_MUL_ABI(bn256, bn, 64, 128)

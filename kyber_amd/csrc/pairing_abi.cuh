@@ -296,6 +296,9 @@ int kyb_##PFX##_g1_unmarshal_dev(size_t n, const void* d_points, void* d_out, vo
         return KYB_E_ARG; \
     } \
     if (!n) return KYB_OK; \
+    bool small_ = false; /* the suite's small-batch kernel took it (BLS12-381: cooperating lanes) */ \
+    KYB_TRY(kyb::NS::unmarshal_small(false, n, (const uint8_t*)d_points, (uint8_t*)d_out, (uint8_t*)d_status, flags, (hipStream_t)stream, &small_)); \
+    if (small_) return KYB_OK; \
     hipLaunchKernelGGL(kyb::PFX##_g1_unmarshal_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
                        (const uint8_t*)d_points, (uint8_t*)d_out, (uint8_t*)d_status, flags); \
     KYB_HIP_CHECK(hipGetLastError()); \
@@ -309,6 +312,9 @@ int kyb_##PFX##_g2_unmarshal_dev(size_t n, const void* d_points, void* d_out, vo
         return KYB_E_ARG; \
     } \
     if (!n) return KYB_OK; \
+    bool small_ = false; /* the suite's small-batch kernel took it (BLS12-381: cooperating lanes) */ \
+    KYB_TRY(kyb::NS::unmarshal_small(true, n, (const uint8_t*)d_points, (uint8_t*)d_out, (uint8_t*)d_status, flags, (hipStream_t)stream, &small_)); \
+    if (small_) return KYB_OK; \
     hipLaunchKernelGGL(kyb::PFX##_g2_unmarshal_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
                        (const uint8_t*)d_points, (uint8_t*)d_out, (uint8_t*)d_status, flags); \
     KYB_HIP_CHECK(hipGetLastError()); \

@@ -92,6 +92,42 @@ def lvm():
         mul, enc = (OB.g1_mul, OB.g1_compress) if grp == 1 else (OB.g2_mul, OB.g2_compress)
         for i in list(range(6)) + [777, n - 1]:
             assert bytes(np.asarray(out)[i]) == enc(mul(ks[i] * hs[i] % B.ORDER, gen)), (grp, i)
+    _lvm_unmarshal()
+
+
+def _lvm_unmarshal():
+    """UnmarshalBinary through whichever kernel the switches select: members, a point outside the subgroup, an encoding
+    the flag rules refuse, infinity -- both groups, compressed and uncompressed output"""
+    from kyber_amd.pairing import bls12381 as B
+    from oracle import bls12381 as OB
+
+    rng = random.Random(9)
+    x = 1
+    while True:
+        y = OB.fp_sqrt((x * x * x + 4) % OB.P)
+        if y is not None and not OB.g1_in_subgroup((x, y)):
+            off1 = OB.g1_compress((x, y))
+            break
+        x += 1
+    x = 1
+    while True:
+        c = (x, 1)
+        y = OB.f2_sqrt(OB.f2_add(OB.f2_mul(OB.f2_sqr(c), c), (4, 4)))
+        if y is not None and not OB.g2_in_subgroup((c, y)):
+            off2 = OB.g2_compress((c, y))
+            break
+        x += 1
+    for grp, mul, gen, enc, unc, off, w in ((1, OB.g1_mul, OB.G1_GEN, OB.g1_compress, OB.g1_serialize_unc, off1, 48),
+                                            (2, OB.g2_mul, OB.G2_GEN, OB.g2_compress, OB.g2_serialize_unc, off2, 96)):
+        pts = [mul(rng.randrange(1, B.ORDER), gen) for _ in range(5)]
+        wire = [enc(p) for p in pts] + [off, bytes(w), enc(None)]
+        out, st = B.ENGINE.batch_unmarshal(grp, b"".join(wire))
+        assert list(np.asarray(st)) == [0] * 5 + [2, 1, 0], (grp, list(np.asarray(st)))
+        assert [bytes(r) for r in np.asarray(out)] == wire[:5] + [bytes(w), bytes(w), enc(None)]
+        outu, st = B.ENGINE.batch_unmarshal(grp, b"".join(wire), B.F_UNCOMPRESSED_OUT)
+        assert [bytes(r) for r in np.asarray(outu)[:5]] == [unc(p) for p in pts] and list(np.asarray(st)) == [0] * 5 + [2, 1, 0]
+        outt, st = B.ENGINE.batch_unmarshal(grp, b"".join(wire), B.F_TRUSTED(0))   # vouched for: the subgroup rule is skipped
+        assert list(np.asarray(st)) == [0] * 6 + [1, 0]
 
 
 if __name__ == "__main__":
