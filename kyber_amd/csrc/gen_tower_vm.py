@@ -31,6 +31,10 @@ OP_DOT, OP_IDLE, OP_GLOAD, OP_INV, OP_GT_STORE, OP_IS_ONE, OP_CLOAD, OP_SPILL, O
 # a check program / rejects a GT element; FLAG_G2_A / FLAG_G2_B say that the G2 operand of pair A / B is outside the
 # order-r subgroup (decided at the end of the Miller loop: bls_g2_member_check)
 FLAG_VERDICT, FLAG_G2_A, FLAG_G2_B = 1, 2, 4
+# raised when a coefficient of the joint Miller value of a product-form check is NON-zero: a lane that leaves the program
+# without it had a zero Miller value -- the one case in which the product form and "two pairings + Equal" differ (bn256's
+# G2 accepts points of small order) -- and is handed to the two-pairing program (tower_vm.cuh Args::redo_out / only)
+FLAG_MILLER_NONZERO = 8
 K_PROD, K_LIN, K_PROD_CONST = 0, 1, 2
 GC_ENTRIES = 4  # table entries one OP_GCLOAD record moves into the constant area (64 lanes x 1 word = 4 x 16 words)
 
@@ -1871,7 +1875,7 @@ def build_bn_check(curve):
     return P
 
 
-def build_bn_check_product(curve, member=True):
+def build_bn_check_product(curve, member=True, zero_flag=False):
     """ValidatePairing as ONE final exponentiation: ok = (f_{Q1}(P1) f_{Q2}(-P2))^e == 1, the two Miller loops sharing the
     squarings of f.  Equivalent to the reference's two pairings + Equal whenever both G2 operands lie in the order-n
     subgroup -- which pairing/bn254's UnmarshalBinary guarantees (twist.go:47-66); bn256, whose G2 is unchecked, keeps
@@ -1941,8 +1945,15 @@ def build_bn_check_product(curve, member=True):
     if curve.strict_g2 and member:
         for k in range(2):
             bn_g2_member_check(P, curve, *Ts[k], Qs[k], tmp, FLAG_G2_B if k else FLAG_G2_A)
-    res = bn_final_exp(P, T, FF, gam, curve)
     one = (P.c_plain_one, 1)
+    if zero_flag:
+        # Is the joint Miller value zero?  (Only a G2 operand with a component of tiny order makes a line vanish; then
+        # e(p1, p2) = 0 or e(inv1, inv2) = 0 in the reference's terms, and "0 == 0" is TRUE there while the product is
+        # never one.)  The twelve coefficients in plain form (set B is free: the points are dead), each raising
+        # FLAG_MILLER_NONZERO unless it is zero.
+        P.dot(sum((outs2(BN_B + 2 * j, BN_B + 2 * j + 1, Acc2().prod_const(FF[j], one, None)) for j in range(6)), []), "miller/to_plain")
+        P.misc([dict(op=OP_IS_ONE, dst=BN_B + i, arg=0, flag=FLAG_MILLER_NONZERO) for i in range(12)], "miller/nonzero")
+    res = bn_final_exp(P, T, FF, gam, curve)
     P.dot(sum((outs2(BN_A + 2 * j, BN_A + 2 * j + 1, Acc2().prod_const(res[j], one, None)) for j in range(6)), []), "to_plain")
     P.misc([dict(op=OP_IS_ONE, dst=BN_A + 2 * j + c, arg=(1 if (j == 0 and c == 0) else 0) << 16) for j in range(6) for c in range(2)],
            "is_one")
@@ -1972,7 +1983,7 @@ def build_bn254_gtmul(): return build_bn_gtmul(BN254)
 def build_bn256_check(): return build_bn_check(BN256)
 def build_bn254_pair(): return build_bn_pair(BN254)
 def build_bn254_check(): return build_bn_check_product(BN254)
-def build_bn256_check_product(): return build_bn_check_product(BN256)
+def build_bn256_check_product(): return build_bn_check_product(BN256, zero_flag=True)
 
 
 # ------------------------------------------------------------------------------------------------ emission

@@ -82,6 +82,10 @@ struct Args {
     uint32_t g2_member;      // bit k: operand k is a G2 point that was decoded without its r-torsion test; the program's
                              // verdict on it (result-flag bit 1 for operands 0-1, bit 2 for operands 2-3) stands in:
                              // status 2 and a rejected pairing, exactly as if the operand kernel had reported it
+    uint8_t* redo_out;       // may be null.  [pairing] <- 1 when the program left result-flag bit 8 CLEAR (a product-form
+                             // check whose joint Miller value was zero: gen_tower_vm.py FLAG_MILLER_NONZERO), else 0
+    const uint8_t* only;     // may be null.  The launch computes and stores ONLY the pairings marked here (the redo_out
+                             // of an earlier launch); a batch of 64 without a marked pairing is skipped whole
 };
 
 template <class F>
@@ -244,7 +248,9 @@ __device__ void words_to_limbs(int32_t (&r)[F::N], const uint32_t (&w)[F::NW]) {
 // EXPO: the GT exponentiation programs -- store mask 3 is decoded, a failed comparison (OP_CMP_EQ: the membership test)
 // rejects the element (zero output, status 2) instead of feeding a boolean.  A separate instantiation, so that the
 // pairing kernels' code is what it was.
-template <class F, class Inv, bool EXPO = false>
+// REDO: the launch honours Args::redo_out / Args::only (a product-form check and its two-pairing fallback: bn_pair.inc);
+// its own instantiation too, for the same reason.
+template <class F, class Inv, bool EXPO = false, bool REDO = false>
 __device__ void run(const Args& a, uint32_t* lds, uint32_t* misc, int32_t* clds) {
     constexpr int N = F::N;
     constexpr int SW = Lds<F>::SLOT_WORDS;
@@ -255,6 +261,9 @@ __device__ void run(const Args& a, uint32_t* lds, uint32_t* misc, int32_t* clds)
         const size_t pairing = batch * LANES + lane;
         const bool valid = pairing < a.n;
         const size_t pidx = valid ? pairing : a.n - 1;  // out-of-range lanes recompute the last pairing, store nothing
+        if constexpr (REDO) {
+            if (a.only && !__syncthreads_or((valid && a.only[pidx]) ? 1 : 0)) continue;  // (uniform: nothing marked in this batch)
+        }
         // lane flags: bit 0 pair A dead (an operand at infinity), bit 1 pair B dead, bit 7 an operand was rejected
         // mchk: the result-flag bits that reject this lane (an operand named by g2_member that decoded fine and is not
         // the point at infinity: its membership verdict is the program's)
@@ -455,8 +464,13 @@ __device__ void run(const Args& a, uint32_t* lds, uint32_t* misc, int32_t* clds)
             recw = rec_next;
             more = more2;
         }
-        if (wave == 0 && valid) {
+        bool store = wave == 0 && valid;
+        if constexpr (REDO) store = store && !(a.only && !a.only[pairing]);
+        if (store) {
             const uint32_t mf = misc[lane];
+            if constexpr (REDO) {
+                if (a.redo_out) a.redo_out[pairing] = (mf & 8u) ? 0 : 1;
+            }
             if (a.check) a.out[pairing * a.out_stride] = (!(mf & (1u | mchk)) && !(fl >> 7)) ? 1 : 0;
             if (a.status) {
                 // the first operand, in argument order, that UnmarshalBinary would have refused: a decode status of the

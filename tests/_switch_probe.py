@@ -130,6 +130,29 @@ def _lvm_unmarshal():
         assert list(np.asarray(st)) == [0] * 6 + [1, 0]
 
 
+def bncheck():
+    """bn256 ValidatePairing -- product form + zero-Miller-value fallback (default) or the reference's two pairings
+    (KYB_BN_CHECK=two): ordinary pairs and the degenerate ones a G2 point of order 13 makes"""
+    from kyber_amd.pairing import bn256 as bn
+    from oracle import bn256 as ON
+
+    rng = random.Random(3)
+    h = 2 * ON.P - ON.ORDER
+    while True:
+        x = (rng.randrange(ON.P), rng.randrange(ON.P))
+        y = ON.f2_sqrt(ON.f2_add(ON.f2_mul(ON.f2_sqr(x), x), ON.TWIST_B))
+        if y is not None:
+            break
+    Q13 = ON.g2_mul(ON.ORDER * h // 13, (x, y))
+    p1, q1 = ON.g1_mul(9, ON.G1_GEN), ON.g2_mul(4, ON.G2_GEN)
+    quads = [(p1, q1, ON.g1_mul(36, ON.G1_GEN), ON.G2_GEN), (p1, q1, ON.g1_mul(37, ON.G1_GEN), ON.G2_GEN),
+             (p1, Q13, ON.g1_mul(2, ON.G1_GEN), ON.g2_mul(3, Q13)), (p1, Q13, p1, q1)] * 20
+    ok, st = bn.batch_validate_pairing(b"".join(ON.g1_marshal(q[0]) for q in quads), b"".join(ON.g2_marshal(q[1]) for q in quads),
+                                       b"".join(ON.g1_marshal(q[2]) for q in quads), b"".join(ON.g2_marshal(q[3]) for q in quads))
+    assert not np.asarray(st).any()
+    assert [bool(v) for v in np.asarray(ok)] == [True, False, True, False] * 20
+
+
 if __name__ == "__main__":
-    {"fb": fb, "msm": msm, "lvm": lvm}[sys.argv[1]]()
+    {"fb": fb, "msm": msm, "lvm": lvm, "bncheck": bncheck}[sys.argv[1]]()
     print("switch-probe ok", sys.argv[1])

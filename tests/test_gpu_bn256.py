@@ -283,3 +283,46 @@ def test_same_base_commit_with_an_off_subgroup_g2_base_at_2p18(bn):
     for p, v in zip(pos, ks):
         assert bytes(out[p]) == O.g2_marshal(O.g2_mul(v, q)), p
     assert bytes(out[5]) == base
+
+
+def test_validate_pairing_product_form_with_the_zero_miller_fallback():
+    """Round 4: bn256's ValidatePairing runs the product form (one final exponentiation) and hands the lanes whose joint
+    Miller value was zero -- a G2 operand with a component of order 13 -- to the two-pairing program: booleans equal the
+    oracle's two pairings + Equal on ordinary pairs, on pairs where one or BOTH pairings are zero (0 == 0 is true in the
+    reference), on G2 operands carrying a small-order component, scattered through a batch of several workgroups."""
+    import random
+
+    from kyber_amd.pairing import bn256 as bn
+    from oracle import bn256 as ON
+
+    rng = random.Random(17)
+    h = 2 * ON.P - ON.ORDER
+    while True:
+        x = (rng.randrange(ON.P), rng.randrange(ON.P))
+        y = ON.f2_sqrt(ON.f2_add(ON.f2_mul(ON.f2_sqr(x), x), ON.TWIST_B))
+        if y is not None:
+            break
+    Q13 = ON.g2_mul(ON.ORDER * h // 13, (x, y))
+    p1, q1 = ON.g1_mul(5, ON.G1_GEN), ON.g2_mul(7, ON.G2_GEN)
+    special = [
+        (p1, q1, ON.g1_mul(35, ON.G1_GEN), ON.G2_GEN),
+        (p1, q1, ON.g1_mul(36, ON.G1_GEN), ON.G2_GEN),
+        (p1, Q13, ON.g1_mul(35, ON.G1_GEN), ON.G2_GEN),
+        (p1, q1, ON.g1_mul(35, ON.G1_GEN), Q13),
+        (p1, Q13, ON.g1_mul(3, ON.G1_GEN), ON.g2_mul(2, Q13)),
+        (p1, ON.g2_add(q1, Q13), ON.g1_mul(7, ON.G1_GEN), ON.g2_add(ON.g2_mul(5, ON.G2_GEN), Q13)),
+        (None, Q13, ON.g1_mul(3, ON.G1_GEN), ON.g2_mul(4, Q13)),   # pair A dead (infinity), pair B's value zero: 1 == 0 false
+    ]
+    n = 300
+    a, b = ON.g1_marshal(p1), ON.g2_marshal(q1)
+    c, d = ON.g1_marshal(ON.g1_mul(35, ON.G1_GEN)), ON.g2_marshal(ON.G2_GEN)
+    P1, P2, I1, I2 = [a] * n, [b] * n, [c] * n, [d] * n
+    want = [True] * n
+    for j, (pa, qa, pb, qb) in enumerate(special):
+        for pos in (j, 64 + 9 * j, n - 1 - j):
+            P1[pos], P2[pos], I1[pos], I2[pos] = ON.g1_marshal(pa), ON.g2_marshal(qa), ON.g1_marshal(pb), ON.g2_marshal(qb)
+            want[pos] = ON.validate_pairing(pa, qa, pb, qb)
+    ok, st = bn.batch_validate_pairing(b"".join(P1), b"".join(P2), b"".join(I1), b"".join(I2))
+    assert not np.asarray(st).any()
+    assert [bool(v) for v in np.asarray(ok)] == want
+    assert want[4] and want[64 + 36] and not want[2]  # (the both-zero case IS true in the reference)

@@ -266,6 +266,51 @@ def test_bn256_product_form_check_and_degenerate_g2_points():
             assert _bn_gt_bytes(res) == ON.gt_marshal(ON.pair(p, Q)), q
 
 
+def test_bn256_product_form_marks_zero_miller_values():
+    """Round 4: bn256's default ValidatePairing is the product form + a fallback.  The product program leaves result-flag
+    bit 8 (FLAG_MILLER_NONZERO) set unless the joint Miller value is zero -- which takes a G2 operand with a component of
+    order 13 -- and exactly then the reference's "two pairings + Equal" can differ (0 == 0 is TRUE there): those lanes go
+    to the two-pairing program, fed -inv1 (zero-ness is untouched by the sign).  Both simulators; the fallback program's
+    verdict on the prepared inputs equals the oracle's ValidatePairing."""
+    from oracle import bn256 as ON
+
+    prod, two = G.build_bn256_check_product(), G.build_bn256_check()
+    f = prod.f
+    h = 2 * ON.P - ON.ORDER
+    rng = random.Random(5)
+    while True:
+        x = (rng.randrange(ON.P), rng.randrange(ON.P))
+        y = ON.f2_sqrt(ON.f2_add(ON.f2_mul(ON.f2_sqr(x), x), ON.TWIST_B))
+        if y is not None:
+            break
+    Q13 = ON.g2_mul(ON.ORDER * h // 13, (x, y))
+    assert Q13 is not None and ON.g2_mul(13, Q13) is None
+    p1, q1 = ON.g1_mul(5, ON.G1_GEN), ON.g2_mul(7, ON.G2_GEN)
+    cases = [
+        (p1, q1, ON.g1_mul(35, ON.G1_GEN), ON.G2_GEN),              # ordinary, true
+        (p1, q1, ON.g1_mul(36, ON.G1_GEN), ON.G2_GEN),              # ordinary, false
+        (p1, Q13, ON.g1_mul(35, ON.G1_GEN), ON.G2_GEN),             # one Miller value zero: false either way
+        (p1, Q13, ON.g1_mul(3, ON.G1_GEN), ON.g2_mul(2, Q13)),      # both zero: the reference says TRUE
+        (p1, ON.g2_add(q1, Q13), ON.g1_mul(7, ON.G1_GEN), ON.g2_add(ON.g2_mul(5, ON.G2_GEN), Q13)),  # a small component, values non-zero
+    ]
+    for k, (pa, qa, pb, qb) in enumerate(cases):
+        ins = _inputs(f, pa, qa) + _inputs(f, ON.g1_neg(pb), qb)      # what check_prep_kernel leaves for the product form
+        want = ON.validate_pairing(pa, qa, pb, qb)
+        _, res = prod.simulate(ins)
+        marked = not (res["flags"] & G.FLAG_MILLER_NONZERO)
+        assert marked == (k in (2, 3)), k
+        if marked:
+            assert not two.simulate(ins)[1]["not_one"] == want, k   # the fallback's verdict on the SAME inputs
+        else:
+            assert (not res["not_one"]) == want, k
+    _, res = prod.simulate_limbs(_inputs(f, *cases[3][:2]) + _inputs(f, ON.g1_neg(cases[3][2]), cases[3][3]))
+    assert not (res["flags"] & G.FLAG_MILLER_NONZERO)
+    _, res = prod.simulate_limbs(_inputs(f, *cases[0][:2]) + _inputs(f, ON.g1_neg(cases[0][2]), cases[0][3]))
+    assert (res["flags"] & G.FLAG_MILLER_NONZERO) and not res["not_one"]
+    col, val = prod.check_bounds()
+    assert col < 63 and val < 1024
+
+
 # ---------------------------------------------------------------- G2 membership decided at the end of the Miller loop
 def _twist_points():
     """members and non-members of G2 on the twist: a member; a random twist point (order r h' with h' huge); points of
