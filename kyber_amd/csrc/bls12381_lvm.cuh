@@ -280,6 +280,18 @@ inline size_t g2_coop_max(int num_cu) {  // the same for G2 (g2coop): 61 KB of s
     if (env >= 0) return (size_t)env;
     return (size_t)num_cu * g2coop::GROUPS * 2;
 }
+// G1Elt.Mul with UnmarshalBinary's checks for a batch that leaves the chip half empty: bls12381_g1split.hip (a translation
+// unit of its own -- its kernel wants two waves per SIMD, and the out-of-line field code takes the loosest register
+// budget of the kernels that reach it).  st: n bytes of scratch on the device.  KYB_G1_SPLIT=0: never (A/B).
+void launch_g1_mul_split(size_t n, const uint8_t* d_scalars, const uint8_t* d_points, uint8_t* d_out, uint8_t* d_st, uint8_t* d_status,
+                         uint32_t flags, hipStream_t st);
+inline bool g1_split_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("KYB_G1_SPLIT");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
 // UnmarshalBinary of a small batch on cooperating lanes (the subgroup rule is what a lone lane spends its time on)
 inline int unmarshal_small(bool g2, size_t n, const uint8_t* d_points, uint8_t* d_out, uint8_t* d_status, uint32_t flags, hipStream_t st,
                            bool* handled) {
@@ -317,7 +329,16 @@ inline int lvm_mul(bool g2, size_t n, const uint8_t* d_scalars, const uint8_t* d
         *handled = true;
         return KYB_OK;
     }
-    if (n < lvm_min_batch(g2, ctx->num_cu)) return KYB_OK;
+    if (n < lvm_min_batch(g2, ctx->num_cu)) {
+        if (!g2 && handled && !trace && point_stride && !(flags & KYB_F_TRUSTED(0)) && n <= (size_t)ctx->num_cu * 2 * 64 && g1_split_enabled()) {
+            uint8_t* stt;  // the test's verdicts; the caller holds enq_mu until the merge kernel is enqueued
+            if ((rc = ctx_workspace(ctx, WS_LVM, st, lvm_al(n), (void**)&stt))) return rc;
+            launch_g1_mul_split(n, d_scalars, d_points, d_out, stt, d_status, flags, st);
+            KYB_HIP_CHECK(hipGetLastError());
+            *handled = true;
+        }
+        return KYB_OK;
+    }
     std::lock_guard<std::recursive_mutex> lk(ctx->enq_mu);
     const size_t chunk = g2 ? (size_t(1) << 16) : (size_t(1) << 17);
     const size_t cn = n < chunk ? n : chunk, cl = g2 ? 2 * cn : cn;

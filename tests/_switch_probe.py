@@ -3,6 +3,9 @@ process, so tests/test_gpu_switches.py runs this file in a subprocess per value)
 
   fb   : same-base batches (fixed_base.cuh) -- KYB_FB_MIN
   msm  : Pippenger pipeline tail (msm.cuh)  -- KYB_MSM_TAIL, KYB_MSM_SUB
+  pipe : Ed25519 host-buffer batches cut in chunks over the page-locked slots (ed25519.hip mul_host) -- KYB_PIPE_CHUNK,
+         KYB_PIPE_STREAMS
+  g1split : BLS12-381 G1 Mul of a half-empty chip, test and multiplication in different workgroups -- KYB_G1_SPLIT
   lvm  : G1 / G2 Mul dispatch (bls12381_lvm.cuh) -- KYB_LVM_MIN, KYB_G1_COOP_MAX (the small-batch kernel on cooperating lanes)
 """
 import os
@@ -130,6 +133,76 @@ def _lvm_unmarshal():
         assert list(np.asarray(st)) == [0] * 6 + [1, 0]
 
 
+def g1split():
+    """G1Elt.Mul, every operand re-validated, at a size between the cooperating-lane kernel and the lane machine: the test
+    and the multiplication in different workgroups (bls12381_g1split.hip) -- members, a point outside the subgroup, a
+    refused encoding, infinity; compressed and uncompressed input"""
+    from kyber_amd.pairing import bls12381 as B
+    from oracle import bls12381 as OB
+
+    rng = random.Random(10)
+    n = 20000 + 37
+    x = 1
+    while True:
+        y = OB.fp_sqrt((x * x * x + 4) % OB.P)
+        if y is not None and not OB.g1_in_subgroup((x, y)):
+            off = (x, y)
+            break
+        x += 1
+    hs = [rng.randrange(1, B.ORDER) for _ in range(n)]
+    ks = [rng.randrange(1 << 256) for _ in range(n)]
+    ks[:4] = [0, 1, B.ORDER, B.ORDER - 1]
+    for unc in (False, True):
+        fl = (B.F_UNCOMPRESSED | B.F_UNCOMPRESSED_OUT) if unc else 0
+        w = 96 if unc else 48
+        enc = OB.g1_serialize_unc if unc else OB.g1_compress
+        pts, _ = B.g1_commit(_be(hs), None, B.F_UNCOMPRESSED_OUT if unc else 0)
+        pts = np.asarray(pts).copy()
+        bad = {63: (enc(off), 2), 64: (bytes(w), 1), 4099: (enc(None), 0), n - 1: (enc(off), 2), n - 2: (b"\xff" * w, 1)}
+        for i, (wire, _) in bad.items():
+            pts[i] = np.frombuffer(wire, dtype=np.uint8)
+        out, st = B.g1_batch_mul(_be(ks), pts, fl)
+        out, st = np.asarray(out), np.asarray(st)
+        for i in list(range(6)) + [62, 65, 4098, 4100, 12345, n - 3]:
+            assert st[i] == 0 and bytes(out[i]) == enc(OB.g1_mul(ks[i] * hs[i] % B.ORDER, OB.G1_GEN)), (unc, i)
+        for i, (_, code) in bad.items():
+            assert st[i] == code, (unc, i, st[i])
+            assert bytes(out[i]) == (enc(None) if code == 0 else bytes(w)), (unc, i)
+        assert int((st != 0).sum()) == 4
+
+
+def pipe():
+    from kyber_amd.group import edwards25519 as E
+    from oracle import ed25519 as OE
+
+    rng = random.Random(8)
+    n = 5 * 4096 + 1000 + 37  # with KYB_PIPE_CHUNK=4096: five whole chunks and a ragged one; one resident call otherwise
+    # (and above the 16 384 from which a same-base batch builds the base's table)
+    s = np.frombuffer(rng.randbytes(32 * n), dtype=np.uint8).reshape(n, 32).copy()
+    pts = np.empty((n, 32), dtype=np.uint8)
+    seeds = [OE.mul_base(rng.randbytes(32)) for _ in range(16)]
+    for i in range(n):
+        pts[i] = np.frombuffer(seeds[i % 16], dtype=np.uint8)
+    bad = [4095, 4096, 8191, n - 1]  # chunk seams and the last element
+    y = 2
+    while OE.decode(y.to_bytes(32, "little")) is not None:  # (kyber accepts non-canonical y: search for a non-square instead)
+        y += 1
+    for i in bad:
+        pts[i] = np.frombuffer(y.to_bytes(32, "little"), dtype=np.uint8)  # no x for this y: UnmarshalBinary fails
+    where = sorted(set([0, 1, 63, 64, 4094, 4097, 8190, 8192, 12287, 12288, 16383, 16384, 20479, 20480, n - 2] + list(range(5, n, n // 48)) + bad))
+    out_b = E.batch_mul_base(s)
+    out_v, st = E.batch_mul(s, pts)
+    out_c = E.commit(s, seeds[3])
+    for i in where:
+        assert bytes(out_b[i]) == OE.mul_base(bytes(s[i])), ("base", i)
+        assert bytes(out_c[i]) == OE.mul(bytes(s[i]), seeds[3]), ("same", i)
+        if i in bad:
+            assert st[i] != 0 and not out_v[i].any(), ("bad", i)
+        else:
+            assert st[i] == 0 and bytes(out_v[i]) == OE.mul(bytes(s[i]), bytes(pts[i])), ("var", i)
+    assert int((st != 0).sum()) == len(bad)
+
+
 def bncheck():
     """bn256 ValidatePairing -- product form + zero-Miller-value fallback (default) or the reference's two pairings
     (KYB_BN_CHECK=two): ordinary pairs and the degenerate ones a G2 point of order 13 makes"""
@@ -154,5 +227,5 @@ def bncheck():
 
 
 if __name__ == "__main__":
-    {"fb": fb, "msm": msm, "lvm": lvm, "bncheck": bncheck}[sys.argv[1]]()
+    {"fb": fb, "msm": msm, "lvm": lvm, "bncheck": bncheck, "pipe": pipe, "g1split": g1split}[sys.argv[1]]()
     print("switch-probe ok", sys.argv[1])

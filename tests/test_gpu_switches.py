@@ -13,6 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [
     ("fb", {}), ("fb", {"KYB_FB_MIN": "0"}), ("fb", {"KYB_FB_MIN": "1000"}),
     ("msm", {"KYB_MSM_TAIL": "coop"}), ("msm", {"KYB_MSM_TAIL": "lane"}), ("msm", {"KYB_MSM_SUB": "64"}),
+    ("pipe", {}), ("pipe", {"KYB_PIPE_CHUNK": "4096", "KYB_PIPE_STREAMS": "1"}), ("pipe", {"KYB_PIPE_CHUNK": "4096", "KYB_PIPE_STREAMS": "3"}),
+    ("g1split", {}), ("g1split", {"KYB_G1_SPLIT": "0"}),
     ("bncheck", {}), ("bncheck", {"KYB_BN_CHECK": "two"}),
     ("lvm", {"KYB_LVM_MIN": "0"}), ("lvm", {"KYB_LVM_MIN": "1000000000"}),
     ("lvm", {"KYB_G2_COOP_MAX": "0"}), ("lvm", {"KYB_G2_COOP_MAX": "0", "KYB_LVM_MIN": "1000000000"}),
