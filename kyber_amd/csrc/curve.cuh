@@ -410,6 +410,52 @@ KYB_HD_NOINLINE void jac_mul_u64(Jac<F>& r, const Jac<F>& p, uint64_t k) {
     r = acc;
 }
 
+// The same for an AFFINE base: the multiplier in non-adjacent form (a third of the digits non-zero instead of half:
+// bn256's u has 29 one bits and 21 NAF digits), every addition a mixed one (7M + 4S against 11M + 5S), no doublings
+// before the first digit.  The subgroup tests of the BN twists (bn_suite.inc g2_in_subgroup: [u]Q) live on this.
+template <class F>
+KYB_HD_NOINLINE void jac_mul_u64_aff(Jac<F>& r, const Aff<F>& p, uint64_t k) {
+    uint64_t pos = 0, neg = 0;  // digit i of the form is +1 / -1; a 65th digit can only be +1 (`top`)
+    bool top = false;
+    {
+        unsigned __int128 x = k;
+#pragma unroll 1
+        for (int i = 0; x != 0; i++) {
+            if (x & 1) {
+                if ((x & 3) == 1) {
+                    if (i < 64) pos |= uint64_t(1) << i;
+                    else top = true;
+                    x -= 1;
+                } else {
+                    neg |= uint64_t(1) << i;
+                    x += 1;
+                }
+            }
+            x >>= 1;
+        }
+    }
+    F ny;
+    f_neg(ny, p.y);
+    Jac<F> acc;
+    jac_set_inf(acc);
+    int run = 0;
+    bool started = false;
+#pragma unroll 1
+    for (int i = 64; i >= 0; i--) {
+        run++;
+        const bool dp = i == 64 ? top : ((pos >> i) & 1) != 0, dn = i < 64 && ((neg >> i) & 1) != 0;
+        if (dp || dn || i == 0) {
+            if (started) jac_dbl_n(acc, acc, run);
+            run = 0;
+            if (dp || dn) {
+                jac_madd(acc, acc, p.x, dp ? p.y : ny, p.inf);
+                started = true;
+            }
+        }
+    }
+    r = acc;
+}
+
 template <class F>
 KYB_HD_NOINLINE void jac_to_aff(Aff<F>& a, const Jac<F>& p) {
     a.inf = jac_is_inf(p);
