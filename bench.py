@@ -268,7 +268,9 @@ def _tvm_mads():
     import gen_tower_vm as G
 
     return {"bls12381": (G.build_bls12381_pair().mads(), G.build_bls12381_check().mads(), G.build_bls12381_verify().mads()),
-            "bn256": (G.build_bn256_pair().mads(), G.build_bn256_check().mads()),
+            # ValidatePairing runs the product-form program by default since round 4 (bn_pair.inc); the two-pairing
+            # program only decides lanes whose joint Miller value is zero
+            "bn256": (G.build_bn256_pair().mads(), G.build_bn256_check_product().mads()),
             "bn254": (G.build_bn254_pair().mads(), G.build_bn254_check().mads()),
             "verifyk": G.build_bls12381_verify_same_key().mads(),
             "gtmul": {"bls12381": G.build_bls12381_gtmul().mads(), "bn256": G.build_bn256_gtmul().mads(),

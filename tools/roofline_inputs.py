@@ -108,7 +108,9 @@ for key, prefix, sub, units in (("ed25519_mul", "ed", "ed25519_mul_kernel<true>"
                                 ("bls12381_check", "bls12381", "bls12381_tvm_kernel<1>", 1 << 16),
                                 ("bls12381_verify", "verify", "bls12381_tvm_kernel<2>", 1 << 16),
                                 ("bn256_pair", "bn256", "bn256_tvm_kernel<0>", 1 << 18),
-                                ("bn256_check", "bn256", "bn256_tvm_kernel<1>", 1 << 18),
+                                # (bn256 ValidatePairing: the product-form program is kernel <2>; <1> only decides
+                                # lanes whose joint Miller value was zero and returns at once otherwise)
+                                ("bn256_check", "bn256", "bn256_tvm_kernel<2>", 1 << 18),
                                 ("bn254_pair", "bn254", "bn254_tvm_kernel<0>", 1 << 18),
                                 ("bn254_check", "bn254", "bn254_tvm_kernel<1>", 1 << 18),
                                 # round 3: the lane machine's ladders (a G2 element is two lanes), the per-lane kernels of the
