@@ -341,6 +341,87 @@ def test_concurrent_host_threads_and_streams():
     assert not errors, errors
 
 
+def test_concurrent_round4_entry_points():
+    """the per-stream caches of round 4 under contention: two signers' same-key verifications on two device streams
+    (a line table per (stream, key)), same-base commitments over two different bases (a window table and its hint per
+    (group, stream)), bn256 ValidatePairing (product program + fallback mask in the call's workspace) and the
+    scalar-field Horner kernel from host threads -- every call returns what it returned alone"""
+    import threading
+
+    import torch
+
+    from kyber_amd.pairing import bls12381 as bls, bn256 as bn
+
+    n = 4096
+    msgs = _shake(b"r4/m", n * 32).reshape(n, 32).copy()
+    keys = [_shake(b"r4/k%d" % j, 32).reshape(1, 32).copy() for j in range(2)]
+    for k in keys:
+        k[0, 0] &= 0x3F
+    X = [np.asarray(bls._mul(2, k, np.frombuffer(bls.G2_BASE, dtype=np.uint8), True)[0])[0] for k in keys]
+    H, _ = bls.batch_hash_g1(msgs)
+    sig = [np.asarray(bls.g1_batch_mul(np.repeat(k, n, axis=0), np.asarray(H), bls.F_TRUSTED(0))[0]) for k in keys]
+    sig[0][7] = sig[1][7]  # one forged signature under the first key
+    ref_v = [np.asarray(bls.batch_verify_g1_same_key(bytes(X[j]), msgs, sig[j])[0]).copy() for j in range(2)]
+    assert ref_v[1].all() and ref_v[0].sum() == n - 1
+    nc = 1 << 17
+    sc = _shake(b"r4/c", nc * 32).reshape(nc, 32).copy()
+    bases = [np.asarray(bls._mul(1, keys[j], np.frombuffer(bls.G1_BASE, dtype=np.uint8), True)[0])[0] for j in range(2)]
+    ref_c = [np.asarray(bls.g1_commit(sc, bases[j])[0]).copy() for j in range(2)]
+    m = 512
+    raw = _shake(b"r4/p", 2 * m * 32).reshape(2, m, 32).copy()
+    raw[:, :, 0] &= 0x3F
+    nP = np.asarray(bn._mul(1, raw[0], np.frombuffer(bn.G1_BASE, dtype=np.uint8), True)[0])
+    nQ = np.asarray(bn._mul(2, raw[1], np.frombuffer(bn.G2_BASE, dtype=np.uint8), True)[0])
+    nP2 = nP.copy()
+    nP2[5] = nP[6]
+    ref_chk = np.asarray(bn.batch_validate_pairing(nP, nQ, nP2, nQ)[0]).copy()
+    assert ref_chk.sum() == m - 1
+    coeffs = _shake(b"r4/poly", 67 * 32).reshape(67, 32).copy()
+    coeffs[:, 0] &= 0x3F
+    idx = np.arange(5000, dtype=np.uint32)
+    ref_poly = bls.ENGINE.scalar_poly_eval(coeffs, idx).copy()
+    errors = []
+
+    def run(fn, check, reps):
+        try:
+            for _ in range(reps):
+                if not check(fn()):
+                    errors.append("mismatch")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def dev_verify(j):
+        def f():
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                ok, _ = bls.batch_verify_g1_same_key(torch.from_numpy(X[j]).cuda(), torch.from_numpy(msgs).cuda(), torch.from_numpy(sig[j]).cuda())
+                st.synchronize()
+                return ok.cpu().numpy()
+        return f
+
+    def dev_commit(j):
+        def f():
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                out, _ = bls.g1_commit(torch.from_numpy(sc).cuda(), torch.from_numpy(bases[j]).cuda())
+                st.synchronize()
+                return out.cpu().numpy()
+        return f
+
+    jobs = [(dev_verify(0), lambda r: (r == ref_v[0]).all(), 5), (dev_verify(1), lambda r: (r == ref_v[1]).all(), 5),
+            (dev_commit(0), lambda r: (r == ref_c[0]).all(), 4), (dev_commit(1), lambda r: (r == ref_c[1]).all(), 4),
+            (lambda: np.asarray(bls.g1_commit(sc, bases[1])[0]), lambda r: (r == ref_c[1]).all(), 3),
+            (lambda: np.asarray(bn.batch_validate_pairing(nP, nQ, nP2, nQ)[0]), lambda r: (r == ref_chk).all(), 6),
+            (lambda: bls.ENGINE.scalar_poly_eval(coeffs, idx), lambda r: (r == ref_poly).all(), 6)]
+    threads = [threading.Thread(target=run, args=j, daemon=True) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=180)
+    assert not any(t.is_alive() for t in threads), "host threads are stuck: lock order?"
+    assert not errors, errors
+
+
 @pytest.mark.parametrize("seed", SEEDS)
 @pytest.mark.parametrize("name", ["bls12381", "bn256", "bn254"])
 def test_fixed_base_policies_soak(name, seed):

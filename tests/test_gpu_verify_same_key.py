@@ -144,3 +144,21 @@ def test_sign_bls_mirror_routes_one_signer_batches_to_the_same_key_program(bls):
     assert list(np.nonzero(~ok)[0]) == [17]
     ok2 = sch.batch_verify([pub] * (sch.SAME_KEY_MIN - 1), msgs[:sch.SAME_KEY_MIN - 1], sigs[:sch.SAME_KEY_MIN - 1])  # the per-key path
     assert list(np.nonzero(~ok2)[0]) == [17]
+
+
+def test_empty_batch_single_element_and_empty_messages(bls):
+    """the ragged ends: no elements at all, one element, messages of length zero (hash-to-curve of the empty string,
+    RFC 9380's first test vector shape) -- the verdicts of the general program"""
+    x = 1234567
+    X = O.g2_compress(O.g2_mul(x, O.G2_GEN))
+    ok, st = bls.batch_verify_g1_same_key(X, [], [])
+    assert len(ok) == 0 and len(st) == 0
+    m = b"one"
+    s = O.g1_compress(O.g1_mul(x, O.hash_to_g1(m, bls.DOMAIN_G1)))
+    ok, st = bls.batch_verify_g1_same_key(X, [m], [s])
+    assert list(ok) == [1] and list(st) == [0]
+    e = O.g1_compress(O.g1_mul(x, O.hash_to_g1(b"", bls.DOMAIN_G1)))
+    ok, st = bls.batch_verify_g1_same_key(X, [b"", b"", b""], [e, s, e])
+    assert list(ok) == [1, 0, 1] and not st.any()
+    ok2, st2 = bls.batch_verify_g1([X] * 3, [b"", b"", b""], [e, s, e])
+    assert list(ok2) == list(ok) and list(st2) == list(st)
