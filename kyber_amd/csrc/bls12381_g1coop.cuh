@@ -147,7 +147,7 @@ KYB_COOP_FN bool member(Slot* S, uint32_t* fl, int r) {
 constexpr int GROUPS = 16;  // points per workgroup of 64 lanes
 // One workgroup = 16 points.  Lane 0 of a group decodes the point, splits and recodes the scalar, and -- after the ladder
 // -- turns the accumulator into the wire form; the subgroup test and the ladder run on the group's four lanes.
-__global__ __launch_bounds__(64) void bls12381_g1_mul_coop_kernel(size_t n, const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ pts,
+__global__ __launch_bounds__(64, KYB_TU_WAVES) void bls12381_g1_mul_coop_kernel(size_t n, const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ pts,
                                                                   size_t pt_stride, uint8_t* __restrict__ out, uint8_t* __restrict__ status,
                                                                   uint32_t flags) {
     __shared__ Slot slots[GROUPS * NS];
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64) void bls12381_g1_mul_coop_kernel(size_t n, cons
 // G1Elt.UnmarshalBinary for small batches: lane 0 applies the flag / range / curve rules and the square root, the group's
 // four lanes the subgroup rule (member()), lane 0 re-encodes -- bls12381_g1_unmarshal_kernel's answer at the latency of
 // 438 product levels instead of ~1 040 dependent multiplications.
-__global__ __launch_bounds__(64) void bls12381_g1_unmarshal_coop_kernel(size_t n, const uint8_t* __restrict__ pts, uint8_t* __restrict__ out,
+__global__ __launch_bounds__(64, KYB_TU_WAVES) void bls12381_g1_unmarshal_coop_kernel(size_t n, const uint8_t* __restrict__ pts, uint8_t* __restrict__ out,
                                                                         uint8_t* __restrict__ status, uint32_t flags) {
     constexpr int MS = TAB + 6;  // ACC, Q, temporaries and two points
     __shared__ Slot slots[GROUPS * MS];
@@ -410,7 +410,7 @@ KYB_COOP_FN bool member(Slot* S, const Slot* C, uint32_t* fl, int r) {
 
 #if defined(__HIPCC__)
 constexpr int GROUPS = 16;
-__global__ __launch_bounds__(64) void bls12381_g2_mul_coop_kernel(size_t n, const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ pts,
+__global__ __launch_bounds__(64, KYB_TU_WAVES) void bls12381_g2_mul_coop_kernel(size_t n, const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ pts,
                                                                   size_t pt_stride, uint8_t* __restrict__ out, uint8_t* __restrict__ status,
                                                                   uint32_t flags) {
     __shared__ Slot slots[GROUPS * NS];
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(64) void bls12381_g2_mul_coop_kernel(size_t n, cons
         if (status) status[idx] = (uint8_t)(v & 0xff);
     }
 }
-__global__ __launch_bounds__(64) void bls12381_g2_unmarshal_coop_kernel(size_t n, const uint8_t* __restrict__ pts, uint8_t* __restrict__ out,
+__global__ __launch_bounds__(64, KYB_TU_WAVES) void bls12381_g2_unmarshal_coop_kernel(size_t n, const uint8_t* __restrict__ pts, uint8_t* __restrict__ out,
                                                                         uint8_t* __restrict__ status, uint32_t flags) {
     constexpr int MS = TAB + 3;
     __shared__ Slot slots[GROUPS * MS];

@@ -8,7 +8,7 @@
 #include <string.h>
 
 namespace kyb {
-__global__ __launch_bounds__(64) void bls12381_hash_g1_kernel(size_t n, const uint8_t* __restrict__ msgs, size_t msg_len,
+__global__ __launch_bounds__(64, KYB_TU_WAVES) void bls12381_hash_g1_kernel(size_t n, const uint8_t* __restrict__ msgs, size_t msg_len,
                                                               bls::DstArg dst, uint8_t* __restrict__ out,
                                                               uint8_t* __restrict__ status) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -16,7 +16,7 @@ __global__ __launch_bounds__(64) void bls12381_hash_g1_kernel(size_t n, const ui
     const int st = bls::hash_g1_wire(out + 48 * idx, msgs + msg_len * idx, msg_len, dst);
     if (status) status[idx] = (uint8_t)st;
 }
-__global__ __launch_bounds__(64) void bls12381_hash_g2_kernel(size_t n, const uint8_t* __restrict__ msgs, size_t msg_len,
+__global__ __launch_bounds__(64, KYB_TU_WAVES) void bls12381_hash_g2_kernel(size_t n, const uint8_t* __restrict__ msgs, size_t msg_len,
                                                               bls::DstArg dst, uint8_t* __restrict__ out,
                                                               uint8_t* __restrict__ status) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -101,7 +101,7 @@ KYB_HD void lvm_digits(uint8_t* dst, const uint32_t (&w)[NWS], int npos, bool fl
 // kernel's status bytes when it ran (then pts is its output), or null: the flag / range rules of the uncompressed form
 // are applied here (bls12381.cuh g*_decode_unc with validate = false -- the caller vouched for the rest).
 template <bool G2>
-__global__ __launch_bounds__(64) void bls12381_lvm_prep_kernel(size_t n, const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ pts,
+__global__ __launch_bounds__(64, KYB_TU_WAVES) void bls12381_lvm_prep_kernel(size_t n, const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ pts,
                                                              size_t pt_stride, const uint8_t* __restrict__ st_in, size_t st_stride,
                                                              uint32_t* __restrict__ in,
                                                              uint8_t* __restrict__ digits, uint8_t* __restrict__ redo) {
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(64) void bls12381_lvm_prep_kernel(size_t n, const u
 
 // canonical words of the affine result -> wire bytes; marks what the per-lane kernel has to redo
 template <bool G2>
-__global__ __launch_bounds__(64) void bls12381_lvm_encode_kernel(size_t n, const uint32_t* __restrict__ res, const uint8_t* __restrict__ zflag,
+__global__ __launch_bounds__(64, KYB_TU_WAVES) void bls12381_lvm_encode_kernel(size_t n, const uint32_t* __restrict__ res, const uint8_t* __restrict__ zflag,
                                                                uint8_t* __restrict__ redo, uint8_t* __restrict__ out, uint8_t* __restrict__ status,
                                                                uint32_t flags) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -285,6 +285,17 @@ inline size_t g2_coop_max(int num_cu) {  // the same for G2 (g2coop): 61 KB of s
 // budget of the kernels that reach it).  st: n bytes of scratch on the device.  KYB_G1_SPLIT=0: never (A/B).
 void launch_g1_mul_split(size_t n, const uint8_t* d_scalars, const uint8_t* d_points, uint8_t* d_out, uint8_t* d_st, uint8_t* d_status,
                          uint32_t flags, hipStream_t st);
+// UnmarshalBinary of a batch with at least two waves per SIMD in flight: bls12381_unm2.hip (the per-lane kernels on a
+// two-wave register budget).  KYB_UNM_W2=0: always the kernels of this unit (A/B).
+void launch_unmarshal_w2(bool g2, size_t n, const uint8_t* d_points, uint8_t* d_out, uint8_t* d_status, uint32_t flags, hipStream_t st);
+inline bool unmarshal_w2(bool g2, size_t n, int num_cu) {
+    static const bool on = [] {
+        const char* e = getenv("KYB_UNM_W2");
+        return !(e && e[0] == '0');
+    }();
+    // measured crossovers: G1 from two waves per SIMD (2^17: +10 %, 2^20: +22 %), G2 level up to 2^18 and +16 % at 2^20
+    return on && n >= (size_t)num_cu * 4 * 64 * (g2 ? 8 : 2);
+}
 inline bool g1_split_enabled() {
     static const bool on = [] {
         const char* e = getenv("KYB_G1_SPLIT");
@@ -299,7 +310,14 @@ inline int unmarshal_small(bool g2, size_t n, const uint8_t* d_points, uint8_t* 
     DeviceCtx* ctx;
     int rc = get_ctx(&ctx);
     if (rc) return rc;
-    if (n > (g2 ? g2_coop_max(ctx->num_cu) : g1_coop_max(ctx->num_cu))) return KYB_OK;
+    if (n > (g2 ? g2_coop_max(ctx->num_cu) : g1_coop_max(ctx->num_cu))) {
+        if (unmarshal_w2(g2, n, ctx->num_cu)) {
+            launch_unmarshal_w2(g2, n, d_points, d_out, d_status, flags, st);
+            KYB_HIP_CHECK(hipGetLastError());
+            *handled = true;
+        }
+        return KYB_OK;
+    }
     const unsigned grid = (unsigned)((n + 15) / 16);
     if (g2) hipLaunchKernelGGL(g2coop::bls12381_g2_unmarshal_coop_kernel, dim3(grid), dim3(64), 0, st, n, d_points, d_out, d_status, flags);
     else hipLaunchKernelGGL(g1coop::bls12381_g1_unmarshal_coop_kernel, dim3(grid), dim3(64), 0, st, n, d_points, d_out, d_status, flags);
@@ -369,7 +387,8 @@ inline int lvm_mul(bool g2, size_t n, const uint8_t* d_scalars, const uint8_t* d
         if (need_unmarshal) {  // UnmarshalBinary's checks, per lane, into validated uncompressed points
             const size_t mu = point_stride ? m : 1;
             const uint32_t uf = (flags & (KYB_F_UNCOMPRESSED | KYB_F_TRUSTED(0))) | KYB_F_UNCOMPRESSED_OUT;
-            if (g2) hipLaunchKernelGGL(bls12381_g2_unmarshal_kernel, dim3((unsigned)((mu + 63) / 64)), dim3(64), 0, st, mu, pts, unm, sta, uf);
+            if (unmarshal_w2(g2, mu, ctx->num_cu)) launch_unmarshal_w2(g2, mu, pts, unm, sta, uf, st);
+            else if (g2) hipLaunchKernelGGL(bls12381_g2_unmarshal_kernel, dim3((unsigned)((mu + 63) / 64)), dim3(64), 0, st, mu, pts, unm, sta, uf);
             else hipLaunchKernelGGL(bls12381_g1_unmarshal_kernel, dim3((unsigned)((mu + 63) / 64)), dim3(64), 0, st, mu, pts, unm, sta, uf);
             pts = unm;
             pstride = point_stride ? unc : 0;

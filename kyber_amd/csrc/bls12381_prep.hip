@@ -34,7 +34,7 @@ __device__ __forceinline__ void put_fp(uint32_t* in, size_t n, uint32_t idx, siz
     for (int k = 0; k < FP_WORDS; k += 4) *reinterpret_cast<uint4*>(d + k) = make_uint4(x.v[k], x.v[k + 1], x.v[k + 2], x.v[k + 3]);
 }
 
-__global__ __launch_bounds__(64) void bls12381_operand_kernel(PrepArgs a) {
+__global__ __launch_bounds__(64, KYB_TU_WAVES) void bls12381_operand_kernel(PrepArgs a) {
     const size_t nblk = (a.n + 63) / 64;
     const int k = (int)(blockIdx.x / nblk);  // uniform per workgroup: no divergence between the kinds
     const size_t i = (blockIdx.x - (size_t)k * nblk) * 64 + threadIdx.x;

@@ -6,6 +6,14 @@
 //   pointG1.Hash                     point.go:207-285 (Keccak-256 expand_message_xmd + Shallue-van de Woestijne) -> bn254_hash_g1_kernel
 // (this translation unit: G1 / G2 scalar multiplication and hashing; pairing kernels are in bn254_pair.hip, MSM in
 //  bn254_msm.hip)
+// Every kernel of this unit on a two-wave register budget (hd.h KYB_TU_WAVES): the out-of-line field and group code takes
+// the loosest budget of the kernels that reach it, and with one kernel at 512 registers the G2 ladder ran at 374 (one wave
+// per SIMD).  At 256 registers: 2^18 G2 multiplications 24.2 -> 18.9 ms with every operand re-validated, 18.0 -> 14.4 ms
+// vouched for; G1 and the fixed-base kernels unchanged; a three-wave budget loses (21.1 ms) --
+// profiles/r04_tu_wave_budgets.json.
+#define KYB_TU_WAVES 2
+#define KYB_G1_MUL_WAVES 2
+#define KYB_G2_MUL_WAVES 2
 #include "bn254.cuh"
 #include "pairing_abi.cuh"
 #include <string.h>
@@ -27,7 +35,7 @@ inline int unmarshal_small(bool, size_t, const uint8_t*, uint8_t*, uint8_t*, uin
 KYB_DEFINE_MUL_ABI(bn254, bn4, 64, 128)
 
 namespace kyb {
-__global__ __launch_bounds__(64) void bn254_hash_g1_kernel(size_t n, const uint8_t* __restrict__ msgs, size_t msg_len, DstArg dst,
+__global__ __launch_bounds__(64, KYB_TU_WAVES) void bn254_hash_g1_kernel(size_t n, const uint8_t* __restrict__ msgs, size_t msg_len, DstArg dst,
                                                            uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;

@@ -7,6 +7,14 @@
 //   (Un)MarshalBinary                point.go:170-238, 423-499, 630-662               -> fused into every kernel
 // (this translation unit: G1 / G2 scalar multiplication; pairing kernels are in bn256_pair.hip, MSM in
 //  bn256_msm.hip -- split only so that the three compile in parallel)
+// Every kernel of this unit on a two-wave register budget (hd.h KYB_TU_WAVES): the out-of-line field and group code takes
+// the loosest budget of the kernels that reach it, and with one kernel at 512 registers the G2 ladder ran at 374 (one wave
+// per SIMD).  At 256 registers: 2^18 G2 multiplications 24.2 -> 18.9 ms with every operand re-validated, 18.0 -> 14.4 ms
+// vouched for; G1 and the fixed-base kernels unchanged; a three-wave budget loses (21.1 ms) --
+// profiles/r04_tu_wave_budgets.json.
+#define KYB_TU_WAVES 2
+#define KYB_G1_MUL_WAVES 2
+#define KYB_G2_MUL_WAVES 2
 #include "bn256.cuh"
 #include "pairing_abi.cuh"
 
@@ -28,7 +36,7 @@ KYB_DEFINE_MUL_ABI(bn256, bn, 64, 128)
 
 // ---- pointG1.Hash (pairing/bn256/point.go:261-313): the step before the pairing check in sign/bls Verify
 namespace kyb {
-__global__ __launch_bounds__(64) void bn256_hash_g1_kernel(size_t n, const uint8_t* __restrict__ msgs, size_t msg_len,
+__global__ __launch_bounds__(64, KYB_TU_WAVES) void bn256_hash_g1_kernel(size_t n, const uint8_t* __restrict__ msgs, size_t msg_len,
                                                            uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64, 2) void chain_kernel(uint8_t* __restrict__ ws, 
 }
 // One lane per table entry
 template <class T>
-__global__ __launch_bounds__(64) void table_kernel(uint8_t* __restrict__ ws) {
+__global__ __launch_bounds__(64, KYB_TU_WAVES) void table_kernel(uint8_t* __restrict__ ws) {
     using F = typename T::F;
     const Header* h = reinterpret_cast<const Header*>(ws);
     if (!h->fresh || h->status || h->inf) return;
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(64, T::MUL_WAVES) void mul_kernel(size_t n, const u
 template <class F>
 constexpr int encode_batch() { return sizeof(F) > 64 ? 4 : 8; }
 template <class T>
-__global__ __launch_bounds__(64) void encode_kernel(size_t n, const uint8_t* __restrict__ ws, const Jac<typename T::F>* __restrict__ park,
+__global__ __launch_bounds__(64, KYB_TU_WAVES) void encode_kernel(size_t n, const uint8_t* __restrict__ ws, const Jac<typename T::F>* __restrict__ park,
                                                     uint8_t* __restrict__ out, uint8_t* __restrict__ status, uint32_t flags) {
     using F = typename T::F;
     constexpr int EB = encode_batch<F>();

@@ -19,6 +19,14 @@
 #define KYB_HD_NOINLINE inline
 #endif
 
+// Register budget (waves per SIMD) of the kernels of a translation unit that name no budget of their own.  Out-of-line
+// device functions take the LOOSEST budget of the kernels that reach them, so one kernel without a budget lets every
+// shared callee -- and with it every kernel of the unit -- grow to 512 registers: a unit that wants two waves per SIMD
+// says so for all of its kernels (-DKYB_TU_WAVES=2).
+#ifndef KYB_TU_WAVES
+#define KYB_TU_WAVES 1
+#endif
+
 // Per-call flags of the pairing-suite entry points (values mirror include/kyber_hip.h; context.hip static_asserts).
 namespace kyb {
 constexpr uint32_t FLAG_UNCOMPRESSED = 2u;  // BLS12-381 point inputs are ZCash uncompressed (96 / 192 B)

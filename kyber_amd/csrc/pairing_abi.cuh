@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64, KYB_G2_MUL_WAVES) void PFX##_g2_mul_kernel(size
     const int st = NS::g2_mul_wire(out + NS::g2_out_size(flags) * idx, scalars + 32 * idx, pts + pt_stride * idx, flags); \
     if (status) status[idx] = (uint8_t)st; \
 } \
-__global__ __launch_bounds__(64) void PFX##_g1_unmarshal_kernel(size_t n, const uint8_t* __restrict__ pts, \
+__global__ __launch_bounds__(64, KYB_TU_WAVES) void PFX##_g1_unmarshal_kernel(size_t n, const uint8_t* __restrict__ pts, \
                                                               uint8_t* __restrict__ out, uint8_t* __restrict__ status, \
                                                               uint32_t flags) { \
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64) void PFX##_g1_unmarshal_kernel(size_t n, const 
     const int st = NS::g1_unmarshal_wire(out + NS::g1_out_size(flags) * idx, pts + NS::g1_wire_size(flags) * idx, flags); \
     if (status) status[idx] = (uint8_t)st; \
 } \
-__global__ __launch_bounds__(64) void PFX##_g2_unmarshal_kernel(size_t n, const uint8_t* __restrict__ pts, \
+__global__ __launch_bounds__(64, KYB_TU_WAVES) void PFX##_g2_unmarshal_kernel(size_t n, const uint8_t* __restrict__ pts, \
                                                               uint8_t* __restrict__ out, uint8_t* __restrict__ status, \
                                                               uint32_t flags) { \
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64) void PFX##_g2_unmarshal_kernel(size_t n, const 
     const int st = NS::g2_unmarshal_wire(out + NS::g2_out_size(flags) * idx, pts + NS::g2_wire_size(flags) * idx, flags); \
     if (status) status[idx] = (uint8_t)st; \
 } \
-__global__ __launch_bounds__(64) void PFX##_g1_add_kernel(size_t n, const uint8_t* __restrict__ a, \
+__global__ __launch_bounds__(64, KYB_TU_WAVES) void PFX##_g1_add_kernel(size_t n, const uint8_t* __restrict__ a, \
                                                         const uint8_t* __restrict__ b, uint8_t* __restrict__ out, \
                                                         uint8_t* __restrict__ status) { \
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64) void PFX##_g1_add_kernel(size_t n, const uint8_
     const int st = NS::g1_add_wire(out + G1SZ * idx, a + G1SZ * idx, b + G1SZ * idx); \
     if (status) status[idx] = (uint8_t)st; \
 } \
-__global__ __launch_bounds__(64) void PFX##_g2_add_kernel(size_t n, const uint8_t* __restrict__ a, \
+__global__ __launch_bounds__(64, KYB_TU_WAVES) void PFX##_g2_add_kernel(size_t n, const uint8_t* __restrict__ a, \
                                                         const uint8_t* __restrict__ b, uint8_t* __restrict__ out, \
                                                         uint8_t* __restrict__ status) { \
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \

@@ -6,6 +6,7 @@ process, so tests/test_gpu_switches.py runs this file in a subprocess per value)
   pipe : Ed25519 host-buffer batches cut in chunks over the page-locked slots (ed25519.hip mul_host) -- KYB_PIPE_CHUNK,
          KYB_PIPE_STREAMS
   g1split : BLS12-381 G1 Mul of a half-empty chip, test and multiplication in different workgroups -- KYB_G1_SPLIT
+  unmw2 : BLS12-381 UnmarshalBinary of large batches through the two-wave kernels -- KYB_UNM_W2
   lvm  : G1 / G2 Mul dispatch (bls12381_lvm.cuh) -- KYB_LVM_MIN, KYB_G1_COOP_MAX (the small-batch kernel on cooperating lanes)
 """
 import os
@@ -171,6 +172,55 @@ def g1split():
         assert int((st != 0).sum()) == 4
 
 
+def unmw2():
+    """UnmarshalBinary of batches large enough for the two-wave kernels (bls12381_unm2.hip): 2^17 + G1 points, 2^19 + G2
+    points made by the engine's own Commit (compared with the oracle on a sample), with a point outside the subgroup, a
+    refused encoding and infinity spliced in at the first, a middle and the last position"""
+    from kyber_amd.pairing import bls12381 as B
+    from oracle import bls12381 as OB
+
+    rng = random.Random(14)
+    x = 1
+    while True:
+        y = OB.fp_sqrt((x * x * x + 4) % OB.P)
+        if y is not None and not OB.g1_in_subgroup((x, y)):
+            off1 = OB.g1_compress((x, y))
+            break
+        x += 1
+    x = 1
+    while True:
+        c = (x, 1)
+        y = OB.f2_sqrt(OB.f2_add(OB.f2_mul(OB.f2_sqr(c), c), (4, 4)))
+        if y is not None and not OB.g2_in_subgroup((c, y)):
+            off2 = OB.g2_compress((c, y))
+            break
+        x += 1
+    for grp, n, off, w, gen, mul, enc, unc in ((1, (1 << 17) + 77, off1, 48, OB.G1_GEN, OB.g1_mul, OB.g1_compress, OB.g1_serialize_unc),
+                                               (2, (1 << 19) + 77, off2, 96, OB.G2_GEN, OB.g2_mul, OB.g2_compress, OB.g2_serialize_unc)):
+        hs = np.frombuffer(rng.randbytes(32 * n), dtype=np.uint8).reshape(n, 32).copy()
+        hs[:, 0] &= 0x3F
+        pts, _ = (B.g1_commit if grp == 1 else B.g2_commit)(hs)
+        pts = np.asarray(pts).copy()
+        sample = [1, 2, 63, 64, n // 3, n - 2]
+        for i in sample:
+            assert bytes(pts[i]) == enc(mul(int.from_bytes(bytes(hs[i]), "big"), gen)), (grp, i)
+        special = {0: (off, 2), n // 2: (bytes(w), 1), n - 1: (enc(None), 0), 4097: (off, 2)}
+        for i, (wire, _) in special.items():
+            pts[i] = np.frombuffer(wire, dtype=np.uint8)
+        out, st = B.ENGINE.batch_unmarshal(grp, pts)
+        out, st = np.asarray(out), np.asarray(st)
+        assert int((st != 0).sum()) == 3
+        for i, (wire, code) in special.items():
+            assert st[i] == code and bytes(out[i]) == (wire if code == 0 else bytes(w)), (grp, i, st[i])
+        keep = np.ones(n, dtype=bool)
+        keep[list(special)] = False
+        assert (out[keep] == pts[keep]).all()
+        outu, st = B.ENGINE.batch_unmarshal(grp, pts, B.F_UNCOMPRESSED_OUT)
+        outu = np.asarray(outu)
+        for i in sample:
+            assert bytes(outu[i]) == unc(mul(int.from_bytes(bytes(hs[i]), "big"), gen)), (grp, i)
+
+
 def pipe():
     from kyber_amd.group import edwards25519 as E
     from oracle import ed25519 as OE
@@ -227,5 +277,5 @@ def bncheck():
 
 
 if __name__ == "__main__":
-    {"fb": fb, "msm": msm, "lvm": lvm, "bncheck": bncheck, "pipe": pipe, "g1split": g1split}[sys.argv[1]]()
+    {"fb": fb, "msm": msm, "lvm": lvm, "bncheck": bncheck, "pipe": pipe, "g1split": g1split, "unmw2": unmw2}[sys.argv[1]]()
     print("switch-probe ok", sys.argv[1])
