@@ -9,6 +9,8 @@
 //   Unmarshal/MarshalBinary          kilic/g1.go:119-131         -> fused into every kernel
 // (this translation unit: G1 / G2 scalar multiplication; pairing kernels are in bls12381_pair.hip, MSM in
 //  bls12381_msm.hip -- split only so that the three compile in parallel)
+// (same-base batches: bls12381_fb.hip -- a unit of its own for its register budget)
+#define KYB_FB_EXTERN
 #include "bls12381.cuh"
 #include "bls12381_lvm.cuh"
 #include "bls12381_fb.cuh"

@@ -29,6 +29,10 @@ struct BlsG2Codec {
 struct BlsG1Msm : msm::Weierstrass<bls::fp, BlsG1Codec> {
     using Base = msm::Weierstrass<bls::fp, BlsG1Codec>;
     static constexpr int SPLIT = 2, SPLIT_BITS = 127;
+#ifndef KYB_BLS_G1_DECODE_WAVES
+#define KYB_BLS_G1_DECODE_WAVES 2
+#endif
+    static constexpr int DECODE_WAVES = KYB_BLS_G1_DECODE_WAVES;  // register budget of decode_kernel (the square root and the subgroup test)
     // 160-bit two's-complement helpers (five words)
     __device__ static void add5(uint32_t (&x)[5], const uint32_t (&y)[5]) {
         uint32_t c = 0;

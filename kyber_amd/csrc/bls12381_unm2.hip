@@ -7,7 +7,9 @@
 // could have two in flight.  Same box, 2^20 points: G1 3.54 -> 4.33e7/s, G2 2.21 -> 2.57e7/s with the kernels below
 // (256 registers); at 2^16 points the loose ones are 1-2 % ahead (profiles/r04_tu_wave_budgets.json), hence the
 // threshold in bls12381_lvm.cuh unmarshal_small: two waves per SIMD.
+#ifndef KYB_TU_WAVES
 #define KYB_TU_WAVES 2
+#endif
 #include "bls12381.cuh"
 #include "context.h"
 

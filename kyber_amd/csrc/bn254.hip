@@ -11,9 +11,11 @@
 // per SIMD).  At 256 registers: 2^18 G2 multiplications 24.2 -> 18.9 ms with every operand re-validated, 18.0 -> 14.4 ms
 // vouched for; G1 and the fixed-base kernels unchanged; a three-wave budget loses (21.1 ms) --
 // profiles/r04_tu_wave_budgets.json.
+#ifndef KYB_TU_WAVES
 #define KYB_TU_WAVES 2
 #define KYB_G1_MUL_WAVES 2
 #define KYB_G2_MUL_WAVES 2
+#endif
 #include "bn254.cuh"
 #include "pairing_abi.cuh"
 #include <string.h>

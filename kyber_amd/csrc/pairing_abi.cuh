@@ -54,7 +54,11 @@ constexpr size_t FB_MIN_KNOWN = 64;  // ... and from this many when the table is
 #ifndef KYB_FB_G2_WAVES
 #define KYB_FB_G2_WAVES 2
 #endif
-#define KYB_DEFINE_MUL_ABI(PFX, NS, G1SZ, G2SZ) \
+// The fixed-base traits of a suite's two groups (fixed_base.cuh) and the entry that runs a same-base batch through them.
+// KYB_FB_EXTERN (set by a suite's scalar-multiplication unit before including this file): the entry is only declared and
+// lives in a translation unit of its own (bls12381_fb.hip), whose kernels then share no out-of-line code -- and no
+// register budget -- with this unit's.
+#define KYB_DEFINE_FB_TRAITS(PFX, NS) \
 namespace kyb { \
 struct PFX##_FbG1 { \
     using F = NS::fp; \
@@ -96,6 +100,28 @@ static std::string PFX##_fb_generator_key(uint32_t flags) { \
     T::encode(buf, g, (flags & KYB_F_UNCOMPRESSED) ? KYB_F_UNCOMPRESSED_OUT : 0u); \
     return std::string((const char*)buf, T::wire_size(flags)); \
 } \
+} \
+
+#ifdef KYB_FB_EXTERN
+#define KYB_DEFINE_FB_RUN(PFX) \
+namespace kyb { \
+int PFX##_fb_run(bool g2, size_t n, const void* d_scalars, const void* d_points, void* d_out, void* d_status, uint32_t flags, \
+                 hipStream_t st, const std::string* key); \
+}
+#else
+#define KYB_DEFINE_FB_RUN(PFX) \
+namespace kyb { \
+inline int PFX##_fb_run(bool g2, size_t n, const void* d_scalars, const void* d_points, void* d_out, void* d_status, uint32_t flags, \
+                        hipStream_t st, const std::string* key) { \
+    return g2 ? fb::run<PFX##_FbG2>(n, d_scalars, d_points, d_out, d_status, flags, st, key) \
+              : fb::run<PFX##_FbG1>(n, d_scalars, d_points, d_out, d_status, flags, st, key); \
+} \
+}
+#endif
+#define KYB_DEFINE_MUL_ABI(PFX, NS, G1SZ, G2SZ) \
+KYB_DEFINE_FB_TRAITS(PFX, NS) \
+KYB_DEFINE_FB_RUN(PFX) \
+namespace kyb { \
 __global__ __launch_bounds__(64, KYB_G1_MUL_WAVES) void PFX##_g1_mul_kernel(size_t n, const uint8_t* __restrict__ scalars, \
                                                         const uint8_t* __restrict__ pts, size_t pt_stride, \
                                                         uint8_t* __restrict__ out, uint8_t* __restrict__ status, \
@@ -159,7 +185,7 @@ int kyb_##PFX##_g1_mul_dev(size_t n, const void* d_scalars, const void* d_points
     } \
     if (!n) return KYB_OK; \
     if (point_stride == 0 && n >= kyb::fb_min_batch(false)) /* one base, many scalars: fixed_base.cuh */ \
-        return kyb::fb::run<kyb::PFX##_FbG1>(n, d_scalars, d_points, d_out, d_status, flags, (hipStream_t)stream); \
+        return kyb::PFX##_fb_run(false, n, d_scalars, d_points, d_out, d_status, flags, (hipStream_t)stream, nullptr); \
     const uint8_t* only = nullptr; \
     /* the machine's steps and the per-lane redo launch are ONE unit on the stream: `only` points into the (WS_LVM, \
        stream) workspace, which another thread's call on the same stream may rewrite or grow (enq_mu is recursive) */ \
@@ -185,7 +211,7 @@ int kyb_##PFX##_g2_mul_dev(size_t n, const void* d_scalars, const void* d_points
     } \
     if (!n) return KYB_OK; \
     if (point_stride == 0 && n >= kyb::fb_min_batch(true)) \
-        return kyb::fb::run<kyb::PFX##_FbG2>(n, d_scalars, d_points, d_out, d_status, flags, (hipStream_t)stream); \
+        return kyb::PFX##_fb_run(true, n, d_scalars, d_points, d_out, d_status, flags, (hipStream_t)stream, nullptr); \
     const uint8_t* only = nullptr; \
     kyb::DeviceCtx* ctx_; \
     KYB_TRY(kyb::get_ctx(&ctx_)); \
@@ -241,8 +267,7 @@ static int PFX##_mul_host(bool g2, size_t n, const uint8_t* scalars, const uint8
             } \
         } \
         if (use) { \
-            KYB_TRY(g2 ? (kyb::fb::run<kyb::PFX##_FbG2>(n, s.p, p.p, o.p, st.p, flags, nullptr, &key)) \
-                       : (kyb::fb::run<kyb::PFX##_FbG1>(n, s.p, p.p, o.p, st.p, flags, nullptr, &key))); \
+            KYB_TRY(kyb::PFX##_fb_run(g2, n, s.p, p.p, o.p, st.p, flags, nullptr, &key)); \
             KYB_TRY(o.download(out, n * psz)); \
             if (status) KYB_TRY(st.download(status, n)); \
             return KYB_OK; \
