@@ -35,10 +35,11 @@ SOURCES = {
               C + "bls12381_tvm.h"],
     "bn256": [C + "bn256_pair.hip", C + "bn_pair.inc", C + "tower_vm.cuh", C + "gen_tower_vm.py", C + "bn256.cuh", C + "bn_suite.inc"] + COMMON_PAIRING,
     "bn254": [C + "bn254_pair.hip", C + "bn_pair.inc", C + "tower_vm.cuh", C + "gen_tower_vm.py", C + "bn254.cuh", C + "bn_suite.inc"] + COMMON_PAIRING,
-    "mul": [C + "bls12381.hip", C + "bls12381_lvm.cuh", C + "lane_vm.cuh", C + "gen_lane_vm.py", C + "bls12381.cuh", C + "pairing_abi.cuh"] + COMMON_PAIRING,
+    "mul": [C + "bls12381.hip", C + "bls12381_lvm.cuh", C + "lane_vm.cuh", C + "gen_lane_vm.py", C + "bls12381.cuh", C + "pairing_abi.cuh",
+            C + "bls12381_unm2.hip", C + "bls12381_g1split.hip"] + COMMON_PAIRING,
     "mulperlane": [C + "bls12381.hip", C + "bls12381.cuh", C + "pairing_abi.cuh"] + COMMON_PAIRING,
     "msm_bls": [C + "bls12381_msm.hip", C + "msm.cuh", C + "msm_ws.cuh", C + "coop_slots.cuh", C + "bls12381.cuh"] + COMMON_PAIRING,
-    "fb": [C + "fixed_base.cuh", C + "bls12381_fb.cuh", C + "pairing_abi.cuh", C + "bls12381.hip", C + "bls12381.cuh", C + "coop_slots.cuh"] + COMMON_PAIRING,
+    "fb": [C + "fixed_base.cuh", C + "bls12381_fb.cuh", C + "pairing_abi.cuh", C + "bls12381_fb.hip", C + "bls12381.cuh", C + "coop_slots.cuh"] + COMMON_PAIRING,
 }
 
 
