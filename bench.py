@@ -295,6 +295,17 @@ _M, _S = 338, 260
 MADS_G1_UNMARSHAL = (379 * _S + 109 * _M) + 2 * (63 * (2 * _M + 5 * _S) + 5 * (11 * _M + 5 * _S))
 MADS_G1_DECOMPRESS = 379 * _S + 109 * _M  # the square root alone (validated compressed points: no subgroup test)
 MADS_G2_UNMARSHAL = 2 * (379 * _S + 109 * _M) + 12 * _M + (63 * (2 * 3 + 5 * 2) + 5 * (11 * 3 + 5 * 2)) * _M
+# pointG1 / pointG2.Mul of the BN suites as the per-lane code does it (bn_suite.inc; nine 29-bit limbs: a field
+# multiplication is 81 + 81 = 162 multiply-adds, a squaring 45 + 81 = 126; Fp2: M2 = 3M, S2 = 2M).  G1: GLV, 34 windows of
+# (4 doublings of 2M + 5S + 2 mixed additions of 7M + 4S), the table (1 doubling + 6 additions of 11M + 5S + ~53 M for the
+# shared inversion).  G2: the membership relation (63 doublings + 21 mixed additions for [u]Q, 3 more additions, a doubling)
+# and the GLS walk (17 windows of (4 + 4), the same table) over Fp2.
+_MB, _SB = 162, 126
+_BN_DBL, _BN_MADD, _BN_ADD = 2 * _MB + 5 * _SB, 7 * _MB + 4 * _SB, 11 * _MB + 5 * _SB
+_BN_DBL2, _BN_MADD2, _BN_ADD2 = (2 * 3 + 5 * 2) * _MB, (7 * 3 + 4 * 2) * _MB, (11 * 3 + 5 * 2) * _MB
+MADS_BN_G1_MUL = 136 * _BN_DBL + 68 * _BN_MADD + _BN_DBL + 6 * _BN_ADD + 53 * _MB
+MADS_BN_G2_GLS = 64 * _BN_DBL2 + 68 * _BN_MADD2 + _BN_DBL2 + 6 * _BN_ADD2 + 53 * 3 * _MB
+MADS_BN_G2_MEMBER = 63 * _BN_DBL2 + 22 * _BN_MADD2 + 2 * _BN_ADD2 + _BN_DBL2 + 6 * 3 * _MB
 # Pippenger on BLS12-381 G1 at 2^20 points (msm.cuh): 2n half-scalars x 8 windows of 16 bits, one mixed addition per
 # (point, window) -- XYZZ form since round 3, 8M + 2S (3 224 multiply-adds; madd-2007-bl, 7M + 4S = 3 406, until then:
 # the numerator FELL with the change) -- + the running-sum reduction of 8 x 2^15 buckets (2 full additions each, 11M + 5S)
@@ -413,6 +424,10 @@ def other_workloads(rank, world, dist):
             out[name]["roofline"]["g1_mul"] = _roof(npair / ms_g1 * 1e3, lm["g1"] + MADS_G1_UNMARSHAL, 32 + 2 * g1b_, prof, "bls12381_g1_mul")
             out[name]["roofline"]["g2_mul"] = _roof(npair / ms_g2 * 1e3, lm["g2"] + MADS_G2_UNMARSHAL, 32 + 2 * g2b_, prof, "bls12381_g2_mul",
                                                     lm["g2_karatsuba"] + MADS_G2_UNMARSHAL)
+        if name in ("bn256", "bn254"):
+            # pointG1 / pointG2.Mul with every operand re-validated (flags = 0): the per-lane kernels of bn_suite.inc
+            out[name]["roofline"]["g1_mul"] = _roof(npair / ms_g1 * 1e3, MADS_BN_G1_MUL, 32 + 2 * g1b_, prof, name + "_g1_mul")
+            out[name]["roofline"]["g2_mul"] = _roof(npair / ms_g2 * 1e3, MADS_BN_G2_GLS + MADS_BN_G2_MEMBER, 32 + 2 * g2b_, prof, name + "_g2_mul")
         if True:
             # the whole sign/bls Verify pipeline on the device: Hash(msg) (bn256: SHA-256 + try-and-increment; bn254:
             # Keccak-256 expand + Shallue-van de Woestijne; BLS12-381: RFC 9380 hash_to_curve) then the pairing check (sign/bls/bls.go:82-96), 32-byte messages

@@ -244,6 +244,17 @@ KYB_HD_NOINLINE void jac_madd(Jac<F>& r, const Jac<F>& p, const F& x2, const F& 
     jac_madd_inl(r, p, x2, y2, q_inf);
 }
 
+// acc <- take ? acc + (x2, y2) : acc in ONE out-of-line call: the accumulator crosses the call boundary (the lane's
+// scratch) once in and once out.  As jac_madd(s, acc, ...) followed by jac_cmov(acc, s, take) at the call site it crossed
+// five times (the sum out, both operands of the select back in, the accumulator out again): 770 of the ~1 200 bytes a
+// window addition of the G2 ladders moved, with 158 KB of such traffic per bn256 G2 multiplication measured
+// (profiles/r04_final_bn256_{fetch,write}.txt).
+template <class F>
+KYB_HD_NOINLINE void jac_madd_if(Jac<F>& acc, const F& x2, const F& y2, bool q_inf, bool take) {
+    Jac<F> o;
+    jac_madd_inl(o, acc, x2, y2, q_inf);
+    jac_cmov(acc, o, take);
+}
 // The eight-entry window table tab[j] = (j + 1) P of the fixed-window ladders, brought to AFFINE form in place (Z = 1;
 // an entry at infinity keeps Z = 0) with ONE shared inversion (Montgomery's trick: 21 multiplications + the
 // inversion + 4 per entry): every table addition of the ladder is then a mixed addition, 7M + 4S instead of

@@ -33,8 +33,10 @@ SOURCES = {
                C + "bls12381_keylines.cuh"] + COMMON_PAIRING,
     "gtmul": [C + "bls12381_pair.hip", C + "bn256_pair.hip", C + "bn254_pair.hip", C + "bn_pair.inc", C + "tower_vm.cuh", C + "gen_tower_vm.py",
               C + "bls12381_tvm.h"],
-    "bn256": [C + "bn256_pair.hip", C + "bn_pair.inc", C + "tower_vm.cuh", C + "gen_tower_vm.py", C + "bn256.cuh", C + "bn_suite.inc"] + COMMON_PAIRING,
-    "bn254": [C + "bn254_pair.hip", C + "bn_pair.inc", C + "tower_vm.cuh", C + "gen_tower_vm.py", C + "bn254.cuh", C + "bn_suite.inc"] + COMMON_PAIRING,
+    "bn256": [C + "bn256_pair.hip", C + "bn_pair.inc", C + "tower_vm.cuh", C + "gen_tower_vm.py", C + "bn256.cuh", C + "bn_suite.inc", C + "bn256.hip",
+              C + "pairing_abi.cuh"] + COMMON_PAIRING,
+    "bn254": [C + "bn254_pair.hip", C + "bn_pair.inc", C + "tower_vm.cuh", C + "gen_tower_vm.py", C + "bn254.cuh", C + "bn_suite.inc", C + "bn254.hip",
+              C + "pairing_abi.cuh"] + COMMON_PAIRING,
     "mul": [C + "bls12381.hip", C + "bls12381_lvm.cuh", C + "lane_vm.cuh", C + "gen_lane_vm.py", C + "bls12381.cuh", C + "pairing_abi.cuh",
             C + "bls12381_unm2.hip", C + "bls12381_g1split.hip"] + COMMON_PAIRING,
     "mulperlane": [C + "bls12381.hip", C + "bls12381.cuh", C + "pairing_abi.cuh"] + COMMON_PAIRING,
@@ -112,6 +114,10 @@ for key, prefix, sub, units in (("ed25519_mul", "ed", "ed25519_mul_kernel<true>"
                                 # (bn256 ValidatePairing: the product-form program is kernel <2>; <1> only decides
                                 # lanes whose joint Miller value was zero and returns at once otherwise)
                                 ("bn256_check", "bn256", "bn256_tvm_kernel<2>", 1 << 18),
+                                ("bn256_g1_mul", "bn256", "kyb::bn256_g1_mul_kernel", 1 << 18),
+                                ("bn256_g2_mul", "bn256", "kyb::bn256_g2_mul_kernel", 1 << 18),
+                                ("bn254_g1_mul", "bn254", "kyb::bn254_g1_mul_kernel", 1 << 18),
+                                ("bn254_g2_mul", "bn254", "kyb::bn254_g2_mul_kernel", 1 << 18),
                                 ("bn254_pair", "bn254", "bn254_tvm_kernel<0>", 1 << 18),
                                 ("bn254_check", "bn254", "bn254_tvm_kernel<1>", 1 << 18),
                                 # round 3: the lane machine's ladders (a G2 element is two lanes), the per-lane kernels of the
