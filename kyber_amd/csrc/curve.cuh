@@ -191,6 +191,19 @@ KYB_HD void jac_select8(Jac<F>& t, const Jac<F> (&tab)[8], int d) {
     f_neg(ny, t.Y);
     f_cmov(t.Y, ny, d < 0);
 }
+// The same from an AFFINE table (jac_table8_to_affine: Z is one, or zero for an entry at infinity): only the two
+// coordinates a mixed addition takes and the flag -- no copy of Z through the lane's scratch.
+template <class F>
+KYB_HD void jac_select8_xy(F& x, F& y, bool& inf, const Jac<F> (&tab)[8], int d) {
+    const int ad = d < 0 ? -d : d;
+    const Jac<F>& e = tab[ad ? ad - 1 : 0];
+    x = e.X;
+    inf = f_is_zero(e.Z);
+    F ny;
+    f_neg(ny, e.Y);
+    y = e.Y;
+    f_cmov(y, ny, d < 0);
+}
 // Mixed addition r = p + (x2, y2) with the second operand affine (madd-2007-bl, 7M + 4S), exceptional
 // cases handled: p at infinity, q at infinity (q_inf), p = q (doubling), p = -q (infinity).
 template <class F>
