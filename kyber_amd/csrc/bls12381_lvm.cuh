@@ -15,6 +15,14 @@
 //   4. the per-lane kernel of round 1 recomputes exactly those (its `only` mask) from the caller's original input.
 //
 // Large batches go through in chunks, so that the window tables (2.3 KB per G1 lane, 4.6 KB per G2 lane) stay bounded.
+//
+// Below the machine's threshold (round 4; lvm_mul and unmarshal_small decide, all of it behind the same entry points):
+//   n <= 2^14 (G1) / 2^13 (G2)   four cooperating lanes per point out of LDS slots, ladder and subgroup rule
+//                                (bls12381_g1coop.cuh): the chip is mostly empty, a call costs one ladder's latency;
+//   2^14 < n <= 2^15, G1, checks  the r-torsion test and the multiplication in different workgroups (bls12381_g1split.hip);
+//   otherwise                     one lane does it all (pairing_abi.cuh's kernels);
+// and UnmarshalBinary of batches with two or more waves per SIMD in flight takes the per-lane kernels compiled on a
+// two-wave register budget (bls12381_unm2.hip).
 #pragma once
 #include <stdlib.h>
 
