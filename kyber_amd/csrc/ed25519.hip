@@ -7,6 +7,14 @@
 //   geScalarMult      ge.go:443-502      -> ed25519_mul_kernel
 //   geScalarMultVartime ge_mult_vartime.go:11 (semantics via KYB_F_VARTIME)
 //   FromBytes/ToBytes ge.go:99-150       -> fused into the kernels
+// The element-wise kernels of this unit that named no register budget (Add, UnmarshalBinary, Hash, the encoder) take two
+// waves per SIMD (hd.h KYB_TU_WAVES): at the default they came out at 268-317 registers, one wave per SIMD.  2^20
+// elements, same box: UnmarshalBinary 2.03 -> 1.66 ms, Add 3.31 -> 2.61 ms, Hash 13.7 -> 9.0 ms
+// (profiles/r04_tu_wave_budgets.json); a three-wave budget gives the same.  The MSM's one-lane reduce kernel (msm.cuh)
+// keeps its registers: a latency-bound grid of 544 waves, 2 % slower at 256.
+#ifndef KYB_TU_WAVES
+#define KYB_TU_WAVES 2
+#endif
 #include "context.h"
 #include "ge25519.cuh"
 #include "msm.cuh"
@@ -123,7 +131,7 @@ KYB_DEV void load_fe(fe& f, const int32_t* __restrict__ p) {
 #pragma unroll
     for (int l = 0; l < 10; l++) f.v[l] = p[l];
 }
-__global__ __launch_bounds__(64) void ed25519_encode_kernel(size_t n, const int32_t* __restrict__ proj,
+__global__ __launch_bounds__(64, KYB_TU_WAVES) void ed25519_encode_kernel(size_t n, const int32_t* __restrict__ proj,
                                                             const uint8_t* __restrict__ status,
                                                             uint32_t* __restrict__ out) {
     const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -874,7 +882,7 @@ int kyb_ed25519_msm_dev(size_t n, const void* d_scalars, const void* d_points, v
 
 // ---------------------------------------------------------------- (*point).Hash (point.go:325-334)
 namespace kyb {
-__global__ __launch_bounds__(64) void ed25519_hash_kernel(size_t n, const uint8_t* __restrict__ msgs, size_t msg_len,
+__global__ __launch_bounds__(64, KYB_TU_WAVES) void ed25519_hash_kernel(size_t n, const uint8_t* __restrict__ msgs, size_t msg_len,
                                                           EdDstArg dst, uint8_t* __restrict__ out) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
@@ -920,7 +928,7 @@ int kyb_ed25519_hash(size_t n, const uint8_t* msgs, size_t msg_len, const uint8_
 
 // ---------------------------------------------------------------- batch Point.Add (point.go:216-223 -> ge.go:183)
 namespace kyb {
-__global__ __launch_bounds__(128) void ed25519_add_kernel(size_t n, const uint32_t* __restrict__ a,
+__global__ __launch_bounds__(128, KYB_TU_WAVES) void ed25519_add_kernel(size_t n, const uint32_t* __restrict__ a,
                                                           const uint32_t* __restrict__ b, uint32_t* __restrict__ out,
                                                           uint8_t* __restrict__ status) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -946,7 +954,7 @@ __global__ __launch_bounds__(128) void ed25519_add_kernel(size_t n, const uint32
 // out = Marshal(Unmarshal(in)): (*point).UnmarshalBinary (group/edwards25519/point.go:65-70 -> ge.go:110-150) as a batch
 // validity check -- bit 255 of y ignored for the field element, y >= p accepted, fails only when x^2 has no root --
 // followed by the canonical encoding MarshalBinary (ge.go:99-107) would give back.
-__global__ __launch_bounds__(128) void ed25519_unmarshal_kernel(size_t n, const uint32_t* __restrict__ in,
+__global__ __launch_bounds__(128, KYB_TU_WAVES) void ed25519_unmarshal_kernel(size_t n, const uint32_t* __restrict__ in,
                                                                 uint32_t* __restrict__ out,
                                                                 uint8_t* __restrict__ status) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
