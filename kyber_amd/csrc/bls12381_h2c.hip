@@ -5,6 +5,7 @@
 #include "bls12381_tvm.h"
 #include "pairing_abi.cuh"
 
+#include <stdlib.h>
 #include <string.h>
 
 namespace kyb {
@@ -23,6 +24,22 @@ __global__ __launch_bounds__(64, KYB_TU_WAVES) void bls12381_hash_g2_kernel(size
     if (idx >= n) return;
     const int st = bls::hash_g2_wire(out + 96 * idx, msgs + msg_len * idx, msg_len, dst);
     if (status) status[idx] = (uint8_t)st;
+}
+}  // namespace kyb
+
+namespace kyb {
+namespace bls {
+// the same kernels on a two-wave register budget (bls12381_unm2.hip), for batches with two waves per SIMD in flight;
+// KYB_UNM_W2=0 keeps every batch on the kernels above (A/B)
+void launch_hash_w2(bool g2, size_t n, const uint8_t* d_msgs, size_t msg_len, const DstArg& dst, uint8_t* d_out, uint8_t* d_status, hipStream_t st);
+}  // namespace bls
+static bool hash_w2(size_t n) {
+    static const bool on = [] {
+        const char* e = getenv("KYB_UNM_W2");
+        return !(e && e[0] == '0');
+    }();
+    DeviceCtx* ctx;
+    return on && get_ctx(&ctx) == KYB_OK && n >= (size_t)ctx->num_cu * 4 * 64 * 2;
 }
 }  // namespace kyb
 
@@ -49,8 +66,10 @@ int kyb_bls12381_hash_g1_dev(size_t n, const void* d_msgs, size_t msg_len, const
     bls::DstArg d;
     KYB_TRY(make_dst(d, dst, dst_len));
     if (!n) return KYB_OK;
-    hipLaunchKernelGGL(bls12381_hash_g1_kernel, dim3(grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n,
-                       (const uint8_t*)d_msgs, msg_len, d, (uint8_t*)d_out, (uint8_t*)d_status);
+    if (hash_w2(n)) bls::launch_hash_w2(false, n, (const uint8_t*)d_msgs, msg_len, d, (uint8_t*)d_out, (uint8_t*)d_status, (hipStream_t)stream);
+    else
+        hipLaunchKernelGGL(bls12381_hash_g1_kernel, dim3(grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n,
+                           (const uint8_t*)d_msgs, msg_len, d, (uint8_t*)d_out, (uint8_t*)d_status);
     KYB_HIP_CHECK(hipGetLastError());
     return KYB_OK;
 }
@@ -63,8 +82,10 @@ int kyb_bls12381_hash_g2_dev(size_t n, const void* d_msgs, size_t msg_len, const
     bls::DstArg d;
     KYB_TRY(make_dst(d, dst, dst_len));
     if (!n) return KYB_OK;
-    hipLaunchKernelGGL(bls12381_hash_g2_kernel, dim3(grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n,
-                       (const uint8_t*)d_msgs, msg_len, d, (uint8_t*)d_out, (uint8_t*)d_status);
+    if (hash_w2(n)) bls::launch_hash_w2(true, n, (const uint8_t*)d_msgs, msg_len, d, (uint8_t*)d_out, (uint8_t*)d_status, (hipStream_t)stream);
+    else
+        hipLaunchKernelGGL(bls12381_hash_g2_kernel, dim3(grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n,
+                           (const uint8_t*)d_msgs, msg_len, d, (uint8_t*)d_out, (uint8_t*)d_status);
     KYB_HIP_CHECK(hipGetLastError());
     return KYB_OK;
 }

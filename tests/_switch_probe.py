@@ -221,6 +221,28 @@ def unmw2():
             assert bytes(outu[i]) == unc(mul(int.from_bytes(bytes(hs[i]), "big"), gen)), (grp, i)
 
 
+def hashw2():
+    """G1Elt.Hash / G2Elt.Hash of a batch large enough for the two-wave kernels (bls12381_unm2.hip): 2^17 + 5 messages,
+    first / seam / last against the oracle's hash_to_curve"""
+    import torch
+
+    from kyber_amd.pairing import bls12381 as B
+    from oracle import bls12381 as OB
+
+    n = (1 << 17) + 5
+    rng = random.Random(15)
+    msgs = np.frombuffer(rng.randbytes(32 * n), dtype=np.uint8).reshape(n, 32).copy()
+    m = torch.from_numpy(msgs).cuda()
+    h1, s1 = B.batch_hash_g1(m)
+    h2, s2 = B.batch_hash_g2(m)
+    torch.cuda.synchronize()
+    assert not s1.any().item() and not s2.any().item()
+    h1, h2 = h1.cpu().numpy(), h2.cpu().numpy()
+    for i in (0, 63, 64, 1 << 16, n - 1):
+        assert bytes(h1[i]) == OB.g1_compress(OB.hash_to_g1(bytes(msgs[i]), B.DOMAIN_G1)), i
+        assert bytes(h2[i]) == OB.g2_compress(OB.hash_to_g2(bytes(msgs[i]), B.DOMAIN_G2)), i
+
+
 def pipe():
     from kyber_amd.group import edwards25519 as E
     from oracle import ed25519 as OE
@@ -277,5 +299,5 @@ def bncheck():
 
 
 if __name__ == "__main__":
-    {"fb": fb, "msm": msm, "lvm": lvm, "bncheck": bncheck, "pipe": pipe, "g1split": g1split, "unmw2": unmw2}[sys.argv[1]]()
+    {"fb": fb, "msm": msm, "lvm": lvm, "bncheck": bncheck, "pipe": pipe, "g1split": g1split, "unmw2": unmw2, "hashw2": hashw2}[sys.argv[1]]()
     print("switch-probe ok", sys.argv[1])

@@ -14,7 +14,7 @@ CASES = [
     ("fb", {}), ("fb", {"KYB_FB_MIN": "0"}), ("fb", {"KYB_FB_MIN": "1000"}),
     ("msm", {"KYB_MSM_TAIL": "coop"}), ("msm", {"KYB_MSM_TAIL": "lane"}), ("msm", {"KYB_MSM_SUB": "64"}),
     ("pipe", {}), ("pipe", {"KYB_PIPE_CHUNK": "4096", "KYB_PIPE_STREAMS": "1"}), ("pipe", {"KYB_PIPE_CHUNK": "4096", "KYB_PIPE_STREAMS": "3"}),
-    ("unmw2", {}), ("unmw2", {"KYB_UNM_W2": "0"}),
+    ("unmw2", {}), ("unmw2", {"KYB_UNM_W2": "0"}), ("hashw2", {}), ("hashw2", {"KYB_UNM_W2": "0"}),
     ("g1split", {}), ("g1split", {"KYB_G1_SPLIT": "0"}),
     ("bncheck", {}), ("bncheck", {"KYB_BN_CHECK": "two"}),
     ("lvm", {"KYB_LVM_MIN": "0"}), ("lvm", {"KYB_LVM_MIN": "1000000000"}),
