@@ -96,3 +96,31 @@ def test_lane_machine_kernels_fit_two_waves_per_simd_without_a_scratch_working_s
         assert lds * 8 <= 160 * 1024, lds               # eight waves per CU
         assert scratch <= 160, scratch                  # the out-of-line inversion's frame and a handful of spilled words
     assert seen == 4
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-readelf")), reason="no llvm-readelf")
+def test_units_on_a_two_wave_budget_keep_it():
+    """an out-of-line device function is compiled for the loosest register budget of the
+    kernels that reach it, so ONE kernel without a budget in a translation unit lets every kernel that shares code with
+    it grow past its own launch bounds (bn256_g2_mul_kernel: 374 registers under a three-wave bound).  The units that
+    are meant to run two waves per SIMD -- every kernel of the BN scalar-multiplication units, the large-batch copies of
+    the BLS12-381 unmarshal / hash kernels, the BLS12-381 fixed-base walk, Ed25519's element-wise kernels -- are pinned
+    at 256 registers here; a new kernel with plain launch bounds in one of them fails this test, not a benchmark."""
+    for obj in ("bn256.o", "bn254.o"):
+        regs = _kernel_regs(os.path.join(CSRC, obj))
+        assert len(regs) >= 15 and all(v <= 256 for v in regs.values()), {k: v for k, v in regs.items() if v > 256}
+    w2 = _kernel_regs(os.path.join(CSRC, "bls12381_unm2.o"))
+    assert len(w2) == 4 and all(v <= 256 for v in w2.values()), w2
+    split = _kernel_regs(os.path.join(CSRC, "bls12381_g1split.o"))
+    assert all(v <= 256 for v in split.values()), split
+    fb = _kernel_regs(os.path.join(CSRC, "bls12381_fb.o"))
+    walk = {k: v for k, v in fb.items() if "10mul_kernel" in k}
+    assert len(walk) == 2 and all(v <= 256 for v in walk.values()), walk
+    ed = _kernel_regs(os.path.join(CSRC, "ed25519.o"))
+    for name in ("ed25519_add_kernel", "ed25519_unmarshal_kernel", "ed25519_hash_kernel", "ed25519_encode_kernel"):
+        hits = [v for k, v in ed.items() if name in k]
+        assert len(hits) == 1 and hits[0] <= 256, (name, hits)
+    # ... and the unit that is meant to keep its registers (cooperating-lane kernels, ladders of a half-empty chip) has
+    # no fixed-base kernels left in it
+    bls = _kernel_regs(os.path.join(CSRC, "bls12381.o"))
+    assert not [k for k in bls if "2fb" in k], [k for k in bls if "2fb" in k]
