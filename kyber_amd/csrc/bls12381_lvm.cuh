@@ -14,7 +14,8 @@
 //      "redo" and
 //   4. the per-lane kernel of round 1 recomputes exactly those (its `only` mask) from the caller's original input.
 //
-// Large batches go through in chunks, so that the window tables (2.3 KB per G1 lane, 4.6 KB per G2 lane) stay bounded.
+// Large batches go through in rounds of 2^19 (G1) / 2^18 (G2) elements, so that the window tables (2.3 KB per G1 lane,
+// 4.6 KB per G2 lane) stay bounded at 1.2 / 2.4 GB.
 //
 // Below the machine's threshold (round 4; lvm_mul and unmarshal_small decide, all of it behind the same entry points):
 //   n <= 2^14 (G1) / 2^13 (G2)   four cooperating lanes per point out of LDS slots, ladder and subgroup rule
@@ -366,7 +367,17 @@ inline int lvm_mul(bool g2, size_t n, const uint8_t* d_scalars, const uint8_t* d
         return KYB_OK;
     }
     std::lock_guard<std::recursive_mutex> lk(ctx->enq_mu);
-    const size_t chunk = g2 ? (size_t(1) << 16) : (size_t(1) << 17);
+    // Elements per round of (unmarshal, prep, mul, encode): the window tables are 2.3 KB per G1 lane and 2 x 4.6 KB per G2
+    // element, i.e. 1.2 / 2.4 GB of the (WS_LVM, stream) workspace at these sizes -- small change on a 288 GB device, and
+    // every round boundary drains the chip: 2^17 / 2^16 elements per round measured 4.6-8.5 % slower at 2^18 - 2^20 elements
+    // (profiles/r04_lvm_chunks.json).
+#ifndef KYB_LVM_G1_CHUNK_LOG
+#define KYB_LVM_G1_CHUNK_LOG 19
+#endif
+#ifndef KYB_LVM_G2_CHUNK_LOG
+#define KYB_LVM_G2_CHUNK_LOG 18
+#endif
+    const size_t chunk = g2 ? (size_t(1) << KYB_LVM_G2_CHUNK_LOG) : (size_t(1) << KYB_LVM_G1_CHUNK_LOG);
     const size_t cn = n < chunk ? n : chunk, cl = g2 ? 2 * cn : cn;
     const size_t unc = g2 ? 192 : 96, dstr = g2 ? LVM_G2_DSTRIDE : LVM_G1_DSTRIDE;
     const uint32_t ncoord = g2 ? LVM_BLS12381_G2_MUL_NCOORD : LVM_BLS12381_G1_MUL_NCOORD, nentry = LVM_BLS12381_G1_MUL_NENTRY;
