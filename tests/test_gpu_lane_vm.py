@@ -153,15 +153,15 @@ def test_mul_through_the_machine_against_the_oracle(bls, grp):
         assert bytes(out[i]) == comp(mul(ki[i], base[3])), i
 
 
-@pytest.mark.parametrize("grp,n", [(1, (1 << 17) + 1000), (2, (1 << 16) + 777)])
+@pytest.mark.parametrize("grp,n", [(1, (1 << 19) + 1000), (2, (1 << 18) + 777)])
 def test_batches_larger_than_one_chunk(bls, grp, n):
-    """The machine works through a large batch in chunks (2^17 G1 / 2^16 G2 elements: the window tables stay bounded):
+    """The machine works through a large batch in chunks (2^19 G1 / 2^18 G2 elements: the window tables stay bounded):
     elements either side of the chunk boundary, the ragged last chunk, a rejected and an infinite point in the second
     chunk, status bytes of the whole batch -- against the oracle, and the identity sum_i k_i P == (sum k_i) P over ALL
     outputs through the MSM (so that no element of either chunk can be wrong unnoticed)."""
     import torch
 
-    chunk = (1 << 17) if grp == 1 else (1 << 16)
+    chunk = (1 << 19) if grp == 1 else (1 << 18)
     k = _scalars(b"lvm/chunk/%d" % grp, n)
     k[:, 0] &= 0x3F
     h = 0xC0FFEE
