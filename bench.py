@@ -12,12 +12,15 @@ rank owns its own 2^20-element batch (weak scaling); independent scalar multipli
 data-path collective, only the timing barrier and a MAX all-reduce of the elapsed time.
 
 BASELINE.json's metric is composite ("scalar-muls/s + pairings/s per node; MSM sec at 2^20"), so the
-same JSON line also carries, under "other_workloads", the BLS12-381 pairing rates at 2^16 pairs per
+run also measures, outside the headline's timed region, the BLS12-381 pairing rates at 2^16 pairs per
 GPU (configs[3]), the node-wide BLS12-381 G1 MSM time at 2^20 points sharded over the ranks with
-the RCCL all-gather of partial points (configs[2]) and the bn256 pairing rate (configs[4]); they
-are measured outside the headline's timed region.
+the RCCL all-gather of partial points (configs[2]) and the bn256 pairing rate (configs[4]).
 
-Prints ONE JSON line on rank 0.
+Output (rank 0): the full record -- every per-kernel roofline object, the CPU legs' sample descriptions -- goes to
+bench_detail.json on disk (and gpurun_out/bench_detail.json when that directory exists); stdout gets ONE compact
+JSON line (compact_line(): < 4 KB, asserted by tests/test_bench_line.py) carrying the headline, ONE roofline
+object, a scalar-only cpu_baseline and the composite metric's other figures as scalars with a fraction beside each
+(one small object per run, like benchmark/benchmark.go:166-200).
 """
 import argparse
 import hashlib
@@ -548,6 +551,98 @@ def other_workloads(rank, world, dist):
     return out
 
 
+LINE_LIMIT = 4096  # bytes of the one stdout line (a 20 KB line no longer parsed)
+
+
+def _g(d, *path):
+    for k in path:
+        if not isinstance(d, dict):
+            return None
+        d = d.get(k)
+    return d
+
+
+def _r4(x):
+    """4 significant digits for the stdout line (the detail file keeps full precision)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    return float("%.4g" % x)
+
+
+def compact_line(res: dict) -> dict:
+    """The one stdout line, built from the full record: headline keys of the bench contract, ONE roofline object
+    (no sentences), a scalar-only cpu_baseline, and the composite metric's other two thirds as scalars, each with
+    the fraction of the integer-MAD peak beside it.  Everything else lives in bench_detail.json."""
+    ro, cb, ow = res.get("roofline") or {}, res.get("cpu_baseline") or {}, res.get("other_workloads") or {}
+    line = {k: res.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {"workload": _g(res, "config", "workload"), "elements_per_gpu": _g(res, "config", "elements_per_gpu")}
+    line["rccl_ranks_seen"] = res.get("rccl_ranks_seen")
+    line["roofline"] = {"bound": ro.get("bound"), "kernel": "ed25519_mul_kernel<true>", "achieved": ro.get("achieved"),
+                        "peak": ro.get("peak"), "unit": ro.get("unit"), "frac": _r4(ro.get("frac")),
+                        "mads_per_op": ro.get("imads_per_op"), "kernel_ms": _r4(_g(res, "detail", "var_base_kernel_ms")),
+                        "valu_busy_profiled": _r4(ro.get("valu_busy_profiled")), "traffic": ro.get("traffic"),
+                        "hbm_frac": _r4(_g(ro, "hbm", "frac")), "profile": ro.get("profile")}
+    if cb:
+        line["cpu_baseline"] = {"value": _r4(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                                "cpu_model": cb.get("cpu_model"), "quota_cores": cb.get("cgroup_cpu_quota_cores"),
+                                "outputs_match": cb.get("outputs_match"), "outputs_compared": cb.get("outputs_compared"),
+                                "sample": "first %s elements of the GPU batch, fixed + var base, oracle/ed25519_ref.c" % (
+                                    (cb.get("outputs_compared") or 0) // 2)}
+    if ow:
+        b, n6, mm, cm = ow.get("bls12381") or {}, ow.get("bn256") or {}, ow.get("bls12381_g1_msm_2p20") or {}, ow.get("bls12381_g1_commit_2p20") or {}
+        cbo = cb.get("other_workloads") or {}
+        sc = {  # name: (value, fraction of the integer-MAD peak)
+            "bls12381_pairings_per_s": (b.get("pairings_per_s"), _g(b, "roofline", "pair", "frac")),
+            "bls12381_pairings_per_s_trusted": (b.get("pairings_per_s_validated_inputs"), _g(b, "roofline", "pair_validated_inputs", "frac")),
+            "bls12381_pair_checks_per_s": (b.get("pairing_checks_per_s"), _g(b, "roofline", "pair_check", "frac")),
+            "bls12381_verifies_per_s": (b.get("bls_verify_pipeline_per_s"), _g(b, "roofline", "verify", "frac")),
+            "bls12381_verifies_per_s_same_key": (b.get("bls_verify_same_key_per_s"), _g(b, "roofline", "verify_same_key", "frac")),
+            "bls12381_g1_muls_per_s": (b.get("g1_muls_per_s"), _g(b, "roofline", "g1_mul", "frac")),
+            "bls12381_g2_muls_per_s": (b.get("g2_muls_per_s"), _g(b, "roofline", "g2_mul", "frac")),
+            # configs[2] at SURVEY 8d's 80 B per point (32-byte scalar + 48-byte compressed point, validated when it
+            # was unmarshalled); _checked = the subgroup test repeated per point; _affine = 96-byte points, no square root
+            "bls12381_g1_msm_2p20_s": (mm.get("seconds_validated_points"), _g(mm, "roofline", "frac")),
+            "bls12381_g1_msm_2p20_s_checked": (mm.get("seconds"), None),
+            "bls12381_g1_msm_2p20_s_affine": (mm.get("seconds_validated_uncompressed_points"), _g(mm, "roofline_uncompressed_points", "frac")),
+            "bls12381_g1_commit_2p20_s": (cm.get("seconds"), _g(cm, "roofline", "frac")),
+            "bn256_pairings_per_s": (n6.get("pairings_per_s"), _g(n6, "roofline", "pair", "frac")),
+            "bn256_g1_muls_per_s": (n6.get("g1_muls_per_s"), _g(n6, "roofline", "g1_mul", "frac")),
+            "bn256_g2_muls_per_s": (n6.get("g2_muls_per_s"), _g(n6, "roofline", "g2_mul", "frac")),
+            "ed25519_msm_2p20_s": (_g(ow, "ed25519_msm_2p20", "seconds"), None),
+        }
+        for k, (v, f) in sc.items():
+            line[k] = _r4(v)
+            if f is not None:
+                line[k + "_frac"] = _r4(f)
+        line["checks"] = {"bls12381_all_true": b.get("all_checks_true"), "bn256_all_true": n6.get("all_checks_true"),
+                          "msm_matches_expectation": mm.get("matches_sum_ki_hi_times_G"),
+                          "commit_matches_var_base": cm.get("matches_variable_base_kernels"),
+                          "commit_matches_oracle": _g(cbo, "bls12381_g1_commit_oracle_sample", "outputs_match"),
+                          "bls12381_pair_matches_cpu_port": _g(cbo, "bls12381_pairings", "outputs_match"),
+                          "bn256_pair_matches_cpu_port": _g(cbo, "bn256_pairings", "outputs_match")}
+        line["cpu_bls12381_pairings_per_s"] = _r4(_g(cbo, "bls12381_pairings", "value"))
+        line["cpu_bn256_pairings_per_s"] = _r4(_g(cbo, "bn256_pairings", "value"))
+        line["cpu_bls12381_g1_mul_add_2p20_s"] = _r4(_g(cbo, "bls12381_g1_mul_add", "seconds_for_2p20_points_extrapolated"))
+    line["detail_file"] = "bench_detail.json"
+    return line
+
+
+def emit(res: dict):
+    """full record to bench_detail.json (+ gpurun_out/), the compact line to stdout"""
+    blob = json.dumps(res, indent=1)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    f.write(blob)
+            except OSError:
+                pass
+    line = json.dumps(compact_line(res), separators=(",", ":"))
+    assert len(line) < LINE_LIMIT, f"bench line is {len(line)} bytes"
+    print(line, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -717,27 +812,7 @@ def main():
 
                 res["cpu_baseline"]["other_workloads"] = cpu_baseline_pairing_and_msm(bn_, bls_)
                 res["cpu_baseline"]["other_workloads"]["reference_published_bls_verify_per_s_single_core"] = REF_BLS_VERIFY_PER_S_SINGLE_CORE
-        if other is not None:
-            # BASELINE.json's metric is composite -- "scalar-muls/s + pairings/s per node; MSM sec at 2^20 points": the
-            # other two thirds as top-level scalars, LAST in the line so that they survive in the driver's stdout tail
-            # (pairing/bls12381/kilic/suite.go:57-75; share/poly.go:340-348 at SURVEY.md 8d's 80 B per point)
-            b, mm = other.get("bls12381", {}), other.get("bls12381_g1_msm_2p20", {})
-            cb = (res.get("cpu_baseline") or {}).get("other_workloads", {})
-            res["composite"] = "scalar-muls/s = value; pairings/s and MSM seconds follow (flags = 0: every operand re-validated as UnmarshalBinary would)"
-            res["bn256_pairings_per_s"] = other.get("bn256", {}).get("pairings_per_s")
-            res["bls12381_g1_commit_2p20_s"] = other.get("bls12381_g1_commit_2p20", {}).get("seconds")
-            res["commit_matches_oracle_sample"] = cb.get("bls12381_g1_commit_oracle_sample", {}).get("outputs_match")
-            res["bls12381_verifies_per_s_same_key"] = b.get("bls_verify_same_key_per_s")
-            res["bls12381_verifies_per_s"] = b.get("bls_verify_pipeline_per_s")
-            res["bls12381_pair_checks_per_s"] = b.get("pairing_checks_per_s")
-            res["bls12381_pairings_per_s_validated_inputs"] = b.get("pairings_per_s_validated_inputs")
-            res["bls12381_pairings_per_s"] = b.get("pairings_per_s")
-            res["bls12381_pairings_match_cpu_port"] = cb.get("bls12381_pairings", {}).get("outputs_match")
-            res["bls12381_g1_msm_2p20_s_checked"] = mm.get("seconds")
-            res["bls12381_g1_msm_2p20_s_affine"] = mm.get("seconds_validated_uncompressed_points")
-            res["bls12381_g1_msm_2p20_s"] = mm.get("seconds_validated_points")
-            res["bls12381_g1_msm_2p20_matches_expectation"] = mm.get("matches_sum_ki_hi_times_G")
-        print(json.dumps(res))
+        emit(res)
     if dist:
         dist.destroy_process_group()
 
