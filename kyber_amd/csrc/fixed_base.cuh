@@ -129,9 +129,10 @@ KYB_HD void entry_images(Entry<F, P::NI>& e, const Jac<F>& q, int j) {
     }
 }
 
-// acc += s * (image j of the table's base), windows 0 .. nw - 1 of s (consumed)
+// acc += s * (image j of the table's base), windows 0 .. nw - 1 of s (consumed).  The accumulator is the field's run
+// form (curve.cuh XyzzSel: limbs for BLS12-381 G1, where the digit's sign is applied inside the addition).
 template <int NI, class F>
-KYB_HD void walk(Xyzz<F>& acc, uint32_t (&s)[8], int j, int nw, const Entry<F, NI>* __restrict__ tab) {
+KYB_HD void walk(typename XyzzSel<F>::type& acc, uint32_t (&s)[8], int j, int nw, const Entry<F, NI>* __restrict__ tab) {
     int carry = 0;
 #pragma unroll 1
     for (int w = 0; w < nw; w++) {
@@ -140,11 +141,9 @@ KYB_HD void walk(Xyzz<F>& acc, uint32_t (&s)[8], int j, int nw, const Entry<F, N
         const int a = dw < 0 ? -dw : dw;
         const F* e = reinterpret_cast<const F*>(tab + (w * NENT + (a - 1)));  // x[0 .. NI), y[0 .. NI)
         const F x = e[j];
-        F y = e[NI + j], ny;
+        const F y = e[NI + j];
         if (f_is_zero(x) & f_is_zero(y)) continue;  // that multiple of the base is the point at infinity
-        f_neg(ny, y);
-        f_cmov(y, ny, dw < 0);
-        xyzz_madd(acc, x, y);
+        XyzzSel<F>::madd(acc, x, y, dw < 0);
     }
 }
 // r = k * P from P's table under policy P_; r comes back in Jacobian form
@@ -152,8 +151,8 @@ template <class P_, class F>
 KYB_HD void mul(Jac<F>& r, const uint32_t (&k)[8], const Entry<F, P_::NI>* __restrict__ tab) {
     uint32_t sub[P_::NI][8];
     P_::split(sub, k);
-    Xyzz<F> acc;
-    xyzz_set_inf(acc);
+    typename XyzzSel<F>::type acc;
+    XyzzSel<F>::identity(acc);
 #pragma unroll 1
     for (int j = 0; j < P_::NI; j++) {
         uint32_t s[8];
@@ -161,7 +160,7 @@ KYB_HD void mul(Jac<F>& r, const uint32_t (&k)[8], const Entry<F, P_::NI>* __res
         for (int i = 0; i < 8; i++) s[i] = sub[j][i];
         walk<P_::NI>(acc, s, j, P_::NW, tab);
     }
-    xyzz_to_jac(r, acc);
+    XyzzSel<F>::finish(r, acc);
 }
 // r = s * P for an integer s below 2^(WBITS nw - 1), from the PLAIN image alone: the integer multiple for any point of
 // the curve -- what the membership criteria are evaluated with
@@ -170,10 +169,10 @@ KYB_HD void mul_plain(Jac<F>& r, const uint32_t (&k)[8], int nw, const Entry<F, 
     uint32_t s[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) s[i] = k[i];
-    Xyzz<F> acc;
-    xyzz_set_inf(acc);
+    typename XyzzSel<F>::type acc;
+    XyzzSel<F>::identity(acc);
     walk<NI>(acc, s, 0, nw, tab);
-    xyzz_to_jac(r, acc);
+    XyzzSel<F>::finish(r, acc);
 }
 
 

@@ -408,8 +408,11 @@ struct PieceOps<A, decltype((void)sizeof(typename A::Piece))> {
 // One lane per bucket piece: sums up to SUB points (mixed additions).  Lanes take the pieces in order of decreasing
 // length, so the lanes of a wave run the same number of additions (bucket sizes are Poisson-spread: in bucket order a
 // wave would wait for its longest piece, ~40 % above the mean at 32 points per bucket).
+#ifndef KYB_MSM_ACC_WAVES
+#define KYB_MSM_ACC_WAVES 2
+#endif
 template <class A>
-__global__ __launch_bounds__(64, 2) void accumulate_kernel(size_t nbk, size_t max_pieces,
+__global__ __launch_bounds__(64, KYB_MSM_ACC_WAVES) void accumulate_kernel(size_t nbk, size_t max_pieces,
                                                         const typename A::Aff* __restrict__ aff,
                                                         const uint32_t* __restrict__ suboffs,
                                                         const uint32_t* __restrict__ order,

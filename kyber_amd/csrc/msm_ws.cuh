@@ -47,16 +47,16 @@ struct Weierstrass {
     }
     // Bucket pieces are runs of mixed additions: they accumulate in XYZZ form (curve.cuh: 8M + 2S, no selects on the
     // common path) and leave it once, at the end of the run (accumulate_kernel: 2^24 additions of a 2^20-point MSM).
-    using Piece = Xyzz<F>;
-    __device__ static void piece_identity(Piece& a) { xyzz_set_inf(a); }
+    // Base fields with headroom (BLS12-381 Fp) run the piece in LIMB form (XyzzL: no packing between the products,
+    // the point's sign applied inside the formula; curve.cuh XyzzSel).
+    using PS = XyzzSel<F>;
+    using Piece = typename PS::type;
+    __device__ static void piece_identity(Piece& a) { PS::identity(a); }
     __device__ static void piece_madd(Piece& acc, const Aff& p, bool neg) {
         if (p.inf) return;
-        F y = p.y, ny;
-        f_neg(ny, p.y);
-        f_cmov(y, ny, neg);
-        xyzz_madd(acc, p.x, y);
+        PS::madd(acc, p.x, p.y, neg);
     }
-    __device__ static void piece_finish(Acc& r, const Piece& a) { xyzz_to_jac(r, a); }
+    __device__ static void piece_finish(Acc& r, const Piece& a) { PS::finish(r, a); }
     // inline bodies: the accumulators of the pipeline's loops (bucket pieces, running sums, folds) stay in registers
     // from one group operation to the next instead of crossing a call boundary (scratch) each time
     __device__ static void add(Acc& r, const Acc& a, const Acc& b) { jac_add_inl(r, a, b); }

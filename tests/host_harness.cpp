@@ -136,7 +136,53 @@ static int coop_run(const char* ops, const uint8_t* pa, const uint8_t* pb, int w
     return 0;
 }
 
+// The same run through the LIMB-form accumulator (curve.cuh XyzzL, fp_limbs.cuh): what accumulate_kernel and the
+// fixed-base walks run for base fields with headroom.  `maxk` receives the largest value / p met in X (the lazy bound
+// the formulas are proved for is 8).
+static int xyzzl_sum_bls_g1(int n, const uint8_t* pts, const uint8_t* signs, uint8_t* out, int* max_top) {
+    XyzzL<bls::FC> acc;
+    xyzzl_set_inf(acc);
+    int bad = 0;
+    uint32_t top = 0;
+    for (int i = 0; i < n; i++) {
+        bls::g1_aff a;
+        if (bls::g1_decode(a, pts + (size_t)48 * i, false)) { bad++; continue; }
+        if (a.inf) continue;
+        xyzzl_madd(acc, a.x, a.y, signs[i] != 0);
+        for (int j = 0; j < bls::FC::N - 1; j++)
+            if (acc.X.l[j] >> bls::FC::W || acc.Y.l[j] >> bls::FC::W || acc.ZZ.l[j] >> bls::FC::W || acc.ZZZ.l[j] >> bls::FC::W) bad += 1000;
+        if (acc.X.l[bls::FC::N - 1] > top) top = acc.X.l[bls::FC::N - 1];
+    }
+    if (max_top) *max_top = (int)top;
+    Jac<bls::fp> j;
+    xyzzl_to_jac(j, acc);
+    bls::g1_aff r;
+    jac_to_aff(r, j);
+    bls::g1_encode(out, r);
+    return bad;
+}
+
 extern "C" {
+
+int hh_bls_g1_xyzzl_sum(int n, const uint8_t* pts, const uint8_t* signs, uint8_t* out, int* max_top) {
+    return xyzzl_sum_bls_g1(n, pts, signs, out, max_top);
+}
+// lazy-form primitives against plain integers: op 0: a - b + 8p, 1: +-a - b + 4p (sign = c[0]), 2: a - b - 2c + 6p,
+// 3: (a b + c d) / R, 4: is a == 0 mod p (a = k p + delta).  Inputs are N little-endian limbs (uint32) each.
+int hh_bls_fpl_op(int op, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, uint32_t* out) {
+    FpL<bls::FC> A, B, Cc, D, R;
+    for (int j = 0; j < bls::FC::N; j++) { A.l[j] = a[j]; B.l[j] = b[j]; Cc.l[j] = c[j]; D.l[j] = d[j]; R.l[j] = 0; }
+    int rv = 0;
+    switch (op) {
+        case 0: fpl_sub<8>(R, A, B); break;
+        case 1: fpl_sub_signed<4>(R, A, c[0] != 0, B); break;
+        case 2: fpl_add_2x(D, B, Cc); fpl_sub<6>(R, A, D); break;
+        case 3: fpl_mul2sum(R, A, B, Cc, D); break;
+        default: rv = fpl_is_zero_mod_p<9>(A) ? 1 : 0; break;
+    }
+    for (int j = 0; j < bls::FC::N; j++) out[j] = R.l[j];
+    return rv;
+}
 
 // canonical big-endian in/out through the Montgomery domain
 void hh_bls_fp_op(int op, const uint8_t* a48, const uint8_t* b48, uint8_t* out48) {

@@ -1,6 +1,7 @@
 """The device arithmetic headers (mont.cuh / tower.cuh / curve.cuh / bls12381.cuh), compiled for the
 host, against the big-integer oracle.  This is the GPU-less debugging loop for the code each lane of
 the HIP kernels runs; the GPU parity tests proper are tests/test_gpu_bls12381.py."""
+import ctypes as C
 import json
 import os
 import random
@@ -500,3 +501,77 @@ def test_g2_mul_and_subgroup_rule_on_four_cooperating_lanes():
     assert verdict(c2) == (0, 0)
     small = O.g2_mul(O.R, c2)
     assert verdict(small) == (0, 0) and verdict(O.g2_add(Qp, small)) == (0, 0)
+
+
+# ---- the limb-form ("lazy") base-field layer of round 5: fp_limbs.cuh, curve.cuh XyzzL ---------------------------------
+_NL, _WL = 13, 30
+
+
+def _limbs(v):
+    assert 0 <= v < 1 << (_NL * _WL)
+    return (C.c_uint32 * _NL)(*[(v >> (_WL * j)) & ((1 << _WL) - 1) if j + 1 < _NL else v >> (_WL * j) for j in range(_NL)])
+
+
+def _fpl(op, a, b=0, c=0, d=0, sign=0):
+    lib = H.lib()
+    out = (C.c_uint32 * _NL)()
+    cc = _limbs(c) if op != 1 else (C.c_uint32 * _NL)(sign)
+    rv = lib.hh_bls_fpl_op(op, _limbs(a), _limbs(b), cc, _limbs(d), out)
+    return rv, sum(int(x) << (_WL * j) for j, x in enumerate(out)), list(out)
+
+
+def test_limb_form_primitives_vs_integers():
+    """fpl_sub / fpl_sub_signed / fpl_sub_b_2c are exact integer identities with normalised limbs out; fpl_mul2sum is
+    (a b + c d) R^-1 mod p below 2p; fpl_is_zero_mod_p is exact on multiples of p and their neighbours."""
+    rng = random.Random(5)
+    p, R = O.P, 1 << (_NL * _WL)
+    norm = lambda limbs: all(x < 1 << _WL for x in limbs[:-1])
+    for _ in range(300):
+        a, b = rng.randrange(2 * p), rng.randrange(8 * p)
+        _, v, l = _fpl(0, a, b)
+        assert v == a - b + 8 * p and norm(l)
+        a, b, s = rng.randrange(2 * p), rng.randrange(2 * p), rng.randrange(2)
+        _, v, l = _fpl(1, a, b, sign=s)
+        assert v == (-a if s else a) - b + 4 * p and norm(l)
+        a, b, c = rng.randrange(2 * p), rng.randrange(2 * p), rng.randrange(2 * p)
+        _, v, l = _fpl(2, a, b, c)
+        assert v == a - b - 2 * c + 6 * p and norm(l)
+        a, b, c, d = rng.randrange(6 * p), rng.randrange(10 * p), rng.randrange(2 * p), rng.randrange(2 * p)
+        _, v, l = _fpl(3, a, b, c, d)
+        assert v < 2 * p and norm(l) and (v * R - a * b - c * d) % p == 0
+    for a, b, c, d in ((6 * p - 1, 10 * p - 1, 2 * p - 1, 2 * p), (0, 0, 0, 0), (p, p, p, p), (10 * p - 1, 10 * p - 1, 0, 0)):
+        _, v, l = _fpl(3, a, b, c, d)
+        assert v < 2 * p and norm(l) and (v * R - a * b - c * d) % p == 0
+    for k in range(10):
+        assert _fpl(4, k * p)[0] == 1
+        for delta in (1, -1, 1 << 30, -(1 << 30), 1 << 360, p // 2):
+            v = k * p + delta
+            if 0 <= v < 10 * p:
+                assert _fpl(4, v)[0] == 0, (k, delta)
+    # same low limb as k p but a different value: the filter passes, the exact comparison must reject
+    for k in (1, 5, 9):
+        assert _fpl(4, k * p + (1 << 30))[0] == 0 and _fpl(4, (k * p + (3 << 90)) % (10 * p))[0] == (1 if (3 << 90) % p == 0 else 0)
+
+
+def test_limb_form_piece_accumulator_vs_oracle():
+    """xyzzl_madd over the exceptional runs of the packed accumulator's test and over long random runs (the lazy bounds
+    are reached only after a few additions); X's top limb stays below 8p's."""
+    rng = random.Random(43)
+    lib = H.lib()
+    runs = list(_xyzz_cases(rng, O.G1_GEN, O.g1_mul, O.g1_neg))
+    base = [O.g1_mul(rng.randrange(1, O.R), O.G1_GEN) for _ in range(24)]
+    for n in (3, 17, 64):
+        runs.append([(rng.choice(base), rng.random() < 0.5) for _ in range(n)])
+    runs.append([(base[0], False)] * 9)                                   # P, 2P (doubling), 3P ...
+    runs.append([(base[1], True), (base[1], False), (base[1], False), (base[1], False)])
+    for run in runs:
+        exp = None
+        for pt, s in run:
+            exp = O.g1_add(exp, O.g1_neg(pt) if s else pt)
+        wire = b"".join(O.g1_compress(pt) for pt, _ in run) or b"\x00"
+        signs = bytes(int(s) for _, s in run) or b"\x00"
+        out = C.create_string_buffer(48)
+        top = C.c_int(0)
+        bad = lib.hh_bls_g1_xyzzl_sum(len(run), wire, signs, out, C.byref(top))
+        assert bad == 0 and out.raw == O.g1_compress(exp), run
+        assert top.value <= (8 * O.P) >> (30 * 12)
