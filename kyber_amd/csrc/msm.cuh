@@ -60,7 +60,12 @@ inline Plan make_plan(size_t n, int scalar_bits = 256, int cmax = 16) {
     // buckets per reduce lane: the running-sum chain of a lane is latency-bound (2 dependent additions per bucket, and
     // a lone wave already saturates its SIMD's issue rate), so take the shortest chains that still leave every wave
     // a SIMD of its own: at most 1024 waves = 65536 lanes, between 8 and 64 buckets each
-    int chunk = 8;
+    static const int chunk_min = [] {  // KYB_MSM_CHUNK: buckets per reduce chain at least (experiments; 8)
+        const char* e = getenv("KYB_MSM_CHUNK");
+        const int v = e ? atoi(e) : 0;
+        return v >= 2 && v <= 64 && (v & (v - 1)) == 0 ? v : 8;
+    }();
+    int chunk = chunk_min;
     while (chunk < 64 && (size_t)p.nwin * (p.nb / chunk) > 65536) chunk <<= 1;
     p.chunk = p.nb < chunk ? p.nb : chunk;
     p.nchunks = p.nb / p.chunk;
