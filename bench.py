@@ -240,6 +240,18 @@ def cpu_baseline_pairing_and_msm(bn, bls):
 REF_BLS_VERIFY_PER_S_SINGLE_CORE = 303  # BASELINE.md section 1 (sign/bls Verify, BLS12-381 circl backend, signatures on G1, one core)
 
 
+def max_over_ranks(dist, values, device="cuda"):
+    """the slowest rank's figure for each of `values` (one all-reduce MAX; the identity without a process group):
+    every per-job rate of this file is units of ALL ranks / this time"""
+    import torch
+
+    if not dist:
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(x) for x in t]
+
+
 def timed(fn, reps=20, warm=5):
     """median of `reps` HIP-event timings (ms) after `warm` untimed calls"""
     import torch
@@ -385,10 +397,8 @@ def other_workloads(rank, world, dist):
         e_kp, _ = m.batch_pair(kP, Q[:ns].contiguous())
         gt_ok = bool((gk[:ns] == e_kp).all().item()) and not bool(st_gt.any().item())
         del gt, gk
-        t = torch.tensor([ms_pair, ms_chk, ms_g1, ms_g2, ms_chk_t, ms_pair_t, ms_gt], dtype=torch.float64, device="cuda")
-        if dist:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ms_pair, ms_chk, ms_g1, ms_g2, ms_chk_t, ms_pair_t, ms_gt = [float(x) for x in t]
+        ms_pair, ms_chk, ms_g1, ms_g2, ms_chk_t, ms_pair_t, ms_gt = max_over_ranks(
+            dist, [ms_pair, ms_chk, ms_g1, ms_g2, ms_chk_t, ms_pair_t, ms_gt])
         good = bool(ok.all().item()) and bool(ok_t.all().item()) and not (
             st1.any().item() or st2.any().item() or st3.any().item() or st_t.any().item())
         out[name] = {"pairs_per_gpu": npair, "pairings_per_s": world * npair / ms_pair * 1e3,
@@ -450,11 +460,9 @@ def other_workloads(rank, world, dist):
 
             ms_v = timed(verify)
             ms_vk = timed(verify_known_keys)
-            tv = torch.tensor([ms_v, ms_vk], dtype=torch.float64, device="cuda")
-            if dist:
-                dist.all_reduce(tv, op=dist.ReduceOp.MAX)
-            out[name]["bls_verify_pipeline_per_s"] = world * npair / float(tv[0].item()) * 1e3
-            out[name]["bls_verify_pipeline_per_s_known_keys"] = world * npair / float(tv[1].item()) * 1e3
+            ms_v, ms_vk = max_over_ranks(dist, [ms_v, ms_vk])
+            out[name]["bls_verify_pipeline_per_s"] = world * npair / ms_v * 1e3
+            out[name]["bls_verify_pipeline_per_s_known_keys"] = world * npair / ms_vk * 1e3
             if name == "bls12381":  # the VERIFY program (generator lines from a table); hashing and unmarshalling are extra
                 out[name]["roofline"]["verify"] = _roof(npair / ms_v * 1e3, mads[name][2], g1b_ + g2b_ + 32 + 1, prof, name + "_verify")
                 # ONE signer for the whole batch (a drand chain; sign/bls/bls.go:82-96 in a loop with the same X): program
@@ -465,10 +473,8 @@ def other_workloads(rank, world, dist):
                 sig1, _ = m.g1_batch_mul(x1.repeat(npair, 1), Hm)
                 ok1, st1 = m.batch_verify_g1_same_key(X1, msgs, sig1)
                 ms_v1 = timed(lambda: m.batch_verify_g1_same_key(X1, msgs, sig1))
-                t1 = torch.tensor([ms_v1], dtype=torch.float64, device="cuda")
-                if dist:
-                    dist.all_reduce(t1, op=dist.ReduceOp.MAX)
-                out[name]["bls_verify_same_key_per_s"] = world * npair / float(t1[0].item()) * 1e3
+                ms_v1, = max_over_ranks(dist, [ms_v1])
+                out[name]["bls_verify_same_key_per_s"] = world * npair / ms_v1 * 1e3
                 out[name]["bls_verify_same_key_all_true"] = bool(ok1.all().item()) and not bool(st1.any().item())
                 out[name]["roofline"]["verify_same_key"] = _roof(npair / ms_v1 * 1e3, mads["verifyk"], g1b_ + 32 + 1, prof, name + "_verifyk")
                 del Hm, sig1
@@ -503,17 +509,15 @@ def other_workloads(rank, world, dist):
             expect = bytes(np.asarray(m.g1_commit(tot.to_bytes(32, "big"))[0])[0])
             same = all(bytes(f()[0].cpu().numpy()) == expect for f in (fn, fn_t, fn_u))
             ms_t, ms_u = timed(fn_t), timed(fn_u)
-            t = torch.tensor([ms, ms_t, ms_u], dtype=torch.float64, device="cuda")
-            if dist:
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            out["bls12381_g1_msm_2p20"] = {"points": n, "seconds": float(t[0].item()) * 1e-3,
-                                           "seconds_validated_points": float(t[1].item()) * 1e-3,
-                                           "seconds_validated_uncompressed_points": float(t[2].item()) * 1e-3,
+            t = max_over_ranks(dist, [ms, ms_t, ms_u])
+            out["bls12381_g1_msm_2p20"] = {"points": n, "seconds": t[0] * 1e-3,
+                                           "seconds_validated_points": t[1] * 1e-3,
+                                           "seconds_validated_uncompressed_points": t[2] * 1e-3,
                                            "matches_sum_ki_hi_times_G": same, "scaling": "strong",
                                            # SURVEY.md section 8d prices configs[2] at 80 B per point: 32-byte scalar +
                                            # 48-byte compressed point, so the decompression (a 379-bit power) is inside
-                                           "roofline": _roof(n / float(t[1].item()) * 1e3, MADS_MSM_BLS_G1_2P20_PER_POINT + MADS_G1_DECOMPRESS, 32 + 48, prof, "bls12381_g1_msm"),
-                                           "roofline_uncompressed_points": _roof(n / float(t[2].item()) * 1e3, MADS_MSM_BLS_G1_2P20_PER_POINT, 32 + 96, prof, "bls12381_g1_msm"),
+                                           "roofline": _roof(n / t[1] * 1e3, MADS_MSM_BLS_G1_2P20_PER_POINT + MADS_G1_DECOMPRESS, 32 + 48, prof, "bls12381_g1_msm"),
+                                           "roofline_uncompressed_points": _roof(n / t[2] * 1e3, MADS_MSM_BLS_G1_2P20_PER_POINT, 32 + 96, prof, "bls12381_g1_msm"),
                                            "exchange": "all-gather of %d encoded partial points" % world if dist else "none"}
             # share.PriPoly.Commit (share/poly.go:143-149): the same n coefficients times ONE base -- an arbitrary
             # point of the group, unmarshalled by the call like any base -- through the fixed-base table
@@ -524,15 +528,13 @@ def other_workloads(rank, world, dist):
             ms_c = timed(fn_c)
             nchk = min(4096, int(ks.shape[0]))
             ok_c = bool(torch.equal(fn_c()[0][:nchk], m.g1_batch_mul(ks[:nchk], cb.repeat(nchk, 1))[0]))
-            tc = torch.tensor([ms_c], dtype=torch.float64, device="cuda")
-            if dist:
-                dist.all_reduce(tc, op=dist.ReduceOp.MAX)
-            out["bls12381_g1_commit_2p20"] = {"coefficients": n, "seconds": float(tc[0].item()) * 1e-3,
-                                              "commits_per_s": n / float(tc[0].item()) * 1e3,
+            ms_c, = max_over_ranks(dist, [ms_c])
+            out["bls12381_g1_commit_2p20"] = {"coefficients": n, "seconds": ms_c * 1e-3,
+                                              "commits_per_s": n / ms_c * 1e3,
                                               "matches_variable_base_kernels": ok_c,
                                               "oracle_sample": "cpu_baseline.other_workloads.bls12381_g1_commit_oracle_sample",
                                               "scaling": "strong",
-                                              "roofline": _roof(n / float(tc[0].item()) * 1e3, MADS_G1_COMMIT, 32 + 48, prof, "bls12381_g1_commit")}
+                                              "roofline": _roof(n / ms_c * 1e3, MADS_G1_COMMIT, 32 + 48, prof, "bls12381_g1_commit")}
             del ks, hs, pts, pts_u
     # Ed25519 MSM at 2^20 points (PubPoly.Eval / RecoverCommit shape), sharded like the BLS one
     from kyber_amd.group import edwards25519 as ed
@@ -543,11 +545,8 @@ def other_workloads(rank, world, dist):
     ks = torch.from_numpy(s_all[lo:hi].copy()).cuda()
     pts = ed.batch_mul_base(torch.from_numpy(h_all[lo:hi].copy()).cuda())
     fn = (lambda: kd.ed25519_msm(ks, pts)) if dist else (lambda: ed.msm(ks, pts))
-    ms = timed(fn)
-    t = torch.tensor([ms], dtype=torch.float64, device="cuda")
-    if dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    out["ed25519_msm_2p20"] = {"points": n, "seconds": float(t.item()) * 1e-3, "scaling": "strong"}
+    ms, = max_over_ranks(dist, [timed(fn)])
+    out["ed25519_msm_2p20"] = {"points": n, "seconds": ms * 1e-3, "scaling": "strong"}
     return out
 
 
@@ -725,10 +724,7 @@ def main():
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, = max_over_ranks(dist, [elapsed])
 
     var_ms = [a.elapsed_time(b) for a, b in evs]
     fix_ms = []

@@ -218,6 +218,11 @@ func ScalarPolyEval(suite string, idx []uint32, coeffs []byte) (out []byte, err 
 	if err != nil {
 		return nil, err
 	}
+	switch suite {
+	case "ed25519", "bls12381", "bn256", "bn254":
+	default: // a mistyped suite name must not fall through to some other group order
+		return nil, fmt.Errorf("kyberhip: ScalarPolyEval: unknown suite %q", suite)
+	}
 	n := len(idx)
 	out = make([]byte, 32*n)
 	err = call(func() C.int {
@@ -228,7 +233,7 @@ func ScalarPolyEval(suite string, idx []uint32, coeffs []byte) (out []byte, err 
 			return C.kyb_bls12381_scalar_poly_eval(C.size_t(n), idxPtr(idx), C.size_t(t), ptr(coeffs), ptr(out))
 		case "bn256":
 			return C.kyb_bn256_scalar_poly_eval(C.size_t(n), idxPtr(idx), C.size_t(t), ptr(coeffs), ptr(out))
-		default:
+		default: // "bn254": the names were checked above
 			return C.kyb_bn254_scalar_poly_eval(C.size_t(n), idxPtr(idx), C.size_t(t), ptr(coeffs), ptr(out))
 		}
 	})
@@ -471,6 +476,20 @@ func Bls12381VerifyG1SameKey(pubkey, msgs []byte, msgLen int, dst, sigs []byte, 
 	ok, status = make([]byte, n), make([]byte, n)
 	err = call(func() C.int {
 		return C.kyb_bls12381_verify_g1_same_key(C.size_t(n), ptr(pubkey), ptr(msgs), C.size_t(msgLen), ptr(dst), C.size_t(len(dst)), ptr(sigs), ptr(ok), ptr(status), C.uint32_t(flags))
+	})
+	return
+}
+
+// Bls12381VerifyG1SameMsg: ok[i] = bls.Verify(pubkeys[i], msg, sigs[i]) for ONE message -- the verification loop of
+// tbls.Recover (sign/tbls/tbls.go:118-131); H(msg) is hashed once per call.
+func Bls12381VerifyG1SameMsg(pubkeys, msg, dst, sigs []byte, flags uint32) (ok, status []byte, err error) {
+	n, err := count("sigs", sigs, g1in(flags))
+	if err = firstErr(err, need("pubkeys", pubkeys, n, g2in(flags))); err != nil {
+		return nil, nil, err
+	}
+	ok, status = make([]byte, n), make([]byte, n)
+	err = call(func() C.int {
+		return C.kyb_bls12381_verify_g1_same_msg(C.size_t(n), ptr(pubkeys), ptr(msg), C.size_t(len(msg)), ptr(dst), C.size_t(len(dst)), ptr(sigs), ptr(ok), ptr(status), C.uint32_t(flags))
 	})
 	return
 }

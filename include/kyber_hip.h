@@ -244,6 +244,17 @@ int kyb_bls12381_verify_g1_same_key(size_t n, const uint8_t *pubkey, const uint8
 int kyb_bls12381_verify_g1_same_key_dev(size_t n, const void *d_pubkey, const void *d_msgs, size_t msg_len,
                                         const uint8_t *dst, size_t dst_len, const void *d_sigs, void *d_ok,
                                         void *d_status, uint32_t flags, void *stream);
+/* ok[i] = bls.Verify(pubkeys[i], msg, sigs[i]) for ONE message: the verification loop of tbls.Recover
+ * (sign/tbls/tbls.go:118-131 -- every partial signature of a round is over the same msg, each under its own public
+ * share public.Eval(idx).V, share/poly.go:340-348).  H(msg) is computed once per call instead of once per element;
+ * everything else is kyb_bls12381_verify_g1 (same flags, same status precedence: key, then signature).  `msg` is a HOST
+ * pointer in the first variant, a device pointer in `_dev`; msg_len may be 0. */
+int kyb_bls12381_verify_g1_same_msg(size_t n, const uint8_t *pubkeys, const uint8_t *msg, size_t msg_len,
+                                    const uint8_t *dst, size_t dst_len, const uint8_t *sigs, uint8_t *ok,
+                                    uint8_t *status, uint32_t flags);
+int kyb_bls12381_verify_g1_same_msg_dev(size_t n, const void *d_pubkeys, const void *d_msg, size_t msg_len,
+                                        const uint8_t *dst, size_t dst_len, const void *d_sigs, void *d_ok,
+                                        void *d_status, uint32_t flags, void *stream);
 /* The same for the scheme with signatures on G2 and keys on G1 (NewSchemeOnG2, sign/bls/bls.go:48-58:
  * ValidatePairing(G1.Base(), sig, X, H(msg)) with H = hash_to_curve on G2): pubkeys 48 B, sigs 96 B. */
 int kyb_bls12381_verify_g2(size_t n, const uint8_t *pubkeys, const uint8_t *msgs, size_t msg_len, const uint8_t *dst,

@@ -74,6 +74,8 @@ SIGNATURES = {
     "kyb_bls12381_verify_g1_dev": [_sz, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _u32, _vp],
     "kyb_bls12381_verify_g1_same_key": [_sz, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _u32],
     "kyb_bls12381_verify_g1_same_key_dev": [_sz, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _u32, _vp],
+    "kyb_bls12381_verify_g1_same_msg": [_sz, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _u32],
+    "kyb_bls12381_verify_g1_same_msg_dev": [_sz, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _u32, _vp],
     "kyb_bls12381_verify_g2": [_sz, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _u32],
     "kyb_bls12381_verify_g2_dev": [_sz, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _u32, _vp],
     "kyb_bls12381_gt_mul": [_sz, _vp, _vp, _vp, _vp],

@@ -229,6 +229,60 @@ int kyb_bls12381_verify_g1_same_key(size_t n, const uint8_t* pk, const uint8_t* 
     if (status) KYB_TRY(st.download(status, n));
     return KYB_OK;
 }
+// sign/bls Verify for n (public key, signature) pairs over ONE message -- tbls.Recover (sign/tbls/tbls.go:118-131: every
+// partial signature of a round signs the same msg, each under its own public share public.Eval(idx).V): H(msg) is hashed
+// once per call, next to the lanes that unmarshal keys and signatures, then dealt to every pairing; program VERIFY as in
+// kyb_bls12381_verify_g1.  d_msg: the message on the device (msg_len bytes).
+int kyb_bls12381_verify_g1_same_msg_dev(size_t n, const void* d_pks, const void* d_msg, size_t msg_len, const uint8_t* dst,
+                                        size_t dst_len, const void* d_sigs, void* d_ok, void* d_status, uint32_t flags, void* stream) {
+    if (n && (!d_pks || (!d_msg && msg_len) || !d_sigs || !d_ok)) {
+        set_error("kyb_bls12381_verify_g1_same_msg_dev: bad argument");
+        return KYB_E_ARG;
+    }
+    KYB_TRY(check_flags(flags, 2, false, "kyb_bls12381_verify_g1_same_msg_dev"));
+    bls::DstArg d;
+    KYB_TRY(make_dst(d, dst, dst_len));
+    if (!n) return KYB_OK;
+    DeviceCtx* ctx;
+    KYB_TRY(get_ctx(&ctx));
+    std::lock_guard<std::recursive_mutex> enq_lock(ctx->enq_mu);
+    blsvm::Work w;
+    // e(H(msg), X_i) e(-sig_i, G2.Base()) == 1   (status precedence: key, then signature)
+    const blsvm::Operand ops[3] = {{(const uint8_t*)d_msg, blsvm::OPND_G1_SHARED_HASH, (uint32_t)msg_len, 0, 0, 0},
+                                   {(const uint8_t*)d_pks, blsvm::OPND_G2, (uint32_t)bls::g2_wire_size(flags), 2, 0, 0},
+                                   {(const uint8_t*)d_sigs, blsvm::OPND_G1, (uint32_t)bls::g1_wire_size(flags), 6, 1, 1}};
+    KYB_TRY(blsvm::workspace(ctx, (hipStream_t)stream, n, blsvm::VERIFY_INPUTS, &w));
+    KYB_TRY(blsvm::launch_prep(w, n, ops, 3, flags, dst, dst_len, (hipStream_t)stream));
+    return blsvm::launch_verify(w, n, (uint8_t*)d_ok, (uint8_t*)d_status, (hipStream_t)stream);
+}
+int kyb_bls12381_verify_g1_same_msg(size_t n, const uint8_t* pks, const uint8_t* msg, size_t msg_len, const uint8_t* dst,
+                                    size_t dst_len, const uint8_t* sigs, uint8_t* ok, uint8_t* status, uint32_t flags) {
+    if (n && (!pks || (!msg && msg_len) || !sigs || !ok)) {
+        set_error("kyb_bls12381_verify_g1_same_msg: bad argument");
+        return KYB_E_ARG;
+    }
+    KYB_TRY(check_flags(flags, 2, false, "kyb_bls12381_verify_g1_same_msg"));
+    if (!n) return KYB_OK;
+    if (md_active(n))
+        return md_run(n, [&](int, size_t lo, size_t hi) {
+            return kyb_bls12381_verify_g1_same_msg(hi - lo, pks + bls::g2_wire_size(flags) * lo, msg, msg_len, dst, dst_len,
+                                                   sigs + bls::g1_wire_size(flags) * lo, ok + lo, status ? status + lo : nullptr, flags);
+        });
+    DeviceCtx* ctx;
+    KYB_TRY(get_ctx(&ctx));
+    kyb::StageScope sc_(ctx);
+    StageBuf p, m, s, o, st;
+    KYB_TRY(p.upload(pks, n * bls::g2_wire_size(flags)));
+    const uint8_t none = 0;
+    KYB_TRY(m.upload(msg_len ? msg : &none, msg_len ? msg_len : 1));
+    KYB_TRY(s.upload(sigs, n * bls::g1_wire_size(flags)));
+    KYB_TRY(o.alloc(n));
+    KYB_TRY(st.alloc(n));
+    KYB_TRY(kyb_bls12381_verify_g1_same_msg_dev(n, p.p, m.p, msg_len, dst, dst_len, s.p, o.p, st.p, flags, nullptr));
+    KYB_TRY(o.download(ok, n));
+    if (status) KYB_TRY(st.download(status, n));
+    return KYB_OK;
+}
 int kyb_bls12381_verify_g2_dev(size_t n, const void* d_pks, const void* d_msgs, size_t msg_len, const uint8_t* dst,
                                size_t dst_len, const void* d_sigs, void* d_ok, void* d_status, uint32_t flags, void* stream) {
     if (n && (!d_pks || (!d_msgs && msg_len) || !d_sigs || !d_ok)) {

@@ -24,6 +24,8 @@ struct PrepArgs {
     size_t n;
     uint32_t* in;
     uint8_t* pst;
+    uint32_t* shared;
+    int has_shared;  // a workgroup ahead of the operands' own hashes the OPND_G1_SHARED_HASH message
     uint32_t flags;
     bls::DstArg dst;
 };
@@ -36,10 +38,37 @@ __device__ __forceinline__ void put_fp(uint32_t* in, size_t n, uint32_t idx, siz
 
 __global__ __launch_bounds__(64, KYB_TU_WAVES) void bls12381_operand_kernel(PrepArgs a) {
     const size_t nblk = (a.n + 63) / 64;
-    const int k = (int)(blockIdx.x / nblk);  // uniform per workgroup: no divergence between the kinds
-    const size_t i = (blockIdx.x - (size_t)k * nblk) * 64 + threadIdx.x;
+    size_t blk = blockIdx.x;
+    if (a.has_shared) {
+        // workgroup 0 (dispatched first: its one lane is the longest chain of the launch) hashes the batch's shared
+        // message once, next to the lanes that decode the other operands, at raised issue priority
+        if (blk == 0) {
+            if (threadIdx.x != 0) return;
+            __builtin_amdgcn_s_setprio(3);
+            for (int j = 0; j < a.nops; j++) {
+                const Operand& o = a.op[j];
+                if (o.kind != OPND_G1_SHARED_HASH) continue;
+                bls::g1_jac h;
+                bls::g1_aff p;
+                bls::hash_g1_point(h, o.src, o.stride, a.dst);
+                jac_to_aff(p, h);
+                if (o.negate) fp_neg(p.y, p.y);
+#pragma unroll
+                for (int w = 0; w < FP_WORDS; w++) {
+                    a.shared[w] = p.x.v[w];
+                    a.shared[FP_WORDS + w] = p.y.v[w];
+                }
+                a.shared[2 * FP_WORDS] = p.inf ? 1u : 0u;
+            }
+            return;
+        }
+        blk -= 1;
+    }
+    const int k = (int)(blk / nblk);  // uniform per workgroup: no divergence between the kinds
+    const size_t i = (blk - (size_t)k * nblk) * 64 + threadIdx.x;
     if (i >= a.n) return;
     const Operand& o = a.op[k];
+    if (o.kind == OPND_G1_SHARED_HASH) return;  // dealt out by bls12381_shared_operand_kernel once the hash is there
     if (o.kind == OPND_STATUS) {  // an operand shared by every pairing: only its verdict
         a.pst[(size_t)k * a.n + i] = o.src[0];
         return;
@@ -89,6 +118,21 @@ __global__ __launch_bounds__(64, KYB_TU_WAVES) void bls12381_operand_kernel(Prep
     a.pst[(size_t)k * a.n + i] = (uint8_t)((st & 0x7f) | ((inf && st == bls::ST_OK) ? PST_INF : 0));
 }
 
+// the shared operand's coordinates and status to every pairing (after the operand kernel: stream order)
+__global__ __launch_bounds__(256) void bls12381_shared_operand_kernel(size_t n, const uint32_t* __restrict__ shared, uint32_t* __restrict__ in,
+                                                                      uint8_t* __restrict__ pst, uint32_t first, int k) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        uint32_t* d = in + ((size_t)(first + c) * n + i) * FP_WORDS;
+#pragma unroll
+        for (int w = 0; w < FP_WORDS; w += 4)
+            *reinterpret_cast<uint4*>(d + w) = *reinterpret_cast<const uint4*>(shared + c * FP_WORDS + w);
+    }
+    pst[(size_t)k * n + i] = shared[2 * FP_WORDS] ? PST_INF : 0;
+}
+
 int launch_prep(Work& w, size_t n, const Operand* ops, int nops, uint32_t flags, const uint8_t* dst, size_t dst_len,
                 hipStream_t st) {
     if (nops < 1 || nops > MAX_OPERANDS || dst_len > 255 || (dst_len && !dst)) {
@@ -106,11 +150,19 @@ int launch_prep(Work& w, size_t n, const Operand* ops, int nops, uint32_t flags,
     a.n = n;
     a.in = w.in;
     a.pst = w.pst;
+    a.shared = w.shared;
     a.flags = flags;
     if (dst_len) memcpy(a.dst.b, dst, dst_len);
     a.dst.len = (uint32_t)dst_len;
     const size_t nblk = (n + 63) / 64;
-    hipLaunchKernelGGL(bls12381_operand_kernel, dim3((unsigned)(nblk * nops)), dim3(64), 0, st, a);
+    int shared_k = -1;
+    for (int k = 0; k < nops; k++)
+        if (ops[k].kind == OPND_G1_SHARED_HASH) shared_k = k;
+    a.has_shared = shared_k >= 0 ? 1 : 0;
+    hipLaunchKernelGGL(bls12381_operand_kernel, dim3((unsigned)(nblk * nops + (shared_k >= 0 ? 1 : 0))), dim3(64), 0, st, a);
+    if (shared_k >= 0)
+        hipLaunchKernelGGL(bls12381_shared_operand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, (const uint32_t*)w.shared,
+                           w.in, w.pst, ops[shared_k].first, shared_k);
     KYB_HIP_CHECK(hipGetLastError());
     return KYB_OK;
 }

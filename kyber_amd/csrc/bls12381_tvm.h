@@ -14,7 +14,11 @@ constexpr int CHECK_INPUTS = 12;      // pair A, then pair B with P_B already ne
 // in a single lane (65 536 pairings are only one wave per SIMD; four operands are four).
 // OPND_STATUS: an operand every lane shares (the one public key of a same-key verification): no coordinates, its status
 // byte -- src[0], on the device -- is copied to every pairing
-enum OperandKind : uint32_t { OPND_G1 = 0, OPND_G2 = 1, OPND_G1_HASH = 2, OPND_G2_HASH = 3, OPND_G1_GEN = 4, OPND_G2_GEN = 5, OPND_STATUS = 6 };
+// OPND_G1_SHARED_HASH: ONE message for the whole batch (sign/tbls/tbls.go:118-131: every partial signature is over the same
+// msg): src = the message, stride = its length.  One extra workgroup of the operand kernel hashes it once into
+// Work::shared while the other operands decode; launch_prep's second kernel deals the point to every pairing.
+enum OperandKind : uint32_t { OPND_G1 = 0, OPND_G2 = 1, OPND_G1_HASH = 2, OPND_G2_HASH = 3, OPND_G1_GEN = 4, OPND_G2_GEN = 5, OPND_STATUS = 6,
+                              OPND_G1_SHARED_HASH = 7 };
 struct Operand {
     const uint8_t* src;  // wire encodings (messages for the hash kinds; unused for the generators)
     uint32_t kind;
@@ -33,6 +37,7 @@ struct Work {
     uint32_t* in;
     uint8_t* pst;
     uint32_t* gspill;
+    uint32_t* shared;  // 256 bytes: the affine coordinates (2 x FP_WORDS) of an operand every pairing shares
     unsigned grid;
     uint32_t g2_member;  // set by launch_prep: bit k = operand k is a G2 point decoded WITHOUT its r-torsion test, which
                          // the machine's program decides at the end of the Miller loop (tvm::Args::g2_member)

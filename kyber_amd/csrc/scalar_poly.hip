@@ -51,6 +51,10 @@ static int run_host(const Mod& m, size_t n, const uint32_t* idx, size_t t, const
         return KYB_E_ARG;
     }
     if (!n) return KYB_OK;
+    if (n >= (size_t(1) << 28) || t >= (size_t(1) << 28)) {  // before any staging allocation: n * 32 and t * 32 below are then exact
+        set_error("scalar_poly_eval: n or t too large");
+        return KYB_E_ARG;
+    }
     DeviceCtx* ctx;
     if (int rc = get_ctx(&ctx)) return rc;
     StageScope sc_(ctx);  // staging pool first, enqueue mutex second (context.h)

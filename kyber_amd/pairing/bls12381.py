@@ -159,8 +159,59 @@ def batch_verify_g1_same_key(pubkey, msgs, sigs, dst: bytes = DOMAIN_G1, flags: 
         return ok, st
     check(lib.kyb_bls12381_verify_g1_same_key(n, kb, mb.ctypes.data, ln, dptr, len(dst), s.ctypes.data, ok.ctypes.data,
                                               st.ctypes.data, flags), "kyb_bls12381_verify_g1_same_key")
-    for i in bad_s:
-        ok[i], st[i] = 0, 1  # KYB_ST_BAD_POINT
+    for i in bad_s:  # precedence as the header documents it: the key's verdict first, then the signature's
+        ok[i] = 0
+        if st[i] == 0:
+            st[i] = 1  # KYB_ST_BAD_POINT
+    return ok, st
+
+
+def batch_verify_g1_same_msg(pubkeys, msg, sigs, dst: bytes = DOMAIN_G1, flags: int = 0):
+    """(ok, status): ok[i] = bls.Verify(pubkeys[i], msg, sigs[i]) for ONE message -- the verification loop of
+    tbls.Recover (sign/tbls/tbls.go:118-131: every partial signature signs the same msg under its own public share):
+    H(msg) is hashed once per call (kyb_bls12381_verify_g1_same_msg), the rest is batch_verify_g1.
+    msg: bytes, or a 1-D CUDA uint8 tensor when pubkeys / sigs are CUDA tensors."""
+    import ctypes
+
+    import numpy as np
+
+    from .._lib import check, load
+    from ._engine import F_UNCOMPRESSED, _host, _is_torch, _stream, pack_fixed
+
+    wk, wsig = (192, 96) if flags & F_UNCOMPRESSED else (96, 48)
+    lib = load()
+    dbuf = ctypes.create_string_buffer(bytes(dst), len(dst)) if dst else None
+    dptr = ctypes.cast(dbuf, ctypes.c_void_p) if dst else None
+    if _is_torch(pubkeys):
+        import torch
+
+        p, s = pubkeys.contiguous().view(-1, wk), sigs.contiguous().view(-1, wsig)
+        m = msg if _is_torch(msg) else torch.from_numpy(np.frombuffer(bytes(msg), dtype=np.uint8).copy())
+        m = m.to(p.device).contiguous().view(-1)
+        n, ln = p.shape[0], int(m.numel())
+        if s.shape[0] != n:
+            raise ValueError(f"batch_verify_same_msg: {n} public keys, {s.shape[0]} signatures")
+        if ln == 0:
+            m = torch.zeros(1, dtype=torch.uint8, device=p.device)
+        ok = torch.empty(n, dtype=torch.uint8, device=p.device)
+        st = torch.empty(n, dtype=torch.uint8, device=p.device)
+        check(lib.kyb_bls12381_verify_g1_same_msg_dev(n, p.data_ptr(), m.data_ptr(), ln, dptr, len(dst), s.data_ptr(), ok.data_ptr(),
+                                                      st.data_ptr(), flags, _stream()), "kyb_bls12381_verify_g1_same_msg_dev")
+        return ok, st
+    mb = bytes(msg)
+    p, bad_p = pack_fixed(pubkeys, wk) if isinstance(pubkeys, (list, tuple)) else (_host(pubkeys, wk), [])
+    s, bad_s = pack_fixed(sigs, wsig) if isinstance(sigs, (list, tuple)) else (_host(sigs, wsig), [])
+    n = p.shape[0]
+    if s.shape[0] != n:
+        raise ValueError(f"batch_verify_same_msg: {n} public keys, {s.shape[0]} signatures")
+    ok = np.empty(n, dtype=np.uint8)
+    st = np.empty(n, dtype=np.uint8)
+    check(lib.kyb_bls12381_verify_g1_same_msg(n, p.ctypes.data, mb if mb else None, len(mb), dptr, len(dst), s.ctypes.data, ok.ctypes.data,
+                                              st.ctypes.data, flags), "kyb_bls12381_verify_g1_same_msg")
+    for i in bad_p + bad_s:  # a wrong-length key / signature fails alone (status 1 unless the native call already said more)
+        ok[i] = 0
+        if st[i] == 0:
+            st[i] = 1
     return ok, st
 
 

@@ -119,8 +119,15 @@ class PriPoly:
         return [PriShare(i, self.g.Scalar().UnmarshalBinary(bytes(row))) for i, row in zip(indices, out)]
 
     def Shares(self, n: int) -> list:  # poly.go:96-102
-        if n >= self.DEVICE_MIN and _engine_backed(self.g):
-            return self.EvalMany(range(n))
+        # the batch kernel is an accelerator of a host-only scalar computation: no device (or any HIP error) falls back
+        # to the reference's own loop, and an empty polynomial never reaches the device
+        if n >= self.DEVICE_MIN and self.coeffs and _engine_backed(self.g):
+            from .._lib import KyberHipError
+
+            try:
+                return self.EvalMany(range(n))
+            except (KyberHipError, OSError):
+                pass
         return [self.Eval(i) for i in range(n)]
 
     def Coefficients(self) -> list:  # poly.go:176-178

@@ -111,6 +111,15 @@ class _Bls12381SchemeOnG1(SchemeOnG1):
 
     SAME_KEY_MIN = 256
 
+    def batch_verify_same_msg(self, publics, msg: bytes, sigs, keys_validated: bool = False):
+        """Verify of many (key, signature) pairs over ONE message -- the loop of tbls.Recover (sign/tbls/tbls.go:118-131):
+        H(msg) once per call (kyb_bls12381_verify_g1_same_msg)."""
+        if not len(publics):
+            return np.zeros(0, dtype=bool)
+        flags = self.m.F_TRUSTED(0) if keys_validated else 0
+        ok, st = self.m.batch_verify_g1_same_msg(list(publics), bytes(msg), list(sigs), self.dst, flags)
+        return (np.asarray(ok) == 1) & (np.asarray(st) == 0)
+
     def batch_verify_same_key(self, public: bytes, msgs, sigs, key_validated: bool = False):
         """Verify for many messages of ONE signer (public: its key): what a drand client does with a chain of beacons."""
         return self.batch_verify([public] * len(msgs), msgs, sigs, key_validated)

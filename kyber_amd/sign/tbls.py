@@ -3,7 +3,7 @@
   Sign           tbls.go:72-86     uint16 big-endian share index || x_i * H(m)
   VerifyPartial  tbls.go:99-106    Verify(public.Eval(i).V, msg, sig)
   Recover        tbls.go:118-151   public.Eval(i) for every partial (ONE poly_eval launch), verify them (ONE
-                                   pairing-check launch), then share.RecoverCommit over the first t valid ones
+                                   launch; the one message hashed once where the suite has the entry point), then share.RecoverCommit over the first t valid ones
                                    (ONE MSM)
 """
 from __future__ import annotations
@@ -40,7 +40,14 @@ class Scheme:
                 continue
         keys = [s.V.MarshalBinary() for s in public.EvalMany([i for i, _ in cand])] if cand else []
         # the evaluated keys are the engine's own outputs: validated by construction
-        ok = self.bls.batch_verify(keys, [msg] * len(cand), [v for _, v in cand], keys_validated=True) if cand else []
+        # ONE message, a different public share per partial signature (tbls.go:118-131): schemes with a same-message
+        # entry point hash it once (BLS12-381: kyb_bls12381_verify_g1_same_msg), the others get the message repeated
+        if not cand:
+            ok = []
+        elif hasattr(self.bls, "batch_verify_same_msg"):
+            ok = self.bls.batch_verify_same_msg(keys, msg, [v for _, v in cand], keys_validated=True)
+        else:
+            ok = self.bls.batch_verify(keys, [msg] * len(cand), [v for _, v in cand], keys_validated=True)
         shares = []
         for (i, v), good in zip(cand, ok):
             if not good:
@@ -57,3 +64,11 @@ def NewThresholdSchemeOnG1_bn256() -> Scheme:
     from ..pairing import bn256
 
     return Scheme(bn256.NewSuite(), bls.NewSchemeOnG1_bn256())
+
+
+def NewThresholdSchemeOnG1_bls12381(dst: bytes | None = None) -> Scheme:
+    """sign/tbls over the BLS12-381 suite (signatures on G1, public sharing polynomial on G2): Recover verifies its
+    partial signatures through kyb_bls12381_verify_g1_same_msg (one message, one hash)."""
+    from ..pairing import bls12381
+
+    return Scheme(bls12381.NewSuite(), bls.NewSchemeOnG1_bls12381(dst))

@@ -255,3 +255,33 @@ def test_bn256_wrong_length_signature_fails_alone():
     assert list(sch.batch_verify(pubs, msgs, bad)) == [True, False, False, True, True, True]
     with pytest.raises(ValueError):
         sch.batch_verify(pubs, msgs, sigs[:-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("suite", ["bls12381", "bn256"])
+def test_g1_poly_eval_at_2p16_against_the_oracle(suite):
+    """kyb_<suite>_g1_poly_eval at n = 2^16 indices held DIRECTLY to the oracle (until now GPU vs GPU
+    plus host mirror vs oracle): commitments C_j = c_j G with known c_j, so lane i must hold (sum_j c_j (i + 1)^j mod r) G
+    -- big-integer Horner + the oracle's own scalar multiplication and encoding on first / last / strided lanes."""
+    import importlib
+
+    m = importlib.import_module("kyber_amd.pairing." + suite)
+    OR = importlib.import_module("oracle." + suite)
+    order = OR.R if suite == "bls12381" else OR.ORDER
+    enc = OR.g1_compress if suite == "bls12381" else OR.g1_marshal
+    rng = random.Random(91)
+    t, n = 5, 1 << 16
+    cs = [rng.randrange(order) for _ in range(t)]
+    commits = b"".join(enc(OR.g1_mul(c, OR.G1_GEN)) for c in cs)
+    idx = np.arange(n, dtype=np.uint32)
+    idx[-1] = (1 << 32) - 1  # the top of the index range on the last lane
+    out, st = m.ENGINE.poly_eval(1, commits, idx)
+    assert not st.any() and out.shape == (n, m.G1_LEN)
+    lanes = [0, 1, 2, n - 2, n - 1] + list(range(977, n - 2, n // 29))
+    assert len(lanes) >= 32
+    for lane in lanes:
+        x = int(idx[lane]) + 1
+        v = 0
+        for c in reversed(cs):
+            v = (v * x + c) % order
+        assert bytes(out[lane]) == enc(OR.g1_mul(v, OR.G1_GEN)), (suite, lane)
