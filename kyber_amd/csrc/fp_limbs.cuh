@@ -17,14 +17,42 @@
 
 namespace kyb {
 
+// -DKYB_LZ_AUDIT (host harness builds only): every element carries an upper bound of its value as a multiple of p,
+// every operation checks its precondition against it (products below R / p, subtrahends below the K p added in) and
+// records a failure -- the lazy bounds of the formulas in curve.cuh / jac_lazy.cuh are then TESTED on real runs
+// (tests/test_lazy_bounds.py), not only argued in comments.
+#ifdef KYB_LZ_AUDIT
+inline double& lz_audit_max_product() { static double v = 0; return v; }
+inline int& lz_audit_failures() { static int v = 0; return v; }
+#define KYB_LZ_K(x) x
+#else
+#define KYB_LZ_K(x)
+#endif
+
 template <class C>
 struct FpL {
     uint32_t l[C::N];
+#ifdef KYB_LZ_AUDIT
+    double k = 1.0;  // value < k p
+#endif
 };
+template <class C>
+constexpr double fpl_headroom() {  // R / p from below: 2^(N W) / ((top word of p + 1) 2^(32 (NWORDS - 1)))
+    double r = 1.0;
+    for (int i = 0; i < C::N * C::W - 32 * (C::NWORDS - 1); i++) r *= 2.0;
+    return r / ((double)C::PW[C::NWORDS - 1] + 1.0);
+}
+#ifdef KYB_LZ_AUDIT
+template <class C>
+inline void lz_check_product(double kk) {
+    if (kk > lz_audit_max_product()) lz_audit_max_product() = kk;
+    if (!(kk < fpl_headroom<C>())) lz_audit_failures()++;
+}
+#endif
 
 template <class C>
 constexpr bool fpl_supported() {
-    return C::N * C::W - C::PBITS >= 9 && C::W <= 30;
+    return C::N * C::W - C::PBITS >= 9 && C::W <= 30 && C::N * C::W >= 32 * C::NWORDS;
 }
 
 // limbs of K p (compile-time), normalised; K p < 2^(N W)
@@ -46,19 +74,32 @@ struct KTimesPL {
     static constexpr Arr value = make();
 };
 
-template <class C> KYB_HD void fpl_unpack(FpL<C>& r, const Fp<C>& a) { fp_unpack<C>(r.l, a.v); }
+template <class C> KYB_HD void fpl_unpack(FpL<C>& r, const Fp<C>& a) {
+    fp_unpack<C>(r.l, a.v);
+    KYB_LZ_K(r.k = 1.0;)
+}
 template <class C>
 KYB_HD void fpl_one(FpL<C>& r) {
     Fp<C> o;
     fp_one(o);
     fp_unpack<C>(r.l, o.v);  // constant-folded
+    KYB_LZ_K(r.k = 1.0;)
 }
-template <class C> KYB_HD void fpl_mul(FpL<C>& r, const FpL<C>& a, const FpL<C>& b) { fp_mul_limbs<C>(r.l, a.l, b.l); }
-template <class C> KYB_HD void fpl_sqr(FpL<C>& r, const FpL<C>& a) { fp_sqr_limbs<C>(r.l, a.l); }
+template <class C> KYB_HD void fpl_mul(FpL<C>& r, const FpL<C>& a, const FpL<C>& b) {
+    KYB_LZ_K(lz_check_product<C>(a.k * b.k);)
+    fp_mul_limbs<C>(r.l, a.l, b.l);
+    KYB_LZ_K(r.k = 2.0;)
+}
+template <class C> KYB_HD void fpl_sqr(FpL<C>& r, const FpL<C>& a) {
+    KYB_LZ_K(lz_check_product<C>(a.k * a.k);)
+    fp_sqr_limbs<C>(r.l, a.l);
+    KYB_LZ_K(r.k = 2.0;)
+}
 // value below 2p -> packed, fully reduced
 template <class C>
 KYB_HD void fpl_finish(Fp<C>& r, const FpL<C>& a) {
     uint32_t s[C::N];
+    KYB_LZ_K(if (a.k > 2.0) lz_audit_failures()++;)
 #pragma unroll
     for (int j = 0; j < C::N; j++) s[j] = a.l[j];
     fp_finish<C>(r, s);
@@ -68,6 +109,7 @@ KYB_HD void fpl_finish(Fp<C>& r, const FpL<C>& a) {
 template <int K, class C>
 KYB_HD void fpl_sub(FpL<C>& r, const FpL<C>& a, const FpL<C>& b) {
     constexpr uint32_t MASK = (1u << C::W) - 1;
+    KYB_LZ_K(if (b.k > K) lz_audit_failures()++; const double rk = a.k + K;)
     int32_t carry = 0;
 #pragma unroll
     for (int j = 0; j < C::N; j++) {
@@ -75,12 +117,14 @@ KYB_HD void fpl_sub(FpL<C>& r, const FpL<C>& a, const FpL<C>& b) {
         r.l[j] = j + 1 < C::N ? ((uint32_t)t & MASK) : (uint32_t)t;
         carry = t >> C::W;
     }
+    KYB_LZ_K(r.k = rk;)
 }
 // r = (neg ? -a : a) - b + K p  (a + b below K p)
 template <int K, class C>
 KYB_HD void fpl_sub_signed(FpL<C>& r, const FpL<C>& a, bool neg, const FpL<C>& b) {
     constexpr uint32_t MASK = (1u << C::W) - 1;
     const uint32_t m = neg ? ~0u : 0u;
+    KYB_LZ_K(if (a.k + b.k > K) lz_audit_failures()++; const double rk = a.k + K;)
     int32_t carry = 0;
 #pragma unroll
     for (int j = 0; j < C::N; j++) {
@@ -89,11 +133,13 @@ KYB_HD void fpl_sub_signed(FpL<C>& r, const FpL<C>& a, bool neg, const FpL<C>& b
         r.l[j] = j + 1 < C::N ? ((uint32_t)t & MASK) : (uint32_t)t;
         carry = t >> C::W;
     }
+    KYB_LZ_K(r.k = rk;)
 }
 // r = a + 2 b, normalised (one unsigned sweep)
 template <class C>
 KYB_HD void fpl_add_2x(FpL<C>& r, const FpL<C>& a, const FpL<C>& b) {
     constexpr uint32_t MASK = (1u << C::W) - 1;
+    KYB_LZ_K(const double rk = a.k + 2 * b.k;)
     uint32_t carry = 0;
 #pragma unroll
     for (int j = 0; j < C::N; j++) {
@@ -101,6 +147,36 @@ KYB_HD void fpl_add_2x(FpL<C>& r, const FpL<C>& a, const FpL<C>& b) {
         r.l[j] = j + 1 < C::N ? (t & MASK) : t;
         carry = t >> C::W;
     }
+    KYB_LZ_K(r.k = rk;)
+}
+// r = a + b, normalised
+template <class C>
+KYB_HD void fpl_add(FpL<C>& r, const FpL<C>& a, const FpL<C>& b) {
+    constexpr uint32_t MASK = (1u << C::W) - 1;
+    KYB_LZ_K(const double rk = a.k + b.k;)
+    uint32_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < C::N; j++) {
+        const uint32_t t = a.l[j] + b.l[j] + carry;
+        r.l[j] = j + 1 < C::N ? (t & MASK) : t;
+        carry = t >> C::W;
+    }
+    KYB_LZ_K(r.k = rk;)
+}
+// r = 4 a, normalised (limbs below 2^30: 4 a_j + carry stays below 2^32)
+template <class C>
+KYB_HD void fpl_mul4(FpL<C>& r, const FpL<C>& a) {
+    static_assert(C::W <= 30, "4 a_j + carry must fit 32 bits");
+    constexpr uint32_t MASK = (1u << C::W) - 1;
+    KYB_LZ_K(const double rk = 4 * a.k;)
+    uint32_t carry = 0;
+#pragma unroll
+    for (int j = 0; j < C::N; j++) {
+        const uint32_t t = (a.l[j] << 2) + carry;
+        r.l[j] = j + 1 < C::N ? (t & MASK) : t;
+        carry = t >> C::W;
+    }
+    KYB_LZ_K(r.k = rk;)
 }
 
 // s = (a b + c d) R^-1 mod p with ONE reduction: the two products share their columns (3 N^2 multiply-adds instead of
@@ -112,6 +188,7 @@ KYB_HD void fpl_mul2sum(FpL<C>& r, const FpL<C>& a, const FpL<C>& b, const FpL<C
     constexpr int MAXP = (int)((~0ull) / ((uint64_t)MASK * MASK)) - 1;
     static_assert(MAXP >= 6, "limb width too large for lazy column accumulation");
     uint64_t t[N];
+    KYB_LZ_K(lz_check_product<C>(a.k * b.k + c.k * d.k);)
 #pragma unroll
     for (int j = 0; j < N; j++) t[j] = 0;
     int pending = 0;
@@ -146,6 +223,7 @@ KYB_HD void fpl_mul2sum(FpL<C>& r, const FpL<C>& a, const FpL<C>& b, const FpL<C
         r.l[j] = (uint32_t)t[j] & MASK;
     }
     r.l[N - 1] = (uint32_t)t[N - 1];
+    KYB_LZ_K(r.k = 2.0;)
 }
 
 // a == 0 (mod p) for a lazy value below (KMAX + 1) p, exactly.  a = k p forces limb 0 to be k p_0 mod 2^W, so
@@ -155,6 +233,7 @@ template <int KMAX, class C>
 KYB_HD bool fpl_is_zero_mod_p(const FpL<C>& a) {
     constexpr uint32_t MASK = (1u << C::W) - 1;
     constexpr uint32_t PINV0 = (0u - C::NINV) & MASK;  // p_0^-1 mod 2^W  (NINV = -p^-1)
+    KYB_LZ_K(if (a.k > KMAX + 1) lz_audit_failures()++;)
     const uint32_t k = (a.l[0] * PINV0) & MASK;
     if (k > (uint32_t)KMAX) return false;
     uint64_t c = 0;

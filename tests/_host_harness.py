@@ -41,12 +41,13 @@ _lib_audit = None
 
 def lib_audit():
     """The same harness built with -DKYB_FE_AUDIT: Ed25519 field elements carry a magnitude bound that every
-    multiplication checks in with (fe25519.cuh).  Rebuilt on every first use (a few seconds)."""
+    multiplication checks in with (fe25519.cuh), and -DKYB_LZ_AUDIT: the lazy limb elements of fp_limbs.cuh
+    carry their bound as a multiple of p and every product / subtraction checks its precondition.  Rebuilt on every first use (a few seconds)."""
     global _lib_audit
     if _lib_audit is None:
         out = OUT.replace("libhostharness.so", "libhostharness_audit.so")
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-DKYB_FE_AUDIT", "-shared", "-fPIC", "-o", out, SRC])
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-DKYB_FE_AUDIT", "-DKYB_LZ_AUDIT", "-shared", "-fPIC", "-o", out, SRC])
         _lib_audit = C.CDLL(out)
     return _lib_audit
 

@@ -521,6 +521,32 @@ int hh_ed_mul_madd(const uint8_t* k32, const uint8_t* p32, uint8_t* out32) {
 #if defined(KYB_FE_AUDIT)
 // bound audit build (tests/_host_harness.py lib_audit): the largest mag_f * mag_g met by a multiplication, scaled by
 // 10^6 (the call interface returns ints), and a reset
+// lazy-limb audit (fp_limbs.cuh KYB_LZ_AUDIT): failures so far / the largest product bound met, as a fraction (in
+// 1e-6) of the field's R / p it must stay below -- the reset returns the failures and clears both
+int hh_lz_audit_failures() {
+#ifdef KYB_LZ_AUDIT
+    return lz_audit_failures();
+#else
+    return -1;
+#endif
+}
+int hh_lz_audit_max_product() {
+#ifdef KYB_LZ_AUDIT
+    return (int)lz_audit_max_product();
+#else
+    return -1;
+#endif
+}
+int hh_lz_audit_reset() {
+#ifdef KYB_LZ_AUDIT
+    const int f = lz_audit_failures();
+    lz_audit_failures() = 0;
+    lz_audit_max_product() = 0;
+    return f;
+#else
+    return -1;
+#endif
+}
 int hh_fe_audit_max_micro() { return (int)(fe_audit_max() * 1e6); }
 int hh_fe_audit_max19_micro() { return (int)(fe_audit_max19() * 1e6); }
 int hh_fe_audit_reset() {

@@ -1,0 +1,58 @@
+"""The lazy bounds of the limb-form formulas (fp_limbs.cuh; curve.cuh XyzzL, jac_lazy.cuh) checked on real runs: the host
+harness built with -DKYB_LZ_AUDIT makes every lazy element carry an upper bound of its value as a multiple of p; every
+multiplication checks that the product of its operands' bounds (the sum of both products for a two-product
+multiplication) stays below R / p, every subtraction that its subtrahend is below the multiple of p it adds, every
+exact-zero test that its operand is inside the range it searches.  One failure anywhere is an error here."""
+import ctypes as C
+import random
+
+from oracle import bls12381 as OB, bn254 as ON4, bn256 as ON
+from tests import _host_harness as H
+
+
+def _reset(lib):
+    lib.hh_lz_audit_reset()
+
+
+def test_bn_ladders_stay_inside_their_bounds():
+    lib = H.lib_audit()
+    assert lib.hh_lz_audit_failures() >= 0, "audit build expected"
+    rng = random.Random(7)
+    for name, O, g1fn, g2fn, enc1, enc2, head in (
+            ("bn256", ON, "hh_bn_g1_mul", "hh_bn_g2_mul_f", ON.g1_marshal, ON.g2_marshal, 29186),
+            ("bn254", ON4, "hh_bn4_g1_mul", "hh_bn4_g2_mul", ON4.g1_marshal, ON4.g2_marshal, 86000)):
+        _reset(lib)
+        ks = [0, 1, 2, O.ORDER - 1, O.ORDER, (1 << 256) - 1, 15, 16, 0x8888888888888888] + [rng.randrange(1 << 256) for _ in range(12)]
+        h1, h2 = rng.randrange(1, O.ORDER), rng.randrange(1, O.ORDER)
+        P, Q = O.g1_mul(h1, O.G1_GEN), O.g2_mul(h2, O.G2_GEN)
+        for k in ks:
+            kb = k.to_bytes(32, "big")
+            out = C.create_string_buffer(64)
+            assert getattr(lib, g1fn)(kb, enc1(P), out) == 0
+            assert out.raw == enc1(O.g1_mul(k % O.ORDER, P)), (name, "g1", hex(k))
+            out = C.create_string_buffer(128)
+            assert getattr(lib, g2fn)(kb, enc2(Q), C.c_int(0x100), out) == 0  # vouched for: the GLS walk
+            assert out.raw == enc2(O.g2_mul(k % O.ORDER, Q)), (name, "g2", hex(k))
+        # flags = 0: the membership relation first ([u] Q on lazy limbs), then the same walk
+        out = C.create_string_buffer(128)
+        assert getattr(lib, g2fn)(ks[-1].to_bytes(32, "big"), enc2(Q), C.c_int(0), out) == 0
+        assert out.raw == enc2(O.g2_mul(ks[-1] % O.ORDER, Q)), (name, "g2 flags = 0")
+        assert lib.hh_lz_audit_failures() == 0, name
+        assert 0 < lib.hh_lz_audit_max_product() < head, (name, lib.hh_lz_audit_max_product())
+
+
+def test_bls12381_limb_form_piece_accumulator_stays_inside_its_bounds():
+    lib = H.lib_audit()
+    _reset(lib)
+    rng = random.Random(9)
+    base = [OB.g1_mul(rng.randrange(1, OB.R), OB.G1_GEN) for _ in range(12)]
+    run = [(rng.choice(base), rng.random() < 0.5) for _ in range(80)] + [(base[0], False)] * 3 + [(base[0], True)] * 2
+    exp = None
+    for pt, s in run:
+        exp = OB.g1_add(exp, OB.g1_neg(pt) if s else pt)
+    out = C.create_string_buffer(48)
+    top = C.c_int(0)
+    bad = lib.hh_bls_g1_xyzzl_sum(len(run), b"".join(OB.g1_compress(pt) for pt, _ in run), bytes(int(s) for _, s in run), out, C.byref(top))
+    assert bad == 0 and out.raw == OB.g1_compress(exp)
+    assert lib.hh_lz_audit_failures() == 0
+    assert 0 < lib.hh_lz_audit_max_product() <= 100  # P^2 with P < 10p: the largest product of the formula
