@@ -162,3 +162,58 @@ def test_empty_batch_single_element_and_empty_messages(bls):
     assert list(ok) == [1, 0, 1] and not st.any()
     ok2, st2 = bls.batch_verify_g1([X] * 3, [b"", b"", b""], [e, s, e])
     assert list(ok2) == list(ok) and list(st2) == list(st)
+
+
+def test_alternating_between_a_handful_of_keys_costs_a_copy_not_a_walk(bls):
+    """A verifier over a small committee (sign/bls/bls.go:82-96 called with three different keys in turn): since round 5
+    the last eight keys' line tables are kept per stream, so after each key has been seen once a switch costs a 17 KB copy
+    instead of the 9 ms walk of the key through the Miller loop.  Verdicts must not depend on the order the keys were
+    seen in; every later call is held to 1.2 x the steady-state time of a single key."""
+    import torch
+
+    n = 1 << 12
+    msgs = torch.from_numpy(_scalars(b"committee/msgs", n)).cuda()
+    Hm, _ = bls.batch_hash_g1(msgs)
+    keys, sigs = [], []
+    for j in range(3):
+        x = torch.from_numpy(_scalars(b"committee/x/%d" % j, 1)).cuda()
+        keys.append(bls.g2_commit(x)[0][0].contiguous())
+        sigs.append(bls.g1_batch_mul(x.repeat(n, 1), Hm)[0])
+    sigs[1] = sigs[1].clone()
+    sigs[1][5] = sigs[1][6]  # one forged signature under the second key
+
+    def timed(fn, reps):
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return r, ts
+
+    for j in range(3):  # first sight of every key: the walk
+        ok, st = bls.batch_verify_g1_same_key(keys[j], msgs, sigs[j])
+        assert not st.any().item() and int(ok.sum().item()) == (n - 1 if j == 1 else n)
+    _, steady = timed(lambda: bls.batch_verify_g1_same_key(keys[0], msgs, sigs[0]), 7)
+    steady_ms = sorted(steady)[len(steady) // 2]
+    seq = [1, 2, 0, 2, 1, 0, 1, 2]
+    worst = 0.0
+    for j in seq:
+        (ok, st), ts = timed(lambda: bls.batch_verify_g1_same_key(keys[j], msgs, sigs[j]), 1)
+        assert not st.any().item() and int(ok.sum().item()) == (n - 1 if j == 1 else n)
+        assert (ok[5].item() == 0) == (j == 1)
+        worst = max(worst, ts[0])
+    assert worst <= 1.2 * steady_ms + 0.3, (worst, steady_ms)  # + 0.3 ms: launch jitter of a 7 ms call
+    # a key signatures do not belong to, between two cached ones: still rejected
+    ok, _ = bls.batch_verify_g1_same_key(keys[2], msgs, sigs[0])
+    assert not ok.any().item()
+    # more distinct keys than slots: the oldest is rebuilt, nothing goes stale
+    for j in range(10):
+        x = torch.from_numpy(_scalars(b"committee/y/%d" % j, 1)).cuda()
+        X = bls.g2_commit(x)[0][0].contiguous()
+        ok, st = bls.batch_verify_g1_same_key(X, msgs[:64].contiguous(), bls.g1_batch_mul(x.repeat(64, 1), Hm[:64].contiguous())[0])
+        assert ok.all().item() and not st.any().item()
+    ok, st = bls.batch_verify_g1_same_key(keys[1], msgs, sigs[1])
+    assert int(ok.sum().item()) == n - 1 and not st.any().item()
