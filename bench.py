@@ -324,10 +324,13 @@ MADS_BN_G2_MEMBER = 63 * _BN_DBL2 + 22 * _BN_MADD2 + 2 * _BN_ADD2 + _BN_DBL2 + 6
 # Pippenger on BLS12-381 G1 at 2^20 points (msm.cuh): 2n half-scalars x 8 windows of 16 bits, one mixed addition per
 # (point, window) -- XYZZ form since round 3, 8M + 2S (3 224 multiply-adds; madd-2007-bl, 7M + 4S = 3 406, until then:
 # the numerator FELL with the change) -- + the running-sum reduction of 8 x 2^15 buckets (2 full additions each, 11M + 5S)
-MADS_MSM_BLS_G1_2P20_PER_POINT = 2 * 8 * (8 * _M + 2 * _S) + (8 * (1 << 15) * 2 * (11 * _M + 5 * _S)) / (1 << 20)
-# share.PriPoly.Commit through the fixed-base table (fixed_base.cuh): 26 XYZZ additions (8M + 2S), leaving the form
+# Round 5: the addition runs in limb form with Y3 = R (Q - X3) - Y1 PPP as ONE two-product multiplication (3 x 169
+# multiply-adds instead of 2 x 338): 6M + 2S + 507 = 3 055 -- the numerator fell again with the change.
+_XYZZ_MADD = 6 * _M + 2 * _S + 3 * 169
+MADS_MSM_BLS_G1_2P20_PER_POINT = 2 * 8 * _XYZZ_MADD + (8 * (1 << 15) * 2 * (11 * _M + 5 * _S)) / (1 << 20)
+# share.PriPoly.Commit through the fixed-base table (fixed_base.cuh): 26 XYZZ additions (limb form, as above), leaving the form
 # (2M), to affine (1S + 3M; the division-step inversion is ~25 batches of ~130 multiply-adds)
-MADS_G1_COMMIT = 26 * (8 * _M + 2 * _S) + 5 * _M + _S + 25 * 130
+MADS_G1_COMMIT = 26 * _XYZZ_MADD + 5 * _M + _S + 25 * 130
 # the best known count for the BLS12-381 pairing on this limb arithmetic: the Karatsuba tower of round 1 (5.4e6 per
 # Pair) against the machine's schoolbook-with-lazy-reduction program; checks / verifies scaled alike
 BLS_PAIR_BEST_KNOWN = 5.4e6
@@ -477,7 +480,15 @@ def other_workloads(rank, world, dist):
                 out[name]["bls_verify_same_key_per_s"] = world * npair / ms_v1 * 1e3
                 out[name]["bls_verify_same_key_all_true"] = bool(ok1.all().item()) and not bool(st1.any().item())
                 out[name]["roofline"]["verify_same_key"] = _roof(npair / ms_v1 * 1e3, mads["verifyk"], g1b_ + 32 + 1, prof, name + "_verifyk")
-                del Hm, sig1
+                # ONE message for the whole batch, a key per signature (tbls.Recover, sign/tbls/tbls.go:118-131): H(m)
+                # hashed once per call; signatures k_i H(m) under the keys k_i G2 of this block
+                m0 = msgs[0].contiguous()
+                sigm, _ = m.g1_batch_mul(k, Hm[:1].repeat(npair, 1))
+                okm, stm = m.batch_verify_g1_same_msg(Q, m0, sigm)
+                ms_vm, = max_over_ranks(dist, [timed(lambda: m.batch_verify_g1_same_msg(Q, m0, sigm))])
+                out[name]["bls_verify_same_msg_per_s"] = world * npair / ms_vm * 1e3
+                out[name]["bls_verify_same_msg_all_true"] = bool(okm.all().item()) and not bool(stm.any().item())
+                del Hm, sig1, sigm
         if name == "bls12381":
             # node-wide MSM at 2^20 points: points sharded over the ranks, all-gather of the partial points
             n = 1 << 20
@@ -597,6 +608,7 @@ def compact_line(res: dict) -> dict:
             "bls12381_pair_checks_per_s": (b.get("pairing_checks_per_s"), _g(b, "roofline", "pair_check", "frac")),
             "bls12381_verifies_per_s": (b.get("bls_verify_pipeline_per_s"), _g(b, "roofline", "verify", "frac")),
             "bls12381_verifies_per_s_same_key": (b.get("bls_verify_same_key_per_s"), _g(b, "roofline", "verify_same_key", "frac")),
+            "bls12381_verifies_per_s_same_msg": (b.get("bls_verify_same_msg_per_s"), None),
             "bls12381_g1_muls_per_s": (b.get("g1_muls_per_s"), _g(b, "roofline", "g1_mul", "frac")),
             "bls12381_g2_muls_per_s": (b.get("g2_muls_per_s"), _g(b, "roofline", "g2_mul", "frac")),
             # configs[2] at SURVEY 8d's 80 B per point (32-byte scalar + 48-byte compressed point, validated when it

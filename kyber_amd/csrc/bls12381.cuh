@@ -10,6 +10,7 @@
 #pragma once
 #include "bls12381_params.h"
 #include "curve.cuh"
+#include "jac_lazy.cuh"
 
 namespace kyb {
 namespace bls {
@@ -48,9 +49,21 @@ KYB_HD bool fp2_is_larger(const fp2& y) {
 // G1: P has order r  <=>  phi(P) = [-x^2] P, phi(x, y) = (beta x, y)   (Scott, eprint 2021/1130)
 KYB_HD_NOINLINE bool g1_in_subgroup(const g1_aff& a) {
     g1_jac p, q;
+#ifdef KYB_BLS_PACKED_LADDER
     jac_from_aff(p, a);
     jac_mul_u64(q, p, CC::X_ABS);
     jac_mul_u64(q, q, CC::X_ABS);  // x^2 P
+#else
+    // both 64-bit multiplications on lazy limbs (jac_lazy.cuh: doublings and MIXED additions only, so [x] P returns to
+    // affine form in between -- one division-step inversion, a twelfth of the chain it feeds)
+    {
+        using LF = LzFp<Limb30<FC>>;
+        g1_aff a1;
+        jaclz_mul_u64_aff<LF>(p, a, CC::X_ABS);
+        jac_to_aff(a1, p);
+        jaclz_mul_u64_aff<LF>(q, a1, CC::X_ABS);  // x^2 P (infinity when [x] P was: Z = 0 fails the comparison below)
+    }
+#endif
     fp beta, bx, ny, z2, z3, l, r;
     fp_const(beta, CC::BETA);
     fp_mul(bx, a.x, beta);
@@ -525,6 +538,56 @@ KYB_HD_NOINLINE void g1_mul_glv(g1_jac& r, const g1_jac& p, const uint32_t (&k)[
     for (int i = 33; i >= 0; i--) g1_glv_step(acc, tab, e0[i], e1[i], beta, i != 33);
     r = acc;
 }
+// The same walk on lazy 30-bit limbs (jac_lazy.cuh; fourteen limbs for the 381-bit prime: R' / p = 2^39): the window
+// table is built by the packed code, its entries and their beta x images enter the limb form once, and the 136
+// doublings + up to 68 mixed additions run inlined with no reduction between products and nothing but the table and
+// the digits in private memory.  (Inlined into its caller for the reason given at bn_suite.inc g1_mul_glv_lz.)
+KYB_HD void g1_mul_glv_lz(g1_jac& r, const g1_jac& p, const uint32_t (&k)[8]) {
+    using LF = LzFp<Limb30<FC>>;
+    uint32_t q[8], rem[4];
+    divmod_z<4>(q, rem, k);
+    int8_t e0[65], e1[65];
+    glv_digits(e0, rem, 4);
+    glv_digits(e1, q, 5);
+    g1_jac tab[8];  // (j + 1) * P
+    tab[0] = p;
+    jac_dbl(tab[1], p);
+#pragma unroll 1
+    for (int j = 2; j < 8; j++) jac_add(tab[j], tab[j - 1], p);
+    jac_table8_to_affine(tab);
+    typename LF::E tx[2][8], ty[8], beta;
+    uint32_t infmask = 0;
+    {
+        fp b;
+        fp_const(b, CC::BETA);
+        LF::enter(beta, b);
+    }
+#pragma unroll 1
+    for (int j = 0; j < 8; j++) {
+        infmask |= (fp_is_zero(tab[j].Z) ? 1u : 0u) << j;
+        LF::enter(tx[0][j], tab[j].X);
+        LF::enter(ty[j], tab[j].Y);
+        LF::template mul<2>(tx[1][j], tx[0][j], beta);
+    }
+    JacLz<LF> acc;
+    jaclz_set_inf(acc);
+#pragma unroll 1
+    for (int i = 33; i >= 0; i--) {
+        if (i != 33) {
+#pragma unroll 1
+            for (int d = 0; d < 4; d++) jaclz_dbl(acc);
+        }
+#pragma unroll 1
+        for (int h = 0; h < 2; h++) {
+            const int d = h == 0 ? e0[i] : e1[i];
+            if (d == 0) continue;
+            const int idx = (d < 0 ? -d : d) - 1;
+            if ((infmask >> idx) & 1u) continue;
+            jaclz_madd(acc, tx[h][idx], ty[idx], (d < 0) != (h == 1));  // z^2 P = (beta x, -y)
+        }
+    }
+    jaclz_leave(r, acc);
+}
 // r = k * Q for Q in G2: k = a0 + a1 |z| + a2 |z|^2 + a3 |z|^3 and |z| Q = -psi(Q), so
 // k Q = a0 Q - a1 psi(Q) + a2 psi^2(Q) - a3 psi^3(Q); 18 windows of (4 doublings + 4 additions).
 // psi(x, y) = (cx conj x, cy conj y) on the affine table entries; psi^2 scales x, y by the norms of cx, cy.
@@ -609,7 +672,11 @@ KYB_HD int g1_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt
     scalar_from_be(k, scalar_be);
     g1_jac p, r;
     jac_from_aff(p, a);
+#ifdef KYB_BLS_PACKED_LADDER
     g1_mul_glv(r, p, k);
+#else
+    g1_mul_glv_lz(r, p, k);
+#endif
     jac_to_aff(a, r);
     g1_encode_f(out, a, flags);
     return ST_OK;

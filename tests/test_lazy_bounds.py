@@ -56,3 +56,16 @@ def test_bls12381_limb_form_piece_accumulator_stays_inside_its_bounds():
     assert bad == 0 and out.raw == OB.g1_compress(exp)
     assert lib.hh_lz_audit_failures() == 0
     assert 0 < lib.hh_lz_audit_max_product() <= 100  # P^2 with P < 10p: the largest product of the formula
+
+
+def test_bls12381_g1_ladder_on_lazy_limbs_stays_inside_its_bounds():
+    lib = H.lib_audit()
+    _reset(lib)
+    rng = random.Random(11)
+    P = OB.g1_mul(rng.randrange(1, OB.R), OB.G1_GEN)
+    for k in [0, 1, OB.R - 1, OB.R, (1 << 256) - 1] + [rng.randrange(1 << 256) for _ in range(8)]:
+        out = C.create_string_buffer(48)
+        assert lib.hh_bls_g1_mul(k.to_bytes(32, "big"), OB.g1_compress(P), out) == 0
+        assert out.raw == OB.g1_compress(OB.g1_mul(k % OB.R, P)), hex(k)
+    assert lib.hh_lz_audit_failures() == 0
+    assert 0 < lib.hh_lz_audit_max_product() < 1 << 20  # R' / p = 2^39 for the fourteen-limb form
