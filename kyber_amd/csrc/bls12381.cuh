@@ -57,11 +57,11 @@ KYB_HD_NOINLINE bool g1_in_subgroup(const g1_aff& a) {
     // both 64-bit multiplications on lazy limbs (jac_lazy.cuh: doublings and MIXED additions only, so [x] P returns to
     // affine form in between -- one division-step inversion, a twelfth of the chain it feeds)
     {
-        using LF = LzFp<Limb30<FC>>;
+        using LF = LzFpN<FC>;
         g1_aff a1;
-        jaclz_mul_u64_aff<LF>(p, a, CC::X_ABS);
+        jaclz_mul_u64_aff_t<LF>(p, a, CC::X_ABS);
         jac_to_aff(a1, p);
-        jaclz_mul_u64_aff<LF>(q, a1, CC::X_ABS);  // x^2 P (infinity when [x] P was: Z = 0 fails the comparison below)
+        jaclz_mul_u64_aff_t<LF>(q, a1, CC::X_ABS);  // x^2 P (infinity when [x] P was: Z = 0 fails the comparison below)
     }
 #endif
     fp beta, bx, ny, z2, z3, l, r;
@@ -538,12 +538,13 @@ KYB_HD_NOINLINE void g1_mul_glv(g1_jac& r, const g1_jac& p, const uint32_t (&k)[
     for (int i = 33; i >= 0; i--) g1_glv_step(acc, tab, e0[i], e1[i], beta, i != 33);
     r = acc;
 }
-// The same walk on lazy 30-bit limbs (jac_lazy.cuh; fourteen limbs for the 381-bit prime: R' / p = 2^39): the window
-// table is built by the packed code, its entries and their beta x images enter the limb form once, and the 136
-// doublings + up to 68 mixed additions run inlined with no reduction between products and nothing but the table and
-// the digits in private memory.  (Inlined into its caller for the reason given at bn_suite.inc g1_mul_glv_lz.)
+// The same walk on lazy limbs (jac_lazy.cuh) -- the field's own thirteen 30-bit limbs, R / p = 630: the formulas written for
+// that headroom (jaclz_dbl_t 3M + 4S, jaclz_madd_t 8M + 3S; a first version on fourteen limbs, R' / p = 2^39, paid 392
+// multiply-adds per product for the generic formulas).  The window table is built by the packed code, its entries and their
+// beta x images are unpacked once, and the 136 doublings + up to 68 mixed additions run inlined with no reduction
+// between products and nothing but the table and the digits in private memory.  (Inlined into its caller for the reason given at bn_suite.inc g1_mul_glv_lz.)
 KYB_HD void g1_mul_glv_lz(g1_jac& r, const g1_jac& p, const uint32_t (&k)[8]) {
-    using LF = LzFp<Limb30<FC>>;
+    using LF = LzFpN<FC>;
     uint32_t q[8], rem[4];
     divmod_z<4>(q, rem, k);
     int8_t e0[65], e1[65];
@@ -567,7 +568,7 @@ KYB_HD void g1_mul_glv_lz(g1_jac& r, const g1_jac& p, const uint32_t (&k)[8]) {
         infmask |= (fp_is_zero(tab[j].Z) ? 1u : 0u) << j;
         LF::enter(tx[0][j], tab[j].X);
         LF::enter(ty[j], tab[j].Y);
-        LF::template mul<2>(tx[1][j], tx[0][j], beta);
+        LF::mul(tx[1][j], tx[0][j], beta);
     }
     JacLz<LF> acc;
     jaclz_set_inf(acc);
@@ -575,7 +576,7 @@ KYB_HD void g1_mul_glv_lz(g1_jac& r, const g1_jac& p, const uint32_t (&k)[8]) {
     for (int i = 33; i >= 0; i--) {
         if (i != 33) {
 #pragma unroll 1
-            for (int d = 0; d < 4; d++) jaclz_dbl(acc);
+            for (int d = 0; d < 4; d++) jaclz_dbl_t(acc);
         }
 #pragma unroll 1
         for (int h = 0; h < 2; h++) {
@@ -583,7 +584,7 @@ KYB_HD void g1_mul_glv_lz(g1_jac& r, const g1_jac& p, const uint32_t (&k)[8]) {
             if (d == 0) continue;
             const int idx = (d < 0 ? -d : d) - 1;
             if ((infmask >> idx) & 1u) continue;
-            jaclz_madd(acc, tx[h][idx], ty[idx], (d < 0) != (h == 1));  // z^2 P = (beta x, -y)
+            jaclz_madd_t(acc, tx[h][idx], ty[idx], (d < 0) != (h == 1));  // z^2 P = (beta x, -y)
         }
     }
     jaclz_leave(r, acc);

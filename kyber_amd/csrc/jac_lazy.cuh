@@ -409,6 +409,153 @@ KYB_HD void jaclz_mul_u64_aff(Jac<F>& r, const Aff<F>& p, uint64_t k) {
     jaclz_leave(r, acc);
 }
 
+// ---- the same two operations for a field's NATIVE limbs when they leave only R / p >= 2^9 of headroom (BLS12-381 Fp:
+// thirteen 30-bit limbs, R / p = 630) -- no conversion into another Montgomery domain, 338 multiply-adds per product
+// instead of the fourteen-limb form's 392.  The formulas above square sums (X + Y^2)^2, (Z + H)^2, r^2 whose operands
+// reach 56p - 76p; here those three become products of small operands (4 X Y^2 = 4 X B, Z3 = 2 Z H, r^2 = 4 rr^2):
+// a doubling is 3M + 4S, a mixed addition 8M + 3S (one of them two-product), every product below 400 < R / p.
+// Between operations X < 18, Y < 18, Z < 4.
+template <class C>
+struct LzFpN {
+    using E = FpL<C>;
+    using Packed = Fp<C>;
+    static_assert(fpl_supported<C>(), "native lazy limbs need R / p >= 2^9");
+    KYB_HD static void enter(E& r, const Packed& a) { fpl_unpack(r, a); }
+    KYB_HD static void leave(Packed& r, const E& a) {  // any lazy value: one multiplication by the Montgomery one brings it below 2p
+        E o, t;
+        fpl_one(o);
+        fpl_mul(t, a, o);
+        fpl_finish(r, t);
+    }
+    KYB_HD static void one(E& r) { fpl_one(r); }
+    KYB_HD static void mul(E& r, const E& a, const E& b) { fpl_mul(r, a, b); }
+    KYB_HD static void sqr(E& r, const E& a) { fpl_sqr(r, a); }
+    KYB_HD static void mul2sum(E& r, const E& a, const E& b, const E& c, const E& d) { fpl_mul2sum(r, a, b, c, d); }
+    KYB_HD static void add(E& r, const E& a, const E& b) { fpl_add(r, a, b); }
+    KYB_HD static void add2x(E& r, const E& a, const E& b) { fpl_add_2x(r, a, b); }
+    KYB_HD static void mul4(E& r, const E& a) { fpl_mul4(r, a); }
+    template <int K> KYB_HD static void sub(E& r, const E& a, const E& b) { fpl_sub<K>(r, a, b); }
+    template <int KMAX> KYB_HD static bool is_zero(const E& a) { return fpl_is_zero_mod_p<KMAX>(a); }
+    template <int K> KYB_HD static void neg_if(E& r, const E& a, bool neg) {  // neg ? K p - a : a
+        E z, n;
+#pragma unroll
+        for (int j = 0; j < C::N; j++) z.l[j] = 0;
+        KYB_LZ_K(z.k = 0.0;)
+        fpl_sub<K>(n, z, a);
+#pragma unroll
+        for (int j = 0; j < C::N; j++) r.l[j] = neg ? n.l[j] : a.l[j];
+        KYB_LZ_K(r.k = neg ? n.k : a.k;)
+    }
+};
+// In: X < 18, Y < 18, Z < 12.  Out: X < 18, Y < 18, Z < 4.
+template <class LF>
+KYB_HD void jaclz_dbl_t(JacLz<LF>& p) {
+    using E = typename LF::E;
+    E A, B, C, D, Ee, G, t, u;
+    LF::sqr(A, p.X);               // 324
+    LF::sqr(B, p.Y);               // 324
+    LF::sqr(C, B);                 // 4
+    LF::mul(t, p.X, B);            // X Y^2: 36
+    LF::mul4(D, t);                // 4 X Y^2  < 8
+    LF::add2x(Ee, A, A);           // 3 X^2  < 6
+    LF::sqr(G, Ee);                // 36
+    LF::mul(t, p.Y, p.Z);          // 216
+    LF::add(p.Z, t, t);            // < 4
+    LF::add(u, D, D);              // < 16
+    LF::template sub<16>(p.X, G, u);   // X3 = G - 2 D  < 18
+    LF::template sub<18>(t, D, p.X);   // D - X3  < 26
+    LF::mul(t, Ee, t);             // 156
+    LF::mul4(u, C);                // < 8
+    LF::add(u, u, u);              // 8 C < 16
+    LF::template sub<16>(p.Y, t, u);   // Y3  < 18
+}
+// p += +-(x2, y2), coordinates below 2p.  In: X < 18, Y < 18, Z < 12.  Out: X < 14, Y < 4, Z < 4.
+template <class LF>
+KYB_HD void jaclz_madd_t(JacLz<LF>& p, const typename LF::E& x2, const typename LF::E& y2in, bool neg) {
+    using E = typename LF::E;
+    E y2;
+    LF::template neg_if<2>(y2, y2in, neg);  // < 2 (+ the input's bound when not negated: < 2)
+    if (p.inf) {
+        p.X = x2;
+        p.Y = y2;
+        LF::one(p.Z);
+        p.inf = 0u;
+        return;
+    }
+    E Z1Z1, U2, S2, H, HH, I, J, rr, V, t, u;
+    LF::sqr(Z1Z1, p.Z);                 // 144
+    LF::mul(U2, x2, Z1Z1);              // 4
+    LF::mul(t, p.Z, Z1Z1);              // 24
+    LF::mul(S2, y2, t);                 // 4
+    LF::template sub<18>(H, U2, p.X);   // < 20
+    LF::template sub<18>(rr, S2, p.Y);  // S2 - Y1 = r / 2  < 20
+    if (LF::template is_zero<20>(H)) {  // same x: the point itself (double it) or its inverse (cancel)
+        if (LF::template is_zero<20>(rr)) {
+            p.X = x2;
+            p.Y = y2;
+            LF::one(p.Z);
+            jaclz_dbl_t(p);
+        } else {
+            jaclz_set_inf(p);
+        }
+        return;
+    }
+    LF::sqr(HH, H);                     // 400
+    LF::mul4(I, HH);                    // < 8
+    LF::mul(J, H, I);                   // 160
+    LF::mul(V, p.X, I);                 // 144
+    LF::sqr(t, rr);                     // 400
+    LF::mul4(t, t);                     // r^2  < 8
+    LF::add2x(u, J, V);                 // J + 2 V  < 6
+    LF::template sub<6>(t, t, u);       // X3  < 14
+    LF::template sub<14>(u, V, t);      // V - X3  < 16
+    E nj, z;
+    LF::template neg_if<2>(nj, J, true);  // 2p - J
+    LF::mul2sum(z, rr, u, p.Y, nj);     // (r / 2)(V - X3) - Y1 J: 320 + 36
+    LF::add(p.Y, z, z);                 // Y3  < 4
+    LF::mul(z, p.Z, H);                 // 240
+    LF::add(p.Z, z, z);                 // Z3 = 2 Z1 H  < 4
+    p.X = t;
+}
+template <class LF, class F>
+KYB_HD void jaclz_mul_u64_aff_t(Jac<F>& r, const Aff<F>& p, uint64_t k) {
+    if (p.inf) {
+        jac_set_inf(r);
+        return;
+    }
+    uint64_t pos = 0, neg = 0;
+    bool top = false;
+    {
+        unsigned __int128 x = k;
+#pragma unroll 1
+        for (int i = 0; x != 0; i++) {
+            if (x & 1) {
+                if ((x & 3) == 1) {
+                    if (i < 64) pos |= uint64_t(1) << i;
+                    else top = true;
+                    x -= 1;
+                } else {
+                    neg |= uint64_t(1) << i;
+                    x += 1;
+                }
+            }
+            x >>= 1;
+        }
+    }
+    typename LF::E x2, y2;
+    LF::enter(x2, p.x);
+    LF::enter(y2, p.y);
+    JacLz<LF> acc;
+    jaclz_set_inf(acc);
+#pragma unroll 1
+    for (int i = 64; i >= 0; i--) {
+        if (!acc.inf) jaclz_dbl_t(acc);
+        const bool dp = i == 64 ? top : ((pos >> i) & 1) != 0, dn = i < 64 && ((neg >> i) & 1) != 0;
+        if (dp || dn) jaclz_madd_t(acc, x2, y2, dn);
+    }
+    jaclz_leave(r, acc);
+}
+
 template <class LF, class F>
 KYB_HD void jaclz_leave(Jac<F>& r, const JacLz<LF>& p) {
     if (p.inf) {

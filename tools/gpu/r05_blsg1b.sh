@@ -3,7 +3,7 @@
 # Point.Mul at 2^15 / 2^16, UnmarshalBinary at 2^20, Pair / verify at 2^16, the checked MSM at 2^20.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/r05_blsg1b; mkdir -p $O; export TMPDIR=/tmp
-timeout 1200 python -m pytest tests/test_gpu_bls12381.py tests/test_gpu_switches.py tests/test_gpu_msm.py tests/test_gpu_unmarshal.py -m gpu -q -x > $O/pytest.log 2>&1; echo "rc=$?" >> $O/pytest.log; tail -4 $O/pytest.log
+timeout 1200 python -m pytest tests/test_gpu_bls12381.py tests/test_gpu_switches.py tests/test_gpu_msm.py -m gpu -q -x > $O/pytest.log 2>&1; echo "rc=$?" >> $O/pytest.log; tail -4 $O/pytest.log
 for rep in 1 2; do
   for lib in "" kyber_amd/lib/libkyberhip_blspacked.so; do
     tag="{\"lib\": \"${lib:-lazy}\", "
