@@ -307,7 +307,14 @@ def _lvm_mads():
 # windows: 379 S + 109 M) + the endomorphism test phi(P) = [-z^2]P (2 x (63 doublings of 2M + 5S + 5 additions of 11M + 5S));
 # G2 = two such powers for the Fp2 square root + psi(Q) = [z]Q (63 doublings + 5 additions over Fp2, Karatsuba: M2 = 3M, S2 = 2M)
 _M, _S = 338, 260
-MADS_G1_UNMARSHAL = (379 * _S + 109 * _M) + 2 * (63 * (2 * _M + 5 * _S) + 5 * (11 * _M + 5 * _S))
+# (round 5: both 63-bit multiplications of the r-torsion test on lazy limbs -- jac_lazy.cuh jaclz_dbl_t 3M + 4S,
+# jaclz_madd_t 6M + 3S + one two-product multiplication of 3 x 169 -- the numerator FELL slightly with the change)
+_DBL_T, _MADD_T = 3 * _M + 4 * _S, 6 * _M + 3 * _S + 3 * 169
+MADS_G1_UNMARSHAL = (379 * _S + 109 * _M) + 126 * _DBL_T + 10 * _MADD_T
+# G1Elt.Mul as the per-lane kernel does it since round 5 (the band the bench's 2^16 elements fall in): the GLV walk of 136
+# doublings + 68 mixed additions on lazy limbs, the packed table of eight multiples (1 doubling + 6 additions + the shared
+# inversion's ~8 M), 8 beta x products, 3 M to leave the form -- 540 566, against 606 046 for the lane machine's program
+MADS_BLS_G1_LADDER = 136 * _DBL_T + 68 * _MADD_T + (2 * _M + 5 * _S) + 6 * (11 * _M + 5 * _S) + 8 * _M + 8 * _M + 3 * _M
 MADS_G1_DECOMPRESS = 379 * _S + 109 * _M  # the square root alone (validated compressed points: no subgroup test)
 MADS_G2_UNMARSHAL = 2 * (379 * _S + 109 * _M) + 12 * _M + (63 * (2 * 3 + 5 * 2) + 5 * (11 * 3 + 5 * 2)) * _M
 # pointG1 / pointG2.Mul of the BN suites as the per-lane code does it (bn_suite.inc; nine 29-bit limbs: a field
@@ -316,7 +323,9 @@ MADS_G2_UNMARSHAL = 2 * (379 * _S + 109 * _M) + 12 * _M + (63 * (2 * 3 + 5 * 2) 
 # shared inversion).  G2: the membership relation (63 doublings + 21 mixed additions for [u]Q, 3 more additions, a doubling)
 # and the GLS walk (17 windows of (4 + 4), the same table) over Fp2.
 _MB, _SB = 162, 126
-_BN_DBL, _BN_MADD, _BN_ADD = 2 * _MB + 5 * _SB, 7 * _MB + 4 * _SB, 11 * _MB + 5 * _SB
+# (round 5, lazy limbs: the mixed addition's Y3 is ONE two-product multiplication on G1 -- 5M + 3 x 81 + 4S; over Fp2 the two
+# products stay two multiplications of two two-product halves each: the same 4 698 as 7 M2 + 4 S2)
+_BN_DBL, _BN_MADD, _BN_ADD = 2 * _MB + 5 * _SB, 5 * _MB + 3 * 81 + 4 * _SB, 11 * _MB + 5 * _SB
 _BN_DBL2, _BN_MADD2, _BN_ADD2 = (2 * 3 + 5 * 2) * _MB, (7 * 3 + 4 * 2) * _MB, (11 * 3 + 5 * 2) * _MB
 MADS_BN_G1_MUL = 136 * _BN_DBL + 68 * _BN_MADD + _BN_DBL + 6 * _BN_ADD + 53 * _MB
 MADS_BN_G2_GLS = 64 * _BN_DBL2 + 68 * _BN_MADD2 + _BN_DBL2 + 6 * _BN_ADD2 + 53 * 3 * _MB
@@ -437,7 +446,7 @@ def other_workloads(rank, world, dist):
             # G1Elt.Mul / G2Elt.Mul with everything UnmarshalBinary checks (flags = 0): the per-lane unmarshal kernel +
             # the lane machine's ladder; G2 also against the count with Karatsuba Fp2 products (3 instead of 4)
             lm = _lvm_mads()
-            out[name]["roofline"]["g1_mul"] = _roof(npair / ms_g1 * 1e3, lm["g1"] + MADS_G1_UNMARSHAL, 32 + 2 * g1b_, prof, "bls12381_g1_mul")
+            out[name]["roofline"]["g1_mul"] = _roof(npair / ms_g1 * 1e3, min(lm["g1"], MADS_BLS_G1_LADDER) + MADS_G1_UNMARSHAL, 32 + 2 * g1b_, prof, "bls12381_g1_mul")
             out[name]["roofline"]["g2_mul"] = _roof(npair / ms_g2 * 1e3, lm["g2"] + MADS_G2_UNMARSHAL, 32 + 2 * g2b_, prof, "bls12381_g2_mul",
                                                     lm["g2_karatsuba"] + MADS_G2_UNMARSHAL)
         if name in ("bn256", "bn254"):
