@@ -79,8 +79,15 @@ KYB_HD_NOINLINE bool g1_in_subgroup(const g1_aff& a) {
 // G2: psi(Q) = [x] Q, psi = twist o Frobenius o untwist
 KYB_HD_NOINLINE bool g2_in_subgroup(const g2_aff& a) {
     g2_jac p, q;
+#ifdef KYB_BLS_PACKED_LADDER
     jac_from_aff(p, a);
     jac_mul_u64(q, p, CC::X_ABS);  // |x| Q ; need psi(Q) = -q
+#else
+    // on lazy limbs (jac_lazy.cuh, fourteen 30-bit limbs per coefficient: the Fp2 formulas need R' / p > 2^14).  The doubling is
+    // ~75 KB of straight line, more than the instruction cache -- and still 17 % ahead of the packed code's calls
+    // (G2 UnmarshalBinary 2^20: 2.20 -> 2.57e7/s, profiles/r05_bls12381_g2_member_lazy_ab.jsonl)
+    jaclz_mul_u64_aff<LzFp2<Limb30<FC>, TC>>(q, a, CC::X_ABS);
+#endif
     fp2 cx, cy, px, py, z2, z3, l, r;
     fp2_load_const<TC>(cx, CC::PSI_CX);
     fp2_load_const<TC>(cy, CC::PSI_CY);

@@ -172,7 +172,17 @@ KYB_HD_NOINLINE void hash_g1_point(g1_jac& r, const uint8_t* msg, size_t msg_len
     g1_sswu(x, y, u);
     g1_iso_map(q1, x, y);
     jac_add(r, q0, q1);
+#ifdef KYB_BLS_PACKED_LADDER
     jac_mul_u64(r, r, 0xd201000000010001ull);
+#else
+    // clear_cofactor = [h_eff] on lazy limbs (jac_lazy.cuh: doublings and mixed additions, so the sum goes through its
+    // affine form first -- one division-step inversion against the 63 doublings it feeds)
+    {
+        g1_aff a;
+        jac_to_aff(a, r);
+        jaclz_mul_u64_aff_t<LzFpN<FC>>(r, a, 0xd201000000010001ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------ G2

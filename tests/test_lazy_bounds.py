@@ -69,3 +69,17 @@ def test_bls12381_g1_ladder_on_lazy_limbs_stays_inside_its_bounds():
         assert out.raw == OB.g1_compress(OB.g1_mul(k % OB.R, P)), hex(k)
     assert lib.hh_lz_audit_failures() == 0
     assert 0 < lib.hh_lz_audit_max_product() <= 400  # H^2, rr^2 with H, rr < 20p: the largest products of the native-limb formulas (R / p = 630)
+
+
+def test_bls12381_g2_membership_on_lazy_limbs_stays_inside_its_bounds():
+    """G2Elt.UnmarshalBinary's r-torsion test: [z]Q through jaclz_mul_u64_aff over fourteen-limb Fp2 (R' / p = 2^39)"""
+    lib = H.lib_audit()
+    _reset(lib)
+    rng = random.Random(13)
+    Q = OB.g2_mul(rng.randrange(1, OB.R), OB.G2_GEN)
+    k = rng.randrange(OB.R)
+    out = C.create_string_buffer(96)
+    assert lib.hh_bls_g2_mul(k.to_bytes(32, "big"), OB.g2_compress(Q), out) == 0
+    assert out.raw == OB.g2_compress(OB.g2_mul(k, Q))
+    assert lib.hh_lz_audit_failures() == 0
+    assert 0 < lib.hh_lz_audit_max_product() <= 23104  # the generic formulas' largest product sum, (2 * 76)^2
