@@ -25,7 +25,7 @@ NOW = source_digest.digests()
 C = "kyber_amd/csrc/"
 # the sources a kernel is compiled from (beyond hd.h / context.h / include/kyber_hip.h, which every kernel shares and
 # whose edits are interface-level): a profile is stale once any of them differs from what the profiled binary was built from
-COMMON_PAIRING = [C + "mont.cuh", C + "curve.cuh", C + "tower.cuh", C + "fp_limbs.cuh"]
+COMMON_PAIRING = [C + "mont.cuh", C + "curve.cuh", C + "tower.cuh", C + "fp_limbs.cuh", C + "jac_lazy.cuh"]
 SOURCES = {
     "ed": [C + "ed25519.hip", C + "fe25519.cuh", C + "ge25519.cuh"],
     "bls12381": [C + "bls12381_pair.hip", C + "tower_vm.cuh", C + "gen_tower_vm.py", C + "bls12381_tvm.h", C + "bls12381_prep.hip", C + "bls12381.cuh"] + COMMON_PAIRING,
@@ -34,9 +34,9 @@ SOURCES = {
     "gtmul": [C + "bls12381_pair.hip", C + "bn256_pair.hip", C + "bn254_pair.hip", C + "bn_pair.inc", C + "tower_vm.cuh", C + "gen_tower_vm.py",
               C + "bls12381_tvm.h"],
     "bn256": [C + "bn256_pair.hip", C + "bn_pair.inc", C + "tower_vm.cuh", C + "gen_tower_vm.py", C + "bn256.cuh", C + "bn_suite.inc", C + "bn256.hip",
-              C + "pairing_abi.cuh", C + "jac_lazy.cuh"] + COMMON_PAIRING,
+              C + "pairing_abi.cuh"] + COMMON_PAIRING,
     "bn254": [C + "bn254_pair.hip", C + "bn_pair.inc", C + "tower_vm.cuh", C + "gen_tower_vm.py", C + "bn254.cuh", C + "bn_suite.inc", C + "bn254.hip",
-              C + "pairing_abi.cuh", C + "jac_lazy.cuh"] + COMMON_PAIRING,
+              C + "pairing_abi.cuh"] + COMMON_PAIRING,
     "mul": [C + "bls12381.hip", C + "bls12381_lvm.cuh", C + "lane_vm.cuh", C + "gen_lane_vm.py", C + "bls12381.cuh", C + "pairing_abi.cuh",
             C + "bls12381_unm2.hip", C + "bls12381_g1split.hip"] + COMMON_PAIRING,
     "mulperlane": [C + "bls12381.hip", C + "bls12381.cuh", C + "pairing_abi.cuh"] + COMMON_PAIRING,
