@@ -162,7 +162,61 @@ static int xyzzl_sum_bls_g1(int n, const uint8_t* pts, const uint8_t* signs, uin
     return bad;
 }
 
+// The lazy Jacobian formulas (jac_lazy.cuh) driven directly: ops[i] = 'a' (acc += pts[i]), 's' (acc -= pts[i]) or 'd'
+// (acc = 2 acc; pts[i] unused) -- the exceptional branches of the mixed addition (accumulator at infinity, the same point,
+// the opposite point) are reached by construction, which a scalar multiplication only does by accident.
+template <class LF, bool TIGHT, class F, class AffT, class Dec, class Enc>
+static int lz_chain(int n, const char* ops, const uint8_t* pts, int wire, uint8_t* out, Dec dec, Enc enc) {
+    JacLz<LF> acc;
+    jaclz_set_inf(acc);
+    for (int i = 0; i < n; i++) {
+        if (ops[i] == 'd') {
+            if (!acc.inf) {
+                if constexpr (TIGHT) jaclz_dbl_t(acc);
+                else jaclz_dbl(acc);
+            }
+            continue;
+        }
+        AffT a;
+        if (dec(a, pts + (size_t)wire * i)) return 1 + i;
+        if (a.inf) continue;
+        typename LF::E x, y;
+        LF::enter(x, a.x);
+        LF::enter(y, a.y);
+        if constexpr (TIGHT) jaclz_madd_t(acc, x, y, ops[i] == 's');
+        else jaclz_madd(acc, x, y, ops[i] == 's');
+    }
+    Jac<F> j;
+    jaclz_leave(j, acc);
+    AffT r;
+    jac_to_aff(r, j);
+    enc(out, r);
+    return 0;
+}
+
 extern "C" {
+
+// which: 0 bn256 G1 (LzFp over Limb30), 1 bn256 G2 (LzFp2), 2 BLS12-381 G1 on the native limbs (the _t formulas),
+// 3 BLS12-381 G1 on fourteen limbs (generic formulas), 4 BLS12-381 G2 (LzFp2 over fourteen limbs)
+int hh_lz_chain(int which, int n, const char* ops, const uint8_t* pts, uint8_t* out) {
+    switch (which) {
+        case 0:
+            return lz_chain<bn::lz1, false, bn::fp, bn::g1_aff>(n, ops, pts, 64, out, [](bn::g1_aff& a, const uint8_t* in) { return bn::g1_decode(a, in); },
+                                                                  [](uint8_t* o, const bn::g1_aff& a) { bn::g1_encode(o, a); });
+        case 1:
+            return lz_chain<bn::lz2, false, bn::fp2, bn::g2_aff>(n, ops, pts, 128, out, [](bn::g2_aff& a, const uint8_t* in) { return bn::g2_decode(a, in); },
+                                                                   [](uint8_t* o, const bn::g2_aff& a) { bn::g2_encode(o, a); });
+        case 2:
+            return lz_chain<LzFpN<bls::FC>, true, bls::fp, bls::g1_aff>(n, ops, pts, 48, out, [](bls::g1_aff& a, const uint8_t* in) { return bls::g1_decode(a, in, false); },
+                                                                          [](uint8_t* o, const bls::g1_aff& a) { bls::g1_encode(o, a); });
+        case 3:
+            return lz_chain<LzFp<Limb30<bls::FC>>, false, bls::fp, bls::g1_aff>(n, ops, pts, 48, out, [](bls::g1_aff& a, const uint8_t* in) { return bls::g1_decode(a, in, false); },
+                                                                                  [](uint8_t* o, const bls::g1_aff& a) { bls::g1_encode(o, a); });
+        default:
+            return lz_chain<LzFp2<Limb30<bls::FC>, bls::TC>, false, bls::fp2, bls::g2_aff>(n, ops, pts, 96, out, [](bls::g2_aff& a, const uint8_t* in) { return bls::g2_decode(a, in, false); },
+                                                                                              [](uint8_t* o, const bls::g2_aff& a) { bls::g2_encode(o, a); });
+    }
+}
 
 int hh_bls_g1_xyzzl_sum(int n, const uint8_t* pts, const uint8_t* signs, uint8_t* out, int* max_top) {
     return xyzzl_sum_bls_g1(n, pts, signs, out, max_top);

@@ -83,3 +83,43 @@ def test_bls12381_g2_membership_on_lazy_limbs_stays_inside_its_bounds():
     assert out.raw == OB.g2_compress(OB.g2_mul(k, Q))
     assert lib.hh_lz_audit_failures() == 0
     assert 0 < lib.hh_lz_audit_max_product() <= 23104  # the generic formulas' largest product sum, (2 * 76)^2
+
+
+def test_lazy_jacobian_formulas_exceptional_branches_vs_oracle():
+    """jaclz_madd / jaclz_dbl (and the _t pair) driven op by op: first point into an accumulator at infinity, the same
+    point again (the doubling branch), the opposite point (cancellation, then a restart), doublings in between, long
+    mixed runs -- every form that ships, against the oracle's plain sum, under the bound audit."""
+    lib = H.lib_audit()
+    rng = random.Random(21)
+    forms = [(0, ON, ON.g1_mul, ON.g1_add, ON.g1_neg, ON.g1_marshal, ON.G1_GEN, ON.ORDER, 64),
+             (1, ON, ON.g2_mul, ON.g2_add, ON.g2_neg, ON.g2_marshal, ON.G2_GEN, ON.ORDER, 128),
+             (2, OB, OB.g1_mul, OB.g1_add, OB.g1_neg, OB.g1_compress, OB.G1_GEN, OB.R, 48),
+             (3, OB, OB.g1_mul, OB.g1_add, OB.g1_neg, OB.g1_compress, OB.G1_GEN, OB.R, 48),
+             (4, OB, OB.g2_mul, OB.g2_add, OB.g2_neg, OB.g2_compress, OB.G2_GEN, OB.R, 96)]
+    for which, O, mul, add, neg, enc, gen, order, size in forms:
+        _reset(lib)
+        P, Q = mul(rng.randrange(1, order), gen), mul(rng.randrange(1, order), gen)
+        P2 = add(P, P)
+        runs = [
+            [("a", P)],
+            [("a", P), ("a", P)],                                   # equal point: the doubling branch
+            [("a", P), ("s", P)],                                   # opposite point: infinity
+            [("a", P), ("s", P), ("a", Q), ("d", None), ("a", Q)],  # restart after a cancellation
+            [("s", P), ("d", None), ("a", P2)],                     # -2P + 2P through a doubling
+            [("a", P), ("d", None), ("s", P2), ("a", Q)],           # 2P - 2P, then Q
+            [("d", None), ("a", Q), ("d", None), ("d", None), ("s", P), ("a", Q), ("d", None), ("a", P)],
+            [(rng.choice("as"), rng.choice([P, Q, P2])) if rng.random() < 0.6 else ("d", None) for _ in range(40)],
+        ]
+        for run in runs:
+            exp = None
+            for op, pt in run:
+                if op == "d":
+                    exp = add(exp, exp) if exp is not None else None
+                else:
+                    exp = add(exp, neg(pt) if op == "s" else pt)
+            ops = "".join(op for op, _ in run).encode()
+            wire = b"".join(enc(pt) if pt is not None else bytes(size) for _, pt in run)
+            out = C.create_string_buffer(size)
+            assert lib.hh_lz_chain(which, len(run), ops, wire, out) == 0, (which, ops)
+            assert out.raw == enc(exp), (which, ops)
+        assert lib.hh_lz_audit_failures() == 0, which
