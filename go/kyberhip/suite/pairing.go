@@ -231,6 +231,89 @@ func (s *PairingSuite) BatchVerify(publics []kyber.Point, msgs [][]byte, sigs []
 	return res, nil
 }
 
+// BatchVerifySameMsg is the verification loop of tbls.Recover (sign/tbls/tbls.go:118-131): ONE message, a different
+// public key per signature (the public shares public.Eval(idx).V).  H(msg) is hashed once per call on the device
+// (kyb_bls12381_verify_g1_same_msg); otherwise BatchVerify.  BLS12-381 only.
+func (s *PairingSuite) BatchVerifySameMsg(publics []kyber.Point, msg []byte, sigs [][]byte, dst []byte) ([]bool, error) {
+	if s.curve != curveBLS12381 {
+		return nil, fmt.Errorf("kyberhip: fused verification exists for BLS12-381 only")
+	}
+	n := len(sigs)
+	if len(publics) != n {
+		return nil, errLen
+	}
+	res := make([]bool, n)
+	if n == 0 {
+		return res, nil
+	}
+	pk, err := encodings(publics, 96)
+	if err != nil {
+		return nil, err
+	}
+	sb := make([]byte, 0, n*48)
+	short := make([]bool, n)
+	for i, sg := range sigs {
+		if len(sg) != 48 {
+			short[i] = true
+			sg = make([]byte, 48)
+		}
+		sb = append(sb, sg...)
+	}
+	ok, st, err := hip.Bls12381VerifyG1SameMsg(pk, msg, dst, sb, hip.Trusted(0))
+	if err != nil {
+		return nil, err
+	}
+	for i := range res {
+		res[i] = ok[i] == 1 && st[i] == 0 && !short[i]
+	}
+	return res, nil
+}
+
+// BatchVerifySameKey is sign/bls Verify (bls.go:82-96) in a loop with ONE public key -- a drand chain, one tbls
+// participant's partial signatures: both Miller loops from line tables (kyb_bls12381_verify_g1_same_key; the tables of
+// the last eight keys are kept per stream, so a committee of a few keys pays the table walk once per key).
+func (s *PairingSuite) BatchVerifySameKey(public kyber.Point, msgs [][]byte, sigs [][]byte, dst []byte) ([]bool, error) {
+	if s.curve != curveBLS12381 {
+		return nil, fmt.Errorf("kyberhip: fused verification exists for BLS12-381 only")
+	}
+	n := len(msgs)
+	if len(sigs) != n {
+		return nil, errLen
+	}
+	res := make([]bool, n)
+	if n == 0 {
+		return res, nil
+	}
+	pk, err := encodings([]kyber.Point{public}, 96)
+	if err != nil {
+		return nil, err
+	}
+	ml := len(msgs[0])
+	mb := make([]byte, 0, n*ml)
+	sb := make([]byte, 0, n*48)
+	short := make([]bool, n)
+	for i := range msgs {
+		if len(msgs[i]) != ml {
+			return nil, fmt.Errorf("kyberhip: messages of different length (group them by length)")
+		}
+		mb = append(mb, msgs[i]...)
+		sg := sigs[i]
+		if len(sg) != 48 {
+			short[i] = true
+			sg = make([]byte, 48)
+		}
+		sb = append(sb, sg...)
+	}
+	ok, st, err := hip.Bls12381VerifyG1SameKey(pk, mb, ml, dst, sb, hip.Trusted(0))
+	if err != nil {
+		return nil, err
+	}
+	for i := range res {
+		res[i] = ok[i] == 1 && st[i] == 0 && !short[i]
+	}
+	return res, nil
+}
+
 // BatchGTMul: out[i] = gt[i]^scalars[i].
 func (s *PairingSuite) BatchGTMul(scalars []kyber.Scalar, gts []kyber.Point) ([]kyber.Point, error) {
 	if len(scalars) != len(gts) {
