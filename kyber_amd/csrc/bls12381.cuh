@@ -557,26 +557,20 @@ KYB_HD void g1_mul_glv_lz(g1_jac& r, const g1_jac& p, const uint32_t (&k)[8]) {
     int8_t e0[65], e1[65];
     glv_digits(e0, rem, 4);
     glv_digits(e1, q, 5);
-    g1_jac tab[8];  // (j + 1) * P
-    tab[0] = p;
-    jac_dbl(tab[1], p);
-#pragma unroll 1
-    for (int j = 2; j < 8; j++) jac_add(tab[j], tab[j - 1], p);
-    jac_table8_to_affine(tab);
-    typename LF::E tx[2][8], ty[8], beta;
-    uint32_t infmask = 0;
+    if (jac_is_inf(p)) {
+        jac_set_inf(r);
+        return;
+    }
+    typename LF::E tx[2][8], ty[8], beta;  // (j + 1) P and its image (beta x, -y): affine, in limb form
+    uint32_t infmask;
+    jaclz_table8<LF, true>(tx[0], ty, infmask, p.X, p.Y);  // p comes from jac_from_aff: Z = 1
     {
         fp b;
         fp_const(b, CC::BETA);
         LF::enter(beta, b);
     }
 #pragma unroll 1
-    for (int j = 0; j < 8; j++) {
-        infmask |= (fp_is_zero(tab[j].Z) ? 1u : 0u) << j;
-        LF::enter(tx[0][j], tab[j].X);
-        LF::enter(ty[j], tab[j].Y);
-        LF::mul(tx[1][j], tx[0][j], beta);
-    }
+    for (int j = 0; j < 8; j++) LF::mul(tx[1][j], tx[0][j], beta);
     JacLz<LF> acc;
     jaclz_set_inf(acc);
 #pragma unroll 1

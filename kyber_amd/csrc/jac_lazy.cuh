@@ -155,6 +155,8 @@ struct LzFp {
     }
     template <int KB> KYB_HD static void mul(E& r, const E& a, const E& b) { fpl_mul(r, a, b); }  // KB: bound of b (unused here)
     template <int KA> KYB_HD static void sqr(E& r, const E& a) { fpl_sqr(r, a); }
+    template <int KB> KYB_HD static void mulb(E& r, const E& a, const E& b) { fpl_mul(r, a, b); }  // the names jaclz_table8 uses on every adaptor
+    template <int KA> KYB_HD static void sqrb(E& r, const E& a) { fpl_sqr(r, a); }
     // r = a b + c d, one reduction per coefficient; KB, KD: bounds of b, d
     template <int KB, int KD> KYB_HD static void mul2sum(E& r, const E& a, const E& b, const E& c, const E& d) { fpl_mul2sum(r, a, b, c, d); }
     KYB_HD static void add(E& r, const E& a, const E& b) { fpl_add(r, a, b); }
@@ -253,6 +255,8 @@ struct LzFp2 {
         B::template neg_if<K>(r.c0, a.c0, neg);
         B::template neg_if<K>(r.c1, a.c1, neg);
     }
+    template <int KB> KYB_HD static void mulb(E& r, const E& a, const E& b) { mul<KB>(r, a, b); }
+    template <int KA> KYB_HD static void sqrb(E& r, const E& a) { sqr<KA>(r, a); }
     // by a base-field element / conjugation: the psi maps of the GLS walk
     KYB_HD static void mul_fp(E& r, const E& a, const FpL<L>& b) {
         fpl_mul(r.c0, a.c0, b);
@@ -430,6 +434,8 @@ struct LzFpN {
     KYB_HD static void one(E& r) { fpl_one(r); }
     KYB_HD static void mul(E& r, const E& a, const E& b) { fpl_mul(r, a, b); }
     KYB_HD static void sqr(E& r, const E& a) { fpl_sqr(r, a); }
+    template <int KB> KYB_HD static void mulb(E& r, const E& a, const E& b) { fpl_mul(r, a, b); }
+    template <int KA> KYB_HD static void sqrb(E& r, const E& a) { fpl_sqr(r, a); }
     KYB_HD static void mul2sum(E& r, const E& a, const E& b, const E& c, const E& d) { fpl_mul2sum(r, a, b, c, d); }
     KYB_HD static void add(E& r, const E& a, const E& b) { fpl_add(r, a, b); }
     KYB_HD static void add2x(E& r, const E& a, const E& b) { fpl_add_2x(r, a, b); }
@@ -554,6 +560,64 @@ KYB_HD void jaclz_mul_u64_aff_t(Jac<F>& r, const Aff<F>& p, uint64_t k) {
         if (dp || dn) jaclz_madd_t(acc, x2, y2, dn);
     }
     jaclz_leave(r, acc);
+}
+
+// The window table of a ladder, built in the lazy form: tx[j], ty[j] = affine coordinates (below 2p per coefficient) of
+// (j + 1) P for a finite affine P, bit j of infmask = that multiple is the point at infinity (a point of small order:
+// only a wrongly vouched-for input gets there).  One doubling and six MIXED additions (every multiple is the previous
+// one plus the affine P: the packed builder paid six full additions through out-of-line calls), the eight Z's inverted
+// together (Montgomery's trick; the one inversion is the packed code's division-step routine).
+template <class LF, bool TIGHT, class F>
+KYB_HD void jaclz_table8(typename LF::E (&tx)[8], typename LF::E (&ty)[8], uint32_t& infmask, const F& px, const F& py) {
+    using E = typename LF::E;
+    E zs[8], c[8];
+    LF::enter(tx[0], px);
+    LF::enter(ty[0], py);
+    LF::one(zs[0]);
+    infmask = 0;
+    JacLz<LF> acc;
+    acc.X = tx[0];
+    acc.Y = ty[0];
+    LF::one(acc.Z);
+    acc.inf = 0u;
+#pragma unroll 1
+    for (int j = 1; j < 8; j++) {
+        if (j == 1) {
+            if constexpr (TIGHT) jaclz_dbl_t(acc);
+            else jaclz_dbl(acc);
+        } else {
+            if constexpr (TIGHT) jaclz_madd_t(acc, tx[0], ty[0], false);
+            else jaclz_madd(acc, tx[0], ty[0], false);
+        }
+        tx[j] = acc.X;
+        ty[j] = acc.Y;
+        if (acc.inf) {
+            infmask |= 1u << j;
+            LF::one(zs[j]);  // a placeholder keeps the running product invertible
+        } else {
+            zs[j] = acc.Z;
+        }
+    }
+    c[0] = zs[0];
+#pragma unroll 1
+    for (int j = 1; j < 8; j++) LF::template mulb<LZ_KZ>(c[j], c[j - 1], zs[j]);
+    E inv;
+    {
+        F pk, pinv;
+        LF::leave(pk, c[7]);
+        f_inv(pinv, pk);
+        LF::enter(inv, pinv);
+    }
+#pragma unroll 1
+    for (int j = 7; j >= 1; j--) {
+        E zi, zi2;
+        LF::template mulb<2>(zi, inv, c[j - 1]);      // 1 / Z_j
+        LF::template mulb<LZ_KZ>(inv, inv, zs[j]);    // 1 / (Z_0 ... Z_{j-1})
+        LF::template sqrb<4>(zi2, zi);
+        LF::template mulb<4>(tx[j], tx[j], zi2);
+        LF::template mulb<4>(zi2, zi2, zi);
+        LF::template mulb<4>(ty[j], ty[j], zi2);
+    }
 }
 
 template <class LF, class F>
