@@ -140,13 +140,10 @@ KYB_HD_NOINLINE int g1_decode(g1_aff& a, const uint8_t* in, bool check_subgroup)
 }
 
 // Square root in Fp2 (p = 3 mod 4) with two base-field exponentiations; false if none exists.
-KYB_HD_NOINLINE bool fp2_sqrt(fp2& r, const fp2& a) {
-    fp n, s, t, u, c, c2, h, inv2;
+// the second half of fp2_sqrt: given s with s^2 = norm(a) (either root), the root of a -- one 379-bit power
+KYB_HD_NOINLINE bool fp2_sqrt_from_norm_root(fp2& r, const fp2& a, const fp& s) {
+    fp t, u, c, c2, h, inv2;
     fp_const(inv2, FC::INV2);
-    fp_sqr(n, a.c0);
-    fp_sqr(t, a.c1);
-    fp_add(n, n, t);
-    fp_pow_words<FC>(s, n, FC::SQRT_EXP, FC::SQRT_BITS);  // sqrt of the norm (if it is a square)
     fp_add(t, a.c0, s);
     fp_mul(t, t, inv2);
     fp_cmov(t, a.c0, fp_is_zero(a.c1));
@@ -168,6 +165,14 @@ KYB_HD_NOINLINE bool fp2_sqrt(fp2& r, const fp2& a) {
     fp2_sqr(chk, x);
     r = x;
     return fp2_eq(chk, a);
+}
+KYB_HD_NOINLINE bool fp2_sqrt(fp2& r, const fp2& a) {
+    fp n, s, t;
+    fp_sqr(n, a.c0);
+    fp_sqr(t, a.c1);
+    fp_add(n, n, t);
+    fp_pow_words<FC>(s, n, FC::SQRT_EXP, FC::SQRT_BITS);  // sqrt of the norm (if it is a square)
+    return fp2_sqrt_from_norm_root(r, a, s);
 }
 
 // 96-byte ZCash compressed G2: x.c1 || x.c0 big-endian, flags in the first byte.

@@ -233,10 +233,33 @@ KYB_HD_NOINLINE void g2_sswu(fp2& x, fp2& y, const fp2& u) {
         fp2_mul_c(x1, x1, k);
     }
     g2_curve_rhs(gx, x1);
-    if (!fp2_sqrt(y, gx)) {
-        fp2_mul_c(x1, t, x1);
-        g2_curve_rhs(gx, x1);
-        fp2_sqrt(y, gx);
+    // g(x1) is a square in Fp2 exactly when its norm n1 is one in Fp: s1 = n1^((p+1)/4) decides it (s1^2 = n1) -- and when it
+    // is not (s1^2 = -n1), the norm root of g(x2) = (Z u^2)^3 g(x1) is s1 sqrt(-N(Z)^3) N(u)^3 without another power.
+    // Either way ONE more power finishes the root (fp2_sqrt_from_norm_root).  Round 1 ran the whole two-power square
+    // root on g(x1) and again on g(x2): half the lanes of a wave need the second, so every wave paid four.
+    {
+        fp n1, s1, tt, nu, k;
+        fp_sqr(n1, gx.c0);
+        fp_sqr(tt, gx.c1);
+        fp_add(n1, n1, tt);
+        fp_pow_words<FC>(s1, n1, FC::SQRT_EXP, FC::SQRT_BITS);
+        fp_sqr(tt, s1);
+        const bool sq = fp_eq(tt, n1);
+        fp2 x2, gx2;
+        fp2_mul_c(x2, t, x1);
+        g2_curve_rhs(gx2, x2);
+        fp_sqr(nu, u.c0);
+        fp_sqr(tt, u.c1);
+        fp_add(nu, nu, tt);   // N(u)
+        fp_sqr(tt, nu);
+        fp_mul(nu, tt, nu);   // N(u)^3
+        fp_const(k, HC::G2_SQRT_NEG_NZ3);
+        fp_mul(k, k, nu);
+        fp_mul(k, k, s1);     // the norm root of g(x2) when g(x1) is no square
+        fp_cmov(s1, k, !sq);
+        fp2_cmov(gx, gx2, !sq);
+        fp2_cmov(x1, x2, !sq);
+        fp2_sqrt_from_norm_root(y, gx, s1);
     }
     fp2 ny;
     fp2_neg(ny, y);

@@ -244,7 +244,8 @@ def main():
           f"    static constexpr uint32_t G2_B[2][12] = {m2(g2['B'])};",
           f"    static constexpr uint32_t G2_Z[2][12] = {m2(g2['Z'])};",
           f"    static constexpr uint32_t G2_NEG_B_OVER_A[2][12] = {m2(nba2)};",
-          f"    static constexpr uint32_t G2_B_OVER_ZA[2][12] = {m2(bza2)};"]
+          f"    static constexpr uint32_t G2_B_OVER_ZA[2][12] = {m2(bza2)};",
+          f"    static constexpr uint32_t G2_SQRT_NEG_NZ3[12] = {m1(pow((-pow(g2['Z'][0] ** 2 + g2['Z'][1] ** 2, 3, p)) % p, (p + 1) // 4, p))};  // sqrt(-N(Z)^3) in Fp: the norm root of g(x2) from the norm root of g(x1) (g2_sswu)"]
     for nm, c in zip(names, g2["maps"]):
         H.append(f"    static constexpr int G2_{nm}_LEN = {len(c)};")
         H.append(f"    static constexpr uint32_t G2_{nm}[{len(c)}][2][12] = {{" + ", ".join(m2(v) for v in c) + "};")
