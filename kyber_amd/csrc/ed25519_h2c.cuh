@@ -96,63 +96,78 @@ KYB_DEV bool fe_sqrt(fe& r, const fe& a) {
     r = c;
     return ok1 | ok2;
 }
-// map_to_curve_elligator2_edwards25519 (RFC 9380 section 6.8.2; behaviour of mapToCurveElligator2Ed25519):
-// Elligator 2 on curve25519 (J = 486662, Z = 2) followed by the birational map to the Edwards curve.
+// map_to_curve_elligator2_edwards25519 (RFC 9380 section 6.8.2; behaviour of mapToCurveElligator2Ed25519): Elligator 2 on
+// curve25519 (J = 486662, Z = 2) followed by the birational map to the Edwards curve -- in the straight-line form of the
+// RFC's appendix G.2.1 / G.2.2: ONE power (gx1 gxd^7)^((p-5)/8) yields the root for x1 and, times u 2^((p+3)/8), the root
+// for x2 = 2 u^2 x1; everything stays a fraction (xn / xd, y) and the fractions go straight into extended coordinates
+// (X : Y : Z : T) = (xn yd : yn xd : xd yd : xn yn) -- no inversion.  Round 1's version inverted the denominator, took a
+// square root for x1, a second one for x2 where the first failed (half the lanes of any wave) and inverted again for
+// the Edwards map: two powers and two inversions of 254 squarings each per map where this takes one.
 KYB_DEV void ed_map_to_curve(ge_p3& q, const fe& u) {
-    fe J, one, t, den, x1, gx, y, xm, nJ;
+    fe J, nJ, one, tv1, tv2, tv3, xd, gxd, gx1, gx2, y11, y12, y21, y22, y1, y2, x2n, xn, y, t;
     fe_0(J);
     J.v[0] = 486662;
     KYB_FE_MAG_SET(J, 486662.0 / (1 << 25));
     fe_1(one);
-    fe_neg(nJ, J);
-    fe_sq2(t, u);  // 2 u^2
-    fe_add(den, t, one);
-    fe_mul(den, den, one);
-    const bool den_zero = !fe_isnonzero(den);
-    fe_invert(x1, den);
-    fe_mul(x1, x1, nJ);  // -J / (1 + 2 u^2)
-    fe_cmov(x1, nJ, den_zero);
-    // g(x) = x^3 + J x^2 + x
-    fe_sq(t, x1);
-    fe_add(gx, x1, J);
-    fe_mul(gx, gx, t);
-    fe_add(gx, gx, x1);
-    const bool sq1 = fe_sqrt(y, gx);
-    xm = x1;
-    bool want_odd = true;  // sgn0(y) = 1 on the first branch, 0 on the second
-    if (!sq1) {
-        fe_sub(xm, nJ, x1);  // -x1 - J
-        fe_mul(xm, xm, one);
-        fe_sq(t, xm);
-        fe_add(gx, xm, J);
-        fe_mul(gx, gx, t);
-        fe_add(gx, gx, xm);
-        fe_sqrt(y, gx);
-        want_odd = false;
-    }
+    fe_neg(nJ, J);            // x1n = -J
+    fe_sq2(tv1, u);           // 2 u^2
+    fe_add(xd, tv1, one);     // 1 + 2 u^2: never zero (-1/2 is no square)
+    fe_sq(tv2, xd);
+    fe_mul(gxd, tv2, xd);     // xd^3
+    fe_mul(gx1, J, tv1);
+    fe_mul(gx1, gx1, nJ);
+    fe_add(gx1, gx1, tv2);
+    fe_mul(gx1, gx1, nJ);     // x1n^3 + J x1n^2 xd + x1n xd^2 = g(x1) xd^3
+    fe_sq(tv3, gxd);
+    fe_sq(tv2, tv3);          // gxd^4
+    fe_mul(tv3, tv3, gxd);    // gxd^3
+    fe_mul(tv3, tv3, gx1);    // gx1 gxd^3
+    fe_mul(tv2, tv2, tv3);    // gx1 gxd^7
+    fe_pow22523(y11, tv2);    // ^((p-5)/8)
+    fe_mul(y11, y11, tv3);
+    fe_mul(y12, y11, fe_sqrtm1());
+    fe_sq(tv2, y11);
+    fe_mul(tv2, tv2, gxd);
+    const bool e1 = fe_eq(tv2, gx1);
+    y1 = y12;
+    fe_cmov(y1, y11, e1);     // the root of g(x1) if there is one
+    fe_mul(x2n, nJ, tv1);     // x2 = 2 u^2 x1
+    fe_mul(y21, y11, u);
+    fe_mul(y21, y21, fe_elligator_c2());
+    fe_mul(y22, y21, fe_sqrtm1());
+    fe_mul(gx2, gx1, tv1);    // g(x2) xd^3 = 2 u^2 g(x1) xd^3
+    fe_sq(tv2, y21);
+    fe_mul(tv2, tv2, gxd);
+    const bool e2 = fe_eq(tv2, gx2);
+    y2 = y22;
+    fe_cmov(y2, y21, e2);
+    fe_sq(tv2, y1);
+    fe_mul(tv2, tv2, gxd);
+    const bool e3 = fe_eq(tv2, gx1);  // g(x1) is a square: x = x1, else x = x2
+    xn = x2n;
+    fe_cmov(xn, nJ, e3);
+    y = y2;
+    fe_cmov(y, y1, e3);
     fe ny;
     fe_neg(ny, y);
-    fe_cmov(y, ny, fe_isnegative(y) != want_odd);
-    // Montgomery (xm, y) -> Edwards: xe = c1 xm / y, ye = (xm - 1) / (xm + 1); exceptional cases -> (0, 1)
-    fe xp1, xm1, d, di, xe, ye;
-    fe_add(xp1, xm, one);
-    fe_sub(xm1, xm, one);
-    fe_mul(d, y, xp1);
-    const bool exc = !fe_isnonzero(d);
-    fe_invert(di, d);  // 1 / (y (xm + 1))
-    fe_mul(xe, xm, fe_elligator_c1());
-    fe_mul(xe, xe, xp1);
-    fe_mul(xe, xe, di);  // c1 xm / y
-    fe_mul(ye, xm1, y);
-    fe_mul(ye, ye, di);  // (xm - 1) / (xm + 1)
-    fe z;
-    fe_0(z);
-    fe_cmov(xe, z, exc);
-    fe_cmov(ye, one, exc);
-    q.X = xe;
-    q.Y = ye;
-    fe_1(q.Z);
-    fe_mul(q.T, xe, ye);
+    fe_cmov(y, ny, e3 != fe_isnegative(y));  // sgn0(y) = 1 on the first branch, 0 on the second
+    // Montgomery (xn / xd, y) -> Edwards: x = c1 (xn / xd) / y, y = (xn - xd) / (xn + xd); a zero denominator -> (0, 1)
+    fe xne, xde, yne, yde, z;
+    fe_mul(xne, xn, fe_elligator_c1());
+    fe_mul(xde, xd, y);
+    fe_sub(yne, xn, xd);
+    fe_add(yde, xn, xd);
+    fe_mul(z, xde, yde);
+    const bool exc = !fe_isnonzero(z);
+    fe_mul(q.X, xne, yde);
+    fe_mul(q.Y, yne, xde);
+    fe_mul(q.T, xne, yne);
+    q.Z = z;
+    fe_0(t);
+    fe_cmov(q.X, t, exc);
+    fe_cmov(q.T, t, exc);
+    fe_cmov(q.Y, one, exc);
+    fe_cmov(q.Z, one, exc);
 }
 // (*point).Hash: 32-byte encoding of 8 * (map(u0) + map(u1))
 KYB_DEV void ed_hash_wire(uint8_t* out, const uint8_t* msg, size_t msg_len, const EdDstArg& dst) {
