@@ -32,6 +32,10 @@ def test_ed25519_consts():
     assert vals["sqrtm1"] == O.SQRT_M1
     assert (vals["bx"], vals["by"]) == O.B
     assert vals["bt"] == O.B[0] * O.B[1] % O.P
+    # the two constants of the straight-line Elligator 2 (RFC 9380 appendix G.2): c1 = sqrt(-486664) with sgn0 = 0,
+    # c2 = 2^((p + 3) / 8)
+    assert vals["elligator_c1"] ** 2 % O.P == (-486664) % O.P and vals["elligator_c1"] % 2 == 0
+    assert vals["elligator_c2"] == pow(2, (O.P + 3) // 8, O.P)
 
 
 # ------------------------------------------------------------------ pairing-curve parameter headers
@@ -234,3 +238,23 @@ def test_bn256_twist_cofactor_and_the_criterion_that_would_gate_gls():
         for mu in roots(t, p, q):
             assert (mu * mu - t * mu + p) % q == 0
             assert ((u + 1) + u * mu + u * mu * mu - 2 * u * mu**3) % q != 0
+
+
+def test_bls12381_hash_to_curve_square_root_constants():
+    """the constants that let one power serve both branches of an SSWU map (round 5): sqrt(-Z) on G1 (RFC 9380 F.2.1.2),
+    sqrt(-N(Z)^3) in Fp on G2 (the norm root of g(x2) from the norm root of g(x1)); Z must be what makes them exist"""
+    from oracle import bls12381 as B
+    from oracle import bls12381_h2c_consts as HC
+
+    arr, _, _ = _parse_params("bls12381_params.h")
+    R = 1 << 390
+    src = open(os.path.join(CSRC, "bls12381_h2c_params.h")).read()
+    get = lambda name: [int(x.rstrip("u"), 16) for x in re.findall(r"0x[0-9a-f]+u", re.search(name + r"\[12\] = (\{.*?\});", src).group(1))]
+    mont = lambda words: _val(words, 32) * pow(R, -1, B.P) % B.P
+    c = mont(get("G1_SQRT_NEG_Z"))
+    assert c * c % B.P == (-HC.G1_Z) % B.P
+    assert pow(HC.G1_Z % B.P, (B.P - 1) // 2, B.P) == B.P - 1          # Z is no square, -Z is one (p = 3 mod 4)
+    nz = (HC.G2_Z[0] ** 2 + HC.G2_Z[1] ** 2) % B.P
+    assert pow(nz, (B.P - 1) // 2, B.P) == B.P - 1                       # N(Z) is no square in Fp <=> Z is none in Fp2
+    c = mont(get("G2_SQRT_NEG_NZ3"))
+    assert c * c % B.P == (-pow(nz, 3, B.P)) % B.P
