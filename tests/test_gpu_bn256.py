@@ -326,3 +326,26 @@ def test_validate_pairing_product_form_with_the_zero_miller_fallback():
     assert not np.asarray(st).any()
     assert [bool(v) for v in np.asarray(ok)] == want
     assert want[4] and want[64 + 36] and not want[2]  # (the both-zero case IS true in the reference)
+
+
+@pytest.mark.parametrize("n", [(1 << 17) + 5, (1 << 18) + 77, (1 << 19) + 1])
+def test_hash_g1_large_batches_take_the_queued_kernel_and_agree_with_the_per_lane_one(bn, n):
+    """pointG1.Hash (try-and-increment, point.go:261-313) for n >= 2^17 runs with the pending candidates of 128 / 256 / 512
+    messages queued per wave in LDS (bn256.hip bn256_hash_g1_queue_kernel); smaller batches keep one message per lane.
+    Same bytes either way: the large batch against itself hashed in 2^16-message pieces, a ragged last workgroup
+    included, and first / last / strided messages against the oracle."""
+    import hashlib
+
+    import torch
+
+    msgs = np.frombuffer(hashlib.shake_256(b"bn256/hash/queue/%d" % n).digest(n * 32), dtype=np.uint8).reshape(n, 32).copy()
+    d = torch.from_numpy(msgs).cuda()
+    out, st = bn.batch_hash_g1(d)
+    assert not st.any().item()
+    step = 1 << 16
+    for lo in range(0, n, step):
+        o2, s2 = bn.batch_hash_g1(d[lo:lo + step].contiguous())
+        assert not s2.any().item() and torch.equal(out[lo:lo + step], o2), lo
+    got = out.cpu().numpy()
+    for i in [0, 1, n - 2, n - 1] + list(range(4099, n - 2, n // 13)):
+        assert bytes(got[i]) == O.g1_marshal(O.hash_to_g1(bytes(msgs[i]))), i
