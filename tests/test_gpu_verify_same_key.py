@@ -198,14 +198,18 @@ def test_alternating_between_a_handful_of_keys_costs_a_copy_not_a_walk(bls):
         assert not st.any().item() and int(ok.sum().item()) == (n - 1 if j == 1 else n)
     _, steady = timed(lambda: bls.batch_verify_g1_same_key(keys[0], msgs, sigs[0]), 7)
     steady_ms = sorted(steady)[len(steady) // 2]
-    seq = [1, 2, 0, 2, 1, 0, 1, 2]
-    worst = 0.0
+    seq = [1, 2, 0, 2, 1, 0, 1, 2, 0, 1]
+    times = []
     for j in seq:
         (ok, st), ts = timed(lambda: bls.batch_verify_g1_same_key(keys[j], msgs, sigs[j]), 1)
         assert not st.any().item() and int(ok.sum().item()) == (n - 1 if j == 1 else n)
         assert (ok[5].item() == 0) == (j == 1)
-        worst = max(worst, ts[0])
-    assert worst <= 1.2 * steady_ms + 0.3, (worst, steady_ms)  # + 0.3 ms: launch jitter of a 7 ms call
+        times.append(ts[0])
+    # a walk costs ~9 ms on top of a ~7 ms call (2.3 x): the typical switch must stay within 1.2 x the steady state, and no
+    # single one may look like a walk (the looser bound absorbs a scheduling hiccup on a shared box)
+    times.sort()
+    assert times[len(times) // 2] <= 1.2 * steady_ms + 0.3, (times, steady_ms)
+    assert times[-1] <= 1.8 * steady_ms + 0.5, (times, steady_ms)
     # a key signatures do not belong to, between two cached ones: still rejected
     ok, _ = bls.batch_verify_g1_same_key(keys[2], msgs, sigs[0])
     assert not ok.any().item()
