@@ -298,6 +298,29 @@ def bncheck():
     assert [bool(v) for v in np.asarray(ok)] == [True, False, True, False] * 20
 
 
+def bnhash():
+    """bn256 pointG1.Hash for a batch large enough for the queued kernel (default), the per-lane kernel
+    (KYB_BN_HASH_QUEUE=0) or a forced number of messages per wave (KYB_BN_HASH_HQ): oracle lanes + a digest that must
+    (computed once with oracle/bn256.py hash_to_g1 over all 131 081 messages) that holds whichever kernel ran"""
+    import hashlib
+
+    import torch
+
+    from kyber_amd.pairing import bn256 as bn
+    from oracle import bn256 as ON
+
+    n = (1 << 17) + 9
+    msgs = np.frombuffer(hashlib.shake_256(b"switch/bnhash").digest(n * 32), dtype=np.uint8).reshape(n, 32).copy()
+    out, st = bn.batch_hash_g1(torch.from_numpy(msgs).cuda())
+    assert not st.any().item()
+    got = out.cpu().numpy()
+    for i in [0, 1, n - 1] + list(range(777, n, n // 9)):
+        assert bytes(got[i]) == ON.g1_marshal(ON.hash_to_g1(bytes(msgs[i]))), i
+    assert hashlib.sha256(got.tobytes()).hexdigest()[:16] == BNHASH_DIGEST, hashlib.sha256(got.tobytes()).hexdigest()[:16]
+
+
+BNHASH_DIGEST = "86f1a16dd7b32606"
+
 if __name__ == "__main__":
-    {"fb": fb, "msm": msm, "lvm": lvm, "bncheck": bncheck, "pipe": pipe, "g1split": g1split, "unmw2": unmw2, "hashw2": hashw2}[sys.argv[1]]()
+    {"bnhash": bnhash, "fb": fb, "msm": msm, "lvm": lvm, "bncheck": bncheck, "pipe": pipe, "g1split": g1split, "unmw2": unmw2, "hashw2": hashw2}[sys.argv[1]]()
     print("switch-probe ok", sys.argv[1])

@@ -13,6 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [
     ("fb", {}), ("fb", {"KYB_FB_MIN": "0"}), ("fb", {"KYB_FB_MIN": "1000"}),
     ("msm", {"KYB_MSM_TAIL": "coop"}), ("msm", {"KYB_MSM_TAIL": "lane"}), ("msm", {"KYB_MSM_SUB": "64"}),
+    ("msm", {"KYB_MSM_CHUNK": "16"}), ("msm", {"KYB_MSM_CHUNK": "4"}),
+    ("bnhash", {}), ("bnhash", {"KYB_BN_HASH_QUEUE": "0"}), ("bnhash", {"KYB_BN_HASH_HQ": "512"}),
     ("pipe", {}), ("pipe", {"KYB_PIPE_CHUNK": "4096", "KYB_PIPE_STREAMS": "1"}), ("pipe", {"KYB_PIPE_CHUNK": "4096", "KYB_PIPE_STREAMS": "3"}),
     ("unmw2", {}), ("unmw2", {"KYB_UNM_W2": "0"}), ("hashw2", {}), ("hashw2", {"KYB_UNM_W2": "0"}),
     ("g1split", {}), ("g1split", {"KYB_G1_SPLIT": "0"}),
