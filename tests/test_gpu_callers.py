@@ -285,3 +285,32 @@ def test_g1_poly_eval_at_2p16_against_the_oracle(suite):
         for c in reversed(cs):
             v = (v * x + c) % order
         assert bytes(out[lane]) == enc(OR.g1_mul(v, OR.G1_GEN)), (suite, lane)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("suite", ["bls12381", "bn256"])
+def test_g2_poly_eval_at_2p14_against_the_oracle(suite):
+    """the same direct comparison on the KEY group of the signature schemes (tbls.Recover evaluates its public polynomial
+    on G2: sign/tbls/tbls.go:124, share/poly.go:340-348): kyb_<suite>_g2_poly_eval at 2^14 indices, oracle lanes"""
+    import importlib
+
+    m = importlib.import_module("kyber_amd.pairing." + suite)
+    OR = importlib.import_module("oracle." + suite)
+    order = OR.R if suite == "bls12381" else OR.ORDER
+    enc = OR.g2_compress if suite == "bls12381" else OR.g2_marshal
+    rng = random.Random(92)
+    t, n = 4, 1 << 14
+    cs = [rng.randrange(order) for _ in range(t)]
+    commits = b"".join(enc(OR.g2_mul(c, OR.G2_GEN)) for c in cs)
+    idx = np.arange(n, dtype=np.uint32)
+    idx[-1] = (1 << 32) - 1
+    out, st = m.ENGINE.poly_eval(2, commits, idx)
+    assert not st.any() and out.shape == (n, m.G2_LEN)
+    lanes = [0, 1, n - 2, n - 1] + list(range(311, n - 2, n // 29))
+    assert len(lanes) >= 32
+    for lane in lanes:
+        x = int(idx[lane]) + 1
+        v = 0
+        for c in reversed(cs):
+            v = (v * x + c) % order
+        assert bytes(out[lane]) == enc(OR.g2_mul(v, OR.G2_GEN)), (suite, lane)
