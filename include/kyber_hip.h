@@ -235,8 +235,8 @@ int kyb_bls12381_verify_g1_dev(size_t n, const void *d_pubkeys, const void *d_ms
  * pointer in the first variant, a device pointer in `_dev`): sign/bls/bls.go:82-96 called in a loop with the same X --
  * a drand chain's beacons, the partial signatures of one tbls participant (sign/tbls/tbls.go:100-107).  With both G2
  * operands the same for every element, both Miller loops read their lines from tables (the generator's is a constant of
- * the program; the key's is built on the device the first time a key is seen and reused while the key stays the same --
- * compared on the device, per stream).  The key is checked as UnmarshalBinary would (KYB_F_TRUSTED(0) vouches for it);
+ * the program; the key's is built on the device the first time a key is seen and kept with those of the last eight keys
+ * of the stream -- looked up on the device -- so that a verifier alternating between a few keys pays the walk once per key).  The key is checked as UnmarshalBinary would (KYB_F_TRUSTED(0) vouches for it);
  * a key that fails gives every element its status and ok = 0; status precedence per element: key, then signature. */
 int kyb_bls12381_verify_g1_same_key(size_t n, const uint8_t *pubkey, const uint8_t *msgs, size_t msg_len,
                                     const uint8_t *dst, size_t dst_len, const uint8_t *sigs, uint8_t *ok,
