@@ -590,3 +590,250 @@ void ora_bls12381_pair(size_t n, const uint8_t *g1, const uint8_t *g2, uint8_t *
     free(th);
     free(jobs);
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * G1Elt.Mul / G2Elt.Mul (kilic/g1.go:110-116, g2.go:109-115) element-wise, for whole-batch digests at BASELINE.json
+ * configs[3]'s size.  The backend's scalar multiplication is external (kilic v0.1.0 MulScalar); what is observable is
+ * the canonical ZCash encoding of k P, so this is the textbook MSB-first double-and-add of the in-tree bn256 suite
+ * (pairing/bn256/curve.go:69-203: add-2007-bl, dbl-2009-l) on y^2 = x^3 + 4 resp. y^2 = x^3 + 4 (1 + i), between
+ * UnmarshalBinary's decompression (kilic/g1.go:127-131: flag rules, x < p, a square root -- WITHOUT the r-torsion test,
+ * which oracle/bls12381.py holds; inputs here are multiples of the generator) and MarshalBinary's compression.
+ * Held byte for byte against oracle/bls12381.py by tests/test_oracle_bls12381_c.py. */
+#define DEFINE_JAC(N, F, ADD, SUB, MUL, SQR, ISZ)                                                                     \
+    typedef struct { F x, y, z; } N;                                                                                  \
+    static void N##_double(N *c, const N *a) {                                                                        \
+        F A, B, C, t, t2, d, e, f;                                                                                    \
+        N r;                                                                                                          \
+        SQR(&A, &a->x); SQR(&B, &a->y); SQR(&C, &B);                                                                  \
+        ADD(&t, &a->x, &B); SQR(&t2, &t); SUB(&t, &t2, &A); SUB(&t2, &t, &C); ADD(&d, &t2, &t2);                      \
+        ADD(&t, &A, &A); ADD(&e, &t, &A); SQR(&f, &e);                                                                \
+        ADD(&t, &d, &d); SUB(&r.x, &f, &t);                                                                           \
+        MUL(&r.z, &a->y, &a->z); ADD(&r.z, &r.z, &r.z);                                                               \
+        ADD(&t, &C, &C); ADD(&t2, &t, &t); ADD(&t, &t2, &t2);                                                         \
+        SUB(&r.y, &d, &r.x); MUL(&t2, &e, &r.y); SUB(&r.y, &t2, &t);                                                  \
+        *c = r;                                                                                                       \
+    }                                                                                                                 \
+    static void N##_add(N *c, const N *a, const N *b) {                                                               \
+        if (ISZ(&a->z)) { *c = *b; return; }                                                                          \
+        if (ISZ(&b->z)) { *c = *a; return; }                                                                          \
+        F z12, z22, u1, u2, t, s1, s2, h, i, j, r, v, t4, t6;                                                         \
+        N o;                                                                                                          \
+        SQR(&z12, &a->z); SQR(&z22, &b->z); MUL(&u1, &a->x, &z22); MUL(&u2, &b->x, &z12);                             \
+        MUL(&t, &b->z, &z22); MUL(&s1, &a->y, &t); MUL(&t, &a->z, &z12); MUL(&s2, &b->y, &t);                         \
+        SUB(&h, &u2, &u1);                                                                                            \
+        const int x_equal = ISZ(&h);                                                                                  \
+        ADD(&t, &h, &h); SQR(&i, &t); MUL(&j, &h, &i); SUB(&t, &s2, &s1);                                             \
+        if (x_equal && ISZ(&t)) { N##_double(c, a); return; }                                                         \
+        ADD(&r, &t, &t); MUL(&v, &u1, &i); SQR(&t4, &r); ADD(&t, &v, &v); SUB(&t6, &t4, &j); SUB(&o.x, &t6, &t);      \
+        SUB(&t, &v, &o.x); MUL(&t4, &s1, &j); ADD(&t6, &t4, &t4); MUL(&t4, &r, &t); SUB(&o.y, &t4, &t6);              \
+        ADD(&t, &a->z, &b->z); SQR(&t4, &t); SUB(&t, &t4, &z12); SUB(&t4, &t, &z22); MUL(&o.z, &t4, &h);              \
+        *c = o;                                                                                                       \
+    }                                                                                                                 \
+    static void N##_mul(N *c, const N *a, const N *inf, const uint8_t *scalar_be) {                                   \
+        N sum = *inf, t;                                                                                              \
+        int top = -1;                                                                                                 \
+        for (int i = 0; i < 256; i++)                                                                                 \
+            if ((scalar_be[i >> 3] >> (7 - (i & 7))) & 1) { top = 255 - i; break; }                                   \
+        for (int i = top; i >= 0; i--) {                                                                              \
+            N##_double(&t, &sum);                                                                                     \
+            if ((scalar_be[31 - (i >> 3)] >> (i & 7)) & 1) N##_add(&sum, &t, a);                                      \
+            else sum = t;                                                                                             \
+        }                                                                                                             \
+        *c = sum;                                                                                                     \
+    }
+DEFINE_JAC(jg1, fq, fq_add, fq_sub, fq_mul, fq_sqr, fq_is_zero)
+DEFINE_JAC(jg2, fq2, f2_add, f2_sub, f2_mul, f2_sqr, f2_is_zero)
+
+static u64 Q_HALF[NL];      /* (q - 1) / 2 */
+static u64 Q_SQRT_E[NL];    /* (q + 1) / 4 */
+static pthread_once_t mul_once = PTHREAD_ONCE_INIT;
+static void mul_init(void) {
+    pthread_once(&pair_once, pair_init);
+    u64 t[NL];
+    memcpy(t, Q, sizeof t);
+    t[0] -= 1;
+    for (int i = 0; i < NL; i++) Q_HALF[i] = (t[i] >> 1) | (i + 1 < NL ? t[i + 1] << 63 : 0);
+    memcpy(t, Q, sizeof t);
+    t[0] += 1;  /* q = 3 mod 4 and its low word does not overflow */
+    for (int i = 0; i < NL; i++) Q_SQRT_E[i] = (t[i] >> 2) | (i + 1 < NL ? t[i + 1] << 62 : 0);
+}
+static void fq_pow_words(fq *r, const fq *a, const u64 *e) {
+    fq acc = Q_ONE, base = *a;
+    for (int i = 0; i < 64 * NL; i++) {
+        if ((e[i >> 6] >> (i & 63)) & 1) fq_mul(&acc, &acc, &base);
+        fq_mul(&base, &base, &base);
+    }
+    *r = acc;
+}
+static int fq_eq(const fq *a, const fq *b) { return !memcmp(a, b, sizeof(fq)); }
+static int fq_sqrt(fq *r, const fq *a) { /* 1 if a is a square: r = a^((q + 1) / 4) */
+    fq s, c;
+    fq_pow_words(&s, a, Q_SQRT_E);
+    fq_sqr(&c, &s);
+    *r = s;
+    return fq_eq(&c, a);
+}
+static int fq_larger(const fq *a) { /* the "lexicographically largest" rule of the ZCash encoding: a > (q - 1) / 2 */
+    fq one = {{1, 0, 0, 0, 0, 0}}, t;
+    fq_mul(&t, a, &one);
+    for (int i = NL - 1; i >= 0; i--) {
+        if (t.v[i] > Q_HALF[i]) return 1;
+        if (t.v[i] < Q_HALF[i]) return 0;
+    }
+    return 0;
+}
+static int f2_larger(const fq2 *a) { return fq_is_zero(&a->c1) ? fq_larger(&a->c0) : fq_larger(&a->c1); }
+/* square root in Fp2 = Fp[i]/(i^2 + 1) by the complex method: with n = a0^2 + a1^2 = s^2, x0^2 = (a0 + s) / 2 (or
+ * (a0 - s) / 2 when that is no square), x1 = a1 / (2 x0) */
+static int f2_sqrt(fq2 *r, const fq2 *a) {
+    fq n, t, s, two_inv, x0, x1;
+    if (fq_is_zero(&a->c1)) {
+        if (fq_sqrt(&x0, &a->c0)) { r->c0 = x0; memset(&r->c1, 0, sizeof(fq)); return 1; }
+        fq_neg(&t, &a->c0);
+        if (!fq_sqrt(&x1, &t)) return 0;
+        memset(&r->c0, 0, sizeof(fq));
+        r->c1 = x1;
+        return 1;
+    }
+    fq_sqr(&n, &a->c0);
+    fq_sqr(&t, &a->c1);
+    fq_add(&n, &n, &t);
+    if (!fq_sqrt(&s, &n)) return 0;
+    fq_add(&t, &Q_ONE, &Q_ONE);
+    fq_inv(&two_inv, &t);
+    fq_add(&t, &a->c0, &s);
+    fq_mul(&t, &t, &two_inv);
+    if (!fq_sqrt(&x0, &t)) {
+        fq_sub(&t, &a->c0, &s);
+        fq_mul(&t, &t, &two_inv);
+        if (!fq_sqrt(&x0, &t)) return 0;
+    }
+    fq_add(&t, &x0, &x0);
+    fq_inv(&t, &t);
+    fq_mul(&x1, &a->c1, &t);
+    r->c0 = x0;
+    r->c1 = x1;
+    fq2 c;
+    f2_sqr(&c, r);
+    return fq_eq(&c.c0, &a->c0) && fq_eq(&c.c1, &a->c1);
+}
+/* the flag rules of the compressed form (bls12381_test.go:74-186's fixtures): bit 7 set, bit 6 = infinity (then bit 5
+ * and every other bit clear), bit 5 = the larger y.  Returns 0 finite, 1 infinity, 2 error. */
+static int zc_flags(const uint8_t *in, size_t len, int *sign) {
+    if (!(in[0] & 0x80)) return 2;
+    *sign = (in[0] >> 5) & 1;
+    if (in[0] & 0x40) {
+        if (in[0] & 0x3f) return 2;
+        for (size_t i = 1; i < len; i++) if (in[i]) return 2;
+        return 1;
+    }
+    return 0;
+}
+static int jg1_decompress(jg1 *p, const uint8_t *in) {
+    int sign;
+    const int k = zc_flags(in, 48, &sign);
+    if (k) return k;
+    fq rhs, four;
+    if (!fq_from_be(&p->x, in, 1)) return 2;
+    fq_sqr(&rhs, &p->x);
+    fq_mul(&rhs, &rhs, &p->x);
+    fq_add(&four, &Q_ONE, &Q_ONE);
+    fq_add(&four, &four, &four);
+    fq_add(&rhs, &rhs, &four);
+    if (!fq_sqrt(&p->y, &rhs)) return 2;
+    if (fq_larger(&p->y) != sign) fq_neg(&p->y, &p->y);
+    p->z = Q_ONE;
+    return 0;
+}
+static int jg2_decompress(jg2 *p, const uint8_t *in) {
+    int sign;
+    const int k = zc_flags(in, 96, &sign);
+    if (k) return k;
+    fq2 rhs, b;
+    if (!fq_from_be(&p->x.c1, in, 1) || !fq_from_be(&p->x.c0, in + 48, 0)) return 2;
+    f2_sqr(&rhs, &p->x);
+    f2_mul(&rhs, &rhs, &p->x);
+    fq_add(&b.c0, &Q_ONE, &Q_ONE);
+    fq_add(&b.c0, &b.c0, &b.c0);
+    b.c1 = b.c0;  /* 4 (1 + i) */
+    f2_add(&rhs, &rhs, &b);
+    if (!f2_sqrt(&p->y, &rhs)) return 2;
+    if (f2_larger(&p->y) != sign) f2_neg(&p->y, &p->y);
+    memset(&p->z, 0, sizeof p->z);
+    p->z.c0 = Q_ONE;
+    return 0;
+}
+static void jg1_compress(uint8_t *out, const jg1 *c) {
+    if (fq_is_zero(&c->z)) { memset(out, 0, 48); out[0] = 0xc0; return; }
+    fq zi, zi2, x, y;
+    fq_inv(&zi, &c->z);
+    fq_sqr(&zi2, &zi);
+    fq_mul(&x, &c->x, &zi2);
+    fq_mul(&zi2, &zi2, &zi);
+    fq_mul(&y, &c->y, &zi2);
+    fq_to_be(out, &x);
+    out[0] |= 0x80 | (fq_larger(&y) ? 0x20 : 0);
+}
+static void jg2_compress(uint8_t *out, const jg2 *c) {
+    if (f2_is_zero(&c->z)) { memset(out, 0, 96); out[0] = 0xc0; return; }
+    fq2 zi, zi2, x, y;
+    f2_inv(&zi, &c->z);
+    f2_sqr(&zi2, &zi);
+    f2_mul(&x, &c->x, &zi2);
+    f2_mul(&zi2, &zi2, &zi);
+    f2_mul(&y, &c->y, &zi2);
+    fq_to_be(out, &x.c1);
+    fq_to_be(out + 48, &x.c0);
+    out[0] |= 0x80 | (f2_larger(&y) ? 0x20 : 0);
+}
+typedef struct { size_t lo, hi; const uint8_t *k, *p; uint8_t *out, *st; int g; } mjob;
+static void *mul_worker(void *arg) {
+    mjob *j = (mjob *)arg;
+    for (size_t i = j->lo; i < j->hi; i++) {
+        if (j->g == 1) {
+            jg1 p, inf, r;
+            memset(&inf, 0, sizeof inf);
+            inf.y = Q_ONE;
+            const int s = jg1_decompress(&p, j->p + 48 * i);
+            if (j->st) j->st[i] = (uint8_t)(s == 2);
+            if (s == 2) { memset(j->out + 48 * i, 0, 48); continue; }
+            if (s == 1) p = inf;
+            jg1_mul(&r, &p, &inf, j->k + 32 * i);
+            jg1_compress(j->out + 48 * i, &r);
+        } else {
+            jg2 p, inf, r;
+            memset(&inf, 0, sizeof inf);
+            inf.y.c0 = Q_ONE;
+            const int s = jg2_decompress(&p, j->p + 96 * i);
+            if (j->st) j->st[i] = (uint8_t)(s == 2);
+            if (s == 2) { memset(j->out + 96 * i, 0, 96); continue; }
+            if (s == 1) p = inf;
+            jg2_mul(&r, &p, &inf, j->k + 32 * i);
+            jg2_compress(j->out + 96 * i, &r);
+        }
+    }
+    return NULL;
+}
+static void mul_run(int g, size_t n, const uint8_t *k, const uint8_t *p, uint8_t *out, uint8_t *st, int threads) {
+    pthread_once(&mul_once, mul_init);
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > n) threads = n ? (int)n : 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+    mjob *jobs = (mjob *)malloc(sizeof(mjob) * (size_t)threads);
+    for (int t = 0; t < threads; t++) {
+        jobs[t] = (mjob){n * (size_t)t / (size_t)threads, n * (size_t)(t + 1) / (size_t)threads, k, p, out, st, g};
+        pthread_create(&th[t], NULL, mul_worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    free(th);
+    free(jobs);
+}
+/* out[i] = k_i P_i: 32-byte big-endian scalars (plain 256-bit integers), 48-byte compressed points in and out;
+ * status 1 = the encoding is rejected (flags, x >= p, not on the curve) */
+void ora_bls12381_g1_mul(size_t n, const uint8_t *scalars_be, const uint8_t *points, uint8_t *out, uint8_t *status, int threads) {
+    mul_run(1, n, scalars_be, points, out, status, threads);
+}
+/* the same on G2: 96-byte compressed points */
+void ora_bls12381_g2_mul(size_t n, const uint8_t *scalars_be, const uint8_t *points, uint8_t *out, uint8_t *status, int threads) {
+    mul_run(2, n, scalars_be, points, out, status, threads);
+}

@@ -18,8 +18,11 @@
  *   curve.go:69-203   curvePoint.Add (add-2007-bl) / Double (dbl-2009-l) / Mul (MSB-first double-and-add from BitLen())
  *   point.go:170-238, 423-499, 630-662   wire formats of G1 / G2 / GT
  *
+ *   twist.go:75-205   twistPoint.Add / Double / Mul / MakeAffine (the same formulas over gfP2), point.go:405-452
+ *
  * Entry points (ctypes, tests/_oracle_c.py): ora_bn256_pair (n pairings, threaded), ora_bn256_g1_mul_sum
- * (sum_i k_i P_i the reference's way: N x (Mul + Add), threaded partial sums).  */
+ * (sum_i k_i P_i the reference's way: N x (Mul + Add), threaded partial sums), ora_bn256_g1_mul / ora_bn256_g2_mul
+ * (element-wise pointG1 / pointG2.Mul, for whole-batch digests at BASELINE.json configs[4]'s size).  */
 #include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -858,4 +861,123 @@ static void *mul_worker(void *arg) {
 void ora_bn256_g1_mul(size_t n, const uint8_t *scalars_be, const uint8_t *points, uint8_t *out, uint8_t *status, int threads) {
     job t = {0, 0, scalars_be, points, out, status};
     run_jobs(mul_worker, &t, n, threads);
+}
+
+/* ---- twist.go: twistPoint.Add (:75-141, add-2007-bl), Double (:143-170, dbl-2009-l), Mul (:172-185, MSB-first
+ * double-and-add from BitLen()), MakeAffine (:187-205); pointG2.Mul / MarshalBinary point.go:405-452.  The t
+ * coordinate is not maintained by these functions in the reference either (only by the line functions). */
+static void twist_set_inf(twist *c) { memset(c, 0, sizeof *c); f2_one(&c->y); }
+static void twist_double(twist *c, const twist *a) {
+    fp2 A, B, C, t, t2, d, e, f;
+    twist r;
+    memset(&r, 0, sizeof r);
+    f2_sqr(&A, &a->x);
+    f2_sqr(&B, &a->y);
+    f2_sqr(&C, &B);
+    f2_add(&t, &a->x, &B);
+    f2_sqr(&t2, &t);
+    f2_sub(&t, &t2, &A);
+    f2_sub(&t2, &t, &C);
+    f2_add(&d, &t2, &t2);
+    f2_add(&t, &A, &A);
+    f2_add(&e, &t, &A);
+    f2_sqr(&f, &e);
+    f2_add(&t, &d, &d);
+    f2_sub(&r.x, &f, &t);
+    f2_mul(&r.z, &a->y, &a->z);
+    f2_add(&r.z, &r.z, &r.z);
+    f2_add(&t, &C, &C);
+    f2_add(&t2, &t, &t);
+    f2_add(&t, &t2, &t2);
+    f2_sub(&r.y, &d, &r.x);
+    f2_mul(&t2, &e, &r.y);
+    f2_sub(&r.y, &t2, &t);
+    *c = r;
+}
+static void twist_add(twist *c, const twist *a, const twist *b) {
+    if (f2_is_zero(&a->z)) { *c = *b; return; }
+    if (f2_is_zero(&b->z)) { *c = *a; return; }
+    fp2 z12, z22, u1, u2, t, s1, s2, h, i, j, r, v, t4, t6;
+    twist o;
+    memset(&o, 0, sizeof o);
+    f2_sqr(&z12, &a->z);
+    f2_sqr(&z22, &b->z);
+    f2_mul(&u1, &a->x, &z22);
+    f2_mul(&u2, &b->x, &z12);
+    f2_mul(&t, &b->z, &z22);
+    f2_mul(&s1, &a->y, &t);
+    f2_mul(&t, &a->z, &z12);
+    f2_mul(&s2, &b->y, &t);
+    f2_sub(&h, &u2, &u1);
+    const int x_equal = f2_is_zero(&h);
+    f2_add(&t, &h, &h);
+    f2_sqr(&i, &t);
+    f2_mul(&j, &h, &i);
+    f2_sub(&t, &s2, &s1);
+    if (x_equal && f2_is_zero(&t)) { twist_double(c, a); return; }
+    f2_add(&r, &t, &t);
+    f2_mul(&v, &u1, &i);
+    f2_sqr(&t4, &r);
+    f2_add(&t, &v, &v);
+    f2_sub(&t6, &t4, &j);
+    f2_sub(&o.x, &t6, &t);
+    f2_sub(&t, &v, &o.x);
+    f2_mul(&t4, &s1, &j);
+    f2_add(&t6, &t4, &t4);
+    f2_mul(&t4, &r, &t);
+    f2_sub(&o.y, &t4, &t6);
+    f2_add(&t, &a->z, &b->z);
+    f2_sqr(&t4, &t);
+    f2_sub(&t, &t4, &z12);
+    f2_sub(&t4, &t, &z22);
+    f2_mul(&o.z, &t4, &h);
+    *c = o;
+}
+static void twist_mul(twist *c, const twist *a, const uint8_t *scalar_be) {
+    twist sum, t;
+    twist_set_inf(&sum);
+    int top = -1;
+    for (int i = 0; i < 256; i++)
+        if ((scalar_be[i >> 3] >> (7 - (i & 7))) & 1) { top = 255 - i; break; }
+    for (int i = top + 1; i >= 0; i--) {
+        twist_double(&t, &sum);
+        const int bit = i <= 255 ? (scalar_be[31 - (i >> 3)] >> (i & 7)) & 1 : 0;
+        if (bit) twist_add(&sum, &t, a);
+        else sum = t;
+    }
+    *c = sum;
+}
+/* MakeAffine + MarshalBinary (point.go:422-452): x.x, x.y, y.x, y.y big-endian; infinity = 128 zero bytes */
+static void twist_to_bytes(uint8_t *out, const twist *c) {
+    if (f2_is_zero(&c->z)) { memset(out, 0, 128); return; }
+    fp2 zi, zi2, x, y, t;
+    f2_inv(&zi, &c->z);
+    f2_mul(&t, &c->y, &zi);
+    f2_sqr(&zi2, &zi);
+    f2_mul(&y, &t, &zi2);
+    f2_mul(&x, &c->x, &zi2);
+    fp_to_be(out, &x.x);
+    fp_to_be(out + 32, &x.y);
+    fp_to_be(out + 64, &y.x);
+    fp_to_be(out + 96, &y.y);
+}
+/* out[i] = k_i Q_i (pointG2.Mul, point.go:405-420): 32 + 128 bytes in, 128 bytes out; status 1 = UnmarshalBinary's
+ * "malformed point" (on-curve only, never the subgroup: twist.go:49-60) */
+static void *g2_mul_worker(void *arg) {
+    job *jb = arg;
+    twist q, kq;
+    int inf;
+    for (size_t i = jb->lo; i < jb->hi; i++) {
+        const int s = twist_from_bytes(&q, &inf, jb->b + 128 * i);
+        if (jb->status) jb->status[i] = (uint8_t)s;
+        if (s) { memset(jb->out + 128 * i, 0, 128); continue; }
+        if (inf) twist_set_inf(&q);
+        twist_mul(&kq, &q, jb->a + 32 * i);
+        twist_to_bytes(jb->out + 128 * i, &kq);
+    }
+    return NULL;
+}
+void ora_bn256_g2_mul(size_t n, const uint8_t *scalars_be, const uint8_t *points, uint8_t *out, uint8_t *status, int threads) {
+    job t = {0, 0, scalars_be, points, out, status};
+    run_jobs(g2_mul_worker, &t, n, threads);
 }

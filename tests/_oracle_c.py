@@ -24,7 +24,8 @@ def lib():
         l.ora_ed25519_mul.restype = None
         l.ora_ed25519_msm.argtypes = [sz, vp, vp, vp]
         l.ora_ed25519_msm.restype = C.c_long
-        for name in ("ora_bn256_pair", "ora_bn256_g1_mul_sum", "ora_bn256_g1_mul", "ora_bls12381_g1_mul_sum", "ora_bls12381_pair"):
+        for name in ("ora_bn256_pair", "ora_bn256_g1_mul_sum", "ora_bn256_g1_mul", "ora_bn256_g2_mul", "ora_bls12381_g1_mul_sum",
+                     "ora_bls12381_pair", "ora_bls12381_g1_mul", "ora_bls12381_g2_mul"):
             f = getattr(l, name)
             f.argtypes = [sz, vp, vp, vp, vp, i]
             f.restype = None
@@ -105,3 +106,28 @@ def bls12381_pair(g1_unc, g2_unc, threads: int = 0):
     st = np.empty(len(a), dtype=np.uint8)
     lib().ora_bls12381_pair(len(a), a.ctypes.data, b.ctypes.data, out.ctypes.data, st.ctypes.data, threads or (os.cpu_count() or 1))
     return out, st
+
+
+def _mul(fn, scalars, points, plen, threads):
+    s = np.ascontiguousarray(np.frombuffer(scalars, dtype=np.uint8) if isinstance(scalars, (bytes, bytearray)) else scalars, dtype=np.uint8).reshape(-1, 32)
+    p = np.ascontiguousarray(np.frombuffer(points, dtype=np.uint8) if isinstance(points, (bytes, bytearray)) else points, dtype=np.uint8).reshape(-1, plen)
+    assert len(s) == len(p)
+    out = np.empty((len(s), plen), dtype=np.uint8)
+    st = np.empty(len(s), dtype=np.uint8)
+    fn(len(s), s.ctypes.data, p.ctypes.data, out.ctypes.data, st.ctypes.data, threads or (os.cpu_count() or 1))
+    return out, st
+
+
+def bn256_g2_mul(scalars, points, threads: int = 0):
+    """(out, status): pointG2.Mul element-wise (twist.go:172-185 restated in oracle/bn256_ref.c), 128-byte points"""
+    return _mul(lib().ora_bn256_g2_mul, scalars, points, 128, threads)
+
+
+def bls12381_g1_mul(scalars, points, threads: int = 0):
+    """(out, status): G1Elt.Mul element-wise, 48-byte compressed points in and out (oracle/bls12381_pair_ref.c)"""
+    return _mul(lib().ora_bls12381_g1_mul, scalars, points, 48, threads)
+
+
+def bls12381_g2_mul(scalars, points, threads: int = 0):
+    """(out, status): G2Elt.Mul element-wise, 96-byte compressed points in and out"""
+    return _mul(lib().ora_bls12381_g2_mul, scalars, points, 96, threads)

@@ -99,3 +99,34 @@ def test_bls12381_g1_mul_sum_matches_the_python_oracle():
     bad[96 * 3] |= 0x80   # compression flag on an uncompressed encoding
     out, st = OC.bls12381_g1_mul_sum(kb, np.frombuffer(bytes(bad), dtype=np.uint8), threads=2)
     assert st[3] == 1 and st.sum() == 1
+
+
+def test_g2_mul_matches_the_python_restatement():
+    """ora_bn256_g2_mul (twist.go:75-205 restated in C) against oracle/bn256.py: edge scalars as plain 256-bit integers,
+    the point at infinity, a point of the twist outside the order-n subgroup (accepted by UnmarshalBinary, point.go:466-499),
+    a point off the curve"""
+    rng = random.Random(41)
+    ks = [0, 1, 2, O.ORDER - 1, O.ORDER, O.ORDER + 1, (1 << 256) - 1, 1 << 255] + [rng.randrange(1 << 256) for _ in range(4)]
+    pts = [O.g2_mul(rng.randrange(1, O.ORDER), O.G2_GEN) for _ in ks]
+    pts[2] = None
+    enc = [O.g2_marshal(p) for p in pts]
+    x0 = 1
+    while True:  # a twist point outside the subgroup: any curve point is, with overwhelming probability
+        x = (x0, 1)
+        y = O.f2_sqrt(O.f2_add(O.f2_mul(O.f2_mul(x, x), x), O.TWIST_B))
+        if y is not None:
+            pts[9] = (x, y)
+            enc[9] = O.g2_marshal(pts[9])
+            break
+        x0 += 1
+    assert O.g2_mul(O.ORDER, pts[9]) is not None
+    k = b"".join(v.to_bytes(32, "big") for v in ks)
+    for threads in (1, 4):
+        out, st = OC.bn256_g2_mul(k, b"".join(enc), threads=threads)
+        assert not st.any()
+        for i, (v, p) in enumerate(zip(ks, pts)):
+            assert bytes(out[i]) == O.g2_marshal(O.g2_mul(v, p)), (threads, i)
+    bad = bytearray(enc[0])
+    bad[127] ^= 1
+    out, st = OC.bn256_g2_mul(k[:32], bytes(bad), threads=1)
+    assert st[0] == 1 and not out.any()
