@@ -837,3 +837,85 @@ void ora_bls12381_g1_mul(size_t n, const uint8_t *scalars_be, const uint8_t *poi
 void ora_bls12381_g2_mul(size_t n, const uint8_t *scalars_be, const uint8_t *points, uint8_t *out, uint8_t *status, int threads) {
     mul_run(2, n, scalars_be, points, out, status, threads);
 }
+
+/* sum_i k_i P_i over COMPRESSED points, the reference's way -- N x (Point.Mul + Point.Add), share/poly.go:340-348,
+ * 449-476, sign/bdn/bdn.go:126-161 -- one partial sum per thread; out = the 48-byte compressed sum.  The same inputs
+ * the engine's MSM takes at BASELINE.json configs[2] (80 bytes per point). */
+typedef struct { size_t lo, hi; const uint8_t *k, *p; uint8_t *st; jg1 acc; } sjob;
+static void *sum_worker(void *arg) {
+    sjob *j = (sjob *)arg;
+    jg1 inf, p, kp;
+    memset(&inf, 0, sizeof inf);
+    inf.y = Q_ONE;
+    j->acc = inf;
+    for (size_t i = j->lo; i < j->hi; i++) {
+        const int s = jg1_decompress(&p, j->p + 48 * i);
+        if (j->st) j->st[i] = (uint8_t)(s == 2);
+        if (s) continue;
+        jg1_mul(&kp, &p, &inf, j->k + 32 * i);
+        jg1_add(&j->acc, &j->acc, &kp);
+    }
+    return NULL;
+}
+void ora_bls12381_g1_mul_sum_compressed(size_t n, const uint8_t *scalars_be, const uint8_t *points, uint8_t *out, uint8_t *status, int threads) {
+    pthread_once(&mul_once, mul_init);
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > n) threads = n ? (int)n : 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+    sjob *jobs = (sjob *)malloc(sizeof(sjob) * (size_t)threads);
+    for (int t = 0; t < threads; t++) {
+        jobs[t].lo = n * (size_t)t / (size_t)threads;
+        jobs[t].hi = n * (size_t)(t + 1) / (size_t)threads;
+        jobs[t].k = scalars_be;
+        jobs[t].p = points;
+        jobs[t].st = status;
+        pthread_create(&th[t], NULL, sum_worker, &jobs[t]);
+    }
+    jg1 acc;
+    memset(&acc, 0, sizeof acc);
+    acc.y = Q_ONE;
+    for (int t = 0; t < threads; t++) {
+        pthread_join(th[t], NULL);
+        jg1_add(&acc, &acc, &jobs[t].acc);
+    }
+    jg1_compress(out, &acc);
+    free(th);
+    free(jobs);
+}
+
+/* n x Suite.Pair over COMPRESSED operands (48 + 96 bytes, what UnmarshalBinary takes): decompression as above, then the
+ * pairing of this file; status 1 = a rejected encoding */
+static void *cpair_worker(void *arg) {
+    job *j = (job *)arg;
+    for (size_t i = j->lo; i < j->hi; i++) {
+        jg1 p;
+        jg2 q;
+        const int s1 = jg1_decompress(&p, j->g1 + 48 * i), s2 = jg2_decompress(&q, j->g2 + 96 * i);
+        uint8_t *gt = j->gt + 576 * i;
+        j->st[i] = (uint8_t)(s1 == 2 || s2 == 2);
+        if (j->st[i]) { memset(gt, 0, 576); continue; }
+        fq12 f, e;
+        if (s1 == 1 || s2 == 1) {
+            f12_one(&e);
+        } else {
+            miller_loop(&f, &p.x, &p.y, &q.x, &q.y);
+            final_exp(&e, &f);
+        }
+        gt_to_bytes(gt, &e);
+    }
+    return NULL;
+}
+void ora_bls12381_pair_compressed(size_t n, const uint8_t *g1, const uint8_t *g2, uint8_t *gt, uint8_t *status, int threads) {
+    pthread_once(&mul_once, mul_init);
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > n) threads = n ? (int)n : 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+    job *jobs = (job *)malloc(sizeof(job) * (size_t)threads);
+    for (int t = 0; t < threads; t++) {
+        jobs[t] = (job){n * (size_t)t / (size_t)threads, n * (size_t)(t + 1) / (size_t)threads, g1, g2, gt, status};
+        pthread_create(&th[t], NULL, cpair_worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    free(th);
+    free(jobs);
+}

@@ -25,7 +25,8 @@ def lib():
         l.ora_ed25519_msm.argtypes = [sz, vp, vp, vp]
         l.ora_ed25519_msm.restype = C.c_long
         for name in ("ora_bn256_pair", "ora_bn256_g1_mul_sum", "ora_bn256_g1_mul", "ora_bn256_g2_mul", "ora_bls12381_g1_mul_sum",
-                     "ora_bls12381_pair", "ora_bls12381_g1_mul", "ora_bls12381_g2_mul"):
+                     "ora_bls12381_pair", "ora_bls12381_g1_mul", "ora_bls12381_g2_mul", "ora_bls12381_g1_mul_sum_compressed",
+                     "ora_bls12381_pair_compressed"):
             f = getattr(l, name)
             f.argtypes = [sz, vp, vp, vp, vp, i]
             f.restype = None
@@ -131,3 +132,39 @@ def bls12381_g1_mul(scalars, points, threads: int = 0):
 def bls12381_g2_mul(scalars, points, threads: int = 0):
     """(out, status): G2Elt.Mul element-wise, 96-byte compressed points in and out"""
     return _mul(lib().ora_bls12381_g2_mul, scalars, points, 96, threads)
+
+
+def bls12381_g1_mul_sum_compressed(scalars, points, threads: int = 0):
+    """(sum, status): sum_i k_i P_i by N x (Mul + Add) over 48-byte compressed points; the 48-byte compressed sum"""
+    s = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, 32)
+    p = np.ascontiguousarray(points, dtype=np.uint8).reshape(-1, 48)
+    out = np.empty(48, dtype=np.uint8)
+    st = np.zeros(len(s), dtype=np.uint8)
+    lib().ora_bls12381_g1_mul_sum_compressed(len(s), s.ctypes.data, p.ctypes.data, out.ctypes.data, st.ctypes.data, threads or host_threads())
+    return out, st
+
+
+def bls12381_pair_compressed(g1, g2, threads: int = 0):
+    """(gt, status): n x Suite.Pair over compressed operands (48 + 96 bytes), kilic's 576-byte GT encoding out"""
+    a = np.ascontiguousarray(np.frombuffer(g1, dtype=np.uint8) if isinstance(g1, (bytes, bytearray)) else g1, dtype=np.uint8).reshape(-1, 48)
+    b = np.ascontiguousarray(np.frombuffer(g2, dtype=np.uint8) if isinstance(g2, (bytes, bytearray)) else g2, dtype=np.uint8).reshape(-1, 96)
+    out = np.empty((len(a), 576), dtype=np.uint8)
+    st = np.empty(len(a), dtype=np.uint8)
+    lib().ora_bls12381_pair_compressed(len(a), a.ctypes.data, b.ctypes.data, out.ctypes.data, st.ctypes.data, threads or host_threads())
+    return out, st
+
+
+def host_threads() -> int:
+    """threads worth starting on this host: the affinity mask capped by the cgroup CPU quota (a GPU lease shows every
+    logical CPU of the machine to os.cpu_count() and grants a fraction of them)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n

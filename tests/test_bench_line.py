@@ -75,3 +75,31 @@ def test_emit_prints_one_line_and_writes_detail(tmp_path, capsys, monkeypatch):
     assert out.count("\n") == 1 and len(out) < bench.LINE_LIMIT
     assert json.loads(out)["detail_file"] == "bench_detail.json"
     assert "other_workloads" in json.load(open(tmp_path / "bench_detail.json"))
+
+
+def test_an_oversized_line_loses_optional_keys_not_the_run():
+    """emit() asserted the length after the whole benchmark had run.  A record whose optional parts are too long
+    (error strings, a long CPU model) still yields a parseable line with the contract keys, marked `truncated`."""
+    full = _full_record()
+    line = bench.compact_line(full)
+    line["other_workloads_error"] = "x" * 3000
+    line["cpu_baseline"]["cpu_model"] = "y" * 1500
+    s = bench.fit_line(line)
+    back = json.loads(s)
+    assert len(s) < bench.LINE_LIMIT and back["truncated"] is True
+    for k in REQUIRED:
+        assert k in back, k
+    assert back["value"] == full["value"] and back["roofline"]["frac"] is not None
+    assert "truncated" not in json.loads(bench.fit_line(bench.compact_line(full)))
+
+
+def test_full_batch_digest_checks_reach_the_line():
+    full = _full_record()
+    ok = {"outputs_match": True, "outputs_compared": 1 << 16, "cpu_per_s": 9000.0}
+    full.setdefault("cpu_baseline", {}).setdefault("other_workloads", {})["full_batch_digests"] = {
+        "bls12381": {"pair": ok, "g1_mul": ok, "g2_mul": dict(ok, outputs_match=False)},
+        "bn256": {"error": "boom"},
+        "bls12381_g1_msm_2p20": {"outputs_match": True, "outputs_compared": 1 << 20, "cpu_seconds": 3.5}}
+    c = bench.compact_line(full)["checks"]
+    assert c["bls12381_pair_full"] == 1 << 16 and c["bls12381_g1_mul_full"] == 1 << 16 and c["bls12381_g2_mul_full"] is False
+    assert c["msm_2p20_full"] == 1 << 20 and c["full_error"].startswith("bn256: boom")

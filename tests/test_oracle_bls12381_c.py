@@ -107,3 +107,21 @@ def test_mul_decompression_follows_the_flag_rules():
             assert (st[0] == 0) == good, (group, case.get("name"))
             if good:
                 assert bytes(out[0]) == buf
+
+
+def test_compressed_pair_and_sum_match_the_uncompressed_entry_points():
+    rng = random.Random(33)
+    pairs = _pairs(rng, 3) + [(None, O.G2_GEN), (O.G1_GEN, None)]
+    gt_u, _ = OC.bls12381_pair(b"".join(O.g1_serialize_unc(p) for p, _ in pairs), b"".join(O.g2_serialize_unc(q) for _, q in pairs), threads=2)
+    gt_c, st = OC.bls12381_pair_compressed(b"".join(O.g1_compress(p) for p, _ in pairs), b"".join(O.g2_compress(q) for _, q in pairs), threads=2)
+    assert not st.any() and (gt_u == gt_c).all()
+    ks = [rng.randrange(1 << 256) for _ in range(7)]
+    pts = [O.g1_mul(rng.randrange(1, O.R), O.G1_GEN) for _ in ks]
+    pts[2] = None
+    k = np.frombuffer(b"".join(x.to_bytes(32, "big") for x in ks), dtype=np.uint8)
+    acc = None
+    for x, p in zip(ks, pts):
+        acc = O.g1_add(acc, O.g1_mul(x, p))
+    for threads in (1, 3):
+        out, st = OC.bls12381_g1_mul_sum_compressed(k, np.frombuffer(b"".join(O.g1_compress(p) for p in pts), dtype=np.uint8), threads=threads)
+        assert not st.any() and bytes(out) == O.g1_compress(acc)
