@@ -39,7 +39,7 @@ N_PER_GPU = 1 << 20
 # algorithmic bytes per unit: var-base 32+32 in, 32 out; fixed-base 32 in, 32 out
 BYTES_VAR, BYTES_FIX = 96, 64
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-IMAD_4CYCLE_PEAK = 256 * 4 * 16 / 4 * 2.4e9  # one 64-bit multiply-add per lane every 4 cycles at 2.4 GHz: 3.93e13 lane-MAD/s
+IMAD_4CYCLE_PEAK = 256 * 4 * 64 / 4 * 2.4e9  # a wave's 64 multiply-adds issue over 4 cycles on each of 1 024 SIMDs at 2.4 GHz: 3.93e13 lane-MAD/s
 REF_SINGLE_CORE_PER_S = 2.0 / (349399e-9 + 60658e-9)
 # 64-bit integer multiply-adds (v_mad_i64_i32) per scalar multiplication as built:
 # a field multiplication is 100 MADs, a squaring 55.  With an in-kernel ToBytes, variable-base = 1366 M + 1517 S
@@ -845,7 +845,7 @@ def main():
                          "traffic_ratio": (ked["hbm_bytes_per_launch"] / (BYTES_VAR * ked.get("units_per_launch", n))) if ked.get("hbm_bytes_per_launch") else None,
                          "hbm_frac_counters": (ked["hbm_bytes_per_launch"] * (n / ked.get("units_per_launch", n)) / var_s / 1e9 / HBM_PEAK_GBS) if ked.get("hbm_bytes_per_launch") else None,
                          # the denominator of `frac` is the MEASURED dependent v_mad_u64_u32 rate; against the paper figure
-                         # (256 CUs x 4 SIMDs x 16 lanes / 4 cycles x 2.4 GHz = 3.93e13 lane-MAD/s) the fraction is:
+                         # (256 CUs x 4 SIMDs x 64 lanes / 4 cycles x 2.4 GHz = 3.93e13 lane-MAD/s) the fraction is:
                          "frac_vs_4cycle_issue": IMADS_VAR * n / var_s / IMAD_4CYCLE_PEAK,
                          "hbm": {"achieved": BYTES_VAR * n / var_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": BYTES_VAR * n / var_s / 1e9 / HBM_PEAK_GBS}},

@@ -835,3 +835,19 @@ func Bn254HashG1(n int, msgs []byte, msgLen int, dst []byte) (out, status []byte
 	})
 	return
 }
+
+// Bn256HashG1: the package-level bn256.HashG1 (pairing/bn256/hash.go:10-110: HKDF-SHA-256 to the base field, then the
+// Shallue-van de Woestijne map) for n messages of msgLen bytes; dst may be nil (hash_test.go:11-20).
+func Bn256HashG1(n int, msgs []byte, msgLen int, dst []byte) (out, status []byte, err error) {
+	if err = messages(msgs, msgLen, n); err != nil {
+		return nil, nil, err
+	}
+	if len(dst) > 255 {
+		return nil, nil, fmt.Errorf("kyberhip: domain separation tag of %d bytes (at most 255)", len(dst))
+	}
+	out, status = make([]byte, 64*n), make([]byte, n)
+	err = call(func() C.int {
+		return C.kyb_bn256_hash_g1_svdw(C.size_t(n), ptr(msgs), C.size_t(msgLen), ptr(dst), C.size_t(len(dst)), ptr(out), ptr(status))
+	})
+	return
+}

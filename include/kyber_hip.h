@@ -319,6 +319,15 @@ int kyb_bn256_pair_dev(size_t n, const void *d_g1, const void *d_g2, void *d_gt,
  * have the same length msg_len and are packed back to back (hash variable-length inputs down first). */
 int kyb_bn256_hash_g1(size_t n, const uint8_t *msgs, size_t msg_len, uint8_t *out, uint8_t *status);
 int kyb_bn256_hash_g1_dev(size_t n, const void *d_msgs, size_t msg_len, void *d_out, void *d_status, void *stream);
+/* out[i] = HashG1(msgs[i], dst): the package-level hash of pairing/bn256/hash.go:10-110 -- hashToBase (gfp.go:46-68:
+ * 48 bytes of HKDF-SHA-256 with secret = msg, salt = dst, info = "H2C" 0x00 0x01, reduced mod p) then the
+ * Shallue-van de Woestijne map in the reference's arrangement (x1, x2, x3 tried in this order with legendre == 1,
+ * y = the power (p + 1) / 4 with sign0(t)'s sign; s = sqrt(-3) of constants.go:105).  dst may be NULL / empty
+ * (hash_test.go:11-20 passes nil), at most 255 bytes.  Pinned by the 11 outputs of hash_test.go:45-57. */
+int kyb_bn256_hash_g1_svdw(size_t n, const uint8_t *msgs, size_t msg_len, const uint8_t *dst, size_t dst_len, uint8_t *out,
+                           uint8_t *status);
+int kyb_bn256_hash_g1_svdw_dev(size_t n, const void *d_msgs, size_t msg_len, const uint8_t *dst, size_t dst_len, void *d_out,
+                               void *d_status, void *stream);
 /* out[i] = gt[i] ^ scalars[i]: pointGT.Mul (pairing/bn256/point.go:613-628 -> gfP12.Exp gfp12.go:177);
  * like pointGT.UnmarshalBinary (point.go:664-716) coefficients are reduced mod p and nothing is rejected. */
 int kyb_bn256_gt_mul(size_t n, const uint8_t *scalars, const uint8_t *gt, uint8_t *out, uint8_t *status);

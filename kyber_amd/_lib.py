@@ -96,6 +96,8 @@ SIGNATURES = {
     "kyb_bn256_pair": [_sz, _vp, _vp, _vp, _vp, _u32],
     "kyb_bn256_hash_g1": [_sz, _vp, _sz, _vp, _vp],
     "kyb_bn256_hash_g1_dev": [_sz, _vp, _sz, _vp, _vp, _vp],
+    "kyb_bn256_hash_g1_svdw": [_sz, _vp, _sz, _vp, _sz, _vp, _vp],
+    "kyb_bn256_hash_g1_svdw_dev": [_sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp],
     "kyb_bn256_gt_mul": [_sz, _vp, _vp, _vp, _vp],
     "kyb_bn256_gt_mul_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
     "kyb_bn256_pair_dev": [_sz, _vp, _vp, _vp, _vp, _u32, _vp],

@@ -183,3 +183,51 @@ int kyb_bn256_hash_g1(size_t n, const uint8_t* msgs, size_t msg_len, uint8_t* ou
     return KYB_OK;
 }
 }
+
+// ---- HashG1 (pairing/bn256/hash.go:10-110): HKDF-SHA-256 + Shallue-van de Woestijne, no divergent retry loop
+namespace kyb {
+__global__ __launch_bounds__(64, KYB_TU_WAVES) void bn256_hash_g1_svdw_kernel(size_t n, const uint8_t* __restrict__ msgs, size_t msg_len, DstArg dst,
+                                                                uint8_t* __restrict__ out, uint8_t* __restrict__ status) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int st = bn::hash_g1_svdw_wire(out + 64 * idx, msgs + msg_len * idx, msg_len, dst);
+    if (status) status[idx] = (uint8_t)st;
+}
+}  // namespace kyb
+extern "C" {
+int kyb_bn256_hash_g1_svdw_dev(size_t n, const void* d_msgs, size_t msg_len, const uint8_t* dst, size_t dst_len, void* d_out,
+                               void* d_status, void* stream) {
+    if ((n && ((!d_msgs && msg_len) || !d_out)) || dst_len > 255 || (dst_len && !dst)) {
+        kyb::set_error("kyb_bn256_hash_g1_svdw_dev: bad argument (the domain separation tag is at most 255 bytes)");
+        return KYB_E_ARG;
+    }
+    kyb::DstArg d;
+    memset(&d, 0, sizeof d);
+    if (dst_len) memcpy(d.b, dst, dst_len);
+    d.len = (uint32_t)dst_len;
+    if (!n) return KYB_OK;
+    hipLaunchKernelGGL(kyb::bn256_hash_g1_svdw_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n,
+                       (const uint8_t*)d_msgs, msg_len, d, (uint8_t*)d_out, (uint8_t*)d_status);
+    KYB_HIP_CHECK(hipGetLastError());
+    return KYB_OK;
+}
+int kyb_bn256_hash_g1_svdw(size_t n, const uint8_t* msgs, size_t msg_len, const uint8_t* dst, size_t dst_len, uint8_t* out,
+                           uint8_t* status) {
+    if ((n && ((!msgs && msg_len) || !out)) || dst_len > 255 || (dst_len && !dst)) {
+        kyb::set_error("kyb_bn256_hash_g1_svdw: bad argument (the domain separation tag is at most 255 bytes)");
+        return KYB_E_ARG;
+    }
+    if (!n) return KYB_OK;
+    kyb::DeviceCtx* ctx;
+    KYB_TRY(kyb::get_ctx(&ctx));
+    kyb::StageScope sc_(ctx);
+    kyb::StageBuf m, o, st;
+    KYB_TRY(m.upload(msgs, n * msg_len));
+    KYB_TRY(o.alloc(n * 64));
+    KYB_TRY(st.alloc(n));
+    KYB_TRY(kyb_bn256_hash_g1_svdw_dev(n, m.p, msg_len, dst, dst_len, o.p, st.p, nullptr));
+    KYB_TRY(o.download(out, n * 64));
+    if (status) KYB_TRY(st.download(status, n));
+    return KYB_OK;
+}
+}

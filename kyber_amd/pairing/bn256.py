@@ -82,3 +82,51 @@ def batch_hash_g1(msgs, msg_len: int | None = None):
     st = np.empty(n, dtype=np.uint8)
     check(lib.kyb_bn256_hash_g1(n, buf.ctypes.data, ln, out.ctypes.data, st.ctypes.data), "kyb_bn256_hash_g1")
     return out, st
+
+
+def batch_hash_g1_svdw(msgs, dst: bytes = b""):
+    """(points, status): HashG1(msg, dst) for a batch -- the package-level hash of pairing/bn256/hash.go:10-110 (HKDF-SHA-256
+    to the base field, gfp.go:46-68, then the Shallue-van de Woestijne map).  `msgs` is a list of equal-length bytes
+    objects, or a packed (n, msg_len) uint8 array / CUDA tensor; `dst` the domain separation tag (hash_test.go passes nil)."""
+    import ctypes
+
+    import numpy as np
+
+    from .._lib import check, load
+    from ._engine import _is_torch, _stream
+
+    lib = load()
+    dst = bytes(dst or b"")
+    dbuf = ctypes.create_string_buffer(dst, len(dst)) if dst else None
+    dptr = ctypes.cast(dbuf, ctypes.c_void_p) if dst else None
+    if _is_torch(msgs):
+        import torch
+
+        m = msgs.contiguous()
+        n, ln = m.shape[0], m.shape[1]
+        out = torch.empty((n, 64), dtype=torch.uint8, device=m.device)
+        st = torch.empty(n, dtype=torch.uint8, device=m.device)
+        check(lib.kyb_bn256_hash_g1_svdw_dev(n, m.data_ptr(), ln, dptr, len(dst), out.data_ptr(), st.data_ptr(), _stream()),
+              "kyb_bn256_hash_g1_svdw_dev")
+        return out, st
+    if isinstance(msgs, (list, tuple)):
+        ln = len(msgs[0]) if msgs else 0
+        if any(len(x) != ln for x in msgs):
+            raise ValueError("batch_hash_g1_svdw: messages must have equal length")
+        n = len(msgs)
+        buf = np.frombuffer(b"".join(msgs), dtype=np.uint8)
+    else:
+        a = np.ascontiguousarray(msgs, dtype=np.uint8)
+        n, ln = a.shape[0], a.shape[1]
+        buf = a.reshape(-1)
+    buf = np.ascontiguousarray(buf) if buf.size else np.zeros(1, dtype=np.uint8)
+    out = np.empty((n, 64), dtype=np.uint8)
+    st = np.empty(n, dtype=np.uint8)
+    check(lib.kyb_bn256_hash_g1_svdw(n, buf.ctypes.data, ln, dptr, len(dst), out.ctypes.data, st.ctypes.data), "kyb_bn256_hash_g1_svdw")
+    return out, st
+
+
+def HashG1(msg: bytes, dst: bytes = b""):
+    """bn256.HashG1 (hash.go:10-12): one message -> a G1 point of this suite"""
+    out, st = batch_hash_g1_svdw([bytes(msg)], dst)
+    return G1Elt(bytes(out[0]))

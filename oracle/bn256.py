@@ -12,6 +12,8 @@ Big-integer restatement of pairing/bn256 (dclxvi parameters, NOT Ethereum's alt_
   point.go:423-499        G2 wire format (x.x || x.y || y.x || y.y with gfP2{x, y} = x i + y)
   point.go:630-662        GT wire format (12 x 32 bytes, x.x.x ... y.z.y)
   point.go:261-313        Hash: SHA-256 try-and-increment, y = t^((p+1)/4)
+  hash.go:10-110, gfp.go:46-68,137-164   HashG1: HKDF-SHA-256 to the base field, then the Shallue-van de Woestijne
+                          map in the reference's own arrangement (x1, x2, x3 in this order, legendre == 1, sign0)
 
 Element conventions here: Fp2 = (real, imag); an Fp12 element is the list [a_0..a_5] of Fp2
 coefficients of w^k (w = omega, w^2 = tau, w^6 = xi), i.e. gfP12{x, y} with gfP6{x, y, z} maps to
@@ -315,6 +317,66 @@ def hash_to_g1(m: bytes):
         if y * y % P == t:
             return (x, y)
         x = (x + 1) % P
+
+
+# s = sqrt(-3) as the reference chose it and (s - 1) / 2 (constants.go:104-108, de-Montgomerised; tests/golden/bn256.json
+# holds the extraction): which root is data -- the other root gives different points
+SVDW_S = 0x196AC037F07E9F9F10EFB671F725F42C373FE702B4D85525D
+SVDW_S_MINUS_1_OVER_2 = (SVDW_S - 1) * pow(2, -1, P) % P
+assert SVDW_S * SVDW_S % P == P - 3
+
+
+def hash_to_base(msg: bytes, dst: bytes = b"") -> int:
+    """hashToBase (gfp.go:46-68): 48 bytes of HKDF-SHA-256 (secret = msg, salt = dst, info = "H2C" 0x00 0x01) as a
+    big-endian integer mod p.  HKDF (RFC 5869): an empty salt is 32 zero bytes."""
+    import hmac
+
+    prk = hmac.new(dst if dst else bytes(32), msg, hashlib.sha256).digest()
+    info = b"H2C\x00\x01"
+    t1 = hmac.new(prk, info + b"\x01", hashlib.sha256).digest()
+    t2 = hmac.new(prk, t1 + info + b"\x02", hashlib.sha256).digest()
+    return int.from_bytes((t1 + t2)[:48], "big") % P
+
+
+def _sign0(x: int) -> int:
+    """sign0 (gfp.go:137-148): 1 when x >= (p - 1) / 2 ... the comparison falls through to 1 on equality"""
+    h = (P - 1) // 2
+    return 1 if x > h else (-1 if x < h else 1)
+
+
+def _legendre(x: int) -> int:
+    """legendre (gfp.go:150-164): x^((p - 1) / 2) as 2 (f & 1) - 1 on the residue, 0 for 0"""
+    f = pow(x, (P - 1) // 2, P)
+    return 0 if f == 0 else 2 * (f & 1) - 1
+
+
+def map_to_curve(t: int):
+    """mapToCurve (hash.go:14-110), statement by statement"""
+    a = (3 + t * t + 1) % P
+    st = SVDW_S * t % P
+    w0 = pow(st * a % P, P - 2, P)  # gfP.Invert = f^(p - 2): 0 stays 0
+    w = st * st % P * w0 % P
+    e = _sign0(t)
+
+    def finish(x):
+        y = pow((x * x * x + 3) % P, (P + 1) // 4, P)
+        if e != _sign0(y):
+            y = -y % P
+        return (x, y)
+
+    x1 = (SVDW_S_MINUS_1_OVER_2 - t * w) % P
+    if _legendre((x1 * x1 * x1 + 3) % P) == 1:
+        return finish(x1)
+    x2 = (-1 - x1) % P
+    if _legendre((x2 * x2 * x2 + 3) % P) == 1:
+        return finish(x2)
+    x3 = (pow(a, 4, P) * w0 % P * w0 + 1) % P
+    return finish(x3)
+
+
+def hash_g1_svdw(msg: bytes, dst: bytes = b""):
+    """HashG1 (hash.go:10-12)"""
+    return map_to_curve(hash_to_base(msg, dst))
 
 
 def g1_mul_bytes(scalar_be: bytes, pt: bytes) -> bytes:

@@ -12,6 +12,10 @@ Sources:
                                         + aggregated signature / key for mask {0, 2} (needs the BLAKE2Xs
                                         coefficients of bdn.go:29-63)
   pairing/bn256/point_test.go:13-45     two pointG1.Hash outputs
+  pairing/bn256/hash_test.go:11-20,45-57  TestKnownHashes: HashG1([]byte{i}, nil) for i = 0..10 (the Shallue-van de
+                                        Woestijne map of hash.go:10-110 over the HKDF of gfp.go:46-68)
+  pairing/bn256/constants.go:104-108    s = sqrt(-3) and (s - 1) / 2, de-Montgomerised here (which of the two roots the
+                                        reference chose is data, not derivable)
 """
 import json
 import os
@@ -37,6 +41,25 @@ m1 = re.search(r'Hash\(\[\]byte\("abc"\)\).*?DecodeString\("([0-9a-f]{128})"\)',
 hashes.append({"msg_hex": b"abc".hex(), "point": m1.group(1)})
 m2 = re.search(r'buf2, err := hex\.DecodeString\("([0-9a-f]{64})"\).*?refBuf2, err := hex\.DecodeString\("([0-9a-f]{128})"\)', pt, re.S)
 hashes.append({"msg_hex": m2.group(1), "point": m2.group(2)})
-json.dump({"bdn_coefs": coefs, "bdn_agg_key": agg, "bdn_pubs": pubs, "bdn_privs": privs, "bdn_sigs": sigs,
+ht = open(os.path.join(REF, "pairing/bn256/hash_test.go")).read()
+rows = re.findall(r"\[64\]byte\{([0-9, ]+)\}", ht[ht.index("var marshaledHashes"):])
+hash_svdw = [bytes(int(x) for x in r.split(",")).hex() for r in rows]
+assert len(hash_svdw) == 11 and all(len(h) == 128 for h in hash_svdw)
+cg = open(os.path.join(REF, "pairing/bn256/constants.go")).read()
+_U = 6518589491078791937
+_P = 36 * _U**4 + 36 * _U**3 + 24 * _U**2 + 6 * _U + 1
+
+
+def _demont(name):
+    w = re.search(r"var %s = &gfP\{(0x[0-9a-f]+), (0x[0-9a-f]+), (0x[0-9a-f]+), (0x[0-9a-f]+)\}" % name, cg).groups()
+    v = sum(int(x, 16) << (64 * i) for i, x in enumerate(w))
+    return v * pow(1 << 256, -1, _P) % _P
+
+
+svdw_s, svdw_h = _demont("s"), _demont("sMinus1Over2")
+assert svdw_s * svdw_s % _P == _P - 3 and (2 * svdw_h + 1) % _P == svdw_s
+json.dump({"hash_g1_svdw": [{"msg_hex": bytes([i]).hex(), "dst_hex": "", "point": h} for i, h in enumerate(hash_svdw)],
+           "svdw_s": "%064x" % svdw_s, "svdw_s_minus_1_over_2": "%064x" % svdw_h,
+           "bdn_coefs": coefs, "bdn_agg_key": agg, "bdn_pubs": pubs, "bdn_privs": privs, "bdn_sigs": sigs,
            "bdn_msg": msg, "bdn_fixture_agg_sig_mask101": agg_sig, "bdn_fixture_agg_key_mask101": agg_key, "hash_g1": hashes}, open(OUT, "w"), indent=1)
 print("ok", OUT)

@@ -456,6 +456,9 @@ static DstArg mk_dst(const uint8_t* dst, int len) {
 int hh_bn4_hash_g1(const uint8_t* msg, int len, const uint8_t* dst, int dlen, uint8_t* out) {
     return bn4::hash_g1_wire(out, msg, (size_t)len, mk_dst(dst, dlen));
 }
+int hh_bn_hash_g1_svdw(const uint8_t* msg, int len, const uint8_t* dst, int dlen, uint8_t* out) {
+    return bn::hash_g1_svdw_wire(out, msg, (size_t)len, mk_dst(dst, dlen));
+}
 int hh_bls_hash_g1(const uint8_t* msg, int len, const uint8_t* dst, int dlen, uint8_t* out) {
     return bls::hash_g1_wire(out, msg, (size_t)len, mk_dst(dst, dlen));
 }

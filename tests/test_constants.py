@@ -116,6 +116,14 @@ def test_bn_params(name):
         assert (k1 + k2 * lam - k) % N.ORDER == 0 and abs(k1) < 1 << 130 and abs(k2) < 1 << 130
     if name == "bn254":
         assert [mont(arr["SVDW_C%d" % i][0]) for i in (1, 2, 3, 4)] == [N.SVDW_C1, N.SVDW_C2, N.SVDW_C3, N.SVDW_C4]
+    if name == "bn256":  # HashG1's root of -3 (constants.go:105): the header, the oracle and the extracted golden value agree
+        import json
+        import os
+
+        g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bn256.json")))
+        assert mont(arr["SVDW_S"][0]) == N.SVDW_S == int(g["svdw_s"], 16)
+        assert mont(arr["SVDW_SM1D2"][0]) == N.SVDW_S_MINUS_1_OVER_2 == int(g["svdw_s_minus_1_over_2"], 16)
+    assert mont(arr["TWO256"][0]) == (1 << 256) % N.P
 
 
 def test_bn254_g2_subgroup_criterion_is_exact():

@@ -349,3 +349,28 @@ def test_hash_g1_large_batches_take_the_queued_kernel_and_agree_with_the_per_lan
     got = out.cpu().numpy()
     for i in [0, 1, n - 2, n - 1] + list(range(4099, n - 2, n // 13)):
         assert bytes(got[i]) == O.g1_marshal(O.hash_to_g1(bytes(msgs[i]))), i
+
+
+def test_hash_g1_svdw_known_hashes_and_batch(bn, G):
+    """bn256.HashG1 (pairing/bn256/hash.go:10-110) on the engine: the 11 outputs of hash_test.go:45-57 one by one and as
+    one batch, a 3000-message batch against the oracle on a stride, domain separation tags of every HMAC key class, host and
+    device buffers"""
+    import torch
+
+    msgs = [bytes.fromhex(v["msg_hex"]) for v in G["hash_g1_svdw"]]
+    out, st = bn.batch_hash_g1_svdw(msgs)
+    assert not np.asarray(st).any()
+    for i, v in enumerate(G["hash_g1_svdw"]):
+        assert bytes(out[i]).hex() == v["point"], i
+        assert bn.HashG1(msgs[i]).MarshalBinary().hex() == v["point"]
+    n = 3000
+    m = np.frombuffer(hashlib.shake_256(b"bn256/svdw").digest(n * 40), dtype=np.uint8).reshape(n, 40).copy()
+    for dst in (b"", b"x", b"kyberhip-test-tag", bytes(range(64)), bytes(range(65)), bytes(255)):
+        out_h, st_h = bn.batch_hash_g1_svdw(m, dst)
+        out_d, st_d = bn.batch_hash_g1_svdw(torch.from_numpy(m).cuda(), dst)
+        assert not np.asarray(st_h).any() and not st_d.any().item() and (out_d.cpu().numpy() == out_h).all()
+        for i in list(range(0, n, 211)) + [n - 1]:
+            assert bytes(out_h[i]) == O.g1_marshal(O.hash_g1_svdw(bytes(m[i]), dst)), (len(dst), i)
+    # every output is a point of the group (cofactor 1: on the curve is in G1)
+    pts, st = bn.g1_batch_unmarshal(out_h)
+    assert not np.asarray(st).any() and (np.asarray(pts) == out_h).all()

@@ -205,3 +205,27 @@ def test_fixed_base_table_multiplication_vs_oracle():
         assert st == 0
         for i, k in enumerate(ks):
             assert out[128 * i:128 * i + 128] == O.g2_marshal(O.g2_mul(k, Q)), hex(k)
+
+
+def test_hash_g1_svdw_reference_vectors_and_padding_boundaries(G):
+    """HashG1 (pairing/bn256/hash.go:10-110) through the device headers on the CPU: the 11 outputs of
+    hash_test.go:45-57 (TestKnownHashes: HashG1([]byte{i}, nil)), then message lengths around the SHA-256 / HMAC block
+    boundaries and domain separation tags of every key-length class (empty, short, one block, longer than a block) against
+    the oracle's restatement"""
+    for v in G["hash_g1_svdw"]:
+        msg, dst = bytes.fromhex(v["msg_hex"]), bytes.fromhex(v["dst_hex"])
+        assert H.call("hh_bn_hash_g1_svdw", msg, len(msg), dst or b"\x00", len(dst), out_sizes=(64,)) == (0, bytes.fromhex(v["point"]))
+    for ln in (0, 1, 31, 32, 54, 55, 56, 63, 64, 65, 119, 120, 200):
+        msg = bytes((5 * i + ln) & 0xFF for i in range(ln))
+        for dl in (0, 1, 13, 63, 64, 65, 128, 255):
+            dst = bytes((3 * i + dl) & 0xFF for i in range(dl))
+            want = O.g1_marshal(O.hash_g1_svdw(msg, dst))
+            assert H.call("hh_bn_hash_g1_svdw", msg or b"\x00", ln, dst or b"\x00", dl, out_sizes=(64,))[1] == want, (ln, dl)
+
+
+def test_svdw_map_edge_inputs():
+    """mapToCurve at t = 0 (w0 = 0: the inversion's 0 -> 0) and other fixed field elements, oracle-side: the restatement
+    lands on the curve for each and on x1 for t = 0 only when (s - 1) / 2 is a valid abscissa"""
+    for t in (0, 1, O.P - 1, 2, (O.P - 1) // 2, (O.P + 1) // 2):
+        x, y = O.map_to_curve(t)
+        assert (y * y - x * x * x - 3) % O.P == 0
