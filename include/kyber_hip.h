@@ -21,10 +21,11 @@
  *   - all entry points are thread-safe; state is a per-device context that is
  *     created on first use on the calling thread's current HIP device.
  *
- * TIMING: NOTHING IN THIS LIBRARY IS CONSTANT-TIME.  Results equal the
+ * TIMING: BY DEFAULT NOTHING IN THIS LIBRARY IS CONSTANT-TIME.  Results equal the
  * reference's on every input, but window tables are indexed by scalar digits
  * (through L2), exceptional additions branch, field inversion is a
- * data-dependent loop and KYB_F_VARTIME skips leading zero windows.  A suite
+ * data-dependent loop and KYB_F_VARTIME skips leading zero windows.  The one
+ * exception is opt-in: KYB_F_UNIFORM on the Ed25519 multiplications (below).  A suite
  * built on it belongs in suites/all_vartime.go only and must not be offered
  * where suites.RequireConstantTime (suites/suites.go:67) is expected to hold
  * (the reference's default Ed25519 Mul scans its table with CMove,
@@ -55,6 +56,16 @@ extern "C" {
                             group/edwards25519/ge_mult_vartime.go:11) and leading zero
                             windows skipped per wave. Default = the VALUE semantics of the reference's
                             constant-time path ge.go:443 incl. its >= 2^255 behaviour (not its timing). */
+
+#define KYB_F_UNIFORM 8u /* Ed25519 mul_base / mul / mul_same_base: scalar-INDEPENDENT memory addresses and control flow --
+                            the access pattern of the reference's default (constant-time) Mul, group/edwards25519/ge.go:352-371,
+                            419-435: every window reads ALL eight table candidates and keeps one by mask, the sign is a
+                            conditional move, no window is skipped; same value semantics as the default (incl. >= 2^255).
+                            For secret scalars: PriPoly.Commit's coefficients (share/poly.go:143-149), signing nonces
+                            (sign/eddsa/eddsa.go), DH.  mul_same_base builds the base's table at any batch size.  Costs
+                            ~2x on the fixed-base path (64 additions instead of 32) -- measured, DESIGN.md.  Exclusive with
+                            KYB_F_VARTIME.  It removes the digit-indexed loads and the scalar-dependent schedule; the
+                            library makes no formal constant-time claim (see TIMING above). */
 
 /* Pairing-suite calls (trailing `flags` argument of mul / msm / pair / pair_check / verify):
  *  KYB_F_UNCOMPRESSED  BLS12-381 point INPUTS are ZCash uncompressed affine (G1 96 B x||y, G2 192 B

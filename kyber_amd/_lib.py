@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KYBER_HIP_LIB") or os.path.join(_HERE, "lib", "libkyberhip.so")  # override: A/B builds
 
 KYB_F_VARTIME = 1
+KYB_F_UNIFORM = 8  # Ed25519: scalar-independent addresses and control flow (include/kyber_hip.h)
 ST_OK, ST_BAD_POINT, ST_NOT_IN_SUBGROUP = 0, 1, 2
 
 

@@ -239,6 +239,71 @@ __global__ __launch_bounds__(256, 3) void ed25519_mul_base_kernel(
     }
 }
 
+// KYB_F_UNIFORM: the fixed-base multiplication with memory addresses and control flow that do not depend on the scalar --
+// the shape of the reference's constant-time geScalarMultBase (ge.go:373-417 with selectPreComputed's CMove scan,
+// ge.go:352-371): one mixed addition per signed radix-16 digit, its operand picked by reading ALL eight candidates of
+// the digit's position (the same lines for every lane: the radix-256 table holds j 256^k B for j <= 136, so the
+// candidates m 16^(2k) B and m 16^(2k+1) B = 16 m 256^k B, m = 1..8, are its rows m - 1 and 16 m - 1) and keeping one
+// by mask; the sign by conditional move; no window skipped, no lane-dependent branch.  64 additions instead of 32 and
+// 240 selects per digit: the price of not indexing by the digit (measured: DESIGN.md section 5).
+KYB_DEV void select_precomp_uniform(ge_precomp& t, const int32_t* __restrict__ tab, int i, int b) {
+    const bool neg = b < 0;
+    const int babs = neg ? -b : b;
+    const int pos = i >> 1, mult = (i & 1) ? 16 : 1;
+    fe_1(t.ypx);
+    fe_1(t.ymx);
+    fe_0(t.xy2d);
+#pragma unroll 1
+    for (int m = 1; m <= 8; m++) {
+        const int4* e = reinterpret_cast<const int4*>(tab + (size_t)(pos * ED_TAB_ENT + (m * mult - 1)) * ED_TAB_STRIDE);
+        int32_t w[32];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int4 x = e[q];
+            w[4 * q] = x.x;
+            w[4 * q + 1] = x.y;
+            w[4 * q + 2] = x.z;
+            w[4 * q + 3] = x.w;
+        }
+        const int32_t keep = -(int32_t)(babs == m);  // all ones for the digit's own multiple
+#pragma unroll
+        for (int l = 0; l < 10; l++) {
+            t.ypx.v[l] ^= (t.ypx.v[l] ^ w[l]) & keep;
+            t.ymx.v[l] ^= (t.ymx.v[l] ^ w[10 + l]) & keep;
+            t.xy2d.v[l] ^= (t.xy2d.v[l] ^ w[20 + l]) & keep;
+        }
+    }
+    ge_precomp_cneg(t, neg);
+}
+__global__ __launch_bounds__(256, 3) void ed25519_mul_base_uniform_kernel(
+    size_t n, const uint32_t* __restrict__ scalars, uint32_t* __restrict__ out,
+    const int32_t* __restrict__ tab, int32_t* __restrict__ proj) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        uint32_t a[8];
+        load_words8(a, scalars + idx * 8);
+        int8_t e[65];
+        recode16(e, a, false);
+        ge_p3 h;
+        ge_p3_0(h);
+        ge_precomp t;
+        ge_p1p1 r;
+#pragma unroll 1
+        for (int i = 0; i < 64; i++) {
+            select_precomp_uniform(t, tab, i, (int)e[i]);
+            ge_madd(r, h, t);
+            ge_p1p1_to_p3(h, r);
+        }
+        if (proj) {
+            store_proj(proj, idx, h);
+            continue;
+        }
+        uint32_t w[8];
+        ge_p3_towords(w, h);
+        store_words8(out + idx * 8, w);
+    }
+}
+
 // --------------------------------------------------------- variable-base mul
 // Shared ladder: h = sum_i e[i] 16^i * A using an 8-entry cached table.  The table (8 x 160 B) is per-lane state
 // that fits neither registers nor LDS at a useful occupancy.  Small batches keep it in the lane's private (scratch)
@@ -281,12 +346,30 @@ struct TabGlobal {
             for (int l = 0; l < 10; l++) f[k]->v[l] = w[10 * k + l];
     }
 };
-template <class Tab>
+template <bool UNI = false, class Tab>
 KYB_DEV void select_cached(ge_cached& c, const Tab& tab, int b) {
     const bool neg = b < 0;
     const int babs = neg ? -b : b;
-    tab.get(c, babs ? babs - 1 : 0);
-    if (babs == 0) ge_cached_0(c);
+    if constexpr (UNI) {
+        // KYB_F_UNIFORM: selectCached's scan (ge.go:419-435) -- all eight entries read, one kept by mask
+        ge_cached_0(c);
+#pragma unroll 1
+        for (int m = 1; m <= 8; m++) {
+            ge_cached x;
+            tab.get(x, m - 1);
+            const int32_t keep = -(int32_t)(babs == m);
+#pragma unroll
+            for (int l = 0; l < 10; l++) {
+                c.YpX.v[l] ^= (c.YpX.v[l] ^ x.YpX.v[l]) & keep;
+                c.YmX.v[l] ^= (c.YmX.v[l] ^ x.YmX.v[l]) & keep;
+                c.Z.v[l] ^= (c.Z.v[l] ^ x.Z.v[l]) & keep;
+                c.T2d.v[l] ^= (c.T2d.v[l] ^ x.T2d.v[l]) & keep;
+            }
+        }
+    } else {
+        tab.get(c, babs ? babs - 1 : 0);
+        if (babs == 0) ge_cached_0(c);
+    }
     ge_cached_cneg(c, neg);
 }
 
@@ -317,7 +400,7 @@ KYB_DEV int wave_top_digit(const uint32_t a[8]) {
 // 128-bit coefficients of sign/bdn, small Lagrange indices -- run proportionally fewer windows) and a window whose
 // digit is zero in EVERY lane skips its addition and the conversion that feeds it.  Random 253-bit scalars take the
 // same 64 windows as the constant-structure path.
-template <class Tab>
+template <bool UNI = false, class Tab>
 KYB_DEV void ge_scalarmult_w4(ge_p3& h, const int8_t e[65], const ge_p3& A, bool full, Tab& tab, int vt_top) {
     ge_p1p1 t;
     ge_p3 u;
@@ -335,7 +418,7 @@ KYB_DEV void ge_scalarmult_w4(ge_p3& h, const int8_t e[65], const ge_p3& A, bool
     ge_p3_0(u);
     int top = 63;
     if (full) top = vt_top;  // uniform across the wave
-    select_cached(c, tab, e[top]);
+    select_cached<UNI>(c, tab, e[top]);
     ge_add(t, u, c);
 #pragma unroll 1
     for (int i = top - 1; i >= 0; i--) {
@@ -348,10 +431,10 @@ KYB_DEV void ge_scalarmult_w4(ge_p3& h, const int8_t e[65], const ge_p3& A, bool
         ge_p1p1_to_p2(r, t);
         ge_dbl(t, r.X, r.Y, r.Z);
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (full && __ballot(e[i] != 0) == 0) continue;  // no lane adds anything in this window
+        if (!UNI && full && __ballot(e[i] != 0) == 0) continue;  // no lane adds anything in this window
 #endif
         ge_p1p1_to_p3(u, t);
-        select_cached(c, tab, e[i]);
+        select_cached<UNI>(c, tab, e[i]);
         ge_add(t, u, c);
     }
     ge_p1p1_to_p3(h, t);
@@ -360,14 +443,15 @@ KYB_DEV void ge_scalarmult_w4(ge_p3& h, const int8_t e[65], const ge_p3& A, bool
 // points_stride = 8 words for per-element points, 0 for one shared base
 // Register budget for three waves per SIMD (<= 170 registers): the default allocation (160 VGPRs + 63 AGPRs of
 // spill space = 2 waves) was 7 % slower, a budget for four waves (128) 18 % slower (spills reach scratch).
-template <bool GTAB>
+// UNI (KYB_F_UNIFORM): the window table is scanned, not indexed -- geScalarMult's access pattern (ge.go:443-502)
+template <bool GTAB, bool UNI = false>
 __global__ __launch_bounds__(128, 3) void ed25519_mul_kernel(
     size_t n, const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ points,
     size_t points_stride, uint32_t* __restrict__ out, uint8_t* __restrict__ status,
     uint32_t flags, int32_t* __restrict__ proj, int4* __restrict__ gtab) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    const bool full = (flags & KYB_F_VARTIME) != 0;
+    const bool full = !UNI && (flags & KYB_F_VARTIME) != 0;
     uint32_t pw[8], a[8];
     load_words8(pw, points + idx * points_stride);
     load_words8(a, scalars + idx * 8);
@@ -379,10 +463,10 @@ __global__ __launch_bounds__(128, 3) void ed25519_mul_kernel(
     const int vt_top = full ? wave_top_digit(a) : 63;
     if constexpr (GTAB) {
         TabGlobal tab{gtab + idx * 80};
-        ge_scalarmult_w4(h, e, A, full, tab, vt_top);
+        ge_scalarmult_w4<UNI>(h, e, A, full, tab, vt_top);
     } else {
         TabScratch tab;
-        ge_scalarmult_w4(h, e, A, full, tab, vt_top);
+        ge_scalarmult_w4<UNI>(h, e, A, full, tab, vt_top);
     }
     if (proj) {  // encoding deferred to ed25519_encode_kernel (status carries the decode verdict)
         store_proj(proj, idx, h);
@@ -447,8 +531,12 @@ static int launch_mul_base(DeviceCtx* ctx, size_t n, const void* d_scalars, void
         int rc = ed_proj_workspace(ctx, st, n, false, &proj, nullptr);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(ed25519_mul_base_kernel, dim3(grid), dim3(block), 0, st, n,
-                       (const uint32_t*)d_scalars, (uint32_t*)d_out, tab, flags, proj);
+    if (flags & KYB_F_UNIFORM)
+        hipLaunchKernelGGL(ed25519_mul_base_uniform_kernel, dim3(grid), dim3(block), 0, st, n,
+                           (const uint32_t*)d_scalars, (uint32_t*)d_out, tab, proj);
+    else
+        hipLaunchKernelGGL(ed25519_mul_base_kernel, dim3(grid), dim3(block), 0, st, n,
+                           (const uint32_t*)d_scalars, (uint32_t*)d_out, tab, flags, proj);
     if (proj) {
         const size_t lanes = (n + ENC_CHUNK - 1) / ENC_CHUNK;
         hipLaunchKernelGGL(ed25519_encode_kernel, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, st, n, proj,
@@ -472,7 +560,16 @@ static int launch_mul(size_t n, const void* d_scalars, const void* d_points, siz
     if (n >= ENC_DEFER_MIN) {
         rc = ed_proj_workspace(ctx, st, n, stat == nullptr, &proj, stat ? nullptr : &stat, &gtab);
         if (rc) return rc;
-        hipLaunchKernelGGL(ed25519_mul_kernel<true>, dim3((unsigned)grid), dim3(block), 0, st, n,
+        if (flags & KYB_F_UNIFORM)
+            hipLaunchKernelGGL((ed25519_mul_kernel<true, true>), dim3((unsigned)grid), dim3(block), 0, st, n,
+                               (const uint32_t*)d_scalars, (const uint32_t*)d_points, stride, (uint32_t*)d_out, stat, flags,
+                               proj, gtab);
+        else
+            hipLaunchKernelGGL(ed25519_mul_kernel<true>, dim3((unsigned)grid), dim3(block), 0, st, n,
+                               (const uint32_t*)d_scalars, (const uint32_t*)d_points, stride, (uint32_t*)d_out, stat, flags,
+                               proj, gtab);
+    } else if (flags & KYB_F_UNIFORM) {
+        hipLaunchKernelGGL((ed25519_mul_kernel<false, true>), dim3((unsigned)grid), dim3(block), 0, st, n,
                            (const uint32_t*)d_scalars, (const uint32_t*)d_points, stride, (uint32_t*)d_out, stat, flags,
                            proj, gtab);
     } else {
@@ -493,10 +590,16 @@ static int launch_mul(size_t n, const void* d_scalars, const void* d_points, siz
 
 using namespace kyb;
 
+// flags of the scalar-multiplication entry points: KYB_F_VARTIME or KYB_F_UNIFORM, never both (one asks for the
+// scalar-dependent schedule, the other forbids it)
+static bool ed_mul_flags_bad(uint32_t flags) {
+    return (flags & ~(KYB_F_VARTIME | KYB_F_UNIFORM)) || (flags & (KYB_F_VARTIME | KYB_F_UNIFORM)) == (KYB_F_VARTIME | KYB_F_UNIFORM);
+}
+
 extern "C" {
 
 int kyb_ed25519_mul_base_dev(size_t n, const void* d_scalars, void* d_out, uint32_t flags, void* stream) {
-    if ((n && (!d_scalars || !d_out)) || (flags & ~KYB_F_VARTIME)) {
+    if ((n && (!d_scalars || !d_out)) || ed_mul_flags_bad(flags)) {
         set_error("kyb_ed25519_mul_base_dev: bad argument");
         return KYB_E_ARG;
     }
@@ -508,7 +611,7 @@ int kyb_ed25519_mul_base_dev(size_t n, const void* d_scalars, void* d_out, uint3
 
 int kyb_ed25519_mul_dev(size_t n, const void* d_scalars, const void* d_points, void* d_out, void* d_status,
                         uint32_t flags, void* stream) {
-    if ((n && (!d_scalars || !d_points || !d_out)) || (flags & ~KYB_F_VARTIME)) {
+    if ((n && (!d_scalars || !d_points || !d_out)) || ed_mul_flags_bad(flags)) {
         set_error("kyb_ed25519_mul_dev: bad argument");
         return KYB_E_ARG;
     }
@@ -522,7 +625,7 @@ static int mul_host(size_t n, const uint8_t* scalars, const uint8_t* points, siz
                     uint8_t* status, uint32_t flags);
 
 int kyb_ed25519_mul_base(size_t n, const uint8_t* scalars, uint8_t* out, uint32_t flags) {
-    if ((n && (!scalars || !out)) || (flags & ~KYB_F_VARTIME)) {
+    if ((n && (!scalars || !out)) || ed_mul_flags_bad(flags)) {
         set_error("kyb_ed25519_mul_base: bad argument");
         return KYB_E_ARG;
     }
@@ -582,7 +685,7 @@ static int mul_host(size_t n, const uint8_t* scalars, const uint8_t* points, siz
     if ((rc = d_o.alloc(n * 32))) return rc;
     if ((rc = d_st.alloc(n))) return rc;
     const int32_t* tab = nullptr;  // nullptr: the device's table of the standard base
-    if (!fixed && !stride && n >= SAME_BASE_TABLE_MIN) {
+    if (!fixed && !stride && (n >= SAME_BASE_TABLE_MIN || (flags & KYB_F_UNIFORM))) {  // (uniform: the shared table at any size)
         // one shared base and many coefficients: give the base a radix-256 table of its own and take the fixed-base path
         if ((rc = d_tab.alloc(ED_TAB_WORDS * sizeof(int32_t) + 256))) return rc;
         uint32_t* d_ok = (uint32_t*)((uint8_t*)d_tab.p + ED_TAB_WORDS * sizeof(int32_t));
@@ -714,7 +817,7 @@ static int mul_host(size_t n, const uint8_t* scalars, const uint8_t* points, siz
 
 int kyb_ed25519_mul(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* out, uint8_t* status,
                     uint32_t flags) {
-    if ((n && (!scalars || !points || !out)) || (flags & ~KYB_F_VARTIME)) {
+    if ((n && (!scalars || !points || !out)) || ed_mul_flags_bad(flags)) {
         set_error("kyb_ed25519_mul: bad argument");
         return KYB_E_ARG;
     }
@@ -728,7 +831,7 @@ int kyb_ed25519_mul(size_t n, const uint8_t* scalars, const uint8_t* points, uin
 
 int kyb_ed25519_mul_same_base(size_t n, const uint8_t* scalars, const uint8_t point[32], uint8_t* out,
                               uint8_t* status, uint32_t flags) {
-    if ((n && (!scalars || !out)) || !point || (flags & ~KYB_F_VARTIME)) {
+    if ((n && (!scalars || !out)) || !point || ed_mul_flags_bad(flags)) {
         set_error("kyb_ed25519_mul_same_base: bad argument");
         return KYB_E_ARG;
     }

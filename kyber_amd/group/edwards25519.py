@@ -26,7 +26,7 @@ import os
 import numpy as np
 
 from .. import _lib
-from .._lib import KYB_F_VARTIME, check, load
+from .._lib import KYB_F_UNIFORM, KYB_F_VARTIME, check, load
 
 # group/edwards25519/const.go:15
 ORDER = 2**252 + 27742317777372353535851937790883648493
@@ -54,10 +54,17 @@ def _stream_ptr():
 
 
 # ------------------------------------------------------------------ batch API
-def batch_mul_base(scalars, vartime: bool = False):
-    """out[i] = scalars[i] * B   (replaces N x Point.Mul(s, nil), ge.go:373)."""
+def _flags(vartime: bool, uniform: bool) -> int:
+    if vartime and uniform:
+        raise ValueError("vartime and uniform are exclusive")
+    return KYB_F_VARTIME if vartime else (KYB_F_UNIFORM if uniform else 0)
+
+
+def batch_mul_base(scalars, vartime: bool = False, uniform: bool = False):
+    """out[i] = scalars[i] * B   (replaces N x Point.Mul(s, nil), ge.go:373).  uniform: KYB_F_UNIFORM -- the table is
+    scanned, not indexed (the access pattern of the reference's constant-time path), for secret scalars."""
     lib = load()
-    flags = KYB_F_VARTIME if vartime else 0
+    flags = _flags(vartime, uniform)
     if _is_torch(scalars):
         import torch
 
@@ -72,12 +79,12 @@ def batch_mul_base(scalars, vartime: bool = False):
     return out
 
 
-def batch_mul(scalars, points, vartime: bool = False):
+def batch_mul(scalars, points, vartime: bool = False, uniform: bool = False):
     """(out, status): out[i] = scalars[i] * points[i]; status[i] != 0 where
     points[i] is not a valid encoding (then out[i] is zero bytes).
     Replaces N x (UnmarshalBinary + Point.Mul(s, A) + MarshalBinary)."""
     lib = load()
-    flags = KYB_F_VARTIME if vartime else 0
+    flags = _flags(vartime, uniform)
     if _is_torch(scalars):
         import torch
 
@@ -101,13 +108,14 @@ def batch_mul(scalars, points, vartime: bool = False):
     return out, st
 
 
-def commit(scalars, base=None, vartime: bool = False):
+def commit(scalars, base=None, vartime: bool = False, uniform: bool = False):
     """commits[i] = coeffs[i] * b  -- share.PriPoly.Commit (share/poly.go:143-149).
-    ``base`` None means the standard base point (poly.go:144 passes nil through)."""
+    ``base`` None means the standard base point (poly.go:144 passes nil through).  uniform: the coefficients of a
+    PriPoly are secrets -- KYB_F_UNIFORM keeps them out of the memory addresses."""
     if base is None:
-        return batch_mul_base(scalars, vartime)
+        return batch_mul_base(scalars, vartime, uniform)
     lib = load()
-    flags = KYB_F_VARTIME if vartime else 0
+    flags = _flags(vartime, uniform)
     s = _as_host(scalars, 32)
     b = _as_host(base, 32)
     out = np.empty_like(s)

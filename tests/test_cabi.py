@@ -109,6 +109,8 @@ def test_empty_batches_and_argument_errors_never_touch_the_device():
     bad = [
         ("kyb_ed25519_mul", (4, None, p, p, p, 0)),
         ("kyb_ed25519_unmarshal", (4, p, None, p)),
+        ("kyb_ed25519_mul_base", (4, p, p, 1 | 8)),  # KYB_F_VARTIME | KYB_F_UNIFORM: exclusive
+        ("kyb_ed25519_mul_same_base", (4, p, p, p, p, 16)),  # an unknown flag bit
         ("kyb_bls12381_g1_mul", (4, p, None, p, p, 0)),
         ("kyb_bls12381_g1_unmarshal", (4, None, p, p, 0)),
         ("kyb_bls12381_g1_mul_dev", (4, p, p, 47, p, p, 0, None)),  # stride that is neither 0 nor the wire size

@@ -329,3 +329,50 @@ def test_same_base_commit_through_its_own_table(ed):
     bad[0] = 2  # y = 2 is not on the curve
     with pytest.raises(ValueError):
         ed.commit(s, bytes(bad))
+
+
+def test_uniform_access_variants_give_the_default_bytes(ed):
+    """KYB_F_UNIFORM (table scanned with masks, no digit-indexed load, no skipped window: the access pattern of the
+    reference's constant-time Mul, group/edwards25519/ge.go:352-371, 419-435) changes addresses, not values: fixed-base,
+    variable-base (scratch-table and global-table kernels) and same-base batches against the C oracle, over any 256-bit
+    scalar -- the >= 2^255 behaviour of the constant-time path included -- from host and device buffers; a base that does
+    not decode; and the flag combination that makes no sense is rejected."""
+    import torch
+
+    from kyber_amd import _lib
+
+    rng = np.random.default_rng(61)
+    edge = [bytes(32), (1).to_bytes(32, "little"), O.L.to_bytes(32, "little"), bytes([0xFF] * 32), (2**255).to_bytes(32, "little"),
+            (2**255 - 1).to_bytes(32, "little"), bytes([0x88] * 32), bytes([0x08] * 32), (2**252).to_bytes(32, "little"),
+            bytes([0x99] * 32), bytes([0x77] * 31 + [0x8F])]
+    for n in (1, 300, 4096 + 77, 20000):
+        s = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+        for j, e in enumerate(edge[:n]):
+            s[(j * 37) % n] = np.frombuffer(e, dtype=np.uint8)
+        # fixed base
+        exp = OC.ed_mul_base(s)
+        assert (ed.batch_mul_base(s, uniform=True) == exp).all(), n
+        assert (ed.batch_mul_base(torch.from_numpy(s).cuda(), uniform=True).cpu().numpy() == exp).all(), n
+        # variable base (n < 4096: the table in scratch; above: the global slab), one undecodable point
+        pts = OC.ed_mul_base(rng.integers(0, 256, size=(n, 32), dtype=np.uint8))
+        if n > 2:
+            pts[n // 2] = 0
+            pts[n // 2, 0] = 2
+        exp_v, est = OC.ed_mul(s, pts)
+        out, st = ed.batch_mul(s, pts, uniform=True)
+        assert (st == est).all() and (out == exp_v).all(), n
+        out, st = ed.batch_mul(torch.from_numpy(s).cuda(), torch.from_numpy(pts).cuda(), uniform=True)
+        assert (st.cpu().numpy() == est).all() and (out.cpu().numpy() == exp_v).all(), n
+        # same base: the table of the base at any batch size
+        base = bytes(pts[0])
+        exp_c, _ = OC.ed_mul(s, np.tile(pts[0], (n, 1)))
+        assert (ed.commit(s, base, uniform=True) == exp_c).all(), n
+    bad = bytearray(32)
+    bad[0] = 2
+    with pytest.raises(ValueError):
+        ed.commit(s[:5], bytes(bad), uniform=True)
+    with pytest.raises(ValueError):
+        ed.batch_mul_base(s[:5], vartime=True, uniform=True)
+    lib = _lib.load()
+    o = np.zeros((5, 32), dtype=np.uint8)
+    assert lib.kyb_ed25519_mul_base(5, s.ctypes.data, o.ctypes.data, _lib.KYB_F_VARTIME | _lib.KYB_F_UNIFORM) == -1

@@ -37,5 +37,10 @@ def t(fn, reps=10):
 res = {"n": n, "digest_4096": want[:16],
        "mul_ms": t(lambda: ed.batch_mul(s, P)),
        "mul_base_ms": t(lambda: ed.batch_mul_base(s)),
-       "msm_ms": t(lambda: ed.msm(s, P))}
+       "msm_ms": t(lambda: ed.msm(s, P)),
+       # KYB_F_UNIFORM (tables scanned, not indexed): what the scalar-independent access pattern costs
+       "mul_uniform_ms": t(lambda: ed.batch_mul(s, P, uniform=True)),
+       "mul_base_uniform_ms": t(lambda: ed.batch_mul_base(s, uniform=True))}
+res["uniform_outputs_equal_default"] = bool(torch.equal(ed.batch_mul_base(s, uniform=True), ed.batch_mul_base(s)) and
+                                            torch.equal(ed.batch_mul(s, P, uniform=True)[0], ed.batch_mul(s, P)[0]))
 print(json.dumps(res))
