@@ -1,6 +1,7 @@
 // bls12381: multi-scalar multiplication entry points (msm.cuh pipeline over the Weierstrass adapter).
 #include "bls12381.cuh"
 #include "pairing_abi.cuh"
+#include "rowfp.cuh"
 #include "msm_ws.cuh"
 namespace kyb {
 struct BlsG1Codec {
@@ -29,6 +30,8 @@ struct BlsG2Codec {
 struct BlsG1Msm : msm::Weierstrass<bls::fp, BlsG1Codec> {
     using Base = msm::Weierstrass<bls::fp, BlsG1Codec>;
     static constexpr int SPLIT = 2, SPLIT_BITS = 127;
+    static constexpr int ROW_FINAL = 1;  // msm.cuh final_rows_kernel: the window sums' doubling chains on rowfp.cuh
+    using RowC = bls::FC;
 #ifndef KYB_BLS_G1_DECODE_WAVES
 #define KYB_BLS_G1_DECODE_WAVES 2
 #endif

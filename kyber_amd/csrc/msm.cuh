@@ -752,6 +752,52 @@ __global__ __launch_bounds__(FINAL_T) void final_kernel(Plan p, const typename A
     }
 }
 
+// ---- The doubling chains of the final stage with ONE LIMB PER LANE (rowfp.cuh; adapters with ROW_FINAL: a base field of
+// 13 x 30-bit limbs) -- round 6.  final_kernel above holds all windows in one wave, three lanes per window, and every
+// doubling costs it three 539-instruction field products in a row: 770 us for the 128 doublings of a 2^20-point G1 MSM,
+// on ONE of the chip's 1 024 SIMDs.  Here every window has a wave of its own; the wave's four rows hold the window's sum
+// and share the seven products of a doubling (three levels of a 57-multiply-add product).  The sums leave in the packed
+// form, 2^(c w) times what they were, and final_kernel -- called with c = 0 -- adds and encodes them.
+template <class A, class = void>
+struct HasRowFinal {
+    static constexpr bool value = false;
+};
+template <class A>
+struct HasRowFinal<A, decltype((void)A::ROW_FINAL)> {
+    static constexpr bool value = A::ROW_FINAL != 0;
+};
+#if defined(KYB_ROWFP_INCLUDED)
+template <class A>
+__global__ __launch_bounds__(64) void final_rows_kernel(Plan p, const typename A::Acc* __restrict__ wsum,
+                                                        typename A::Acc* __restrict__ shifted) {
+    using C = typename A::RowC;
+    using namespace rowfp;
+    __shared__ uint32_t limbs[3][ROW];
+    const int w = blockIdx.x;
+    const auto cx = make_ctx<C>();
+    const auto dc = make_dbl_consts<C>();
+    const V32 row = row_of_lane();
+    const typename A::Acc* src = wsum + w;
+    JacRow<C> pt{load_packed<C>(src->X.v), load_packed<C>(src->Y.v), load_packed<C>(src->Z.v)};
+    const int ndbl = w * p.c;
+#pragma unroll 1
+    for (int k = 0; k < ndbl; k++) jac_dbl_wave<C>(cx, dc, row, pt);
+    const V32 X = below_2p<C>(cx, pt.X), Y = below_2p<C>(cx, pt.Y), Z = below_2p<C>(cx, pt.Z);
+    if (threadIdx.x < ROW) {
+        limbs[0][threadIdx.x] = X;
+        limbs[1][threadIdx.x] = Y;
+        limbs[2][threadIdx.x] = Z;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        typename A::Field f;
+        finish_limbs<C>(f, limbs[threadIdx.x]);
+        typename A::Field* dst = reinterpret_cast<typename A::Field*>(shifted + w);
+        dst[threadIdx.x] = f;
+    }
+}
+#endif
+
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
 // Enqueue the whole MSM on `st`.  d_status may be null.  n == 0 writes the identity encoding.
@@ -899,6 +945,25 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
             // (the final kernel stays the three-lane register version: a slot-based one measured 5.48 against 5.39 ms
             // for the whole 2^20-point MSM -- a lone chain of doublings gains nothing from slots)
             const unsigned final_t = (unsigned)((p.nwin * Coop<A>::value + 63) / 64 * 64);
+#if defined(KYB_ROWFP_INCLUDED)
+            if constexpr (HasRowFinal<A>::value) {
+                // the doubling chains one wave per window on the limb-per-lane arithmetic (KYB_MSM_FINAL=lanes: the old kernel, A/B)
+                static const bool lanes_final = [] {
+                    const char* e = getenv("KYB_MSM_FINAL");
+                    return e && e[0] == 'l';
+                }();
+                if (!lanes_final && p.nwin > 1) {
+                    typename A::Acc* shifted = cur == partial ? folded : partial;  // the fold buffer not holding the sums
+                    hipLaunchKernelGGL(final_rows_kernel<A>, dim3((unsigned)p.nwin), dim3(64), 0, st, pr, (const typename A::Acc*)cur, shifted);
+                    Plan p0 = pr;
+                    p0.c = 0;  // nothing left to double
+                    hipLaunchKernelGGL(final_kernel<A>, dim3(1), dim3(final_t), 0, st, p0, (const typename A::Acc*)shifted, winsum, bad,
+                                       (uint8_t*)d_out);
+                    KYB_HIP_CHECK(hipGetLastError());
+                    return KYB_OK;
+                }
+            }
+#endif
             hipLaunchKernelGGL(final_kernel<A>, dim3(1), dim3(final_t), 0, st, pr, cur, winsum, bad, (uint8_t*)d_out);
             KYB_HIP_CHECK(hipGetLastError());
             return KYB_OK;

@@ -16,6 +16,7 @@
 #include "../kyber_amd/csrc/bls12381_g1coop.cuh"
 #include "../kyber_amd/csrc/coop_slots.cuh"
 #include "../kyber_amd/csrc/scalar_field.cuh"
+#include "../kyber_amd/csrc/rowfp.cuh"
 #include <pthread.h>
 #include <thread>
 #include <vector>
@@ -743,5 +744,76 @@ int hh_bls_g2_mul_coop(const uint8_t* k32, const uint8_t* pt, int flags, uint8_t
     jac_to_aff(a, p);
     g2_encode_f(out, a, (uint32_t)flags);
     return 0;
+}
+}
+
+// ---- rowfp.cuh: the limb-per-lane field arithmetic, emulated lane by lane (V32 = 64 lanes).  Operands and results travel
+// as raw limbs, 4 rows x 16 lanes of uint32 (lanes 13..15 zero), so the tests see the redundant representation itself.
+static rowfp::V32 row_in(const uint32_t* x) { rowfp::V32 v; for (int i = 0; i < 64; i++) v.v[i] = x[i]; return v; }
+static void row_out(uint32_t* o, const rowfp::V32& v) { for (int i = 0; i < 64; i++) o[i] = v.v[i]; }
+// op 0: mul, 1: add2, 2: dbl, 3: triple, 4: a - b + 3p, 5: a - b + 5p, 6: a - b + 8p.  Returns the number of 64-bit
+// accumulator overflows the emulation saw (must be 0).
+extern "C" {
+int hh_row_op(int op, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+    using C = bls::FC;
+    rowfp::overflow_count() = 0;
+    const auto cx = rowfp::make_ctx<C>();
+    const auto dc = rowfp::make_dbl_consts<C>();
+    const rowfp::V32 A = row_in(a), B = row_in(b);
+    rowfp::V32 R;
+    switch (op) {
+        case 0: R = rowfp::mul<C>(cx, A, B); break;
+        case 1: R = rowfp::add2<C>(A, B); break;
+        case 2: R = rowfp::dbl<C>(A); break;
+        case 3: R = rowfp::triple<C>(A); break;
+        case 4: R = rowfp::sub_k<3, C>(A, B, dc.b3); break;
+        case 5: R = rowfp::sub_k<5, C>(A, B, dc.b5); break;
+        default: R = rowfp::sub_k<8, C>(A, B, dc.b8); break;
+    }
+    row_out(out, R);
+    return rowfp::overflow_count();
+}
+// n doublings of the points (X, Y, Z) -- wave = 0: each row its own point; wave = 1: the four rows hold the same point and
+// share the products (jac_dbl_wave).  maxlimb receives the largest limb seen at the end of any doubling.
+int hh_row_dbl_chain(int wave, int n, const uint32_t* X, const uint32_t* Y, const uint32_t* Z, uint32_t* oX, uint32_t* oY, uint32_t* oZ,
+                     uint32_t* maxlimb) {
+    using C = bls::FC;
+    rowfp::overflow_count() = 0;
+    const auto cx = rowfp::make_ctx<C>();
+    const auto dc = rowfp::make_dbl_consts<C>();
+    const rowfp::V32 row = rowfp::row_of_lane();
+    rowfp::JacRow<C> p{row_in(X), row_in(Y), row_in(Z)};
+    uint32_t mx = 0;
+    for (int k = 0; k < n; k++) {
+        if (wave) rowfp::jac_dbl_wave<C>(cx, dc, row, p);
+        else rowfp::jac_dbl<C>(cx, dc, p);
+        for (int i = 0; i < 64; i++) {
+            if (p.X.v[i] > mx) mx = p.X.v[i];
+            if (p.Y.v[i] > mx) mx = p.Y.v[i];
+            if (p.Z.v[i] > mx) mx = p.Z.v[i];
+        }
+    }
+    row_out(oX, p.X);
+    row_out(oY, p.Y);
+    row_out(oZ, p.Z);
+    *maxlimb = mx;
+    return rowfp::overflow_count();
+}
+// the way out of the row form: a product with R mod p (value below 2p), the limbs of row 0 rippled by one lane, fp_finish;
+// out = the 12 packed words of the residue, fully reduced.  Also checks load_packed against the limbs it came from.
+int hh_row_finish(const uint32_t* x, uint32_t* out12) {
+    using C = bls::FC;
+    rowfp::overflow_count() = 0;
+    const auto cx = rowfp::make_ctx<C>();
+    const rowfp::V32 y = rowfp::below_2p<C>(cx, row_in(x));
+    Fp<C> f;
+    rowfp::finish_limbs<C>(f, y.v);
+    for (int j = 0; j < C::NWORDS; j++) out12[j] = f.v[j];
+    const rowfp::V32 back = rowfp::load_packed<C>(f.v);
+    Fp<C> g;
+    rowfp::finish_limbs<C>(g, back.v + 32);  // row 2 of the reloaded element: the same limbs in every row
+    for (int j = 0; j < C::NWORDS; j++)
+        if (g.v[j] != f.v[j]) return -1;
+    return rowfp::overflow_count();
 }
 }
