@@ -952,13 +952,17 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
                     const char* e = getenv("KYB_MSM_FINAL");
                     return e && e[0] == 'l';
                 }();
-                if (!lanes_final && p.nwin > 1) {
+                if (!lanes_final && p.nwin > 1 && p.nwin <= FG) {
                     typename A::Acc* shifted = cur == partial ? folded : partial;  // the fold buffer not holding the sums
                     hipLaunchKernelGGL(final_rows_kernel<A>, dim3((unsigned)p.nwin), dim3(64), 0, st, pr, (const typename A::Acc*)cur, shifted);
+                    // the nwin shifted sums are one more row of partials for the cooperative fold (a tree of four-lane additions:
+                    // final_kernel's own tree is one lane per addition), and final_kernel is left with the encoding
+                    typename A::Acc* total = cur;  // the sums were read by the kernel above: their buffer is free again
+                    hipLaunchKernelGGL(tree_fold_coop_kernel<A>, dim3(1), dim3(4 * FG), 0, st, 1, p.nwin, (const typename A::Acc*)shifted, total);
                     Plan p0 = pr;
-                    p0.c = 0;  // nothing left to double
-                    hipLaunchKernelGGL(final_kernel<A>, dim3(1), dim3(final_t), 0, st, p0, (const typename A::Acc*)shifted, winsum, bad,
-                                       (uint8_t*)d_out);
+                    p0.c = 0;     // nothing left to double
+                    p0.nwin = 1;  // nor to add
+                    hipLaunchKernelGGL(final_kernel<A>, dim3(1), dim3(64), 0, st, p0, (const typename A::Acc*)total, winsum, bad, (uint8_t*)d_out);
                     KYB_HIP_CHECK(hipGetLastError());
                     return KYB_OK;
                 }

@@ -251,15 +251,24 @@ KYB_ROW void carry_pass(V64& lo, V64& hi) {
     lo = add64(low64(lo, K<C>::MASK), shr_lanes64<1>(cl));
     hi = add64(add64(low64(hi, K<C>::MASK), shr_lanes64<1>(ch)), shl_lanes64<ROW - 1>(cl));
 }
-// the same once every column is below 2^32 (second passes): 32-bit carries
+// the second pass: columns below 2^62 in, so the carries fit 32 bits and travel as one register; columns come out as
+// 32-bit values (below 2^30 + the carry)
 template <class C>
-KYB_ROW void carry_pass32(V64& lo, V64& hi) {
+KYB_ROW void carry_pass_narrow(V64 lo, V64 hi, V32& l, V32& h) {
     constexpr int W = C::W;
-    const V32 l = lo32(lo), h = lo32(hi);
-    const V32 cl = shr(l, W), ch = shr(h, W);
+    const V32 cl = lo32(shr64(lo, W)), ch = lo32(shr64(hi, W));
     const V32 m = splat(K<C>::MASK);
-    lo = widen(add(band(l, m), shr_lanes<1>(cl)));
-    hi = widen(add(add(band(h, m), shr_lanes<1>(ch)), shl_lanes<ROW - 1>(cl)));
+    l = add(band(lo32(lo), m), shr_lanes<1>(cl));
+    h = add(add(band(lo32(hi), m), shr_lanes<1>(ch)), shl_lanes<ROW - 1>(cl));
+}
+// both passes over ONE accumulator whose carry out of lane 15 is not wanted (the quotient q: cut at R anyway)
+template <class C>
+KYB_ROW V32 carry_twice_low(V64 x) {
+    constexpr int W = C::W;
+    const V64 c1 = shr64(x, W);
+    const V64 y = add64(low64(x, K<C>::MASK), shr_lanes64<1>(c1));  // below 2^30 + 2^34
+    const V32 c2 = lo32(shr64(y, W));
+    return add(band(lo32(y), splat(K<C>::MASK)), shr_lanes<1>(c2));
 }
 
 // lo / hi += x (x) y: x a row element (limbs below 2^30 + 2^6), y_s = Y::get(s) -- a broadcast limb of a second row element
@@ -307,13 +316,14 @@ KYB_ROW V32 mul(const Ctx<C>& cx, V32 a, V32 b) {
     constexpr int N = C::N;
     V64 lo = zero64(), hi = zero64();
     accumulate_product<C>(lo, hi, a, broadcast_limbs<C>(b));
-    carry_pass<C>(lo, hi);    // columns below 2^30 + 2^34
-    carry_pass<C>(lo, hi);    // below 2^30 + 2^5 (a carry of 2^4 + 1 on top of a 30-bit rest)
+    V32 l32, h32;
+    carry_pass<C>(lo, hi);                     // columns below 2^30 + 2^34
+    carry_pass_narrow<C>(lo, hi, l32, h32);    // below 2^30 + 2^5 (a carry of 2^4 + 1 on top of a 30-bit rest)
     // q = (c mod R) n' mod R from the low N columns; columns N.. of this half product are not computed (lanes >= N are
     // cut by q_mask together with the bits of limb N - 1 above R)
-    V64 qa = zero64(), qdummy = zero64();
+    V64 qa = zero64();
     {
-        const V32 cl = band(lo32(lo), cx.limb_lanes);
+        const V32 cl = band(l32, cx.limb_lanes);
         const NprLimbs<C> npr;
         constexpr int Nq = C::N;
 #define KYB_ROW_Q(S) if constexpr (S < Nq) qa = mad64(qa, shr_lanes<S>(cl), npr.template get<S>());
@@ -321,16 +331,16 @@ KYB_ROW V32 mul(const Ctx<C>& cx, V32 a, V32 b) {
         KYB_ROW_Q(7) KYB_ROW_Q(8) KYB_ROW_Q(9) KYB_ROW_Q(10) KYB_ROW_Q(11) KYB_ROW_Q(12)
 #undef KYB_ROW_Q
     }
-    carry_pass<C>(qa, qdummy);
-    carry_pass<C>(qa, qdummy);
-    const V32 q = band(lo32(qa), cx.q_mask);  // below 2^30 + 2^5 per limb, limb N - 1 below 2^30: q below R (1 + 2^-24)
+    const V32 q = band(carry_twice_low<C>(qa), cx.q_mask);  // below 2^30 + 2^5 per limb, limb N - 1 below 2^30: q below R (1 + 2^-24)
+    lo = widen(l32);
+    hi = widen(h32);
     accumulate_product<C>(lo, hi, q, PLimbs<C>());
     carry_pass<C>(lo, hi);
-    carry_pass<C>(lo, hi);
+    carry_pass_narrow<C>(lo, hi, l32, h32);
     // the low N columns now hold 0 or R in total; R shows as a non-zero column N - 1 and is one unit of column N
-    const V32 top = band(ne0(lo32(lo)), band(cx.lane12, splat(1)));
-    const V32 l13 = add(lo32(lo), shr_lanes<1>(top));
-    return add(shl_lanes<N>(l13), shr_lanes<ROW - N>(lo32(hi)));
+    const V32 top = band(ne0(l32), band(cx.lane12, splat(1)));
+    const V32 l13 = add(l32, shr_lanes<1>(top));
+    return add(shl_lanes<N>(l13), shr_lanes<ROW - N>(h32));
 }
 
 // one carry pass over a row element (limbs below 2^32): limbs below 2^30 + 4 afterwards.  The top limb keeps what it
