@@ -255,6 +255,9 @@ int kyb_bls12381_verify_g1_same_key(size_t n, const uint8_t *pubkey, const uint8
 int kyb_bls12381_verify_g1_same_key_dev(size_t n, const void *d_pubkey, const void *d_msgs, size_t msg_len,
                                         const uint8_t *dst, size_t dst_len, const void *d_sigs, void *d_ok,
                                         void *d_status, uint32_t flags, void *stream);
+/* test hook: out3 = {cache hits, table builds, next slot} of `stream`'s key cache behind kyb_bls12381_verify_g1_same_key
+ * (sign/bls/bls.go:82-96 over a committee of keys); synchronises the stream */
+int kyb_bls12381_debug_vkey_stats(void *stream, uint32_t *out3);
 /* ok[i] = bls.Verify(pubkeys[i], msg, sigs[i]) for ONE message: the verification loop of tbls.Recover
  * (sign/tbls/tbls.go:118-131 -- every partial signature of a round is over the same msg, each under its own public
  * share public.Eval(idx).V, share/poly.go:340-348).  H(msg) is computed once per call instead of once per element;

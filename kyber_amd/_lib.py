@@ -41,6 +41,7 @@ SIGNATURES = {
     "kyb_ed25519_mul_dev": [_sz, _vp, _vp, _vp, _vp, _u32, _vp],
     "kyb_ed25519_mul_same_base": [_sz, _vp, _vp, _vp, _vp, _u32],
     "kyb_ed25519_debug_base_table": [_vp],
+    "kyb_bls12381_debug_vkey_stats": [_vp, _vp],
     "kyb_ed25519_add": [_sz, _vp, _vp, _vp, _vp],
     "kyb_ed25519_add_dev": [_sz, _vp, _vp, _vp, _vp, _vp],
     "kyb_ed25519_hash": [_sz, _vp, _sz, _vp, _sz, _vp],

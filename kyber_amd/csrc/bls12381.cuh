@@ -688,7 +688,8 @@ KYB_HD int g1_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt
     g1_encode_f(out, a, flags);
     return ST_OK;
 }
-KYB_HD int g2_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt, uint32_t flags = 0) {
+constexpr size_t G2_TAB_WORDS = 0;  // (pairing_abi.cuh: no per-lane table slab in global memory for this suite's G2 kernel)
+KYB_HD int g2_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt, uint32_t flags = 0, uint32_t* = nullptr) {
     g2_aff a;
     const int st = g2_decode_f(a, pt, flags, 0);
     if (st != ST_OK) {

@@ -6,6 +6,7 @@
 // fixed-base kernels share that code, it is 256: 2^18 G2 commits 5.61 -> 5.0 ms.  (The table, chain and encode kernels
 // keep their own looser budgets: all five kernels on two waves measured 2.5 % slower, profiles/r04_tu_wave_budgets.json.)
 #include "bls12381.cuh"
+#include "rowfp.cuh"
 #include "bls12381_fb.cuh"
 #include "pairing_abi.cuh"
 

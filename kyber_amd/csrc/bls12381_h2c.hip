@@ -104,8 +104,8 @@ static int hash_host(bool g2, size_t n, const uint8_t* msgs, size_t msg_len, con
     KYB_TRY(m.upload(msgs, n * msg_len));
     KYB_TRY(o.alloc(n * osz));
     KYB_TRY(st.alloc(n));
-    KYB_TRY(g2 ? kyb_bls12381_hash_g2_dev(n, m.p, msg_len, dst, dst_len, o.p, st.p, nullptr)
-               : kyb_bls12381_hash_g1_dev(n, m.p, msg_len, dst, dst_len, o.p, st.p, nullptr));
+    KYB_TRY(g2 ? kyb_bls12381_hash_g2_dev(n, m.p, msg_len, dst, dst_len, o.p, st.p, sc_.stream())
+               : kyb_bls12381_hash_g1_dev(n, m.p, msg_len, dst, dst_len, o.p, st.p, sc_.stream()));
     KYB_TRY(o.download(out, n * osz));
     if (status) KYB_TRY(st.download(status, n));
     return KYB_OK;
@@ -170,7 +170,7 @@ int kyb_bls12381_verify_g1(size_t n, const uint8_t* pks, const uint8_t* msgs, si
     KYB_TRY(s.upload(sigs, n * bls::g1_wire_size(flags)));
     KYB_TRY(o.alloc(n));
     KYB_TRY(st.alloc(n));
-    KYB_TRY(kyb_bls12381_verify_g1_dev(n, p.p, m.p, msg_len, dst, dst_len, s.p, o.p, st.p, flags, nullptr));
+    KYB_TRY(kyb_bls12381_verify_g1_dev(n, p.p, m.p, msg_len, dst, dst_len, s.p, o.p, st.p, flags, sc_.stream()));
     KYB_TRY(o.download(ok, n));
     if (status) KYB_TRY(st.download(status, n));
     return KYB_OK;
@@ -224,7 +224,7 @@ int kyb_bls12381_verify_g1_same_key(size_t n, const uint8_t* pk, const uint8_t* 
     KYB_TRY(s.upload(sigs, n * bls::g1_wire_size(flags)));
     KYB_TRY(o.alloc(n));
     KYB_TRY(st.alloc(n));
-    KYB_TRY(kyb_bls12381_verify_g1_same_key_dev(n, p.p, m.p, msg_len, dst, dst_len, s.p, o.p, st.p, flags, nullptr));
+    KYB_TRY(kyb_bls12381_verify_g1_same_key_dev(n, p.p, m.p, msg_len, dst, dst_len, s.p, o.p, st.p, flags, sc_.stream()));
     KYB_TRY(o.download(ok, n));
     if (status) KYB_TRY(st.download(status, n));
     return KYB_OK;
@@ -278,7 +278,7 @@ int kyb_bls12381_verify_g1_same_msg(size_t n, const uint8_t* pks, const uint8_t*
     KYB_TRY(s.upload(sigs, n * bls::g1_wire_size(flags)));
     KYB_TRY(o.alloc(n));
     KYB_TRY(st.alloc(n));
-    KYB_TRY(kyb_bls12381_verify_g1_same_msg_dev(n, p.p, m.p, msg_len, dst, dst_len, s.p, o.p, st.p, flags, nullptr));
+    KYB_TRY(kyb_bls12381_verify_g1_same_msg_dev(n, p.p, m.p, msg_len, dst, dst_len, s.p, o.p, st.p, flags, sc_.stream()));
     KYB_TRY(o.download(ok, n));
     if (status) KYB_TRY(st.download(status, n));
     return KYB_OK;
@@ -328,7 +328,7 @@ int kyb_bls12381_verify_g2(size_t n, const uint8_t* pks, const uint8_t* msgs, si
     KYB_TRY(s.upload(sigs, n * bls::g2_wire_size(flags)));
     KYB_TRY(o.alloc(n));
     KYB_TRY(st.alloc(n));
-    KYB_TRY(kyb_bls12381_verify_g2_dev(n, p.p, m.p, msg_len, dst, dst_len, s.p, o.p, st.p, flags, nullptr));
+    KYB_TRY(kyb_bls12381_verify_g2_dev(n, p.p, m.p, msg_len, dst, dst_len, s.p, o.p, st.p, flags, sc_.stream()));
     KYB_TRY(o.download(ok, n));
     if (status) KYB_TRY(st.download(status, n));
     return KYB_OK;

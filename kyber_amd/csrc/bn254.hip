@@ -84,7 +84,7 @@ int kyb_bn254_hash_g1(size_t n, const uint8_t* msgs, size_t msg_len, const uint8
     KYB_TRY(m.upload(msgs, n * msg_len));
     KYB_TRY(o.alloc(n * 64));
     KYB_TRY(st.alloc(n));
-    KYB_TRY(kyb_bn254_hash_g1_dev(n, m.p, msg_len, dst, dst_len, o.p, st.p, nullptr));
+    KYB_TRY(kyb_bn254_hash_g1_dev(n, m.p, msg_len, dst, dst_len, o.p, st.p, sc_.stream()));
     KYB_TRY(o.download(out, n * 64));
     if (status) KYB_TRY(st.download(status, n));
     return KYB_OK;

@@ -177,7 +177,7 @@ int kyb_bn256_hash_g1(size_t n, const uint8_t* msgs, size_t msg_len, uint8_t* ou
     KYB_TRY(m.upload(msgs, n * msg_len));
     KYB_TRY(o.alloc(n * 64));
     KYB_TRY(st.alloc(n));
-    KYB_TRY(kyb_bn256_hash_g1_dev(n, m.p, msg_len, o.p, st.p, nullptr));
+    KYB_TRY(kyb_bn256_hash_g1_dev(n, m.p, msg_len, o.p, st.p, sc_.stream()));
     KYB_TRY(o.download(out, n * 64));
     if (status) KYB_TRY(st.download(status, n));
     return KYB_OK;
@@ -225,7 +225,7 @@ int kyb_bn256_hash_g1_svdw(size_t n, const uint8_t* msgs, size_t msg_len, const 
     KYB_TRY(m.upload(msgs, n * msg_len));
     KYB_TRY(o.alloc(n * 64));
     KYB_TRY(st.alloc(n));
-    KYB_TRY(kyb_bn256_hash_g1_svdw_dev(n, m.p, msg_len, dst, dst_len, o.p, st.p, nullptr));
+    KYB_TRY(kyb_bn256_hash_g1_svdw_dev(n, m.p, msg_len, dst, dst_len, o.p, st.p, sc_.stream()));
     KYB_TRY(o.download(out, n * 64));
     if (status) KYB_TRY(st.download(status, n));
     return KYB_OK;

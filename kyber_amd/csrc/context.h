@@ -5,7 +5,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <string>
@@ -32,11 +35,12 @@ struct DeviceCtx {
     int num_cu = 0;
     bool ready = false;
     std::mutex mu;
-    // Held for the whole enqueue sequence of every call that takes a (kind, stream) workspace below -- the ~20 kernels of
+    // Held for the whole ENQUEUE sequence of every call that takes a (kind, stream) workspace below -- the ~20 kernels of
     // the MSM pipeline, the Ed25519 batch kernels with their parked triples: two host threads that use the same stream
-    // (including the null stream) therefore enqueue one whole call after the other, which the stream then runs in that
-    // order, and a workspace is never grown (freed) while another thread is still enqueueing kernels on the old
-    // pointer.  Recursive: the host-buffer wrappers hold it around upload / enqueue / download.
+    // therefore enqueue one whole call after the other, which the stream then runs in that order, and a workspace is
+    // never grown (freed) while another thread is still enqueueing kernels on the old pointer.  Since round 6 it is NOT
+    // held across a host-buffer call's copies: those calls run on their staging pool's stream (StageScope below), whose
+    // workspaces no other call in flight shares.  Recursive: entry points that call other enqueueing helpers re-enter it.
     std::recursive_mutex enq_mu;
     // Ed25519 fixed-base table: [33][136] entries of 32 int32 (30 limbs + 2 pad), built on device at init
     int32_t* ed_base_tab = nullptr;
@@ -48,30 +52,37 @@ struct DeviceCtx {
         size_t cap = 0;
     };
     std::map<std::pair<int, hipStream_t>, StreamBuf> sws;
-    // grow-only device staging buffers of the host-buffer entry points (no hipMalloc / hipFree per call);
-    // stage_mu serialises those calls per device -- they synchronise the device anyway.  LOCK ORDER: stage_mu (StageScope)
-    // before enq_mu, never the other way round
-    static constexpr int NSTAGE = 8;
-    void* stage[NSTAGE] = {};
-    size_t stage_cap[NSTAGE] = {};
+    // Staging of the host-buffer entry points: NPOOL pools, each with its own stream, grow-only device buffers (no hipMalloc /
+    // hipFree per call), page-locked slots and pipeline streams.  A host-buffer call holds ONE pool for its duration
+    // (StageScope) and runs its copies and kernels on the pool's stream, so two host threads on one device overlap one
+    // call's staging with the other's kernels (round 6; until then one mutex serialised whole calls per device).  A thread
+    // waits when every pool is taken; the lowest free pool is handed out, so a single-threaded caller always meets pool 0 and
+    // the per-stream caches behind it (fixed-base tables, a verifier's key lines).  stage_mu guards only the `busy` flags.
+    static constexpr int NSTAGE = 8, NPOOL = 2, NPIN = 6;
+    struct StagePool {
+        bool busy = false;
+        hipStream_t stream = nullptr;  // a BLOCKING stream (it synchronises with the null stream, never with the other pool's)
+        void* stage[NSTAGE] = {};
+        size_t stage_cap[NSTAGE] = {};
+        hipStream_t pipe[3] = {};      // chunk-pipelined host paths (H2D | compute | D2H), created on first use
+        // page-locked staging of those paths: six chunk slots each way (allocated on first use).  A copy from pageable
+        // memory is staged by the runtime at ~10 GB/s and blocks the issuing thread; through these slots the DMA is
+        // asynchronous and the host's own memcpy into / out of them overlaps the kernels (ed25519.hip mul_host).
+        void* pin_in[NPIN] = {};   // PIN_SLOT_ELEMS * 64 bytes each
+        void* pin_out[NPIN] = {};  // PIN_SLOT_ELEMS * 33 bytes each
+        bool pinned = false;
+    };
+    StagePool pools[NPOOL];
     std::mutex stage_mu;
-    // streams of the chunk-pipelined host paths (H2D | compute | D2H), created on first use
-    hipStream_t pipe[3] = {};
+    std::condition_variable stage_cv;
     // fixed_base.cuh: per (workspace kind, stream), the wire bytes + flag bytes of the base whose table the last call
     // through the HOST-buffer entry points enqueued there -- a hint (the chain kernel decides on the device) that lets
     // small same-base batches take the table path.  Guarded by mu; gone with the context at kyb_shutdown.
     std::map<std::pair<int, hipStream_t>, std::string> fb_hint;
-    // page-locked staging of those paths: six chunk slots each way (allocated on first use).  A copy from pageable memory is staged
-    // by the runtime at ~10 GB/s and blocks the issuing thread; through these slots the DMA is asynchronous and the
-    // host's own memcpy into / out of them overlaps the kernels (ed25519.hip mul_host).
-    static constexpr int NPIN = 6;
-    void* pin_in[NPIN] = {};   // PIN_SLOT_ELEMS * 64 bytes each
-    void* pin_out[NPIN] = {};  // PIN_SLOT_ELEMS * 33 bytes each
-    bool pinned = false;
 };
 constexpr size_t PIN_SLOT_ELEMS = size_t(1) << 17;
 constexpr size_t PIN_IN_BYTES = PIN_SLOT_ELEMS * 64, PIN_OUT_BYTES = PIN_SLOT_ELEMS * 33;
-int ctx_pin_slots(DeviceCtx* ctx);  // allocates the slots on first use (hipHostMalloc)
+int ctx_pin_slots(DeviceCtx::StagePool* pool);  // allocates the slots on first use (hipHostMalloc)
 // memcpy between pageable buffers and page-locked slots, cut over a few threads: one core moves ~10 GB/s
 void par_memcpy(void* dst, const void* src, size_t bytes);
 
@@ -110,7 +121,7 @@ inline bool md_active(size_t n) { return md_count() > 1 && n >= md_threshold() &
 
 // Context for the calling thread's current device (created on first use).
 int get_ctx(DeviceCtx** out);
-enum { WS_MSM = 0, WS_ED = 1, WS_PAIR = 2, WS_LVM = 3, WS_SCALAR = 4, WS_VKEY = 5, WS_FB = 16 };  // WS_FB + 2 * suite + group: fixed_base.cuh
+enum { WS_MSM = 0, WS_ED = 1, WS_PAIR = 2, WS_LVM = 3, WS_SCALAR = 4, WS_VKEY = 5, WS_G2TAB = 6, WS_FB = 16 };  // WS_G2TAB: pairing_abi.cuh, the BN G2 ladders' table slabs;  // WS_FB + 2 * suite + group: fixed_base.cuh
 // Grow (never shrink) the (kind, stream) workspace; caller holds no lock.
 // `grew` (optional): set when the buffer was (re)allocated by this call -- its contents are undefined
 int ctx_workspace(DeviceCtx* ctx, int kind, hipStream_t stream, size_t bytes, void** out, bool* grew = nullptr);
@@ -128,19 +139,50 @@ inline bool fb_hint_is(DeviceCtx* ctx, int kind, hipStream_t stream, const std::
     return it != ctx->fb_hint.end() && it->second == key;
 }
 
-// A host-buffer call: holds the device's staging pool for its duration and hands out slots in order.
+// A host-buffer call: holds one of the device's staging pools for its duration and hands out its buffers in order.
+// KYB_STAGE_POOLS=1 keeps every call on pool 0 (the serialised behaviour of rounds 1-5, for A/B runs).
 struct StageScope {
     DeviceCtx* ctx;
-    std::unique_lock<std::mutex> lk;
+    DeviceCtx::StagePool* pool = nullptr;
     int next = 0;
-    explicit StageScope(DeviceCtx* c) : ctx(c), lk(c->stage_mu) { current() = this; }
-    ~StageScope() { current() = nullptr; }
+    explicit StageScope(DeviceCtx* c) : ctx(c) {
+        static const int npool = [] {
+            const char* e = getenv("KYB_STAGE_POOLS");
+            const int v = e ? atoi(e) : 0;
+            return v >= 1 && v <= DeviceCtx::NPOOL ? v : DeviceCtx::NPOOL;
+        }();
+        {
+            std::unique_lock<std::mutex> lk(c->stage_mu);
+            for (;;) {
+                for (int i = 0; i < npool && !pool; i++)
+                    if (!c->pools[i].busy) pool = &c->pools[i];
+                if (pool) break;
+                c->stage_cv.wait(lk);
+            }
+            pool->busy = true;
+        }
+        // (a stream that cannot be created leaves the pool on the null stream: correct, without the overlap)
+        if (!pool->stream && hipStreamCreateWithFlags(&pool->stream, hipStreamDefault) != hipSuccess) pool->stream = nullptr;
+        current() = this;
+    }
+    ~StageScope() {
+        current() = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(ctx->stage_mu);
+            pool->busy = false;
+        }
+        ctx->stage_cv.notify_one();
+    }
+    StageScope(const StageScope&) = delete;
+    StageScope& operator=(const StageScope&) = delete;
+    hipStream_t stream() const { return pool->stream; }
     static StageScope*& current() {
         static thread_local StageScope* cur = nullptr;
         return cur;
     }
 };
-// One device staging buffer of the current StageScope (pooled: freed only by kyb_shutdown).
+// One device staging buffer of the current StageScope's pool (freed only by kyb_shutdown).  Copies run on the pool's stream;
+// download() leaves the stream idle (the call's kernels were enqueued on it: what it copies out is final).
 struct StageBuf {
     void* p = nullptr;
     int alloc(size_t bytes) {
@@ -150,7 +192,7 @@ struct StageBuf {
             return KYB_E_ARG;
         }
         const int slot = sc->next++;
-        DeviceCtx* c = sc->ctx;
+        DeviceCtx::StagePool* c = sc->pool;
         if (c->stage_cap[slot] < bytes || !c->stage[slot]) {
             if (c->stage[slot]) {
                 hipFree(c->stage[slot]);
@@ -176,7 +218,9 @@ struct StageBuf {
         if (rc) return rc;
         if (!bytes) return KYB_OK;
         if (bytes < BOUNCE_MIN) {
-            KYB_HIP_CHECK(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+            const hipStream_t st = StageScope::current()->stream();
+            KYB_HIP_CHECK(hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, st));
+            KYB_HIP_CHECK(hipStreamSynchronize(st));  // the source is the caller's pageable memory: done with it on return
             return KYB_OK;
         }
         return bounce(const_cast<void*>(src), bytes, true);
@@ -184,14 +228,17 @@ struct StageBuf {
     int download(void* dst, size_t bytes) {
         if (!bytes) return KYB_OK;
         if (bytes < BOUNCE_MIN) {
-            KYB_HIP_CHECK(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
+            const hipStream_t st = StageScope::current()->stream();
+            KYB_HIP_CHECK(hipMemcpyAsync(dst, p, bytes, hipMemcpyDeviceToHost, st));
+            KYB_HIP_CHECK(hipStreamSynchronize(st));
             return KYB_OK;
         }
         return bounce(dst, bytes, false);
     }
     int bounce(void* host, size_t bytes, bool up) {
         StageScope* sc = StageScope::current();
-        DeviceCtx* c = sc->ctx;
+        DeviceCtx::StagePool* c = sc->pool;
+        const hipStream_t st = sc->stream();
         int rc = ctx_pin_slots(c);
         if (rc) return rc;
         hipEvent_t ev[2];
@@ -207,14 +254,14 @@ struct StageBuf {
                 const size_t off = i * piece, len = std::min(piece, bytes - off);
                 if (i >= 2 && hipEventSynchronize(ev[i & 1]) != hipSuccess) rc = KYB_E_HIP;
                 par_memcpy(c->pin_in[i & 1], (const uint8_t*)host + off, len);
-                if (hipMemcpyAsync((uint8_t*)p + off, c->pin_in[i & 1], len, hipMemcpyHostToDevice, nullptr) != hipSuccess ||
-                    hipEventRecord(ev[i & 1], nullptr) != hipSuccess)
+                if (hipMemcpyAsync((uint8_t*)p + off, c->pin_in[i & 1], len, hipMemcpyHostToDevice, st) != hipSuccess ||
+                    hipEventRecord(ev[i & 1], st) != hipSuccess)
                     rc = KYB_E_HIP;
             } else {
                 if (i < npiece) {
                     const size_t off = i * piece, len = std::min(piece, bytes - off);
-                    if (hipMemcpyAsync(c->pin_in[i & 1], (const uint8_t*)p + off, len, hipMemcpyDeviceToHost, nullptr) != hipSuccess ||
-                        hipEventRecord(ev[i & 1], nullptr) != hipSuccess)
+                    if (hipMemcpyAsync(c->pin_in[i & 1], (const uint8_t*)p + off, len, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                        hipEventRecord(ev[i & 1], st) != hipSuccess)
                         rc = KYB_E_HIP;
                 }
                 if (i >= 1 && rc == KYB_OK) {
@@ -224,7 +271,7 @@ struct StageBuf {
                 }
             }
         }
-        if (hipStreamSynchronize(nullptr) != hipSuccess) rc = KYB_E_HIP;
+        if (hipStreamSynchronize(st) != hipSuccess) rc = KYB_E_HIP;
         for (int k = 0; k < 2; k++) hipEventDestroy(ev[k]);
         if (rc == KYB_E_HIP) set_error("staging: page-locked bounce copy failed");
         return rc;

@@ -130,13 +130,13 @@ int md_run_impl(size_t n, int (*thunk)(void*, int, size_t, size_t), void* arg, c
 }  // namespace kyb
 
 namespace kyb {
-int ctx_pin_slots(DeviceCtx* ctx) {
-    if (ctx->pinned) return KYB_OK;
+int ctx_pin_slots(DeviceCtx::StagePool* pool) {
+    if (pool->pinned) return KYB_OK;
     for (int i = 0; i < DeviceCtx::NPIN; i++) {
-        if (!ctx->pin_in[i]) KYB_HIP_CHECK(hipHostMalloc(&ctx->pin_in[i], PIN_IN_BYTES, hipHostMallocDefault));
-        if (!ctx->pin_out[i]) KYB_HIP_CHECK(hipHostMalloc(&ctx->pin_out[i], PIN_OUT_BYTES, hipHostMallocDefault));
+        if (!pool->pin_in[i]) KYB_HIP_CHECK(hipHostMalloc(&pool->pin_in[i], PIN_IN_BYTES, hipHostMallocDefault));
+        if (!pool->pin_out[i]) KYB_HIP_CHECK(hipHostMalloc(&pool->pin_out[i], PIN_OUT_BYTES, hipHostMallocDefault));
     }
-    ctx->pinned = true;
+    pool->pinned = true;
     return KYB_OK;
 }
 void par_memcpy(void* dst, const void* src, size_t bytes) {
@@ -262,13 +262,16 @@ int kyb_shutdown(void) {
         kyb::ed25519_free_tables(c);
         for (auto& w : c->sws)
             if (w.second.p) hipFree(w.second.p);
-        for (int i = 0; i < kyb::DeviceCtx::NSTAGE; i++)
-            if (c->stage[i]) hipFree(c->stage[i]);
-        for (int i = 0; i < 3; i++)
-            if (c->pipe[i]) hipStreamDestroy(c->pipe[i]);
-        for (int i = 0; i < 6; i++) {
-            if (c->pin_in[i]) hipHostFree(c->pin_in[i]);
-            if (c->pin_out[i]) hipHostFree(c->pin_out[i]);
+        for (auto& pool : c->pools) {
+            for (int i = 0; i < kyb::DeviceCtx::NSTAGE; i++)
+                if (pool.stage[i]) hipFree(pool.stage[i]);
+            for (int i = 0; i < 3; i++)
+                if (pool.pipe[i]) hipStreamDestroy(pool.pipe[i]);
+            for (int i = 0; i < kyb::DeviceCtx::NPIN; i++) {
+                if (pool.pin_in[i]) hipHostFree(pool.pin_in[i]);
+                if (pool.pin_out[i]) hipHostFree(pool.pin_out[i]);
+            }
+            if (pool.stream) hipStreamDestroy(pool.stream);
         }
         delete c;
     }

@@ -664,9 +664,9 @@ static int pipe_nstreams() {
 }
 constexpr size_t SAME_BASE_TABLE_MIN = 16384;  // below this the table (4 544 short multiplications) does not pay
 
-static int pipe_streams(DeviceCtx* ctx) {
+static int pipe_streams(DeviceCtx::StagePool* pool) {
     for (int i = 0; i < PIPE_STREAMS; i++)
-        if (!ctx->pipe[i]) KYB_HIP_CHECK(hipStreamCreateWithFlags(&ctx->pipe[i], hipStreamNonBlocking));
+        if (!pool->pipe[i]) KYB_HIP_CHECK(hipStreamCreateWithFlags(&pool->pipe[i], hipStreamNonBlocking));
     return KYB_OK;
 }
 
@@ -690,7 +690,7 @@ static int mul_host(size_t n, const uint8_t* scalars, const uint8_t* points, siz
         if ((rc = d_tab.alloc(ED_TAB_WORDS * sizeof(int32_t) + 256))) return rc;
         uint32_t* d_ok = (uint32_t*)((uint8_t*)d_tab.p + ED_TAB_WORDS * sizeof(int32_t));
         KYB_HIP_CHECK(hipMemcpy(d_p.p, points, 32, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(ed25519_build_base_table_kernel, dim3((ED_TAB_POS * ED_TAB_ENT + 63) / 64), dim3(64), 0, nullptr,
+        hipLaunchKernelGGL(ed25519_build_base_table_kernel, dim3((ED_TAB_POS * ED_TAB_ENT + 63) / 64), dim3(64), 0, sc_.stream(),
                            (int32_t*)d_tab.p, (const uint32_t*)d_p.p, d_ok);
         uint32_t ok = 0;
         KYB_HIP_CHECK(hipMemcpy(&ok, d_ok, 4, hipMemcpyDeviceToHost));
@@ -719,12 +719,13 @@ static int mul_host(size_t n, const uint8_t* scalars, const uint8_t* points, siz
         if (status && !fixed) rc = d_st.download(status, n);
         return rc;
     }
-    if ((rc = pipe_streams(ctx))) return rc;
+    DeviceCtx::StagePool* pool = sc_.pool;  // this call's page-locked slots and pipeline streams
+    if ((rc = pipe_streams(pool))) return rc;
     const int nstreams = pipe_nstreams();
     const bool per_point = !fixed && stride;
     const bool want_status = status && !fixed;
     // page-locked slots: [scalars | points] in, [points | status] out, one chunk each, PIPE_SLOTS of each
-    if ((rc = ctx_pin_slots(ctx))) return rc;
+    if ((rc = ctx_pin_slots(pool))) return rc;
     const size_t nchunks = (n + PIPE_CHUNK - 1) / PIPE_CHUNK;
     std::vector<hipEvent_t> ev_out(nchunks);
     for (size_t i = 0; i < nchunks; i++) KYB_HIP_CHECK(hipEventCreateWithFlags(&ev_out[i], hipEventDisableTiming));
@@ -734,9 +735,9 @@ static int mul_host(size_t n, const uint8_t* scalars, const uint8_t* points, siz
     // kernels of the chunks in between execute.
     auto enqueue = [&](size_t i) -> int {
         const size_t off = i * PIPE_CHUNK, cnt = std::min(PIPE_CHUNK, n - off);
-        uint8_t* pin = (uint8_t*)ctx->pin_in[i % PIPE_SLOTS];
-        uint8_t* pout = (uint8_t*)ctx->pin_out[i % PIPE_SLOTS];
-        hipStream_t s_k = ctx->pipe[i % nstreams];
+        uint8_t* pin = (uint8_t*)pool->pin_in[i % PIPE_SLOTS];
+        uint8_t* pout = (uint8_t*)pool->pin_out[i % PIPE_SLOTS];
+        hipStream_t s_k = pool->pipe[i % nstreams];
         par_memcpy(pin, scalars + off * 32, cnt * 32);
         if (per_point) par_memcpy(pin + PIPE_CHUNK_MAX * 32, points + off * 32, cnt * 32);
         // zero copy: the kernels read the chunk's scalars / points straight from the page-locked slot over PCIe (one
@@ -759,7 +760,7 @@ static int mul_host(size_t n, const uint8_t* scalars, const uint8_t* points, siz
     auto drain = [&](size_t i) -> int {
         const size_t off = i * PIPE_CHUNK, cnt = std::min(PIPE_CHUNK, n - off);
         KYB_HIP_CHECK(hipEventSynchronize(ev_out[i]));
-        const uint8_t* pout = (const uint8_t*)ctx->pin_out[i % PIPE_SLOTS];
+        const uint8_t* pout = (const uint8_t*)pool->pin_out[i % PIPE_SLOTS];
         par_memcpy(out + off * 32, pout, cnt * 32);
         if (want_status) memcpy(status + off, pout + PIPE_CHUNK_MAX * 32, cnt);
         return KYB_OK;
@@ -804,7 +805,7 @@ static int mul_host(size_t n, const uint8_t* scalars, const uint8_t* points, siz
     if (rc == KYB_OK && (rc = drain_rc.load()) != KYB_OK) set_error(drain_err);
     hipError_t e2 = hipSuccess;
     for (int i = 0; i < PIPE_STREAMS; i++) {
-        const hipError_t e = hipStreamSynchronize(ctx->pipe[i]);
+        const hipError_t e = hipStreamSynchronize(pool->pipe[i]);
         if (e != hipSuccess) e2 = e;
     }
     for (size_t i = 0; i < nchunks; i++) hipEventDestroy(ev_out[i]);
@@ -1023,7 +1024,7 @@ int kyb_ed25519_hash(size_t n, const uint8_t* msgs, size_t msg_len, const uint8_
     kyb::StageBuf d_m, d_o;
     rc = d_m.upload(msgs, n * msg_len);
     if (rc == KYB_OK) rc = d_o.alloc(n * 32);
-    if (rc == KYB_OK) rc = kyb_ed25519_hash_dev(n, d_m.p, msg_len, dst, dst_len, d_o.p, nullptr);
+    if (rc == KYB_OK) rc = kyb_ed25519_hash_dev(n, d_m.p, msg_len, dst, dst_len, d_o.p, sc_.stream());
     if (rc == KYB_OK) rc = d_o.download(out, n * 32);
     return rc;
 }
@@ -1101,7 +1102,7 @@ int kyb_ed25519_unmarshal(size_t n, const uint8_t* points, uint8_t* out, uint8_t
     rc = d_p.upload(points, n * 32);
     if (rc == KYB_OK) rc = d_o.alloc(n * 32);
     if (rc == KYB_OK) rc = d_st.alloc(n);
-    if (rc == KYB_OK) rc = kyb_ed25519_unmarshal_dev(n, d_p.p, d_o.p, d_st.p, nullptr);
+    if (rc == KYB_OK) rc = kyb_ed25519_unmarshal_dev(n, d_p.p, d_o.p, d_st.p, sc_.stream());
     if (rc == KYB_OK) rc = d_o.download(out, n * 32);
     if (rc == KYB_OK && status) rc = d_st.download(status, n);
     return rc;
@@ -1132,7 +1133,7 @@ int kyb_ed25519_add(size_t n, const uint8_t* a, const uint8_t* b, uint8_t* out, 
     if (rc == KYB_OK) rc = d_b.upload(b, n * 32);
     if (rc == KYB_OK) rc = d_o.alloc(n * 32);
     if (rc == KYB_OK) rc = d_st.alloc(n);
-    if (rc == KYB_OK) rc = kyb_ed25519_add_dev(n, d_a.p, d_b.p, d_o.p, d_st.p, nullptr);
+    if (rc == KYB_OK) rc = kyb_ed25519_add_dev(n, d_a.p, d_b.p, d_o.p, d_st.p, sc_.stream());
     if (rc == KYB_OK) rc = d_o.download(out, n * 32);
     if (rc == KYB_OK && status) rc = d_st.download(status, n);
     return rc;

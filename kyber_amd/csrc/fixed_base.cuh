@@ -193,9 +193,45 @@ __device__ __forceinline__ Aff<typename T::F>* base_slot(uint8_t* ws) {  // the 
     return reinterpret_cast<Aff<typename T::F>*>(ws + HDR_BYTES + sizeof(Jac<typename T::F>) * T::P::NW);
 }
 
-// Is the table already this base's?  Otherwise lane 0 decodes the base and FOUR cooperating lanes walk the doubling
-// chain (coop_slots.cuh: a doubling is three product levels deep instead of seven multiplications).  One workgroup of
-// four lanes.
+// Run by ONE lane: is the table already this base's?  Otherwise decode the base (every rule of UnmarshalBinary but the
+// subgroup), write the header and, when there is a table to build, the chain's first point q[0] (returned in `start`).
+// Returns 1 when the doubling chain has to be walked.
+template <class T>
+__device__ int chain_begin(uint8_t* __restrict__ ws, const uint8_t* __restrict__ base, uint32_t flags, Jac<typename T::F>& start) {
+    using F = typename T::F;
+    Header* h = reinterpret_cast<Header*>(ws);
+    Jac<F>* q = reinterpret_cast<Jac<F>*>(ws + HDR_BYTES);
+    const uint32_t kf = flags & T::KEY_FLAGS, len = (uint32_t)T::wire_size(flags);
+    bool same = h->magic == MAGIC && h->key_flags == kf && h->key_len == len;
+    for (uint32_t i = 0; i < len && same; i++) same = h->key[i] == base[i];
+    if (same) {
+        h->fresh = 0;
+        h->member_pending = 0;
+        return 0;
+    }
+    h->magic = 0;
+    Aff<F> a;
+    const int st = T::decode_on_curve(a, base, flags);
+    const bool build = st == 0 && !a.inf;
+    h->status = (uint32_t)st;
+    h->inf = (st == 0 && a.inf) ? 1u : 0u;
+    h->key_flags = kf;
+    h->key_len = len;
+    for (uint32_t i = 0; i < len; i++) h->key[i] = base[i];
+    h->fresh = 1;
+    h->member_pending = (build && T::needs_member(flags)) ? 1u : 0u;
+    if (build) {
+        jac_from_aff(start, a);
+        q[0] = start;
+        *base_slot<T>(ws) = a;
+        return 1;
+    }
+    __threadfence();
+    h->magic = MAGIC;
+    return 0;
+}
+// FOUR cooperating lanes walk the doubling chain (coop_slots.cuh: a doubling is three product levels deep instead of
+// seven multiplications).  One workgroup of four lanes.
 template <class T>
 __global__ __launch_bounds__(64, 2) void chain_kernel(uint8_t* __restrict__ ws, const uint8_t* __restrict__ base, uint32_t flags) {
     using F = typename T::F;
@@ -206,38 +242,12 @@ __global__ __launch_bounds__(64, 2) void chain_kernel(uint8_t* __restrict__ ws, 
     Header* h = reinterpret_cast<Header*>(ws);
     Jac<F>* q = reinterpret_cast<Jac<F>*>(ws + HDR_BYTES);
     if (threadIdx.x == 0) {
-        const uint32_t kf = flags & T::KEY_FLAGS, len = (uint32_t)T::wire_size(flags);
-        bool same = h->magic == MAGIC && h->key_flags == kf && h->key_len == len;
-        for (uint32_t i = 0; i < len && same; i++) same = h->key[i] == base[i];
-        go = 0;
-        if (same) {
-            h->fresh = 0;
-            h->member_pending = 0;
-        } else {
-            h->magic = 0;
-            Aff<F> a;
-            const int st = T::decode_on_curve(a, base, flags);
-            const bool build = st == 0 && !a.inf;
-            h->status = (uint32_t)st;
-            h->inf = (st == 0 && a.inf) ? 1u : 0u;
-            h->key_flags = kf;
-            h->key_len = len;
-            for (uint32_t i = 0; i < len; i++) h->key[i] = base[i];
-            h->fresh = 1;
-            h->member_pending = (build && T::needs_member(flags)) ? 1u : 0u;
-            if (build) {
-                Jac<F> t;
-                jac_from_aff(t, a);
-                q[0] = t;
-                *base_slot<T>(ws) = a;
-                S[P].f = t.X;
-                S[P + 1].f = t.Y;
-                S[P + 2].f = t.Z;
-                go = 1;
-            } else {
-                __threadfence();
-                h->magic = MAGIC;
-            }
+        Jac<F> t;
+        go = chain_begin<T>(ws, base, flags, t);
+        if (go) {
+            S[P].f = t.X;
+            S[P + 1].f = t.Y;
+            S[P + 2].f = t.Z;
         }
     }
     __syncthreads();
@@ -254,6 +264,62 @@ __global__ __launch_bounds__(64, 2) void chain_kernel(uint8_t* __restrict__ ws, 
         h->magic = MAGIC;
     }
 }
+// The same chain with ONE LIMB PER LANE (rowfp.cuh; traits with ROW_CHAIN: a base field of 13 x 30-bit limbs) -- round 6:
+// one wave, its four rows holding the running point and sharing the seven products of a doubling.  The four-lane
+// kernel above spends 1.4 ms on the 120 doublings of a BLS12-381 G1 table -- most of what a new base costs.
+template <class T, class = void>
+struct HasRowChain {
+    static constexpr bool value = false;
+};
+template <class T>
+struct HasRowChain<T, decltype((void)T::ROW_CHAIN)> {
+    static constexpr bool value = T::ROW_CHAIN != 0;
+};
+#if defined(KYB_ROWFP_INCLUDED)
+template <class T>
+__global__ __launch_bounds__(64) void chain_rows_kernel(uint8_t* __restrict__ ws, const uint8_t* __restrict__ base, uint32_t flags) {
+    using F = typename T::F;
+    using C = typename T::RowC;
+    using namespace rowfp;
+    __shared__ uint32_t limbs[3][ROW];
+    __shared__ int go;
+    Header* h = reinterpret_cast<Header*>(ws);
+    Jac<F>* q = reinterpret_cast<Jac<F>*>(ws + HDR_BYTES);
+    if (threadIdx.x == 0) {
+        Jac<F> t;
+        go = chain_begin<T>(ws, base, flags, t);
+        __threadfence_block();
+    }
+    __syncthreads();
+    if (!go) return;
+    const auto cx = make_ctx<C>();
+    const auto dc = make_dbl_consts<C>();
+    const V32 row = row_of_lane();
+    JacRow<C> pt{load_packed<C>(q[0].X.v), load_packed<C>(q[0].Y.v), load_packed<C>(q[0].Z.v)};
+#pragma unroll 1
+    for (int w = 1; w < T::P::NW; w++) {
+#pragma unroll 1
+        for (int i = 0; i < WBITS; i++) jac_dbl_wave<C>(cx, dc, row, pt);
+        const V32 X = below_2p<C>(cx, pt.X), Y = below_2p<C>(cx, pt.Y), Z = below_2p<C>(cx, pt.Z);
+        if (threadIdx.x < ROW) {
+            limbs[0][threadIdx.x] = X;
+            limbs[1][threadIdx.x] = Y;
+            limbs[2][threadIdx.x] = Z;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            F f;
+            finish_limbs<C>(f, limbs[threadIdx.x]);
+            reinterpret_cast<F*>(q + w)[threadIdx.x] = f;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        h->magic = MAGIC;
+    }
+}
+#endif
 // One lane per table entry
 template <class T>
 __global__ __launch_bounds__(64, KYB_TU_WAVES) void table_kernel(uint8_t* __restrict__ ws) {
@@ -390,7 +456,20 @@ int run(size_t n, const void* d_scalars, const void* d_base, void* d_out, void* 
     if (int rc = ctx_workspace(ctx, T::KIND, st, tab_bytes + (parked ? n * sizeof(Jac<typename T::F>) : 0), &ws, &grew)) return rc;
     if (grew) KYB_HIP_CHECK(hipMemsetAsync(ws, 0, HDR_BYTES, st));
     auto* park = parked ? reinterpret_cast<Jac<typename T::F>*>((uint8_t*)ws + tab_bytes) : nullptr;
-    hipLaunchKernelGGL(chain_kernel<T>, dim3(1), dim3(4), 0, st, (uint8_t*)ws, (const uint8_t*)d_base, flags);
+    bool rows_chain = false;
+#if defined(KYB_ROWFP_INCLUDED)
+    if constexpr (HasRowChain<T>::value) {
+        static const bool lanes_chain = [] {  // KYB_FB_CHAIN=lanes: the four-lane kernel (A/B)
+            const char* e = getenv("KYB_FB_CHAIN");
+            return e && e[0] == 'l';
+        }();
+        if (!lanes_chain) {
+            rows_chain = true;
+            hipLaunchKernelGGL(chain_rows_kernel<T>, dim3(1), dim3(64), 0, st, (uint8_t*)ws, (const uint8_t*)d_base, flags);
+        }
+    }
+#endif
+    if (!rows_chain) hipLaunchKernelGGL(chain_kernel<T>, dim3(1), dim3(4), 0, st, (uint8_t*)ws, (const uint8_t*)d_base, flags);
     hipLaunchKernelGGL(table_kernel<T>, dim3((T::P::NW * NENT + 63) / 64), dim3(64), 0, st, (uint8_t*)ws);
     if (T::needs_member(flags)) hipLaunchKernelGGL(member_kernel<T>, dim3(1), dim3(64), 0, st, (uint8_t*)ws);
     hipLaunchKernelGGL(mul_kernel<T>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, (const uint8_t*)d_scalars, (const uint8_t*)ws,

@@ -629,6 +629,11 @@ KYB_HD void jaclz_leave(Jac<F>& r, const JacLz<LF>& p) {
     LF::leave(r.X, p.X);
     LF::leave(r.Y, p.Y);
     LF::leave(r.Z, p.Z);
+    // The doublings never set the flag (no point of an odd-order curve has Y = 0) -- a precondition that a vouched-for
+    // (KYB_F_TRUSTED) operand off the curve or of even order could break: Z = 0 (mod p) then arrives here with inf = 0.
+    // The packed form reads Z = 0 as infinity; make the whole point the canonical (1, 1, 0) so that nothing downstream
+    // sees the meaningless X, Y.
+    if (f_is_zero(r.Z)) jac_set_inf(r);
 }
 
 }  // namespace kyb

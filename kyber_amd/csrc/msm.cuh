@@ -1009,14 +1009,15 @@ int run_host_single(size_t n, const uint8_t* scalars, const uint8_t* points, uin
     // as in every other host-buffer call -- the staging pool first, the enqueue mutex second (taken the other way round
     // here until the concurrency test of tests/test_gpu_soak.py ran this against a host-buffer multiplication on a
     // second thread: each held what the other waited for)
+    // (round 6: the pipeline's workspace belongs to the pool's stream, so the enqueue mutex is held for the enqueue only --
+    // run() takes it -- and a second thread's upload overlaps this call's kernels)
     StageScope sc_(ctx);
-    std::lock_guard<std::recursive_mutex> ws_lock(ctx->enq_mu);
     StageBuf d_s, d_p, d_o, d_st;
     rc = d_s.upload(scalars, n * 32);
     if (rc == KYB_OK) rc = d_p.upload(points, n * A::wire_size(flags));
     if (rc == KYB_OK) rc = d_o.alloc(A::OUT);
     if (rc == KYB_OK) rc = d_st.alloc(n + 1);
-    if (rc == KYB_OK) rc = run<A>(ctx, n, d_s.p, d_p.p, d_o.p, d_st.p, nullptr, flags);
+    if (rc == KYB_OK) rc = run<A>(ctx, n, d_s.p, d_p.p, d_o.p, d_st.p, sc_.stream(), flags);
     if (rc == KYB_OK) rc = d_o.download(out, A::OUT);
     if (rc == KYB_OK && status && n) rc = d_st.download(status, n);
     return rc;
@@ -1159,14 +1160,13 @@ int poly_eval_host(size_t n, const uint32_t* idx, size_t t, const uint8_t* commi
     DeviceCtx* ctx;
     int rc = get_ctx(&ctx);
     if (rc) return rc;
-    StageScope sc_(ctx);  // staging pool first, enqueue mutex second (the order of every host-buffer call)
-    std::lock_guard<std::recursive_mutex> ws_lock(ctx->enq_mu);
+    StageScope sc_(ctx);
     StageBuf d_i, d_c, d_o, d_st;
     rc = d_i.upload(idx, n * 4);
     if (rc == KYB_OK) rc = d_c.upload(commits, t * A::wire_size(flags));
     if (rc == KYB_OK) rc = d_o.alloc(n * A::OUT);
     if (rc == KYB_OK) rc = d_st.alloc(t + 1);
-    if (rc == KYB_OK) rc = poly_eval_run<A>(ctx, n, d_i.p, t, d_c.p, d_o.p, d_st.p, flags, nullptr);
+    if (rc == KYB_OK) rc = poly_eval_run<A>(ctx, n, d_i.p, t, d_c.p, d_o.p, d_st.p, flags, sc_.stream());
     if (rc == KYB_OK) rc = d_o.download(out, n * A::OUT);
     if (rc == KYB_OK && status && t) rc = d_st.download(status, t);
     return rc;

@@ -65,6 +65,9 @@ struct PFX##_FbG1 { \
     using P = NS::fb_g1_policy; \
     static constexpr int MUL_WAVES = KYB_FB_G1_WAVES; /* register budget of fb::mul_kernel in waves per SIMD */ \
     static constexpr int KIND = WS_FB + 2 * fb_suite_id(#PFX); \
+    /* fixed_base.cuh chain_rows_kernel: the table's doubling chain on rowfp.cuh where the base field has its limb shape */ \
+    static constexpr int ROW_CHAIN = (NS::FC::N == 13 && NS::FC::W == 30) ? 1 : 0; \
+    using RowC = NS::FC; \
     static constexpr uint32_t KEY_FLAGS = KYB_F_UNCOMPRESSED | KYB_F_TRUSTED(0); \
     __host__ __device__ static int decode_on_curve(Aff<F>& a, const uint8_t* in, uint32_t flags) { return P::decode_on_curve(a, in, flags); } \
     __host__ __device__ static bool needs_member(uint32_t flags) { return P::needs_member(flags); } \
@@ -135,11 +138,15 @@ __global__ __launch_bounds__(64, KYB_G1_MUL_WAVES) void PFX##_g1_mul_kernel(size
 __global__ __launch_bounds__(64, KYB_G2_MUL_WAVES) void PFX##_g2_mul_kernel(size_t n, const uint8_t* __restrict__ scalars, \
                                                         const uint8_t* __restrict__ pts, size_t pt_stride, \
                                                         uint8_t* __restrict__ out, uint8_t* __restrict__ status, \
-                                                        uint32_t flags, const uint8_t* __restrict__ only) { \
+                                                        uint32_t flags, const uint8_t* __restrict__ only, \
+                                                        uint32_t* __restrict__ tabs) { \
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
     if (idx >= n) return; \
     if (only && !only[idx]) return;  /* the lane machine did this element (bls12381_lvm.cuh step 4) */ \
-    const int st = NS::g2_mul_wire(out + NS::g2_out_size(flags) * idx, scalars + 32 * idx, pts + pt_stride * idx, flags); \
+    /* tabs: a slab of NS::G2_TAB_WORDS words per lane for the ladder's window tables (suites that keep them in global \
+       memory: bn_suite.inc), indexed by the lane's position in THIS launch */ \
+    const int st = NS::g2_mul_wire(out + NS::g2_out_size(flags) * idx, scalars + 32 * idx, pts + pt_stride * idx, flags, \
+                                   tabs + NS::G2_TAB_WORDS * idx); \
     if (status) status[idx] = (uint8_t)st; \
 } \
 __global__ __launch_bounds__(64, KYB_TU_WAVES) void PFX##_g1_unmarshal_kernel(size_t n, const uint8_t* __restrict__ pts, \
@@ -220,9 +227,26 @@ int kyb_##PFX##_g2_mul_dev(size_t n, const void* d_scalars, const void* d_points
     KYB_TRY(kyb::NS::lvm_mul(true, n, (const uint8_t*)d_scalars, (const uint8_t*)d_points, point_stride, (uint8_t*)d_out, \
                              (uint8_t*)d_status, flags, (hipStream_t)stream, &only, &handled_)); \
     if (handled_) return KYB_OK; \
+    if (kyb::NS::G2_TAB_WORDS) { \
+        /* the per-lane table slab: (WS_G2TAB, stream) workspace, at most 2^20 lanes of it -- larger batches go through it in \
+           pieces (stream-ordered: a piece's kernel has read its tables before the next one writes them) */ \
+        const size_t piece = n < (size_t(1) << 20) ? n : (size_t(1) << 20); \
+        void* tw_; \
+        KYB_TRY(kyb::ctx_workspace(ctx_, kyb::WS_G2TAB, (hipStream_t)stream, piece * kyb::NS::G2_TAB_WORDS * sizeof(uint32_t), &tw_)); \
+        const size_t osz_ = kyb::NS::g2_out_size(flags); \
+        for (size_t off = 0; off < n; off += piece) { \
+            const size_t cnt = n - off < piece ? n - off : piece; \
+            hipLaunchKernelGGL(kyb::PFX##_g2_mul_kernel, dim3(kyb::grid_for(cnt, 64)), dim3(64), 0, (hipStream_t)stream, cnt, \
+                               (const uint8_t*)d_scalars + 32 * off, (const uint8_t*)d_points + point_stride * off, point_stride, \
+                               (uint8_t*)d_out + osz_ * off, d_status ? (uint8_t*)d_status + off : nullptr, flags, \
+                               (const uint8_t*)nullptr, (uint32_t*)tw_); \
+        } \
+        KYB_HIP_CHECK(hipGetLastError()); \
+        return KYB_OK; \
+    } \
     hipLaunchKernelGGL(kyb::PFX##_g2_mul_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
                        (const uint8_t*)d_scalars, (const uint8_t*)d_points, point_stride, (uint8_t*)d_out, \
-                       (uint8_t*)d_status, flags, only); \
+                       (uint8_t*)d_status, flags, only, (uint32_t*)nullptr); \
     KYB_HIP_CHECK(hipGetLastError()); \
     return KYB_OK; \
 } \
@@ -259,7 +283,7 @@ static int PFX##_mul_host(bool g2, size_t n, const uint8_t* scalars, const uint8
         key.push_back((char)((flags >> 8) & 0xff)); \
         bool use = n >= kyb::fb_min_batch(g2); \
         if (!use && n >= kyb::FB_MIN_KNOWN) { \
-            use = kyb::fb_hint_is(ctx, kind, nullptr, key); \
+            use = kyb::fb_hint_is(ctx, kind, sc_.stream(), key); \
             if (!use) { \
                 std::string gk = g2 ? kyb::PFX##_fb_generator_key<kyb::PFX##_FbG2>(flags) \
                                     : kyb::PFX##_fb_generator_key<kyb::PFX##_FbG1>(flags); \
@@ -267,7 +291,7 @@ static int PFX##_mul_host(bool g2, size_t n, const uint8_t* scalars, const uint8
             } \
         } \
         if (use) { \
-            KYB_TRY(kyb::PFX##_fb_run(g2, n, s.p, p.p, o.p, st.p, flags, nullptr, &key)); \
+            KYB_TRY(kyb::PFX##_fb_run(g2, n, s.p, p.p, o.p, st.p, flags, sc_.stream(), &key)); \
             KYB_TRY(o.download(out, n * psz)); \
             if (status) KYB_TRY(st.download(status, n)); \
             return KYB_OK; \
@@ -280,8 +304,8 @@ static int PFX##_mul_host(bool g2, size_t n, const uint8_t* scalars, const uint8
            other (measured: 2^16 coefficients 6.0 ms per-lane against 6.9 ms this way; from 2^18 on it wins).  Not for a G2 \
            base of a suite whose UnmarshalBinary does not prove subgroup membership (bn256): there TRUSTED selects the GLS \
            walk, which differs from the reference's double-and-add on off-subgroup points whatever n is */ \
-        KYB_TRY(g2 ? kyb_##PFX##_g2_unmarshal_dev(1, p.p, o.p, st.p, flags & ~KYB_F_UNCOMPRESSED_OUT, nullptr) \
-                   : kyb_##PFX##_g1_unmarshal_dev(1, p.p, o.p, st.p, flags & ~KYB_F_UNCOMPRESSED_OUT, nullptr)); \
+        KYB_TRY(g2 ? kyb_##PFX##_g2_unmarshal_dev(1, p.p, o.p, st.p, flags & ~KYB_F_UNCOMPRESSED_OUT, sc_.stream()) \
+                   : kyb_##PFX##_g1_unmarshal_dev(1, p.p, o.p, st.p, flags & ~KYB_F_UNCOMPRESSED_OUT, sc_.stream())); \
         uint8_t st0 = 0; \
         KYB_HIP_CHECK(hipMemcpy(&st0, st.p, 1, hipMemcpyDeviceToHost)); \
         if (st0) { \
@@ -291,8 +315,8 @@ static int PFX##_mul_host(bool g2, size_t n, const uint8_t* scalars, const uint8
         } \
         flags |= KYB_F_TRUSTED(0); \
     } \
-    KYB_TRY(g2 ? kyb_##PFX##_g2_mul_dev(n, s.p, p.p, stride, o.p, st.p, flags, nullptr) \
-               : kyb_##PFX##_g1_mul_dev(n, s.p, p.p, stride, o.p, st.p, flags, nullptr)); \
+    KYB_TRY(g2 ? kyb_##PFX##_g2_mul_dev(n, s.p, p.p, stride, o.p, st.p, flags, sc_.stream()) \
+               : kyb_##PFX##_g1_mul_dev(n, s.p, p.p, stride, o.p, st.p, flags, sc_.stream())); \
     KYB_TRY(o.download(out, n * psz)); \
     if (status) KYB_TRY(st.download(status, n)); \
     return KYB_OK; \
@@ -362,8 +386,8 @@ static int PFX##_unmarshal_host(bool g2, size_t n, const uint8_t* points, uint8_
     KYB_TRY(p.upload(points, n * isz)); \
     KYB_TRY(o.alloc(n * psz)); \
     KYB_TRY(st.alloc(n)); \
-    KYB_TRY(g2 ? kyb_##PFX##_g2_unmarshal_dev(n, p.p, o.p, st.p, flags, nullptr) \
-               : kyb_##PFX##_g1_unmarshal_dev(n, p.p, o.p, st.p, flags, nullptr)); \
+    KYB_TRY(g2 ? kyb_##PFX##_g2_unmarshal_dev(n, p.p, o.p, st.p, flags, sc_.stream()) \
+               : kyb_##PFX##_g1_unmarshal_dev(n, p.p, o.p, st.p, flags, sc_.stream())); \
     KYB_TRY(o.download(out, n * psz)); \
     if (status) KYB_TRY(st.download(status, n)); \
     return KYB_OK; \
@@ -390,10 +414,10 @@ static int PFX##_add_host(bool g2, size_t n, const uint8_t* a, const uint8_t* b,
     KYB_TRY(o.alloc(n * psz)); \
     KYB_TRY(st.alloc(n)); \
     if (g2) \
-        hipLaunchKernelGGL(kyb::PFX##_g2_add_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, nullptr, n, (const uint8_t*)x.p, \
+        hipLaunchKernelGGL(kyb::PFX##_g2_add_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, sc_.stream(), n, (const uint8_t*)x.p, \
                            (const uint8_t*)y.p, (uint8_t*)o.p, (uint8_t*)st.p); \
     else \
-        hipLaunchKernelGGL(kyb::PFX##_g1_add_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, nullptr, n, (const uint8_t*)x.p, \
+        hipLaunchKernelGGL(kyb::PFX##_g1_add_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, sc_.stream(), n, (const uint8_t*)x.p, \
                            (const uint8_t*)y.p, (uint8_t*)o.p, (uint8_t*)st.p); \
     KYB_HIP_CHECK(hipGetLastError()); \
     KYB_TRY(o.download(out, n * psz)); \
@@ -461,7 +485,7 @@ int kyb_##PFX##_gt_mul(size_t n, const uint8_t* scalars, const uint8_t* gt, uint
     KYB_TRY(b.upload(gt, n * GTSZ)); \
     KYB_TRY(o.alloc(n * GTSZ)); \
     KYB_TRY(st.alloc(n)); \
-    KYB_TRY(kyb_##PFX##_gt_mul_dev(n, a.p, b.p, o.p, st.p, nullptr)); \
+    KYB_TRY(kyb_##PFX##_gt_mul_dev(n, a.p, b.p, o.p, st.p, sc_.stream())); \
     KYB_TRY(o.download(out, n * GTSZ)); \
     if (status) KYB_TRY(st.download(status, n)); \
     return KYB_OK; \
@@ -490,7 +514,7 @@ int kyb_##PFX##_pair(size_t n, const uint8_t* g1, const uint8_t* g2, uint8_t* gt
     KYB_TRY(b.upload(g2, n * kyb::NS::g2_wire_size(flags))); \
     KYB_TRY(o.alloc(n * GTSZ)); \
     KYB_TRY(st.alloc(n)); \
-    KYB_TRY(kyb_##PFX##_pair_dev(n, a.p, b.p, o.p, st.p, flags, nullptr)); \
+    KYB_TRY(kyb_##PFX##_pair_dev(n, a.p, b.p, o.p, st.p, flags, sc_.stream())); \
     KYB_TRY(o.download(gt, n * GTSZ)); \
     if (status) KYB_TRY(st.download(status, n)); \
     return KYB_OK; \
@@ -519,7 +543,7 @@ int kyb_##PFX##_pair_check(size_t n, const uint8_t* p1, const uint8_t* p2, const
     KYB_TRY(d.upload(inv2, n * kyb::NS::g2_wire_size(flags))); \
     KYB_TRY(o.alloc(n)); \
     KYB_TRY(st.alloc(n)); \
-    KYB_TRY(kyb_##PFX##_pair_check_dev(n, a.p, b.p, c.p, d.p, o.p, st.p, flags, nullptr)); \
+    KYB_TRY(kyb_##PFX##_pair_check_dev(n, a.p, b.p, c.p, d.p, o.p, st.p, flags, sc_.stream())); \
     KYB_TRY(o.download(ok, n)); \
     if (status) KYB_TRY(st.download(status, n)); \
     return KYB_OK; \

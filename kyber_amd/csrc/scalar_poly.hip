@@ -57,13 +57,12 @@ static int run_host(const Mod& m, size_t n, const uint32_t* idx, size_t t, const
     }
     DeviceCtx* ctx;
     if (int rc = get_ctx(&ctx)) return rc;
-    StageScope sc_(ctx);  // staging pool first, enqueue mutex second (context.h)
-    std::lock_guard<std::recursive_mutex> ws_lock(ctx->enq_mu);
+    StageScope sc_(ctx);  // (the enqueue mutex is run()'s: held for the enqueue, not for the copies)
     StageBuf d_i, d_c, d_o;
     int rc = d_i.upload(idx, n * 4);
     if (rc == KYB_OK) rc = d_c.upload(coeffs, t * 32);
     if (rc == KYB_OK) rc = d_o.alloc(n * 32);
-    if (rc == KYB_OK) rc = run(m, n, d_i.p, t, d_c.p, d_o.p, nullptr);
+    if (rc == KYB_OK) rc = run(m, n, d_i.p, t, d_c.p, d_o.p, sc_.stream());
     if (rc == KYB_OK) rc = d_o.download(out, n * 32);
     return rc;
 }

@@ -119,15 +119,21 @@ class PriPoly:
         return [PriShare(i, self.g.Scalar().UnmarshalBinary(bytes(row))) for i, row in zip(indices, out)]
 
     def Shares(self, n: int) -> list:  # poly.go:96-102
-        # the batch kernel is an accelerator of a host-only scalar computation: no device (or any HIP error) falls back
-        # to the reference's own loop, and an empty polynomial never reaches the device
+        # the batch kernel is an accelerator of a host-only scalar computation: WITHOUT a device (library missing, no gfx950:
+        # KYB_E_NODEV = -3) the reference's own loop runs, and an empty polynomial never reaches the device.  Any other
+        # failure -- a kernel fault, a poisoned context -- is the caller's to see: it is raised, not hidden behind an
+        # O(n t) host loop.
         if n >= self.DEVICE_MIN and self.coeffs and _engine_backed(self.g):
             from .._lib import KyberHipError
 
             try:
                 return self.EvalMany(range(n))
-            except (KyberHipError, OSError):
-                pass
+            except OSError:
+                pass  # the shared library is not there
+            except KyberHipError as e:
+                no_device = ("rc=-3", "no ROCm-capable device", "no usable", "not found")  # KYB_E_NODEV, HIP's own wording, a missing library
+                if not any(w in str(e) for w in no_device):
+                    raise
         return [self.Eval(i) for i in range(n)]
 
     def Coefficients(self) -> list:  # poly.go:176-178

@@ -13,6 +13,7 @@ import pytest
 from oracle import bls12381 as O
 
 pytestmark = pytest.mark.gpu
+VKEY_SLOTS_PLUS = 10  # more rejected keys than the cache has slots (bls12381_pair.hip VKEY_SLOTS = 8)
 
 
 @pytest.fixture(scope="module")
@@ -193,9 +194,24 @@ def test_alternating_between_a_handful_of_keys_costs_a_copy_not_a_walk(bls):
             ts.append(e0.elapsed_time(e1))
         return r, ts
 
+    import ctypes
+
+    import warnings
+
+    from kyber_amd import _lib
+    from kyber_amd.pairing._engine import _stream
+
+    def stats():  # (hits, builds, next slot) of this stream's key cache: the mechanism, asserted by what it did
+        out = (ctypes.c_uint32 * 3)()
+        _lib.check(_lib.load().kyb_bls12381_debug_vkey_stats(_stream(), out), "kyb_bls12381_debug_vkey_stats")
+        return tuple(out)
+
+    h0, b0, _ = stats()
     for j in range(3):  # first sight of every key: the walk
         ok, st = bls.batch_verify_g1_same_key(keys[j], msgs, sigs[j])
         assert not st.any().item() and int(ok.sum().item()) == (n - 1 if j == 1 else n)
+    h1, b1, _ = stats()
+    assert b1 - b0 <= 3 and h1 == h0  # at most three walks (a key met by an earlier test may still be active), no hit yet
     _, steady = timed(lambda: bls.batch_verify_g1_same_key(keys[0], msgs, sigs[0]), 7)
     steady_ms = sorted(steady)[len(steady) // 2]
     seq = [1, 2, 0, 2, 1, 0, 1, 2, 0, 1]
@@ -207,9 +223,27 @@ def test_alternating_between_a_handful_of_keys_costs_a_copy_not_a_walk(bls):
         times.append(ts[0])
     # a walk costs ~9 ms on top of a ~7 ms call (2.3 x): the typical switch must stay within 1.2 x the steady state, and no
     # single one may look like a walk (the looser bound absorbs a scheduling hiccup on a shared box)
+    # the mechanism: every switch of the sequence was a hit, none a walk (steady-state repeats of the active key are neither)
+    h2, b2, _ = stats()
+    assert b2 == b1 and h2 - h1 == len(seq) + 1, ((h1, b1), (h2, b2))
+    # the timing: soft (ADVICE r5 -- a shared or throttled box can push a single un-repeated sample over any bound)
     times.sort()
-    assert times[len(times) // 2] <= 1.2 * steady_ms + 0.3, (times, steady_ms)
-    assert times[-1] <= 1.8 * steady_ms + 0.5, (times, steady_ms)
+    if not (times[len(times) // 2] <= 1.2 * steady_ms + 0.3 and times[-1] <= 1.8 * steady_ms + 0.5):
+        warnings.warn(f"key-cache switches slower than expected: {times} against a steady state of {steady_ms} ms")
+    # rejected keys and the point at infinity take no slot: a stream fed bad keys does not evict the committee's tables
+    bad_key = bytearray(bytes(keys[0].cpu().numpy()))
+    bad_key[5] ^= 0x55
+    inf_key = bytes([0xC0]) + bytes(95)
+    for _ in range(VKEY_SLOTS_PLUS):
+        for kk in (bytes(bad_key), inf_key):
+            ok, st = bls.batch_verify_g1_same_key(torch.from_numpy(np.frombuffer(kk, dtype=np.uint8).copy()).cuda(), msgs[:64].contiguous(), sigs[0][:64].contiguous())
+            assert not ok.any().item()
+    h3, b3, nx3 = stats()
+    for j in (0, 1, 2):
+        ok, st = bls.batch_verify_g1_same_key(keys[j], msgs, sigs[j])
+        assert not st.any().item() and int(ok.sum().item()) == (n - 1 if j == 1 else n)
+    h4, b4, nx4 = stats()
+    assert b4 == b3 and nx4 == nx3 and h4 - h3 == 3, ((h3, b3, nx3), (h4, b4, nx4))
     # a key signatures do not belong to, between two cached ones: still rejected
     ok, _ = bls.batch_verify_g1_same_key(keys[2], msgs, sigs[0])
     assert not ok.any().item()

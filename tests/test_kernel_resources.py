@@ -47,7 +47,9 @@ def test_tuned_kernels_keep_their_register_budget():
         return hits[0]
 
     # three waves per SIMD: <= 170 registers
-    assert find(ed, "ed25519_mul_kernelILb1E") <= 170
+    assert find(ed, "ed25519_mul_kernelILb1ELb0E") <= 170
+    assert find(ed, "ed25519_mul_kernelILb1ELb1E") <= 170  # KYB_F_UNIFORM: the scanned table, same budget
+    assert find(ed, "ed25519_mul_base_uniform_kernel") <= 170
     assert find(ed, "13decode_kernel", "EdMsm") <= 170
     # two waves per SIMD: <= 256
     assert find(msm, "13decode_kernel", "BlsG1Msm") <= 256

@@ -1,6 +1,9 @@
 """Static check of the host library's lock order: wherever one function takes both the
-device's staging pool (StageScope -> stage_mu) and its enqueue mutex (enq_mu), the staging pool comes first.  The
-deadlock this guards against needs a GPU and two threads to show; the order itself is visible in the text."""
+device's staging pool (StageScope) and its enqueue mutex (enq_mu), the staging pool comes first.  The deadlock this
+guards against needs a GPU and two threads to show; the order itself is visible in the text.  Since round 6 a host-buffer
+call holds a POOL (its own stream and buffers), not the device's one staging mutex, and the enqueue mutex only for the
+enqueue (inside run() / the _dev entry points): the MSM, poly-eval and scalar-Horner host wrappers, which used to hold
+enq_mu across their copies, must no longer name it."""
 import glob
 import os
 import re
@@ -45,4 +48,12 @@ def test_staging_pool_is_locked_before_the_enqueue_mutex():
                 if i_stage >= 0 and i_enq >= 0:
                     seen += 1
                     assert i_stage < i_enq, f"{os.path.basename(path)}: enqueue mutex taken before the staging pool"
-    assert seen >= 2  # the MSM and poly_eval host paths at least
+    # round 6: the host wrappers that held the enqueue mutex across upload / run / download no longer take it themselves
+    for name, fn in (("msm.cuh", "run_host_single"), ("msm.cuh", "poly_eval_host_single"), ("scalar_poly.hip", "eval_host")):
+        text = re.sub(r"//[^\n]*", "", open(os.path.join(CSRC, name)).read())
+        hits = [m.start() for m in re.finditer(r"StageScope sc_\(ctx\)", text)]
+        assert hits, name
+        for h in hits:
+            # up to the wrapper's download (the end of the copies): no enqueue mutex in between
+            end = text.find("download(", h)
+            assert end > h and "enq_mu" not in text[h:end], f"{name}: a host wrapper holds enq_mu across its copies again"

@@ -25,9 +25,10 @@ __global__ __launch_bounds__(256) void k(uint64_t* out, uint32_t seed) {
             if (KIND == 2) acc[c] = (uint32_t)acc[c] * b + a;                                   // v_mul_lo_u32 (+add) / v_mad_u32?
             if (KIND == 3) acc[c] = __umulhi((uint32_t)acc[c], b) + a;                          // v_mul_hi_u32
             if (KIND == 4) acc[c] = __umul24((uint32_t)acc[c], b) + a;                          // v_mad_u32_u24
-            if (KIND == 5) acc[c] = (uint32_t)acc[c] + b;                                       // v_add_u32
+            // (KIND 5, a bare v_add_u32 of a loop-invariant, and KIND 7, its 64-bit form, were folded by the compiler into one
+            // addition per chain -- their rows claimed 3x the chip's full-rate VALU ceiling; removed in round 6.
+            // The loop body of every remaining kind is dumped beside the figures: profiles/r06_valu_peak_isa.txt)
             if (KIND == 6) facc[c] = fma(facc[c], fa, fb);                                      // v_fma_f64
-            if (KIND == 7) acc[c] = acc[c] + (((uint64_t)b << 32) | a);                         // 64-bit add (2 instr)
             if (KIND == 8) acc[c] = (uint64_t)((int64_t)acc[c] >> 26) + b;                      // 64-bit ashr + add
             if (KIND == 9) acc[c] = (uint64_t)acc[c] * 3 + ((uint64_t)a * b);                   // pure mad chain (mul by small const + mad)
             if (KIND == 10) acc[c] = (acc[c] << 3) + (((uint64_t)b << 32) | a);                  // v_lshl_add_u64
@@ -69,9 +70,7 @@ int main() {
     run<2>("mul_lo_u32+add", d);
     run<3>("mul_hi_u32+add", d);
     run<4>("mad_u32_u24", d);
-    run<5>("add_u32", d);
     run<6>("fma_f64", d);
-    run<7>("add_u64", d);
     run<8>("ashr_i64+add", d);
     run<10>("lshl_add_u64", d);
     run<11>("alignbit+add(+or)", d);
