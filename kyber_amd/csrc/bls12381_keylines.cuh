@@ -133,5 +133,142 @@ KYB_HD_NOINLINE bool g2_key_lines(uint32_t (*out)[4][12], const g2_aff& q) {
     return true;
 }
 
+#if defined(KYB_ROWFP_INCLUDED)
+// ---- The same walk with ONE LIMB PER LANE (rowfp.cuh), one wave -- round 6.  A lone lane needs ~9 ms for the 890 Fp2
+// products above (the first sight of a key by kyb_bls12381_verify_g1_same_key); here an Fp2 product is one LEVEL of the
+// wave's four rows (rowfp.cuh f2_mul) and the walk ~1 000 levels.  Same formulas, same outputs word for word
+// (tests/test_host_harness_rowfp.py runs both on the CPU); the doubling's B = Y^2 is a product (Y comes out of an addition
+// step below 13p: the squaring form's (y0 + y1)(y0 - y1) would not fit R / p) and 12 xi Z^2 is a product by the constant
+// 12 (1 + i) (the sums 12 u, 36 u would not either).
+// Value bounds (multiples of p, (c0, c1)), products marked M = (5, 4):
+//   doubling, X (5,4) Y (13,12) Z (5,4):  XY, YZ, B = YY: M (5 x 13, 13 x 5, 169);  X^2, Z^2: (2,4) (s < 9, d < 13);
+//     E = Z^2 C12: M, 3E (15,12);  l0 = B - E + 8p (13,12);  c2 = 3 (8p - X^2) (24,24), c3 = 2YZ (10,8);
+//     X3 = 2XY (B - 3E + 16p): (10,8) x (21,20) = 210 -> M;  Y3 = B^2 + 3E (2B - E + 8p): (15,12) x (18,16) = 270 -> (7,8);
+//     Z3 = (2B)(4YZ): (10,8) x (20,16) = 200 -> M
+//   addition, X (5,4) Y (7,8) Z (5,4), q (1,1):  TH = Y - yq Z + 8p (15,16), LA = X - xq Z + 8p (13,12);
+//     l0 = TH xq - LA yq + 8p (13,12);  c2 = 24p - TH (24,24), c3 = LA;  C = TH TH (256), D = LA LA (169), E = LA D, F = Z C,
+//     G = X D: M;  X' = LA (E + F - 2G + 16p): 13 x 26 = 338;  Y' = TH (3G - E - F + 16p) - E Y + 8p: 16 x 31 = 496, (13,12);
+//     Z' = Z E: M
+//   second pass: pre = pre l0 (5 x 13), 1/l0 = inv pre (25), inv = inv l0, c2 / l0 (24 x 5), c3 / l0 (13 x 5); x 4 below 22p.
+struct KeyLinesMem {  // 35 KB of LDS (device) for the per-step values the second pass needs
+    uint32_t l0[KEYLINE_STEPS][2][rowfp::ROW], pre[KEYLINE_STEPS][2][rowfp::ROW], c2[KEYLINE_STEPS][2][rowfp::ROW],
+        c3[KEYLINE_STEPS][2][rowfp::ROW];
+    uint32_t fin[4][rowfp::ROW];
+    uint32_t inv[2][12];
+    uint32_t ok;
+};
+// q: a finite affine point of the twist, packed words qx0, qx1, qy0, qy1 (Montgomery form).  Every lane of the (one-wave)
+// workgroup calls it; out as g2_key_lines.  Returns false (in every lane) when some l0 vanished.
+KYB_ROW bool g2_key_lines_rows(KeyLinesMem& m, uint32_t (*out)[4][12], const uint32_t* qx0, const uint32_t* qx1, const uint32_t* qy0,
+                               const uint32_t* qy1) {
+    using namespace rowfp;
+    using C = FC;
+    using E2 = F2<C>;
+    const auto cx = make_ctx<C>();
+    const auto k = make_f2_consts<C>();
+    const V32 row = row_of_lane();
+    const V32 zero = splat(0u);
+    const E2 qx{load_packed<C>(qx0), load_packed<C>(qx1)}, qy{load_packed<C>(qy0), load_packed<C>(qy1)};
+    const V32 twelve = lane_table(K<C>::small_limbs(12));
+    const E2 c12{twelve, twelve};  // 12 (1 + i)
+    E2 X = qx, Y = qy, Z{lane_table(K<C>::one_limbs()), zero};
+    int s = 0;
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+    for (int bit = 62; bit >= 0; bit--) {
+        const E2 XY = f2_mul<C>(cx, k, row, X, Y), YZ = f2_mul<C>(cx, k, row, Y, Z), B = f2_mul<C>(cx, k, row, Y, Y);
+        E2 A, Zs;
+        f2_sqr2<C>(cx, row, A, X, k.b8, Zs, Z, k.b8);
+        const E2 Ee = f2_mul<C>(cx, k, row, Zs, c12), E3 = f2_triple<C>(Ee);
+        f2_store<C>(m.l0[s], f2_sub<C>(B, Ee, k.b8));
+        f2_store<C>(m.c2[s], f2_triple<C>(f2_neg<C>(A, k.b8)));
+        f2_store<C>(m.c3[s], f2_dbl<C>(YZ));
+        s++;
+        E2 BB, unused;
+        f2_sqr2<C>(cx, row, BB, B, k.b8, unused, B, k.b8);
+        X = f2_mul<C>(cx, k, row, f2_dbl<C>(XY), f2_sub<C>(B, E3, k.b16));
+        Y = f2_add<C>(BB, f2_mul<C>(cx, k, row, E3, f2_sub<C>(f2_dbl<C>(B), Ee, k.b8)));
+        Z = f2_mul<C>(cx, k, row, f2_dbl<C>(B), f2_dbl<C>(f2_dbl<C>(YZ)));
+        if ((CC::X_ABS >> bit) & 1ull) {
+            const E2 TH = f2_sub<C>(Y, f2_mul<C>(cx, k, row, qy, Z), k.b8), LA = f2_sub<C>(X, f2_mul<C>(cx, k, row, qx, Z), k.b8);
+            f2_store<C>(m.l0[s], f2_sub<C>(f2_mul<C>(cx, k, row, TH, qx), f2_mul<C>(cx, k, row, LA, qy), k.b8));
+            f2_store<C>(m.c2[s], f2_neg<C>(TH, k.b24));
+            f2_store<C>(m.c3[s], LA);
+            s++;
+            const E2 Cc = f2_mul<C>(cx, k, row, TH, TH), D = f2_mul<C>(cx, k, row, LA, LA);
+            const E2 Ea = f2_mul<C>(cx, k, row, LA, D), Ff = f2_mul<C>(cx, k, row, Z, Cc), Gg = f2_mul<C>(cx, k, row, X, D);
+            const E2 EF = f2_add<C>(Ea, Ff);
+            X = f2_mul<C>(cx, k, row, LA, f2_sub<C>(EF, f2_dbl<C>(Gg), k.b16));
+            const E2 t = f2_mul<C>(cx, k, row, TH, f2_sub<C>(f2_triple<C>(Gg), EF, k.b16));
+            Y = f2_sub<C>(t, f2_mul<C>(cx, k, row, Ea, Y), k.b8);
+            Z = f2_mul<C>(cx, k, row, Z, Ea);
+        }
+    }
+    row_sync();
+    // prefix products of the l0's
+    E2 pre = f2_load<C>(m.l0[0]);
+    f2_store<C>(m.pre[0], pre);
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+    for (int j = 1; j < KEYLINE_STEPS; j++) {
+        pre = f2_mul<C>(cx, k, row, pre, f2_load<C>(m.l0[j]));
+        f2_store<C>(m.pre[j], pre);
+    }
+    // the one inversion, in the packed form by one lane (zero: some l0 vanished)
+    const V32 one = lane_table(K<C>::one_limbs());
+    {
+        V32 p0, p1, p2, p3;
+        level4<C>(cx, row, pre.c0, one, pre.c1, one, pre.c0, one, pre.c1, one, p0, p1, p2, p3);
+        store_row(m.fin[0], p0);
+        store_row(m.fin[1], p1);
+    }
+    row_sync();
+    KYB_ROW_LONE {
+        fp2 v, vi;
+        finish_limbs<C>(v.c0, m.fin[0]);
+        finish_limbs<C>(v.c1, m.fin[1]);
+        m.ok = fp2_is_zero(v) ? 0u : 1u;
+        fp2_inv(vi, v);
+        for (int w = 0; w < 12; w++) {
+            m.inv[0][w] = vi.c0.v[w];
+            m.inv[1][w] = vi.c1.v[w];
+        }
+    }
+    row_sync();
+    if (!m.ok) return false;
+    E2 inv{load_packed<C>(m.inv[0]), load_packed<C>(m.inv[1])};
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+    for (int j = KEYLINE_STEPS - 1; j >= 0; j--) {
+        E2 li = inv;
+        if (j > 0) {
+            li = f2_mul<C>(cx, k, row, inv, f2_load<C>(m.pre[j - 1]));  // 1 / l0[j]
+            inv = f2_mul<C>(cx, k, row, inv, f2_load<C>(m.l0[j]));      // 1 / (l0[0] .. l0[j-1])
+        }
+        // Montgomery residue v 2^390 -> the plain integer v 2^392 mod p: four times the value, then the canonical words
+        const E2 c2 = f2_dbl<C>(f2_dbl<C>(f2_mul<C>(cx, k, row, f2_load<C>(m.c2[j]), li)));
+        const E2 c3 = f2_dbl<C>(f2_dbl<C>(f2_mul<C>(cx, k, row, f2_load<C>(m.c3[j]), li)));
+        V32 p0, p1, p2, p3;
+        level4<C>(cx, row, c2.c0, one, c2.c1, one, c3.c0, one, c3.c1, one, p0, p1, p2, p3);
+        row_sync();  // (the lanes below have read the previous step's fin)
+        store_row(m.fin[0], p0);
+        store_row(m.fin[1], p1);
+        store_row(m.fin[2], p2);
+        store_row(m.fin[3], p3);
+        row_sync();
+        KYB_ROW_LANES(4) {
+            fp f;
+            finish_limbs<C>(f, m.fin[j_]);
+            for (int w = 0; w < 12; w++) out[j][j_][w] = f.v[w];
+        }
+    }
+    row_sync();
+    return true;
+}
+#endif
+
 }  // namespace bls
 }  // namespace kyb

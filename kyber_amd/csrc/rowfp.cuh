@@ -93,6 +93,12 @@ template <class Arr> KYB_ROW V32 lane_table(const Arr& t) {  // t.v[lane in row]
     for (int i = 0; i < ROW; i++) r = l == (uint32_t)i ? t.v[i] : r;
     return r;
 }
+// a row element parked in memory (LDS / global): 16 words, limb l at word l; every row stores the same value, every row loads it
+KYB_ROW void store_row(uint32_t* m, V32 v) { m[__lane_id() & 15u] = v; }
+KYB_ROW V32 load_row(const uint32_t* m) { return m[__lane_id() & 15u]; }
+KYB_ROW void row_sync() { __syncthreads(); }  // (one wave per workgroup: orders its own memory traffic for the compiler)
+#define KYB_ROW_LONE if (__lane_id() == 0)
+#define KYB_ROW_LANES(n) for (int j_ = (int)__lane_id(); j_ < (n); j_ += 64)
 #else
 #define KYB_ROW inline
 // host emulation of one wave: 64 lanes, four rows of 16
@@ -144,6 +150,11 @@ KYB_ROW V32 hi32(V64 a) { V32 r; KYB_ROW_EACH r.v[i_] = (uint32_t)(a.v[i_] >> 32
 KYB_ROW V64 make64(V32 lo, V32 hi) { V64 r; KYB_ROW_EACH r.v[i_] = ((uint64_t)hi.v[i_] << 32) | lo.v[i_]; return r; }
 KYB_ROW V64 widen(V32 a) { V64 r; KYB_ROW_EACH r.v[i_] = a.v[i_]; return r; }
 template <class Arr> KYB_ROW V32 lane_table(const Arr& t) { V32 r; KYB_ROW_EACH r.v[i_] = t.v[i_ & 15]; return r; }
+KYB_ROW void store_row(uint32_t* m, V32 v) { for (int i = 0; i < 16; i++) m[i] = v.v[i]; }
+KYB_ROW V32 load_row(const uint32_t* m) { V32 r; KYB_ROW_EACH r.v[i_] = m[i_ & 15]; return r; }
+KYB_ROW void row_sync() {}
+#define KYB_ROW_LONE
+#define KYB_ROW_LANES(n) for (int j_ = 0; j_ < (n); j_++)
 #endif
 
 template <int S> KYB_ROW V64 shr_lanes64(V64 x) { return make64(shr_lanes<S>(lo32(x)), shr_lanes<S>(hi32(x))); }
@@ -220,6 +231,41 @@ struct K {
             v >>= sh;
             o.v[j] = j + 1 < N ? (uint32_t)(v & MASK) : (uint32_t)v;
         }
+        return o;
+    }
+    // k in the Montgomery domain (k R mod p) as limbs, for small k: R mod p added k times with a conditional subtraction
+    static constexpr Arr16 small_limbs(int k) {
+        uint64_t acc[N] = {};
+        const Arr16 one = one_limbs();
+        for (int t = 0; t < k; t++) {
+            uint64_t c = 0;
+            for (int j = 0; j < N; j++) {
+                const uint64_t x = acc[j] + one.v[j] + c;
+                acc[j] = j + 1 < N ? (x & MASK) : x;
+                c = j + 1 < N ? (x >> W) : 0;
+            }
+            // acc >= p ?  compare from the top limb
+            bool ge = true;
+            for (int j = N - 1; j >= 0; j--) {
+                if (acc[j] != C::P[j]) {
+                    ge = acc[j] > C::P[j];
+                    break;
+                }
+            }
+            if (ge) {
+                int64_t b = 0;
+                for (int j = 0; j < N; j++) {
+                    int64_t x = (int64_t)acc[j] - (int64_t)C::P[j] + b;
+                    if (j + 1 < N) {
+                        b = x < 0 ? -1 : 0;
+                        x &= (int64_t)MASK;
+                    }
+                    acc[j] = (uint64_t)x;
+                }
+            }
+        }
+        Arr16 o{};
+        for (int j = 0; j < N; j++) o.v[j] = (uint32_t)acc[j];
         return o;
     }
     static constexpr Arr16 only_lane(int l) {
@@ -473,6 +519,67 @@ KYB_HD void finish_limbs(Fp<C>& r, const uint32_t* limbs) {
     }
     fp_finish<C>(r, s);
 }
+
+// ---- Fp2 = Fp[i] / (i^2 + 1) on the wave: an element is two row elements (c0, c1) held by all four rows; a LEVEL is four
+// base-field products at once, row r computing the r-th and the results gathered over the rows.  An Fp2 product is one
+// level (a0 b0, a1 b1, a0 b1, a1 b0), two Fp2 squarings share one ((a0 + a1)(a0 - a1), a0 a1 each).
+// Value bounds: a product comes out as c0 < 5p (P0 - P1 + 3p), c1 < 4p; the caller keeps every operand product below R / p.
+template <class C>
+struct F2 {
+    V32 c0, c1;
+};
+template <class C>
+struct F2Consts {
+    V32 b3, b8, b16, b24;  // borrow-proof limbs of 3p, 8p, 16p, 24p: a subtrahend must stay a whole p BELOW the constant used
+};
+template <class C>
+KYB_ROW F2Consts<C> make_f2_consts() {
+    F2Consts<C> d;
+    d.b3 = lane_table(K<C>::template borrow<3>());
+    d.b8 = lane_table(K<C>::template borrow<8>());
+    d.b16 = lane_table(K<C>::template borrow<16>());
+    d.b24 = lane_table(K<C>::template borrow<24>());
+    return d;
+}
+template <class C>
+KYB_ROW void level4(const Ctx<C>& cx, V32 row, V32 x0, V32 y0, V32 x1, V32 y1, V32 x2, V32 y2, V32 x3, V32 y3, V32& p0, V32& p1,
+                    V32& p2, V32& p3) {
+    const V32 m = mul<C>(cx, pick4<C>(row, x0, x1, x2, x3), pick4<C>(row, y0, y1, y2, y3));
+    p0 = from_row(m, 0);
+    p1 = from_row(m, 1);
+    p2 = from_row(m, 2);
+    p3 = from_row(m, 3);
+}
+template <class C>
+KYB_ROW F2<C> f2_mul(const Ctx<C>& cx, const F2Consts<C>& k, V32 row, const F2<C>& a, const F2<C>& b) {
+    V32 p0, p1, p2, p3;
+    level4<C>(cx, row, a.c0, b.c0, a.c1, b.c1, a.c0, b.c1, a.c1, b.c0, p0, p1, p2, p3);
+    return F2<C>{sub_k<3, C>(p0, p1, k.b3), add2<C>(p2, p3)};
+}
+// a^2 and b^2 in one level; ba / bb: borrow constants at least a whole p above a.c1 / b.c1.  Results: c0 < 2p, c1 < 4p.
+template <class C>
+KYB_ROW void f2_sqr2(const Ctx<C>& cx, V32 row, F2<C>& ra, const F2<C>& a, V32 ba, F2<C>& rb, const F2<C>& b, V32 bb) {
+    const V32 sa = add2<C>(a.c0, a.c1), da = carry<C>(sub(add(a.c0, ba), a.c1));
+    const V32 sb = add2<C>(b.c0, b.c1), db = carry<C>(sub(add(b.c0, bb), b.c1));
+    V32 p0, p1, p2, p3;
+    level4<C>(cx, row, sa, da, a.c0, a.c1, sb, db, b.c0, b.c1, p0, p1, p2, p3);
+    ra = F2<C>{p0, dbl<C>(p1)};
+    rb = F2<C>{p2, dbl<C>(p3)};
+}
+template <class C> KYB_ROW F2<C> f2_add(const F2<C>& a, const F2<C>& b) { return F2<C>{add2<C>(a.c0, b.c0), add2<C>(a.c1, b.c1)}; }
+template <class C> KYB_ROW F2<C> f2_dbl(const F2<C>& a) { return F2<C>{dbl<C>(a.c0), dbl<C>(a.c1)}; }
+template <class C> KYB_ROW F2<C> f2_triple(const F2<C>& a) { return F2<C>{triple<C>(a.c0), triple<C>(a.c1)}; }
+template <class C> KYB_ROW F2<C> f2_sub(const F2<C>& a, const F2<C>& b, V32 bk) {  // a - b + K p per component
+    return F2<C>{carry<C>(sub(add(a.c0, bk), b.c0)), carry<C>(sub(add(a.c1, bk), b.c1))};
+}
+template <class C> KYB_ROW F2<C> f2_neg(const F2<C>& a, V32 bk) {  // K p - a
+    return F2<C>{carry<C>(sub(bk, a.c0)), carry<C>(sub(bk, a.c1))};
+}
+template <class C> KYB_ROW void f2_store(uint32_t (*m)[ROW], const F2<C>& a) {
+    store_row(m[0], a.c0);
+    store_row(m[1], a.c1);
+}
+template <class C> KYB_ROW F2<C> f2_load(const uint32_t (*m)[ROW]) { return F2<C>{load_row(m[0]), load_row(m[1])}; }
 
 }  // namespace rowfp
 }  // namespace kyb

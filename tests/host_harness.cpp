@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "../kyber_amd/csrc/bls12381.cuh"
+#include "../kyber_amd/csrc/rowfp.cuh"
 #include "../kyber_amd/csrc/bls12381_h2c.cuh"
 #include "../kyber_amd/csrc/bn254.cuh"
 #include "../kyber_amd/csrc/bn256.cuh"
@@ -16,7 +17,6 @@
 #include "../kyber_amd/csrc/bls12381_g1coop.cuh"
 #include "../kyber_amd/csrc/coop_slots.cuh"
 #include "../kyber_amd/csrc/scalar_field.cuh"
-#include "../kyber_amd/csrc/rowfp.cuh"
 #include <pthread.h>
 #include <thread>
 #include <vector>
@@ -645,6 +645,20 @@ int hh_bls_g2_key_lines(const uint8_t* q96, uint8_t* out) {
     if (st || q.inf) return st ? st : 64;
     static uint32_t lines[bls::KEYLINE_STEPS][4][12];
     if (!bls::g2_key_lines(lines, q)) return 65;
+    memcpy(out, lines, sizeof lines);
+    return 0;
+}
+// the same walk on the limb-per-lane arithmetic (g2_key_lines_rows, emulated lane by lane): must give the same words
+int hh_bls_g2_key_lines_rows(const uint8_t* q96, uint8_t* out, int* overflows) {
+    bls::g2_aff q;
+    const int st = bls::g2_decode(q, q96, true);
+    if (st || q.inf) return st ? st : 64;
+    static uint32_t lines[bls::KEYLINE_STEPS][4][12];
+    static bls::KeyLinesMem mem;
+    rowfp::overflow_count() = 0;
+    const bool ok = bls::g2_key_lines_rows(mem, lines, q.x.c0.v, q.x.c1.v, q.y.c0.v, q.y.c1.v);
+    *overflows = rowfp::overflow_count();
+    if (!ok) return 65;
     memcpy(out, lines, sizeof lines);
     return 0;
 }

@@ -156,3 +156,19 @@ def test_leaving_the_row_form_gives_the_canonical_residue():
         out = (C.c_uint32 * 12)()
         assert lib.hh_row_finish(_rows([v, 3, 5, 7], 40, rng), out) == 0
         assert sum(w << (32 * j) for j, w in enumerate(out)) == v % O.P, hex(v)
+
+
+def test_key_lines_on_rows_equal_the_lone_lane_walk():
+    """bls12381_keylines.cuh g2_key_lines_rows (one wave, an Fp2 product per level of its four rows) against g2_key_lines
+    (one lane) on the CPU: the 68 x 4 x 12 words of the line table, equal word for word, for the generator and random keys;
+    no 64-bit accumulator of the emulation wraps (the value bounds in the header hold)"""
+    rng = random.Random(76)
+    lib = H.lib()
+    n = 68 * 4 * 48
+    for x in (1, 2, O.R - 1, rng.randrange(1, O.R), rng.randrange(1, O.R)):
+        key = O.g2_compress(O.g2_mul(x, O.G2_GEN))
+        a, b, ov = C.create_string_buffer(n), C.create_string_buffer(n), C.c_int(-1)
+        assert lib.hh_bls_g2_key_lines(key, a) == 0
+        assert lib.hh_bls_g2_key_lines_rows(key, b, C.byref(ov)) == 0
+        assert ov.value == 0
+        assert a.raw == b.raw, x
