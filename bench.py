@@ -539,6 +539,15 @@ def other_workloads(rank, world, dist):
     fn = (lambda: kd.ed25519_msm(ks, pts)) if dist else (lambda: ed.msm(ks, pts))
     ms, = max_over_ranks(dist, [timed(fn)])
     out["ed25519_msm_2p20"] = {"points": n, "seconds": ms * 1e-3, "scaling": "strong"}
+    # KYB_F_UNIFORM (round 6): the same 2^20 multiplications with the window tables scanned, not indexed -- the access pattern
+    # of the reference's default constant-time Mul (ge.go:352-371, 419-435), for secret scalars; same bytes as the default
+    ms_uv, ms_uf = max_over_ranks(dist, [timed(lambda: ed.batch_mul(ks, pts, uniform=True), reps=10, warm=2),
+                                         timed(lambda: ed.batch_mul_base(ks, uniform=True), reps=10, warm=2)])
+    same = bool(torch.equal(ed.batch_mul(ks, pts, uniform=True)[0], ed.batch_mul(ks, pts)[0]) and
+                torch.equal(ed.batch_mul_base(ks, uniform=True), ed.batch_mul_base(ks)))
+    per = hi - lo
+    out["ed25519_uniform"] = {"var_base_per_s": world * per / ms_uv * 1e3, "fixed_base_per_s": world * per / ms_uf * 1e3,
+                              "outputs_equal_default": same, "elements_per_gpu": per}
     return out
 
 
@@ -604,6 +613,8 @@ def compact_line(res: dict) -> dict:
             "bn256_g1_muls_per_s": (n6.get("g1_muls_per_s"), _g(n6, "roofline", "g1_mul", "frac")),
             "bn256_g2_muls_per_s": (n6.get("g2_muls_per_s"), _g(n6, "roofline", "g2_mul", "frac")),
             "ed25519_msm_2p20_s": (_g(ow, "ed25519_msm_2p20", "seconds"), None),
+            "ed25519_uniform_var_base_per_s": (_g(ow, "ed25519_uniform", "var_base_per_s"), None),
+            "ed25519_uniform_fixed_base_per_s": (_g(ow, "ed25519_uniform", "fixed_base_per_s"), None),
         }
         for k, (v, f) in sc.items():
             line[k] = _r4(v)
@@ -612,6 +623,7 @@ def compact_line(res: dict) -> dict:
         line["checks"] = {"bls12381_all_true": b.get("all_checks_true"), "bn256_all_true": n6.get("all_checks_true"),
                           "msm_matches_expectation": mm.get("matches_sum_ki_hi_times_G"),
                           "commit_matches_var_base": cm.get("matches_variable_base_kernels"),
+                          "uniform_equals_default": _g(ow, "ed25519_uniform", "outputs_equal_default"),
                           "commit_matches_oracle": _g(cbo, "bls12381_g1_commit_oracle_sample", "outputs_match"),
                           "bls12381_pair_matches_cpu_port": _g(cbo, "bls12381_pairings", "outputs_match"),
                           "bn256_pair_matches_cpu_port": _g(cbo, "bn256_pairings", "outputs_match")}

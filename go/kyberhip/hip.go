@@ -35,6 +35,7 @@ import (
 // Flags of the calls (kyber_hip.h).
 const (
 	Vartime         = uint32(C.KYB_F_VARTIME)          // Ed25519: geScalarMultVartime semantics
+	Uniform         = uint32(C.KYB_F_UNIFORM)          // Ed25519: tables scanned, not indexed (the constant-time path's access pattern); exclusive with Vartime
 	Uncompressed    = uint32(C.KYB_F_UNCOMPRESSED)     // BLS12-381 inputs in the 96 / 192-byte uncompressed form
 	UncompressedOut = uint32(C.KYB_F_UNCOMPRESSED_OUT) // BLS12-381 mul outputs too
 	TrustedAll      = uint32(C.KYB_F_TRUSTED_ALL)      // the four point arguments of a pairing check

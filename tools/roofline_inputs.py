@@ -30,7 +30,7 @@ SOURCES = {
     "ed": [C + "ed25519.hip", C + "fe25519.cuh", C + "ge25519.cuh"],
     "bls12381": [C + "bls12381_pair.hip", C + "tower_vm.cuh", C + "gen_tower_vm.py", C + "bls12381_tvm.h", C + "bls12381_prep.hip", C + "bls12381.cuh"] + COMMON_PAIRING,
     "verify": [C + "bls12381_pair.hip", C + "tower_vm.cuh", C + "gen_tower_vm.py", C + "bls12381_tvm.h", C + "bls12381_prep.hip", C + "bls12381.cuh", C + "bls12381_h2c.cuh",
-               C + "bls12381_keylines.cuh"] + COMMON_PAIRING,
+               C + "bls12381_keylines.cuh", C + "rowfp.cuh"] + COMMON_PAIRING,
     "gtmul": [C + "bls12381_pair.hip", C + "bn256_pair.hip", C + "bn254_pair.hip", C + "bn_pair.inc", C + "tower_vm.cuh", C + "gen_tower_vm.py",
               C + "bls12381_tvm.h"],
     "bn256": [C + "bn256_pair.hip", C + "bn_pair.inc", C + "tower_vm.cuh", C + "gen_tower_vm.py", C + "bn256.cuh", C + "bn_suite.inc", C + "bn256.hip",
@@ -40,8 +40,8 @@ SOURCES = {
     "mul": [C + "bls12381.hip", C + "bls12381_lvm.cuh", C + "lane_vm.cuh", C + "gen_lane_vm.py", C + "bls12381.cuh", C + "pairing_abi.cuh",
             C + "bls12381_unm2.hip", C + "bls12381_g1split.hip"] + COMMON_PAIRING,
     "mulperlane": [C + "bls12381.hip", C + "bls12381.cuh", C + "pairing_abi.cuh"] + COMMON_PAIRING,
-    "msm_bls": [C + "bls12381_msm.hip", C + "msm.cuh", C + "msm_ws.cuh", C + "coop_slots.cuh", C + "bls12381.cuh"] + COMMON_PAIRING,
-    "fb": [C + "fixed_base.cuh", C + "bls12381_fb.cuh", C + "pairing_abi.cuh", C + "bls12381_fb.hip", C + "bls12381.cuh", C + "coop_slots.cuh"] + COMMON_PAIRING,
+    "msm_bls": [C + "bls12381_msm.hip", C + "msm.cuh", C + "msm_ws.cuh", C + "coop_slots.cuh", C + "bls12381.cuh", C + "rowfp.cuh"] + COMMON_PAIRING,
+    "fb": [C + "fixed_base.cuh", C + "bls12381_fb.cuh", C + "pairing_abi.cuh", C + "bls12381_fb.hip", C + "bls12381.cuh", C + "coop_slots.cuh", C + "rowfp.cuh"] + COMMON_PAIRING,
 }
 
 
