@@ -578,7 +578,7 @@ def compact_line(res: dict) -> dict:
                                     "scaling", "vs_baseline", "dtype", "data")}
     line["config"] = {"workload": _g(res, "config", "workload"), "elements_per_gpu": _g(res, "config", "elements_per_gpu")}
     line["rccl_ranks_seen"] = res.get("rccl_ranks_seen")
-    line["roofline"] = {"bound": ro.get("bound"), "kernel": ro.get("kernel_symbol") or "ed25519_mul_kernel<true>", "achieved": ro.get("achieved"),
+    line["roofline"] = {"bound": ro.get("bound"), "kernel": ro.get("kernel_symbol") or "ed25519_mul_kernel<true, false>", "achieved": ro.get("achieved"),
                         "peak": ro.get("peak"), "unit": ro.get("unit"), "frac": _r4(ro.get("frac")),
                         "mads_per_op": ro.get("imads_per_op"), "kernel_ms": _r4(_g(res, "detail", "var_base_kernel_ms")),
                         "valu_busy_profiled": _r4(ro.get("valu_busy_profiled")), "traffic": ro.get("traffic"),
@@ -844,7 +844,7 @@ def main():
                        "host_buffer_path_scalar_muls_per_s": host_rate},
             "roofline": {"bound": "valu-imad",
                          "kernel": "ed25519_mul_kernel (variable-base, dominant: ~85% of a step)",
-                         "kernel_symbol": "ed25519_mul_kernel<true>",
+                         "kernel_symbol": "ed25519_mul_kernel<true, false>",
                          "binding_resource": "integer VALU issue (v_mad_i64_i32 at half rate): 96 algorithmic bytes per "
                                              "2.06e5 integer MADs, no dense contraction for MFMA",
                          "imads_per_op": IMADS_VAR, "achieved": IMADS_VAR * n / var_s, "peak": imad_peak,

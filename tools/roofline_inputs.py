@@ -106,7 +106,7 @@ res = {"_comment": "Inputs bench.py reads for its roofline objects; every number
                    "(tools/roofline_inputs.py).",
        "imad_peak_lane_ops_per_s": old["imad_peak_lane_ops_per_s"], "imad_peak_source": old["imad_peak_source"],
        "kernels": {}}
-for key, prefix, sub, units in (("ed25519_mul", "ed", "ed25519_mul_kernel<true>", 1 << 20),
+for key, prefix, sub, units in (("ed25519_mul", "ed", "ed25519_mul_kernel<true, false>", 1 << 20),
                                 ("bls12381_pair", "bls12381", "bls12381_tvm_kernel<0>", 1 << 16),
                                 ("bls12381_check", "bls12381", "bls12381_tvm_kernel<1>", 1 << 16),
                                 ("bls12381_verify", "verify", "bls12381_tvm_kernel<2>", 1 << 16),
