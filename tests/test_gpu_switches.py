@@ -14,6 +14,8 @@ CASES = [
     ("fb", {}), ("fb", {"KYB_FB_MIN": "0"}), ("fb", {"KYB_FB_MIN": "1000"}),
     ("msm", {"KYB_MSM_TAIL": "coop"}), ("msm", {"KYB_MSM_TAIL": "lane"}), ("msm", {"KYB_MSM_SUB": "64"}),
     ("msm", {"KYB_MSM_CHUNK": "16"}), ("msm", {"KYB_MSM_CHUNK": "4"}),
+    # round 6: the three-lane final kernel instead of the limb-per-lane one; the four-lane fixed-base chain; one staging pool
+    ("msm", {"KYB_MSM_FINAL": "lanes"}), ("fb", {"KYB_FB_CHAIN": "lanes"}), ("pipe", {"KYB_STAGE_POOLS": "1"}), ("msm", {"KYB_STAGE_POOLS": "1"}),
     ("bnhash", {}), ("bnhash", {"KYB_BN_HASH_QUEUE": "0"}), ("bnhash", {"KYB_BN_HASH_HQ": "512"}),
     ("pipe", {}), ("pipe", {"KYB_PIPE_CHUNK": "4096", "KYB_PIPE_STREAMS": "1"}), ("pipe", {"KYB_PIPE_CHUNK": "4096", "KYB_PIPE_STREAMS": "3"}),
     ("unmw2", {}), ("unmw2", {"KYB_UNM_W2": "0"}), ("hashw2", {}), ("hashw2", {"KYB_UNM_W2": "0"}),
