@@ -67,9 +67,12 @@ def counters(path):
 
 
 def kernel(cs, sub):
-    for k, v in cs.items():
-        if sub in k:
-            return v
+    """counters of the first kernel whose name contains `sub`; `sub` may list alternatives with '|' (a kernel whose template
+    gained a parameter: profiles of earlier rounds carry the shorter name)"""
+    for alt in sub.split("|"):
+        for k, v in cs.items():
+            if alt in k:
+                return v
     return {}
 
 
@@ -93,7 +96,7 @@ def entry(prefix, sub, units):
          "valu_busy": min(1.0, busy), "valu_busy_raw": busy,
          "valu_insts_per_unit": sq["SQ_INSTS_VALU"] * 64 / units,
          "wait_share_of_wave_cycles": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"],
-         "source": f"profiles/{tag}_{prefix}_{{sq,fetch,write}}.txt ({sub})",
+         "source": f"profiles/{tag}_{prefix}_{{sq,fetch,write}}.txt ({next((a for a in sub.split('|') if kernel(counters(os.path.join(d, f'{tag}_{prefix}_sq.txt')), a)), sub)})",
          "sources_unchanged_since_profile": changed == []}
     if fe and wr:
         e["hbm_bytes_per_launch"] = (fe["FETCH_SIZE"] + wr["WRITE_SIZE"]) * 1024
@@ -106,7 +109,7 @@ res = {"_comment": "Inputs bench.py reads for its roofline objects; every number
                    "(tools/roofline_inputs.py).",
        "imad_peak_lane_ops_per_s": old["imad_peak_lane_ops_per_s"], "imad_peak_source": old["imad_peak_source"],
        "kernels": {}}
-for key, prefix, sub, units in (("ed25519_mul", "ed", "ed25519_mul_kernel<true, false>", 1 << 20),
+for key, prefix, sub, units in (("ed25519_mul", "ed", "ed25519_mul_kernel<true, false>|ed25519_mul_kernel<true>", 1 << 20),
                                 ("bls12381_pair", "bls12381", "bls12381_tvm_kernel<0>", 1 << 16),
                                 ("bls12381_check", "bls12381", "bls12381_tvm_kernel<1>", 1 << 16),
                                 ("bls12381_verify", "verify", "bls12381_tvm_kernel<2>", 1 << 16),
