@@ -555,7 +555,56 @@ KYB_HD_NOINLINE void g1_mul_glv(g1_jac& r, const g1_jac& p, const uint32_t (&k)[
 // multiply-adds per product for the generic formulas).  The window table is built by the packed code, its entries and their
 // beta x images are unpacked once, and the 136 doublings + up to 68 mixed additions run inlined with no reduction
 // between products and nothing but the table and the digits in private memory.  (Inlined into its caller for the reason given at bn_suite.inc g1_mul_glv_lz.)
-KYB_HD void g1_mul_glv_lz(g1_jac& r, const g1_jac& p, const uint32_t (&k)[8]) {
+// TAB (round 6): the 16 table entries the walk reads by the lane's own digits -- (j + 1) P and its image (beta x, -y) --
+// live in a lane-contiguous slab of global memory (`tab`: this lane's G1_TAB_WORDS words; an entry is seven 16-byte loads)
+// instead of private scratch, whose per-dword interleaving over the wave turns an indexed entry read into up to eight
+// rows per dword: 2.1 GB per 2^16 multiplications against 8 MB of operands (252 x; "bound by its scratch
+// traffic", bls12381_g1split.hip).  The BN G2 ladders did the same (bn_suite.inc g2_mul_gls_lz<TAB>).  TAB = false: the
+// arrays (host harness; -DKYB_BLS_G1_TAB_SCRATCH for A/B builds).
+constexpr size_t G1_TAB_ENTRY_WORDS = 28;                       // x (13 limbs), y (13 limbs), 2 words of padding: 7 x 16 bytes
+constexpr size_t G1_TAB_WORDS = 2 * 8 * G1_TAB_ENTRY_WORDS;     // per lane: the two images of eight multiples
+static_assert(2 * FC::N <= G1_TAB_ENTRY_WORDS, "entry layout");
+KYB_HD void g1_tab_put(uint32_t* __restrict__ tab, int h, int i, const LzFpN<FC>::E& x, const LzFpN<FC>::E& y) {
+    uint32_t w[G1_TAB_ENTRY_WORDS];
+#pragma unroll
+    for (int l = 0; l < FC::N; l++) {
+        w[l] = x.l[l];
+        w[FC::N + l] = y.l[l];
+    }
+    w[26] = w[27] = 0;
+    uint32_t* q = tab + (size_t)(h * 8 + i) * G1_TAB_ENTRY_WORDS;
+#if defined(__HIPCC__)
+#pragma unroll
+    for (int v = 0; v < (int)G1_TAB_ENTRY_WORDS / 4; v++)
+        reinterpret_cast<uint4*>(q)[v] = make_uint4(w[4 * v], w[4 * v + 1], w[4 * v + 2], w[4 * v + 3]);
+#else
+    for (int v = 0; v < (int)G1_TAB_ENTRY_WORDS; v++) q[v] = w[v];
+#endif
+}
+KYB_HD void g1_tab_get(LzFpN<FC>::E& x, LzFpN<FC>::E& y, const uint32_t* __restrict__ tab, int h, int i) {
+    uint32_t w[G1_TAB_ENTRY_WORDS];
+    const uint32_t* q = tab + (size_t)(h * 8 + i) * G1_TAB_ENTRY_WORDS;
+#if defined(__HIPCC__)
+#pragma unroll
+    for (int v = 0; v < (int)G1_TAB_ENTRY_WORDS / 4; v++) {
+        const uint4 t = reinterpret_cast<const uint4*>(q)[v];
+        w[4 * v] = t.x;
+        w[4 * v + 1] = t.y;
+        w[4 * v + 2] = t.z;
+        w[4 * v + 3] = t.w;
+    }
+#else
+    for (int v = 0; v < (int)G1_TAB_ENTRY_WORDS; v++) w[v] = q[v];
+#endif
+#pragma unroll
+    for (int l = 0; l < FC::N; l++) {
+        x.l[l] = w[l];
+        y.l[l] = w[FC::N + l];
+    }
+    KYB_LZ_K(x.k = y.k = 2.0;)
+}
+template <bool TAB>
+KYB_HD void g1_mul_glv_lz(g1_jac& r, const g1_jac& p, const uint32_t (&k)[8], uint32_t* __restrict__ tab = nullptr) {
     using LF = LzFpN<FC>;
     uint32_t q[8], rem[4];
     divmod_z<4>(q, rem, k);
@@ -566,7 +615,8 @@ KYB_HD void g1_mul_glv_lz(g1_jac& r, const g1_jac& p, const uint32_t (&k)[8]) {
         jac_set_inf(r);
         return;
     }
-    typename LF::E tx[2][8], ty[8], beta;  // (j + 1) P and its image (beta x, -y): affine, in limb form
+    constexpr int NT = TAB ? 1 : 2;
+    typename LF::E tx[NT][8], ty[8], beta;  // (j + 1) P and its image (beta x, -y): affine, in limb form
     uint32_t infmask;
     jaclz_table8<LF, true>(tx[0], ty, infmask, p.X, p.Y);  // p comes from jac_from_aff: Z = 1
     {
@@ -575,7 +625,16 @@ KYB_HD void g1_mul_glv_lz(g1_jac& r, const g1_jac& p, const uint32_t (&k)[8]) {
         LF::enter(beta, b);
     }
 #pragma unroll 1
-    for (int j = 0; j < 8; j++) LF::mul(tx[1][j], tx[0][j], beta);
+    for (int j = 0; j < 8; j++) {
+        typename LF::E bx;
+        LF::mul(bx, tx[0][j], beta);
+        if constexpr (TAB) {
+            g1_tab_put(tab, 0, j, tx[0][j], ty[j]);
+            g1_tab_put(tab, 1, j, bx, ty[j]);
+        } else {
+            tx[NT - 1][j] = bx;
+        }
+    }
     JacLz<LF> acc;
     jaclz_set_inf(acc);
 #pragma unroll 1
@@ -590,7 +649,13 @@ KYB_HD void g1_mul_glv_lz(g1_jac& r, const g1_jac& p, const uint32_t (&k)[8]) {
             if (d == 0) continue;
             const int idx = (d < 0 ? -d : d) - 1;
             if ((infmask >> idx) & 1u) continue;
-            jaclz_madd_t(acc, tx[h][idx], ty[idx], (d < 0) != (h == 1));  // z^2 P = (beta x, -y)
+            if constexpr (TAB) {
+                typename LF::E ex, ey;
+                g1_tab_get(ex, ey, tab, h, idx);
+                jaclz_madd_t(acc, ex, ey, (d < 0) != (h == 1));  // z^2 P = (beta x, -y)
+            } else {
+                jaclz_madd_t(acc, tx[h < NT ? h : 0][idx], ty[idx], (d < 0) != (h == 1));
+            }
         }
     }
     jaclz_leave(r, acc);
@@ -668,7 +733,8 @@ KYB_HD void zero_bytes(uint8_t* out, int n) {
     for (int k = 0; k < n / 4; k++) q[k] = 0;
 }
 // out = k * P   (G1Elt.UnmarshalBinary + Mul + MarshalBinary, kilic/g1.go:110-131)
-KYB_HD int g1_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt, uint32_t flags = 0) {
+// `tab`: this lane's table slab (G1_TAB_WORDS words of global memory; device code always gets one) or nullptr on the host
+KYB_HD int g1_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt, uint32_t flags = 0, uint32_t* tab = nullptr) {
     g1_aff a;
     const int st = g1_decode_f(a, pt, flags, 0);
     if (st != ST_OK) {
@@ -682,7 +748,12 @@ KYB_HD int g1_mul_wire(uint8_t* out, const uint8_t* scalar_be, const uint8_t* pt
 #ifdef KYB_BLS_PACKED_LADDER
     g1_mul_glv(r, p, k);
 #else
-    g1_mul_glv_lz(r, p, k);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KYB_BLS_G1_TAB_SCRATCH)
+    g1_mul_glv_lz<true>(r, p, k, tab);
+#else
+    (void)tab;
+    g1_mul_glv_lz<false>(r, p, k);
+#endif
 #endif
     jac_to_aff(a, r);
     g1_encode_f(out, a, flags);

@@ -293,7 +293,7 @@ inline size_t g2_coop_max(int num_cu) {  // the same for G2 (g2coop): 61 KB of s
 // unit of its own -- its kernel wants two waves per SIMD, and the out-of-line field code takes the loosest register
 // budget of the kernels that reach it).  st: n bytes of scratch on the device.  KYB_G1_SPLIT=0: never (A/B).
 void launch_g1_mul_split(size_t n, const uint8_t* d_scalars, const uint8_t* d_points, uint8_t* d_out, uint8_t* d_st, uint8_t* d_status,
-                         uint32_t flags, hipStream_t st);
+                         uint32_t flags, hipStream_t st, uint32_t* d_tabs);
 // UnmarshalBinary of a batch with at least two waves per SIMD in flight: bls12381_unm2.hip (the per-lane kernels on a
 // two-wave register budget).  KYB_UNM_W2=0: always the kernels of this unit (A/B).
 void launch_unmarshal_w2(bool g2, size_t n, const uint8_t* d_points, uint8_t* d_out, uint8_t* d_status, uint32_t flags, hipStream_t st);
@@ -360,7 +360,9 @@ inline int lvm_mul(bool g2, size_t n, const uint8_t* d_scalars, const uint8_t* d
         if (!g2 && handled && !trace && point_stride && !(flags & KYB_F_TRUSTED(0)) && n <= (size_t)ctx->num_cu * 2 * 64 && g1_split_enabled()) {
             uint8_t* stt;  // the test's verdicts; the caller holds enq_mu until the merge kernel is enqueued
             if ((rc = ctx_workspace(ctx, WS_LVM, st, lvm_al(n), (void**)&stt))) return rc;
-            launch_g1_mul_split(n, d_scalars, d_points, d_out, stt, d_status, flags, st);
+            void* tabs;  // the ladder's per-lane table slab (bls12381.cuh g1_mul_glv_lz<true>)
+            if ((rc = ctx_workspace(ctx, WS_G1TAB, st, n * G1_TAB_WORDS * sizeof(uint32_t), &tabs))) return rc;
+            launch_g1_mul_split(n, d_scalars, d_points, d_out, stt, d_status, flags, st, (uint32_t*)tabs);
             KYB_HIP_CHECK(hipGetLastError());
             *handled = true;
         }

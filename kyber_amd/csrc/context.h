@@ -121,7 +121,7 @@ inline bool md_active(size_t n) { return md_count() > 1 && n >= md_threshold() &
 
 // Context for the calling thread's current device (created on first use).
 int get_ctx(DeviceCtx** out);
-enum { WS_MSM = 0, WS_ED = 1, WS_PAIR = 2, WS_LVM = 3, WS_SCALAR = 4, WS_VKEY = 5, WS_G2TAB = 6, WS_FB = 16 };  // WS_G2TAB: pairing_abi.cuh, the BN G2 ladders' table slabs;  // WS_FB + 2 * suite + group: fixed_base.cuh
+enum { WS_MSM = 0, WS_ED = 1, WS_PAIR = 2, WS_LVM = 3, WS_SCALAR = 4, WS_VKEY = 5, WS_G2TAB = 6, WS_G1TAB = 7, WS_FB = 16 };  // WS_G2TAB: pairing_abi.cuh, the BN G2 ladders' table slabs;  // WS_FB + 2 * suite + group: fixed_base.cuh
 // Grow (never shrink) the (kind, stream) workspace; caller holds no lock.
 // `grew` (optional): set when the buffer was (re)allocated by this call -- its contents are undefined
 int ctx_workspace(DeviceCtx* ctx, int kind, hipStream_t stream, size_t bytes, void** out, bool* grew = nullptr);

@@ -128,11 +128,13 @@ namespace kyb { \
 __global__ __launch_bounds__(64, KYB_G1_MUL_WAVES) void PFX##_g1_mul_kernel(size_t n, const uint8_t* __restrict__ scalars, \
                                                         const uint8_t* __restrict__ pts, size_t pt_stride, \
                                                         uint8_t* __restrict__ out, uint8_t* __restrict__ status, \
-                                                        uint32_t flags, const uint8_t* __restrict__ only) { \
+                                                        uint32_t flags, const uint8_t* __restrict__ only, \
+                                                        uint32_t* __restrict__ tabs) { \
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; \
     if (idx >= n) return; \
     if (only && !only[idx]) return;  /* the lane machine did this element (bls12381_lvm.cuh step 4) */ \
-    const int st = NS::g1_mul_wire(out + NS::g1_out_size(flags) * idx, scalars + 32 * idx, pts + pt_stride * idx, flags); \
+    const int st = NS::g1_mul_wire(out + NS::g1_out_size(flags) * idx, scalars + 32 * idx, pts + pt_stride * idx, flags, \
+                                   tabs + NS::G1_TAB_WORDS * idx); \
     if (status) status[idx] = (uint8_t)st; \
 } \
 __global__ __launch_bounds__(64, KYB_G2_MUL_WAVES) void PFX##_g2_mul_kernel(size_t n, const uint8_t* __restrict__ scalars, \
@@ -203,9 +205,16 @@ int kyb_##PFX##_g1_mul_dev(size_t n, const void* d_scalars, const void* d_points
     KYB_TRY(kyb::NS::lvm_mul(false, n, (const uint8_t*)d_scalars, (const uint8_t*)d_points, point_stride, (uint8_t*)d_out, \
                              (uint8_t*)d_status, flags, (hipStream_t)stream, &only, &handled_)); \
     if (handled_) return KYB_OK; \
+    uint32_t* g1tabs_ = nullptr; \
+    if (kyb::NS::G1_TAB_WORDS) { /* per-lane table slab of the ladder: (WS_G1TAB, stream), one launch's worth (this kernel \
+                                    only ever runs batches below the lane machine's threshold) */ \
+        void* tw_; \
+        KYB_TRY(kyb::ctx_workspace(ctx_, kyb::WS_G1TAB, (hipStream_t)stream, n * kyb::NS::G1_TAB_WORDS * sizeof(uint32_t), &tw_)); \
+        g1tabs_ = (uint32_t*)tw_; \
+    } \
     hipLaunchKernelGGL(kyb::PFX##_g1_mul_kernel, dim3(kyb::grid_for(n, 64)), dim3(64), 0, (hipStream_t)stream, n, \
                        (const uint8_t*)d_scalars, (const uint8_t*)d_points, point_stride, (uint8_t*)d_out, \
-                       (uint8_t*)d_status, flags, only); \
+                       (uint8_t*)d_status, flags, only, g1tabs_); \
     KYB_HIP_CHECK(hipGetLastError()); \
     return KYB_OK; \
 } \
