@@ -148,27 +148,50 @@ __global__ __launch_bounds__(64, DecodeWaves<A>::value) void decode_kernel(Plan 
                                                     uint8_t* __restrict__ status,
                                                     uint32_t* __restrict__ bad) {
     constexpr int S = Split<A>::value;
+    // the decoded points leave through LDS: a lane's Aff is ~100 bytes, and stored from its registers every dword of the
+    // wave's 64 lands in a line of its own (50 stores x 64 lines per wave for BLS12-381 G1's two halves: the address unit's
+    // time, not the memory's, was a third of this kernel); staged, a wave stores whole lines
+    constexpr int W = (int)(sizeof(typename A::Aff) / 4);
+    static_assert(sizeof(typename A::Aff) % 4 == 0, "Aff is staged word by word");
+    __shared__ uint32_t stage[64 * W];
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_in) return;
+    const bool live = i < n_in;
     typename A::Aff a[S];
     uint32_t k[S][8];
-    int st;
-    if constexpr (S == 1) {
-        st = A::decode(a[0], points + A::wire_size(p.flags) * i, p.flags);
-        A::scalar_words(k[0], scalars + 32 * i);
-        Effective<A>::apply(k[0], a[0], p.bits);
-    } else {
-        st = A::decode_split(a, k, points + A::wire_size(p.flags) * i, scalars + 32 * i, p.flags);
+    int st = 0;
+    if (live) {
+        if constexpr (S == 1) {
+            st = A::decode(a[0], points + A::wire_size(p.flags) * i, p.flags);
+            A::scalar_words(k[0], scalars + 32 * i);
+            Effective<A>::apply(k[0], a[0], p.bits);
+        } else {
+            st = A::decode_split(a, k, points + A::wire_size(p.flags) * i, scalars + 32 * i, p.flags);
+        }
+        if (status) status[i] = (uint8_t)st;
+        if (st) atomicAdd(bad, 1u);
     }
-    if (status) status[i] = (uint8_t)st;
-    if (st) atomicAdd(bad, 1u);
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x;
+    const size_t nvalid = i0 < n_in ? (n_in - i0 < 64 ? n_in - i0 : 64) : 0;
 #pragma unroll
     for (int h = 0; h < S; h++) {
         const size_t e = (size_t)h * n_in + i;
-        aff[e] = a[h];
+        {
+            uint32_t words[W];
+            __builtin_memcpy(words, &a[h], sizeof(typename A::Aff));
+#pragma unroll
+            for (int j = 0; j < W; j++) stage[threadIdx.x * W + j] = words[j];
+        }
+        __syncthreads();
+        uint32_t* dst = reinterpret_cast<uint32_t*>(aff + (size_t)h * n_in + i0);
+#pragma unroll
+        for (int j = 0; j < W; j++) {
+            const size_t idx = (size_t)j * 64 + threadIdx.x;
+            if (idx < nvalid * W) dst[idx] = stage[idx];
+        }
+        __syncthreads();
         // the digits go straight to memory as the recoding produces them (a digit array indexed by the window would
         // live in scratch: 516 B per lane and half); histogrammed per (window, tile) out of LDS: hist_lds_kernel
-        recode_each(k[h], p.c, p.nwin, p.bits, [&](int w, int d) { digits[(size_t)w * p.n + e] = st ? 0 : d; });
+        if (live) recode_each(k[h], p.c, p.nwin, p.bits, [&](int w, int d) { digits[(size_t)w * p.n + e] = st ? 0 : d; });
     }
 }
 
@@ -255,12 +278,16 @@ static inline void launch_scan(const uint32_t* hist, uint32_t* offs, size_t m, u
 // Counting sort of the (point, window) digits by bucket, staged in LDS -- no global atomics.  A workgroup owns one
 // (window, tile of points) pair and a counter per bucket of that window in LDS (2^15 buckets x 4 B = 128 KB of the
 // CU's 160 KB):
-//   hist_lds_kernel     counts its tile with ds_add_u32 and stores the counters bucket-major, tile-minor
-//                       (hist2[(w nb + b) T + tile]), so that one exclusive scan of that array ...
-//   scatter_lds_kernel  ... is, for every (bucket, tile), the first output slot of the tile's points of that bucket:
-//                       the workgroup loads its row into the same LDS array and every point takes its slot with one
-//                       returning ds_add (rank within the bucket = arrival order, any order is a valid sort)
-//   bucket_offs_kernel  picks offs[b] = offs2[b T] -- what the rest of the pipeline indexes buckets by.
+//   hist_lds_kernel     counts its tile with ds_add_u32 and stores the counters tile-major (hist2[(w T + tile) nb + b]:
+//                       whole lines -- rounds 1-5 stored them bucket-major, one 4-byte store per 128-byte line, and scanned
+//                       all nwin x nb x T of them: item 58 of DESIGN.md section 5)
+//   tile_scan_kernel    one lane per (window, bucket) walks its T counters (lanes side by side: coalesced), leaves in each
+//                       the number of the bucket's points in earlier tiles, and stores the bucket's total
+//   launch_scan         of the nwin x nb totals: offs[b], what the rest of the pipeline indexes buckets by
+//   scatter_lds_kernel  loads offs[b] + its tile's counter -- for every (bucket, tile) the first output slot of the
+//                       tile's points of that bucket -- into the same LDS array and every point takes its slot with one
+//                       returning ds_add (rank within the bucket = arrival order, any order is a valid sort).
+// One workgroup per CU at a time (128 KB of LDS), so the grid is cut to WHOLE rounds of the chip (sort_tiles below).
 // (Round 1 paid one global atomicAdd per digit in the decode kernel and another in the scatter: 2 x 16.8 M for
 // 2^20 BLS12-381 G1 points; with 2^15 buckets per window two lanes of a wave rarely meet in a bucket, so wave-level
 // ballot aggregation would save nothing on top of the LDS counters.)
@@ -277,7 +304,7 @@ constexpr int HIST_MAX_NB = 1 << 15;
 static __global__ __launch_bounds__(HIST_T) void hist_lds_kernel(Plan p, int tiles, const int32_t* __restrict__ digits,
                                                                  uint32_t* __restrict__ hist2) {
     __shared__ uint32_t h[HIST_MAX_NB];
-    const int w = blockIdx.y, tile = blockIdx.x;
+    const int w = blockIdx.x % p.nwin, tile = blockIdx.x / p.nwin;  // as in scatter_lds_kernel
     for (int b = threadIdx.x; b < p.nb; b += HIST_T) h[b] = 0;
     __syncthreads();
     const size_t per = (p.n + tiles - 1) / tiles, lo = per * tile, hi = lo + per < p.n ? lo + per : p.n;
@@ -298,16 +325,34 @@ static __global__ __launch_bounds__(HIST_T) void hist_lds_kernel(Plan p, int til
             if (d[u]) atomicAdd(&h[(d[u] < 0 ? -d[u] : d[u]) - 1], 1u);
     }
     __syncthreads();
-    uint32_t* row = hist2 + (size_t)w * p.nb * tiles + tile;
-    for (int b = threadIdx.x; b < p.nb; b += HIST_T) row[(size_t)b * tiles] = h[b];
+    uint32_t* row = hist2 + ((size_t)w * tiles + tile) * p.nb;
+    for (int b = threadIdx.x; b < p.nb; b += HIST_T) row[b] = h[b];
+}
+static __global__ __launch_bounds__(256) void tile_scan_kernel(size_t nbk, int nb, int tiles, uint32_t* __restrict__ hist2,
+                                                               uint32_t* __restrict__ total) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nbk) return;
+    const size_t w = g / (size_t)nb, b = g % (size_t)nb;
+    uint32_t* col = hist2 + w * tiles * (size_t)nb + b;
+    uint32_t run = 0;
+    for (int t = 0; t < tiles; t++) {
+        const uint32_t v = col[(size_t)t * nb];
+        col[(size_t)t * nb] = run;
+        run += v;
+    }
+    total[g] = run;
 }
 static __global__ __launch_bounds__(HIST_T) void scatter_lds_kernel(Plan p, int tiles, const int32_t* __restrict__ digits,
-                                                                    const uint32_t* __restrict__ offs2,
-                                                                    uint32_t* __restrict__ sorted) {
+                                                                    const uint32_t* __restrict__ before,
+                                                                    const uint32_t* __restrict__ offs,
+                                                                    uint32_t* __restrict__ sorted, int xcd_major) {
     __shared__ uint32_t cur[HIST_MAX_NB];
-    const int w = blockIdx.y, tile = blockIdx.x;
-    const uint32_t* row = offs2 + (size_t)w * p.nb * tiles + tile;
-    for (int b = threadIdx.x; b < p.nb; b += HIST_T) cur[b] = row[(size_t)b * tiles];
+    // window-minor: workgroups go round-robin over the 8 XCDs, so with 8 windows (the 2^20-point BLS12-381 G1 MSM) every
+    // window's slice of `sorted` is written through ONE L2, where the 4-byte stores of a line can meet
+    const int w = xcd_major ? blockIdx.x % p.nwin : blockIdx.x / tiles, tile = xcd_major ? blockIdx.x / p.nwin : blockIdx.x % tiles;
+    const uint32_t* row = before + ((size_t)w * tiles + tile) * p.nb;
+    const uint32_t* first = offs + (size_t)w * p.nb;
+    for (int b = threadIdx.x; b < p.nb; b += HIST_T) cur[b] = first[b] + row[b];
     __syncthreads();
     const size_t per = (p.n + tiles - 1) / tiles, lo = per * tile, hi = lo + per < p.n ? lo + per : p.n;
     const int32_t* dw = digits + (size_t)w * p.n;
@@ -326,10 +371,18 @@ static __global__ __launch_bounds__(HIST_T) void scatter_lds_kernel(Plan p, int 
             if (d[u]) sorted[pos[u]] = (uint32_t)(i0 + (size_t)u * HIST_T) | (d[u] < 0 ? 0x80000000u : 0u);
     }
 }
-static __global__ __launch_bounds__(256) void bucket_offs_kernel(size_t nbk, int tiles, const uint32_t* __restrict__ offs2,
-                                                                 uint32_t* __restrict__ offs) {
-    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b <= nbk) offs[b] = offs2[b * (size_t)tiles];  // b == nbk: the total (offs2 has one entry past the end)
+// Tiles per window: as many workgroups as fill `rounds` whole rounds of the chip (rounds 1-5 aimed at "about two per CU"
+// and got 288 workgroups for the 2^20-point BLS12-381 G1 MSM: a full round and an eighth of one, i.e. two), a tile of at
+// least two points per bucket (the per-tile flush is per bucket).  KYB_MSM_SORT_TILES forces a count (A/B runs).
+inline int sort_tiles(int num_cu, int nwin, size_t ne, int nb) {
+    static const int forced = [] {
+        const char* e = getenv("KYB_MSM_SORT_TILES");
+        return e ? atoi(e) : 0;
+    }();
+    int tiles = forced > 0 ? forced : num_cu / nwin;
+    if (tiles < 1) tiles = 1;
+    while (tiles > 1 && (ne ? ne : 1) / tiles < 2 * (size_t)nb) tiles--;
+    return tiles;
 }
 
 constexpr int MAXSUB = 256;
@@ -350,16 +403,34 @@ inline uint32_t piece_len(size_t ne, int nb) {
 constexpr uint32_t LONG_PIECES = 4;  // a bucket of more pieces is joined by a workgroup (tree), not by one lane
 
 // nsub[b] = number of SUB-sized pieces of bucket b; buckets of more than LONG_PIECES pieces (skewed digits: a short top
-// window, equal or small scalars) are appended to longlist (counter in nlong[0]).
-static __global__ __launch_bounds__(256) void subcount_kernel(size_t nbk, uint32_t SUB, const uint32_t* __restrict__ offs,
-                                                              uint32_t* __restrict__ nsub,
-                                                              uint32_t* __restrict__ nlong,
-                                                              uint32_t* __restrict__ longlist) {
+// window, equal or small scalars) are appended to longlist (counter in nlong[0]), buckets of 2 .. LONG_PIECES pieces to
+// joinlist (counter in nlong[1], one atomic per wave): bucket_kernel visits those only.  An empty bucket is written here.
+template <class A>
+__global__ __launch_bounds__(256) void subcount_kernel(size_t nbk, uint32_t SUB, const uint32_t* __restrict__ offs,
+                                                       uint32_t* __restrict__ nsub, uint32_t* __restrict__ nlong,
+                                                       uint32_t* __restrict__ longlist, uint32_t* __restrict__ joinlist,
+                                                       typename A::Acc* __restrict__ buckets) {
     const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nbk) return;
-    const uint32_t k = (offs[b + 1] - offs[b] + SUB - 1) / SUB;
-    nsub[b] = k;
-    if (k > LONG_PIECES) longlist[atomicAdd(nlong, 1u)] = (uint32_t)b;
+    uint32_t k = 1;
+    if (b < nbk) {
+        k = (offs[b + 1] - offs[b] + SUB - 1) / SUB;
+        nsub[b] = k;
+        if (k > LONG_PIECES) longlist[atomicAdd(nlong, 1u)] = (uint32_t)b;
+        if (k == 0) {
+            typename A::Acc id;
+            A::identity(id);
+            buckets[b] = id;
+        }
+    }
+    const bool join = k >= 2 && k <= LONG_PIECES;
+    const unsigned long long mask = __ballot(join);
+    if (mask) {
+        const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)mask) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(nlong + 1, (uint32_t)__popcll(mask));
+        base = __shfl(base, leader);
+        if (join) joinlist[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)b;
+    }
 }
 
 // Piece t -> (first index into `sorted`, length), plus a histogram of the lengths.  The piece -> bucket map is a
@@ -367,7 +438,7 @@ static __global__ __launch_bounds__(256) void subcount_kernel(size_t nbk, uint32
 static __global__ __launch_bounds__(256) void piece_kernel(size_t nbk, size_t max_pieces, uint32_t SUB, const uint32_t* __restrict__ offs,
                                                            const uint32_t* __restrict__ suboffs,
                                                            uint32_t* __restrict__ plo, uint32_t* __restrict__ plen,
-                                                           uint32_t* __restrict__ lenhist) {
+                                                           uint32_t* __restrict__ pdst, uint32_t* __restrict__ lenhist) {
     __shared__ uint32_t h[MAXSUB + 1];
     for (uint32_t i = threadIdx.x; i <= SUB; i += 256) h[i] = 0;
     __syncthreads();
@@ -385,6 +456,9 @@ static __global__ __launch_bounds__(256) void piece_kernel(size_t nbk, size_t ma
         const uint32_t len = (lo + SUB < end ? lo + SUB : end) - lo;
         plo[t] = lo;
         plen[t] = len;
+        // where the piece's sum goes: a bucket's only piece (all but skewed buckets) is the bucket -- accumulate_kernel
+        // stores it there and bucket_kernel has nothing to copy (74 us of the 2^20-point BLS12-381 G1 MSM)
+        pdst[t] = suboffs[b + 1] - suboffs[b] == 1 ? (uint32_t)b | 0x80000000u : (uint32_t)t;
         atomicAdd(&h[SUB - len], 1u);  // bin 0 = longest
     }
     __syncthreads();
@@ -446,8 +520,10 @@ __global__ __launch_bounds__(64, KYB_MSM_ACC_WAVES) void accumulate_kernel(size_
                                                         const uint32_t* __restrict__ order,
                                                         const uint32_t* __restrict__ plo,
                                                         const uint32_t* __restrict__ plen,
+                                                        const uint32_t* __restrict__ pdst,
                                                         const uint32_t* __restrict__ sorted,
-                                                        typename A::Acc* __restrict__ pieces) {
+                                                        typename A::Acc* __restrict__ pieces,
+                                                        typename A::Acc* __restrict__ buckets) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= max_pieces || i >= suboffs[nbk]) return;
     const uint32_t t = order[i];
@@ -465,27 +541,33 @@ __global__ __launch_bounds__(64, KYB_MSM_ACC_WAVES) void accumulate_kernel(size_
     }
     typename A::Acc res;
     PieceOps<A>::finish(res, acc);
-    pieces[t] = res;
+    const uint32_t d = pdst[t];
+    if (d >> 31) buckets[d & 0x7fffffffu] = res;
+    else pieces[t] = res;
 }
 
-// bucket b = sum of its pieces (one piece for all but skewed buckets; long ones are left to bucket_long_kernel)
+// bucket b = sum of its 2 .. LONG_PIECES pieces, for the buckets of joinlist (a lone piece was stored as the bucket by
+// accumulate_kernel, an empty bucket by subcount_kernel, long ones are left to bucket_long_kernel).  Grid-stride over the
+// list: for uniform scalars it is empty and the kernel is a launch (a lane per bucket cost 74 us of copying, then 42 us of
+// finding out that there was nothing to do: 4 096 waves, each with its scratch to set up).
 template <class A>
-__global__ __launch_bounds__(64, 2) void bucket_kernel(size_t nbk, const uint32_t* __restrict__ suboffs,
+__global__ __launch_bounds__(64, 2) void bucket_kernel(const uint32_t* __restrict__ nlong, const uint32_t* __restrict__ joinlist,
+                                                    const uint32_t* __restrict__ suboffs,
                                                     const typename A::Acc* __restrict__ pieces,
                                                     typename A::Acc* __restrict__ buckets) {
-    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nbk) return;
-    const uint32_t lo = suboffs[b], hi = suboffs[b + 1];
-    if (hi - lo > LONG_PIECES) return;
-    typename A::Acc acc;
-    A::identity(acc);
-    if (hi > lo) acc = pieces[lo];
+    const uint32_t cnt = nlong[1];
 #pragma unroll 1
-    for (uint32_t q = lo + 1; q < hi; q++) {
-        const typename A::Acc v = pieces[q];
-        A::add(acc, acc, v);
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < cnt; j += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t b = joinlist[j];
+        const uint32_t lo = suboffs[b], hi = suboffs[b + 1];
+        typename A::Acc acc = pieces[lo];
+#pragma unroll 1
+        for (uint32_t q = lo + 1; q < hi; q++) {
+            const typename A::Acc v = pieces[q];
+            A::add(acc, acc, v);
+        }
+        buckets[b] = acc;
     }
-    buckets[b] = acc;
 }
 
 // Long buckets: one workgroup each (grid-stride over longlist); every thread sums a strided share of the pieces, then
@@ -598,10 +680,16 @@ struct HasCoopSlots<A, decltype((void)A::COOP_SLOTS)> {
     static constexpr bool value = A::COOP_SLOTS != 0;
 };
 
-// partial[w][ch] = sum_{b in chunk} (b + 1) * B_b, one GROUP of four lanes per chunk, 16 groups per workgroup
+constexpr int REDUCE_FUSED_BITS = 4;  // log2 of reduce_coop_kernel's 16 groups
+// partial[w][ch] = sum_{b in chunk} (b + 1) * B_b, one GROUP of four lanes per chunk, 16 groups per workgroup.
+// runs != null (round 6, the split tail below): the chunk's own part only -- partial[w][ch] = sum (b - lo + 1) B_b and
+// runs[w][ch] = sum B_b; the lo * run term of every chunk -- a double-and-add of 2 log2(nchunks) + log2(chunk) steps, two
+// thirds of this kernel's 42 for the 2^20-point BLS12-381 G1 MSM, half of its additions computed and dropped -- is left
+// to tree_fold_bits_coop_kernel.
 template <class A>
 __global__ __launch_bounds__(64, 2) void reduce_coop_kernel(Plan p, const typename A::Acc* __restrict__ buckets,
-                                                         typename A::Acc* __restrict__ partial) {
+                                                         typename A::Acc* __restrict__ partial,
+                                                         typename A::Acc* __restrict__ runs, int fuse) {
     constexpr int G = 16, RUN = 0, TOT = 3, BK = 6, M = 9, T = 12, NS = T + A::COOP_TEMPS;
     __shared__ typename A::Slot slots[G * NS];
     __shared__ uint32_t flags[G * 2];
@@ -627,7 +715,12 @@ __global__ __launch_bounds__(64, 2) void reduce_coop_kernel(Plan p, const typena
     int chbits = 0, tz = 0;
     while ((1 << chbits) < p.nchunks) chbits++;
     while ((1 << tz) < p.chunk) tz++;
-    const int nsum = 2 * (p.chunk - 1), nmul = 2 * chbits + tz, nsteps = nsum + nmul + 1;
+    const bool split = runs != nullptr;
+    // fuse (split, nchunks a multiple of 16): the first four levels of the split tail's tree (tree_fold_bits_coop_kernel)
+    // right here, over the workgroup's 16 chunks -- RUN slots: the bit tree (A in group 0, D_m in group 2^m); TOT slots: the
+    // plain sum, carried by the LAST group of every node, which the bit tree leaves idle.  One addition per group and level.
+    const int nsum = 2 * (p.chunk - 1), nmul = split ? 0 : 2 * chbits + tz, ntree = fuse ? REDUCE_FUSED_BITS : 0;
+    const int nsteps = nsum + nmul + (split ? 0 : 1) + ntree;
 #pragma unroll 1
     for (int s = 0; s < nsteps; s++) {
         bool is_dbl = false, commit = true, skip = false;
@@ -642,7 +735,7 @@ __global__ __launch_bounds__(64, 2) void reduce_coop_kernel(Plan p, const typena
                 P = TOT;
                 Q = RUN;
             }
-        } else if (s < nsum + 2 * chbits) {
+        } else if (!split && s < nsum + 2 * chbits) {
             const int k = s - nsum, bit = chbits - 1 - (k >> 1);
             if ((k & 1) == 0) {
                 is_dbl = true;
@@ -652,13 +745,35 @@ __global__ __launch_bounds__(64, 2) void reduce_coop_kernel(Plan p, const typena
                 P = M;
                 Q = RUN;
             }
-        } else if (s < nsum + nmul) {
+        } else if (!split && s < nsum + nmul) {
             is_dbl = true;
+        } else if (fuse) {
+            const int off = 1 << (s - nsum), low = gi & (2 * off - 1);
+            const bool t_act = (low & (low - 1)) == 0 && low < off, w_act = low == 2 * off - 1;
+            if (r < 3) {
+                if (t_act) S[BK + r].f = slots[(gi + off) * NS + RUN + r].f;
+                if (w_act) S[BK + r].f = slots[(gi - off) * NS + TOT + r].f;
+            }
+            __syncthreads();
+            P = t_act ? RUN : TOT;
+            Q = BK;
+            commit = t_act || w_act;
         }
         if (is_dbl) A::coop_dbl_slots(S, r, M, T, true);
         else if (!skip) A::coop_add(S, fl, r, P, Q, T, commit);
     }
-    if (live) A::slot_store(partial + t, S, TOT, r);
+    if (fuse) {  // rows of nchunks / 16: W (nwin), D_m (nwin x 4), A (nwin) -- tree_fold_bits_coop_kernel's layout
+        const size_t ncur = (size_t)p.nchunks / G, blk = blockIdx.x, w0 = blk / ncur, c0 = blk - w0 * ncur;
+        if (gi == G - 1) A::slot_store(partial + w0 * ncur + c0, S, TOT, r);
+        if (gi == 0) A::slot_store(partial + ((size_t)p.nwin * (1 + REDUCE_FUSED_BITS) + w0) * ncur + c0, S, RUN, r);
+        if (gi && (gi & (gi - 1)) == 0) {
+            const int m = gi == 1 ? 0 : (gi == 2 ? 1 : (gi == 4 ? 2 : 3));
+            A::slot_store(partial + ((size_t)p.nwin + w0 * REDUCE_FUSED_BITS + m) * ncur + c0, S, RUN, r);
+        }
+    } else if (live) {
+        A::slot_store(partial + t, S, TOT, r);
+        if (split) A::slot_store(runs + t, S, RUN, r);
+    }
 }
 
 // out[w][g] = sum of in[w][FG g .. FG g + FG): a group per partial, added as a tree (depth log2 FG)
@@ -669,17 +784,23 @@ constexpr int fold_groups() {
 template <class A>
 __global__ __launch_bounds__(4 * fold_groups<A>(), 2) void tree_fold_coop_kernel(int nwin, int nin,
                                                                               const typename A::Acc* __restrict__ in,
-                                                                              typename A::Acc* __restrict__ out) {
+                                                                              typename A::Acc* __restrict__ out, int per) {
     constexpr int FG = fold_groups<A>(), P = 0, Q = 3, T = 6, NS = T + A::COOP_TEMPS;
     __shared__ typename A::Slot slots[FG * NS];
     __shared__ uint32_t flags[FG * 2];
     const int gi = (int)threadIdx.x >> 2, r = (int)threadIdx.x & 3;
-    const int nout = (nin + FG - 1) / FG;
+    const int nout = (nin + FG * per - 1) / (FG * per);  // per = 2: a group starts from the sum of two inputs (one more level)
     const int w = blockIdx.x / nout, g = blockIdx.x - w * nout;
-    const int k = g * FG + gi;
+    const int k = g * FG * per + gi;
     typename A::Slot* S = slots + gi * NS;
     if (k < nin) A::slot_load(S, P, in + (size_t)w * nin + k, r);
     else A::slot_identity(S, P, r);
+    if (per == 2) {  // uniform
+        if (k + FG < nin) A::slot_load(S, Q, in + (size_t)w * nin + k + FG, r);
+        else A::slot_identity(S, Q, r);
+        __syncthreads();
+        A::coop_add(S, flags + gi * 2, r, P, Q, T, true);
+    }
     __syncthreads();
 #pragma unroll 1
     for (int off = FG / 2; off >= 1; off >>= 1) {
@@ -688,6 +809,101 @@ __global__ __launch_bounds__(4 * fold_groups<A>(), 2) void tree_fold_coop_kernel
         A::coop_add(S, flags + gi * 2, r, P, Q, T, gi < off);
     }
     if (gi == 0) A::slot_store(out + (size_t)w * nout + g, S, P, r);
+}
+
+// bucket_kernel on cooperating lanes: a group of four per bucket of joinlist.  The one-lane join is a 45 us addition, and
+// a few hundred buckets of a 2^20-point BLS12-381 G1 MSM do have a second piece (the halves' top window is not uniform:
+// the fold of k1 into (-z^2 / 2, z^2 / 2] doubles the density of part of its range).
+template <class A>
+__global__ __launch_bounds__(64, 2) void bucket_coop_kernel(const uint32_t* __restrict__ nlong, const uint32_t* __restrict__ joinlist,
+                                                         const uint32_t* __restrict__ suboffs,
+                                                         const typename A::Acc* __restrict__ pieces,
+                                                         typename A::Acc* __restrict__ buckets) {
+    constexpr int G = 16, P = 0, Q = 3, T = 6, NS = T + A::COOP_TEMPS;
+    __shared__ typename A::Slot slots[G * NS];
+    __shared__ uint32_t flags[G * 2];
+    const int gi = (int)threadIdx.x >> 2, r = (int)threadIdx.x & 3;
+    typename A::Slot* S = slots + gi * NS;
+    const uint32_t cnt = nlong[1];
+#pragma unroll 1
+    for (size_t j0 = (size_t)blockIdx.x * G; j0 < cnt; j0 += (size_t)gridDim.x * G) {
+        const size_t j = j0 + gi;
+        const bool live = j < cnt;
+        uint32_t b = 0, lo = 0, hi = 0;
+        if (live) {
+            b = joinlist[j];
+            lo = suboffs[b];
+            hi = suboffs[b + 1];
+            A::slot_load(S, P, pieces + lo, r);
+        } else {
+            A::slot_identity(S, P, r);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (uint32_t s = 1; s < LONG_PIECES; s++) {
+            const bool more = live && lo + s < hi;
+            if (!__syncthreads_or(more ? 1 : 0)) break;
+            if (more) A::slot_load(S, Q, pieces + lo + s, r);
+            else A::slot_identity(S, Q, r);
+            __syncthreads();
+            A::coop_add(S, flags + gi * 2, r, P, Q, T, more);
+        }
+        if (live) A::slot_store(buckets + b, S, P, r);
+        __syncthreads();
+    }
+}
+
+// The split tail (round 6).  With W_j = sum_{b in chunk j} (b - lo_j + 1) B_b and T_j = sum_{b in chunk j} B_b from
+// reduce_coop_kernel, a window's sum is  sum_j W_j + chunk * sum_j j T_j,  and over the bits of the chunk number
+//     sum_j j T_j = sum_k 2^k D_k,   D_k = sum of T_j over the j whose bit k is set.
+// The D_k fall out of the SAME tree that sums the T_j, at the same depth: a node of level k (2^k leaves) carries its sum A
+// and D_0 .. D_(k-1) of its leaves; joining L and R, A = A_L + A_R, D_m = D_m(L) + D_m(R), and the new D_k is A_R as it
+// stands.  With the node's A in its first group and D_m in group 2^m of its span, every join is "group g += group g + 2^k"
+// for the groups whose low k + 1 bits are zero or a single bit below 2^k -- at most 32 additions side by side per level,
+// one addition deep like the plain tree.  A launch consumes log2(FG) bits of j; its D rows join the plain rows (summed
+// as they are by the next launch) and its A row is the bits row of the next launch.  Rows: [0, nplain) plain,
+// [nplain, nplain + nbits) bits; out rows: the plain ones in place, D of bits row w and bit m < lb_out (the bits the chunk
+// numbers still have) at nplain + w lb_out + m, the A rows behind them.  What is left for the doubling chains of final_rows_kernel is 2^(c w) W_w and 2^(c w + tz + k) D_k(w):
+// one wave each, all at once -- no addition waits for a doubling any more.
+template <class A>
+constexpr int fold_bits() {
+    return fold_groups<A>() == 64 ? 6 : 5;
+}
+template <class A>
+__global__ __launch_bounds__(4 * fold_groups<A>(), 2) void tree_fold_bits_coop_kernel(int nplain, int nbits, int nin, int lb_out,
+                                                                                   const typename A::Acc* __restrict__ in,
+                                                                                   typename A::Acc* __restrict__ out) {
+    constexpr int FG = fold_groups<A>(), P = 0, Q = 3, T = 6, NS = T + A::COOP_TEMPS;
+    __shared__ typename A::Slot slots[FG * NS];
+    __shared__ uint32_t flags[FG * 2];
+    const int gi = (int)threadIdx.x >> 2, r = (int)threadIdx.x & 3;
+    const int nout = (nin + FG - 1) / FG;
+    const int row = blockIdx.x / nout, g = blockIdx.x - row * nout;
+    const bool bits = row >= nplain;
+    const int k0 = g * FG + gi;
+    typename A::Slot* S = slots + gi * NS;
+    if (k0 < nin) A::slot_load(S, P, in + (size_t)row * nin + k0, r);
+    else A::slot_identity(S, P, r);
+    __syncthreads();
+#pragma unroll 1
+    for (int off = 1; off < FG; off <<= 1) {
+        const int low = gi & (2 * off - 1);
+        const bool active = bits ? ((low & (low - 1)) == 0 && low < off) : low == 0;
+        if (active && r < 3) S[Q + r].f = slots[(gi + off) * NS + P + r].f;
+        __syncthreads();
+        A::coop_add(S, flags + gi * 2, r, P, Q, T, active);
+    }
+    if (!bits) {
+        if (gi == 0) A::slot_store(out + (size_t)row * nout + g, S, P, r);
+    } else {
+        const int w = row - nplain;
+        if (gi == 0) A::slot_store(out + (size_t)(nplain + nbits * lb_out + w) * nout + g, S, P, r);
+        if (gi && (gi & (gi - 1)) == 0) {
+            int m = 0;
+            while ((1 << m) < gi) m++;
+            if (m < lb_out) A::slot_store(out + (size_t)(nplain + w * lb_out + m) * nout + g, S, P, r);
+        }
+    }
 }
 
 // Coop<A>::value: the adapter offers dbl_coop (COOP lanes per point)
@@ -767,19 +983,40 @@ struct HasRowFinal<A, decltype((void)A::ROW_FINAL)> {
     static constexpr bool value = A::ROW_FINAL != 0;
 };
 #if defined(KYB_ROWFP_INCLUDED)
+// Chain b < nwin: window b's sum, c b doublings.  Split tail: the rows behind them are D_k of window w in the order the tree
+// produced them (lb0 bits per window from the reduce kernel, then per fold launch the bits that are left, lb at most),
+// doubled c w + tz + k times.
 template <class A>
 __global__ __launch_bounds__(64) void final_rows_kernel(Plan p, const typename A::Acc* __restrict__ wsum,
-                                                        typename A::Acc* __restrict__ shifted) {
+                                                        typename A::Acc* __restrict__ shifted, int lb0, int lb, int tz, int chbits) {
     using C = typename A::RowC;
     using namespace rowfp;
     __shared__ uint32_t limbs[3][ROW];
     const int w = blockIdx.x;
+    int ndbl = w * p.c;
+    if (w >= p.nwin) {  // lb0 bits from the reduce kernel's own tree come first, lb per fold launch after them
+        int q = w - p.nwin, ww, k;
+        if (q < p.nwin * lb0) {
+            ww = q / lb0;
+            k = q - ww * lb0;
+        } else {
+            q -= p.nwin * lb0;
+            int k0 = lb0, lbl = chbits - k0 < lb ? chbits - k0 : lb;  // a launch emits the bits that are left, lb at most
+            while (q >= p.nwin * lbl) {
+                q -= p.nwin * lbl;
+                k0 += lbl;
+                lbl = chbits - k0 < lb ? chbits - k0 : lb;
+            }
+            ww = q / lbl;
+            k = k0 + (q - ww * lbl);
+        }
+        ndbl = ww * p.c + tz + k;
+    }
     const auto cx = make_ctx<C>();
     const auto dc = make_dbl_consts<C>();
     const V32 row = row_of_lane();
     const typename A::Acc* src = wsum + w;
     JacRow<C> pt{load_packed<C>(src->X.v), load_packed<C>(src->Y.v), load_packed<C>(src->Z.v)};
-    const int ndbl = w * p.c;
 #pragma unroll 1
     for (int k = 0; k < ndbl; k++) jac_dbl_wave<C>(cx, dc, row, pt);
     const V32 X = below_2p<C>(cx, pt.X), Y = below_2p<C>(cx, pt.Y), Z = below_2p<C>(cx, pt.Z);
@@ -797,6 +1034,17 @@ __global__ __launch_bounds__(64) void final_rows_kernel(Plan p, const typename A
     }
 }
 #endif
+
+// the split tail (reduce_coop_kernel's runs, tree_fold_bits_coop_kernel, one doubling chain per term) wants the cooperative
+// slots and the limb-per-lane doubling chains: BLS12-381 G1
+template <class A>
+constexpr bool split_tail() {
+#if defined(KYB_ROWFP_INCLUDED)
+    return HasCoopSlots<A>::value && HasRowFinal<A>::value;
+#else
+    return false;
+#endif
+}
 
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
@@ -834,13 +1082,10 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     const size_t o_aff = take(sizeof(typename A::Aff) * (ne ? ne : 1));
     const size_t o_dig = take(sizeof(int32_t) * (ne ? ne : 1) * p.nwin);
     const size_t o_sorted = take(sizeof(uint32_t) * (ne ? ne : 1) * p.nwin);
-    // tiles per window of the LDS-staged sort: about two workgroups per CU in total, a tile of at least two points per
-    // bucket (the per-tile flush and the scan are per bucket)
-    int tiles = (int)((size_t)(2 * ctx->num_cu + p.nwin - 1) / p.nwin);
-    while (tiles > 1 && (ne ? ne : 1) / tiles < 2 * (size_t)p.nb) tiles--;
+    const int tiles = sort_tiles(ctx->num_cu, p.nwin, ne, p.nb);
     const size_t m2 = nbk * (size_t)tiles;
     const size_t o_hist = take(sizeof(uint32_t) * m2);
-    const size_t o_cursor = take(sizeof(uint32_t) * (m2 + 1));  // offs2: the scanned hist2
+    const size_t o_total = take(sizeof(uint32_t) * nbk);  // points per bucket
     const uint32_t SUB = piece_len(ne ? ne : 1, p.nb);
     const size_t o_lenhist = take(sizeof(uint32_t) * (MAXSUB + 2));
     const size_t o_lencursor = take(sizeof(uint32_t) * (MAXSUB + 2));
@@ -855,12 +1100,38 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     const size_t o_plo = take(sizeof(uint32_t) * max_pieces);
     const size_t o_plen = take(sizeof(uint32_t) * max_pieces);
     const size_t o_order = take(sizeof(uint32_t) * max_pieces);
+    const size_t o_pdst = take(sizeof(uint32_t) * max_pieces);
     const size_t o_longlist = take(sizeof(uint32_t) * nbk);
+    const size_t o_joinlist = take(sizeof(uint32_t) * nbk);
     const size_t o_buckets = take(sizeof(typename A::Acc) * nbk);
-    const size_t o_partial = take(sizeof(typename A::Acc) * (size_t)p.nwin * p.nchunks);
     const int nfold = (p.nchunks + 31) / 32;  // first fold level: 64 (one-lane tail) or 32 / 64 (cooperative tail) partials per output
-    const size_t o_fold = take(sizeof(typename A::Acc) * (size_t)p.nwin * nfold);
-    const size_t o_tile = take(sizeof(uint32_t) * ((m2 + SCAN_TILE - 1) / SCAN_TILE + 2));
+    size_t n_partial = (size_t)p.nwin * p.nchunks, n_fold = (size_t)p.nwin * nfold, n_chains = (size_t)p.nwin;
+    if constexpr (split_tail<A>()) {
+        // the split tail's rows (tree_fold_bits_coop_kernel): W and T rows side by side, then ping-pong between the two
+        // buffers with nwin * fold_bits more plain rows per launch
+        constexpr int FG = fold_groups<A>(), LB = fold_bits<A>();
+        n_partial *= 2;
+        auto rows = [&](size_t nplain, int ncur) {  // for either start: with and without the reduce kernel's own levels
+            bool to_fold = true;
+            while (ncur > 1) {
+                const int nout = (ncur + FG - 1) / FG;
+                const size_t need = (nplain + (size_t)p.nwin * (LB + 1)) * nout;
+                size_t& dst = to_fold ? n_fold : n_partial;
+                if (need > dst) dst = need;
+                nplain += (size_t)p.nwin * LB;
+                ncur = nout;
+                to_fold = !to_fold;
+            }
+            if (nplain > n_chains) n_chains = nplain;
+        };
+        rows((size_t)p.nwin, p.nchunks);
+        if (p.nchunks >= 16) rows((size_t)p.nwin * (1 + REDUCE_FUSED_BITS), p.nchunks / 16);
+    }
+    const size_t o_partial = take(sizeof(typename A::Acc) * n_partial);
+    const size_t o_fold = take(sizeof(typename A::Acc) * n_fold);
+    const size_t o_shift = take(sizeof(typename A::Acc) * n_chains);
+    const size_t o_shift2 = take(sizeof(typename A::Acc) * ((n_chains + 63) / 64));
+    const size_t o_tile = take(sizeof(uint32_t) * ((nbk + SCAN_TILE - 1) / SCAN_TILE + 2));
     const size_t o_winsum = take(sizeof(typename A::Acc) * p.nwin);
     void* ws;
     int rc = ctx_workspace(ctx, WS_MSM, st, off, &ws);
@@ -870,7 +1141,7 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     auto* digits = (int32_t*)(base + o_dig);
     auto* sorted = (uint32_t*)(base + o_sorted);
     auto* hist = (uint32_t*)(base + o_hist);
-    auto* offs2 = (uint32_t*)(base + o_cursor);
+    auto* total = (uint32_t*)(base + o_total);
     auto* bad = (uint32_t*)(base + o_bad);
     auto* offs = (uint32_t*)(base + o_offs);
     auto* nsub = (uint32_t*)(base + o_nsub);
@@ -879,14 +1150,18 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     auto* plo = (uint32_t*)(base + o_plo);
     auto* plen = (uint32_t*)(base + o_plen);
     auto* order = (uint32_t*)(base + o_order);
+    auto* pdst = (uint32_t*)(base + o_pdst);
     auto* lenhist = (uint32_t*)(base + o_lenhist);
     auto* lencursor = (uint32_t*)(base + o_lencursor);
     auto* nlong = (uint32_t*)(base + o_nlong);
     auto* longlist = (uint32_t*)(base + o_longlist);
+    auto* joinlist = (uint32_t*)(base + o_joinlist);
     auto* buckets = (typename A::Acc*)(base + o_buckets);
     auto* partial = (typename A::Acc*)(base + o_partial);
     auto* winsum = (typename A::Acc*)(base + o_winsum);
     auto* folded = (typename A::Acc*)(base + o_fold);
+    auto* shift = (typename A::Acc*)(base + o_shift);
+    auto* shift2 = (typename A::Acc*)(base + o_shift2);
     auto* tile = (uint32_t*)(base + o_tile);
     KYB_HIP_CHECK(hipMemsetAsync(base + o_lenhist, 0, zero_end - o_lenhist, st));
     if (n) {
@@ -897,25 +1172,42 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
         set_error("msm: window too wide for the LDS-staged sort");
         return KYB_E_ARG;
     }
-    hipLaunchKernelGGL(hist_lds_kernel, dim3(tiles, p.nwin), dim3(HIST_T), 0, st, pr, tiles, (const int32_t*)digits, hist);
-    launch_scan(hist, offs2, m2, tile, st);
-    hipLaunchKernelGGL(scatter_lds_kernel, dim3(tiles, p.nwin), dim3(HIST_T), 0, st, pr, tiles, (const int32_t*)digits,
-                       (const uint32_t*)offs2, sorted);
-    hipLaunchKernelGGL(bucket_offs_kernel, dim3((unsigned)((nbk + 256) / 256)), dim3(256), 0, st, nbk, tiles,
-                       (const uint32_t*)offs2, offs);
-    hipLaunchKernelGGL(subcount_kernel, dim3((unsigned)((nbk + 255) / 256)), dim3(256), 0, st, nbk, SUB, offs, nsub, nlong,
-                       longlist);
+    hipLaunchKernelGGL(hist_lds_kernel, dim3(tiles * p.nwin), dim3(HIST_T), 0, st, pr, tiles, (const int32_t*)digits, hist);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3((unsigned)((nbk + 255) / 256)), dim3(256), 0, st, nbk, p.nb, tiles, hist, total);
+    launch_scan(total, offs, nbk, tile, st);
+    static const int xcd_major = [] {  // KYB_MSM_SORT_XCD=0: tile-minor workgroup order (A/B)
+        const char* e = getenv("KYB_MSM_SORT_XCD");
+        return e && e[0] == '0' ? 0 : 1;
+    }();
+    hipLaunchKernelGGL(scatter_lds_kernel, dim3(tiles * p.nwin), dim3(HIST_T), 0, st, pr, tiles, (const int32_t*)digits,
+                       (const uint32_t*)hist, (const uint32_t*)offs, sorted, xcd_major);
+    hipLaunchKernelGGL(subcount_kernel<A>, dim3((unsigned)((nbk + 255) / 256)), dim3(256), 0, st, nbk, SUB, (const uint32_t*)offs, nsub,
+                       nlong, longlist, joinlist, buckets);
     launch_scan(nsub, suboffs, nbk, tile, st);
     const unsigned pgrid = (unsigned)((max_pieces + 255) / 256);
     hipLaunchKernelGGL(piece_kernel, dim3(pgrid), dim3(256), 0, st, nbk, max_pieces, SUB, (const uint32_t*)offs,
-                       (const uint32_t*)suboffs, plo, plen, lenhist);
+                       (const uint32_t*)suboffs, plo, plen, pdst, lenhist);
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_T), 0, st, lenhist, (size_t)(SUB + 1));
     hipLaunchKernelGGL(piece_order_kernel, dim3(pgrid), dim3(256), 0, st, nbk, max_pieces, SUB, (const uint32_t*)suboffs,
                        (const uint32_t*)plen, (const uint32_t*)lenhist, lencursor, order);
     hipLaunchKernelGGL(accumulate_kernel<A>, dim3((unsigned)((max_pieces + 63) / 64)), dim3(64), 0, st, nbk, max_pieces, aff,
                        (const uint32_t*)suboffs, (const uint32_t*)order, (const uint32_t*)plo, (const uint32_t*)plen,
-                       sorted, pieces);
-    hipLaunchKernelGGL(bucket_kernel<A>, dim3((unsigned)((nbk + 63) / 64)), dim3(64), 0, st, nbk, suboffs, pieces, buckets);
+                       (const uint32_t*)pdst, sorted, pieces, buckets);
+    bool coop_join = false;
+    if constexpr (HasCoopSlots<A>::value) {
+        static const bool lane_join = [] {  // KYB_MSM_JOIN=lane: the one-lane bucket_kernel (A/B)
+            const char* e = getenv("KYB_MSM_JOIN");
+            return e && e[0] == 'l';
+        }();
+        coop_join = !lane_join;
+        if (coop_join)
+            hipLaunchKernelGGL(bucket_coop_kernel<A>, dim3((unsigned)(nbk / 16 < 1024 ? nbk / 16 + 1 : 1024)), dim3(64), 0, st,
+                               (const uint32_t*)nlong, (const uint32_t*)joinlist, (const uint32_t*)suboffs, (const typename A::Acc*)pieces,
+                               buckets);
+    }
+    if (!coop_join)
+    hipLaunchKernelGGL(bucket_kernel<A>, dim3((unsigned)(nbk / 64 < 1024 ? nbk / 64 + 1 : 1024)), dim3(64), 0, st, (const uint32_t*)nlong,
+                       (const uint32_t*)joinlist, (const uint32_t*)suboffs, (const typename A::Acc*)pieces, buckets);
     hipLaunchKernelGGL(bucket_long_kernel<A>, dim3(1024), dim3(long_threads<A>()), 0, st, (const uint32_t*)nlong,
                        (const uint32_t*)longlist, (const uint32_t*)suboffs, pieces, buckets);
     const size_t nred = (size_t)p.nwin * p.nchunks;
@@ -926,15 +1218,73 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
             return e && e[0] == 'l';
         }();
         if (!lane_tail) {
-            hipLaunchKernelGGL(reduce_coop_kernel<A>, dim3((unsigned)((nred + 15) / 16)), dim3(64), 0, st, pr, buckets, partial);
             constexpr int FG = fold_groups<A>();
+#if defined(KYB_ROWFP_INCLUDED)
+            if constexpr (split_tail<A>()) {
+                // KYB_MSM_REDUCE=mul: every chunk multiplies its own lo * run (rounds 3-5); KYB_MSM_FINAL=lanes implies it
+                static const bool split = [] {
+                    const char* e = getenv("KYB_MSM_REDUCE");
+                    const char* f = getenv("KYB_MSM_FINAL");
+                    return !(e && e[0] == 'm') && !(f && f[0] == 'l');
+                }();
+                if (split && p.nwin > 1) {
+                    constexpr int LB = fold_bits<A>();
+                    int chbits = 0, tz = 0;
+                    while ((1 << chbits) < p.nchunks) chbits++;
+                    while ((1 << tz) < p.chunk) tz++;
+                    static const bool fuse_ok = [] {  // KYB_MSM_REDUCE=nofuse: the whole tree in the fold launches (A/B)
+                        const char* e = getenv("KYB_MSM_REDUCE");
+                        return !(e && e[0] == 'n');
+                    }();
+                    const int fuse = fuse_ok && p.nchunks >= 16 ? 1 : 0, lb0 = fuse ? REDUCE_FUSED_BITS : 0;
+                    hipLaunchKernelGGL(reduce_coop_kernel<A>, dim3((unsigned)((nred + 15) / 16)), dim3(64), 0, st, pr, buckets, partial,
+                                       partial + nred, fuse);
+                    typename A::Acc* cur = partial;
+                    typename A::Acc* nxt = folded;
+                    int nplain = p.nwin * (1 + lb0), done = lb0;
+                    for (int ncur = fuse ? p.nchunks / 16 : p.nchunks; ncur > 1;) {
+                        const int nout = (ncur + FG - 1) / FG, lb_out = chbits - done < LB ? chbits - done : LB;
+                        hipLaunchKernelGGL(tree_fold_bits_coop_kernel<A>, dim3((unsigned)((nplain + p.nwin) * nout)), dim3(4 * FG), 0, st,
+                                           nplain, p.nwin, ncur, lb_out, (const typename A::Acc*)cur, nxt);
+                        typename A::Acc* t = cur;
+                        cur = nxt;
+                        nxt = t;
+                        nplain += p.nwin * lb_out;
+                        done += lb_out;
+                        ncur = nout;
+                    }
+                    // nplain terms now: the W sums and every D_k, each with a doubling chain of its own
+                    hipLaunchKernelGGL(final_rows_kernel<A>, dim3((unsigned)nplain), dim3(64), 0, st, pr, (const typename A::Acc*)cur, shift, lb0,
+                                       LB, tz, chbits);
+                    typename A::Acc* a = shift;
+                    typename A::Acc* b = shift2;
+                    int m = nplain;
+                    while (m > 2) {
+                        const int nout = (m + 2 * FG - 1) / (2 * FG);
+                        hipLaunchKernelGGL(tree_fold_coop_kernel<A>, dim3((unsigned)nout), dim3(4 * FG), 0, st, 1, m, (const typename A::Acc*)a, b, 2);
+                        typename A::Acc* t = a;
+                        a = b;
+                        b = t;
+                        m = nout;
+                    }
+                    Plan p0 = pr;
+                    p0.c = 0;     // nothing left to double
+                    p0.nwin = m;  // one or two terms for final_kernel's own tree
+                    hipLaunchKernelGGL(final_kernel<A>, dim3(1), dim3(64), 0, st, p0, (const typename A::Acc*)a, winsum, bad, (uint8_t*)d_out);
+                    KYB_HIP_CHECK(hipGetLastError());
+                    return KYB_OK;
+                }
+            }
+#endif
+            hipLaunchKernelGGL(reduce_coop_kernel<A>, dim3((unsigned)((nred + 15) / 16)), dim3(64), 0, st, pr, buckets, partial,
+                               (typename A::Acc*)nullptr, 0);
             typename A::Acc* cur = partial;
             typename A::Acc* nxt = folded;
             int ncur = p.nchunks;
             while (ncur > 1) {
                 const int nout = (ncur + FG - 1) / FG;
                 hipLaunchKernelGGL(tree_fold_coop_kernel<A>, dim3((unsigned)(p.nwin * nout)), dim3(4 * FG), 0, st, p.nwin, ncur,
-                                   cur, nxt);
+                                   cur, nxt, 1);
                 typename A::Acc* t = cur;
                 cur = nxt;
                 nxt = t;
@@ -954,11 +1304,11 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
                 }();
                 if (!lanes_final && p.nwin > 1 && p.nwin <= FG) {
                     typename A::Acc* shifted = cur == partial ? folded : partial;  // the fold buffer not holding the sums
-                    hipLaunchKernelGGL(final_rows_kernel<A>, dim3((unsigned)p.nwin), dim3(64), 0, st, pr, (const typename A::Acc*)cur, shifted);
+                    hipLaunchKernelGGL(final_rows_kernel<A>, dim3((unsigned)p.nwin), dim3(64), 0, st, pr, (const typename A::Acc*)cur, shifted, 0, 1, 0, 0);
                     // the nwin shifted sums are one more row of partials for the cooperative fold (a tree of four-lane additions:
                     // final_kernel's own tree is one lane per addition), and final_kernel is left with the encoding
                     typename A::Acc* total = cur;  // the sums were read by the kernel above: their buffer is free again
-                    hipLaunchKernelGGL(tree_fold_coop_kernel<A>, dim3(1), dim3(4 * FG), 0, st, 1, p.nwin, (const typename A::Acc*)shifted, total);
+                    hipLaunchKernelGGL(tree_fold_coop_kernel<A>, dim3(1), dim3(4 * FG), 0, st, 1, p.nwin, (const typename A::Acc*)shifted, total, 1);
                     Plan p0 = pr;
                     p0.c = 0;     // nothing left to double
                     p0.nwin = 1;  // nor to add
