@@ -213,7 +213,7 @@ KYB_HD_NOINLINE int g2_decode(g2_aff& a, const uint8_t* in, bool check_subgroup)
 // byte: compression 0, infinity, sort 0) -- the `_aff` inputs of SURVEY.md section 8(b): no square root.  With
 // validate = false (KYB_F_TRUSTED_*) the curve-equation and subgroup checks are skipped as well.
 constexpr int G1_WIRE_UNC = 96, G2_WIRE_UNC = 192;
-KYB_HD_NOINLINE int g1_decode_unc(g1_aff& a, const uint8_t* in, bool validate, bool subgroup = true) {
+KYB_HD int g1_decode_unc_inl(g1_aff& a, const uint8_t* in, bool validate, bool subgroup) {
     uint32_t wx[12], wy[12];
     words_from_be<12>(wx, in);
     words_from_be<12>(wy, in + 48);
@@ -247,6 +247,12 @@ KYB_HD_NOINLINE int g1_decode_unc(g1_aff& a, const uint8_t* in, bool validate, b
     if (validate && subgroup && !g1_in_subgroup(a)) return ST_NOT_IN_SUBGROUP;
     return ST_OK;
 }
+KYB_HD_NOINLINE int g1_decode_unc(g1_aff& a, const uint8_t* in, bool validate, bool subgroup = true) {
+    return g1_decode_unc_inl(a, in, validate, subgroup);
+}
+// the vouched-for uncompressed form with the body in the caller (msm.cuh's light decode kernel: no curve equation, no
+// subgroup rule, nothing that would need the out-of-line routines' register budget)
+KYB_HD int g1_decode_unc_trusted(g1_aff& a, const uint8_t* in) { return g1_decode_unc_inl(a, in, false, false); }
 KYB_HD_NOINLINE int g2_decode_unc(g2_aff& a, const uint8_t* in, bool validate, bool subgroup = true) {
     uint32_t w[4][12];
     uint32_t any = 0;

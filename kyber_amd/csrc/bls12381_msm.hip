@@ -65,6 +65,23 @@ struct BlsG1Msm : msm::Weierstrass<bls::fp, BlsG1Codec> {
     __device__ static int decode_split(Aff (&a)[2], uint32_t (&k)[2][8], const uint8_t* pt, const uint8_t* scalar,
                                        uint32_t flags) {
         const int st = Base::decode(a[0], pt, flags);
+        split_halves(a, k, scalar);
+        return st;
+    }
+    // KYB_F_UNCOMPRESSED | KYB_F_TRUSTED(0), the form a resident pipeline keeps its points in: a decode kernel of its own
+    // (msm.cuh decode_kernel<A, true>) without the square root, the curve equation and the subgroup rule in its code --
+    // a third of the registers, twice the waves to hide the loads behind
+    static constexpr int LIGHT_DECODE_WAVES = 4;
+    __device__ static int decode_split_light(Aff (&a)[2], uint32_t (&k)[2][8], const uint8_t* pt, const uint8_t* scalar) {
+        bls::g1_aff t;
+        const int st = bls::g1_decode_unc_trusted(t, pt);
+        a[0].x = t.x;
+        a[0].y = t.y;
+        a[0].inf = t.inf ? 1u : 0u;
+        split_halves(a, k, scalar);
+        return st;
+    }
+    __device__ __forceinline__ static void split_halves(Aff (&a)[2], uint32_t (&k)[2][8], const uint8_t* scalar) {
         uint32_t kk[8], q8[8], rem[4];
         Base::scalar_words(kk, scalar);
         bls::divmod_z<4>(q8, rem, kk);
@@ -99,7 +116,6 @@ struct BlsG1Msm : msm::Weierstrass<bls::fp, BlsG1Codec> {
             k[0][i] = i < 5 ? r[i] : 0u;
             k[1][i] = i < 5 ? q[i] : 0u;
         }
-        return st;
     }
 };
 using BlsG2Msm = msm::Weierstrass<bls::fp2, BlsG2Codec>;

@@ -141,8 +141,20 @@ struct DecodeWaves<A, decltype((void)A::DECODE_WAVES)> {
     static constexpr int value = A::DECODE_WAVES;
 };
 
+// LightDecode<A>: the adapter has a decode of its own for vouched-for points in their uncompressed form
+// (decode_split_light, LIGHT_DECODE_WAVES): decode_kernel<A, true>
+template <class A, class = void>
+struct LightDecode {
+    static constexpr bool value = false;
+    static constexpr int waves = 2;
+};
 template <class A>
-__global__ __launch_bounds__(64, DecodeWaves<A>::value) void decode_kernel(Plan p, size_t n_in, const uint8_t* __restrict__ scalars,
+struct LightDecode<A, decltype((void)A::LIGHT_DECODE_WAVES)> {
+    static constexpr bool value = true;
+    static constexpr int waves = A::LIGHT_DECODE_WAVES;
+};
+template <class A, bool LIGHT = false>
+__global__ __launch_bounds__(64, LIGHT ? LightDecode<A>::waves : DecodeWaves<A>::value) void decode_kernel(Plan p, size_t n_in, const uint8_t* __restrict__ scalars,
                                                     const uint8_t* __restrict__ points,
                                                     typename A::Aff* __restrict__ aff, int32_t* __restrict__ digits,
                                                     uint8_t* __restrict__ status,
@@ -160,7 +172,9 @@ __global__ __launch_bounds__(64, DecodeWaves<A>::value) void decode_kernel(Plan 
     uint32_t k[S][8];
     int st = 0;
     if (live) {
-        if constexpr (S == 1) {
+        if constexpr (LIGHT) {
+            st = A::decode_split_light(a, k, points + A::wire_size(p.flags) * i, scalars + 32 * i);
+        } else if constexpr (S == 1) {
             st = A::decode(a[0], points + A::wire_size(p.flags) * i, p.flags);
             A::scalar_words(k[0], scalars + 32 * i);
             Effective<A>::apply(k[0], a[0], p.bits);
@@ -1165,8 +1179,20 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     auto* tile = (uint32_t*)(base + o_tile);
     KYB_HIP_CHECK(hipMemsetAsync(base + o_lenhist, 0, zero_end - o_lenhist, st));
     if (n) {
-        hipLaunchKernelGGL(decode_kernel<A>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, pr, n, (const uint8_t*)d_scalars,
-                           (const uint8_t*)d_points, aff, digits, (uint8_t*)d_status, bad);
+        bool light = false;
+        if constexpr (LightDecode<A>::value) {
+            static const bool off = [] {  // KYB_MSM_DECODE=full: the one decode kernel for every calling convention (A/B)
+                const char* e = getenv("KYB_MSM_DECODE");
+                return e && e[0] == 'f';
+            }();
+            light = !off && (flags & FLAG_UNCOMPRESSED) && flag_trusted(flags, 0);
+            if (light)
+                hipLaunchKernelGGL((decode_kernel<A, true>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, pr, n, (const uint8_t*)d_scalars,
+                                   (const uint8_t*)d_points, aff, digits, (uint8_t*)d_status, bad);
+        }
+        if (!light)
+            hipLaunchKernelGGL(decode_kernel<A>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, pr, n, (const uint8_t*)d_scalars,
+                               (const uint8_t*)d_points, aff, digits, (uint8_t*)d_status, bad);
     }
     if (p.nb > HIST_MAX_NB) {
         set_error("msm: window too wide for the LDS-staged sort");
