@@ -385,6 +385,139 @@ static __global__ __launch_bounds__(HIST_T) void scatter_lds_kernel(Plan p, int 
             if (d[u]) sorted[pos[u]] = (uint32_t)(i0 + (size_t)u * HIST_T) | (d[u] < 0 ? 0x80000000u : 0u);
     }
 }
+// ---- The sort in two passes (round 6; plans of at least 2^13 buckets per window and at most 2^23 points) ----------------
+// scatter_lds_kernel above stores every sorted entry on its own: 16.8 M four-byte stores into 16.8 M different lines for a
+// 2^20-point BLS12-381 G1 MSM -- 220 us at the rate the L2 channels take partial-line writes, whatever order the
+// workgroups run in and however many sweeps they make (profiles/r06_msm_scatter_sweeps.txt).  Two passes whose stores are
+// RUNS instead:
+//   1  by coarse bin (bucket / 256; <= 128 bins per window): coarse_hist_kernel counts every (window, bin, tile of 2^13
+//      entries), one scan of the counters gives each (bin, tile) its first slot, coarse_scatter_kernel orders its tile by bin
+//      in LDS and writes each bin's run of the tile as one piece -- entry = index | sign << 23 | (bucket mod 256) << 24;
+//   2  fine_sort_kernel, one workgroup per (window, bin): counts the 256 buckets of its bin, writes their offsets (the
+//      pipeline's offs[]), orders the bin's ~2^14 entries in LDS and writes them as ONE run of `sorted` (a bin too long
+//      for LDS -- skewed digits -- is scattered directly).
+#ifndef KYB_MSM_P2_T1
+#define KYB_MSM_P2_T1 8192
+#endif
+#ifndef KYB_MSM_P2_LMAX
+#define KYB_MSM_P2_LMAX 18432
+#endif
+// (tile and staging sizes that leave two workgroups per CU: fine_sort 76 -> 65 us, coarse_scatter 45 -> 38 us against 2^14 / 24 576;
+// a bin of the halves' top window where the density doubles goes the direct way)
+constexpr int P2_FB = 256, P2_T1 = KYB_MSM_P2_T1, P2_MAXCB = 128, P2_LMAX = KYB_MSM_P2_LMAX, P2_T = 1024;
+static __global__ __launch_bounds__(P2_T) void coarse_hist_kernel(Plan p, int tiles1, int cb, const int32_t* __restrict__ digits,
+                                                                  uint32_t* __restrict__ ch) {
+    __shared__ uint32_t h[P2_T / 64][P2_MAXCB];  // a histogram per wave: the lanes of ONE wave meet in a counter often enough
+    const int w = blockIdx.x % p.nwin, tile = blockIdx.x / p.nwin, wave = threadIdx.x >> 6;
+    for (int j = threadIdx.x; j < (P2_T / 64) * P2_MAXCB; j += P2_T) (&h[0][0])[j] = 0;
+    __syncthreads();
+    const size_t lo = (size_t)tile * P2_T1, hi = lo + P2_T1 < p.n ? lo + P2_T1 : p.n;
+    const int32_t* dw = digits + (size_t)w * p.n;
+#pragma unroll 4
+    for (size_t i = lo + threadIdx.x; i < hi; i += P2_T) {
+        const int d = dw[i];
+        if (d) atomicAdd(&h[wave][((d < 0 ? -d : d) - 1) / P2_FB], 1u);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < cb) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < P2_T / 64; k++) v += h[k][threadIdx.x];
+        ch[((size_t)w * cb + threadIdx.x) * tiles1 + tile] = v;  // bin-major, tile-minor: the scan order
+    }
+}
+static __global__ __launch_bounds__(P2_T) void coarse_scatter_kernel(Plan p, int tiles1, int cb, const int32_t* __restrict__ digits,
+                                                                     const uint32_t* __restrict__ ch,
+                                                                     const uint32_t* __restrict__ offs1,
+                                                                     uint32_t* __restrict__ mid) {
+    __shared__ uint32_t stage[P2_T1], dest[P2_T1];
+    __shared__ uint32_t lpre[P2_MAXCB], gstart[P2_MAXCB], cur[P2_MAXCB], tot;
+    const int w = blockIdx.x % p.nwin, tile = blockIdx.x / p.nwin;
+    if ((int)threadIdx.x < cb) {
+        const size_t j = ((size_t)w * cb + threadIdx.x) * tiles1 + tile;
+        lpre[threadIdx.x] = ch[j];
+        gstart[threadIdx.x] = offs1[j];
+        cur[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // <= 128 counters
+        uint32_t run = 0;
+        for (int b = 0; b < cb; b++) {
+            const uint32_t v = lpre[b];
+            lpre[b] = run;
+            run += v;
+        }
+        tot = run;
+    }
+    __syncthreads();
+    const size_t lo = (size_t)tile * P2_T1, hi = lo + P2_T1 < p.n ? lo + P2_T1 : p.n;
+    const int32_t* dw = digits + (size_t)w * p.n;
+#pragma unroll 4
+    for (size_t i = lo + threadIdx.x; i < hi; i += P2_T) {
+        const int d = dw[i];
+        if (d) {
+            const uint32_t bk = (uint32_t)((d < 0 ? -d : d) - 1), bin = bk / P2_FB;
+            const uint32_t r = atomicAdd(&cur[bin], 1u), pos = lpre[bin] + r;
+            stage[pos] = (uint32_t)i | (d < 0 ? 1u << 23 : 0u) | (bk % P2_FB) << 24;
+            dest[pos] = gstart[bin] + r;
+        }
+    }
+    __syncthreads();
+    const uint32_t m = tot;
+    for (uint32_t q = threadIdx.x; q < m; q += P2_T) mid[dest[q]] = stage[q];  // neighbours in a bin are neighbours in mid
+}
+static __global__ __launch_bounds__(P2_T) void fine_sort_kernel(int tiles1, const uint32_t* __restrict__ offs1,
+                                                                const uint32_t* __restrict__ mid, uint32_t* __restrict__ offs,
+                                                                uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t stage[P2_LMAX];
+    __shared__ uint32_t cnt[P2_FB], pre[P2_FB];
+    const size_t g = blockIdx.x;  // window * bins + bin
+    const uint32_t lo = offs1[g * tiles1], hi = offs1[(g + 1) * tiles1], len = hi - lo;
+    if (threadIdx.x < P2_FB) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += P2_T) atomicAdd(&cnt[mid[i] >> 24], 1u);
+    __syncthreads();
+    if (threadIdx.x < P2_FB) pre[threadIdx.x] = cnt[threadIdx.x];
+    __syncthreads();
+    for (int off = 1; off < P2_FB; off <<= 1) {  // Hillis-Steele over the 256 counters
+        uint32_t add = 0;
+        if (threadIdx.x < P2_FB && (int)threadIdx.x >= off) add = pre[threadIdx.x - off];
+        __syncthreads();
+        if (threadIdx.x < P2_FB) pre[threadIdx.x] += add;
+        __syncthreads();
+    }
+    if (threadIdx.x < P2_FB) {
+        const uint32_t first = pre[threadIdx.x] - cnt[threadIdx.x];  // exclusive
+        offs[g * P2_FB + threadIdx.x] = lo + first;
+        pre[threadIdx.x] = first;
+        cnt[threadIdx.x] = 0;  // the cursors now
+    }
+    if (g == gridDim.x - 1 && threadIdx.x == 0) offs[(size_t)gridDim.x * P2_FB] = hi;
+    __syncthreads();
+    if (len <= (uint32_t)P2_LMAX) {
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += P2_T) {
+            const uint32_t x = mid[i], f = x >> 24;
+            stage[pre[f] + atomicAdd(&cnt[f], 1u)] = (x & 0x7fffffu) | ((x >> 23) & 1u) << 31;
+        }
+        __syncthreads();
+        for (uint32_t q = threadIdx.x; q < len; q += P2_T) sorted[lo + q] = stage[q];
+    } else {
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += P2_T) {
+            const uint32_t x = mid[i], f = x >> 24;
+            sorted[lo + pre[f] + atomicAdd(&cnt[f], 1u)] = (x & 0x7fffffu) | ((x >> 23) & 1u) << 31;
+        }
+    }
+}
+// the plan takes the two passes: whole bins of 256 buckets, an index that fits 23 bits.  KYB_MSM_SORT=single: never (A/B)
+inline bool sort_two_pass(const Plan& p, size_t ne) {
+    static const bool off = [] {
+        const char* e = getenv("KYB_MSM_SORT");
+        return e && e[0] == 's';
+    }();
+    // (below 2^19 entries per window the one pass is ahead: 1.70 against 1.85 ms for 2^16 points, 1.78 against 2.00 for 2^17)
+    return !off && p.nb >= 8192 && p.nb / P2_FB <= P2_MAXCB && ne >= (size_t(1) << 19) && ne <= (size_t(1) << 23);
+}
+
 // Tiles per window: as many workgroups as fill `rounds` whole rounds of the chip (rounds 1-5 aimed at "about two per CU"
 // and got 288 workgroups for the 2^20-point BLS12-381 G1 MSM: a full round and an eighth of one, i.e. two), a tile of at
 // least two points per bucket (the per-tile flush is per bucket).  KYB_MSM_SORT_TILES forces a count (A/B runs).
@@ -1100,6 +1233,12 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     const size_t m2 = nbk * (size_t)tiles;
     const size_t o_hist = take(sizeof(uint32_t) * m2);
     const size_t o_total = take(sizeof(uint32_t) * nbk);  // points per bucket
+    const bool two_pass = sort_two_pass(p, ne);
+    const int cb = p.nb / P2_FB, tiles1 = (int)(((ne ? ne : 1) + P2_T1 - 1) / P2_T1);
+    const size_t m1 = two_pass ? (size_t)p.nwin * cb * tiles1 : 0;
+    const size_t o_mid = take(two_pass ? sizeof(uint32_t) * (ne ? ne : 1) * p.nwin : 0);
+    const size_t o_ch = take(sizeof(uint32_t) * m1);
+    const size_t o_offs1 = take(sizeof(uint32_t) * (m1 + 1));
     const uint32_t SUB = piece_len(ne ? ne : 1, p.nb);
     const size_t o_lenhist = take(sizeof(uint32_t) * (MAXSUB + 2));
     const size_t o_lencursor = take(sizeof(uint32_t) * (MAXSUB + 2));
@@ -1145,7 +1284,7 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     const size_t o_fold = take(sizeof(typename A::Acc) * n_fold);
     const size_t o_shift = take(sizeof(typename A::Acc) * n_chains);
     const size_t o_shift2 = take(sizeof(typename A::Acc) * ((n_chains + 63) / 64));
-    const size_t o_tile = take(sizeof(uint32_t) * ((nbk + SCAN_TILE - 1) / SCAN_TILE + 2));
+    const size_t o_tile = take(sizeof(uint32_t) * (((nbk > m1 ? nbk : m1) + SCAN_TILE - 1) / SCAN_TILE + 2));
     const size_t o_winsum = take(sizeof(typename A::Acc) * p.nwin);
     void* ws;
     int rc = ctx_workspace(ctx, WS_MSM, st, off, &ws);
@@ -1156,6 +1295,9 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     auto* sorted = (uint32_t*)(base + o_sorted);
     auto* hist = (uint32_t*)(base + o_hist);
     auto* total = (uint32_t*)(base + o_total);
+    auto* mid = (uint32_t*)(base + o_mid);
+    auto* ch = (uint32_t*)(base + o_ch);
+    auto* offs1 = (uint32_t*)(base + o_offs1);
     auto* bad = (uint32_t*)(base + o_bad);
     auto* offs = (uint32_t*)(base + o_offs);
     auto* nsub = (uint32_t*)(base + o_nsub);
@@ -1198,6 +1340,14 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
         set_error("msm: window too wide for the LDS-staged sort");
         return KYB_E_ARG;
     }
+    if (two_pass) {
+        hipLaunchKernelGGL(coarse_hist_kernel, dim3((unsigned)(tiles1 * p.nwin)), dim3(P2_T), 0, st, pr, tiles1, cb, (const int32_t*)digits, ch);
+        launch_scan(ch, offs1, m1, tile, st);
+        hipLaunchKernelGGL(coarse_scatter_kernel, dim3((unsigned)(tiles1 * p.nwin)), dim3(P2_T), 0, st, pr, tiles1, cb, (const int32_t*)digits,
+                           (const uint32_t*)ch, (const uint32_t*)offs1, mid);
+        hipLaunchKernelGGL(fine_sort_kernel, dim3((unsigned)(p.nwin * cb)), dim3(P2_T), 0, st, tiles1, (const uint32_t*)offs1,
+                           (const uint32_t*)mid, offs, sorted);
+    } else {
     hipLaunchKernelGGL(hist_lds_kernel, dim3(tiles * p.nwin), dim3(HIST_T), 0, st, pr, tiles, (const int32_t*)digits, hist);
     hipLaunchKernelGGL(tile_scan_kernel, dim3((unsigned)((nbk + 255) / 256)), dim3(256), 0, st, nbk, p.nb, tiles, hist, total);
     launch_scan(total, offs, nbk, tile, st);
@@ -1207,6 +1357,7 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     }();
     hipLaunchKernelGGL(scatter_lds_kernel, dim3(tiles * p.nwin), dim3(HIST_T), 0, st, pr, tiles, (const int32_t*)digits,
                        (const uint32_t*)hist, (const uint32_t*)offs, sorted, xcd_major);
+    }
     hipLaunchKernelGGL(subcount_kernel<A>, dim3((unsigned)((nbk + 255) / 256)), dim3(256), 0, st, nbk, SUB, (const uint32_t*)offs, nsub,
                        nlong, longlist, joinlist, buckets);
     launch_scan(nsub, suboffs, nbk, tile, st);

@@ -77,6 +77,35 @@ def msm():
             assert bytes(np.asarray(out)) == want, (m.__name__, grp, n)
 
 
+def msmbig():
+    """2^17 BLS12-381 G1 points: a plan of 2^14 buckets per window (the two-pass sort, the split tail with fused tree levels,
+    the light decode kernel), with a block of 30 000 equal scalars (a coarse bin too long for the second pass's LDS, a long
+    bucket), zero scalars (empty top windows for some points) and scalars >= r"""
+    import torch  # noqa: F401
+
+    from kyber_amd.pairing import bls12381 as B
+    from oracle import bls12381 as OB
+
+    rng = random.Random(66)
+    n = 1 << 17
+    hs = [rng.randrange(1, B.ORDER) for _ in range(n)]
+    ks = [rng.randrange(1 << 256) for _ in range(n)]
+    ks[0], ks[1], ks[2] = 0, B.ORDER - 1, B.ORDER + 5
+    ks[100:30100] = [ks[100]] * 30000
+    ks[40000:40100] = [rng.randrange(1 << 40) for _ in range(100)]
+    pts, st = B.g1_commit(_be(hs))
+    assert not np.asarray(st).any()
+    tot = sum(k * h for k, h in zip(ks, hs)) % B.ORDER
+    want = OB.g1_compress(OB.g1_mul(tot, OB.G1_GEN))
+    out, st = B.g1_msm(_be(ks), pts)
+    assert not np.asarray(st).any() and bytes(np.asarray(out)) == want
+    unc, st = B._mul(1, torch.from_numpy(_be(hs)).cuda(), torch.from_numpy(np.frombuffer(B.G1_BASE, dtype=np.uint8).copy()).cuda(), True,
+                     B.F_UNCOMPRESSED_OUT)
+    assert not st.any().item()
+    out, st = B.g1_msm(torch.from_numpy(_be(ks)).cuda(), unc, B.F_TRUSTED(0) | B.F_UNCOMPRESSED)
+    assert not st.any().item() and bytes(out.cpu().numpy()) == want
+
+
 def lvm():
     import torch  # noqa: F401
 
@@ -322,5 +351,5 @@ def bnhash():
 BNHASH_DIGEST = "86f1a16dd7b32606"
 
 if __name__ == "__main__":
-    {"bnhash": bnhash, "fb": fb, "msm": msm, "lvm": lvm, "bncheck": bncheck, "pipe": pipe, "g1split": g1split, "unmw2": unmw2, "hashw2": hashw2}[sys.argv[1]]()
+    {"bnhash": bnhash, "fb": fb, "msm": msm, "msmbig": msmbig, "lvm": lvm, "bncheck": bncheck, "pipe": pipe, "g1split": g1split, "unmw2": unmw2, "hashw2": hashw2}[sys.argv[1]]()
     print("switch-probe ok", sys.argv[1])

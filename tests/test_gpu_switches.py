@@ -16,6 +16,11 @@ CASES = [
     ("msm", {"KYB_MSM_CHUNK": "16"}), ("msm", {"KYB_MSM_CHUNK": "4"}),
     # round 6: the three-lane final kernel instead of the limb-per-lane one; the four-lane fixed-base chain; one staging pool
     ("msm", {"KYB_MSM_FINAL": "lanes"}), ("fb", {"KYB_FB_CHAIN": "lanes"}), ("pipe", {"KYB_STAGE_POOLS": "1"}), ("msm", {"KYB_STAGE_POOLS": "1"}),
+    # round 6, the MSM: one-pass sort, the tail that multiplies every chunk's lo * run / the tree all in the fold launches, the
+    # one-lane bucket join, one decode kernel for every convention
+    ("msmbig", {}), ("msmbig", {"KYB_MSM_SORT": "single"}), ("msmbig", {"KYB_MSM_REDUCE": "mul"}), ("msmbig", {"KYB_MSM_REDUCE": "nofuse"}),
+    ("msmbig", {"KYB_MSM_JOIN": "lane"}), ("msmbig", {"KYB_MSM_DECODE": "full"}), ("msmbig", {"KYB_MSM_FINAL": "lanes"}),
+    ("msm", {"KYB_MSM_REDUCE": "mul"}), ("msm", {"KYB_MSM_REDUCE": "nofuse"}), ("msm", {"KYB_MSM_JOIN": "lane"}),
     ("bnhash", {}), ("bnhash", {"KYB_BN_HASH_QUEUE": "0"}), ("bnhash", {"KYB_BN_HASH_HQ": "512"}),
     ("pipe", {}), ("pipe", {"KYB_PIPE_CHUNK": "4096", "KYB_PIPE_STREAMS": "1"}), ("pipe", {"KYB_PIPE_CHUNK": "4096", "KYB_PIPE_STREAMS": "3"}),
     ("unmw2", {}), ("unmw2", {"KYB_UNM_W2": "0"}), ("hashw2", {}), ("hashw2", {"KYB_UNM_W2": "0"}),
