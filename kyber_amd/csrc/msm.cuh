@@ -1032,8 +1032,10 @@ __global__ __launch_bounds__(4 * fold_groups<A>(), 2) void tree_fold_bits_coop_k
     if (k0 < nin) A::slot_load(S, P, in + (size_t)row * nin + k0, r);
     else A::slot_identity(S, P, r);
     __syncthreads();
+    const int have = nin - g * FG;  // inputs of this block: the levels above them would add identities (a last launch of 4
+                                    // inputs per row: 2 levels instead of 6, 64 -> 25 us)
 #pragma unroll 1
-    for (int off = 1; off < FG; off <<= 1) {
+    for (int off = 1; off < FG && off < have; off <<= 1) {
         const int low = gi & (2 * off - 1);
         const bool active = bits ? ((low & (low - 1)) == 0 && low < off) : low == 0;
         if (active && r < 3) S[Q + r].f = slots[(gi + off) * NS + P + r].f;
