@@ -7,18 +7,23 @@
 // encodings are canonical any correct summation order gives the same bytes.
 //
 // Pipeline (all on one stream, no host synchronisation):
-//   1 decode    : lane i decodes point i to affine form in HBM (AoS, one gather unit per point),
-//                 recodes scalar i into signed c-bit digits and histograms them per (window, |digit|)
-//   2 scan      : exclusive prefix sum of the histogram -> start offset of every bucket
-//   3 scatter   : counting sort of point indices (sign in bit 31) by (window, bucket)
-//   4 accumulate: one lane per bucket piece (at most twice the mean bucket length; long buckets from skewed digits are
-//                 split) adds its points with mixed additions -- in XYZZ form on the Weierstrass curves -- then one
-//                 lane per bucket joins the pieces
-//   5 reduce    : per window, chunks of buckets -> sum_b b * B_b by running sums; Weierstrass curves: FOUR lanes per
+//   1 decode    : lane i decodes point i to affine form in HBM (AoS, one gather unit per point; stored through LDS as
+//                 whole lines) and recodes scalar i into signed c-bit digits, window-major.  Adapters with a light decode
+//                 (vouched-for uncompressed points) have a kernel of their own for it.
+//   2 sort      : counting sort of point indices (sign in bit 31) by (window, bucket) -- large plans in two passes whose
+//                 stores are runs (coarse bins of 256 buckets, then one workgroup per bin), small ones in one pass with a
+//                 counter per bucket in LDS; either way offs[] = the first entry of every bucket
+//   3 accumulate: one lane per bucket piece (at most twice the mean bucket length; long buckets from skewed digits are
+//                 split) adds its points with mixed additions -- in XYZZ form on the Weierstrass curves.  A bucket's only
+//                 piece is stored as the bucket; buckets of several pieces are joined afterwards (four lanes per bucket on
+//                 the Weierstrass curves)
+//   4 reduce    : per window, chunks of buckets -> sum_b b * B_b by running sums; Weierstrass curves: FOUR lanes per
 //                 chunk cooperating through LDS slots (reduce_coop_kernel), others: one lane per chunk
-//   6 fold+final: chunk partials are folded 32 / 64 at a time as trees, then the window sums are shifted by 2^(c w)
-//                 (3 - 4 lanes per point share the products of a doubling), added and encoded.  If any input failed to
-//                 decode the output is all-zero bytes.
+//   5 fold+final: chunk partials are folded 32 / 64 at a time as trees, then the window sums are shifted by 2^(c w)
+//                 (3 - 4 lanes per point share the products of a doubling), added and encoded.  BLS12-381 G1 (the split
+//                 tail): the chunks keep their lo * run apart, the fold tree yields the bit sums D_k, and every term
+//                 2^(c w) W_w, 2^(c w + tz + k) D_k(w) has a limb-per-lane doubling chain of its own (rowfp.cuh).
+//                 If any input failed to decode the output is all-zero bytes.
 // Sorting instead of atomics on ~150-byte points: the only atomics are 32-bit counters.
 //
 // Adapter A: typename Aff (decoded input), Acc (accumulator); WIRE (input bytes), OUT (output bytes);
