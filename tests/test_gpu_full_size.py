@@ -223,7 +223,7 @@ def _be_scalars_mod(label: bytes, n: int, order: int) -> np.ndarray:
     return out
 
 
-@pytest.mark.parametrize("name,grp,n", [("bls12381", 1, 1 << 20), ("bls12381", 2, 1 << 18),
+@pytest.mark.parametrize("name,grp,n", [("bls12381", 1, 1 << 20), ("bls12381", 1, 1 << 22), ("bls12381", 2, 1 << 18),  # 2^22: the two-pass sort's largest index
                                         ("bn256", 1, 1 << 20), ("bn254", 1, 1 << 20), ("bn256", 2, 1 << 17)])
 def test_msm_at_config_size_against_an_independent_expectation(name, grp, n):
     """configs[2] (BLS12-381 G1 Pippenger MSM, 2^20 points; share/poly.go:340-348, 449-476, sign/bdn/bdn.go:126-161 are
