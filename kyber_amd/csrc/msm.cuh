@@ -166,8 +166,8 @@ __global__ __launch_bounds__(64, LIGHT ? LightDecode<A>::waves : DecodeWaves<A>:
                                                     uint32_t* __restrict__ bad) {
     constexpr int S = Split<A>::value;
     // the decoded points leave through LDS: a lane's Aff is ~100 bytes, and stored from its registers every dword of the
-    // wave's 64 lands in a line of its own (50 stores x 64 lines per wave for BLS12-381 G1's two halves: the address unit's
-    // time, not the memory's, was a third of this kernel); staged, a wave stores whole lines
+    // wave's 64 lands in a line of its own (50 stores x 64 lines per wave for BLS12-381 G1's two halves); staged, a wave
+    // stores whole lines (222 -> 210 us per 2^20 points: the smaller part of what the light kernel gained)
     constexpr int W = (int)(sizeof(typename A::Aff) / 4);
     static_assert(sizeof(typename A::Aff) % 4 == 0, "Aff is staged word by word");
     __shared__ uint32_t stage[64 * W];
@@ -306,7 +306,7 @@ static inline void launch_scan(const uint32_t* hist, uint32_t* offs, size_t m, u
 //   scatter_lds_kernel  loads offs[b] + its tile's counter -- for every (bucket, tile) the first output slot of the
 //                       tile's points of that bucket -- into the same LDS array and every point takes its slot with one
 //                       returning ds_add (rank within the bucket = arrival order, any order is a valid sort).
-// One workgroup per CU at a time (128 KB of LDS), so the grid is cut to WHOLE rounds of the chip (sort_tiles below).
+// One workgroup per CU at a time (128 KB of LDS), so the grid is cut to a whole round of the chip (sort_tiles below).
 // (Round 1 paid one global atomicAdd per digit in the decode kernel and another in the scatter: 2 x 16.8 M for
 // 2^20 BLS12-381 G1 points; with 2^15 buckets per window two lanes of a wave rarely meet in a bucket, so wave-level
 // ballot aggregation would save nothing on top of the LDS counters.)
@@ -367,7 +367,8 @@ static __global__ __launch_bounds__(HIST_T) void scatter_lds_kernel(Plan p, int 
                                                                     uint32_t* __restrict__ sorted, int xcd_major) {
     __shared__ uint32_t cur[HIST_MAX_NB];
     // window-minor: workgroups go round-robin over the 8 XCDs, so with 8 windows (the 2^20-point BLS12-381 G1 MSM) every
-    // window's slice of `sorted` is written through ONE L2, where the 4-byte stores of a line can meet
+    // window's slice of `sorted` is written through ONE L2, where the 4-byte stores of a line can meet (by itself no
+    // different, 223 against 227 us; it is what lets a scatter in sweeps gain anything: profiles/r06_msm_scatter_sweeps.txt)
     const int w = xcd_major ? blockIdx.x % p.nwin : blockIdx.x / tiles, tile = xcd_major ? blockIdx.x / p.nwin : blockIdx.x % tiles;
     const uint32_t* row = before + ((size_t)w * tiles + tile) * p.nb;
     const uint32_t* first = offs + (size_t)w * p.nb;
@@ -523,9 +524,10 @@ inline bool sort_two_pass(const Plan& p, size_t ne) {
     return !off && p.nb >= 8192 && p.nb / P2_FB <= P2_MAXCB && ne >= (size_t(1) << 19) && ne <= (size_t(1) << 23);
 }
 
-// Tiles per window: as many workgroups as fill `rounds` whole rounds of the chip (rounds 1-5 aimed at "about two per CU"
-// and got 288 workgroups for the 2^20-point BLS12-381 G1 MSM: a full round and an eighth of one, i.e. two), a tile of at
-// least two points per bucket (the per-tile flush is per bucket).  KYB_MSM_SORT_TILES forces a count (A/B runs).
+// Tiles per window of the one-pass sort: at most ONE round of the chip's CUs in all (a workgroup holds 128 KB of LDS;
+// rounds 1-5 aimed at "about two per CU" and, for 17 windows of Ed25519 scalars, got 272 workgroups: a full round and a
+// sixteenth of one, i.e. two), a tile of at least two points per bucket (the per-tile flush is per bucket).
+// KYB_MSM_SORT_TILES forces a count (A/B runs: 14 .. 56 tiles all within 1 % for the 2^20-point BLS12-381 G1 MSM).
 inline int sort_tiles(int num_cu, int nwin, size_t ne, int nb) {
     static const int forced = [] {
         const char* e = getenv("KYB_MSM_SORT_TILES");
@@ -700,8 +702,8 @@ __global__ __launch_bounds__(64, KYB_MSM_ACC_WAVES) void accumulate_kernel(size_
 
 // bucket b = sum of its 2 .. LONG_PIECES pieces, for the buckets of joinlist (a lone piece was stored as the bucket by
 // accumulate_kernel, an empty bucket by subcount_kernel, long ones are left to bucket_long_kernel).  Grid-stride over the
-// list: for uniform scalars it is empty and the kernel is a launch (a lane per bucket cost 74 us of copying, then 42 us of
-// finding out that there was nothing to do: 4 096 waves, each with its scratch to set up).
+// list.  One lane per join: the Weierstrass adapters take bucket_coop_kernel below instead (a one-lane addition is 45 us
+// of latency, and that -- not the copying of 262 144 lone pieces -- was most of this stage's 74 us).
 template <class A>
 __global__ __launch_bounds__(64, 2) void bucket_kernel(const uint32_t* __restrict__ nlong, const uint32_t* __restrict__ joinlist,
                                                     const uint32_t* __restrict__ suboffs,
@@ -1015,8 +1017,9 @@ __global__ __launch_bounds__(64, 2) void bucket_coop_kernel(const uint32_t* __re
 // one addition deep like the plain tree.  A launch consumes log2(FG) bits of j; its D rows join the plain rows (summed
 // as they are by the next launch) and its A row is the bits row of the next launch.  Rows: [0, nplain) plain,
 // [nplain, nplain + nbits) bits; out rows: the plain ones in place, D of bits row w and bit m < lb_out (the bits the chunk
-// numbers still have) at nplain + w lb_out + m, the A rows behind them.  What is left for the doubling chains of final_rows_kernel is 2^(c w) W_w and 2^(c w + tz + k) D_k(w):
-// one wave each, all at once -- no addition waits for a doubling any more.
+// numbers still have) at nplain + w lb_out + m, the A rows behind them.  What is left for the doubling chains of
+// final_rows_kernel is 2^(c w) W_w and 2^(c w + tz + k) D_k(w): one wave each, all at once -- no addition waits for a
+// doubling any more.
 template <class A>
 constexpr int fold_bits() {
     return fold_groups<A>() == 64 ? 6 : 5;
