@@ -20,9 +20,10 @@
 //   4 reduce    : per window, chunks of buckets -> sum_b b * B_b by running sums; Weierstrass curves: FOUR lanes per
 //                 chunk cooperating through LDS slots (reduce_coop_kernel), others: one lane per chunk
 //   5 fold+final: chunk partials are folded 32 / 64 at a time as trees, then the window sums are shifted by 2^(c w)
-//                 (3 - 4 lanes per point share the products of a doubling), added and encoded.  BLS12-381 G1 (the split
-//                 tail): the chunks keep their lo * run apart, the fold tree yields the bit sums D_k, and every term
-//                 2^(c w) W_w, 2^(c w + tz + k) D_k(w) has a limb-per-lane doubling chain of its own (rowfp.cuh).
+//                 (3 - 4 lanes per point share the products of a doubling), added and encoded.  The Weierstrass curves
+//                 (the split tail): the chunks keep their lo * run apart, the fold tree yields the bit sums D_k, and every
+//                 term 2^(c w) W_w, 2^(c w + tz + k) D_k(w) has a doubling chain of its own -- limb-per-lane rows
+//                 (rowfp.cuh) on BLS12-381 G1, three cooperating lanes elsewhere.
 //                 If any input failed to decode the output is all-zero bytes.
 // Sorting instead of atomics on ~150-byte points: the only atomics are 32-bit counters.
 //
@@ -1125,6 +1126,66 @@ __global__ __launch_bounds__(FINAL_T) void final_kernel(Plan p, const typename A
     }
 }
 
+// Doublings of chain b of the split tail.  Chain b < nwin: window b's sum, c b doublings.  The rows behind them are D_k of
+// window w in the order the tree produced them (lb0 bits per window from the reduce kernel, then per fold launch the bits
+// that are left, lb at most), doubled c w + tz + k times.
+__device__ __forceinline__ int tail_chain_doublings(const Plan& p, int b, int lb0, int lb, int tz, int chbits) {
+    if (b < p.nwin) return b * p.c;
+    int q = b - p.nwin, ww, k;
+    if (q < p.nwin * lb0) {
+        ww = q / lb0;
+        k = q - ww * lb0;
+    } else {
+        q -= p.nwin * lb0;
+        int k0 = lb0, lbl = chbits - k0 < lb ? chbits - k0 : lb;  // a launch emits the bits that are left, lb at most
+        while (q >= p.nwin * lbl) {
+            q -= p.nwin * lbl;
+            k0 += lbl;
+            lbl = chbits - k0 < lb ? chbits - k0 : lb;
+        }
+        ww = q / lbl;
+        k = k0 + (q - ww * lbl);
+    }
+    return ww * p.c + tz + k;
+}
+
+// The split tail's doubling chains for adapters without the limb-per-lane rows (BLS12-381 G2, the BN curves): final_kernel's
+// cooperative doubling (COOP lanes per chain), one WAVE per workgroup (21 chains of three lanes: its barriers stay inside
+// the wave -- three waves per workgroup measured 3.69 against 2.59 ms for the 269 doublings of a 2^18-point G2 MSM), as
+// many workgroups as the terms need.  A chain is as long as final_kernel's longest was -- what the split buys these
+// curves is the reduce kernel's 24 - 28 steps.
+constexpr int CHAINS_T = 64;
+template <class A>
+__global__ __launch_bounds__(CHAINS_T) void final_chains_kernel(Plan p, const typename A::Acc* __restrict__ src,
+                                                           typename A::Acc* __restrict__ shifted, int nchains, int lb0, int lb,
+                                                           int tz, int chbits) {
+    constexpr int L = Coop<A>::value, T = CHAINS_T, CPB = T / L;
+    __shared__ typename A::Field sh[T + L];
+    __shared__ int longest;
+    const int t = threadIdx.x, ci = t / L, r = t - ci * L;
+    const int b = blockIdx.x * CPB + ci;
+    const bool live = ci < CPB && b < nchains;
+    typename A::Acc s;
+    A::identity(s);
+    int ndbl = 0;
+    if (live) {
+        s = src[b];
+        ndbl = tail_chain_doublings(p, b, lb0, lb, tz, chbits);
+    }
+    if (t == 0) longest = 0;
+    __syncthreads();
+    atomicMax(&longest, ndbl);
+    __syncthreads();
+    const int total = longest;
+#pragma unroll 1
+    for (int k = 0; k < total; k++) {
+        typename A::Acc d = s;
+        A::dbl_coop(d, r, sh + ci * L);  // (a thread past the last whole chain has slots of its own: sh[T + L])
+        if (k < ndbl) s = d;
+    }
+    if (live && r == 0) shifted[b] = s;
+}
+
 // ---- The doubling chains of the final stage with ONE LIMB PER LANE (rowfp.cuh; adapters with ROW_FINAL: a base field of
 // 13 x 30-bit limbs) -- round 6.  final_kernel above holds all windows in one wave, three lanes per window, and every
 // doubling costs it three 539-instruction field products in a row: 770 us for the 128 doublings of a 2^20-point G1 MSM,
@@ -1140,9 +1201,6 @@ struct HasRowFinal<A, decltype((void)A::ROW_FINAL)> {
     static constexpr bool value = A::ROW_FINAL != 0;
 };
 #if defined(KYB_ROWFP_INCLUDED)
-// Chain b < nwin: window b's sum, c b doublings.  Split tail: the rows behind them are D_k of window w in the order the tree
-// produced them (lb0 bits per window from the reduce kernel, then per fold launch the bits that are left, lb at most),
-// doubled c w + tz + k times.
 template <class A>
 __global__ __launch_bounds__(64) void final_rows_kernel(Plan p, const typename A::Acc* __restrict__ wsum,
                                                         typename A::Acc* __restrict__ shifted, int lb0, int lb, int tz, int chbits) {
@@ -1150,25 +1208,7 @@ __global__ __launch_bounds__(64) void final_rows_kernel(Plan p, const typename A
     using namespace rowfp;
     __shared__ uint32_t limbs[3][ROW];
     const int w = blockIdx.x;
-    int ndbl = w * p.c;
-    if (w >= p.nwin) {  // lb0 bits from the reduce kernel's own tree come first, lb per fold launch after them
-        int q = w - p.nwin, ww, k;
-        if (q < p.nwin * lb0) {
-            ww = q / lb0;
-            k = q - ww * lb0;
-        } else {
-            q -= p.nwin * lb0;
-            int k0 = lb0, lbl = chbits - k0 < lb ? chbits - k0 : lb;  // a launch emits the bits that are left, lb at most
-            while (q >= p.nwin * lbl) {
-                q -= p.nwin * lbl;
-                k0 += lbl;
-                lbl = chbits - k0 < lb ? chbits - k0 : lb;
-            }
-            ww = q / lbl;
-            k = k0 + (q - ww * lbl);
-        }
-        ndbl = ww * p.c + tz + k;
-    }
+    const int ndbl = tail_chain_doublings(p, w, lb0, lb, tz, chbits);
     const auto cx = make_ctx<C>();
     const auto dc = make_dbl_consts<C>();
     const V32 row = row_of_lane();
@@ -1193,14 +1233,10 @@ __global__ __launch_bounds__(64) void final_rows_kernel(Plan p, const typename A
 #endif
 
 // the split tail (reduce_coop_kernel's runs, tree_fold_bits_coop_kernel, one doubling chain per term) wants the cooperative
-// slots and the limb-per-lane doubling chains: BLS12-381 G1
+// slots and a doubling chain that is not one lane's: the limb-per-lane rows (BLS12-381 G1) or the adapter's dbl_coop
 template <class A>
 constexpr bool split_tail() {
-#if defined(KYB_ROWFP_INCLUDED)
-    return HasCoopSlots<A>::value && HasRowFinal<A>::value;
-#else
-    return false;
-#endif
+    return HasCoopSlots<A>::value && (HasRowFinal<A>::value || Coop<A>::value > 1);
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
@@ -1406,7 +1442,6 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
         }();
         if (!lane_tail) {
             constexpr int FG = fold_groups<A>();
-#if defined(KYB_ROWFP_INCLUDED)
             if constexpr (split_tail<A>()) {
                 // KYB_MSM_REDUCE=mul: every chunk multiplies its own lo * run (rounds 3-5); KYB_MSM_FINAL=lanes implies it
                 static const bool split = [] {
@@ -1441,8 +1476,19 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
                         ncur = nout;
                     }
                     // nplain terms now: the W sums and every D_k, each with a doubling chain of its own
-                    hipLaunchKernelGGL(final_rows_kernel<A>, dim3((unsigned)nplain), dim3(64), 0, st, pr, (const typename A::Acc*)cur, shift, lb0,
-                                       LB, tz, chbits);
+                    bool rows_done = false;
+#if defined(KYB_ROWFP_INCLUDED)
+                    if constexpr (HasRowFinal<A>::value) {
+                        hipLaunchKernelGGL(final_rows_kernel<A>, dim3((unsigned)nplain), dim3(64), 0, st, pr, (const typename A::Acc*)cur, shift,
+                                           lb0, LB, tz, chbits);
+                        rows_done = true;
+                    }
+#endif
+                    if (!rows_done) {
+                        constexpr int CPB = CHAINS_T / Coop<A>::value;
+                        hipLaunchKernelGGL(final_chains_kernel<A>, dim3((unsigned)((nplain + CPB - 1) / CPB)), dim3(CHAINS_T), 0, st, pr,
+                                           (const typename A::Acc*)cur, shift, nplain, lb0, LB, tz, chbits);
+                    }
                     typename A::Acc* a = shift;
                     typename A::Acc* b = shift2;
                     int m = nplain;
@@ -1462,7 +1508,6 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
                     return KYB_OK;
                 }
             }
-#endif
             hipLaunchKernelGGL(reduce_coop_kernel<A>, dim3((unsigned)((nred + 15) / 16)), dim3(64), 0, st, pr, buckets, partial,
                                (typename A::Acc*)nullptr, 0);
             typename A::Acc* cur = partial;
