@@ -278,3 +278,39 @@ def test_msm_at_config_size_against_an_independent_expectation(name, grp, n):
     out, st = msm(dk, bad)
     st = st.cpu().numpy()
     assert st[n - 5] != 0 and not np.delete(st, n - 5).any() and not out.cpu().numpy().any()
+
+
+@pytest.mark.parametrize("name,grp", [("bls12381", 1), ("bn256", 1), ("bls12381", 2)])
+def test_msm_across_the_planner_thresholds(name, grp):
+    """Sizes either side of every switch the MSM planner makes (msm.cuh make_plan / sort_two_pass / the split tail's fused
+    tree levels and fold launches): the window width steps with log2 n, the reduce kernel fuses four tree levels from 16
+    chunks per window, a second fold launch appears from 2^10 chunks, the two-pass sort from 2^19 entries per window.  One
+    set of 2^18 + 7 points h_i G; every size is a prefix, the expectation (sum k_i h_i mod r) G one fixed-base
+    multiplication -- independent of the bucket pipeline."""
+    import importlib
+
+    import torch
+
+    m = importlib.import_module("kyber_amd.pairing." + name)
+    r = m.ORDER
+    nmax = (1 << 18) + 7 if grp == 1 else (1 << 14) + 7
+    tag = ("msm-sizes/%s/%d" % (name, grp)).encode()
+    k, h = _be_scalars_mod(tag + b"/k", nmax, r), _be_scalars_mod(tag + b"/h", nmax, r)
+    k[5] = 0
+    k[6] = np.frombuffer(((1 << 256) - 1).to_bytes(32, "big"), dtype=np.uint8)
+    commit, msm = (m.g1_commit, m.g1_msm) if grp == 1 else (m.g2_commit, m.g2_msm)
+    dk, dh = torch.from_numpy(k).cuda(), torch.from_numpy(h).cuda()
+    P, st = commit(dh)
+    assert not st.any().item()
+    prod = [int.from_bytes(bytes(a), "big") * int.from_bytes(bytes(b), "big") for a, b in zip(k, h)]
+    sizes = [1, 2, 3, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 1000, 1023, 1024, 1025, 4095, 4096, 4097, 8191, 8192,
+             16383, 16384, 16391]
+    if grp == 1:
+        sizes += [32768, 65535, 65536, 65537, 131071, 131072, 131073, 200000, 262143, 262144, 262145, nmax]
+    acc, done = 0, 0
+    for n in sizes:
+        acc = (acc + sum(prod[done:n])) % r
+        done = n
+        exp = bytes(commit(acc.to_bytes(32, "big"))[0][0])
+        out, st = msm(dk[:n], P[:n], m.F_TRUSTED(0))
+        assert not st.any().item() and bytes(out.cpu().numpy()) == exp, (name, grp, n)
