@@ -63,3 +63,37 @@ def test_balanced_halves_fit_eight_windows_for_every_scalar(header):
         assert s1 <= 5 and s2 <= 5  # the kernel makes six
         worst = max(worst, s1, s2)
     assert worst >= 1  # the correction is exercised
+
+
+def test_bls12381_g2_quarters_fit_four_windows_for_every_scalar():
+    """bls12381_msm.hip BlsG2MsmGls::decode_split: k = a0 + a1 |z| + a2 |z|^2 + a3 |z|^3 by long division, the quarters moved
+    into (-|z| / 2, |z| / 2] with carries, the overflow of a3 folded back through |z|^4 = z^2 - 1 (mod r)"""
+    Z = 0xd201000000010000
+    r = Z**4 - Z**2 + 1
+    assert r == 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001  # kilic/scalar.go:11-12
+    H = Z >> 1
+    rng = random.Random(381)
+    ks = [0, 1, r - 1, r, r + 1, (1 << 256) - 1, 1 << 255, Z, Z - 1, Z * Z, Z**3, Z**3 - 1, H, H + 1, Z**3 * 2 + H * Z * Z + H * Z + H + 1]
+    ks += [rng.randrange(1 << 256) for _ in range(20000)] + [rng.randrange(r) for _ in range(20000)]
+    ks += [(1 << 256) - 1 - rng.randrange(1 << 64) for _ in range(2000)]
+    for k in ks:
+        q1, a0 = divmod(k, Z)
+        q2, a1 = divmod(q1, Z)
+        a3, a2 = divmod(q2, Z)
+        assert a3 < 1 << 65
+        A = [a0, a1, a2, a3]
+        for i in range(3):
+            if A[i] > H:
+                A[i] -= Z
+                A[i + 1] += 1
+        a4 = 0
+        for _ in range(4):
+            if A[3] > H:
+                A[3] -= Z
+                a4 += 1
+        assert A[3] <= H and a4 <= 3
+        A[2] += a4
+        A[0] -= a4
+        assert (sum(a * Z**i for i, a in enumerate(A)) - k) % r == 0
+        for a in A:
+            assert abs(a) < 1 << 63 and (abs(a) >> 48) < 1 << 15  # four 16-bit windows, the top one never reaches 2^15
