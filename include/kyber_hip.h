@@ -83,7 +83,8 @@ extern "C" {
 #define KYB_F_SCALAR_BITS(b) ((uint32_t)(b) << 16) /* *_msm only: every scalar is below 2^b (1 <= b <= 256) -- the
                                      128-bit coefficients of sign/bdn (bdn.go:29-63) run half the windows.  Bits at
                                      and above b are IGNORED (the result is sum (k_i mod 2^b) P_i).  BLS12-381 G1,
-                                     which already splits scalars into 127-bit halves, takes no notice. */
+                                     which splits full-length scalars into 127-bit halves, honours it for b <= 160
+                                     (plain windows) and takes no notice above. */
 #define KYB_F_SCALAR_BITS_MASK (0x1ffu << 16)
 #define KYB_F_TRUSTED(i) (0x100u << (i))
 #define KYB_F_TRUSTED_ALL 0xF00u /* the four point arguments of pair_check; calls with fewer point arguments reject the extra bits */

@@ -128,6 +128,31 @@ struct BlsG1Msm : msm::Weierstrass<bls::fp, BlsG1Codec> {
 // 16 window visits instead of 18.  Calls with KYB_F_SCALAR_BITS keep the plain adapter (kyb_bls12381_g2_msm below): a
 // 128-bit coefficient is 9 window visits there, and here its third quarter is 0 or 1 -- a third of all points in ONE
 // bucket (measured: 9.1 against 7.5 ms for 2^18 points).
+// G1 WITHOUT the split, for calls that say their scalars are short (KYB_F_SCALAR_BITS(b), b <= 160: bdn's 128-bit
+// coefficients, sign/bdn/bdn.go:126-161 on a G1 signature scheme).  On halves a 128-bit k is k0 + k1 z^2 with k1 in {0, +-1}:
+// two fifths of all points in ONE bucket of the second half, and the call took LONGER than with full scalars (4.85
+// against 3.83 ms for 2^20 points).  Plain windows: ceil(129 / 16) = 9 visits per point instead of 16, the same tail
+// kernels (limb-per-lane chains, light decode).
+struct BlsG1MsmPlain : msm::Weierstrass<bls::fp, BlsG1Codec> {
+    using Base = msm::Weierstrass<bls::fp, BlsG1Codec>;
+    static constexpr int ROW_FINAL = 1;
+    using RowC = bls::FC;
+    static constexpr int DECODE_WAVES = KYB_BLS_G1_DECODE_WAVES;
+    static constexpr int LIGHT_DECODE_WAVES = 4;
+    __device__ static int decode_split_light(Aff (&a)[1], uint32_t (&k)[1][8], const uint8_t* pt, const uint8_t* scalar) {
+        bls::g1_aff t;
+        const int st = bls::g1_decode_unc_trusted(t, pt);
+        a[0].x = t.x;
+        a[0].y = t.y;
+        a[0].inf = t.inf ? 1u : 0u;
+        Base::scalar_words(k[0], scalar);
+        return st;
+    }
+};
+inline bool bls_g1_msm_plain(uint32_t flags) {
+    const uint32_t want = (flags >> 16) & 0x1ffu;
+    return want != 0 && want <= 160;
+}
 using BlsG2Msm = msm::Weierstrass<bls::fp2, BlsG2Codec>;
 struct BlsG2MsmGls : msm::Weierstrass<bls::fp2, BlsG2Codec> {
     using Base = msm::Weierstrass<bls::fp2, BlsG2Codec>;
@@ -208,6 +233,7 @@ inline bool bls_g2_msm_gls(uint32_t flags) {
 extern "C" {
 int kyb_bls12381_g1_msm(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t out[48], uint8_t* status,
                          uint32_t flags) {
+    if (kyb::bls_g1_msm_plain(flags)) return kyb::msm::run_host<kyb::BlsG1MsmPlain>(n, scalars, points, out, status, flags);
     return kyb::msm::run_host<kyb::BlsG1Msm>(n, scalars, points, out, status, flags);
 }
 int kyb_bls12381_g2_msm(size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t out[96], uint8_t* status,
@@ -219,6 +245,8 @@ int kyb_bls12381_g1_msm_dev(size_t n, const void* d_scalars, const void* d_point
                             uint32_t flags, void* stream) {
     kyb::DeviceCtx* ctx;
     KYB_TRY(kyb::get_ctx(&ctx));
+    if (kyb::bls_g1_msm_plain(flags))
+        return kyb::msm::run<kyb::BlsG1MsmPlain>(ctx, n, d_scalars, d_points, d_out, d_status, (hipStream_t)stream, flags);
     return kyb::msm::run<kyb::BlsG1Msm>(ctx, n, d_scalars, d_points, d_out, d_status, (hipStream_t)stream, flags);
 }
 int kyb_bls12381_g2_msm_dev(size_t n, const void* d_scalars, const void* d_points, void* d_out, void* d_status,

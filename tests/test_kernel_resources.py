@@ -52,15 +52,15 @@ def test_tuned_kernels_keep_their_register_budget():
     assert find(ed, "ed25519_mul_base_uniform_kernel") <= 170
     assert find(ed, "13decode_kernel", "EdMsm") <= 170
     # two waves per SIMD: <= 256
-    assert find(msm, "13decode_kernel", "BlsG1MsmELb0E") <= 256
+    assert find(msm, "13decode_kernel", "_8BlsG1MsmELb0E") <= 256
     # the light decode (vouched-for uncompressed points): four waves per SIMD
-    assert find(msm, "13decode_kernel", "BlsG1MsmELb1E") <= 128
-    assert find(msm, "26tree_fold_bits_coop_kernel", "BlsG1Msm") <= 256
-    assert find(msm, "18bucket_coop_kernel", "BlsG1Msm") <= 256
-    assert find(msm, "17accumulate_kernel", "BlsG1Msm") <= 256
+    assert find(msm, "13decode_kernel", "_8BlsG1MsmELb1E") <= 128
+    assert find(msm, "26tree_fold_bits_coop_kernel", "_8BlsG1MsmE") <= 256
+    assert find(msm, "18bucket_coop_kernel", "_8BlsG1MsmE") <= 256
+    assert find(msm, "17accumulate_kernel", "_8BlsG1MsmE") <= 256
     # the cooperative tail (four lanes per point): twice the lanes of the one-lane kernels, so two waves per SIMD
-    assert find(msm, "18reduce_coop_kernel", "BlsG1Msm") <= 256
-    assert find(msm, "21tree_fold_coop_kernel", "BlsG1Msm") <= 256
+    assert find(msm, "18reduce_coop_kernel", "_8BlsG1MsmE") <= 256
+    assert find(msm, "21tree_fold_coop_kernel", "_8BlsG1MsmE") <= 256
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-readelf")), reason="no llvm-readelf")
