@@ -40,7 +40,7 @@ SOURCES = {
     "mul": [C + "bls12381.hip", C + "bls12381_lvm.cuh", C + "lane_vm.cuh", C + "gen_lane_vm.py", C + "bls12381.cuh", C + "pairing_abi.cuh",
             C + "bls12381_unm2.hip", C + "bls12381_g1split.hip"] + COMMON_PAIRING,
     "mulperlane": [C + "bls12381.hip", C + "bls12381.cuh", C + "pairing_abi.cuh"] + COMMON_PAIRING,
-    "msm_bls": [C + "bls12381_msm.hip", C + "msm.cuh", C + "msm_ws.cuh", C + "coop_slots.cuh", C + "bls12381.cuh", C + "rowfp.cuh"] + COMMON_PAIRING,
+    "msm_bls": [C + "bls12381_msm.hip", C + "bls12381_msm_codec.cuh", C + "msm_adapters.h", C + "msm.cuh", C + "msm_ws.cuh", C + "coop_slots.cuh", C + "bls12381.cuh", C + "rowfp.cuh"] + COMMON_PAIRING,
     "fb": [C + "fixed_base.cuh", C + "bls12381_fb.cuh", C + "pairing_abi.cuh", C + "bls12381_fb.hip", C + "bls12381.cuh", C + "coop_slots.cuh", C + "rowfp.cuh"] + COMMON_PAIRING,
 }
 
