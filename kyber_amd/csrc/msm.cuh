@@ -16,7 +16,7 @@
 //   3 accumulate: one lane per bucket piece (at most twice the mean bucket length; long buckets from skewed digits are
 //                 split) adds its points with mixed additions -- in XYZZ form on the Weierstrass curves.  A bucket's only
 //                 piece is stored as the bucket; buckets of several pieces are joined afterwards (four lanes per bucket on
-//                 the Weierstrass curves)
+//                 the Weierstrass curves; a bucket of many pieces by workgroups of the cooperative fold, in two launches)
 //   4 reduce    : per window, chunks of buckets -> sum_b b * B_b by running sums; Weierstrass curves: FOUR lanes per
 //                 chunk cooperating through LDS slots (reduce_coop_kernel), others: one lane per chunk
 //   5 fold+final: chunk partials are folded 32 / 64 at a time as trees, then the window sums are shifted by 2^(c w)
@@ -411,6 +411,7 @@ static __global__ __launch_bounds__(HIST_T) void scatter_lds_kernel(Plan p, int 
 #endif
 // (tile and staging sizes that leave two workgroups per CU: fine_sort 76 -> 65 us, coarse_scatter 45 -> 38 us against 2^14 / 24 576;
 // a bin of the halves' top window where the density doubles goes the direct way)
+constexpr int P2_GIANT = 131072, P2_GS = 64;  // giant bins (giant_*_kernel below): entries from which, slices per bin
 constexpr int P2_FB = 256, P2_T1 = KYB_MSM_P2_T1, P2_MAXCB = 128, P2_LMAX = KYB_MSM_P2_LMAX, P2_T = 1024;
 static __global__ __launch_bounds__(P2_T) void coarse_hist_kernel(Plan p, int tiles1, int cb, const int32_t* __restrict__ digits,
                                                                   uint32_t* __restrict__ ch) {
@@ -475,11 +476,17 @@ static __global__ __launch_bounds__(P2_T) void coarse_scatter_kernel(Plan p, int
 }
 static __global__ __launch_bounds__(P2_T) void fine_sort_kernel(int tiles1, const uint32_t* __restrict__ offs1,
                                                                 const uint32_t* __restrict__ mid, uint32_t* __restrict__ offs,
-                                                                uint32_t* __restrict__ sorted) {
+                                                                uint32_t* __restrict__ sorted, uint32_t* __restrict__ ngiant,
+                                                                uint32_t* __restrict__ giant) {
     __shared__ uint32_t stage[P2_LMAX];
     __shared__ uint32_t cnt[P2_FB], pre[P2_FB];
     const size_t g = blockIdx.x;  // window * bins + bin
     const uint32_t lo = offs1[g * tiles1], hi = offs1[(g + 1) * tiles1], len = hi - lo;
+    if (g == gridDim.x - 1 && threadIdx.x == 0) offs[(size_t)gridDim.x * P2_FB] = hi;
+    if (len > (uint32_t)P2_GIANT) {  // a giant bin (one bucket with a large share of all points): giant_*_kernel, several workgroups
+        if (threadIdx.x == 0) giant[atomicAdd(ngiant, 1u)] = (uint32_t)g;
+        return;
+    }
     if (threadIdx.x < P2_FB) cnt[threadIdx.x] = 0;
     __syncthreads();
     for (uint32_t i = lo + threadIdx.x; i < hi; i += P2_T) atomicAdd(&cnt[mid[i] >> 24], 1u);
@@ -499,7 +506,6 @@ static __global__ __launch_bounds__(P2_T) void fine_sort_kernel(int tiles1, cons
         pre[threadIdx.x] = first;
         cnt[threadIdx.x] = 0;  // the cursors now
     }
-    if (g == gridDim.x - 1 && threadIdx.x == 0) offs[(size_t)gridDim.x * P2_FB] = hi;
     __syncthreads();
     if (len <= (uint32_t)P2_LMAX) {
         for (uint32_t i = lo + threadIdx.x; i < hi; i += P2_T) {
@@ -513,6 +519,82 @@ static __global__ __launch_bounds__(P2_T) void fine_sort_kernel(int tiles1, cons
             const uint32_t x = mid[i], f = x >> 24;
             sorted[lo + pre[f] + atomicAdd(&cnt[f], 1u)] = (x & 0x7fffffu) | ((x >> 23) & 1u) << 31;
         }
+    }
+}
+// A GIANT bin (more than P2_GIANT entries: one bucket holding a large share of all points -- the carry-only top window of
+// short scalars, equal scalars) would keep ONE workgroup of fine_sort_kernel busy for a millisecond.  It is cut into
+// P2_GS slices: giant_count_kernel counts every slice's 256 buckets, giant_offs_kernel turns the counts into the bin's
+// offs[] and every (slice, bucket)'s first slot, giant_scatter_kernel places the slices.  All three read the list of giant
+// bins fine_sort_kernel left on the device and are a launch when it is empty.
+static __global__ __launch_bounds__(P2_T) void giant_count_kernel(int tiles1, const uint32_t* __restrict__ offs1,
+                                                                  const uint32_t* __restrict__ mid,
+                                                                  const uint32_t* __restrict__ ngiant,
+                                                                  const uint32_t* __restrict__ giant, uint32_t* __restrict__ gcnt) {
+    __shared__ uint32_t cnt[P2_FB];
+    const uint32_t ng = ngiant[0];
+#pragma unroll 1
+    for (uint32_t gi = blockIdx.y; gi < ng; gi += gridDim.y) {
+        const size_t g = giant[gi];
+        const uint32_t lo = offs1[g * tiles1], hi = offs1[(g + 1) * tiles1], per = (hi - lo + P2_GS - 1) / P2_GS;
+        const uint32_t a = lo + blockIdx.x * per < hi ? lo + blockIdx.x * per : hi, b = a + per < hi ? a + per : hi;
+        if (threadIdx.x < P2_FB) cnt[threadIdx.x] = 0;
+        __syncthreads();
+        for (uint32_t i = a + threadIdx.x; i < b; i += P2_T) atomicAdd(&cnt[mid[i] >> 24], 1u);
+        __syncthreads();
+        if (threadIdx.x < P2_FB) gcnt[((size_t)gi * P2_GS + blockIdx.x) * P2_FB + threadIdx.x] = cnt[threadIdx.x];
+        __syncthreads();
+    }
+}
+static __global__ __launch_bounds__(P2_FB) void giant_offs_kernel(int tiles1, const uint32_t* __restrict__ offs1,
+                                                                  const uint32_t* __restrict__ ngiant,
+                                                                  const uint32_t* __restrict__ giant, uint32_t* __restrict__ gcnt,
+                                                                  uint32_t* __restrict__ offs) {
+    __shared__ uint32_t pre[P2_FB];
+    const uint32_t ng = ngiant[0];
+#pragma unroll 1
+    for (uint32_t gi = blockIdx.x; gi < ng; gi += gridDim.x) {
+        const size_t g = giant[gi];
+        const uint32_t lo = offs1[g * tiles1];
+        uint32_t* col = gcnt + (size_t)gi * P2_GS * P2_FB + threadIdx.x;  // bucket threadIdx.x, slice-major
+        uint32_t tot = 0;
+        for (int sl = 0; sl < P2_GS; sl++) {  // within the bucket: the slices in order
+            const uint32_t v = col[(size_t)sl * P2_FB];
+            col[(size_t)sl * P2_FB] = tot;
+            tot += v;
+        }
+        pre[threadIdx.x] = tot;
+        __syncthreads();
+        for (int off = 1; off < P2_FB; off <<= 1) {
+            const uint32_t add = (int)threadIdx.x >= off ? pre[threadIdx.x - off] : 0u;
+            __syncthreads();
+            pre[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const uint32_t first = lo + pre[threadIdx.x] - tot;
+        offs[g * P2_FB + threadIdx.x] = first;
+        for (int sl = 0; sl < P2_GS; sl++) col[(size_t)sl * P2_FB] += first;  // first slot of (slice, bucket)
+        __syncthreads();
+    }
+}
+static __global__ __launch_bounds__(P2_T) void giant_scatter_kernel(int tiles1, const uint32_t* __restrict__ offs1,
+                                                                    const uint32_t* __restrict__ mid,
+                                                                    const uint32_t* __restrict__ ngiant,
+                                                                    const uint32_t* __restrict__ giant,
+                                                                    const uint32_t* __restrict__ gcnt, uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t cur[P2_FB];
+    const uint32_t ng = ngiant[0];
+#pragma unroll 1
+    for (uint32_t gi = blockIdx.y; gi < ng; gi += gridDim.y) {
+        const size_t g = giant[gi];
+        const uint32_t lo = offs1[g * tiles1], hi = offs1[(g + 1) * tiles1], per = (hi - lo + P2_GS - 1) / P2_GS;
+        const uint32_t a = lo + blockIdx.x * per < hi ? lo + blockIdx.x * per : hi, b = a + per < hi ? a + per : hi;
+        if (threadIdx.x < P2_FB) cur[threadIdx.x] = gcnt[((size_t)gi * P2_GS + blockIdx.x) * P2_FB + threadIdx.x];
+        __syncthreads();
+        for (uint32_t i = a + threadIdx.x; i < b; i += P2_T) {
+            const uint32_t x = mid[i];
+            sorted[atomicAdd(&cur[x >> 24], 1u)] = (x & 0x7fffffu) | ((x >> 23) & 1u) << 31;
+        }
+        __syncthreads();
     }
 }
 // the plan takes the two passes: whole bins of 256 buckets, an index that fits 23 bits.  KYB_MSM_SORT=single: never (A/B)
@@ -1008,6 +1090,87 @@ __global__ __launch_bounds__(64, 2) void bucket_coop_kernel(const uint32_t* __re
     }
 }
 
+// Long buckets (more than LONG_PIECES pieces: skewed digits, a carry-only top window, equal scalars) on cooperating lanes,
+// in two launches: bucket_long_kernel above is ONE workgroup per bucket whose threads first add a strided share of the
+// pieces each with the one-lane addition (45 us apiece) -- 840 us for the half-of-all-points bucket of 2^20 short scalars.
+// Launch 1 gives every 2 FG pieces of a long bucket a workgroup of the cooperative fold (the sum of a slice; a bucket of
+// one slice is finished there); launch 2 folds a bucket's slice sums, 2 FG at a time with a running total.
+template <class A>
+__device__ __forceinline__ void coop_fold_range(typename A::Slot* slots, uint32_t* flags, const typename A::Acc* __restrict__ src,
+                                                int count, int gi, int r) {
+    // count <= 2 FG inputs: group gi starts from src[gi] + src[gi + FG]; tree over the groups; the sum ends in group 0's P
+    constexpr int FG = fold_groups<A>(), P = 0, Q = 3, T = 6, NS = T + A::COOP_TEMPS + 3;
+    typename A::Slot* S = slots + gi * NS;
+    if (gi < count) A::slot_load(S, P, src + gi, r);
+    else A::slot_identity(S, P, r);
+    if (gi + FG < count) A::slot_load(S, Q, src + gi + FG, r);
+    else A::slot_identity(S, Q, r);
+    __syncthreads();
+    A::coop_add(S, flags + gi * 2, r, P, Q, T, true);
+#pragma unroll 1
+    for (int off = FG / 2; off >= 1; off >>= 1) {
+        if (gi < off && r < 3) S[Q + r].f = slots[(gi + off) * NS + P + r].f;
+        __syncthreads();
+        A::coop_add(S, flags + gi * 2, r, P, Q, T, gi < off);
+    }
+}
+template <class A>
+__global__ __launch_bounds__(4 * fold_groups<A>(), 2) void bucket_long_coop1_kernel(const uint32_t* __restrict__ nlong,
+                                                                                 const uint32_t* __restrict__ longlist,
+                                                                                 const uint32_t* __restrict__ suboffs,
+                                                                                 const typename A::Acc* __restrict__ pieces,
+                                                                                 typename A::Acc* __restrict__ lpart,
+                                                                                 typename A::Acc* __restrict__ buckets) {
+    constexpr int FG = fold_groups<A>(), P = 0, T = 6, NS = T + A::COOP_TEMPS + 3, SL = 2 * FG;
+    __shared__ typename A::Slot slots[FG * NS];
+    __shared__ uint32_t flags[FG * 2];
+    const int gi = (int)threadIdx.x >> 2, r = (int)threadIdx.x & 3;
+    const uint32_t cnt = nlong[0];
+#pragma unroll 1
+    for (uint32_t j = blockIdx.y; j < cnt; j += gridDim.y) {
+        const uint32_t b = longlist[j], lo = suboffs[b], np = suboffs[b + 1] - lo, ns = (np + SL - 1) / SL;
+#pragma unroll 1
+        for (uint32_t sl = blockIdx.x; sl < ns; sl += gridDim.x) {
+            const uint32_t left = np - sl * SL;
+            coop_fold_range<A>(slots, flags, pieces + lo + sl * SL, (int)(left < (uint32_t)SL ? left : (uint32_t)SL), gi, r);
+            if (gi == 0) A::slot_store(ns == 1 ? buckets + b : lpart + lo + sl, slots, P, r);
+            __syncthreads();
+        }
+    }
+}
+template <class A>
+__global__ __launch_bounds__(4 * fold_groups<A>(), 2) void bucket_long_coop2_kernel(const uint32_t* __restrict__ nlong,
+                                                                                 const uint32_t* __restrict__ longlist,
+                                                                                 const uint32_t* __restrict__ suboffs,
+                                                                                 const typename A::Acc* __restrict__ lpart,
+                                                                                 typename A::Acc* __restrict__ buckets) {
+    constexpr int FG = fold_groups<A>(), P = 0, Q = 3, T = 6, TOT = T + A::COOP_TEMPS, NS = TOT + 3, SL = 2 * FG;
+    __shared__ typename A::Slot slots[FG * NS];
+    __shared__ uint32_t flags[FG * 2];
+    const int gi = (int)threadIdx.x >> 2, r = (int)threadIdx.x & 3;
+    typename A::Slot* S = slots + gi * NS;
+    const uint32_t cnt = nlong[0];
+#pragma unroll 1
+    for (uint32_t j = blockIdx.x; j < cnt; j += gridDim.x) {
+        const uint32_t b = longlist[j], lo = suboffs[b], np = suboffs[b + 1] - lo, ns = (np + SL - 1) / SL;
+        if (ns == 1) continue;  // finished by the first launch (uniform)
+#pragma unroll 1
+        for (uint32_t c0 = 0; c0 < ns; c0 += SL) {  // 2 FG slice sums at a time; group 0 keeps the running total
+            const uint32_t left = ns - c0;
+            coop_fold_range<A>(slots, flags, lpart + lo + c0, (int)(left < (uint32_t)SL ? left : (uint32_t)SL), gi, r);
+            if (c0) {
+                if (r < 3) S[Q + r].f = S[TOT + r].f;
+                __syncthreads();
+                A::coop_add(S, flags + gi * 2, r, P, Q, T, gi == 0);
+            }
+            if (r < 3) S[TOT + r].f = S[P + r].f;
+            __syncthreads();
+        }
+        if (gi == 0) A::slot_store(buckets + b, slots, P, r);
+        __syncthreads();
+    }
+}
+
 // The split tail (round 6).  With W_j = sum_{b in chunk j} (b - lo_j + 1) B_b and T_j = sum_{b in chunk j} B_b from
 // reduce_coop_kernel, a window's sum is  sum_j W_j + chunk * sum_j j T_j,  and over the bits of the chunk number
 //     sum_j j T_j = sum_k 2^k D_k,   D_k = sum of T_j over the j whose bit k is set.
@@ -1285,6 +1448,9 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     const size_t o_mid = take(two_pass ? sizeof(uint32_t) * (ne ? ne : 1) * p.nwin : 0);
     const size_t o_ch = take(sizeof(uint32_t) * m1);
     const size_t o_offs1 = take(sizeof(uint32_t) * (m1 + 1));
+    const size_t max_giant = two_pass ? (ne ? ne : 1) * (size_t)p.nwin / P2_GIANT + 1 : 0;  // bins of more than P2_GIANT entries
+    const size_t o_giant = take(sizeof(uint32_t) * max_giant);
+    const size_t o_gcnt = take(sizeof(uint32_t) * max_giant * P2_GS * P2_FB);
     const uint32_t SUB = piece_len(ne ? ne : 1, p.nb);
     const size_t o_lenhist = take(sizeof(uint32_t) * (MAXSUB + 2));
     const size_t o_lencursor = take(sizeof(uint32_t) * (MAXSUB + 2));
@@ -1302,6 +1468,7 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     const size_t o_pdst = take(sizeof(uint32_t) * max_pieces);
     const size_t o_longlist = take(sizeof(uint32_t) * nbk);
     const size_t o_joinlist = take(sizeof(uint32_t) * nbk);
+    const size_t o_lpart = take(HasCoopSlots<A>::value ? sizeof(typename A::Acc) * max_pieces : 0);  // slice sums of long buckets
     const size_t o_buckets = take(sizeof(typename A::Acc) * nbk);
     const int nfold = (p.nchunks + 31) / 32;  // first fold level: 64 (one-lane tail) or 32 / 64 (cooperative tail) partials per output
     size_t n_partial = (size_t)p.nwin * p.nchunks, n_fold = (size_t)p.nwin * nfold, n_chains = (size_t)p.nwin;
@@ -1344,6 +1511,8 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     auto* mid = (uint32_t*)(base + o_mid);
     auto* ch = (uint32_t*)(base + o_ch);
     auto* offs1 = (uint32_t*)(base + o_offs1);
+    auto* giant = (uint32_t*)(base + o_giant);
+    auto* gcnt = (uint32_t*)(base + o_gcnt);
     auto* bad = (uint32_t*)(base + o_bad);
     auto* offs = (uint32_t*)(base + o_offs);
     auto* nsub = (uint32_t*)(base + o_nsub);
@@ -1358,6 +1527,7 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     auto* nlong = (uint32_t*)(base + o_nlong);
     auto* longlist = (uint32_t*)(base + o_longlist);
     auto* joinlist = (uint32_t*)(base + o_joinlist);
+    auto* lpart = (typename A::Acc*)(base + o_lpart);
     auto* buckets = (typename A::Acc*)(base + o_buckets);
     auto* partial = (typename A::Acc*)(base + o_partial);
     auto* winsum = (typename A::Acc*)(base + o_winsum);
@@ -1392,7 +1562,13 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
         hipLaunchKernelGGL(coarse_scatter_kernel, dim3((unsigned)(tiles1 * p.nwin)), dim3(P2_T), 0, st, pr, tiles1, cb, (const int32_t*)digits,
                            (const uint32_t*)ch, (const uint32_t*)offs1, mid);
         hipLaunchKernelGGL(fine_sort_kernel, dim3((unsigned)(p.nwin * cb)), dim3(P2_T), 0, st, tiles1, (const uint32_t*)offs1,
-                           (const uint32_t*)mid, offs, sorted);
+                           (const uint32_t*)mid, offs, sorted, nlong + 2, giant);
+        hipLaunchKernelGGL(giant_count_kernel, dim3(P2_GS, 16), dim3(P2_T), 0, st, tiles1, (const uint32_t*)offs1, (const uint32_t*)mid,
+                           (const uint32_t*)(nlong + 2), (const uint32_t*)giant, gcnt);
+        hipLaunchKernelGGL(giant_offs_kernel, dim3(64), dim3(P2_FB), 0, st, tiles1, (const uint32_t*)offs1, (const uint32_t*)(nlong + 2),
+                           (const uint32_t*)giant, gcnt, offs);
+        hipLaunchKernelGGL(giant_scatter_kernel, dim3(P2_GS, 16), dim3(P2_T), 0, st, tiles1, (const uint32_t*)offs1, (const uint32_t*)mid,
+                           (const uint32_t*)(nlong + 2), (const uint32_t*)giant, (const uint32_t*)gcnt, sorted);
     } else {
     hipLaunchKernelGGL(hist_lds_kernel, dim3(tiles * p.nwin), dim3(HIST_T), 0, st, pr, tiles, (const int32_t*)digits, hist);
     hipLaunchKernelGGL(tile_scan_kernel, dim3((unsigned)((nbk + 255) / 256)), dim3(256), 0, st, nbk, p.nb, tiles, hist, total);
@@ -1431,8 +1607,18 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     if (!coop_join)
     hipLaunchKernelGGL(bucket_kernel<A>, dim3((unsigned)(nbk / 64 < 1024 ? nbk / 64 + 1 : 1024)), dim3(64), 0, st, (const uint32_t*)nlong,
                        (const uint32_t*)joinlist, (const uint32_t*)suboffs, (const typename A::Acc*)pieces, buckets);
+    if (coop_join) {
+        if constexpr (HasCoopSlots<A>::value) {
+            constexpr int FG = fold_groups<A>();
+            hipLaunchKernelGGL(bucket_long_coop1_kernel<A>, dim3(64, 64), dim3(4 * FG), 0, st, (const uint32_t*)nlong, (const uint32_t*)longlist,
+                               (const uint32_t*)suboffs, (const typename A::Acc*)pieces, lpart, buckets);
+            hipLaunchKernelGGL(bucket_long_coop2_kernel<A>, dim3(256), dim3(4 * FG), 0, st, (const uint32_t*)nlong, (const uint32_t*)longlist,
+                               (const uint32_t*)suboffs, (const typename A::Acc*)lpart, buckets);
+        }
+    } else {
     hipLaunchKernelGGL(bucket_long_kernel<A>, dim3(1024), dim3(long_threads<A>()), 0, st, (const uint32_t*)nlong,
                        (const uint32_t*)longlist, (const uint32_t*)suboffs, pieces, buckets);
+    }
     const size_t nred = (size_t)p.nwin * p.nchunks;
     if constexpr (HasCoopSlots<A>::value) {
         // the tail on cooperating lanes (four per point); KYB_MSM_TAIL=lane keeps the one-lane kernels (A/B)

@@ -106,6 +106,33 @@ def msmbig():
     assert not st.any().item() and bytes(out.cpu().numpy()) == want
 
 
+def msmgiant():
+    """2^19 BLS12-381 G1 points with GIANT buckets (msm.cuh giant_*_kernel, bucket_long_coop*_kernel): half of the scalars
+    equal (a bucket of 2^18 entries in every window of both GLV halves), and the same points under 128-bit coefficients
+    with KYB_F_SCALAR_BITS(128) (the plain adapter: its ninth window holds only the recoding's carry)"""
+    import torch
+
+    from kyber_amd.pairing import bls12381 as B
+    from oracle import bls12381 as OB
+
+    rng = random.Random(67)
+    n = 1 << 19
+    hs = [rng.randrange(1, B.ORDER) for _ in range(n)]
+    ks = [rng.randrange(1 << 256) for _ in range(n)]
+    ks[1000:1000 + (n >> 1)] = [ks[1000]] * (n >> 1)
+    g1b = torch.from_numpy(np.frombuffer(B.G1_BASE, dtype=np.uint8).copy()).cuda()
+    unc, st = B._mul(1, torch.from_numpy(_be(hs)).cuda(), g1b, True, B.F_UNCOMPRESSED_OUT)
+    assert not st.any().item()
+    fl = B.F_TRUSTED(0) | B.F_UNCOMPRESSED
+    tot = sum(k * h for k, h in zip(ks, hs)) % B.ORDER
+    out, st = B.g1_msm(torch.from_numpy(_be(ks)).cuda(), unc, fl)
+    assert not st.any().item() and bytes(out.cpu().numpy()) == OB.g1_compress(OB.g1_mul(tot, OB.G1_GEN))
+    k128 = [k & ((1 << 128) - 1) for k in ks]
+    tot = sum(k * h for k, h in zip(k128, hs)) % B.ORDER
+    out, st = B.g1_msm(torch.from_numpy(_be(k128)).cuda(), unc, fl | B.F_SCALAR_BITS(128))
+    assert not st.any().item() and bytes(out.cpu().numpy()) == OB.g1_compress(OB.g1_mul(tot, OB.G1_GEN))
+
+
 def lvm():
     import torch  # noqa: F401
 
@@ -351,5 +378,5 @@ def bnhash():
 BNHASH_DIGEST = "86f1a16dd7b32606"
 
 if __name__ == "__main__":
-    {"bnhash": bnhash, "fb": fb, "msm": msm, "msmbig": msmbig, "lvm": lvm, "bncheck": bncheck, "pipe": pipe, "g1split": g1split, "unmw2": unmw2, "hashw2": hashw2}[sys.argv[1]]()
+    {"bnhash": bnhash, "fb": fb, "msm": msm, "msmbig": msmbig, "msmgiant": msmgiant, "lvm": lvm, "bncheck": bncheck, "pipe": pipe, "g1split": g1split, "unmw2": unmw2, "hashw2": hashw2}[sys.argv[1]]()
     print("switch-probe ok", sys.argv[1])

@@ -21,6 +21,7 @@ CASES = [
     ("msmbig", {}), ("msmbig", {"KYB_MSM_SORT": "single"}), ("msmbig", {"KYB_MSM_REDUCE": "mul"}), ("msmbig", {"KYB_MSM_REDUCE": "nofuse"}),
     ("msmbig", {"KYB_MSM_JOIN": "lane"}), ("msmbig", {"KYB_MSM_DECODE": "full"}), ("msmbig", {"KYB_MSM_FINAL": "lanes"}),
     ("msm", {"KYB_MSM_REDUCE": "mul"}), ("msm", {"KYB_MSM_REDUCE": "nofuse"}), ("msm", {"KYB_MSM_JOIN": "lane"}),
+    ("msmgiant", {}), ("msmgiant", {"KYB_MSM_JOIN": "lane"}), ("msmgiant", {"KYB_MSM_SORT": "single"}),  # giant buckets
     ("msm", {"KYB_BN_MSM_GLV": "0"}),  # the BN G1 MSM on plain windows instead of balanced GLV halves
     ("msm", {"KYB_BLS_G2_MSM_GLS": "0"}),  # the BLS12-381 G2 MSM on plain windows instead of balanced GLS quarters
     ("bnhash", {}), ("bnhash", {"KYB_BN_HASH_QUEUE": "0"}), ("bnhash", {"KYB_BN_HASH_HQ": "512"}),
