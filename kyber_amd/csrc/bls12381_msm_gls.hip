@@ -25,6 +25,14 @@ struct BlsG2MsmGls : msm::Weierstrass<bls::fp2, BlsG2Codec> {
         const int st = Base::decode(a[0], pt, flags);
         uint32_t kk[8];
         Base::scalar_words(kk, scalar);
+        const int want = (int)((flags >> 16) & 0x1ffu);  // KYB_F_SCALAR_BITS(b): the bits from b up are ignored
+        if (want && want < 256) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int lo = 32 * i;
+                kk[i] &= want >= lo + 32 ? 0xffffffffu : (want > lo ? (1u << (want - lo)) - 1u : 0u);
+            }
+        }
         uint32_t q1[8], q2[8], q3[8], r0[2], r1[2], r2[2];
         bls::divmod_z<2>(q1, r0, kk);
         bls::divmod_z<2>(q2, r1, q1);

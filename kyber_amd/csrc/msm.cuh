@@ -1106,9 +1106,11 @@ __device__ __forceinline__ void coop_fold_range(typename A::Slot* slots, uint32_
     if (gi + FG < count) A::slot_load(S, Q, src + gi + FG, r);
     else A::slot_identity(S, Q, r);
     __syncthreads();
-    A::coop_add(S, flags + gi * 2, r, P, Q, T, true);
+    if (count > FG) A::coop_add(S, flags + gi * 2, r, P, Q, T, true);  // (uniform)
+    int top = FG / 2;
+    while (top >= 1 && top >= count) top >>= 1;  // levels whose partners would all be identities are skipped
 #pragma unroll 1
-    for (int off = FG / 2; off >= 1; off >>= 1) {
+    for (int off = top; off >= 1; off >>= 1) {
         if (gi < off && r < 3) S[Q + r].f = slots[(gi + off) * NS + P + r].f;
         __syncthreads();
         A::coop_add(S, flags + gi * 2, r, P, Q, T, gi < off);
@@ -1126,11 +1128,15 @@ __global__ __launch_bounds__(4 * fold_groups<A>(), 2) void bucket_long_coop1_ker
     __shared__ uint32_t flags[FG * 2];
     const int gi = (int)threadIdx.x >> 2, r = (int)threadIdx.x & 3;
     const uint32_t cnt = nlong[0];
+    // work item t = (long bucket t mod cnt, slices t / cnt, + 32, ...): many buckets of one slice and one bucket of many slices
+    // both spread over the grid (a grid of (slices, buckets) left 512 one-slice buckets to 64 rows, eight in a row each)
+    constexpr uint32_t VS = 32;
 #pragma unroll 1
-    for (uint32_t j = blockIdx.y; j < cnt; j += gridDim.y) {
+    for (size_t t = blockIdx.x; t < (size_t)cnt * VS; t += gridDim.x) {
+        const uint32_t j = (uint32_t)(t % cnt), s0 = (uint32_t)(t / cnt);  // first slices first: consecutive workgroups, consecutive buckets
         const uint32_t b = longlist[j], lo = suboffs[b], np = suboffs[b + 1] - lo, ns = (np + SL - 1) / SL;
 #pragma unroll 1
-        for (uint32_t sl = blockIdx.x; sl < ns; sl += gridDim.x) {
+        for (uint32_t sl = s0; sl < ns; sl += VS) {
             const uint32_t left = np - sl * SL;
             coop_fold_range<A>(slots, flags, pieces + lo + sl * SL, (int)(left < (uint32_t)SL ? left : (uint32_t)SL), gi, r);
             if (gi == 0) A::slot_store(ns == 1 ? buckets + b : lpart + lo + sl, slots, P, r);
@@ -1610,9 +1616,9 @@ int run(DeviceCtx* ctx, size_t n, const void* d_scalars, const void* d_points, v
     if (coop_join) {
         if constexpr (HasCoopSlots<A>::value) {
             constexpr int FG = fold_groups<A>();
-            hipLaunchKernelGGL(bucket_long_coop1_kernel<A>, dim3(64, 64), dim3(4 * FG), 0, st, (const uint32_t*)nlong, (const uint32_t*)longlist,
+            hipLaunchKernelGGL(bucket_long_coop1_kernel<A>, dim3(4096), dim3(4 * FG), 0, st, (const uint32_t*)nlong, (const uint32_t*)longlist,
                                (const uint32_t*)suboffs, (const typename A::Acc*)pieces, lpart, buckets);
-            hipLaunchKernelGGL(bucket_long_coop2_kernel<A>, dim3(256), dim3(4 * FG), 0, st, (const uint32_t*)nlong, (const uint32_t*)longlist,
+            hipLaunchKernelGGL(bucket_long_coop2_kernel<A>, dim3(1024), dim3(4 * FG), 0, st, (const uint32_t*)nlong, (const uint32_t*)longlist,
                                (const uint32_t*)suboffs, (const typename A::Acc*)lpart, buckets);
         }
     } else {
