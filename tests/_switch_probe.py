@@ -133,6 +133,30 @@ def msmgiant():
     assert not st.any().item() and bytes(out.cpu().numpy()) == OB.g1_compress(OB.g1_mul(tot, OB.G1_GEN))
 
 
+def msmg2short():
+    """BLS12-381 G2 MSM under KYB_F_SCALAR_BITS(128) on both adapters (KYB_BLS_G2_MSM_GLS: 0 plain windows, 1 quarters for
+    full-length scalars only, 2 quarters always; default: quarters up to 2^15 points): 900 points with a long bucket, junk
+    above bit 128 ignored, against the oracle's multiplication of the generator"""
+    import torch  # noqa: F401
+
+    from kyber_amd.pairing import bls12381 as B
+    from oracle import bls12381 as OB
+
+    rng = random.Random(68)
+    n = 900
+    hs = [rng.randrange(1, B.ORDER) for _ in range(n)]
+    ks = [rng.randrange(1 << 128) for _ in range(n)]
+    ks[0], ks[1] = 0, (1 << 128) - 1
+    ks[10:310] = [ks[10]] * 300
+    pts, st = B.g2_commit(_be(hs))
+    assert not np.asarray(st).any()
+    want = OB.g2_compress(OB.g2_mul(sum(k * h for k, h in zip(ks, hs)) % B.ORDER, OB.G2_GEN))
+    junk = [k | (rng.randrange(1 << 120) << 130) for k in ks]
+    for kk, fl in ((ks, 0), (ks, B.F_SCALAR_BITS(128)), (junk, B.F_SCALAR_BITS(128)), (ks, B.F_SCALAR_BITS(200))):
+        out, st = B.g2_msm(_be(kk), pts, fl)
+        assert not np.asarray(st).any() and bytes(np.asarray(out)) == want, fl
+
+
 def lvm():
     import torch  # noqa: F401
 
@@ -378,5 +402,5 @@ def bnhash():
 BNHASH_DIGEST = "86f1a16dd7b32606"
 
 if __name__ == "__main__":
-    {"bnhash": bnhash, "fb": fb, "msm": msm, "msmbig": msmbig, "msmgiant": msmgiant, "lvm": lvm, "bncheck": bncheck, "pipe": pipe, "g1split": g1split, "unmw2": unmw2, "hashw2": hashw2}[sys.argv[1]]()
+    {"bnhash": bnhash, "fb": fb, "msm": msm, "msmbig": msmbig, "msmgiant": msmgiant, "msmg2short": msmg2short, "lvm": lvm, "bncheck": bncheck, "pipe": pipe, "g1split": g1split, "unmw2": unmw2, "hashw2": hashw2}[sys.argv[1]]()
     print("switch-probe ok", sys.argv[1])

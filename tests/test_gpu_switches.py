@@ -24,6 +24,8 @@ CASES = [
     ("msmgiant", {}), ("msmgiant", {"KYB_MSM_JOIN": "lane"}), ("msmgiant", {"KYB_MSM_SORT": "single"}),  # giant buckets
     ("msm", {"KYB_BN_MSM_GLV": "0"}),  # the BN G1 MSM on plain windows instead of balanced GLV halves
     ("msm", {"KYB_BLS_G2_MSM_GLS": "0"}),  # the BLS12-381 G2 MSM on plain windows instead of balanced GLS quarters
+    ("msmg2short", {}), ("msmg2short", {"KYB_BLS_G2_MSM_GLS": "0"}), ("msmg2short", {"KYB_BLS_G2_MSM_GLS": "1"}),
+    ("msmg2short", {"KYB_BLS_G2_MSM_GLS": "2"}),  # short scalars (KYB_F_SCALAR_BITS) on either G2 adapter
     ("bnhash", {}), ("bnhash", {"KYB_BN_HASH_QUEUE": "0"}), ("bnhash", {"KYB_BN_HASH_HQ": "512"}),
     ("pipe", {}), ("pipe", {"KYB_PIPE_CHUNK": "4096", "KYB_PIPE_STREAMS": "1"}), ("pipe", {"KYB_PIPE_CHUNK": "4096", "KYB_PIPE_STREAMS": "3"}),
     ("unmw2", {}), ("unmw2", {"KYB_UNM_W2": "0"}), ("hashw2", {}), ("hashw2", {"KYB_UNM_W2": "0"}),
