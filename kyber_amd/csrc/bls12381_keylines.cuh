@@ -155,12 +155,44 @@ struct KeyLinesMem {  // 35 KB of LDS (device) for the per-step values the secon
         c3[KEYLINE_STEPS][2][rowfp::ROW];
     uint32_t fin[4][rowfp::ROW];
     uint32_t inv[2][12];
+    uint32_t tw[6][12];  // the walk's end T = |z| q, homogeneous (X, Y, Z), packed words (x0, x1, y0, y1, z0, z1)
     uint32_t ok;
 };
+// The r-torsion rule read off the walk's end (round 6): psi(q) = [z] q, z < 0, i.e. T = |z| q = -psi(q) (g2_in_subgroup's
+// test, bls12381.cuh -- whose own 63 doublings and 5 additions in one lane the walk has just done on the rows).  A walk
+// that degenerated (T = +-q at an addition step, a doubled 2-torsion point: only off the subgroup) ends with Z = 0.
+KYB_HD bool g2_walk_end_is_minus_psi(const uint32_t (*tw)[12], const uint32_t* qx0, const uint32_t* qx1, const uint32_t* qy0,
+                                      const uint32_t* qy1) {
+    fp2 x, y, X, Y, Z, cx, cy, px, py, l, r;
+#pragma unroll
+    for (int w = 0; w < 12; w++) {
+        x.c0.v[w] = qx0[w];
+        x.c1.v[w] = qx1[w];
+        y.c0.v[w] = qy0[w];
+        y.c1.v[w] = qy1[w];
+        X.c0.v[w] = tw[0][w];
+        X.c1.v[w] = tw[1][w];
+        Y.c0.v[w] = tw[2][w];
+        Y.c1.v[w] = tw[3][w];
+        Z.c0.v[w] = tw[4][w];
+        Z.c1.v[w] = tw[5][w];
+    }
+    fp2_load_const<TC>(cx, CC::PSI_CX);
+    fp2_load_const<TC>(cy, CC::PSI_CY);
+    fp2_conj(px, x);
+    fp2_mul_c(px, px, cx);
+    fp2_conj(py, y);
+    fp2_mul_c(py, py, cy);
+    fp2_neg(py, py);
+    fp2_mul_c(l, px, Z);
+    fp2_mul_c(r, py, Z);
+    return fp2_eq(l, X) & fp2_eq(r, Y) & !fp2_is_zero(Z);
+}
 // q: a finite affine point of the twist, packed words qx0, qx1, qy0, qy1 (Montgomery form).  Every lane of the (one-wave)
-// workgroup calls it; out as g2_key_lines.  Returns false (in every lane) when some l0 vanished.
+// workgroup calls it; out as g2_key_lines.  Returns false (in every lane) when some l0 vanished -- or, with member_test, when
+// the point fails the r-torsion rule at the walk's end (before the second pass: nothing is written to out then).
 KYB_ROW bool g2_key_lines_rows(KeyLinesMem& m, uint32_t (*out)[4][12], const uint32_t* qx0, const uint32_t* qx1, const uint32_t* qy0,
-                               const uint32_t* qy1) {
+                               const uint32_t* qy1, bool member_test = false) {
     using namespace rowfp;
     using C = FC;
     using E2 = F2<C>;
@@ -206,6 +238,38 @@ KYB_ROW bool g2_key_lines_rows(KeyLinesMem& m, uint32_t (*out)[4][12], const uin
         }
     }
     row_sync();
+    const V32 one = lane_table(K<C>::one_limbs());
+    {  // T = (X, Y, Z) below 2p, then as packed residues (X (5,4), Y (13,12), Z (5,4): all below below_2p's 22p)
+        V32 p0, p1, p2, p3;
+        level4<C>(cx, row, X.c0, one, X.c1, one, Y.c0, one, Y.c1, one, p0, p1, p2, p3);
+        store_row(m.fin[0], p0);
+        store_row(m.fin[1], p1);
+        store_row(m.fin[2], p2);
+        store_row(m.fin[3], p3);
+        row_sync();
+        KYB_ROW_LANES(4) {
+            fp f;
+            finish_limbs<C>(f, m.fin[j_]);
+            for (int w = 0; w < 12; w++) m.tw[j_][w] = f.v[w];
+        }
+        row_sync();
+        level4<C>(cx, row, Z.c0, one, Z.c1, one, Z.c0, one, Z.c1, one, p0, p1, p2, p3);
+        store_row(m.fin[0], p0);
+        store_row(m.fin[1], p1);
+        row_sync();
+        KYB_ROW_LANES(2) {
+            fp f;
+            finish_limbs<C>(f, m.fin[j_]);
+            for (int w = 0; w < 12; w++) m.tw[4 + j_][w] = f.v[w];
+        }
+        row_sync();
+        if (member_test) {  // (uniform)
+            KYB_ROW_LONE { m.ok = g2_walk_end_is_minus_psi(m.tw, qx0, qx1, qy0, qy1) ? 1u : 0u; }
+            row_sync();
+            if (!m.ok) return false;
+            row_sync();  // (m.ok is written again below)
+        }
+    }
     // prefix products of the l0's
     E2 pre = f2_load<C>(m.l0[0]);
     f2_store<C>(m.pre[0], pre);
@@ -217,7 +281,6 @@ KYB_ROW bool g2_key_lines_rows(KeyLinesMem& m, uint32_t (*out)[4][12], const uin
         f2_store<C>(m.pre[j], pre);
     }
     // the one inversion, in the packed form by one lane (zero: some l0 vanished)
-    const V32 one = lane_table(K<C>::one_limbs());
     {
         V32 p0, p1, p2, p3;
         level4<C>(cx, row, pre.c0, one, pre.c1, one, pre.c0, one, pre.c1, one, p0, p1, p2, p3);

@@ -662,6 +662,26 @@ int hh_bls_g2_key_lines_rows(const uint8_t* q96, uint8_t* out, int* overflows) {
     memcpy(out, lines, sizeof lines);
     return 0;
 }
+// the walk with the r-torsion rule read off its end (member_test): an uncompressed key, curve equation checked, subgroup not;
+// 0 = accepted, 65 = rejected; tw = the walk's end T = |z| q (six packed Montgomery residues, valid up to the rejection)
+int hh_bls_g2_key_walk_member(const uint8_t* q192, uint8_t* tw, int* overflows) {
+    bls::g2_aff q;
+    const int st = bls::g2_decode_unc(q, q192, true, false);
+    if (st || q.inf) return st ? st : 64;
+    static uint32_t lines[bls::KEYLINE_STEPS][4][12];
+    static bls::KeyLinesMem mem;
+    rowfp::overflow_count() = 0;
+    const bool ok = bls::g2_key_lines_rows(mem, lines, q.x.c0.v, q.x.c1.v, q.y.c0.v, q.y.c1.v, true);
+    *overflows = rowfp::overflow_count();
+    for (int j = 0; j < 6; j++) {  // out of the Montgomery domain: plain little-endian integers
+        bls::fp f;
+        for (int w = 0; w < 12; w++) f.v[w] = mem.tw[j][w];
+        uint32_t words[12];
+        kyb::fp_to_words<bls::FC>(words, f);
+        memcpy(tw + 48 * j, words, 48);
+    }
+    return ok ? 0 : 65;
+}
 // ---- G1Elt.Mul on four cooperating lanes (bls12381_g1coop.cuh) with four THREADS as the lanes of one group: the whole
 // ladder -- table, 34 windows, the z^2 half from the beta x slots -- against the per-lane routine's answer
 int hh_bls_g1_mul_coop(const uint8_t* k32, const uint8_t* pt, int flags, uint8_t* out) {

@@ -114,6 +114,13 @@ def test_rejected_and_infinite_keys(bls):
         xx += 1
     ok, st = bls.batch_verify_g1_same_key(off, msgs, sigs)
     assert not ok.any() and (st == 2).all()
+    # the rule is read off the key's own line walk (g2_walk_end_is_minus_psi): a key of order 13 -- the walk's point runs
+    # through +-key and infinity on the way -- and such a point plus a good key are outside too
+    o13 = O.g2_mul(O.R * O.H2 // 169, (c, y))
+    assert o13 is not None and O.g2_mul(13, o13) is None
+    for K in (o13, O.g2_add(o13, O.g2_mul(x, O.G2_GEN))):
+        ok, st = bls.batch_verify_g1_same_key(O.g2_compress(K), msgs, sigs)
+        assert not ok.any() and (st == 2).all()
     inf2 = b"\xc0" + bytes(95)
     sigs2 = list(sigs)
     sigs2[4] = b"\xc0" + bytes(47)

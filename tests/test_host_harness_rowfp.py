@@ -172,3 +172,49 @@ def test_key_lines_on_rows_equal_the_lone_lane_walk():
         assert lib.hh_bls_g2_key_lines_rows(key, b, C.byref(ov)) == 0
         assert ov.value == 0
         assert a.raw == b.raw, x
+
+
+def test_r_torsion_rule_read_off_the_walks_end():
+    """g2_key_lines_rows(member_test): the walk's last point is |z| q -- held against the oracle's multiplication -- and
+    g2_walk_end_is_minus_psi on it decides exactly what g2_in_subgroup decides: keys of G2 accepted; curve points off the
+    subgroup (random points of E'(Fp2), a point of order 13, sums of both kinds) rejected"""
+    rng = random.Random(77)
+    lib = H.lib()
+    lib.hh_bls_g2_key_walk_member.restype = C.c_int
+
+    def walk(Q):
+        tw, ov = C.create_string_buffer(6 * 48), C.c_int(-1)
+        rc = lib.hh_bls_g2_key_walk_member(O.g2_serialize_unc(Q), tw, C.byref(ov))
+        assert ov.value == 0
+        v = [int.from_bytes(tw.raw[48 * j:48 * j + 48], "little") for j in range(6)]
+        return rc, ((v[0], v[1]), (v[2], v[3]), (v[4], v[5]))
+
+    def off_subgroup_point():
+        while True:
+            x = (rng.randrange(O.P), rng.randrange(O.P))
+            y = O.f2_sqrt(O.f2_add(O.f2_mul(O.f2_sqr(x), x), (4, 4)))
+            if y is not None:
+                return (x, y)
+
+    for k in (1, 2, O.R - 1, rng.randrange(1, O.R), rng.randrange(1, O.R)):
+        Q = O.g2_mul(k, O.G2_GEN)
+        rc, (X, Y, Z) = walk(Q)
+        assert rc == 0, k
+        zi = O.f2_inv(Z)
+        assert (O.f2_mul(X, zi), O.f2_mul(Y, zi)) == O.g2_mul(O.X_ABS, Q), k
+    W = off_subgroup_point()
+    assert O.g2_on_curve(W) and not O.g2_in_subgroup(W)
+    rc, (X, Y, Z) = walk(W)
+    assert rc == 65
+    zi = O.f2_inv(Z)
+    assert (O.f2_mul(X, zi), O.f2_mul(Y, zi)) == O.g2_mul(O.X_ABS, W)   # the walk itself is exact off the subgroup too
+    assert O.H2 % 169 == 0 and O.H2 % 2197 != 0   # the 13-part of E'(Fp2) is Z/13 x Z/13
+    S = None
+    while S is None:
+        S = O.g2_mul(O.R * O.H2 // 169, off_subgroup_point())            # order 13
+    assert O.g2_mul(13, S) is None
+    assert walk(S)[0] == 65
+    assert walk(O.g2_add(S, O.g2_mul(5, O.G2_GEN)))[0] == 65
+    for _ in range(3):
+        assert walk(off_subgroup_point())[0] == 65
+    assert walk(O.g2_add(O.g2_mul(O.R, off_subgroup_point()), O.g2_mul(7, O.G2_GEN)))[0] == 65  # cofactor part + a key
