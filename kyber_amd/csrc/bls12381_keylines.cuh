@@ -188,6 +188,115 @@ KYB_HD bool g2_walk_end_is_minus_psi(const uint32_t (*tw)[12], const uint32_t* q
     fp2_mul_c(r, py, Z);
     return fp2_eq(l, X) & fp2_eq(r, Y) & !fp2_is_zero(Z);
 }
+// ---- UnmarshalBinary of a COMPRESSED key without the r-torsion rule (g2_decode(a, in, false), bls12381.cuh -- restated here
+// so that the batch kernels' copy keeps its shape) with the square root's two 379-bit powers on the rows: lane 0 parses,
+// forms x^3 + b and its norm; the rows raise it to (p + 1) / 4; lane 0 forms t = (a0 + s) / 2; the rows raise that to
+// (p - 3) / 4; lane 0 finishes as fp2_sqrt_from_norm_root does and picks the sign.  Every lane of the one-wave workgroup
+// calls it.  Returns the status (in every lane); *inf_out for the point at infinity; the point as packed words in qw[4].
+struct KeyDecodeMem {
+    uint32_t tab[15][rowfp::ROW];
+    uint32_t io[12], fin[rowfp::ROW];
+    fp2 x, rhs;
+    fp t;
+    int st, inf, go, sflag;
+};
+KYB_ROW int g2_decode_rows(KeyDecodeMem& m, uint32_t (*qw)[12], int* inf_out, const uint8_t* in) {
+    using namespace rowfp;
+    using C = FC;
+    KYB_ROW_LONE {
+        uint32_t w1[12], w0[12];
+        words_from_be<12>(w1, in);
+        words_from_be<12>(w0, in + 48);
+        const uint32_t top = w1[11] >> 29;
+        const bool c = top & 4, inf = top & 2, s = top & 1;
+        w1[11] &= 0x1fffffffu;
+        uint32_t any = 0;
+        for (int k = 0; k < 12; k++) any |= w1[k] | w0[k];
+        m.inf = 1;
+        m.go = 0;
+        m.sflag = s ? 1 : 0;
+        if (!c) m.st = ST_BAD_POINT;
+        else if (inf) m.st = (s || any) ? ST_BAD_POINT : ST_OK;
+        else if (!fp_words_lt_p<FC>(w1) || !fp_words_lt_p<FC>(w0)) m.st = ST_BAD_POINT;
+        else {
+            fp2 x, rhs, b;
+            fp n, t;
+            fp_from_words<FC>(x.c0, w0);
+            fp_from_words<FC>(x.c1, w1);
+            fp2_load_const<TC>(b, CC::B2);
+            fp2_sqr_c(rhs, x);
+            fp2_mul_c(rhs, rhs, x);
+            fp2_add(rhs, rhs, b);
+            fp_sqr(n, rhs.c0);
+            fp_sqr(t, rhs.c1);
+            fp_add(n, n, t);
+            m.x = x;
+            m.rhs = rhs;
+            for (int k = 0; k < 12; k++) m.io[k] = n.v[k];
+            m.st = ST_OK;
+            m.go = 1;
+        }
+    }
+    row_sync();
+    if (m.go) {  // (uniform)
+        const auto cx = make_ctx<C>();
+        V32 r = below_2p<C>(cx, pow_words<C>(cx, load_packed<C>(m.io), m.tab, FC::SQRT_EXP, FC::SQRT_BITS));
+        store_row(m.fin, r);
+        row_sync();
+        KYB_ROW_LONE {
+            fp s, t, inv2;
+            finish_limbs<C>(s, m.fin);  // a root of the norm if it has one (checked with the final square below)
+            fp_const(inv2, FC::INV2);
+            fp_add(t, m.rhs.c0, s);
+            fp_mul(t, t, inv2);
+            fp_cmov(t, m.rhs.c0, fp_is_zero(m.rhs.c1));
+            m.t = t;
+            for (int k = 0; k < 12; k++) m.io[k] = t.v[k];
+        }
+        row_sync();
+        r = below_2p<C>(cx, pow_words<C>(cx, load_packed<C>(m.io), m.tab, FC::PM3D4, FC::SQRT_BITS));  // t^((p-3)/4)
+        store_row(m.fin, r);
+        row_sync();
+        KYB_ROW_LONE {
+            fp u, c, c2, h, inv2;
+            const fp t = m.t;
+            const fp2 a = m.rhs;
+            finish_limbs<C>(u, m.fin);
+            fp_const(inv2, FC::INV2);
+            fp_mul(c, u, t);  // t^((p+1)/4)
+            fp_sqr(c2, c);
+            const bool qr = fp_eq(c2, t);  // chi(t) = +1 ; otherwise c^2 = -t and 1/c = -u
+            fp_mul(h, a.c1, inv2);
+            fp_mul(h, h, u);  // a1 / (2c) up to the sign chi
+            fp2 y, chk, ny;
+            if (qr) {
+                y.c0 = c;
+                y.c1 = h;
+            } else {
+                fp_neg(y.c0, h);
+                y.c1 = c;
+            }
+            fp2_sqr(chk, y);
+            if (!fp2_eq(chk, a)) {
+                m.st = ST_BAD_POINT;
+            } else {
+                fp2_neg(ny, y);
+                fp2_cmov(y, ny, fp2_is_larger(y) != (m.sflag != 0));
+                for (int k = 0; k < 12; k++) {
+                    qw[0][k] = m.x.c0.v[k];
+                    qw[1][k] = m.x.c1.v[k];
+                    qw[2][k] = y.c0.v[k];
+                    qw[3][k] = y.c1.v[k];
+                }
+                m.inf = 0;
+            }
+        }
+        row_sync();
+    }
+    *inf_out = m.inf;
+    return m.st;
+}
+
 // q: a finite affine point of the twist, packed words qx0, qx1, qy0, qy1 (Montgomery form).  Every lane of the (one-wave)
 // workgroup calls it; out as g2_key_lines.  Returns false (in every lane) when some l0 vanished -- or, with member_test, when
 // the point fails the r-torsion rule at the walk's end (before the second pass: nothing is written to out then).

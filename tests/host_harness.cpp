@@ -682,6 +682,24 @@ int hh_bls_g2_key_walk_member(const uint8_t* q192, uint8_t* tw, int* overflows) 
     }
     return ok ? 0 : 65;
 }
+// a compressed key's UnmarshalBinary without the r-torsion rule, the square root's two powers on the rows (g2_decode_rows);
+// returns the status; out = x.c0, x.c1, y.c0, y.c1 as plain little-endian integers (when accepted and finite)
+int hh_bls_g2_decode_rows(const uint8_t* in96, uint8_t* out, int* inf, int* overflows) {
+    static bls::KeyDecodeMem mem;
+    static uint32_t qw[4][12];
+    rowfp::overflow_count() = 0;
+    memset(qw, 0, sizeof qw);
+    const int st = bls::g2_decode_rows(mem, qw, inf, in96);
+    *overflows = rowfp::overflow_count();
+    for (int j = 0; j < 4; j++) {
+        bls::fp f;
+        for (int w = 0; w < 12; w++) f.v[w] = qw[j][w];
+        uint32_t words[12];
+        kyb::fp_to_words<bls::FC>(words, f);
+        memcpy(out + 48 * j, words, 48);
+    }
+    return st;
+}
 // ---- G1Elt.Mul on four cooperating lanes (bls12381_g1coop.cuh) with four THREADS as the lanes of one group: the whole
 // ladder -- table, 34 windows, the z^2 half from the beta x slots -- against the per-lane routine's answer
 int hh_bls_g1_mul_coop(const uint8_t* k32, const uint8_t* pt, int flags, uint8_t* out) {

@@ -218,3 +218,54 @@ def test_r_torsion_rule_read_off_the_walks_end():
     for _ in range(3):
         assert walk(off_subgroup_point())[0] == 65
     assert walk(O.g2_add(O.g2_mul(O.R, off_subgroup_point()), O.g2_mul(7, O.G2_GEN)))[0] == 65  # cofactor part + a key
+
+
+def test_compressed_key_decode_with_its_powers_on_the_rows():
+    """bls12381_keylines.cuh g2_decode_rows (lane 0 parses, the rows run the square root's two 379-bit powers through
+    rowfp::pow_words) against the oracle's decompression without the subgroup rule: keys of G2, curve points off the
+    subgroup, both sort flags, x with no point above it, x >= p, the flag combinations kilic rejects, infinity"""
+    rng = random.Random(78)
+    lib = H.lib()
+    lib.hh_bls_g2_decode_rows.restype = C.c_int
+
+    def dec(buf):
+        out, inf, ov = C.create_string_buffer(4 * 48), C.c_int(-1), C.c_int(-1)
+        st = lib.hh_bls_g2_decode_rows(bytes(buf), out, C.byref(inf), C.byref(ov))
+        assert ov.value == 0
+        v = [int.from_bytes(out.raw[48 * j:48 * j + 48], "little") for j in range(4)]
+        return st, inf.value, ((v[0], v[1]), (v[2], v[3]))
+
+    pts = [O.g2_mul(k, O.G2_GEN) for k in (1, 2, O.R - 1, rng.randrange(1, O.R))]
+    tries = 0
+    while len(pts) < 9:                                    # curve points off the subgroup; x real (c1 = 0) and x imaginary too
+        tries += 1
+        x = [(rng.randrange(O.P), rng.randrange(O.P)), (rng.randrange(O.P), 0), (0, rng.randrange(O.P))][tries % 3]
+        y = O.f2_sqrt(O.f2_add(O.f2_mul(O.f2_sqr(x), x), (4, 4)))
+        if y is not None:
+            pts.append((x, y))
+    for Q in pts:
+        for R_ in (Q, O.g2_neg(Q)):
+            buf = O.g2_compress(R_)
+            assert O.g2_decompress(buf, subgroup_check=False) == R_
+            assert dec(buf) == (0, 0, R_)
+    bad = 0
+    while bad < 4:                                         # no point above x: status 1
+        x = (rng.randrange(O.P), rng.randrange(O.P))
+        if O.f2_sqrt(O.f2_add(O.f2_mul(O.f2_sqr(x), x), (4, 4))) is None:
+            buf = bytearray(x[1].to_bytes(48, "big") + x[0].to_bytes(48, "big"))
+            buf[0] |= 0x80 | (0x20 if bad & 1 else 0)
+            assert dec(buf)[0] == 1
+            bad += 1
+    good = bytearray(O.g2_compress(pts[3]))
+    assert dec(b"\xc0" + bytes(95))[:2] == (0, 1)          # infinity
+    assert dec(b"\xe0" + bytes(95))[0] == 1                # infinity with the sort flag
+    assert dec(b"\xc0" + bytes(94) + b"\x01")[0] == 1      # infinity with a coordinate
+    nocomp = bytearray(good)
+    nocomp[0] &= 0x7F
+    assert dec(nocomp)[0] == 1                              # compression bit clear
+    big = bytearray((O.P).to_bytes(48, "big") + (5).to_bytes(48, "big"))
+    big[0] |= 0x80
+    assert dec(big)[0] == 1                                 # x.c1 = p
+    big = bytearray((5).to_bytes(48, "big") + (O.P + 1).to_bytes(48, "big"))
+    big[0] |= 0x80
+    assert dec(big)[0] == 1                                 # x.c0 = p + 1
