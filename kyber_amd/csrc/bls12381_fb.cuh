@@ -35,6 +35,48 @@ struct fb_g1_policy {
         const bool trusted = flag_trusted(flags, 0);
         return (flags & FLAG_UNCOMPRESSED) ? g1_decode_unc(a, in, !trusted, false) : g1_decode(a, in, false);
     }
+    // g1_decode(a, in, false) in two halves around its one 379-bit power, which fixed_base.cuh chain_rows_kernel runs on a
+    // row (rowfp::pow_words: 0.25 ms instead of a lane's 0.5) -- restated rather than shared, so that the batch kernels'
+    // copy keeps its shape.  decode_head: flag bits, range, x and x^3 + b; go = there is a root to take.
+    static constexpr int ROW_SQRT = 1;
+    KYB_HD static int decode_head(fp& x, fp& rhs, int& sflag, int& inf, const uint8_t* in) {
+        uint32_t w[12];
+        words_from_be<12>(w, in);
+        const uint32_t top = w[11] >> 29;
+        const bool c = top & 4, i = top & 2, s = top & 1;
+        w[11] &= 0x1fffffffu;
+        uint32_t any = 0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) any |= w[k];
+        inf = 1;
+        sflag = s ? 1 : 0;
+        if (!c) return ST_BAD_POINT;
+        if (i) return (s || any) ? ST_BAD_POINT : ST_OK;
+        if (!fp_words_lt_p<FC>(w)) return ST_BAD_POINT;
+        fp b;
+        fp_from_words<FC>(x, w);
+        fp_const(b, CC::B1);
+        fp_sqr(rhs, x);
+        fp_mul(rhs, rhs, x);
+        fp_add(rhs, rhs, b);
+        inf = 0;
+        return ST_OK;
+    }
+    // y0 = rhs^((p + 1) / 4), fully reduced: a root iff its square is rhs; the sort flag picks the sign
+    KYB_HD static int decode_tail(g1_aff& a, const fp& x, const fp& rhs, const fp& y0, int sflag) {
+        fp t, y = y0;
+        fp_zero(a.x);
+        fp_zero(a.y);
+        a.inf = true;
+        fp_sqr(t, y);
+        if (!fp_eq(t, rhs)) return ST_BAD_POINT;
+        fp_neg(t, y);
+        fp_cmov(y, t, fp_is_larger(y) != (sflag != 0));
+        a.x = x;
+        a.y = y;
+        a.inf = false;
+        return ST_OK;
+    }
     KYB_HD static bool needs_member(uint32_t flags) { return !flag_trusted(flags, 0); }
     // Scott's criterion (g1_in_subgroup): z^2 P = -phi(P) = (beta x, -y), with z^2 P walked over the table's plain image
     KYB_HD static bool member(const g1_aff& a, const fb::Entry<fp, 2>* __restrict__ tab) {

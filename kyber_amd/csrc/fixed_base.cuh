@@ -196,22 +196,39 @@ __device__ __forceinline__ Aff<typename T::F>* base_slot(uint8_t* ws) {  // the 
 // Run by ONE lane: is the table already this base's?  Otherwise decode the base (every rule of UnmarshalBinary but the
 // subgroup), write the header and, when there is a table to build, the chain's first point q[0] (returned in `start`).
 // Returns 1 when the doubling chain has to be walked.
+// chain_begin in its three parts (chain_rows_kernel puts the wave between the second and the third): is the table this
+// base's already; the base's decoding; the header and the chain's first point
 template <class T>
-__device__ int chain_begin(uint8_t* __restrict__ ws, const uint8_t* __restrict__ base, uint32_t flags, Jac<typename T::F>& start) {
-    using F = typename T::F;
+__device__ bool chain_same(uint8_t* __restrict__ ws, const uint8_t* __restrict__ base, uint32_t flags) {
     Header* h = reinterpret_cast<Header*>(ws);
-    Jac<F>* q = reinterpret_cast<Jac<F>*>(ws + HDR_BYTES);
     const uint32_t kf = flags & T::KEY_FLAGS, len = (uint32_t)T::wire_size(flags);
     bool same = h->magic == MAGIC && h->key_flags == kf && h->key_len == len;
     for (uint32_t i = 0; i < len && same; i++) same = h->key[i] == base[i];
     if (same) {
         h->fresh = 0;
         h->member_pending = 0;
-        return 0;
+        return true;
     }
     h->magic = 0;
-    Aff<F> a;
+    return false;
+}
+template <class T>
+__device__ int chain_commit(uint8_t* __restrict__ ws, const uint8_t* __restrict__ base, uint32_t flags, int st, const Aff<typename T::F>& a,
+                            Jac<typename T::F>& start);
+template <class T>
+__device__ int chain_begin(uint8_t* __restrict__ ws, const uint8_t* __restrict__ base, uint32_t flags, Jac<typename T::F>& start) {
+    if (chain_same<T>(ws, base, flags)) return 0;
+    Aff<typename T::F> a;
     const int st = T::decode_on_curve(a, base, flags);
+    return chain_commit<T>(ws, base, flags, st, a, start);
+}
+template <class T>
+__device__ int chain_commit(uint8_t* __restrict__ ws, const uint8_t* __restrict__ base, uint32_t flags, int st, const Aff<typename T::F>& a,
+                            Jac<typename T::F>& start) {
+    using F = typename T::F;
+    Header* h = reinterpret_cast<Header*>(ws);
+    Jac<F>* q = reinterpret_cast<Jac<F>*>(ws + HDR_BYTES);
+    const uint32_t kf = flags & T::KEY_FLAGS, len = (uint32_t)T::wire_size(flags);
     const bool build = st == 0 && !a.inf;
     h->status = (uint32_t)st;
     h->inf = (st == 0 && a.inf) ? 1u : 0u;
@@ -275,6 +292,14 @@ template <class T>
 struct HasRowChain<T, decltype((void)T::ROW_CHAIN)> {
     static constexpr bool value = T::ROW_CHAIN != 0;
 };
+template <class P, class = void>
+struct HasRowSqrt {
+    static constexpr bool value = false;
+};
+template <class P>
+struct HasRowSqrt<P, decltype((void)P::ROW_SQRT)> {
+    static constexpr bool value = P::ROW_SQRT != 0;
+};
 #if defined(KYB_ROWFP_INCLUDED)
 template <class T>
 __global__ __launch_bounds__(64) void chain_rows_kernel(uint8_t* __restrict__ ws, const uint8_t* __restrict__ base, uint32_t flags) {
@@ -285,14 +310,66 @@ __global__ __launch_bounds__(64) void chain_rows_kernel(uint8_t* __restrict__ ws
     __shared__ int go;
     Header* h = reinterpret_cast<Header*>(ws);
     Jac<F>* q = reinterpret_cast<Jac<F>*>(ws + HDR_BYTES);
-    if (threadIdx.x == 0) {
-        Jac<F> t;
-        go = chain_begin<T>(ws, base, flags, t);
-        __threadfence_block();
-    }
-    __syncthreads();
-    if (!go) return;
     const auto cx = make_ctx<C>();
+    if constexpr (HasRowSqrt<typename T::P>::value) {
+        // a new COMPRESSED base: its square root's power is the wave's (rowfp::pow_words), the rest of UnmarshalBinary lane 0's
+        __shared__ uint32_t ptab[15][ROW], pio[C::NWORDS];
+        __shared__ F sx, srhs;
+        __shared__ int root, sflag;
+        if (threadIdx.x == 0) {
+            Jac<F> t;
+            go = 0;
+            root = 0;
+            if (!chain_same<T>(ws, base, flags)) {
+                Aff<F> a;
+                if (flags & FLAG_UNCOMPRESSED) {
+                    const int st = T::decode_on_curve(a, base, flags);
+                    go = chain_commit<T>(ws, base, flags, st, a, t);
+                } else {
+                    F x, rhs;
+                    int inf = 1, sf = 0;
+                    const int st = T::P::decode_head(x, rhs, sf, inf, base);
+                    if (st == 0 && !inf) {
+                        sx = x;
+                        srhs = rhs;
+                        sflag = sf;
+                        for (int k = 0; k < C::NWORDS; k++) pio[k] = rhs.v[k];
+                        root = 1;
+                    } else {
+                        a.x = F{};
+                        a.y = F{};
+                        a.inf = true;
+                        go = chain_commit<T>(ws, base, flags, st, a, t);
+                    }
+                }
+            }
+            __threadfence_block();
+        }
+        __syncthreads();
+        if (root) {  // (uniform)
+            const V32 y = below_2p<C>(cx, pow_words<C>(cx, load_packed<C>(pio), ptab, C::SQRT_EXP, C::SQRT_BITS));
+            store_row(limbs[0], y);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                Jac<F> t;
+                F y0;
+                Aff<F> a;
+                finish_limbs<C>(y0, limbs[0]);
+                const int st = T::P::decode_tail(a, sx, srhs, y0, sflag);
+                go = chain_commit<T>(ws, base, flags, st, a, t);
+                __threadfence_block();
+            }
+            __syncthreads();
+        }
+    } else {
+        if (threadIdx.x == 0) {
+            Jac<F> t;
+            go = chain_begin<T>(ws, base, flags, t);
+            __threadfence_block();
+        }
+        __syncthreads();
+    }
+    if (!go) return;
     const auto dc = make_dbl_consts<C>();
     const V32 row = row_of_lane();
     JacRow<C> pt{load_packed<C>(q[0].X.v), load_packed<C>(q[0].Y.v), load_packed<C>(q[0].Z.v)};

@@ -136,3 +136,46 @@ def test_bls12381_flags_through_the_table():
     torch.cuda.synchronize()
     assert not st.any().item() and not st2.any().item() and not st3.any().item()
     assert torch.equal(a[:8192], ref) and torch.equal(b[:8192], refu) and torch.equal(c, a)
+
+
+def test_bls12381_new_compressed_bases_decoded_with_the_wave():
+    """fixed_base.cuh chain_rows_kernel + fb_g1_policy::decode_head / decode_tail: a NEW compressed G1 base has its square
+    root's power run on a row.  Both sort flags, an x with no point above it (status 1), a curve point outside the
+    subgroup (status 2, read off the table), infinity with a stray flag -- against the per-element ladder / the oracle"""
+    import torch
+
+    from oracle import bls12381 as O
+
+    m, _ = _suite("bls12381")
+    n = 1 << 16
+    s = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda")
+    P = O.g1_mul(0xC0FFEE, O.G1_GEN)
+    for Q in (P, O.g1_neg(P)):
+        base = torch.from_numpy(np.frombuffer(O.g1_compress(Q), dtype=np.uint8).copy()).cuda()
+        out, st = m.g1_commit(s, base)
+        ref, _ = m.g1_batch_mul(s[:2048], base.repeat(2048, 1))
+        torch.cuda.synchronize()
+        assert not st.any().item() and torch.equal(out[:2048], ref)
+        assert bytes(out[7].cpu().numpy()) == O.g1_mul_bytes(bytes(s[7].cpu().numpy()), O.g1_compress(Q))
+    x = 1
+    while O.fp_sqrt((x * x * x + 4) % O.P) is not None:
+        x += 1
+    nox = bytearray(x.to_bytes(48, "big"))
+    nox[0] |= 0x80
+    out, st = m.g1_commit(s, torch.tensor(list(nox), dtype=torch.uint8, device="cuda"))
+    assert (st == 1).all().item() and not out.any().item()
+    x = 1
+    while True:
+        y = O.fp_sqrt((x * x * x + 4) % O.P)
+        if y is not None and not O.g1_in_subgroup((x, y)):
+            break
+        x += 1
+    off = torch.from_numpy(np.frombuffer(O.g1_compress((x, y)), dtype=np.uint8).copy()).cuda()
+    out, st = m.g1_commit(s, off)
+    assert (st == 2).all().item() and not out.any().item()
+    bad_inf = torch.tensor([0xE0] + [0] * 47, dtype=torch.uint8, device="cuda")   # infinity with the sort flag
+    out, st = m.g1_commit(s, bad_inf)
+    assert (st == 1).all().item() and not out.any().item()
+    base = torch.from_numpy(np.frombuffer(O.g1_compress(P), dtype=np.uint8).copy()).cuda()  # and a good base afterwards
+    out, st = m.g1_commit(s, base)
+    assert not st.any().item() and bytes(out[9].cpu().numpy()) == O.g1_mul_bytes(bytes(s[9].cpu().numpy()), O.g1_compress(P))
