@@ -179,3 +179,47 @@ def test_bls12381_new_compressed_bases_decoded_with_the_wave():
     base = torch.from_numpy(np.frombuffer(O.g1_compress(P), dtype=np.uint8).copy()).cuda()  # and a good base afterwards
     out, st = m.g1_commit(s, base)
     assert not st.any().item() and bytes(out[9].cpu().numpy()) == O.g1_mul_bytes(bytes(s[9].cpu().numpy()), O.g1_compress(P))
+
+
+def test_bls12381_new_g2_bases_through_the_table():
+    """a NEW G2 base (fixed_base.cuh chain_kernel on four cooperating lanes): compressed with both sort flags and
+    uncompressed, an x with no point (status 1), a curve point outside G2 (status 2, read off the table), a good base
+    afterwards -- against the ladder / the oracle"""
+    import torch
+
+    from oracle import bls12381 as O
+
+    m, _ = _suite("bls12381")
+    n = 1 << 16
+    s = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda")
+    P = O.g2_mul(0xBADC0DE, O.G2_GEN)
+    for Q in (P, O.g2_neg(P)):
+        base = torch.from_numpy(np.frombuffer(O.g2_compress(Q), dtype=np.uint8).copy()).cuda()
+        out, st = m.g2_commit(s, base)
+        ref, _ = m.g2_batch_mul(s[:1024], base.repeat(1024, 1))
+        torch.cuda.synchronize()
+        assert not st.any().item() and torch.equal(out[:1024], ref)
+        assert bytes(out[5].cpu().numpy()) == O.g2_mul_bytes(bytes(s[5].cpu().numpy()), O.g2_compress(Q))
+        unc = torch.from_numpy(np.frombuffer(O.g2_serialize_unc(Q), dtype=np.uint8).copy()).cuda()
+        out2, st2 = m.g2_commit(s, unc, m.F_UNCOMPRESSED)
+        assert not st2.any().item() and torch.equal(out2, out)
+    xx = 1
+    while O.f2_sqrt(O.f2_add(O.f2_mul(O.f2_sqr((xx, 1)), (xx, 1)), (4, 4))) is not None:
+        xx += 1
+    nox = bytearray((1).to_bytes(48, "big") + xx.to_bytes(48, "big"))
+    nox[0] |= 0x80
+    out, st = m.g2_commit(s, torch.tensor(list(nox), dtype=torch.uint8, device="cuda"))
+    assert (st == 1).all().item() and not out.any().item()
+    xx = 1
+    while True:
+        c = (xx, 1)
+        y = O.f2_sqrt(O.f2_add(O.f2_mul(O.f2_sqr(c), c), (4, 4)))
+        if y is not None and not O.g2_in_subgroup((c, y)):
+            break
+        xx += 1
+    off = torch.from_numpy(np.frombuffer(O.g2_compress((c, y)), dtype=np.uint8).copy()).cuda()
+    out, st = m.g2_commit(s, off)
+    assert (st == 2).all().item() and not out.any().item()
+    base = torch.from_numpy(np.frombuffer(O.g2_compress(P), dtype=np.uint8).copy()).cuda()
+    out, st = m.g2_commit(s, base)
+    assert not st.any().item() and bytes(out[9].cpu().numpy()) == O.g2_mul_bytes(bytes(s[9].cpu().numpy()), O.g2_compress(P))
